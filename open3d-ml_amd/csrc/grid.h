@@ -1,0 +1,119 @@
+// grid.h — counting-sorted uniform grid shared by the k-NN and fixed-radius kernels.
+//
+// One grid per batch item ("segment").  Build = bbox -> multi-resolution
+// occupancy probe -> cell size -> histogram -> scan -> scatter.  The sorted
+// copy stores (x, y, z, local index) as one float4 so a candidate is ONE 16-byte
+// load and a cell's points are contiguous (coalesced, L1/L2 friendly).
+//
+// The cell size only affects speed: the query kernels expand shells until the
+// k-th distance is provably final, so results are exact for any grid.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ml3d {
+
+constexpr int GRID_CAP = 8;      // dense cell table: at most GRID_CAP * n + 64 cells per segment
+constexpr int GRID_SLACK = 64;
+constexpr int GRID_LEVELS = 5;   // occupancy probed at cell sizes c0 * {1,2,4,8,16}
+
+// How batch items are laid out in the point array.
+//  splits != nullptr : item s = rows [splits[s], splits[s+1])           (packed == global row)
+//  splits == nullptr : item s = rows [s*stride, s*stride + n_uniform)   (prefix of a [B, stride, 3] tensor)
+struct Segs {
+    const int64_t* splits;
+    int64_t stride;
+    int64_t n_uniform;
+    int batch;
+};
+
+struct GridSeg {
+    float lo[3];
+    float c, inv_c;
+    float margin;      // absolute slack subtracted from shell guarantee distances
+    int dims[3];
+    int cell_base;     // first cell of this segment in the cell table
+    int n;             // points in the segment
+    int sorted_base;   // first slot of this segment in the sorted array (== packed begin)
+    float c0;          // finest probe cell size
+    int dims0[3];
+};
+
+// Device-side view of a built grid.
+struct GridView {
+    const GridSeg* segs;
+    const int* cell_start;   // start(j) = cell_start[j], end(j) = cell_start[j + 1]
+    const float4* sorted;    // (x, y, z, bits(local index)), grouped by cell, segment-contiguous
+    int batch;
+};
+
+// Workspace carve for one grid (all device memory, 256-byte aligned pieces).
+struct GridWs {
+    GridSeg* segs;
+    unsigned* bbox;      // [batch][6] order-preserving uint encoding of float min/max
+    unsigned* occ;       // [batch][GRID_LEVELS] occupied-cell counters
+    unsigned* bitmap;    // [GRID_LEVELS][bitmap_words]
+    int* cells;          // cell table, total_cells + 2
+    int* block_sums;     // scan scratch
+    float4* sorted;      // [n_total]
+    int64_t total_cells;
+    int64_t bitmap_words;
+    int64_t n_total;
+    int batch;
+};
+
+size_t grid_ws_bytes(int64_t n_total, int64_t batch);
+// carve `ws` (must hold grid_ws_bytes) — returns false if too small
+bool grid_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, GridWs* out);
+// enqueue the build; `points` row = 3 floats.  target_occ <= 0 -> default.
+int grid_build(const float* points, Segs segs, const GridWs& ws, float target_occ, hipStream_t stream);
+
+inline GridView grid_view(const GridWs& ws) {
+    GridView v;
+    v.segs = ws.segs;
+    v.cell_start = ws.cells;
+    v.sorted = ws.sorted;
+    v.batch = ws.batch;
+    return v;
+}
+
+// ---- device helpers ---------------------------------------------------------------------------
+
+__device__ __forceinline__ int64_t seg_begin_global(const Segs& S, int s) {
+    return S.splits ? S.splits[s] : (int64_t)s * S.stride;
+}
+__device__ __forceinline__ int64_t seg_begin_packed(const Segs& S, int s) {
+    return S.splits ? S.splits[s] : (int64_t)s * S.n_uniform;
+}
+__device__ __forceinline__ int64_t seg_len(const Segs& S, int s) {
+    return S.splits ? (S.splits[s + 1] - S.splits[s]) : S.n_uniform;
+}
+// packed index -> (segment, local index)
+__device__ __forceinline__ void seg_locate(const Segs& S, int64_t packed, int& s, int64_t& local) {
+    if (!S.splits) {
+        s = (int)(packed / S.n_uniform);
+        local = packed - (int64_t)s * S.n_uniform;
+        return;
+    }
+    int lo = 0, hi = S.batch;  // find largest s with splits[s] <= packed; skips empty items
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (S.splits[mid] <= packed) lo = mid; else hi = mid;
+    }
+    s = lo;
+    local = packed - S.splits[lo];
+}
+
+__device__ __forceinline__ int cell_coord(float p, float lo, float inv_c, int dim) {
+    int v = (int)((p - lo) * inv_c);
+    v = v < 0 ? 0 : v;
+    return v > dim - 1 ? dim - 1 : v;
+}
+
+// canonical squared distance: ((dx*dx)+(dy*dy))+(dz*dz), every step rounded (no fma)
+__device__ __forceinline__ float dist2_canon(float qx, float qy, float qz, float px, float py, float pz) {
+    float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+}  // namespace ml3d

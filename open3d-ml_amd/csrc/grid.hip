@@ -1,0 +1,368 @@
+// grid.hip — build of the counting-sorted uniform grid (see grid.h).
+//
+// HBM traffic per build, per point: 12 B (bbox) + 12 B (occupancy probe) +
+// 12 B (histogram) + 12 B + 16 B (scatter read + sorted write); the cell table
+// adds <= 2 * 4 * GRID_CAP bytes per point for zero + scan.  Everything is a
+// coalesced stream; the only scattered accesses are the 4-byte atomics on the
+// cell table, which stays L2-resident (<= 32 B per point).
+#include "grid.h"
+
+#include <math.h>
+
+namespace ml3d {
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static void grid_sizes(int64_t n_total, int64_t batch, int64_t* total_cells, int64_t* bitmap_words,
+                       int64_t* n_blocks) {
+    *total_cells = (int64_t)GRID_CAP * n_total + (int64_t)GRID_SLACK * batch;
+    *bitmap_words = (*total_cells + 31) / 32 + batch;
+    *n_blocks = (*total_cells + 2 + 1023) / 1024 + 1;
+}
+
+size_t grid_ws_bytes(int64_t n_total, int64_t batch) {
+    int64_t tc, bw, nb;
+    grid_sizes(n_total, batch, &tc, &bw, &nb);
+    size_t b = 0;
+    b += align_up(sizeof(GridSeg) * (size_t)batch);
+    b += align_up(sizeof(unsigned) * 6 * (size_t)batch);
+    b += align_up(sizeof(unsigned) * GRID_LEVELS * (size_t)batch);
+    b += align_up(sizeof(unsigned) * GRID_LEVELS * (size_t)bw);
+    b += align_up(sizeof(int) * (size_t)(tc + 2));
+    b += align_up(sizeof(int) * (size_t)nb);
+    b += align_up(sizeof(float4) * (size_t)(n_total > 0 ? n_total : 1));
+    return b + 256;
+}
+
+bool grid_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, GridWs* out) {
+    if (bytes < grid_ws_bytes(n_total, batch)) return false;
+    int64_t tc, bw, nb;
+    grid_sizes(n_total, batch, &tc, &bw, &nb);
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    out->segs = (GridSeg*)p;      p += align_up(sizeof(GridSeg) * (size_t)batch);
+    out->bbox = (unsigned*)p;     p += align_up(sizeof(unsigned) * 6 * (size_t)batch);
+    out->occ = (unsigned*)p;      p += align_up(sizeof(unsigned) * GRID_LEVELS * (size_t)batch);
+    out->bitmap = (unsigned*)p;   p += align_up(sizeof(unsigned) * GRID_LEVELS * (size_t)bw);
+    out->cells = (int*)p;         p += align_up(sizeof(int) * (size_t)(tc + 2));
+    out->block_sums = (int*)p;    p += align_up(sizeof(int) * (size_t)nb);
+    out->sorted = (float4*)p;
+    out->total_cells = tc;
+    out->bitmap_words = bw;
+    out->n_total = n_total;
+    out->batch = (int)batch;
+    return true;
+}
+
+// ---- order-preserving float <-> uint so atomicMin/atomicMax work on floats --------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// ---- K1: bounding box per segment -------------------------------------------------------------
+__global__ void grid_bbox_init(unsigned* bbox, unsigned* occ, int batch) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    for (int a = 0; a < 3; ++a) { bbox[6 * s + a] = 0xffffffffu; bbox[6 * s + 3 + a] = 0u; }
+    for (int l = 0; l < GRID_LEVELS; ++l) occ[GRID_LEVELS * s + l] = 0u;
+}
+
+__global__ void grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox) {
+    // Each block covers a contiguous packed range; threads reduce what they can in registers over a
+    // short strided loop and then issue at most 6 atomics per (thread, segment change).
+    int64_t i = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x;
+    int cur = -1;
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int it = 0; it < 4; ++it, i += blockDim.x) {
+        if (i >= n_total) break;
+        int s; int64_t local;
+        seg_locate(S, i, s, local);
+        const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+        float x = p[0], y = p[1], z = p[2];
+        if (s != cur) {
+            if (cur >= 0)
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
+                    atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
+                }
+            cur = s;
+            mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
+        } else {
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+    if (cur >= 0)
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
+            atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
+        }
+}
+
+// ---- K2: finest probe grid per segment --------------------------------------------------------
+__device__ __forceinline__ bool dims_fit(const float ext[3], float c, int64_t cap, int dims[3]) {
+    int64_t prod = 1;
+    for (int a = 0; a < 3; ++a) {
+        float q = ext[a] / c;
+        if (!(q < 1.0e6f)) return false;
+        dims[a] = (int)q + 1;
+        prod *= dims[a];
+        if (prod > cap) return false;
+    }
+    return true;
+}
+
+__global__ void grid_setup0(Segs S, const unsigned* bbox, GridSeg* segs, int batch) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    GridSeg g;
+    int64_t n = seg_len(S, s);
+    int64_t pb = seg_begin_packed(S, s);
+    g.n = (int)n;
+    g.sorted_base = (int)pb;
+    g.cell_base = (int)(GRID_CAP * pb + (int64_t)GRID_SLACK * s);
+    float ext[3], amax = 0.f, emax = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        float lo = n > 0 ? ord2f(bbox[6 * s + a]) : 0.f;
+        float hi = n > 0 ? ord2f(bbox[6 * s + 3 + a]) : 0.f;
+        g.lo[a] = lo;
+        ext[a] = hi - lo;
+        emax = fmaxf(emax, ext[a]);
+        amax = fmaxf(amax, fmaxf(fabsf(lo), fabsf(hi)));
+    }
+    g.margin = 4.0e-6f * (amax + emax) + 1.0e-30f;
+    int64_t cap = (int64_t)GRID_CAP * n + GRID_SLACK;
+    float c = emax > 0.f ? emax : 1.0f;
+    int d[3] = {1, 1, 1}, dn[3];
+    if (emax > 0.f) {
+        // halve while the dense table still fits: ends within 2x of the finest admissible size
+        dims_fit(ext, c, cap, d);
+        for (int it = 0; it < 40; ++it) {
+            if (!dims_fit(ext, c * 0.5f, cap, dn)) break;
+            c *= 0.5f;
+            d[0] = dn[0]; d[1] = dn[1]; d[2] = dn[2];
+        }
+    }
+    g.c0 = c;
+    g.c = c;
+    g.inv_c = 1.0f / c;
+    for (int a = 0; a < 3; ++a) { g.dims0[a] = d[a]; g.dims[a] = d[a]; }
+    segs[s] = g;
+}
+
+// ---- K3: occupancy probe at GRID_LEVELS power-of-two resolutions ------------------------------
+__global__ void grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total,
+                               const GridSeg* __restrict__ segs, unsigned* bitmap, int64_t bitmap_words,
+                               unsigned* occ) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+    const GridSeg* g = &segs[s];
+    float inv = 1.0f / g->c0;
+    int cx = cell_coord(p[0], g->lo[0], inv, g->dims0[0]);
+    int cy = cell_coord(p[1], g->lo[1], inv, g->dims0[1]);
+    int cz = cell_coord(p[2], g->lo[2], inv, g->dims0[2]);
+    int64_t bit_base = (int64_t)g->cell_base + 32 * (int64_t)s;  // word-aligned per segment
+    for (int l = 0; l < GRID_LEVELS; ++l) {
+        int dx = ((g->dims0[0] - 1) >> l) + 1, dy = ((g->dims0[1] - 1) >> l) + 1;
+        int64_t id = (cx >> l) + (int64_t)dx * ((cy >> l) + (int64_t)dy * (cz >> l));
+        int64_t bit = bit_base + id;
+        unsigned m = 1u << (unsigned)(bit & 31);
+        unsigned old = atomicOr(&bitmap[(int64_t)l * bitmap_words + (bit >> 5)], m);
+        if (!(old & m)) atomicAdd(&occ[GRID_LEVELS * s + l], 1u);
+    }
+}
+
+// ---- K4: final cell size from the occupancy curve ----------------------------------------------
+__global__ void grid_setup1(const unsigned* occ, const unsigned* bbox, GridSeg* segs, int batch,
+                            float target) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    GridSeg g = segs[s];
+    int64_t n = g.n;
+    float ext[3], emax = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = n > 0 ? ord2f(bbox[6 * s + 3 + a]) - g.lo[a] : 0.f;
+        emax = fmaxf(emax, ext[a]);
+    }
+    int64_t cap = (int64_t)GRID_CAP * n + GRID_SLACK;
+    float c = g.c0;
+    if (n > 0 && emax > 0.f) {
+        float m_prev = 0.f;
+        int lsel = -1;
+        float mcur = 0.f;
+        for (int l = 0; l < GRID_LEVELS; ++l) {
+            unsigned cnt = occ[GRID_LEVELS * s + l];
+            mcur = (float)n / (float)(cnt > 0u ? cnt : 1u);
+            if (mcur >= target) { lsel = l; break; }
+            m_prev = mcur;
+        }
+        if (lsel == 0) {
+            c = g.c0;
+        } else if (lsel > 0) {
+            float D = log2f(mcur / m_prev);
+            D = fminf(fmaxf(D, 1.0f), 3.0f);
+            c = g.c0 * (float)(1 << (lsel - 1)) * powf(target / m_prev, 1.0f / D);
+        } else {
+            c = g.c0 * (float)(1 << (GRID_LEVELS - 1));
+            if (n <= 64) c = emax * 2.0f;  // tiny item: one cell, i.e. brute force
+        }
+    }
+    int d[3] = {1, 1, 1};
+    if (emax > 0.f) {
+        for (int it = 0; it < 200; ++it) {
+            if (dims_fit(ext, c, cap, d)) break;
+            c *= 1.1f;
+        }
+    }
+    g.c = c;
+    g.inv_c = 1.0f / c;
+    for (int a = 0; a < 3; ++a) g.dims[a] = d[a];
+    segs[s] = g;
+}
+
+// ---- K5: histogram ------------------------------------------------------------------------------
+__device__ __forceinline__ int point_cell(const GridSeg* g, float x, float y, float z) {
+    int cx = cell_coord(x, g->lo[0], g->inv_c, g->dims[0]);
+    int cy = cell_coord(y, g->lo[1], g->inv_c, g->dims[1]);
+    int cz = cell_coord(z, g->lo[2], g->inv_c, g->dims[2]);
+    return g->cell_base + cx + g->dims[0] * (cy + g->dims[1] * cz);
+}
+
+__global__ void grid_hist(const float* __restrict__ pts, Segs S, int64_t n_total,
+                          const GridSeg* __restrict__ segs, int* cells) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+    int cid = point_cell(&segs[s], p[0], p[1], p[2]);
+    atomicAdd(&cells[cid + 2], 1);
+}
+
+// ---- K6: in-place inclusive scan of cells[2 .. 2 + n) -------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
+    __shared__ int sh[256];
+    int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int add = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    int incl = sh[t];
+    *total = sh[255];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ void scan_block_sums(const int* __restrict__ a, int64_t n, int* block_sums) {
+    int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+    int v = 0;
+    for (int j = 0; j < 4; ++j) if (base + j < n) v += a[base + j];
+    int total;
+    block_exclusive_scan_256(v, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void scan_sums(int* block_sums, int64_t nb) {
+    // single block: exclusive scan of block_sums in chunks of 256 with a running carry
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256) {
+        int64_t i = base + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int total;
+        int ex = block_exclusive_scan_256(v, &total);
+        int c = carry;
+        if (i < nb) block_sums[i] = ex + c;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+
+__global__ void scan_final(int* a, int64_t n, const int* __restrict__ block_sums) {
+    int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+    int v[4], sum = 0;
+    for (int j = 0; j < 4; ++j) { v[j] = base + j < n ? a[base + j] : 0; sum += v[j]; }
+    int total;
+    int ex = block_exclusive_scan_256(sum, &total) + block_sums[blockIdx.x];
+    for (int j = 0; j < 4; ++j) {
+        ex += v[j];
+        if (base + j < n) a[base + j] = ex;
+    }
+}
+
+// ---- K7: scatter into the cell-sorted float4 array ---------------------------------------------
+__global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_total,
+                             const GridSeg* __restrict__ segs, int* cells, float4* sorted) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+    float x = p[0], y = p[1], z = p[2];
+    int cid = point_cell(&segs[s], x, y, z);
+    int pos = atomicAdd(&cells[cid + 1], 1);
+    sorted[pos] = make_float4(x, y, z, __int_as_float((int)local));
+}
+
+#define ML3D_LAUNCH_CHECK()                         \
+    do {                                            \
+        if (hipGetLastError() != hipSuccess) return -3; \
+    } while (0)
+
+int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, hipStream_t stream) {
+    int64_t n = ws.n_total;
+    int B = ws.batch;
+    if (B <= 0) return 0;
+    if (target_occ <= 0.f) target_occ = 4.0f;
+    int sb = (B + 63) / 64;
+    hipMemsetAsync(ws.bitmap, 0, sizeof(unsigned) * GRID_LEVELS * (size_t)ws.bitmap_words, stream);
+    hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    hipLaunchKernelGGL(grid_bbox_init, dim3(sb), dim3(64), 0, stream, ws.bbox, ws.occ, B);
+    ML3D_LAUNCH_CHECK();
+    if (n > 0) {
+        int nb4 = (int)((n + 1023) / 1024);
+        hipLaunchKernelGGL(grid_bbox, dim3(nb4), dim3(256), 0, stream, points, S, n, ws.bbox);
+        ML3D_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(grid_setup0, dim3(sb), dim3(64), 0, stream, S, ws.bbox, ws.segs, B);
+    ML3D_LAUNCH_CHECK();
+    int nb = (int)((n + 255) / 256);
+    if (n > 0) {
+        hipLaunchKernelGGL(grid_occupancy, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.bitmap,
+                           ws.bitmap_words, ws.occ);
+        ML3D_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(grid_setup1, dim3(sb), dim3(64), 0, stream, ws.occ, ws.bbox, ws.segs, B, target_occ);
+    ML3D_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(grid_hist, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells);
+        ML3D_LAUNCH_CHECK();
+        int64_t tc = ws.total_cells;
+        int sbk = (int)((tc + 1023) / 1024);
+        hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, ws.block_sums, (int64_t)sbk);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_final, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_scatter, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells,
+                           ws.sorted);
+        ML3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace ml3d

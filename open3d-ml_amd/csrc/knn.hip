@@ -1,0 +1,282 @@
+// knn.hip — exact k-nearest-neighbour search on the counting-sorted grid (gfx950).
+//
+// Replaces o3c.nns.NearestNeighborSearch.knn_search as called from
+// ml3d/datasets/utils/dataprocessing.py:99-103 (RandLANet.transform,
+// ml3d/torch/models/randlanet.py:218-229).  Result order is the oracle's
+// canonical one: ascending (d2, index), d2 = ((dx*dx)+(dy*dy))+(dz*dz) in f32
+// without fma — so indices are bit-exact against oracle/ml3d_oracle.c.
+//
+// One thread per query.  Queries are visited in the CELL-SORTED order of their
+// own grid, so the 64 lanes of a wave sit in the same or adjacent cells: the
+// 16-byte candidate loads of neighbouring lanes hit the same lines (L1/L2), and
+// loop trip counts are similar across the wave.  The running best-k list lives
+// in registers as K packed 64-bit keys (bits(d2) << 32 | index): one unsigned
+// compare orders (d2, index) pairs exactly.
+//
+// Roofline: HBM-bound by design intent (12 B/query read + 4*k B/query written),
+// in practice VALU/latency-bound on the candidate loop; see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "grid.h"
+#include "ml3d_hip.h"
+
+namespace ml3d {
+
+typedef unsigned long long u64;
+constexpr u64 KEY_EMPTY = ~0ull;
+
+// Where queries come from:
+//  sorted_q != nullptr : query t = sorted_q[t] (xyz + local index) of grid `qsegs` (packed order)
+//  else                : query t = raw[global(t)]
+struct QuerySrc {
+    const float4* sorted_q;
+    const GridSeg* qsegs;   // segs of the query grid (for sorted_base -> segment lookup)
+    const float* raw;
+    Segs segs;              // layout of the raw queries / output rows
+    int64_t n_total;
+};
+
+template <int K>
+__device__ __forceinline__ void topk_insert(u64 (&best)[K], u64 key) {
+    if (key < best[K - 1]) {
+        best[K - 1] = key;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            u64 a = best[j - 1], b = best[j];
+            bool sw = b < a;
+            best[j - 1] = sw ? b : a;
+            best[j] = sw ? a : b;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
+                                         float qz, u64 (&best)[K]) {
+    int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
+    for (int p = p0; p < p1; ++p) {
+        float4 c = G.sorted[p];
+        float d2 = dist2_canon(qx, qy, qz, c.x, c.y, c.z);
+        u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
+        topk_insert<K>(best, key);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int32_t* __restrict__ out_idx,
+          float* __restrict__ out_d2) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q.n_total) return;
+    int s; int64_t local;
+    float qx, qy, qz;
+    seg_locate(Q.segs, t, s, local);
+    if (Q.sorted_q) {
+        float4 q = Q.sorted_q[t];
+        qx = q.x; qy = q.y; qz = q.z;
+        local = __float_as_int(q.w);
+    } else {
+        const float* p = Q.raw + 3 * (seg_begin_global(Q.segs, s) + local);
+        qx = p[0]; qy = p[1]; qz = p[2];
+    }
+    int64_t out_row = seg_begin_packed(Q.segs, s) + local;
+
+    const GridSeg g = G.segs[s];
+    u64 best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = KEY_EMPTY;
+
+    if (g.n > 0) {
+        int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
+        int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
+        int cz = cell_coord(qz, g.lo[2], g.inv_c, g.dims[2]);
+        int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
+        for (int r = 1;; ++r) {
+            int xa = max(cx - r, 0), xb = min(cx + r, dxm);
+            int ya = max(cy - r, 0), yb = min(cy + r, dym);
+            int za = max(cz - r, 0), zb = min(cz + r, dzm);
+            for (int z = za; z <= zb; ++z) {
+                int az = z > cz ? z - cz : cz - z;
+                for (int y = ya; y <= yb; ++y) {
+                    int ay = y > cy ? y - cy : cy - y;
+                    int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+                    if (r == 1 || az == r || ay == r) {
+                        scan_run<K>(G, row + xa, row + xb, qx, qy, qz, best);
+                    } else {
+                        if (cx - r >= 0) scan_run<K>(G, row + cx - r, row + cx - r, qx, qy, qz, best);
+                        if (cx + r <= dxm) scan_run<K>(G, row + cx + r, row + cx + r, qx, qy, qz, best);
+                    }
+                }
+            }
+            // every point outside the scanned box is at least `gd` away (inf when the box face is
+            // past the grid).  Stop once the k-th best is strictly inside that radius.
+            bool all = (cx - r <= 0) && (cx + r >= dxm) && (cy - r <= 0) && (cy + r >= dym) &&
+                       (cz - r <= 0) && (cz + r >= dzm);
+            if (all) break;
+            float gd = 3.0e38f;
+            if (cx - r > 0) gd = fminf(gd, qx - (g.lo[0] + (float)(cx - r) * g.c));
+            if (cx + r < dxm) gd = fminf(gd, (g.lo[0] + (float)(cx + r + 1) * g.c) - qx);
+            if (cy - r > 0) gd = fminf(gd, qy - (g.lo[1] + (float)(cy - r) * g.c));
+            if (cy + r < dym) gd = fminf(gd, (g.lo[1] + (float)(cy + r + 1) * g.c) - qy);
+            if (cz - r > 0) gd = fminf(gd, qz - (g.lo[2] + (float)(cz - r) * g.c));
+            if (cz + r < dzm) gd = fminf(gd, (g.lo[2] + (float)(cz + r + 1) * g.c) - qz);
+            gd -= g.margin;
+            u64 kth = best[K - 1];
+            if (k < K) {
+                // fewer than K requested: the k-th entry decides
+#pragma unroll
+                for (int j = 0; j < K; ++j) if (j == k - 1) kth = best[j];
+            }
+            if (kth != KEY_EMPTY && gd > 0.f) {
+                float dk = __uint_as_float((unsigned)(kth >> 32));
+                if (dk < gd * gd * 0.999999f) break;
+            }
+        }
+    }
+    int64_t base = index_local ? 0 : seg_begin_global(support_segs, s);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < k) {
+            u64 key = best[j];
+            bool ok = key != KEY_EMPTY;
+            out_idx[out_row * k + j] = ok ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
+            if (out_d2) out_d2[out_row * k + j] = ok ? __uint_as_float((unsigned)(key >> 32)) : __uint_as_float(0x7f800000u);
+        }
+    }
+}
+
+static int launch_query(const GridView& G, const QuerySrc& Q, int k, int index_local, Segs support_segs,
+                        int32_t* out_idx, float* out_d2, hipStream_t stream) {
+    if (Q.n_total <= 0) return 0;
+    dim3 grid((unsigned)((Q.n_total + 255) / 256)), block(256);
+    if (k == 1)
+        hipLaunchKernelGGL(knn_query<1>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 8)
+        hipLaunchKernelGGL(knn_query<8>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 16)
+        hipLaunchKernelGGL(knn_query<16>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 32)
+        hipLaunchKernelGGL(knn_query<32>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 64)
+        hipLaunchKernelGGL(knn_query<64>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else
+        return ML3D_E_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+static float tuning_occ() {
+    const char* e = getenv("ML3D_KNN_OCC");  // tuning knob only; speed, never results
+    return e ? (float)atof(e) : 0.f;
+}
+
+}  // namespace ml3d
+
+using namespace ml3d;
+
+extern "C" int ml3d_abi_version(void) { return 1; }
+
+extern "C" size_t ml3d_knn_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch) {
+    (void)n_queries;
+    return grid_ws_bytes(n_points, batch);
+}
+
+extern "C" int ml3d_knn_search(const float* points, const int64_t* points_row_splits, const float* queries,
+                               const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
+                               int64_t n_queries, int k, int index_local, int32_t* out_index,
+                               float* out_dist2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!points_row_splits || !queries_row_splits || batch <= 0 || k <= 0 || n_points < 0 || n_queries < 0 ||
+        n_points > 0x7fffffffll / GRID_CAP - 4096 || n_queries > 0x7fffffffll)
+        return ML3D_E_INVALID;
+    if (k > 64) return ML3D_E_UNSUPPORTED;
+    if (n_queries == 0) return 0;
+    if (!out_index || (n_points > 0 && !points) || !queries) return ML3D_E_INVALID;
+    GridWs ws;
+    if (!grid_ws_carve(workspace, workspace_bytes, n_points, batch, &ws)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Segs ps = {points_row_splits, 0, 0, (int)batch};
+    Segs qs = {queries_row_splits, 0, 0, (int)batch};
+    int rc = grid_build(points, ps, ws, tuning_occ(), st);
+    if (rc) return ML3D_E_LAUNCH;
+    GridView G = grid_view(ws);
+    QuerySrc Q;
+    bool self = (queries == points) && (queries_row_splits == points_row_splits) && (n_queries == n_points);
+    Q.sorted_q = self ? ws.sorted : nullptr;
+    Q.qsegs = ws.segs;
+    Q.raw = queries;
+    Q.segs = qs;
+    Q.n_total = n_queries;
+    return launch_query(G, Q, k, index_local, ps, out_index, out_dist2, st);
+}
+
+static int pyramid_sizes(int64_t n0, int num_layers, const int32_t* ratios, int64_t* n /* L+1 */) {
+    n[0] = n0;
+    for (int l = 0; l < num_layers; ++l) {
+        if (ratios[l] <= 0) return -1;
+        n[l + 1] = n[l] / ratios[l];
+    }
+    return 0;
+}
+
+extern "C" size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0, int num_layers,
+                                                      const int32_t* ratios_host) {
+    if (num_layers <= 0 || num_layers > 15 || !ratios_host) return 0;
+    int64_t n[17];
+    if (pyramid_sizes(n0, num_layers, ratios_host, n)) return 0;
+    size_t b = 0;
+    for (int l = 0; l <= num_layers; ++l) b += grid_ws_bytes(n[l] * batch, batch) + 256;
+    return b;
+}
+
+extern "C" int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64_t n0, int num_layers,
+                                       const int32_t* ratios_host, int k, int32_t* const* neighbor_idx_host,
+                                       int32_t* const* interp_idx_host, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > 15 || !ratios_host || k <= 0 ||
+        !neighbor_idx_host || !interp_idx_host)
+        return ML3D_E_INVALID;
+    if (k > 64) return ML3D_E_UNSUPPORTED;
+    int64_t n[17];
+    if (pyramid_sizes(n0, num_layers, ratios_host, n)) return ML3D_E_INVALID;
+    if (n0 * batch > 0x7fffffffll / GRID_CAP - 4096) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_randla_pyramid_workspace_bytes(batch, n0, num_layers, ratios_host))
+        return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    GridWs ws[17];
+    char* p = (char*)workspace;
+    for (int l = 0; l <= num_layers; ++l) {
+        size_t bytes = grid_ws_bytes(n[l] * batch, batch) + 256;
+        if (!grid_ws_carve(p, bytes, n[l] * batch, batch, &ws[l])) return ML3D_E_WORKSPACE;
+        p += bytes;
+    }
+    float occ = tuning_occ();
+    // grids of every level: level l = prefix [:n_l] of each cloud (randlanet.py:222)
+    for (int l = 0; l <= num_layers; ++l) {
+        if (n[l] == 0) continue;
+        Segs S = {nullptr, n0, n[l], (int)batch};
+        if (grid_build(points, S, ws[l], occ, st)) return ML3D_E_LAUNCH;
+    }
+    for (int l = 0; l < num_layers; ++l) {
+        if (n[l] == 0) continue;
+        Segs S = {nullptr, n0, n[l], (int)batch};
+        QuerySrc Q;
+        Q.sorted_q = ws[l].sorted;
+        Q.qsegs = ws[l].segs;
+        Q.raw = points;
+        Q.segs = S;
+        Q.n_total = n[l] * batch;
+        // k-NN of level l onto itself (randlanet.py:220)
+        int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
+        if (rc) return rc;
+        // 1-NN of level l in level l+1 (randlanet.py:224)
+        if (n[l + 1] > 0) {
+            Segs S1 = {nullptr, n0, n[l + 1], (int)batch};
+            rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
+            if (rc) return rc;
+        } else {
+            hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
+        }
+    }
+    return 0;
+}
