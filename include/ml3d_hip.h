@@ -82,6 +82,89 @@ int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64_t n0, int 
                             int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ------------------------------------------------------------------------- */
+/* RandLA-Net inference forward (eval mode, BatchNorm folded by the caller)   */
+/* replaces the PyTorch op chain of RandLANet.forward                          */
+/*   ml3d/torch/models/randlanet.py:241-298 — fc0/bn0 (:266-271), per layer    */
+/*   LocalFeatureAggregation.forward (:667-692) = mlp1, LocalSpatialEncoding   */
+/*   (:533-605), AttentivePooling (:622-639) x2, mlp2 + shortcut, then         */
+/*   random_sample (:300-327); mlp (:285); decoder nearest_interpolation       */
+/*   (:329-350) + cat + ConvTranspose2d (:287-293); fc1 (:296).                */
+/*                                                                             */
+/* Every Linear/Conv1x1 is y = act(W^T-packed x + b) with BatchNorm (eval)     */
+/* folded into W, b by the host.  Packed weights are [C_in][C_out] row-major   */
+/* ("WT").  `params` is ONE device buffer; slot offsets (in floats) come from  */
+/* ml3d_randla_param_layout, in this fixed slot order:                         */
+/*   0 fc0_WT[in][F] 1 fc0_b[F]                                                */
+/*   per encoder layer l (base 2 + 18*l), d_in -> d=dim_output[l], h=d/2:      */
+/*     +0 mlp1_WT[d_in][h] +1 mlp1_b  +2 lse1_WT[10][h] +3 lse1_b              */
+/*     +4 pool1_score_WT[d][d] +5 pool1_score_b +6 pool1_mlp_WT[d][h] +7 b     */
+/*     +8 lse2_WT[h][h] +9 lse2_b +10 pool2_score_WT[d][d] +11 pool2_score_b   */
+/*     +12 pool2_mlp_WT[d][d] +13 b +14 mlp2_WT[d][2d] +15 b                   */
+/*     +16 shortcut_WT[d_in][2d] +17 b                                         */
+/*   then mlp_WT[D][D], mlp_b (D = 2*dim_output[L-1]);                         */
+/*   then per decoder stage i: dec_WT[C_in_i][C_out_i], dec_b;                 */
+/*   then fc1_0_WT[C][64], b, fc1_1_WT[64][32], b, fc1_3_WT[32][classes], b.   */
+/* ------------------------------------------------------------------------- */
+#define ML3D_RANDLA_MAX_LAYERS 8
+
+typedef struct ml3d_randla_desc {
+    int32_t num_layers;
+    int32_t in_channels;   /* 3 + feature dims (randlanet.py:208-211) */
+    int32_t dim_features;  /* fc0 width */
+    int32_t num_classes;
+    int32_t num_neighbors; /* must be 16 (every reference config) */
+    int32_t dim_output[ML3D_RANDLA_MAX_LAYERS];
+    int32_t sub_sampling_ratio[ML3D_RANDLA_MAX_LAYERS];
+    int64_t batch;
+    int64_t num_points;    /* n0 per cloud */
+} ml3d_randla_desc;
+
+/* number of parameter slots; offsets_out[i] = start of slot i in floats,       */
+/* offsets_out[n_slots] = total floats.  Returns n_slots or <0.                 */
+int ml3d_randla_param_layout(const ml3d_randla_desc* desc_host, int64_t* offsets_out, int max_slots);
+
+size_t ml3d_randla_forward_workspace_bytes(const ml3d_randla_desc* desc_host);
+
+/* features [batch, n0, in_channels] f32; points [batch, n0, 3] f32;            */
+/* neighbor_idx[l] [batch, n_l, 16] i32 and interp_idx[l] [batch, n_l, 1] i32   */
+/* as produced by ml3d_randla_knn_pyramid (item-local indices);                 */
+/* out_scores [batch, n0, num_classes] f32 (the tensor RandLANet.forward        */
+/* returns, randlanet.py:298).                                                  */
+int ml3d_randla_forward(const ml3d_randla_desc* desc_host, const float* params,
+                        const float* features, const float* points,
+                        const int32_t* const* neighbor_idx_host,
+                        const int32_t* const* interp_idx_host, float* out_scores,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same as ml3d_randla_forward, plus an optional measurement hook: when trace_host is    */
+/* non-NULL the library records ev_start / ev_stop (hipEvent_t, created by the caller)   */
+/* on `stream` immediately before / after the ONE kernel launch whose tag matches, so a  */
+/* harness can time a single kernel inside a full forward without a profiler.            */
+/* tag = 8*layer + {0 mlp1, 1 lfa_stage1, 2 lfa_stage2, 3 gather_max};                   */
+/*       1000 fc0, 1001 mlp, 1100+i decoder stage i, 1200/1201/1202 fc1 layers.          */
+typedef struct ml3d_trace {
+    int32_t tag;
+    void* ev_start;
+    void* ev_stop;
+} ml3d_trace;
+
+int ml3d_randla_forward_traced(const ml3d_randla_desc* desc_host, const float* params,
+                               const float* features, const float* points,
+                               const int32_t* const* neighbor_idx_host,
+                               const int32_t* const* interp_idx_host, float* out_scores,
+                               void* workspace, size_t workspace_bytes, void* stream,
+                               const ml3d_trace* trace_host);
+
+/* ml3d_randla_knn_pyramid with the same measurement hook: tag = 2*l (k-NN query kernel of  */
+/* level l), 2*l+1 (1-NN interpolation query of level l), 100+l (whole grid build of level l). */
+int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch, int64_t n0, int num_layers,
+                                   const int32_t* ratios_host, int k,
+                                   int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
+                                   void* workspace, size_t workspace_bytes, void* stream,
+                                   const ml3d_trace* trace_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,17 @@ extern "C" int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64
                                        const int32_t* ratios_host, int k, int32_t* const* neighbor_idx_host,
                                        int32_t* const* interp_idx_host, void* workspace, size_t workspace_bytes,
                                        void* stream) {
+    return ml3d_randla_knn_pyramid_traced(points, batch, n0, num_layers, ratios_host, k, neighbor_idx_host,
+                                          interp_idx_host, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch, int64_t n0, int num_layers,
+                                              const int32_t* ratios_host, int k,
+                                              int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
+                                              void* workspace, size_t workspace_bytes, void* stream,
+                                              const ml3d_trace* tr) {
+    auto tb = [&](int tag) { if (tr && tr->tag == tag && tr->ev_start) (void)hipEventRecord((hipEvent_t)tr->ev_start, (hipStream_t)stream); };
+    auto te = [&](int tag) { if (tr && tr->tag == tag && tr->ev_stop) (void)hipEventRecord((hipEvent_t)tr->ev_stop, (hipStream_t)stream); };
     if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > 15 || !ratios_host || k <= 0 ||
         !neighbor_idx_host || !interp_idx_host)
         return ML3D_E_INVALID;
@@ -255,7 +266,9 @@ extern "C" int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64
     for (int l = 0; l <= num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
+        tb(100 + l);
         if (grid_build(points, S, ws[l], occ, st)) return ML3D_E_LAUNCH;
+        te(100 + l);
     }
     for (int l = 0; l < num_layers; ++l) {
         if (n[l] == 0) continue;
@@ -267,15 +280,19 @@ extern "C" int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64
         Q.segs = S;
         Q.n_total = n[l] * batch;
         // k-NN of level l onto itself (randlanet.py:220)
+        tb(2 * l);
         int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
+        te(2 * l);
         if (rc) return rc;
         // 1-NN of level l in level l+1 (randlanet.py:224)
         if (n[l + 1] > 0) {
             Segs S1 = {nullptr, n0, n[l + 1], (int)batch};
+            tb(2 * l + 1);
             rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
+            te(2 * l + 1);
             if (rc) return rc;
         } else {
-            hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
+            (void)hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
         }
     }
     return 0;

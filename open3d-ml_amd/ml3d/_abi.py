@@ -1,0 +1,122 @@
+"""ctypes binding of the C ABI declared in include/ml3d_hip.h.
+
+``get()`` loads the in-tree ``lib/libml3d_hip.so`` (built by ``__graft_entry__.build()`` with
+hipcc for gfx950) and FAILS LOUDLY if it is missing — there is no CPU fallback in this
+package.  The raw functions below take integer device addresses so the same signatures
+serve the torch front end (``ml3d.ops``) and the ABI tests.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libml3d_hip.so")
+MAX_LAYERS = 8
+_lib = None
+
+ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
+
+# every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "ml3d_abi_version",
+    "ml3d_knn_workspace_bytes",
+    "ml3d_knn_search",
+    "ml3d_randla_pyramid_workspace_bytes",
+    "ml3d_randla_knn_pyramid",
+    "ml3d_randla_param_layout",
+    "ml3d_randla_forward_workspace_bytes",
+    "ml3d_randla_forward",
+    "ml3d_randla_forward_traced",
+    "ml3d_randla_knn_pyramid_traced",
+]
+
+
+class RandlaDesc(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32),
+        ("in_channels", C.c_int32),
+        ("dim_features", C.c_int32),
+        ("num_classes", C.c_int32),
+        ("num_neighbors", C.c_int32),
+        ("dim_output", C.c_int32 * MAX_LAYERS),
+        ("sub_sampling_ratio", C.c_int32 * MAX_LAYERS),
+        ("batch", C.c_int64),
+        ("num_points", C.c_int64),
+    ]
+
+
+class Trace(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+
+
+def bind(lib):
+    """Attach argtypes/restypes to a loaded library object."""
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+    lib.ml3d_abi_version.restype = C.c_int
+    lib.ml3d_knn_workspace_bytes.restype = sz
+    lib.ml3d_knn_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.ml3d_knn_search.restype = C.c_int
+    lib.ml3d_knn_search.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]
+    lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
+    lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
+    lib.ml3d_randla_knn_pyramid.restype = C.c_int
+    lib.ml3d_randla_knn_pyramid.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, sz, vp]
+    lib.ml3d_randla_param_layout.restype = C.c_int
+    lib.ml3d_randla_param_layout.argtypes = [C.POINTER(RandlaDesc), vp, i32]
+    lib.ml3d_randla_forward_workspace_bytes.restype = sz
+    lib.ml3d_randla_forward_workspace_bytes.argtypes = [C.POINTER(RandlaDesc)]
+    lib.ml3d_randla_forward.restype = C.c_int
+    lib.ml3d_randla_forward.argtypes = [C.POINTER(RandlaDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_randla_forward_traced.restype = C.c_int
+    lib.ml3d_randla_forward_traced.argtypes = [C.POINTER(RandlaDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Trace)]
+    lib.ml3d_randla_knn_pyramid_traced.restype = C.c_int
+    lib.ml3d_randla_knn_pyramid_traced.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, sz, vp, C.POINTER(Trace)]
+    return lib
+
+
+def get():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "ml3d: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "error"), rc))
+
+
+def make_desc(cfg, batch, num_points):
+    d = RandlaDesc()
+    L = int(cfg["num_layers"])
+    if L > MAX_LAYERS:
+        raise RuntimeError("num_layers > %d unsupported" % MAX_LAYERS)
+    d.num_layers = L
+    d.in_channels = int(cfg["in_channels"])
+    d.dim_features = int(cfg["dim_features"])
+    d.num_classes = int(cfg["num_classes"])
+    d.num_neighbors = int(cfg["num_neighbors"])
+    for l in range(L):
+        d.dim_output[l] = int(cfg["dim_output"][l])
+        d.sub_sampling_ratio[l] = int(cfg["sub_sampling_ratio"][l])
+    d.batch = int(batch)
+    d.num_points = int(num_points)
+    return d
+
+
+def randla_param_offsets(lib, desc):
+    import numpy as np
+    off = np.zeros(256, np.int64)
+    n = lib.ml3d_randla_param_layout(C.byref(desc), off.ctypes.data, 256)
+    if n < 0:
+        check(n, "ml3d_randla_param_layout")
+    return off[:n + 1].copy()
+
+
+def ptr_table(ptrs):
+    """HOST array of device pointers (kept alive by the caller)."""
+    arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs])
+    return arr

@@ -1,0 +1,86 @@
+"""Preallocated RandLA-Net inference engine (one process per GPU).
+
+Everything a step needs lives in HBM before the step starts: packed BatchNorm-folded weights,
+the int32 neighbour pyramid, the forward workspace and the score tensor.  A step is two C-ABI
+calls on torch's current stream — ``ml3d_randla_knn_pyramid`` (replaces the 8 CPU knn_search
+calls of RandLANet.transform, reference randlanet.py:218-229) and ``ml3d_randla_forward``
+(replaces RandLANet.forward, randlanet.py:241-298) — with no host synchronisation.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from .ops import pyramid_sizes
+from .torch.models import _randla_pack
+
+
+class RandLAInferenceEngine:
+
+    def __init__(self, cfg, state_dict, batch, num_points, device):
+        self.lib = _abi.get()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("RandLAInferenceEngine needs an MI355X device; there is no CPU fallback")
+        self.B, self.N = int(batch), int(num_points)
+        self.L = int(cfg["num_layers"])
+        self.K = int(cfg["num_neighbors"])
+        self.desc = _abi.make_desc(cfg, self.B, self.N)
+        off = _abi.randla_param_offsets(self.lib, self.desc)
+        self.params = torch.from_numpy(_randla_pack.pack(state_dict, cfg, off)).to(self.device)
+        self.n = pyramid_sizes(self.N, cfg["sub_sampling_ratio"])
+        dev = self.device
+        self.nbr = [torch.empty((self.B, self.n[l], self.K), dtype=torch.int32, device=dev) for l in range(self.L)]
+        self.itp = [torch.empty((self.B, self.n[l], 1), dtype=torch.int32, device=dev) for l in range(self.L)]
+        self.scores = torch.empty((self.B, self.N, int(cfg["num_classes"])), dtype=torch.float32, device=dev)
+        self.ratios = (C.c_int32 * self.L)(*[int(r) for r in cfg["sub_sampling_ratio"]])
+        self.pyr_ws_bytes = self.lib.ml3d_randla_pyramid_workspace_bytes(self.B, self.N, self.L, self.ratios)
+        self.fwd_ws_bytes = self.lib.ml3d_randla_forward_workspace_bytes(C.byref(self.desc))
+        if self.pyr_ws_bytes == 0 or self.fwd_ws_bytes == 0:
+            raise RuntimeError("RandLAInferenceEngine: invalid model/pyramid description")
+        self.pyr_ws = torch.empty(self.pyr_ws_bytes, dtype=torch.uint8, device=dev)
+        self.fwd_ws = torch.empty(self.fwd_ws_bytes, dtype=torch.uint8, device=dev)
+        self._t_n = _abi.ptr_table([t.data_ptr() for t in self.nbr])
+        self._t_i = _abi.ptr_table([t.data_ptr() for t in self.itp])
+
+    def _check(self, points, features):
+        if tuple(points.shape) != (self.B, self.N, 3) or points.dtype != torch.float32 or \
+                not points.is_cuda or not points.is_contiguous():
+            raise RuntimeError("engine: points must be a contiguous float32 CUDA tensor [%d, %d, 3]" % (self.B, self.N))
+        if tuple(features.shape) != (self.B, self.N, int(self.cfg["in_channels"])) or \
+                features.dtype != torch.float32 or not features.is_cuda or not features.is_contiguous():
+            raise RuntimeError("engine: features must be a contiguous float32 CUDA tensor [B, N, in_channels]")
+
+    def neighbors(self, points, trace=None):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.ml3d_randla_knn_pyramid_traced(points.data_ptr(), self.B, self.N, self.L, self.ratios, self.K,
+                                                     self._t_n, self._t_i, self.pyr_ws.data_ptr(),
+                                                     self.pyr_ws_bytes, st, trace)
+        _abi.check(rc, "ml3d_randla_knn_pyramid")
+        return self.nbr, self.itp
+
+    def forward(self, points, features, trace=None):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.ml3d_randla_forward_traced(C.byref(self.desc), self.params.data_ptr(), features.data_ptr(),
+                                                 points.data_ptr(), self._t_n, self._t_i, self.scores.data_ptr(),
+                                                 self.fwd_ws.data_ptr(), self.fwd_ws_bytes, st, trace)
+        _abi.check(rc, "ml3d_randla_forward")
+        return self.scores
+
+    def step(self, points, features, knn_trace=None, fwd_trace=None):
+        """One hot-path pass over a batch of frames: neighbour pyramid + forward -> scores [B, N, classes]."""
+        self._check(points, features)
+        with torch.cuda.device(self.device):
+            self.neighbors(points, knn_trace)
+            return self.forward(points, features, fwd_trace)
+
+
+def make_trace(tag, ev_start, ev_stop):
+    """Trace record from two ``torch.cuda.Event(enable_timing=True)`` objects (must be created on
+    the current device; ``.record()`` once beforehand materialises the underlying hipEvent_t)."""
+    t = _abi.Trace()
+    t.tag = int(tag)
+    t.ev_start = C.c_void_p(ev_start.cuda_event)
+    t.ev_stop = C.c_void_p(ev_stop.cuda_event)
+    return t

@@ -1,0 +1,84 @@
+"""Seeded synthetic inputs shaped like the reference's datasets.
+
+Bench/test data only — there is no network for SemanticKITTI/Toronto3D/KITTI.  Pure numpy.
+"""
+import numpy as np
+
+
+def _grid_barycentre(points, cell):
+    """Voxel-grid barycentre subsample (numpy stand-in for the 0.06 m preprocess step,
+    ml3d/torch/models/randlanet.py:133-139).  Order = ascending voxel key."""
+    org = np.floor(points.min(0) / cell) * cell
+    c = np.floor((points - org) / cell).astype(np.int64)
+    dims = c.max(0) + 1
+    key = c[:, 0] + dims[0] * (c[:, 1] + dims[1] * c[:, 2])
+    uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    out = np.zeros((uniq.size, 3), np.float64)
+    np.add.at(out, inv, points.astype(np.float64))
+    return (out / cnt[:, None]).astype(np.float32)
+
+
+def lidar_sweep(seed, n_beams=64, n_azimuth=2048, with_intensity=False):
+    """One spinning-lidar sweep: rays hit the nearest of a ground plane (z = -1.73 m) and 40
+    axis-aligned boxes; range <= 80 m; N(0, 0.02) m range noise.  ~100-130 k points."""
+    rng = np.random.default_rng(seed)
+    elev = np.deg2rad(np.linspace(-24.8, 2.0, n_beams))
+    azim = np.linspace(-np.pi, np.pi, n_azimuth, endpoint=False)
+    el, az = np.meshgrid(elev, azim, indexing="ij")
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1).reshape(-1, 3)
+    t_best = np.full(d.shape[0], np.inf)
+    # ground plane
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(d[:, 2] < -1e-6, -1.73 / d[:, 2], np.inf)
+    t_best = np.minimum(t_best, tg)
+    # boxes (slab test)
+    n_box = 40
+    ctr = np.concatenate([rng.uniform(-40, 40, (n_box, 2)), np.full((n_box, 1), -1.73)], 1)
+    size = np.concatenate([rng.uniform(1, 10, (n_box, 2)), rng.uniform(1, 6, (n_box, 1))], 1)
+    lo = ctr - size * np.array([0.5, 0.5, 0.0])
+    hi = ctr + size * np.array([0.5, 0.5, 1.0])
+    keep = np.linalg.norm(ctr[:, :2], axis=1) > 4.0  # nothing on top of the sensor
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        for b in np.nonzero(keep)[0]:
+            t0 = lo[b] * inv
+            t1 = hi[b] * inv
+            tmin = np.minimum(t0, t1).max(1)
+            tmax = np.maximum(t0, t1).min(1)
+            hit = (tmax >= tmin) & (tmax > 0) & (tmin > 0)
+            t_best = np.where(hit & (tmin < t_best), tmin, t_best)
+    ok = np.isfinite(t_best) & (t_best < 80.0)
+    t = t_best[ok] + rng.normal(0, 0.02, ok.sum())
+    pts = (d[ok] * t[:, None]).astype(np.float32)
+    if with_intensity:
+        return np.concatenate([pts, rng.uniform(0, 1, (pts.shape[0], 1)).astype(np.float32)], 1)
+    return pts
+
+
+def semantickitti_patch(frame_id, num_points=45056):
+    """What ``RandLANet.transform`` sees after the sampler: [num_points, 3] f32, the num_points
+    nearest (to a random centre) points of a 0.06 m grid-subsampled sweep, recentred in x/y
+    (randlanet_semantickitti.yml augment.recenter dim [0, 1]) and shuffled.  seed = 1000 + frame_id."""
+    seed = 1000 + int(frame_id)
+    rng = np.random.default_rng(seed)
+    sweep = lidar_sweep(seed)
+    sub = _grid_barycentre(sweep, 0.06)
+    if sub.shape[0] < num_points:  # extremely sparse seed: densify by jittered duplication
+        extra = sub[rng.integers(0, sub.shape[0], num_points - sub.shape[0])]
+        sub = np.concatenate([sub, extra + rng.normal(0, 0.03, extra.shape).astype(np.float32)], 0)
+    centre = sub[rng.integers(0, sub.shape[0])]
+    d2 = ((sub - centre) ** 2).sum(1)
+    sel = np.argpartition(d2, num_points - 1)[:num_points]
+    sel = sel[rng.permutation(num_points)]
+    pc = sub[sel].copy()
+    pc[:, :2] -= pc[:, :2].mean(0)
+    return np.ascontiguousarray(pc, np.float32)
+
+
+def semantickitti_batch(first_frame, batch, num_points=45056):
+    return np.stack([semantickitti_patch(first_frame + i, num_points) for i in range(batch)])
+
+
+def uniform_cloud(seed, n, extent=(10.0, 10.0, 2.0)):
+    rng = np.random.default_rng(seed)
+    return (rng.random((n, 3), dtype=np.float32) * np.asarray(extent, np.float32)).astype(np.float32)

@@ -17,5 +17,5 @@ for s in $SRCS "$HERE/hipemu.cpp"; do
   fi
   OBJS="$OBJS $o"
 done
-$CXX -shared -o "$OUT/libml3d_emu.so" $OBJS -lpthread
+$CXX -shared -rdynamic -o "$OUT/libml3d_emu.so" $OBJS -lpthread
 echo "$OUT/libml3d_emu.so"

@@ -1,6 +1,9 @@
 // hipemu runtime: fiber scheduler for the host-side HIP stand-in (tests only).
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <mutex>
 
 namespace hipemu {
@@ -104,6 +107,32 @@ static void run_block(Block* b) {
         }
     }
     g_blk = nullptr;
+}
+
+static void segv_handler(int sig) {
+    void* bt[48];
+    int n = backtrace(bt, 48);
+    const char msg[] = "hipemu: fatal signal inside an emulated kernel; backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    if (g_blk) fprintf(stderr, "hipemu: block (%u,%u,%u) thread %d\n", g_blk->bidx.x, g_blk->bidx.y, g_blk->bidx.z, g_blk->cur);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+void trace(const char* name) {
+    static bool installed = false;
+    if (!installed && getenv("HIPEMU_TRACE")) {
+        installed = true;
+        static char altstack[1 << 16];
+        stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof(altstack); ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa; memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = segv_handler; sa.sa_flags = SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+    }
+    static const bool on = getenv("HIPEMU_TRACE") != nullptr;
+    if (on) { fprintf(stderr, "hipemu: launch %s\n", name); fflush(stderr); }
 }
 
 static int n_workers() {

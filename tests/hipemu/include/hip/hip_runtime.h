@@ -68,6 +68,10 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
 namespace hipemu {
 
@@ -147,6 +151,7 @@ inline WaveView wave_exchange(const void* data, size_t n) {
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void trace(const char* name);
 
 }  // namespace hipemu
 
@@ -157,7 +162,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })
+    (hipemu::trace(#kernel), hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); }))
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __threadfence() {}

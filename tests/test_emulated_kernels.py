@@ -1,0 +1,119 @@
+"""CPU: run the SAME .hip sources the GPU runs through the host emulator (tests/hipemu) and compare
+with the oracle: neighbour indices bit-exact, logits within 1e-4.  This is a logic check of the
+kernels; the authoritative parity tests are the `-m gpu` ones."""
+import os
+
+import numpy as np
+import pytest
+
+import emu
+import synth_data
+from oracle import ops as oops
+from oracle import randlanet_ref as R
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="clang++ for the host emulator not found")
+
+
+@pytest.mark.parametrize("n,kind", [(3000, "vol"), (5000, "surf"), (100, "vol"), (17, "vol"), (2000, "dup"), (1, "vol")])
+def test_knn_self_query(n, kind):
+    rng = np.random.default_rng(n)
+    if kind == "vol":
+        p = rng.random((n, 3), dtype=np.float32) * 10
+    elif kind == "surf":
+        p = rng.random((n, 3), dtype=np.float32) * np.array([30, 30, 0.05], np.float32)
+    else:
+        p = np.repeat(rng.random((n // 4, 3), dtype=np.float32), 4, 0)
+    idx, d2 = emu.knn(p, [0, n], k=16)
+    ref, rd = oops.knn_search(p, p, 16, return_distances=True)
+    kk = ref.shape[1]
+    assert np.array_equal(idx[:, :kk], ref) and np.array_equal(d2[:, :kk], rd)
+    assert (idx[:, kk:] == -1).all()
+
+
+def test_knn_external_queries_and_other_k():
+    rng = np.random.default_rng(5)
+    p = rng.random((4000, 3), dtype=np.float32) * 10
+    q = rng.random((777, 3), dtype=np.float32) * 14 - 2        # some queries outside the support bbox
+    for k in (1, 5, 8, 20, 33):
+        idx, _ = emu.knn(p, [0, 4000], q, [0, 777], k=k)
+        assert np.array_equal(idx, oops.knn_search(p, q, k))
+
+
+def test_knn_batched_row_splits_with_empty_item():
+    p = np.random.default_rng(6).random((4000, 3), dtype=np.float32)
+    ps = [0, 1000, 1000, 2500, 4000]
+    idx, _ = emu.knn(p, ps, k=16)
+    ref, _ = oops.knn_search_batched(p, ps, p, ps, 16)
+    assert np.array_equal(idx, ref)
+    loc, _ = emu.knn(p, ps, k=1, local=True)
+    assert np.array_equal(loc[:, 0], np.concatenate([np.arange(1000), np.arange(1500), np.arange(1500)]))
+
+
+def test_degenerate_clouds():
+    same = np.ones((50, 3), np.float32) * 3.5                  # zero extent
+    idx, _ = emu.knn(same, [0, 50], k=4)
+    assert np.array_equal(idx, oops.knn_search(same, same, 4))
+    line = np.zeros((500, 3), np.float32); line[:, 0] = np.linspace(0, 1, 500)
+    idx, _ = emu.knn(line, [0, 500], k=16)
+    assert np.array_equal(idx, oops.knn_search(line, line, 16))
+    far = np.random.default_rng(1).random((2000, 3), dtype=np.float32); far[0] = [1e4, -1e4, 5e3]   # outlier
+    idx, _ = emu.knn(far, [0, 2000], k=16)
+    assert np.array_equal(idx, oops.knn_search(far, far, 16))
+
+
+def test_randla_pyramid_on_lidar_patches():
+    pts = np.stack([synth_data.semantickitti_patch(i, 4096) for i in range(2)])
+    nbr, itp = emu.pyramid(pts, [4, 4, 4, 4])
+    for b in range(2):
+        pc = pts[b]
+        for l in range(4):
+            assert np.array_equal(nbr[l][b], oops.knn_search(pc, pc, 16))
+            sub = pc[:pc.shape[0] // 4]
+            assert np.array_equal(itp[l][b], oops.knn_search(sub, pc, 1))
+            pc = sub
+
+
+CFGS = [
+    dict(num_neighbors=16, num_layers=4, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+         dim_features=8, dim_output=[16, 64, 128, 256]),
+    dict(num_neighbors=16, num_layers=2, num_classes=5, sub_sampling_ratio=[4, 2], in_channels=6,
+         dim_features=8, dim_output=[8, 32]),
+]
+
+
+@pytest.mark.parametrize("ci,B,N", [(0, 2, 1024), (1, 3, 515)])
+def test_randla_forward_matches_oracle(ci, B, N):
+    cfg = CFGS[ci]
+    rng = np.random.default_rng(3)
+    pts = synth_data.uniform_cloud(3, B * N).reshape(B, N, 3)
+    feats = pts.copy() if cfg["in_channels"] == 3 else np.concatenate(
+        [pts, rng.random((B, N, cfg["in_channels"] - 3), dtype=np.float32)], 2)
+    sd = R.make_state_dict(cfg, 11)
+    inp = R.build_inputs(pts, feats, cfg, oops.knn_search)
+    ref = R.forward(sd, cfg, inp).numpy()
+    nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
+    itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
+    rc, out = emu.randla_forward(cfg, sd, pts, feats, nbr, itp)
+    assert rc == 0
+    assert np.abs(out - ref).max() <= 1e-4
+
+
+def test_randla_forward_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "randlanet_small.npz"))
+    cfg = dict(num_neighbors=16, num_layers=3, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
+               dim_features=8, dim_output=[16, 32, 64])
+    sd = R.make_state_dict(cfg, int(g["weights_seed"]))
+    nbr, itp = emu.pyramid(g["points"], cfg["sub_sampling_ratio"])
+    assert np.array_equal(nbr[0], g["nbr0"]) and np.array_equal(itp[0], g["interp0"])
+    rc, out = emu.randla_forward(cfg, sd, g["points"], g["features"], nbr, itp)
+    assert rc == 0 and np.abs(out - g["logits"]).max() <= 1e-4
+
+
+def test_forward_rejects_levels_with_fewer_than_16_points():
+    cfg = dict(CFGS[0])
+    sd = R.make_state_dict(cfg, 1)
+    pts = synth_data.uniform_cloud(1, 512).reshape(1, 512, 3)         # level 3 would have 8 < 16 points
+    nbr = [np.zeros((1, 512 // 4 ** l, 16), np.int32) for l in range(4)]
+    itp = [np.zeros((1, 512 // 4 ** l, 1), np.int32) for l in range(4)]
+    rc, _ = emu.randla_forward(cfg, sd, pts, pts, nbr, itp)
+    assert rc == -4

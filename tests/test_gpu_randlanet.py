@@ -1,0 +1,113 @@
+"""GPU parity: RandLA-Net inference (GPU neighbour pyramid + fused HIP forward) vs the CPU oracle and
+the reference-generated golden vectors.  Tolerance: indices exact, logits max|d| <= 1e-4 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth_data
+from oracle import ops as oops
+from oracle import randlanet_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+KITTI = dict(num_neighbors=16, num_layers=4, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+             dim_features=8, dim_output=[16, 64, 128, 256])
+SMALL = dict(num_neighbors=16, num_layers=3, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
+             dim_features=8, dim_output=[16, 32, 64])
+FIVE = dict(num_neighbors=16, num_layers=5, num_classes=13, sub_sampling_ratio=[4, 4, 4, 4, 2], in_channels=6,
+            dim_features=8, dim_output=[16, 64, 128, 256, 512])
+
+
+def _model(cfg, sd):
+    from ml3d.torch.models.randlanet import RandLANet
+    assert torch.cuda.is_available()
+    m = RandLANet(**cfg, device="cuda:0")
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def _run(cfg, sd, pts, feats):
+    m = _model(cfg, sd)
+    d = torch.device("cuda:0")
+    out = m({"coords": [torch.from_numpy(pts).to(d)], "features": torch.from_numpy(feats).to(d)})
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg,B,N,seed", [(KITTI, 2, 4096, 1), (SMALL, 3, 1030, 2), (FIVE, 1, 8192, 3)])
+def test_forward_matches_oracle(cfg, B, N, seed):
+    rng = np.random.default_rng(seed)
+    pts = np.stack([synth_data.semantickitti_patch(50 + seed * 10 + b, N) for b in range(B)])
+    feats = pts.copy() if cfg["in_channels"] == 3 else np.concatenate(
+        [pts, rng.random((B, N, cfg["in_channels"] - 3), dtype=np.float32)], 2)
+    sd = R.make_state_dict(cfg, 40 + seed)
+    ref = R.forward(sd, cfg, R.build_inputs(pts, feats, cfg, oops.knn_search)).numpy()
+    out = _run(cfg, sd, pts, feats)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= TOL
+
+
+def test_reference_golden_small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "randlanet_small.npz"))
+    sd = R.make_state_dict(SMALL, int(g["weights_seed"]))
+    out = _run(SMALL, sd, g["points"], g["features"])
+    assert np.abs(out - g["logits"]).max() <= TOL
+
+
+def test_reference_golden_kitti4096(golden_dir):
+    g = np.load(os.path.join(golden_dir, "randlanet_kitti4096.npz"))
+    sd = R.make_state_dict(KITTI, int(g["weights_seed"]))
+    out = _run(KITTI, sd, g["points"], g["points"].copy())
+    assert np.abs(out - g["logits"]).max() <= TOL
+    assert (out.argmax(-1) == g["logits"].argmax(-1)).mean() >= 0.9999
+
+
+def test_reference_golden_full_frame_45056(golden_dir):
+    """BASELINE size: one 45056-point frame against the reference's logits (every 64th point stored)
+    and its arg-max labels for every point (the quantity mIoU is computed from)."""
+    g = np.load(os.path.join(golden_dir, "randlanet_kitti45056.npz"))
+    pts = synth_data.semantickitti_patch(int(g["frame_id"]), 45056)[None]
+    assert abs(pts.astype(np.float64).sum() - float(g["points_sum"])) < 1e-6
+    sd = R.make_state_dict(KITTI, int(g["weights_seed"]))
+    from ml3d import ops
+    t = torch.from_numpy(pts).cuda()
+    nbr, _ = ops.randla_knn_pyramid(t, KITTI["sub_sampling_ratio"], 16)
+    nb0 = nbr[0].cpu().numpy().astype(np.int64)
+    assert int((nb0 * (np.arange(16) + 1)).sum()) == int(g["nbr0_checksum"])
+    assert np.array_equal(nb0.sum(-1)[0, ::16], g["nbr0_rowsum"])
+    out = _run(KITTI, sd, pts, pts.copy())
+    assert np.abs(out[:, ::64] - g["logits_every64"]).max() <= TOL
+    agree = (out.argmax(-1).astype(np.int8) == g["argmax"]).mean()
+    assert agree >= 0.9999, agree
+
+
+def test_accepts_reference_style_precomputed_indices():
+    """The dict RandLANet.transform produces (int64 index lists) is consumed unchanged."""
+    B, N = 1, 4096
+    pts = synth_data.semantickitti_patch(9, N)[None]
+    sd = R.make_state_dict(KITTI, 77)
+    inp = R.build_inputs(pts, pts.copy(), KITTI, oops.knn_search)
+    ref = R.forward(sd, KITTI, inp).numpy()
+    m = _model(KITTI, sd)
+    out = m(inp)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL
+
+
+def test_engine_batch_is_frame_independent_and_deterministic():
+    from ml3d.engine import RandLAInferenceEngine
+    B, N = 4, 45056
+    base = np.stack([synth_data.semantickitti_patch(200 + i, N) for i in range(2)])
+    frames = np.concatenate([base, base], 0)
+    sd = R.make_state_dict(KITTI, 5)
+    eng = RandLAInferenceEngine(dict(KITTI, num_points=N), sd, B, N, "cuda:0")
+    t = torch.from_numpy(frames).cuda()
+    a = eng.step(t, t.clone()).clone()
+    b = eng.step(t, t.clone()).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                       # run-to-run deterministic
+    assert torch.equal(a[0], a[2]) and torch.equal(a[1], a[3])   # a frame's result does not depend on its batch slot
+    assert torch.isfinite(a).all()

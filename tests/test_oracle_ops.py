@@ -1,0 +1,159 @@
+"""CPU: pin the oracle's primitive ops (oracle/ml3d_oracle.c) against independent implementations
+and the only published known-answer vector for them (upstream voxelize docstring)."""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from oracle import ops
+
+
+def _cloud(seed, n, surface=False):
+    rng = np.random.default_rng(seed)
+    ext = np.array([30, 30, 0.05] if surface else [10, 10, 10], np.float32)
+    return rng.random((n, 3), dtype=np.float32) * ext
+
+
+@pytest.mark.parametrize("n,k,surface", [(1, 1, False), (17, 16, False), (3000, 16, False), (5000, 16, True), (800, 5, False)])
+def test_knn_kdtree_equals_bruteforce(n, k, surface):
+    p = _cloud(n, n, surface)
+    a, da = ops.knn_search(p, p, k, return_distances=True)
+    b, db = ops.knn_search(p, p, k, brute=True, return_distances=True)
+    assert a.shape == (n, min(k, n))
+    assert np.array_equal(a, b) and np.array_equal(da, db)
+    assert np.array_equal(a[:, 0], np.arange(n))          # self match first (d2 = 0)
+    assert (np.diff(da, axis=1) >= 0).all()
+
+
+def test_knn_matches_scipy_where_distances_are_distinct():
+    p = _cloud(3, 20000)
+    idx, d2 = ops.knn_search(p, p, 16, return_distances=True)
+    _, ref = cKDTree(p).query(p, 16)
+    assert (idx == ref).mean() > 0.9999      # float64 vs canonical float32 ordering differs only on near-ties
+    assert np.allclose(d2, ((p[:, None] - p[idx]) ** 2).sum(-1), rtol=1e-5, atol=1e-7)
+
+
+def test_knn_tie_break_by_index():
+    base = _cloud(5, 300)
+    p = np.repeat(base, 4, 0)                 # every point duplicated 4x: exact distance ties
+    idx = ops.knn_search(p, p, 8)
+    for i in (0, 5, 1199):
+        g = (i // 4) * 4
+        assert list(idx[i, :4]) == [g, g + 1, g + 2, g + 3]
+
+
+def test_knn_batched_global_indices_and_padding():
+    p = _cloud(9, 1000)
+    splits = [0, 400, 400, 410, 1000]
+    idx, d2 = ops.knn_search_batched(p, splits, p, splits, 16)
+    for b in range(4):
+        s, e = splits[b], splits[b + 1]
+        if e - s == 0:
+            continue
+        kk = min(16, e - s)
+        ref = ops.knn_search(p[s:e], p[s:e], 16)
+        assert np.array_equal(idx[s:e, :kk], ref + s)
+        assert (idx[s:e, kk:] == -1).all() and np.isinf(d2[s:e, kk:]).all()
+
+
+def test_fixed_radius_search_matches_scipy_sets_and_is_sorted():
+    p = _cloud(11, 4000)
+    q = _cloud(12, 500)
+    r = ops.fixed_radius_search(p, q, 0.7, return_distances=True)
+    ref = cKDTree(p).query_ball_point(q, 0.7)
+    rs = r.neighbors_row_splits
+    assert rs[0] == 0 and (np.diff(rs) >= 0).all()
+    bad = 0
+    for i in range(len(q)):
+        mine = r.neighbors_index[rs[i]:rs[i + 1]]
+        d = r.neighbors_distance[rs[i]:rs[i + 1]]
+        assert (np.diff(d) >= 0).all() and (d <= np.float32(0.7) * np.float32(0.7)).all()
+        bad += set(mine.tolist()) != set(ref[i])
+    assert bad <= 2          # only points within float rounding of the sphere may differ
+
+
+def test_fixed_radius_batched():
+    p = _cloud(13, 900)
+    ps = [0, 300, 900]
+    r = ops.fixed_radius_search(p, p, 1.0, ps, ps)
+    rs = r.neighbors_row_splits
+    for i in (0, 299):
+        assert r.neighbors_index[rs[i]:rs[i + 1]].max() < 300
+    for i in (300, 899):
+        assert r.neighbors_index[rs[i]:rs[i + 1]].min() >= 300
+    assert r.neighbors_index[rs[5]] == 5     # self first
+
+
+def test_ragged_to_dense():
+    v = np.arange(10, dtype=np.int32).reshape(-1, 1)
+    out = ops.ragged_to_dense(v, [0, 3, 3, 10], 4, [-1]).squeeze(-1)
+    assert out.tolist() == [[0, 1, 2, -1], [-1, -1, -1, -1], [3, 4, 5, 6]]
+
+
+def test_voxelize_upstream_docstring_known_answer():
+    pts = np.array([[.1, .1, .1], [.5, .5, .5], [1.7, 1.7, 1.7], [1.8, 1.8, 1.8], [9.3, 9.4, 9.4]], np.float32)
+    r = ops.voxelize(pts, [0, 5], [1, 1, 1], [0, 0, 0], [2, 2, 2])
+    assert r.voxel_coords.tolist() == [[0, 0, 0], [1, 1, 1]]
+    assert r.voxel_point_indices.tolist() == [0, 1, 2, 3]
+    assert r.voxel_point_row_splits.tolist() == [0, 2, 4]
+    assert r.voxel_batch_splits.tolist() == [0, 2]
+
+
+def test_voxelize_against_numpy_grouping_with_limits():
+    rng = np.random.default_rng(4)
+    pts = (rng.random((20000, 3), dtype=np.float32) * np.array([80, 90, 5], np.float32) - np.array([5, 45, 3.5], np.float32))
+    vs, mn, mx = [0.16, 0.16, 4.0], [0, -39.68, -3], [69.12, 39.68, 1]
+    r = ops.voxelize(pts, [0, 12000, 20000], vs, mn, mx, max_points_per_voxel=3, max_voxels=4000)
+    assert r.voxel_batch_splits[0] == 0 and r.voxel_batch_splits[-1] == len(r.voxel_coords)
+    assert (np.diff(r.voxel_batch_splits) <= 4000).all()
+    cnt = np.diff(r.voxel_point_row_splits)
+    assert cnt.min() >= 1 and cnt.max() <= 3
+    vsf, mnf = np.asarray(vs, np.float32), np.asarray(mn, np.float32)
+    for v in (0, len(cnt) // 2, len(cnt) - 1):
+        ids = r.voxel_point_indices[r.voxel_point_row_splits[v]:r.voxel_point_row_splits[v + 1]]
+        assert (np.diff(ids) > 0).all()
+        c = ((pts[ids] - mnf) / vsf).astype(np.int32)
+        assert (c == r.voxel_coords[v]).all()
+    # voxels ascending by linear id inside each batch item
+    G = (((np.asarray(mx, np.float32) - mnf) / vsf).astype(np.int64) + 1)
+    for b in range(2):
+        c = r.voxel_coords[r.voxel_batch_splits[b]:r.voxel_batch_splits[b + 1]].astype(np.int64)
+        lin = c[:, 0] + G[0] * (c[:, 1] + G[1] * c[:, 2])
+        assert (np.diff(lin) > 0).all()
+
+
+def test_subsample_barycentres_and_labels():
+    rng = np.random.default_rng(8)
+    pts = rng.random((5000, 3), dtype=np.float32) * 4
+    feat = rng.random((5000, 2), dtype=np.float32)
+    lab = rng.integers(0, 5, 5000).astype(np.int32)
+    sp, sf, sl = ops.subsample(pts, features=feat, classes=lab, sampleDl=0.5)
+    org = np.floor(pts.min(0) / np.float32(0.5)) * np.float32(0.5)
+    key = np.floor((pts - org) / np.float32(0.5)).astype(np.int64)
+    dims = key.max(0) + 1
+    lin = key[:, 0] + dims[0] * (key[:, 1] + dims[1] * key[:, 2])
+    uniq, inv = np.unique(lin, return_inverse=True)
+    assert sp.shape[0] == uniq.size
+    ref = np.zeros((uniq.size, 3)); np.add.at(ref, inv, pts)
+    ref /= np.bincount(inv)[:, None]
+    assert np.allclose(sp, ref, atol=1e-5)
+    reff = np.zeros((uniq.size, 2)); np.add.at(reff, inv, feat)
+    assert np.allclose(sf, reff / np.bincount(inv)[:, None], atol=1e-5)
+    v = 7
+    assert sl[v] == np.bincount(lab[inv == v]).argmax()
+    only = ops.subsample(pts, sampleDl=0.5)
+    assert np.array_equal(only, sp)
+
+
+def test_subsample_batch_lengths():
+    pts = np.random.default_rng(2).random((3000, 3), dtype=np.float32)
+    sp, lens = ops.subsample_batch(pts, [1000, 2000], sampleDl=0.25)
+    assert lens.sum() == sp.shape[0] and len(lens) == 2
+    assert np.array_equal(sp[:lens[0]], ops.subsample(pts[:1000], sampleDl=0.25))
+
+
+def test_nms_rotated():
+    boxes = np.array([[0, 0, 2, 2, 0], [0.1, 0, 2.1, 2, 0.05], [5, 5, 6, 6, 0], [0, 0, 2, 2, np.pi / 2]], np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.6], np.float32)
+    assert ops.nms(boxes, scores, 0.3).tolist() == [0, 2]
+    assert ops.nms(boxes, scores, 0.99).tolist() == [0, 1, 2]   # box 3 == box 0 rotated by 90 deg: IoU 1
+    assert ops.nms(boxes[:0], scores[:0], 0.5).tolist() == []
