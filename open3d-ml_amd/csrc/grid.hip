@@ -70,37 +70,74 @@ __global__ void grid_bbox_init(unsigned* bbox, unsigned* occ, int batch) {
     for (int l = 0; l < GRID_LEVELS; ++l) occ[GRID_LEVELS * s + l] = 0u;
 }
 
-__global__ void grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox) {
-    // Each block covers a contiguous packed range; threads reduce what they can in registers over a
-    // short strided loop and then issue at most 6 atomics per (thread, segment change).
-    int64_t i = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x;
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox) {
+    // A block covers 1024 consecutive packed points.  When they all belong to one batch item (the
+    // common case) the block reduces in registers/LDS and issues 6 atomics in total; a block that
+    // straddles an item boundary falls back to per-thread atomics.
+    __shared__ float red[4][6];
+    const int64_t first = (int64_t)blockIdx.x * 1024;
+    const int64_t last = first + 1023 < n_total ? first + 1023 : n_total - 1;
+    int s0, s1; int64_t l0, l1;
+    seg_locate(S, first, s0, l0);
+    seg_locate(S, last, s1, l1);
+    const bool one_item = (s0 == s1);            // block-uniform
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     int cur = -1;
-    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
-    for (int it = 0; it < 4; ++it, i += blockDim.x) {
+    int64_t i = first + threadIdx.x;
+    for (int it = 0; it < 4; ++it, i += 256) {
         if (i >= n_total) break;
         int s; int64_t local;
-        seg_locate(S, i, s, local);
+        if (one_item) { s = s0; local = l0 + (i - first); } else seg_locate(S, i, s, local);
         const float* p = pts + 3 * (seg_begin_global(S, s) + local);
         float x = p[0], y = p[1], z = p[2];
-        if (s != cur) {
+        if (!one_item && s != cur) {
             if (cur >= 0)
                 for (int a = 0; a < 3; ++a) {
                     atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
                     atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
                 }
-            cur = s;
             mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
         } else {
             mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         }
+        cur = s;
     }
-    if (cur >= 0)
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
-            atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
-        }
+    if (!one_item) {
+        if (cur >= 0)
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
+                atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
+            }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+        if (lane == 0) { red[wv][a] = lo; red[wv][3 + a] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int a = threadIdx.x;
+        float v = red[0][a];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+        if (a < 3) atomicMin(&bbox[6 * s0 + a], f2ord(v));
+        else atomicMax(&bbox[6 * s0 + a], f2ord(v));
+    }
 }
 
 // ---- K2: finest probe grid per segment --------------------------------------------------------
@@ -155,28 +192,54 @@ __global__ void grid_setup0(Segs S, const unsigned* bbox, GridSeg* segs, int bat
 }
 
 // ---- K3: occupancy probe at GRID_LEVELS power-of-two resolutions ------------------------------
-__global__ void grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total,
-                               const GridSeg* __restrict__ segs, unsigned* bitmap, int64_t bitmap_words,
-                               unsigned* occ) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    int s; int64_t local;
-    seg_locate(S, i, s, local);
-    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+__global__ void __launch_bounds__(256)
+grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total, const GridSeg* __restrict__ segs,
+               unsigned* bitmap, int64_t bitmap_words, unsigned* occ) {
+    // one bit per (level, cell); the number of bits a block newly sets is summed per block (ballot
+    // + popcount) so the per-item counters see one atomic per block and level, not one per point.
+    __shared__ unsigned cnt[GRID_LEVELS];
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t last = first + blockDim.x - 1 < n_total ? first + blockDim.x - 1 : n_total - 1;
+    int s0, s1; int64_t l0, l1;
+    seg_locate(S, first, s0, l0);
+    seg_locate(S, last, s1, l1);
+    const bool one_item = (s0 == s1);            // block-uniform
+    if (threadIdx.x < GRID_LEVELS) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t i = first + threadIdx.x;
+    const bool valid = i < n_total;
+    int s = s0; int64_t local = l0 + threadIdx.x;
+    if (valid && !one_item) seg_locate(S, i, s, local);
+    int cx = 0, cy = 0, cz = 0;
     const GridSeg* g = &segs[s];
-    float inv = 1.0f / g->c0;
-    int cx = cell_coord(p[0], g->lo[0], inv, g->dims0[0]);
-    int cy = cell_coord(p[1], g->lo[1], inv, g->dims0[1]);
-    int cz = cell_coord(p[2], g->lo[2], inv, g->dims0[2]);
-    int64_t bit_base = (int64_t)g->cell_base + 32 * (int64_t)s;  // word-aligned per segment
-    for (int l = 0; l < GRID_LEVELS; ++l) {
-        int dx = ((g->dims0[0] - 1) >> l) + 1, dy = ((g->dims0[1] - 1) >> l) + 1;
-        int64_t id = (cx >> l) + (int64_t)dx * ((cy >> l) + (int64_t)dy * (cz >> l));
-        int64_t bit = bit_base + id;
-        unsigned m = 1u << (unsigned)(bit & 31);
-        unsigned old = atomicOr(&bitmap[(int64_t)l * bitmap_words + (bit >> 5)], m);
-        if (!(old & m)) atomicAdd(&occ[GRID_LEVELS * s + l], 1u);
+    if (valid) {
+        const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+        float inv = 1.0f / g->c0;
+        cx = cell_coord(p[0], g->lo[0], inv, g->dims0[0]);
+        cy = cell_coord(p[1], g->lo[1], inv, g->dims0[1]);
+        cz = cell_coord(p[2], g->lo[2], inv, g->dims0[2]);
     }
+    const int64_t bit_base = (int64_t)g->cell_base + 32 * (int64_t)s;  // word-aligned per segment
+    for (int l = 0; l < GRID_LEVELS; ++l) {
+        bool fresh = false;
+        if (valid) {
+            int dx = ((g->dims0[0] - 1) >> l) + 1, dy = ((g->dims0[1] - 1) >> l) + 1;
+            int64_t id = (cx >> l) + (int64_t)dx * ((cy >> l) + (int64_t)dy * (cz >> l));
+            int64_t bit = bit_base + id;
+            unsigned m = 1u << (unsigned)(bit & 31);
+            unsigned old = atomicOr(&bitmap[(int64_t)l * bitmap_words + (bit >> 5)], m);
+            fresh = !(old & m);
+        }
+        if (one_item) {
+            unsigned long long b = __ballot(fresh);
+            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt[l], (unsigned)__popcll(b));
+        } else if (fresh) {
+            atomicAdd(&occ[GRID_LEVELS * s + l], 1u);
+        }
+    }
+    __syncthreads();
+    if (one_item && threadIdx.x < GRID_LEVELS && cnt[threadIdx.x])
+        atomicAdd(&occ[GRID_LEVELS * s0 + threadIdx.x], cnt[threadIdx.x]);
 }
 
 // ---- K4: final cell size from the occupancy curve ----------------------------------------------
