@@ -101,8 +101,8 @@ int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64_t n0, int 
 /*     +0 mlp1_WT[d_in][h] +1 mlp1_b  +2 lse1_WT[10][h] +3 lse1_b              */
 /*     +4 pool1_score_WT[d][d] +5 pool1_score_b +6 pool1_mlp_WT[d][h] +7 b     */
 /*     +8 lse2_WT[h][h] +9 lse2_b +10 pool2_score_WT[d][d] +11 pool2_score_b   */
-/*     +12 pool2_mlp_WT[d][d] +13 b +14 mlp2_WT[d][2d] +15 b                   */
-/*     +16 shortcut_WT[d_in][2d] +17 b                                         */
+/*     +12 pool2_mlp_WT[d][d] +13 b +14 mlp2_WT[d][2d] +15 shortcut_WT[d_in][2d]*/
+/*     (adjacent: one stacked [d + d_in][2d] matrix) +16 mlp2_b +17 shortcut_b */
 /*   then mlp_WT[D][D], mlp_b (D = 2*dim_output[L-1]);                         */
 /*   then per decoder stage i: dec_WT[C_in_i][C_out_i], dec_b;                 */
 /*   then fc1_0_WT[C][64], b, fc1_1_WT[64][32], b, fc1_3_WT[32][classes], b.   */

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ml3d_hip.h"
 
@@ -40,6 +41,7 @@ struct LinArgs {
     int64_t a1_rows_per_item;            // n of the gathered level
     const float* wt;                     // [c0 + c1][cout]
     const float* bias;                   // [cout]
+    const float* bias2;                  // optional second bias added to `bias` (mlp2 + shortcut fusion)
     float* out;                          // [m][cout]
     int64_t m_total;
     int cout;
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(256) linear_act(LinArgs A) {
 #pragma unroll
     for (int r = 0; r < LIN_RM; ++r) {
         int64_t m = m0 + r < A.m_total ? m0 + r : A.m_total - 1;
-        acc[r] = A.bias[o];
+        acc[r] = A.bias2 ? A.bias[o] + A.bias2[o] : A.bias[o];
         r0[r] = A.a0 + m * A.c0;
         r1[r] = nullptr;
         if (A.a1) {
@@ -306,6 +308,359 @@ __global__ void __launch_bounds__(LFA_THREADS) lfa_stage(LfaArgs A) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MFMA path (D in {32, 64, 128, 256}): the per-neighbour GEMMs on v_mfma_f32_32x32x2_f32
+// (exact f32: bitwise an fmaf chain, 157 TFLOP/s peak — MI355X_MICROARCH.md).
+//
+// Rows of the GEMM are (point, neighbour) pairs: a 32-row MFMA tile = 2 points x 16 neighbours.
+//   stage 2 only:  R2[rows, H] = lrelu(R1[rows, H] . lse2_WT + b)          (LocalSpatialEncoding #2)
+//   both stages :  S[rows, D]  = X[rows, D] . score_WT + b                  (AttentivePooling Linear)
+// X = [gathered neighbour features | encoded relative positions] lives in LDS as the A operand
+// (row pitch D+4 floats: conflict-free ds_read_b128, four K-steps per read).  Each wave owns one
+// 32-column tile of the weight matrix IN REGISTERS for the whole kernel (D/2 VGPRs) and walks the
+// row tiles.  In the 32x32 C layout a lane holds one column and 8 of the 16 neighbours of each of
+// the two points, so the softmax over K is 8 in-lane values + ONE lane^32 exchange; the weighted
+// sum reads X back from LDS and only agg[point, D] leaves the CU.
+// K is split between the wave halves: lanes 0-31 feed k in [0, K/2), lanes 32-63 k in [K/2, K).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int D>
+struct MfmaCfg {
+    static constexpr int H = D / 2;
+    static constexpr int NT = D / 32;                        // score column tiles
+    static constexpr int NT2 = (H + 31) / 32;                // lse2 column tiles
+    static constexpr int WAVES = NT > 4 ? NT : 4;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int TP = D <= 64 ? 8 : (D == 128 ? 4 : 2);   // points per tile
+    static constexpr int ROWS = TP * RK;
+    static constexpr int RT = ROWS / 32;                     // 32-row MFMA tiles
+    static constexpr int RG = WAVES / NT;                    // waves sharing a column tile take different row tiles
+    static constexpr int RG2 = WAVES / NT2;
+    static constexpr int XP = D + 4;                         // LDS row pitch of X
+    static constexpr int RP = H + 4;                         // LDS row pitch of R1
+};
+
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// acc += A[rows of tile, K] . B[K, 32 cols]; A from LDS (pitch AP), B from registers
+template <int KD, int AP>
+__device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/2] */, const float (&b)[KD / 2],
+                                            f32x16 acc) {
+#pragma unroll
+    for (int s4 = 0; s4 < KD / 8; ++s4) {
+        float4 a = *reinterpret_cast<const float4*>(a_row + 4 * s4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * s4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * s4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * s4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * s4 + 3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <int D, int STAGE>
+__global__ void __launch_bounds__(MfmaCfg<D>::THREADS) lfa_attn_mfma(LfaArgs A) {
+    using C = MfmaCfg<D>;
+    constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* X = smem;                                              // [ROWS][XP]
+    float* R1 = X + ROWS * XP;                                    // [ROWS][RP]   (stage 2)
+    float* REL = R1 + (STAGE == 2 ? ROWS * RP : 0);               // [ROWS][12]
+    int* NROW = reinterpret_cast<int*>(REL + ROWS * 12);          // [ROWS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+
+    // ---- weights that stay in registers for the whole kernel ---------------------------------
+    const int ct = wave % C::NT, rg = wave / C::NT;
+    float bs[D / 2];
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) bs[s] = A.score_wt[(hi * (D / 2) + s) * D + ct * 32 + col];
+    const float sbias = A.score_b[ct * 32 + col];
+    const int ct2 = wave % C::NT2, rg2 = wave / C::NT2;
+    const int col2 = ct2 * 32 + col;
+    float b2[STAGE == 2 ? H / 2 : 1];
+    float l2bias = 0.f;
+    if constexpr (STAGE == 2) {
+#pragma unroll
+        for (int s = 0; s < H / 2; ++s) b2[s] = col2 < H ? A.lse2_wt[(hi * (H / 2) + s) * H + col2] : 0.f;
+        l2bias = col2 < H ? A.lse2_b[col2] : 0.f;
+    }
+    const int cc = tid % H;                                       // r1 channel of this thread
+    float w1[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w1[j] = A.lse1_wt[j * H + cc];
+    const float b1 = A.lse1_b[cc];
+
+    const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t m_base = tile * C::TP;
+        // ---- P1: relative-position inputs + neighbour rows -------------------------------------
+        for (int e = tid; e < ROWS; e += THREADS) {
+            int p = e / RK, k = e % RK;
+            int64_t m = m_base + p;
+            float* r = REL + e * 12;
+            if (m < A.m_total) {
+                int64_t b = m / A.n, nl = m - b * A.n;
+                int nb = A.nidx[m * RK + k];
+                const float* q = A.xyz + 3 * (b * A.n0 + nl);
+                const float* sp = A.xyz + 3 * (b * A.n0 + nb);
+                float qx = q[0], qy = q[1], qz = q[2], sx = sp[0], sy = sp[1], sz = sp[2];
+                float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
+                NROW[e] = (int)(b * A.n + nb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) r[j] = 0.f;
+                NROW[e] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- P2a: gather neighbour feature rows (16-byte bursts) -> X[:, 0:H] ---------------------
+        for (int e = tid; e < ROWS * (H / 4); e += THREADS) {
+            int row = e / (H / 4), q = e % (H / 4);
+            float4 v = *reinterpret_cast<const float4*>(A.gfeat + (int64_t)NROW[row] * H + 4 * q);
+            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = v;
+        }
+        // ---- P2b: r1 = lrelu(lse1(rel))  -> X[:, H:] (stage 1) or R1 (stage 2) ---------------------
+        for (int row = tid / H; row < ROWS; row += THREADS / H) {
+            const float* r = REL + row * 12;
+            float v = b1;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v = fmaf(r[j], w1[j], v);
+            v = lrelu(v, 0.2f);
+            if (STAGE == 1) X[row * XP + H + cc] = v; else R1[row * RP + cc] = v;
+        }
+        __syncthreads();
+        if constexpr (STAGE == 2) {
+            // ---- P2c: r2 = lrelu(lse2(r1)) on MFMA -> X[:, H:] -------------------------------------
+            for (int rt = rg2; rt < C::RT; rt += C::RG2) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = l2bias;
+                acc = mfma_rows<H, RP>(R1 + (rt * 32 + col) * RP + hi * (H / 2), b2, acc);
+                if (col2 < H) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu(acc[r], 0.2f);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- P3: scores on MFMA, softmax over the 16 neighbours, weighted sum ----------------------
+        for (int rt = rg; rt < C::RT; rt += C::RG) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = sbias;
+            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
+            const float* xc = X + (rt * 32) * XP + ct * 32 + col;
+            float agg_mine = 0.f;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                float mx = acc[8 * pt];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[8 * pt + r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f, ag = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float e = expf(acc[8 * pt + r] - mx);
+                    sum += e;
+                    ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
+                }
+                sum += __shfl_xor(sum, 32);
+                ag += __shfl_xor(ag, 32);
+                if (pt == hi) agg_mine = ag / sum;
+            }
+            int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
+            if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
+        }
+        __syncthreads();
+    }
+}
+
+template <int D, int STAGE>
+static size_t mfma_smem_bytes() {
+    using C = MfmaCfg<D>;
+    return ((size_t)C::ROWS * C::XP + (STAGE == 2 ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
+           (size_t)C::ROWS * 4;
+}
+
+// launches the attention part of one stage; `a.out` receives agg [m, D]
+template <int D, int STAGE>
+static int launch_attn_mfma(const LfaArgs& a, hipStream_t st) {
+    using C = MfmaCfg<D>;
+    int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
+    unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);     // persistent-ish: weights load once per block
+    size_t sm = mfma_smem_bytes<D, STAGE>();
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// mlp_chain_mfma — up to 4 per-point Linear(+folded BN)+activation layers back to back on
+// v_mfma_f32_32x32x2_f32.  A workgroup owns 64 rows; the first layer streams its input rows from
+// HBM in K-chunks of 32 (optionally [a0 | a1[gather]] = nearest_interpolation + cat of the decoder,
+// randlanet.py:288-291), intermediate activations stay in LDS, only the last layer's output is
+// written.  One optional extra input `cat` is appended to the input of layer `cat_layer`
+// (mlp2(p2) + shortcut(feat) = one Linear over [p2 | feat], randlanet.py:692).
+// HBM traffic = first-layer inputs + last-layer outputs (+ weights from L2).
+// ------------------------------------------------------------------------------------------------
+constexpr int CH_MAX = 4;
+constexpr int CH_BM = 64;      // rows per workgroup
+constexpr int CH_KC = 32;      // K chunk
+constexpr int CH_AP = CH_KC + 4;
+constexpr int CH_BN = 64;      // columns per pass (2 MFMA column tiles)
+
+struct ChainLayer {
+    const float* wt;     // [cin][cout]
+    const float* bias;
+    const float* bias2;  // optional
+    int cin, cout;
+    int act;             // 0 none, 1 leaky relu
+    float slope;
+};
+
+struct ChainArgs {
+    const float* a0; int c0;
+    const float* a1; int c1;
+    const int32_t* gather;
+    int64_t rows_per_item, a1_rows_per_item;
+    const float* cat; int cat_c; int cat_layer;
+    int n_layers;
+    ChainLayer L[CH_MAX];
+    float* out;
+    int64_t m_total;
+    int act_pitch;       // floats, LDS pitch of the intermediate activations (max width + 4)
+    int n_act_buf;       // 0, 1 or 2
+};
+
+__global__ void __launch_bounds__(256) mlp_chain_mfma(ChainArgs A) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* As = smem;                               // [64][CH_AP]
+    float* Bs = As + CH_BM * CH_AP;                 // [CH_KC][CH_BN]
+    float* ACT0 = Bs + CH_KC * CH_BN;               // [64][act_pitch]
+    float* ACT1 = ACT0 + (A.n_act_buf > 1 ? CH_BM * A.act_pitch : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    const int rt = wave & 1, ctw = wave >> 1;
+    const int64_t m_base = (int64_t)blockIdx.x * CH_BM;
+
+    for (int li = 0; li < A.n_layers; ++li) {
+        const ChainLayer Ly = A.L[li];
+        const float* act_in = (li & 1) ? ACT0 : ACT1;       // layer li reads what layer li-1 wrote
+        float* act_out = (li & 1) ? ACT1 : ACT0;
+        if (A.n_act_buf < 2) { act_in = ACT0; act_out = ACT0; }
+        const bool last = (li == A.n_layers - 1);
+        const int prev_c = li == 0 ? 0 : A.L[li - 1].cout;
+        const int n_pass = (Ly.cout + CH_BN - 1) / CH_BN;
+        // single-layer launches spread the column passes over blockIdx.y
+        const int p_begin = A.n_layers == 1 ? blockIdx.y : 0;
+        const int p_step = A.n_layers == 1 ? gridDim.y : 1;
+        for (int cp = p_begin; cp < n_pass; cp += p_step) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int k0 = 0; k0 < Ly.cin; k0 += CH_KC) {
+                // ---- stage A chunk [64][32] ---------------------------------------------------
+                for (int e = tid; e < CH_BM * (CH_KC / 4); e += 256) {
+                    int row = e / (CH_KC / 4), q = e % (CH_KC / 4);
+                    int k = k0 + 4 * q;
+                    int64_t m = m_base + row;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < A.m_total && k < Ly.cin) {
+                        if (li == 0) {
+                            if (k < A.c0) {
+                                v = *reinterpret_cast<const float4*>(A.a0 + m * A.c0 + k);
+                            } else {
+                                int64_t grow = m;
+                                if (A.gather) grow = (m / A.rows_per_item) * A.a1_rows_per_item + A.gather[m];
+                                v = *reinterpret_cast<const float4*>(A.a1 + grow * A.c1 + (k - A.c0));
+                            }
+                        } else if (k < prev_c) {
+                            v = *reinterpret_cast<const float4*>(act_in + row * A.act_pitch + k);
+                        } else {
+                            v = *reinterpret_cast<const float4*>(A.cat + m * A.cat_c + (k - prev_c));
+                        }
+                    }
+                    *reinterpret_cast<float4*>(As + row * CH_AP + 4 * q) = v;
+                }
+                // ---- stage B chunk [32][64] ---------------------------------------------------
+                for (int e = tid; e < CH_KC * CH_BN; e += 256) {
+                    int kk = e / CH_BN, c = e % CH_BN;
+                    int k = k0 + kk, col = cp * CH_BN + c;
+                    Bs[e] = (k < Ly.cin && col < Ly.cout) ? Ly.wt[(int64_t)k * Ly.cout + col] : 0.f;
+                }
+                __syncthreads();
+                const float* ar = As + (rt * 32 + cl) * CH_AP + hi * (CH_KC / 2);
+                const float* br = Bs + (hi * (CH_KC / 2)) * CH_BN + ctw * 32 + cl;
+#pragma unroll
+                for (int s4 = 0; s4 < CH_KC / 8; ++s4) {
+                    float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, br[(4 * s4 + 0) * CH_BN], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, br[(4 * s4 + 1) * CH_BN], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, br[(4 * s4 + 2) * CH_BN], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, br[(4 * s4 + 3) * CH_BN], acc, 0, 0, 0);
+                }
+                __syncthreads();
+            }
+            // ---- epilogue ---------------------------------------------------------------------
+            const int col = cp * CH_BN + ctw * 32 + cl;
+            if (col < Ly.cout) {
+                float b = Ly.bias[col];
+                if (Ly.bias2) b += Ly.bias2[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rt * 32 + mfma_row(r, hi);
+                    float v = acc[r] + b;
+                    if (Ly.act) v = lrelu(v, Ly.slope);
+                    if (last) {
+                        int64_t m = m_base + row;
+                        if (m < A.m_total) A.out[m * Ly.cout + col] = v;
+                    } else {
+                        act_out[row * A.act_pitch + col] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static bool chain_supported(const ChainArgs& a) {
+    if (a.n_layers < 1 || a.n_layers > CH_MAX) return false;
+    if ((a.c0 & 3) || (a.a1 && (a.c1 & 3)) || (a.cat && (a.cat_c & 3))) return false;
+    for (int i = 0; i + 1 < a.n_layers; ++i)
+        if (a.L[i].cout & 3) return false;
+    return true;
+}
+
+static int launch_chain(ChainArgs a, hipStream_t st) {
+    if (a.m_total <= 0) return 0;
+    int maxw = 0;
+    for (int i = 0; i + 1 < a.n_layers; ++i) maxw = a.L[i].cout > maxw ? a.L[i].cout : maxw;
+    a.act_pitch = maxw + 4;
+    a.n_act_buf = a.n_layers == 1 ? 0 : (a.n_layers == 2 ? 1 : 2);
+    size_t sm = ((size_t)CH_BM * CH_AP + (size_t)CH_KC * CH_BN + (size_t)a.n_act_buf * CH_BM * a.act_pitch) * 4;
+    if (sm > 160 * 1024) return ML3D_E_UNSUPPORTED;
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)mlp_chain_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    unsigned gx = (unsigned)((a.m_total + CH_BM - 1) / CH_BM);
+    unsigned gy = a.n_layers == 1 ? (unsigned)((a.L[0].cout + CH_BN - 1) / CH_BN) : 1u;
+    hipLaunchKernelGGL(mlp_chain_mfma, dim3(gx, gy), dim3(256), sm, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+// one Linear described by LinArgs: MFMA chain kernel when the shapes allow, VALU kernel otherwise
+static int launch_linear_auto(const LinArgs& a, hipStream_t st);
+
 template <int D, int STAGE>
 static size_t lfa_smem_bytes(int d_in) {
     using C = LfaCfg<D>;
@@ -370,6 +725,21 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
+    const char* e = getenv("ML3D_RANDLA_LINEAR");                  // A/B knob: "valu" forces the scalar kernel
+    if (!(e && e[0] == 'v') && a.c0 + a.c1 >= 8) {
+        ChainArgs c = {};
+        c.a0 = a.a0; c.c0 = a.c0; c.a1 = a.a1; c.c1 = a.a1 ? a.c1 : 0; c.gather = a.gather;
+        c.rows_per_item = a.rows_per_item; c.a1_rows_per_item = a.a1_rows_per_item;
+        c.n_layers = 1;
+        c.L[0].wt = a.wt; c.L[0].bias = a.bias; c.L[0].bias2 = a.bias2; c.L[0].cin = a.c0 + c.c1; c.L[0].cout = a.cout;
+        c.L[0].act = a.act; c.L[0].slope = a.slope;
+        c.out = a.out; c.m_total = a.m_total;
+        if (chain_supported(c)) return launch_chain(c, st);
+    }
+    return launch_linear(a, st);
+}
+
 // ---- parameter layout ---------------------------------------------------------------------------
 struct Layout {
     int n_slots;
@@ -410,8 +780,8 @@ static void make_layout(const ml3d_randla_desc* d, Layout* L) {
         push(h * h); push(h);
         push(dd * dd); push(dd);
         push(dd * dd); push(dd);
-        push(dd * 2 * dd); push(2 * dd);
-        push((int64_t)d_in * 2 * dd); push(2 * dd);
+        push(dd * 2 * dd); push((int64_t)d_in * 2 * dd);   // mlp2_WT | shortcut_WT: one stacked [d + d_in][2d] matrix
+        push(2 * dd); push(2 * dd);
         d_in = (int)(2 * dd);
     }
     int64_t Dm = d_in;
@@ -440,7 +810,7 @@ static size_t fwd_ws_floats(const ml3d_randla_desc* d) {
     f += al(B * n[0] * d->dim_features);
     for (int l = 0; l < d->num_layers; ++l) {
         int64_t dd = d->dim_output[l], h = dd / 2;
-        f += 2 * al(B * n[l] * h) + al(B * n[l] * 2 * dd) + al(B * n[l + 1] * 2 * dd);
+        f += 2 * al(B * n[l] * h) + al(B * n[l] * 2 * dd) + al(B * n[l + 1] * 2 * dd) + 2 * al(B * n[l] * dd);
     }
     int64_t Dm = 2 * d->dim_output[d->num_layers - 1];
     f += al(B * n[d->num_layers] * Dm);
@@ -487,6 +857,8 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
     if (workspace_bytes < ml3d_randla_forward_workspace_bytes(d)) return ML3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Tracer T = {trace, st};
+    const char* path_env = getenv("ML3D_RANDLA_PATH");          // A/B knob: "valu" forces the v1 kernels
+    const bool force_valu = path_env && path_env[0] == 'v';
     const int Lr = d->num_layers;
     const int64_t B = d->batch;
     int64_t n[ML3D_RANDLA_MAX_LAYERS + 1];
@@ -506,7 +878,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         LinArgs a = {};
         a.a0 = features; a.c0 = d->in_channels; a.wt = P(0); a.bias = P(1); a.out = feat;
         a.m_total = B * n[0]; a.cout = d->dim_features; a.act = 1; a.slope = 0.2f;
-        T.begin(1000); int rc = launch_linear(a, st); T.end(1000); if (rc) return rc;
+        T.begin(1000); int rc = launch_linear_auto(a, st); T.end(1000); if (rc) return rc;
     }
     int d_in = d->dim_features;
     float* enc_keep[ML3D_RANDLA_MAX_LAYERS + 1];   // encoder_feat_list (randlanet.py:274-283)
@@ -521,7 +893,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             LinArgs a = {};
             a.a0 = feat; a.c0 = d_in; a.wt = P(sb + 0); a.bias = P(sb + 1); a.out = f1;
             a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
-            T.begin(8 * l); int rc = launch_linear(a, st); T.end(8 * l); if (rc) return rc;
+            T.begin(8 * l); int rc = launch_linear_auto(a, st); T.end(8 * l); if (rc) return rc;
         }
         LfaArgs s1 = {};
         s1.xyz = points; s1.nidx = neighbor_idx[l]; s1.n = n[l]; s1.n0 = n[0]; s1.m_total = M;
@@ -531,18 +903,63 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         LfaArgs s2 = s1;
         s2.gfeat = p1; s2.lse2_wt = P(sb + 8); s2.lse2_b = P(sb + 9);
         s2.score_wt = P(sb + 10); s2.score_b = P(sb + 11); s2.pool_wt = P(sb + 12); s2.pool_b = P(sb + 13);
-        s2.mlp2_wt = P(sb + 14); s2.mlp2_b = P(sb + 15); s2.short_wt = P(sb + 16); s2.short_b = P(sb + 17);
+        s2.mlp2_wt = P(sb + 14); s2.mlp2_b = P(sb + 16); s2.short_wt = P(sb + 15); s2.short_b = P(sb + 17);
         s2.feat_in = feat; s2.out = enc;
-        int rc;
-        switch (dd) {
-            case 8: rc = launch_lfa<8>(s1, s2, st, trace, 8 * l + 1); break;
-            case 16: rc = launch_lfa<16>(s1, s2, st, trace, 8 * l + 1); break;
-            case 32: rc = launch_lfa<32>(s1, s2, st, trace, 8 * l + 1); break;
-            case 64: rc = launch_lfa<64>(s1, s2, st, trace, 8 * l + 1); break;
-            case 128: rc = launch_lfa<128>(s1, s2, st, trace, 8 * l + 1); break;
-            case 256: rc = launch_lfa<256>(s1, s2, st, trace, 8 * l + 1); break;
-            case 512: rc = launch_lfa<512>(s1, s2, st, trace, 8 * l + 1); break;
-            default: return ML3D_E_UNSUPPORTED;
+        int rc = 0;
+        const bool mfma_ok = (dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu;
+        if (mfma_ok) {
+            float* agg = take(M * dd);
+            float* p2 = take(M * dd);
+            LfaArgs q1 = s1; q1.out = agg;
+            T.begin(8 * l + 1);
+            switch (dd) {
+                case 32: rc = launch_attn_mfma<32, 1>(q1, st); break;
+                case 64: rc = launch_attn_mfma<64, 1>(q1, st); break;
+                case 128: rc = launch_attn_mfma<128, 1>(q1, st); break;
+                default: rc = launch_attn_mfma<256, 1>(q1, st); break;
+            }
+            T.end(8 * l + 1);
+            if (rc) return rc;
+            {   // pool1.mlp: SharedMLP(d, d/2) lrelu 0.2            (randlanet.py:639)
+                LinArgs a = {};
+                a.a0 = agg; a.c0 = dd; a.wt = P(sb + 6); a.bias = P(sb + 7); a.out = p1;
+                a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
+                T.begin(8 * l + 4); rc = launch_linear_auto(a, st); T.end(8 * l + 4); if (rc) return rc;
+            }
+            LfaArgs q2 = s2; q2.out = agg;
+            T.begin(8 * l + 2);
+            switch (dd) {
+                case 32: rc = launch_attn_mfma<32, 2>(q2, st); break;
+                case 64: rc = launch_attn_mfma<64, 2>(q2, st); break;
+                case 128: rc = launch_attn_mfma<128, 2>(q2, st); break;
+                default: rc = launch_attn_mfma<256, 2>(q2, st); break;
+            }
+            T.end(8 * l + 2);
+            if (rc) return rc;
+            {   // pool2.mlp: SharedMLP(d, d) lrelu 0.2
+                LinArgs a = {};
+                a.a0 = agg; a.c0 = dd; a.wt = P(sb + 12); a.bias = P(sb + 13); a.out = p2;
+                a.m_total = M; a.cout = dd; a.act = 1; a.slope = 0.2f;
+                T.begin(8 * l + 5); rc = launch_linear_auto(a, st); T.end(8 * l + 5); if (rc) return rc;
+            }
+            {   // lrelu_0.01(mlp2(p2) + shortcut(feat)) as ONE linear over [p2 | feat]   (randlanet.py:692)
+                LinArgs a = {};
+                a.a0 = p2; a.c0 = dd; a.a1 = feat; a.c1 = d_in; a.wt = P(sb + 14);
+                a.bias = P(sb + 16); a.bias2 = P(sb + 17); a.out = enc;
+                a.m_total = M; a.cout = 2 * dd; a.act = 1; a.slope = 0.01f;
+                T.begin(8 * l + 6); rc = launch_linear_auto(a, st); T.end(8 * l + 6); if (rc) return rc;
+            }
+        } else {
+            switch (dd) {
+                case 8: rc = launch_lfa<8>(s1, s2, st, trace, 8 * l + 1); break;
+                case 16: rc = launch_lfa<16>(s1, s2, st, trace, 8 * l + 1); break;
+                case 32: rc = launch_lfa<32>(s1, s2, st, trace, 8 * l + 1); break;
+                case 64: rc = launch_lfa<64>(s1, s2, st, trace, 8 * l + 1); break;
+                case 128: rc = launch_lfa<128>(s1, s2, st, trace, 8 * l + 1); break;
+                case 256: rc = launch_lfa<256>(s1, s2, st, trace, 8 * l + 1); break;
+                case 512: rc = launch_lfa<512>(s1, s2, st, trace, 8 * l + 1); break;
+                default: return ML3D_E_UNSUPPORTED;
+            }
         }
         if (rc) return rc;
         {   // random_sample onto the kept prefix      (randlanet.py:278)
@@ -565,7 +982,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         LinArgs a = {};
         a.a0 = feat; a.c0 = Dm; a.wt = P(slot); a.bias = P(slot + 1); a.out = cur;
         a.m_total = B * n[Lr]; a.cout = Dm; a.act = 1; a.slope = 0.2f;
-        T.begin(1001); int rc = launch_linear(a, st); T.end(1001); if (rc) return rc;
+        T.begin(1001); int rc = launch_linear_auto(a, st); T.end(1001); if (rc) return rc;
         slot += 2;
     }
     int ed[ML3D_RANDLA_MAX_LAYERS + 1];
@@ -582,7 +999,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         a.rows_per_item = n[lev]; a.a1_rows_per_item = n[lev + 1];
         a.wt = P(slot); a.bias = P(slot + 1); a.out = outp;
         a.m_total = B * n[lev]; a.cout = skip_c; a.act = 1; a.slope = 0.2f;
-        T.begin(1100 + i); int rc = launch_linear(a, st); T.end(1100 + i); if (rc) return rc;
+        T.begin(1100 + i); int rc = launch_linear_auto(a, st); T.end(1100 + i); if (rc) return rc;
         slot += 2;
         cur = outp;
         cprev = skip_c;
@@ -593,12 +1010,12 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         LinArgs a = {};
         a.a0 = cur; a.c0 = cprev; a.wt = P(slot); a.bias = P(slot + 1); a.out = t0;
         a.m_total = B * n[0]; a.cout = 64; a.act = 1; a.slope = 0.2f;
-        T.begin(1200); int rc = launch_linear(a, st); T.end(1200); if (rc) return rc;
+        T.begin(1200); int rc = launch_linear_auto(a, st); T.end(1200); if (rc) return rc;
         a.a0 = t0; a.c0 = 64; a.wt = P(slot + 2); a.bias = P(slot + 3); a.out = t1; a.cout = 32;
-        T.begin(1201); rc = launch_linear(a, st); T.end(1201); if (rc) return rc;
+        T.begin(1201); rc = launch_linear_auto(a, st); T.end(1201); if (rc) return rc;
         a.a0 = t1; a.c0 = 32; a.wt = P(slot + 4); a.bias = P(slot + 5); a.out = out_scores;
         a.cout = d->num_classes; a.act = 0;
-        T.begin(1202); rc = launch_linear(a, st); T.end(1202); if (rc) return rc;
+        T.begin(1202); rc = launch_linear_auto(a, st); T.end(1202); if (rc) return rc;
     }
     return 0;
 }

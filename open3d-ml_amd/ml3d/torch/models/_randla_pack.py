@@ -46,8 +46,9 @@ def slot_tensors(sd, cfg):
         out += list(_conv(sd, p + "lse2.mlp"))
         out += list(_fold(_np(sd[p + "pool2.score_fn.0.weight"]), _np(sd[p + "pool2.score_fn.0.bias"]), sd, None))
         out += list(_conv(sd, p + "pool2.mlp"))
-        out += list(_conv(sd, p + "mlp2"))
-        out += list(_conv(sd, p + "shortcut"))
+        m2w, m2b = _conv(sd, p + "mlp2")
+        scw, scb = _conv(sd, p + "shortcut")
+        out += [m2w, scw, m2b, scb]        # weights adjacent: one stacked [d + d_in][2d] matrix
     out += list(_conv(sd, "mlp"))
     for i in range(cfg["num_layers"]):
         out += list(_conv(sd, "decoder.%d" % i, transpose=True))
