@@ -37,6 +37,9 @@ struct GridSeg {
     int sorted_base;   // first slot of this segment in the sorted array (== packed begin)
     float c0;          // finest probe cell size
     int dims0[3];
+    float ext[3];      // bbox extent
+    float dim_est;     // local dimension of the cloud estimated by the occupancy probe (1..3)
+    int probe_stride;  // the probe looked at every probe_stride-th point
 };
 
 // Device-side view of a built grid.
@@ -67,6 +70,10 @@ size_t grid_ws_bytes(int64_t n_total, int64_t batch);
 bool grid_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, GridWs* out);
 // enqueue the build; `points` row = 3 floats.  target_occ <= 0 -> default.
 int grid_build(const float* points, Segs segs, const GridWs& ws, float target_occ, hipStream_t stream);
+// Build the grid of a SUBSET of the points of `parent` (same batch items, e.g. the RandLA prefix
+// sub-cloud): reuses the parent's bounding box and dimension estimate, cell size scaled for the
+// thinner sampling — skips the bbox and occupancy passes.
+int grid_build_derived(const float* points, Segs segs, const GridWs& ws, const GridWs& parent, hipStream_t stream);
 
 inline GridView grid_view(const GridWs& ws) {
     GridView v;

@@ -187,7 +187,9 @@ __global__ void grid_setup0(Segs S, const unsigned* bbox, GridSeg* segs, int bat
     g.c0 = c;
     g.c = c;
     g.inv_c = 1.0f / c;
-    for (int a = 0; a < 3; ++a) { g.dims0[a] = d[a]; g.dims[a] = d[a]; }
+    for (int a = 0; a < 3; ++a) { g.dims0[a] = d[a]; g.dims[a] = d[a]; g.ext[a] = ext[a]; }
+    g.dim_est = 2.5f;
+    g.probe_stride = n >= 8192 ? 4 : 1;   // the probe is a statistic: a quarter of the points is plenty
     segs[s] = g;
 }
 
@@ -207,11 +209,12 @@ grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total, const Gri
     if (threadIdx.x < GRID_LEVELS) cnt[threadIdx.x] = 0u;
     __syncthreads();
     const int64_t i = first + threadIdx.x;
-    const bool valid = i < n_total;
+    bool valid = i < n_total;
     int s = s0; int64_t local = l0 + threadIdx.x;
     if (valid && !one_item) seg_locate(S, i, s, local);
     int cx = 0, cy = 0, cz = 0;
     const GridSeg* g = &segs[s];
+    valid = valid && (local % g->probe_stride == 0);
     if (valid) {
         const float* p = pts + 3 * (seg_begin_global(S, s) + local);
         float inv = 1.0f / g->c0;
@@ -243,50 +246,87 @@ grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total, const Gri
 }
 
 // ---- K4: final cell size from the occupancy curve ----------------------------------------------
-__global__ void grid_setup1(const unsigned* occ, const unsigned* bbox, GridSeg* segs, int batch,
-                            float target) {
+// Model: points fall into the occupied cells of a level like a Poisson process of intensity lam per
+// cell, so the mean occupancy of NON-EMPTY cells is m(lam) = lam / (1 - exp(-lam)).  The probe
+// measured m at 5 resolutions on every probe_stride-th point; invert to lam per level, read the
+// local dimension D off the growth of lam between levels, and pick the cell size whose full-data
+// intensity gives the requested mean occupancy.
+__device__ __forceinline__ float occ_of_lam(float lam) { return lam / (1.0f - expf(-lam)); }
+__device__ __forceinline__ float lam_of_occ(float m) {
+    if (m <= 1.0005f) return 1.0e-3f;
+    float lo = 1.0e-3f, hi = 64.0f;
+    if (m >= hi) return m;
+    for (int it = 0; it < 40; ++it) {
+        float mid = 0.5f * (lo + hi);
+        if (occ_of_lam(mid) < m) lo = mid; else hi = mid;
+    }
+    return 0.5f * (lo + hi);
+}
+
+__device__ __forceinline__ void finish_grid(GridSeg& g, float c, int64_t cap) {
+    float emax = fmaxf(g.ext[0], fmaxf(g.ext[1], g.ext[2]));
+    int d[3] = {1, 1, 1};
+    if (emax > 0.f) {
+        for (int it = 0; it < 200; ++it) {
+            if (dims_fit(g.ext, c, cap, d)) break;
+            c *= 1.1f;
+        }
+    } else {
+        c = 1.0f;
+    }
+    g.c = c;
+    g.inv_c = 1.0f / c;
+    for (int a = 0; a < 3; ++a) g.dims[a] = d[a];
+}
+
+__global__ void grid_setup1(const unsigned* occ, GridSeg* segs, int batch, float target) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= batch) return;
     GridSeg g = segs[s];
     int64_t n = g.n;
-    float ext[3], emax = 0.f;
-    for (int a = 0; a < 3; ++a) {
-        ext[a] = n > 0 ? ord2f(bbox[6 * s + 3 + a]) - g.lo[a] : 0.f;
-        emax = fmaxf(emax, ext[a]);
-    }
+    float emax = fmaxf(g.ext[0], fmaxf(g.ext[1], g.ext[2]));
     int64_t cap = (int64_t)GRID_CAP * n + GRID_SLACK;
     float c = g.c0;
     if (n > 0 && emax > 0.f) {
-        float m_prev = 0.f;
+        const float n_probe = (float)((n + g.probe_stride - 1) / g.probe_stride);
+        const float lam_goal = lam_of_occ(target) / (float)g.probe_stride;
+        float lam_prev = 0.f, lam_cur = 0.f;
         int lsel = -1;
-        float mcur = 0.f;
         for (int l = 0; l < GRID_LEVELS; ++l) {
             unsigned cnt = occ[GRID_LEVELS * s + l];
-            mcur = (float)n / (float)(cnt > 0u ? cnt : 1u);
-            if (mcur >= target) { lsel = l; break; }
-            m_prev = mcur;
+            lam_cur = lam_of_occ(n_probe / (float)(cnt > 0u ? cnt : 1u));
+            if (lam_cur >= lam_goal) { lsel = l; break; }
+            lam_prev = lam_cur;
         }
         if (lsel == 0) {
             c = g.c0;
         } else if (lsel > 0) {
-            float D = log2f(mcur / m_prev);
-            D = fminf(fmaxf(D, 1.0f), 3.0f);
-            c = g.c0 * (float)(1 << (lsel - 1)) * powf(target / m_prev, 1.0f / D);
+            float D = fminf(fmaxf(log2f(lam_cur / lam_prev), 1.0f), 3.0f);
+            g.dim_est = D;
+            c = g.c0 * (float)(1 << (lsel - 1)) * powf(lam_goal / lam_prev, 1.0f / D);
         } else {
             c = g.c0 * (float)(1 << (GRID_LEVELS - 1));
             if (n <= 64) c = emax * 2.0f;  // tiny item: one cell, i.e. brute force
         }
     }
-    int d[3] = {1, 1, 1};
-    if (emax > 0.f) {
-        for (int it = 0; it < 200; ++it) {
-            if (dims_fit(ext, c, cap, d)) break;
-            c *= 1.1f;
-        }
-    }
-    g.c = c;
-    g.inv_c = 1.0f / c;
-    for (int a = 0; a < 3; ++a) g.dims[a] = d[a];
+    finish_grid(g, c, cap);
+    segs[s] = g;
+}
+
+// grid of a thinner subset of the parent's points: same box, c scaled by (n_parent / n)^(1/D)
+__global__ void grid_setup_derived(Segs S, const GridSeg* parent, GridSeg* segs, int batch) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    GridSeg g = parent[s];
+    int64_t n = seg_len(S, s);
+    int64_t pb = seg_begin_packed(S, s);
+    float ratio = n > 0 ? (float)g.n / (float)n : 1.0f;
+    float c = g.c * powf(fmaxf(ratio, 1.0f), 1.0f / g.dim_est);
+    g.n = (int)n;
+    g.sorted_base = (int)pb;
+    g.cell_base = (int)(GRID_CAP * pb + (int64_t)GRID_SLACK * s);
+    if (n <= 64) c = fmaxf(g.ext[0], fmaxf(g.ext[1], g.ext[2])) * 2.0f;
+    finish_grid(g, c, (int64_t)GRID_CAP * n + GRID_SLACK);
     segs[s] = g;
 }
 
@@ -385,6 +425,28 @@ __global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_to
         if (hipGetLastError() != hipSuccess) return -3; \
     } while (0)
 
+static int grid_sort(const float* points, Segs S, const GridWs& ws, hipStream_t stream) {
+    int64_t n = ws.n_total;
+    int nb = (int)((n + 255) / 256);
+    if (n > 0) {
+        hipLaunchKernelGGL(grid_hist, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells);
+        ML3D_LAUNCH_CHECK();
+        int64_t tc = ws.total_cells;
+        int sbk = (int)((tc + 1023) / 1024);
+        hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, ws.block_sums, (int64_t)sbk);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_final, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
+        ML3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_scatter, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells,
+                           ws.sorted);
+        ML3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+
 int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, hipStream_t stream) {
     int64_t n = ws.n_total;
     int B = ws.batch;
@@ -408,24 +470,18 @@ int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, 
                            ws.bitmap_words, ws.occ);
         ML3D_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(grid_setup1, dim3(sb), dim3(64), 0, stream, ws.occ, ws.bbox, ws.segs, B, target_occ);
+    hipLaunchKernelGGL(grid_setup1, dim3(sb), dim3(64), 0, stream, ws.occ, ws.segs, B, target_occ);
     ML3D_LAUNCH_CHECK();
-    if (n > 0) {
-        hipLaunchKernelGGL(grid_hist, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells);
-        ML3D_LAUNCH_CHECK();
-        int64_t tc = ws.total_cells;
-        int sbk = (int)((tc + 1023) / 1024);
-        hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
-        ML3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, ws.block_sums, (int64_t)sbk);
-        ML3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_final, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
-        ML3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(grid_scatter, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells,
-                           ws.sorted);
-        ML3D_LAUNCH_CHECK();
-    }
-    return 0;
+    return grid_sort(points, S, ws, stream);
+}
+
+int grid_build_derived(const float* points, Segs S, const GridWs& ws, const GridWs& parent, hipStream_t stream) {
+    int B = ws.batch;
+    if (B <= 0) return 0;
+    (void)hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    hipLaunchKernelGGL(grid_setup_derived, dim3((B + 63) / 64), dim3(64), 0, stream, S, parent.segs, ws.segs, B);
+    ML3D_LAUNCH_CHECK();
+    return grid_sort(points, S, ws, stream);
 }
 
 }  // namespace ml3d

@@ -267,7 +267,9 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
         tb(100 + l);
-        if (grid_build(points, S, ws[l], occ, st)) return ML3D_E_LAUNCH;
+        // level 0 probes the cloud; the thinner prefix levels reuse its box and dimension estimate
+        if (l == 0 ? grid_build(points, S, ws[l], occ, st) : grid_build_derived(points, S, ws[l], ws[0], st))
+            return ML3D_E_LAUNCH;
         te(100 + l);
     }
     for (int l = 0; l < num_layers; ++l) {

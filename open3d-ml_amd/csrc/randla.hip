@@ -503,6 +503,117 @@ static int launch_attn_mfma(const LfaArgs& a, hipStream_t st) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// lfa_attn_mfma16 — the D = 16 (first encoder layer, 45 056 points per frame) attention stage on
+// v_mfma_f32_16x16x4_f32: one 16x16 MFMA tile = the 16 neighbours of ONE point x 16 channels.
+// Build phase: one thread per (point, neighbour) row keeps everything in registers — relative
+// position, r1 = lse1(rel) (10->8), stage 2: r2 = lse2(r1) (8->8) — gathers its neighbour's
+// 8-float feature row (two 16-byte loads) and writes the 16-float X row to LDS.
+// MFMA phase: lane group g = lane>>4 feeds k in [4g, 4g+4): the lane's four A values are ONE
+// ds_read_b128; B = score_WT lives in 4 VGPRs.  C layout: lane holds column lane&15 and rows
+// 4g..4g+3, so softmax over the 16 neighbours = 4 in-lane values + lane^16 and lane^32 exchanges.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int A16_TP = 16;           // points per tile (256 rows = 256 threads)
+constexpr int A16_XP = 20;           // X row pitch
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) lfa_attn_mfma16(LfaArgs A) {
+    constexpr int D = 16, H = 8;
+    __shared__ __attribute__((aligned(16))) float X[A16_TP * RK * A16_XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    float bs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bs[s] = A.score_wt[(4 * g + s) * D + col];
+    const float sbias = A.score_b[col];
+    const int64_t tiles = (A.m_total + A16_TP - 1) / A16_TP;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t m_base = tile * A16_TP;
+        {   // ---- build: thread = (point p, neighbour k) -------------------------------------------
+            const int p = tid >> 4, k = tid & 15;
+            const int64_t m = m_base + p;
+            float xr[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) xr[c] = 0.f;
+            if (m < A.m_total) {
+                int64_t b = m / A.n, nl = m - b * A.n;
+                int nb = A.nidx[m * RK + k];
+                const float* q = A.xyz + 3 * (b * A.n0 + nl);
+                const float* sp = A.xyz + 3 * (b * A.n0 + nb);
+                float rel[10];
+                rel[4] = q[0]; rel[5] = q[1]; rel[6] = q[2]; rel[7] = sp[0]; rel[8] = sp[1]; rel[9] = sp[2];
+                rel[1] = rel[4] - rel[7]; rel[2] = rel[5] - rel[8]; rel[3] = rel[6] - rel[9];
+                rel[0] = sqrtf(rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
+                float r1[H];
+#pragma unroll
+                for (int c = 0; c < H; ++c) {
+                    float v = A.lse1_b[c];
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) v = fmaf(rel[j], A.lse1_wt[j * H + c], v);
+                    r1[c] = lrelu(v, 0.2f);
+                }
+                if (STAGE == 2) {
+#pragma unroll
+                    for (int c = 0; c < H; ++c) {
+                        float v = A.lse2_b[c];
+#pragma unroll
+                        for (int j = 0; j < H; ++j) v = fmaf(r1[j], A.lse2_wt[j * H + c], v);
+                        xr[H + c] = lrelu(v, 0.2f);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < H; ++c) xr[H + c] = r1[c];
+                }
+                const float4* gf = reinterpret_cast<const float4*>(A.gfeat + (b * A.n + nb) * H);
+                float4 g0 = gf[0], g1 = gf[1];
+                xr[0] = g0.x; xr[1] = g0.y; xr[2] = g0.z; xr[3] = g0.w;
+                xr[4] = g1.x; xr[5] = g1.y; xr[6] = g1.z; xr[7] = g1.w;
+            }
+            float4* dst = reinterpret_cast<float4*>(X + tid * A16_XP);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) dst[q4] = make_float4(xr[4 * q4], xr[4 * q4 + 1], xr[4 * q4 + 2], xr[4 * q4 + 3]);
+        }
+        __syncthreads();
+        // ---- MFMA: wave w owns points 4w .. 4w+3 of the tile ------------------------------------------
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = 4 * wave + pp;
+            const float* Xp = X + p * RK * A16_XP;
+            float4 a = *reinterpret_cast<const float4*>(Xp + col * A16_XP + 4 * g);
+            f32x4 acc = {sbias, sbias, sbias, sbias};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bs[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bs[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bs[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bs[3], acc, 0, 0, 0);
+            float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f, ag = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = expf(acc[r] - mx);
+                sum += e;
+                ag = fmaf(e, Xp[(4 * g + r) * A16_XP + col], ag);
+            }
+            sum += __shfl_xor(sum, 16); ag += __shfl_xor(ag, 16);
+            sum += __shfl_xor(sum, 32); ag += __shfl_xor(ag, 32);
+            const int64_t m = m_base + p;
+            if (g == 0 && m < A.m_total) A.out[m * D + col] = ag / sum;
+        }
+        __syncthreads();
+    }
+}
+
+template <int STAGE>
+static int launch_attn_mfma16(const LfaArgs& a, hipStream_t st) {
+    int64_t tiles = (a.m_total + A16_TP - 1) / A16_TP;
+    unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
+    hipLaunchKernelGGL((lfa_attn_mfma16<STAGE>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------------------
 // mlp_chain_mfma — up to 4 per-point Linear(+folded BN)+activation layers back to back on
 // v_mfma_f32_32x32x2_f32.  A workgroup owns 64 rows; the first layer streams its input rows from
@@ -906,13 +1017,14 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         s2.mlp2_wt = P(sb + 14); s2.mlp2_b = P(sb + 16); s2.short_wt = P(sb + 15); s2.short_b = P(sb + 17);
         s2.feat_in = feat; s2.out = enc;
         int rc = 0;
-        const bool mfma_ok = (dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu;
+        const bool mfma_ok = (dd == 16 || dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu;
         if (mfma_ok) {
             float* agg = take(M * dd);
             float* p2 = take(M * dd);
             LfaArgs q1 = s1; q1.out = agg;
             T.begin(8 * l + 1);
             switch (dd) {
+                case 16: rc = launch_attn_mfma16<1>(q1, st); break;
                 case 32: rc = launch_attn_mfma<32, 1>(q1, st); break;
                 case 64: rc = launch_attn_mfma<64, 1>(q1, st); break;
                 case 128: rc = launch_attn_mfma<128, 1>(q1, st); break;
@@ -929,6 +1041,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             LfaArgs q2 = s2; q2.out = agg;
             T.begin(8 * l + 2);
             switch (dd) {
+                case 16: rc = launch_attn_mfma16<2>(q2, st); break;
                 case 32: rc = launch_attn_mfma<32, 2>(q2, st); break;
                 case 64: rc = launch_attn_mfma<64, 2>(q2, st); break;
                 case 128: rc = launch_attn_mfma<128, 2>(q2, st); break;
