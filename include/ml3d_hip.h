@@ -62,6 +62,106 @@ int ml3d_knn_search(const float* points, const int64_t* points_row_splits,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* batched fixed-radius search (two-phase ragged result)                       */
+/* replaces open3d.ml.torch.layers.FixedRadiusSearch()(supports, queries, r,   */
+/*   s_splits, q_splits) — ml3d/torch/models/kpconv.py:2021-2026               */
+/*   (batch_neighbors; 3 calls per layer from KPConvBatch.segmentation_inputs, */
+/*   ml3d/torch/dataloaders/concat_batcher.py:186-305).                        */
+/* neighbour iff d2 <= radius*radius (f32, no fma); a row lists its neighbours */
+/* ascending (d2, index).  Indices are GLOBAL rows of `points` unless          */
+/* index_local != 0.                                                           */
+/*  count: builds the grid in `workspace`, writes neighbors_row_splits         */
+/*         int64[n_queries + 1] and out_stats int64[2] = {total, longest row}. */
+/*  fill : must get the SAME workspace contents back (grown to                 */
+/*         ml3d_radius_workspace_bytes(.., total) if the grid part is copied). */
+/*         dense_cols == 0 -> ragged out_index[total];                         */
+/*         dense_cols  > 0 -> the ragged_to_dense of kpconv.py:2030-2032 fused */
+/*         in: out_index[n_queries, dense_cols], rows truncated / padded with  */
+/*         pad_value.  out_dist2 may be NULL.                                  */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_radius_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch,
+                                   int64_t total_neighbors);
+
+int ml3d_radius_count(const float* points, const int64_t* points_row_splits,
+                      const float* queries, const int64_t* queries_row_splits,
+                      int64_t batch, int64_t n_points, int64_t n_queries, float radius,
+                      int64_t* out_row_splits, int64_t* out_stats,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+int ml3d_radius_fill(const float* points, const int64_t* points_row_splits,
+                     const float* queries, const int64_t* queries_row_splits,
+                     int64_t batch, int64_t n_points, int64_t n_queries, float radius,
+                     const int64_t* row_splits, int64_t total_neighbors, int index_local,
+                     int64_t dense_cols, int32_t pad_value, int32_t* out_index, float* out_dist2,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* ragged_to_dense — replaces open3d.ml.torch.ops.ragged_to_dense              */
+/*   (ml3d/torch/models/kpconv.py:2030, ml3d/torch/models/point_pillars.py:364)*/
+/* values [K, elem_bytes] (elem_bytes multiple of 4), row_splits int64[rows+1],*/
+/* out [rows, out_cols, elem_bytes]; row r = values[rs[r] : rs[r] + out_cols]  */
+/* padded with default_value (device, elem_bytes).                             */
+/* ------------------------------------------------------------------------- */
+int ml3d_ragged_to_dense(const void* values, const int64_t* row_splits, int64_t rows,
+                         int64_t out_cols, int64_t elem_bytes, const void* default_value,
+                         void* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* voxelize (two-phase) — replaces open3d.ml.torch.ops.voxelize                */
+/*   ml3d/torch/models/point_pillars.py:354-357.                               */
+/* points: rows of `point_stride` floats whose first 3 are xyz (the reference  */
+/* passes the view points[:, :3] of an [N,4] tensor — no copy needed here);    */
+/* keep iff min <= p <= max; coord = (int)((p - min) / voxel_size);            */
+/* voxels ascending linear id x + X*(y + Y*z) per batch item, points inside a  */
+/* voxel in original order, first max_points_per_voxel kept, first max_voxels  */
+/* voxels per item kept.  voxel_size / range_* are HOST float[3] (the          */
+/* reference keeps them as CPU tensors, point_pillars.py:317-320).             */
+/*  count: out_batch_splits int64[batch+1], out_stats int64[2] =               */
+/*         {n_voxels M, n_point_indices K}.                                    */
+/*  fill : voxel_coords int32[M,3] (x,y,z), point_indices int64[K] (global     */
+/*         rows), point_row_splits int64[M+1].  Same workspace as count.       */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_voxelize_workspace_bytes(int64_t n_points, int64_t batch);
+
+int ml3d_voxelize_count(const float* points, int64_t point_stride, const int64_t* row_splits,
+                        int64_t batch, int64_t n_points, const float* voxel_size_host,
+                        const float* range_min_host, const float* range_max_host,
+                        int64_t max_points_per_voxel, int64_t max_voxels,
+                        int64_t* out_batch_splits, int64_t* out_stats,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* voxel_size_host,
+                       const float* range_min_host, const float* range_max_host,
+                       int64_t max_points_per_voxel, int64_t max_voxels,
+                       const int64_t* batch_splits, int32_t* out_voxel_coords,
+                       int64_t* out_point_indices, int64_t* out_point_row_splits,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* grid subsample (two-phase) — replaces open3d.ml.contrib.subsample /         */
+/*   subsample_batch: ml3d/datasets/utils/dataprocessing.py:32-49,             */
+/*   ml3d/torch/models/kpconv.py:2098-2155.                                    */
+/* Per batch item: origin = floor(min/dl)*dl, voxel = floor((p-origin)/dl),    */
+/* output = barycentre (float32 sums in original point order / count),         */
+/* feature mean, majority label (ties: smallest); voxels ascending linear key. */
+/*  count: out_lengths int64[batch], out_stats int64[2] = {total M, error}     */
+/*         (error != 0: an item spans >= 2^48 voxels — unsupported).           */
+/*  fill : out_points [M,3], out_features [M,feature_dim] / out_labels [M]     */
+/*         when the inputs are non-NULL.  Same workspace as count.             */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_subsample_workspace_bytes(int64_t n_points, int64_t batch);
+
+int ml3d_subsample_count(const float* points, const int64_t* row_splits, int64_t batch,
+                         int64_t n_points, float sample_dl, int64_t* out_lengths,
+                         int64_t* out_stats, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+int ml3d_subsample_fill(const float* points, const float* features, int64_t feature_dim,
+                        const int32_t* labels, int64_t batch, int64_t n_points,
+                        float* out_points, float* out_features, int32_t* out_labels,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */
 /*   ml3d/torch/models/randlanet.py:218-229 for a batch of equally sized       */
 /*   clouds in ONE call.  Layer l has n_l = n_{l-1} / ratio[l-1] points, the   */

@@ -74,6 +74,29 @@ int grid_build(const float* points, Segs segs, const GridWs& ws, float target_oc
 // sub-cloud): reuses the parent's bounding box and dimension estimate, cell size scaled for the
 // thinner sampling — skips the bbox and occupancy passes.
 int grid_build_derived(const float* points, Segs segs, const GridWs& ws, const GridWs& parent, hipStream_t stream);
+// Build with a caller-chosen cell size (fixed-radius search: cell ~ radius, so a query's box is 3x3x3
+// cells); skips the occupancy probe.  The size is grown until the dense table fits.
+int grid_build_fixed(const float* points, Segs segs, const GridWs& ws, float cell, hipStream_t stream);
+// bounding boxes only: bbox[6*s + {0..2}] = ordered-uint(min), [3..5] = ordered-uint(max)
+int bbox_compute(const float* points, Segs segs, int64_t n_total, unsigned* bbox, unsigned* occ_scratch,
+                 hipStream_t stream);
+// in-place inclusive scan of a[0 .. n) (int32); block_sums must hold (n + 1023) / 1024 + 1 ints
+int scan_inclusive_i32(int* a, int64_t n, int* block_sums, hipStream_t stream);
+
+// order-preserving float <-> uint so atomicMin/atomicMax work on floats
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// wave-level rendezvous + LDS/global visibility between the lanes of ONE wave
+__device__ __forceinline__ void wave_sync() {
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
 
 inline GridView grid_view(const GridWs& ws) {
     GridView v;

@@ -53,15 +53,6 @@ bool grid_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, GridW
     return true;
 }
 
-// ---- order-preserving float <-> uint so atomicMin/atomicMax work on floats --------------------
-__device__ __forceinline__ unsigned f2ord(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned u) {
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
 // ---- K1: bounding box per segment -------------------------------------------------------------
 __global__ void grid_bbox_init(unsigned* bbox, unsigned* occ, int batch) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,20 +416,25 @@ __global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_to
         if (hipGetLastError() != hipSuccess) return -3; \
     } while (0)
 
+int scan_inclusive_i32(int* a, int64_t n, int* block_sums, hipStream_t stream) {
+    if (n <= 0) return 0;
+    int sbk = (int)((n + 1023) / 1024);
+    hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, a, n, block_sums);
+    ML3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, block_sums, (int64_t)sbk);
+    ML3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_final, dim3(sbk), dim3(256), 0, stream, a, n, block_sums);
+    ML3D_LAUNCH_CHECK();
+    return 0;
+}
+
 static int grid_sort(const float* points, Segs S, const GridWs& ws, hipStream_t stream) {
     int64_t n = ws.n_total;
     int nb = (int)((n + 255) / 256);
     if (n > 0) {
         hipLaunchKernelGGL(grid_hist, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells);
         ML3D_LAUNCH_CHECK();
-        int64_t tc = ws.total_cells;
-        int sbk = (int)((tc + 1023) / 1024);
-        hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
-        ML3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, ws.block_sums, (int64_t)sbk);
-        ML3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_final, dim3(sbk), dim3(256), 0, stream, ws.cells + 2, tc, ws.block_sums);
-        ML3D_LAUNCH_CHECK();
+        if (scan_inclusive_i32(ws.cells + 2, ws.total_cells, ws.block_sums, stream)) return -3;
         hipLaunchKernelGGL(grid_scatter, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.cells,
                            ws.sorted);
         ML3D_LAUNCH_CHECK();
@@ -471,6 +467,43 @@ int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, 
         ML3D_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(grid_setup1, dim3(sb), dim3(64), 0, stream, ws.occ, ws.segs, B, target_occ);
+    ML3D_LAUNCH_CHECK();
+    return grid_sort(points, S, ws, stream);
+}
+
+// fixed cell size: a fixed-radius search wants cell ~ radius
+__global__ void grid_setup_fixed(GridSeg* segs, int batch, float cell) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    GridSeg g = segs[s];
+    float c = cell;
+    if (!(c > 0.f)) c = g.c0;
+    if (c < g.c0 * 0.5f) c = g.c0 * 0.5f;   // never finer than the dense table admits
+    finish_grid(g, c, (int64_t)GRID_CAP * g.n + GRID_SLACK);
+    segs[s] = g;
+}
+
+int bbox_compute(const float* points, Segs S, int64_t n, unsigned* bbox, unsigned* occ_scratch, hipStream_t stream) {
+    int B = S.batch;
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(grid_bbox_init, dim3((B + 63) / 64), dim3(64), 0, stream, bbox, occ_scratch, B);
+    ML3D_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(grid_bbox, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, points, S, n, bbox);
+        ML3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int grid_build_fixed(const float* points, Segs S, const GridWs& ws, float cell, hipStream_t stream) {
+    int B = ws.batch;
+    if (B <= 0) return 0;
+    int sb = (B + 63) / 64;
+    (void)hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    if (bbox_compute(points, S, ws.n_total, ws.bbox, ws.occ, stream)) return -3;
+    hipLaunchKernelGGL(grid_setup0, dim3(sb), dim3(64), 0, stream, S, ws.bbox, ws.segs, B);
+    ML3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grid_setup_fixed, dim3(sb), dim3(64), 0, stream, ws.segs, B, cell);
     ML3D_LAUNCH_CHECK();
     return grid_sort(points, S, ws, stream);
 }

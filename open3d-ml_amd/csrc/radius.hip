@@ -1,0 +1,311 @@
+// radius.hip — batched fixed-radius neighbour search + ragged_to_dense (gfx950).
+//
+// Replaces open3d.ml.torch.layers.FixedRadiusSearch()(supports, queries, r, s_splits, q_splits)
+// and open3d.ml.torch.ops.ragged_to_dense as called from batch_neighbors
+// (ml3d/torch/models/kpconv.py:2002-2034) — 3 calls per KPConv layer in
+// KPConvBatch.segmentation_inputs (ml3d/torch/dataloaders/concat_batcher.py:186-305) — and the
+// ragged_to_dense of PointPillarsVoxelization (ml3d/torch/models/point_pillars.py:364-366).
+//
+// neighbour iff d2 <= r*r, d2 = ((dx*dx)+(dy*dy))+(dz*dz) in f32 without fma; rows are emitted in
+// the oracle's canonical order, ascending (d2, index) — so "first column = closest point"
+// (closest_pool, kpconv.py:821-838) and "truncate = drop the furthest" (big_neighborhood_filter,
+// concat_batcher.py:176-184) hold as in the original KPConv.
+//
+// One WAVE per query on a counting-sorted grid with cell ~ r: the query's box is <= 3x3x3 cells =
+// 9 contiguous x-runs; the 64 lanes stream a run's float4 candidates (coalesced 1 KiB per step),
+// ballot the hits and compact them with a popcount prefix into an LDS-staged row (<= 256
+// neighbours; longer rows spill to the caller's workspace), then rank-sort the row in place.
+// Two-phase ragged result: count -> caller allocates -> fill (the library never allocates).
+// Roofline: HBM — algorithmic bytes 12 B/query + 12 B/support read, 4 B per neighbour written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grid.h"
+#include "ml3d_hip.h"
+
+namespace ml3d {
+
+typedef unsigned long long u64;
+constexpr int RAD_LDS_ROW = 256;   // neighbours staged in LDS per wave
+
+struct RadArgs {
+    GridView G;
+    const float* queries;
+    Segs qsegs;      // layout of queries / output rows
+    Segs psegs;      // layout of the support points (for global index base)
+    int64_t nq;
+    float r, r2;
+};
+
+// the query of this wave and the cell box that covers its ball
+struct RadQuery {
+    float qx, qy, qz;
+    int s;
+    int xa, xb, ya, yb, za, zb;
+    bool any;
+};
+
+__device__ __forceinline__ RadQuery rad_setup(const RadArgs& A, int64_t t) {
+    RadQuery Q;
+    int64_t local;
+    seg_locate(A.qsegs, t, Q.s, local);
+    const float* p = A.queries + 3 * (seg_begin_global(A.qsegs, Q.s) + local);
+    Q.qx = p[0]; Q.qy = p[1]; Q.qz = p[2];
+    Q.any = false;
+    Q.xa = Q.xb = Q.ya = Q.yb = Q.za = Q.zb = 0;
+    return Q;
+}
+
+__device__ __forceinline__ void rad_box(RadQuery& Q, const GridSeg& g, float r) {
+    Q.any = g.n > 0;
+    // a point accepted by the f32 test d2 <= r2 lies within r * (1 + 2^-22) + rounding of the
+    // differences; pad the box so that cell_coord (monotone in its argument) cannot miss it.
+    const float pad = r * 1.00001f + g.margin;
+    Q.xa = cell_coord(Q.qx - pad, g.lo[0], g.inv_c, g.dims[0]);
+    Q.xb = cell_coord(Q.qx + pad, g.lo[0], g.inv_c, g.dims[0]);
+    Q.ya = cell_coord(Q.qy - pad, g.lo[1], g.inv_c, g.dims[1]);
+    Q.yb = cell_coord(Q.qy + pad, g.lo[1], g.inv_c, g.dims[1]);
+    Q.za = cell_coord(Q.qz - pad, g.lo[2], g.inv_c, g.dims[2]);
+    Q.zb = cell_coord(Q.qz + pad, g.lo[2], g.inv_c, g.dims[2]);
+}
+
+// ---- phase 1: neighbours per query ---------------------------------------------------------------
+__global__ void __launch_bounds__(256) radius_count(RadArgs A, int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= A.nq) return;                       // wave-uniform
+    RadQuery Q = rad_setup(A, t);
+    const GridSeg g = A.G.segs[Q.s];
+    rad_box(Q, g, A.r);
+    int total = 0;
+    if (Q.any) {
+        for (int z = Q.za; z <= Q.zb; ++z)
+            for (int y = Q.ya; y <= Q.yb; ++y) {
+                const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+                const int p0 = A.G.cell_start[row + Q.xa], p1 = A.G.cell_start[row + Q.xb + 1];
+                for (int pb = p0; pb < p1; pb += 64) {
+                    const int p = pb + lane;
+                    bool hit = false;
+                    if (p < p1) {
+                        const float4 c = A.G.sorted[p];
+                        hit = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z) <= A.r2;
+                    }
+                    total += __popcll(__ballot(hit));
+                }
+            }
+    }
+    if (lane == 0) counts[t] = total;
+}
+
+// counts were scanned in place (inclusive) in c[1 .. nq]; c[0] = 0.  Emit int64 row_splits and the
+// (total, longest row) pair the host needs to size the ragged / dense result.
+__global__ void radius_splits(const int* __restrict__ c, int64_t nq, int64_t* __restrict__ row_splits,
+                              unsigned long long* __restrict__ stats) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long len = 0ull;
+    if (i <= nq) row_splits[i] = (int64_t)c[i];
+    if (i < nq) len = (unsigned long long)(c[i + 1] - c[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {       // wave max, one atomic per wave
+        unsigned long long other = __shfl_xor(len, o);
+        len = other > len ? other : len;
+    }
+    if ((threadIdx.x & 63) == 0 && len > 0ull) atomicMax(&stats[1], len);
+    if (i == nq) stats[0] = (unsigned long long)c[nq];
+}
+
+// ---- phase 2: fill ---------------------------------------------------------------------------------
+// dense_cols == 0 : ragged — out_index[row_splits[t] + j]
+// dense_cols  > 0 : dense  — out_index[t * dense_cols + j], truncated / padded with pad_value
+__global__ void __launch_bounds__(256)
+radius_fill(RadArgs A, const int64_t* __restrict__ row_splits, int index_local, int64_t dense_cols,
+            int32_t pad_value, int32_t* __restrict__ out_index, float* __restrict__ out_d2, u64* spill) {
+    __shared__ u64 rows[4][RAD_LDS_ROW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + w;
+    if (t >= A.nq) return;                       // wave-uniform; no block barrier below
+    RadQuery Q = rad_setup(A, t);
+    const GridSeg g = A.G.segs[Q.s];
+    rad_box(Q, g, A.r);
+    const int64_t rs = row_splits[t];
+    const int L = (int)(row_splits[t + 1] - rs);
+    const bool in_lds = L <= RAD_LDS_ROW;
+    u64* buf = in_lds ? rows[w] : (spill + rs);
+    int total = 0;
+    if (Q.any) {
+        for (int z = Q.za; z <= Q.zb; ++z)
+            for (int y = Q.ya; y <= Q.yb; ++y) {
+                const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+                const int p0 = A.G.cell_start[row + Q.xa], p1 = A.G.cell_start[row + Q.xb + 1];
+                for (int pb = p0; pb < p1; pb += 64) {
+                    const int p = pb + lane;
+                    bool hit = false;
+                    u64 key = 0ull;
+                    if (p < p1) {
+                        const float4 c = A.G.sorted[p];
+                        const float d2 = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z);
+                        hit = d2 <= A.r2;
+                        key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
+                    }
+                    const u64 m = __ballot(hit);
+                    if (hit) {
+                        const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < L) buf[pos] = key;
+                    }
+                    total += __popcll(m);
+                }
+            }
+    }
+    if (!in_lds) __threadfence();
+    wave_sync();   // every lane's keys are in `buf` before any lane ranks
+    // rank sort: keys are distinct (distinct indices), rank = number of smaller keys
+    const int64_t base = index_local ? 0 : seg_begin_global(A.psegs, Q.s);
+    const int n_out = dense_cols > 0 ? (int)(L < dense_cols ? L : dense_cols) : L;
+    int32_t* orow = dense_cols > 0 ? out_index + t * dense_cols : out_index + rs;
+    float* drow = out_d2 ? (dense_cols > 0 ? out_d2 + t * dense_cols : out_d2 + rs) : nullptr;
+    const volatile u64* vb = buf;
+    for (int e = lane; e < L; e += 64) {
+        const u64 key = vb[e];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) rank += (vb[j] < key) ? 1 : 0;
+        if (rank < n_out) {
+            orow[rank] = (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base);
+            if (drow) drow[rank] = __uint_as_float((unsigned)(key >> 32));
+        }
+    }
+    if (dense_cols > 0)
+        for (int64_t e = n_out + lane; e < dense_cols; e += 64) {
+            orow[e] = pad_value;
+            if (drow) drow[e] = __uint_as_float(0x7f800000u);
+        }
+}
+
+// ---- ragged_to_dense -----------------------------------------------------------------------------
+// element = `elem` 4-byte words; out[r][c] = values[rs[r] + c] for c < min(len, cols), else default
+__global__ void ragged_to_dense_k(const uint32_t* __restrict__ values, const int64_t* __restrict__ rs, int64_t rows,
+                                  int64_t cols, int elem, const uint32_t* __restrict__ def, uint32_t* __restrict__ out) {
+    const int64_t total = rows * cols * elem;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = i % elem, rc = i / elem;
+        const int64_t c = rc % cols, r = rc / cols;
+        const int64_t s = rs[r], len = rs[r + 1] - s;
+        out[i] = c < len ? values[(s + c) * elem + w] : def[w];
+    }
+}
+
+static inline size_t rad_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace ml3d
+
+using namespace ml3d;
+
+// workspace layout: [grid | counts int32 (nq + 1) | scan scratch | stats u64[2] | spill u64[total]]
+static size_t rad_fixed_bytes(int64_t n_points, int64_t n_queries, int64_t batch) {
+    size_t b = grid_ws_bytes(n_points, batch);
+    b += rad_align(sizeof(int) * (size_t)(n_queries + 2));
+    b += rad_align(sizeof(int) * (size_t)((n_queries + 1 + 1023) / 1024 + 2));
+    b += rad_align(16);
+    return b + 256;
+}
+
+struct RadWs {
+    GridWs grid;
+    int* counts;
+    int* block_sums;
+    unsigned long long* stats;
+    u64* spill;
+};
+
+static bool rad_carve(void* ws, size_t bytes, int64_t n_points, int64_t n_queries, int64_t batch, RadWs* out) {
+    if (bytes < rad_fixed_bytes(n_points, n_queries, batch)) return false;
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    size_t gb = grid_ws_bytes(n_points, batch);
+    if (!grid_ws_carve(p, gb, n_points, batch, &out->grid)) return false;
+    p += rad_align(gb);
+    out->counts = (int*)p;       p += rad_align(sizeof(int) * (size_t)(n_queries + 2));
+    out->block_sums = (int*)p;   p += rad_align(sizeof(int) * (size_t)((n_queries + 1 + 1023) / 1024 + 2));
+    out->stats = (unsigned long long*)p; p += rad_align(16);
+    out->spill = (u64*)p;
+    return true;
+}
+
+extern "C" size_t ml3d_radius_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch,
+                                              int64_t total_neighbors) {
+    if (n_points < 0 || n_queries < 0 || batch <= 0 || total_neighbors < 0) return 0;
+    return rad_fixed_bytes(n_points, n_queries, batch) + sizeof(u64) * (size_t)total_neighbors + 256;
+}
+
+static int rad_args(const float* points, const int64_t* prs, const float* queries, const int64_t* qrs,
+                    int64_t batch, int64_t n_points, int64_t n_queries, float radius) {
+    if (!prs || !qrs || batch <= 0 || n_points < 0 || n_queries < 0 || !(radius >= 0.f)) return ML3D_E_INVALID;
+    if (n_points > 0x7fffffffll / GRID_CAP - 4096 || n_queries > 0x7ffffff0ll) return ML3D_E_INVALID;
+    if ((n_points > 0 && !points) || (n_queries > 0 && !queries)) return ML3D_E_INVALID;
+    return 0;
+}
+
+extern "C" int ml3d_radius_count(const float* points, const int64_t* points_row_splits, const float* queries,
+                                 const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
+                                 int64_t n_queries, float radius, int64_t* out_row_splits, int64_t* out_stats,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = rad_args(points, points_row_splits, queries, queries_row_splits, batch, n_points, n_queries, radius);
+    if (rc) return rc;
+    if (!out_row_splits || !out_stats) return ML3D_E_INVALID;
+    RadWs W;
+    if (!rad_carve(workspace, workspace_bytes, n_points, n_queries, batch, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Segs ps = {points_row_splits, 0, 0, (int)batch};
+    Segs qs = {queries_row_splits, 0, 0, (int)batch};
+    if (grid_build_fixed(points, ps, W.grid, radius, st)) return ML3D_E_LAUNCH;
+    (void)hipMemsetAsync(W.counts, 0, sizeof(int) * (size_t)(n_queries + 2), st);
+    (void)hipMemsetAsync(out_stats, 0, 16, st);
+    RadArgs A;
+    A.G = grid_view(W.grid);
+    A.queries = queries; A.qsegs = qs; A.psegs = ps; A.nq = n_queries;
+    A.r = radius; A.r2 = radius * radius;
+    if (n_queries > 0) {
+        hipLaunchKernelGGL(radius_count, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, A, W.counts + 1);
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+        if (scan_inclusive_i32(W.counts + 1, n_queries, W.block_sums, st)) return ML3D_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(radius_splits, dim3((unsigned)((n_queries + 1 + 255) / 256)), dim3(256), 0, st, W.counts,
+                       n_queries, out_row_splits, (unsigned long long*)out_stats);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_radius_fill(const float* points, const int64_t* points_row_splits, const float* queries,
+                                const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
+                                int64_t n_queries, float radius, const int64_t* row_splits, int64_t total_neighbors,
+                                int index_local, int64_t dense_cols, int32_t pad_value, int32_t* out_index,
+                                float* out_dist2, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = rad_args(points, points_row_splits, queries, queries_row_splits, batch, n_points, n_queries, radius);
+    if (rc) return rc;
+    if (!row_splits || total_neighbors < 0 || dense_cols < 0) return ML3D_E_INVALID;
+    if (n_queries == 0) return 0;
+    if (!out_index) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_radius_workspace_bytes(n_points, n_queries, batch, total_neighbors)) return ML3D_E_WORKSPACE;
+    RadWs W;
+    if (!rad_carve(workspace, workspace_bytes, n_points, n_queries, batch, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    RadArgs A;
+    A.G = grid_view(W.grid);
+    A.queries = queries;
+    A.qsegs = Segs{queries_row_splits, 0, 0, (int)batch};
+    A.psegs = Segs{points_row_splits, 0, 0, (int)batch};
+    A.nq = n_queries;
+    A.r = radius; A.r2 = radius * radius;
+    hipLaunchKernelGGL(radius_fill, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, A, row_splits, index_local,
+                       dense_cols, pad_value, out_index, out_dist2, W.spill);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_ragged_to_dense(const void* values, const int64_t* row_splits, int64_t rows, int64_t out_cols,
+                                    int64_t elem_bytes, const void* default_value, void* out, void* stream) {
+    if (rows < 0 || out_cols < 0 || elem_bytes <= 0 || (elem_bytes & 3)) return ML3D_E_INVALID;
+    if (rows == 0 || out_cols == 0) return 0;
+    if (!row_splits || !default_value || !out) return ML3D_E_INVALID;
+    int64_t total = rows * out_cols * (elem_bytes / 4);
+    unsigned nb = (unsigned)((total + 255) / 256 < 65535 * 4 ? (total + 255) / 256 : 65535 * 4);
+    hipLaunchKernelGGL(ragged_to_dense_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)values,
+                       row_splits, rows, out_cols, (int)(elem_bytes / 4), (const uint32_t*)default_value, (uint32_t*)out);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}

@@ -1,0 +1,456 @@
+// voxel.hip — voxelize (PointPillars) and grid subsample (KPConv / RandLA-Net preprocessing), gfx950.
+//
+// voxelize  replaces open3d.ml.torch.ops.voxelize as called from PointPillarsVoxelization.forward
+//           (ml3d/torch/models/point_pillars.py:354-357);
+// subsample replaces open3d.ml.contrib.subsample / subsample_batch as called from
+//           DataProcessing.grid_subsampling (ml3d/datasets/utils/dataprocessing.py:14-49) and
+//           batch_grid_subsampling (ml3d/torch/models/kpconv.py:2037-2164).
+//
+// Both group points by an integer voxel key.  A hash table would make the order of voxels and of
+// the points inside a voxel depend on atomics; the oracle's canonical order is ascending voxel key
+// with ORIGINAL point order inside a voxel, and the subsample barycentres are float32 sums in that
+// order, so the grouping is a stable LSD radix sort of (key, point index) pairs (sort.hip) followed
+// by head flags, an int32 scan and one thread per voxel walking its run.  Everything is an HBM stream:
+// algorithmic bytes per point 12 (xyz read) + 12 * passes (sort) + 4..16 (outputs).
+// Two-phase ragged results (count -> caller allocates -> fill); the workspace carries the sorted pairs
+// between the two calls.  No allocation, no global state.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "grid.h"
+#include "ml3d_hip.h"
+#include "sort.h"
+
+namespace ml3d {
+
+static inline size_t vx_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace shared by voxelize and subsample
+struct GroupWs {
+    u64* keys;          // [n]
+    uint32_t* vals;     // [n]
+    int* flags;         // [n + 1] head flags -> inclusive scan (flags[0] = 0)
+    int* hp;            // [n + 1] first sorted slot of voxel ordinal v; hp[n_vox] = number of valid pairs
+    int* cnt;           // [n + 1] kept points per voxel ordinal -> inclusive scan (cnt[0] = 0)
+    int* fv;            // [batch + 1] first voxel ordinal of a batch item
+    int* block_sums;    // scan scratch
+    unsigned* bbox;     // [batch][6]  (subsample)
+    unsigned* occ;      // [batch][GRID_LEVELS] scratch of bbox_compute
+    float* seg;         // [batch][8]  org[3], then G[3] as int bits, pad (subsample)
+    SortWs sort;
+    int64_t n;
+    int batch;
+};
+
+static size_t group_ws_bytes(int64_t n, int64_t batch) {
+    int64_t m = n > 0 ? n : 1;
+    size_t b = 0;
+    b += vx_align(sizeof(u64) * (size_t)m);
+    b += vx_align(sizeof(uint32_t) * (size_t)m);
+    b += 3 * vx_align(sizeof(int) * (size_t)(m + 2));
+    b += vx_align(sizeof(int) * (size_t)(batch + 2));
+    b += vx_align(sizeof(int) * (size_t)((m + 1 + 1023) / 1024 + 2));
+    b += vx_align(sizeof(unsigned) * 6 * (size_t)batch);
+    b += vx_align(sizeof(unsigned) * GRID_LEVELS * (size_t)batch);
+    b += vx_align(sizeof(float) * 8 * (size_t)batch);
+    b += sort_ws_bytes(m);
+    return b + 256;
+}
+
+static bool group_ws_carve(void* ws, size_t bytes, int64_t n, int64_t batch, GroupWs* o) {
+    if (bytes < group_ws_bytes(n, batch)) return false;
+    int64_t m = n > 0 ? n : 1;
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    o->keys = (u64*)p;          p += vx_align(sizeof(u64) * (size_t)m);
+    o->vals = (uint32_t*)p;     p += vx_align(sizeof(uint32_t) * (size_t)m);
+    o->flags = (int*)p;         p += vx_align(sizeof(int) * (size_t)(m + 2));
+    o->hp = (int*)p;            p += vx_align(sizeof(int) * (size_t)(m + 2));
+    o->cnt = (int*)p;           p += vx_align(sizeof(int) * (size_t)(m + 2));
+    o->fv = (int*)p;            p += vx_align(sizeof(int) * (size_t)(batch + 2));
+    o->block_sums = (int*)p;    p += vx_align(sizeof(int) * (size_t)((m + 1 + 1023) / 1024 + 2));
+    o->bbox = (unsigned*)p;     p += vx_align(sizeof(unsigned) * 6 * (size_t)batch);
+    o->occ = (unsigned*)p;      p += vx_align(sizeof(unsigned) * GRID_LEVELS * (size_t)batch);
+    o->seg = (float*)p;         p += vx_align(sizeof(float) * 8 * (size_t)batch);
+    size_t sb = sort_ws_bytes(m);
+    if (!sort_ws_carve(p, sb, m, &o->sort)) return false;
+    o->n = n;
+    o->batch = (int)batch;
+    return true;
+}
+
+static int bits_for(unsigned long long v) {   // bits needed to represent every value in [0, v]
+    int b = 1;
+    while (b < 64 && (v >> b) != 0ull) ++b;
+    return b;
+}
+
+// ---- shared grouping kernels -----------------------------------------------------------------------
+// flags[i + 1] = 1 iff sorted pair i opens a voxel (valid key differing from its predecessor)
+__global__ void group_heads(const u64* __restrict__ keys, int64_t n, u64 key_invalid, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) flags[0] = 0;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    flags[i + 1] = (k != key_invalid && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// after the scan: hp[v] = slot of the head of voxel ordinal v; hp[n_vox] = number of valid pairs
+__global__ void group_headpos(const u64* __restrict__ keys, int64_t n, u64 key_invalid, const int* __restrict__ flags,
+                              int* __restrict__ hp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    const bool valid = k != key_invalid;
+    if (valid && (i == 0 || keys[i - 1] != k)) hp[flags[i + 1] - 1] = (int)i;
+    const int nv = flags[n];
+    if (!valid && (i == 0 || keys[i - 1] != key_invalid)) hp[nv] = (int)i;   // first invalid pair
+    if (i == n - 1 && valid) hp[nv] = (int)n;
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const u64* a, int64_t n, u64 v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// fv[b] = number of voxels whose key is below the first key of batch item b
+__global__ void group_first_voxel(const u64* __restrict__ keys, int64_t n, const int* __restrict__ flags, int batch,
+                                  u64 item_stride, int item_shift, int* __restrict__ fv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > batch) return;
+    if (b == batch) { fv[b] = n > 0 ? flags[n] : 0; return; }
+    const u64 first = item_shift >= 0 ? ((u64)b << item_shift) : (u64)b * item_stride;
+    fv[b] = n > 0 ? flags[lower_bound_u64(keys, n, first)] : 0;
+}
+
+// ---- voxelize ------------------------------------------------------------------------------------------
+struct VoxParams {
+    float vs[3], rmin[3], rmax[3];
+    long long G[3];
+    long long cells;        // G0 * G1 * G2
+    long long max_points, max_voxels;
+};
+
+__global__ void vox_keys(const float* __restrict__ pts, int64_t stride, Segs S, int64_t n, VoxParams P,
+                         u64* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* p = pts + stride * i;
+    bool ok = true;
+    long long c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = p[a];
+        ok = ok && (v >= P.rmin[a]) && (v <= P.rmax[a]);
+        c[a] = (long long)__fdiv_rn(__fsub_rn(v, P.rmin[a]), P.vs[a]);
+    }
+    const u64 inval = (u64)S.batch * (u64)P.cells;
+    keys[i] = ok ? (u64)s * (u64)P.cells + (u64)(c[0] + P.G[0] * (c[1] + P.G[1] * c[2])) : inval;
+    vals[i] = (uint32_t)i;
+}
+
+// kept points per voxel ordinal (0 for voxels beyond max_voxels of their batch item)
+__global__ void vox_counts(const u64* __restrict__ keys, const int* __restrict__ flags, int64_t n,
+                           const int* __restrict__ hp, const int* __restrict__ fv, VoxParams P, int* __restrict__ cnt) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) cnt[0] = 0;
+    if (v >= n) return;
+    const int nv = flags[n];
+    if (v >= nv) { cnt[v + 1] = 0; return; }
+    const int h = hp[v];
+    const int b = (int)(keys[h] / (u64)P.cells);
+    const long long rank = v - fv[b];
+    long long c = hp[v + 1] - h;
+    if (c > P.max_points) c = P.max_points;
+    cnt[v + 1] = rank < P.max_voxels ? (int)c : 0;
+}
+
+__global__ void vox_batch_splits(const int* __restrict__ fv, int batch, long long max_voxels, const int* __restrict__ cnt,
+                                 const int* __restrict__ flags, int64_t n, int64_t* __restrict__ batch_splits,
+                                 int64_t* __restrict__ stats) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int64_t acc = 0;
+    batch_splits[0] = 0;
+    for (int b = 0; b < batch; ++b) {
+        long long nvb = fv[b + 1] - fv[b];
+        acc += nvb < max_voxels ? nvb : max_voxels;
+        batch_splits[b + 1] = acc;
+    }
+    stats[0] = acc;
+    stats[1] = n > 0 ? (int64_t)cnt[flags[n]] : 0;
+}
+
+__global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const int* __restrict__ flags,
+                         int64_t n, const int* __restrict__ hp, const int* __restrict__ fv, const int* __restrict__ cnt,
+                         const int64_t* __restrict__ batch_splits, VoxParams P, int32_t* __restrict__ coords,
+                         int64_t* __restrict__ pidx, int64_t* __restrict__ prs) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) prs[0] = 0;
+    if (v >= n || v >= flags[n]) return;
+    const int h = hp[v];
+    const u64 key = keys[h];
+    const int b = (int)(key / (u64)P.cells);
+    const long long rank = v - fv[b];
+    if (rank >= P.max_voxels) return;
+    const int64_t ov = batch_splits[b] + rank;
+    const long long lin = (long long)(key - (u64)b * (u64)P.cells);
+    coords[3 * ov + 0] = (int32_t)(lin % P.G[0]);
+    coords[3 * ov + 1] = (int32_t)((lin / P.G[0]) % P.G[1]);
+    coords[3 * ov + 2] = (int32_t)(lin / (P.G[0] * P.G[1]));
+    const int64_t o = cnt[v];
+    const int c = cnt[v + 1] - cnt[v];
+    prs[ov + 1] = cnt[v + 1];
+    for (int j = 0; j < c; ++j) pidx[o + j] = (int64_t)vals[h + j];
+}
+
+// ---- grid subsample ------------------------------------------------------------------------------------
+constexpr int SUB_ITEM_SHIFT = 48;   // key = item << 48 | linear voxel id
+
+__global__ void sub_setup(const unsigned* __restrict__ bbox, Segs S, float dl, float* __restrict__ seg, int64_t* err) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S.batch) return;
+    float* o = seg + 8 * s;
+    if (seg_len(S, s) <= 0) {
+        for (int a = 0; a < 3; ++a) { o[a] = 0.f; o[3 + a] = __int_as_float(1); }
+        return;
+    }
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        const float mn = ord2f(bbox[6 * s + a]), mx = ord2f(bbox[6 * s + 3 + a]);
+        const float org = __fmul_rn(floorf(__fdiv_rn(mn, dl)), dl);
+        const float gf = floorf(__fdiv_rn(__fsub_rn(mx, org), dl));
+        int G = gf < 2.0e9f ? (int)gf + 1 : 0x7fffffff;
+        if (G < 1) G = 1;
+        o[a] = org;
+        o[3 + a] = __int_as_float(G);
+        cells *= (double)G;
+    }
+    if (cells >= 281474976710656.0) *err = 1;   // 2^48 voxels per item
+}
+
+__global__ void sub_keys(const float* __restrict__ pts, Segs S, int64_t n, float dl, const float* __restrict__ seg,
+                         u64* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* o = seg + 8 * s;
+    const float* p = pts + 3 * i;
+    long long c[3], G[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c[a] = (long long)floorf(__fdiv_rn(__fsub_rn(p[a], o[a]), dl));
+        G[a] = (long long)__float_as_int(o[3 + a]);
+    }
+    const u64 lin = (u64)(c[0] + G[0] * (c[1] + G[1] * c[2]));
+    keys[i] = ((u64)s << SUB_ITEM_SHIFT) | (lin & ((1ull << SUB_ITEM_SHIFT) - 1ull));
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void sub_lengths(const int* __restrict__ fv, int batch, int64_t* __restrict__ lengths, int64_t* __restrict__ stats) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) lengths[b] = fv[b + 1] - fv[b];
+    if (b == 0) stats[0] = fv[batch];
+}
+
+// one thread per output voxel: float32 sums in original point order, then / count
+__global__ void sub_fill(const uint32_t* __restrict__ vals, const int* __restrict__ flags, int64_t n,
+                         const int* __restrict__ hp, const float* __restrict__ pts, const float* __restrict__ feats,
+                         int64_t fdim, const int32_t* __restrict__ labels, float* __restrict__ out_pts,
+                         float* __restrict__ out_feats, int32_t* __restrict__ out_labels) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || v >= flags[n]) return;
+    const int h0 = hp[v], h1 = hp[v + 1];
+    const float cnt = (float)(h1 - h0);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int h = h0; h < h1; ++h) {
+        const float* p = pts + 3 * (int64_t)vals[h];
+        sx = __fadd_rn(sx, p[0]); sy = __fadd_rn(sy, p[1]); sz = __fadd_rn(sz, p[2]);
+    }
+    out_pts[3 * v + 0] = __fdiv_rn(sx, cnt);
+    out_pts[3 * v + 1] = __fdiv_rn(sy, cnt);
+    out_pts[3 * v + 2] = __fdiv_rn(sz, cnt);
+    if (feats && out_feats)
+        for (int64_t f = 0; f < fdim; ++f) {
+            float fs = 0.f;
+            for (int h = h0; h < h1; ++h) fs = __fadd_rn(fs, feats[(int64_t)vals[h] * fdim + f]);
+            out_feats[v * fdim + f] = __fdiv_rn(fs, cnt);
+        }
+    if (labels && out_labels) {     // majority vote, ties -> smallest label
+        int32_t bestl = 0; int bestc = -1;
+        for (int h = h0; h < h1; ++h) {
+            const int32_t l = labels[vals[h]];
+            int cc = 0;
+            for (int e = h0; e < h1; ++e) cc += (labels[vals[e]] == l) ? 1 : 0;
+            if (cc > bestc || (cc == bestc && l < bestl)) { bestc = cc; bestl = l; }
+        }
+        out_labels[v] = bestl;
+    }
+}
+
+#define VX_CHECK()                                                   \
+    do {                                                             \
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;   \
+    } while (0)
+
+// sort the pairs, flag the heads, scan, record head positions, first voxel per item
+static int group_pairs(const GroupWs& W, int64_t n, int key_bits, u64 key_invalid, u64 item_stride, int item_shift,
+                       hipStream_t st) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (n > 0) {
+        if (sort_pairs_u64(W.keys, W.vals, n, key_bits, W.sort, st)) return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL(group_heads, dim3(nb), dim3(256), 0, st, W.keys, n, key_invalid, W.flags);
+        VX_CHECK();
+        if (scan_inclusive_i32(W.flags + 1, n, W.block_sums, st)) return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL(group_headpos, dim3(nb), dim3(256), 0, st, W.keys, n, key_invalid, W.flags, W.hp);
+        VX_CHECK();
+    }
+    hipLaunchKernelGGL(group_first_voxel, dim3((unsigned)(W.batch + 1 + 63) / 64), dim3(64), 0, st, W.keys, n, W.flags,
+                       W.batch, item_stride, item_shift, W.fv);
+    VX_CHECK();
+    return 0;
+}
+
+static int vox_params(const float* vs, const float* rmin, const float* rmax, int64_t max_points, int64_t max_voxels,
+                      int64_t batch, VoxParams* P) {
+    if (!vs || !rmin || !rmax || max_points <= 0 || max_voxels <= 0) return ML3D_E_INVALID;
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(vs[a] > 0.f) || !(rmax[a] >= rmin[a])) return ML3D_E_INVALID;
+        P->vs[a] = vs[a]; P->rmin[a] = rmin[a]; P->rmax[a] = rmax[a];
+        // largest coordinate a kept point can take is int((max - min) / vs), all in float32
+        float q = (float)(rmax[a] - rmin[a]) / vs[a];
+        if (!(q < 2.0e9f)) return ML3D_E_UNSUPPORTED;
+        P->G[a] = (long long)q + 1;
+        if (P->G[a] < 1) P->G[a] = 1;
+        cells *= (double)P->G[a];
+    }
+    if (cells * (double)(batch + 1) >= 9.0e18) return ML3D_E_UNSUPPORTED;
+    P->cells = P->G[0] * P->G[1] * P->G[2];
+    P->max_points = max_points;
+    P->max_voxels = max_voxels;
+    return 0;
+}
+
+}  // namespace ml3d
+
+using namespace ml3d;
+
+extern "C" size_t ml3d_voxelize_workspace_bytes(int64_t n_points, int64_t batch) {
+    if (n_points < 0 || batch <= 0) return 0;
+    return group_ws_bytes(n_points, batch);
+}
+
+extern "C" int ml3d_voxelize_count(const float* points, int64_t point_stride, const int64_t* row_splits, int64_t batch,
+                                   int64_t n_points, const float* voxel_size_host, const float* range_min_host,
+                                   const float* range_max_host, int64_t max_points_per_voxel, int64_t max_voxels,
+                                   int64_t* out_batch_splits, int64_t* out_stats, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!row_splits || batch <= 0 || n_points < 0 || n_points > 0x7ffffff0ll || point_stride < 3 ||
+        !out_batch_splits || !out_stats || (n_points > 0 && !points))
+        return ML3D_E_INVALID;
+    VoxParams P;
+    int rc = vox_params(voxel_size_host, range_min_host, range_max_host, max_points_per_voxel, max_voxels, batch, &P);
+    if (rc) return rc;
+    GroupWs W;
+    if (!group_ws_carve(workspace, workspace_bytes, n_points, batch, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Segs S = {row_splits, 0, 0, (int)batch};
+    const int64_t n = n_points;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    const u64 inval = (u64)batch * (u64)P.cells;
+    if (n > 0) {
+        hipLaunchKernelGGL(vox_keys, dim3(nb), dim3(256), 0, st, points, point_stride, S, n, P, W.keys, W.vals);
+        VX_CHECK();
+    }
+    rc = group_pairs(W, n, bits_for(inval), inval, (u64)P.cells, -1, st);
+    if (rc) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(vox_counts, dim3(nb), dim3(256), 0, st, W.keys, W.flags, n, W.hp, W.fv, P, W.cnt);
+        VX_CHECK();
+        if (scan_inclusive_i32(W.cnt + 1, n, W.block_sums, st)) return ML3D_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(vox_batch_splits, dim3(1), dim3(64), 0, st, W.fv, (int)batch, P.max_voxels, W.cnt, W.flags, n,
+                       out_batch_splits, out_stats);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* voxel_size_host,
+                                  const float* range_min_host, const float* range_max_host,
+                                  int64_t max_points_per_voxel, int64_t max_voxels, const int64_t* batch_splits,
+                                  int32_t* out_voxel_coords, int64_t* out_point_indices, int64_t* out_point_row_splits,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch <= 0 || n_points < 0 || !batch_splits || !out_point_row_splits) return ML3D_E_INVALID;
+    VoxParams P;
+    int rc = vox_params(voxel_size_host, range_min_host, range_max_host, max_points_per_voxel, max_voxels, batch, &P);
+    if (rc) return rc;
+    GroupWs W;
+    if (!group_ws_carve(workspace, workspace_bytes, n_points, batch, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_points == 0) {
+        (void)hipMemsetAsync(out_point_row_splits, 0, sizeof(int64_t), st);
+        return 0;
+    }
+    hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, W.keys, W.vals, W.flags,
+                       n_points, W.hp, W.fv, W.cnt, batch_splits, P, out_voxel_coords, out_point_indices,
+                       out_point_row_splits);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" size_t ml3d_subsample_workspace_bytes(int64_t n_points, int64_t batch) {
+    if (n_points < 0 || batch <= 0) return 0;
+    return group_ws_bytes(n_points, batch);
+}
+
+extern "C" int ml3d_subsample_count(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
+                                    float sample_dl, int64_t* out_lengths, int64_t* out_stats, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!row_splits || batch <= 0 || batch > 65535 || n_points < 0 || n_points > 0x7ffffff0ll || !(sample_dl > 0.f) ||
+        !out_lengths || !out_stats || (n_points > 0 && !points))
+        return ML3D_E_INVALID;
+    GroupWs W;
+    if (!group_ws_carve(workspace, workspace_bytes, n_points, batch, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Segs S = {row_splits, 0, 0, (int)batch};
+    const int64_t n = n_points;
+    (void)hipMemsetAsync(out_stats, 0, 2 * sizeof(int64_t), st);
+    if (bbox_compute(points, S, n, W.bbox, W.occ, st)) return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL(sub_setup, dim3((unsigned)(batch + 63) / 64), dim3(64), 0, st, W.bbox, S, sample_dl, W.seg,
+                       out_stats + 1);
+    VX_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(sub_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, points, S, n, sample_dl, W.seg,
+                           W.keys, W.vals);
+        VX_CHECK();
+    }
+    int rc = group_pairs(W, n, SUB_ITEM_SHIFT + bits_for((u64)batch), ~0ull, 0ull, SUB_ITEM_SHIFT, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sub_lengths, dim3((unsigned)(batch + 63) / 64), dim3(64), 0, st, W.fv, (int)batch, out_lengths,
+                       out_stats);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" int ml3d_subsample_fill(const float* points, const float* features, int64_t feature_dim,
+                                   const int32_t* labels, int64_t batch, int64_t n_points, float* out_points,
+                                   float* out_features, int32_t* out_labels, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (batch <= 0 || n_points < 0 || feature_dim < 0) return ML3D_E_INVALID;
+    if (n_points == 0) return 0;
+    if (!points || !out_points) return ML3D_E_INVALID;
+    GroupWs W;
+    if (!group_ws_carve(workspace, workspace_bytes, n_points, batch, &W)) return ML3D_E_WORKSPACE;
+    hipLaunchKernelGGL(sub_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W.vals,
+                       W.flags, n_points, W.hp, points, features, feature_dim, labels, out_points, out_features,
+                       out_labels);
+    VX_CHECK();
+    return 0;
+}

@@ -20,6 +20,16 @@ SYMBOLS = [
     "ml3d_abi_version",
     "ml3d_knn_workspace_bytes",
     "ml3d_knn_search",
+    "ml3d_radius_workspace_bytes",
+    "ml3d_radius_count",
+    "ml3d_radius_fill",
+    "ml3d_ragged_to_dense",
+    "ml3d_voxelize_workspace_bytes",
+    "ml3d_voxelize_count",
+    "ml3d_voxelize_fill",
+    "ml3d_subsample_workspace_bytes",
+    "ml3d_subsample_count",
+    "ml3d_subsample_fill",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -56,6 +66,27 @@ def bind(lib):
     lib.ml3d_knn_workspace_bytes.argtypes = [i64, i64, i64]
     lib.ml3d_knn_search.restype = C.c_int
     lib.ml3d_knn_search.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]
+    f32 = C.c_float
+    lib.ml3d_radius_workspace_bytes.restype = sz
+    lib.ml3d_radius_workspace_bytes.argtypes = [i64, i64, i64, i64]
+    lib.ml3d_radius_count.restype = C.c_int
+    lib.ml3d_radius_count.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_radius_fill.restype = C.c_int
+    lib.ml3d_radius_fill.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, i64, i32, i64, C.c_int32, vp, vp, vp, sz, vp]
+    lib.ml3d_ragged_to_dense.restype = C.c_int
+    lib.ml3d_ragged_to_dense.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+    lib.ml3d_voxelize_workspace_bytes.restype = sz
+    lib.ml3d_voxelize_workspace_bytes.argtypes = [i64, i64]
+    lib.ml3d_voxelize_count.restype = C.c_int
+    lib.ml3d_voxelize_count.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp, i64, i64, vp, vp, vp, sz, vp]
+    lib.ml3d_voxelize_fill.restype = C.c_int
+    lib.ml3d_voxelize_fill.argtypes = [i64, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_subsample_workspace_bytes.restype = sz
+    lib.ml3d_subsample_workspace_bytes.argtypes = [i64, i64]
+    lib.ml3d_subsample_count.restype = C.c_int
+    lib.ml3d_subsample_count.argtypes = [vp, vp, i64, i64, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_subsample_fill.restype = C.c_int
+    lib.ml3d_subsample_fill.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

@@ -135,3 +135,225 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
                                      t_n, t_i, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _abi.check(rc, "ml3d_randla_forward")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# fixed-radius search / ragged_to_dense / voxelize / subsample  
+# ---------------------------------------------------------------------------------------------------
+RadiusResult = namedtuple("RadiusResult", ["neighbors_index", "neighbors_row_splits", "neighbors_distance"])
+VoxelizeResult = namedtuple("VoxelizeResult", ["voxel_coords", "voxel_point_indices", "voxel_point_row_splits",
+                                               "voxel_batch_splits"])
+
+
+def _splits(rs, n, dev):
+    if rs is None:
+        return torch.tensor([0, int(n)], dtype=torch.int64, device=dev)
+    return rs.to(device=dev, dtype=torch.int64).contiguous()
+
+
+class _RadiusPlan:
+    """Phase 1 of the fixed-radius search: grid + per-query counts (kept on the device)."""
+
+    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits):
+        lib = _abi.get()
+        _need_gpu(points, queries)
+        self.points = points.contiguous().float()
+        self.queries = self.points if queries is points else queries.contiguous().float()
+        dev = self.points.device
+        self.ns, self.nq = self.points.shape[0], self.queries.shape[0]
+        self.prs = _splits(points_row_splits, self.ns, dev)
+        self.qrs = _splits(queries_row_splits, self.nq, dev)
+        if self.prs.numel() != self.qrs.numel():
+            raise RuntimeError("fixed_radius_search: points and queries must have the same batch size")
+        self.batch = self.prs.numel() - 1
+        self.radius = float(radius)
+        self.row_splits = torch.empty(self.nq + 1, dtype=torch.int64, device=dev)
+        self.stats = torch.empty(2, dtype=torch.int64, device=dev)
+        # room for ~96 neighbours per query before the workspace has to grow for the spill area
+        self.ws_total = 96 * self.nq
+        self.wsb = lib.ml3d_radius_workspace_bytes(self.ns, self.nq, self.batch, self.ws_total)
+        self.ws = _ws(self.wsb, dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_radius_count(self.points.data_ptr(), self.prs.data_ptr(), self.queries.data_ptr(),
+                                       self.qrs.data_ptr(), self.batch, self.ns, self.nq, self.radius,
+                                       self.row_splits.data_ptr(), self.stats.data_ptr(), self.ws.data_ptr(), self.wsb,
+                                       _stream())
+        _abi.check(rc, "ml3d_radius_count")
+        self.total, self.longest = (int(x) for x in self.stats.tolist())     # the one host sync (the reference's .item())
+
+    def fill(self, dense_cols=0, pad_value=0, index_local=False, return_distances=False):
+        lib = _abi.get()
+        dev = self.points.device
+        if self.total > self.ws_total:       # grow: the grid part of the workspace is relocatable
+            wsb = lib.ml3d_radius_workspace_bytes(self.ns, self.nq, self.batch, self.total)
+            ws = _ws(wsb, dev)
+            ws[:self.wsb].copy_(self.ws)
+            if (ws.data_ptr() - self.ws.data_ptr()) % 256:
+                raise RuntimeError("fixed_radius_search: allocator returned a differently aligned workspace")
+            self.ws, self.wsb, self.ws_total = ws, wsb, self.total
+        shape = (self.nq, int(dense_cols)) if dense_cols > 0 else (self.total,)
+        idx = torch.empty(shape, dtype=torch.int32, device=dev)
+        d2 = torch.empty(shape, dtype=torch.float32, device=dev) if return_distances else None
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_radius_fill(self.points.data_ptr(), self.prs.data_ptr(), self.queries.data_ptr(),
+                                      self.qrs.data_ptr(), self.batch, self.ns, self.nq, self.radius,
+                                      self.row_splits.data_ptr(), self.total, 1 if index_local else 0, int(dense_cols),
+                                      int(pad_value), idx.data_ptr(), d2.data_ptr() if d2 is not None else None,
+                                      self.ws.data_ptr(), self.wsb, _stream())
+        _abi.check(rc, "ml3d_radius_fill")
+        return idx, d2
+
+
+def fixed_radius_search(points, queries, radius, points_row_splits=None, queries_row_splits=None,
+                        return_distances=False):
+    """Functional form of ``open3d.ml.torch.layers.FixedRadiusSearch`` (ml3d/torch/models/kpconv.py:2021-2026):
+    ragged neighbours (d2 <= r^2), each row ascending (d2, index), GLOBAL int32 indices."""
+    plan = _RadiusPlan(points, queries, radius, points_row_splits, queries_row_splits)
+    idx, d2 = plan.fill(return_distances=return_distances)
+    return RadiusResult(idx, plan.row_splits, d2 if d2 is not None else torch.empty(0, device=idx.device))
+
+
+def radius_neighbors_dense(queries, supports, q_lengths, s_lengths, radius, max_cols=None):
+    """``batch_neighbors`` (ml3d/torch/models/kpconv.py:2002-2034) on the GPU: dense int32 [Nq, max_nbrs]
+    neighbour matrix padded with the shadow index Ns; search + ragged_to_dense fused in one fill kernel."""
+    dev = supports.device
+    qs = torch.zeros(len(q_lengths) + 1, dtype=torch.int64)
+    ss = torch.zeros(len(s_lengths) + 1, dtype=torch.int64)
+    qs[1:] = torch.cumsum(torch.as_tensor(q_lengths, dtype=torch.int64).cpu(), 0)
+    ss[1:] = torch.cumsum(torch.as_tensor(s_lengths, dtype=torch.int64).cpu(), 0)
+    plan = _RadiusPlan(supports, queries, radius, ss.to(dev), qs.to(dev))
+    cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
+    if plan.nq == 0 or cols == 0:
+        return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
+    idx, _ = plan.fill(dense_cols=cols, pad_value=supports.shape[0])
+    return idx
+
+
+def ragged_to_dense(values, row_splits, out_col_size, default_value):
+    """``open3d.ml.torch.ops.ragged_to_dense`` (kpconv.py:2030, point_pillars.py:364)."""
+    lib = _abi.get()
+    _need_gpu(values, row_splits)
+    values = values.contiguous()
+    if values.element_size() not in (4, 8):
+        raise RuntimeError("ragged_to_dense: 4- or 8-byte element types only")
+    inner = tuple(values.shape[1:])
+    elem = values.element_size()
+    for s in inner:
+        elem *= s
+    dev = values.device
+    dv = torch.as_tensor(default_value, dtype=values.dtype).to(dev).expand(inner if inner else ()).contiguous()
+    rs = row_splits.to(device=dev, dtype=torch.int64).contiguous()
+    rows = rs.numel() - 1
+    out = torch.empty((rows, int(out_col_size)) + inner, dtype=values.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_ragged_to_dense(values.data_ptr(), rs.data_ptr(), rows, int(out_col_size), elem, dv.data_ptr(),
+                                      out.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_ragged_to_dense")
+    return out
+
+
+def _host3(x):
+    t = torch.as_tensor(x, dtype=torch.float32).detach().cpu().contiguous().reshape(-1)
+    if t.numel() != 3:
+        raise RuntimeError("voxelize: voxel_size / range tensors must have 3 elements")
+    return t
+
+
+def voxelize(points, row_splits, voxel_size, points_range_min, points_range_max,
+             max_points_per_voxel=2 ** 62, max_voxels=2 ** 62):
+    """``open3d.ml.torch.ops.voxelize`` (ml3d/torch/models/point_pillars.py:354-357).  ``points`` may be the
+    strided view ``points[:, :3]`` of an [N, C] tensor (no copy).  voxel_size / range_* are CPU tensors as in
+    the reference (point_pillars.py:317-320)."""
+    lib = _abi.get()
+    _need_gpu(points)
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype != torch.float32:
+        raise RuntimeError("voxelize: points must be float32 [N, 3]")
+    if points.stride(1) != 1:
+        points = points.contiguous()
+    stride = points.stride(0) if points.shape[0] > 1 else 3
+    dev = points.device
+    n = points.shape[0]
+    rs = _splits(row_splits, n, dev)
+    B = rs.numel() - 1
+    vs, mn, mx = _host3(voxel_size), _host3(points_range_min), _host3(points_range_max)
+    mp, mv = int(min(max_points_per_voxel, 2 ** 62)), int(min(max_voxels, 2 ** 62))
+    wsb = lib.ml3d_voxelize_workspace_bytes(n, B)
+    ws = _ws(wsb, dev)
+    bs = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    stats = torch.empty(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_voxelize_count(points.data_ptr(), stride, rs.data_ptr(), B, n, vs.data_ptr(), mn.data_ptr(),
+                                     mx.data_ptr(), mp, mv, bs.data_ptr(), stats.data_ptr(), ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_voxelize_count")
+        M, K = (int(x) for x in stats.tolist())
+        coords = torch.empty((M, 3), dtype=torch.int32, device=dev)
+        pidx = torch.empty(K, dtype=torch.int64, device=dev)
+        prs = torch.empty(M + 1, dtype=torch.int64, device=dev)
+        rc = lib.ml3d_voxelize_fill(B, n, vs.data_ptr(), mn.data_ptr(), mx.data_ptr(), mp, mv, bs.data_ptr(),
+                                    coords.data_ptr(), pidx.data_ptr(), prs.data_ptr(), ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_voxelize_fill")
+    return VoxelizeResult(coords, pidx, prs, bs)
+
+
+def subsample_batch(points, batches_len, features=None, classes=None, sampleDl=0.1, max_p=0, verbose=0):
+    """``open3d.ml.contrib.subsample_batch`` (ml3d/torch/models/kpconv.py:2098-2155) for CUDA tensors:
+    returns (points, lengths[, features][, classes]) — voxel barycentres per batch item, ascending voxel key."""
+    lib = _abi.get()
+    _need_gpu(points, features, classes)
+    points = points.contiguous().float()
+    dev = points.device
+    n = points.shape[0]
+    lens = torch.as_tensor(batches_len, dtype=torch.int64).cpu()
+    rs = torch.zeros(lens.numel() + 1, dtype=torch.int64)
+    rs[1:] = torch.cumsum(lens, 0)
+    if int(rs[-1]) != n:
+        raise RuntimeError("subsample_batch: batches_len does not sum to the number of points")
+    rs = rs.to(dev)
+    B = lens.numel()
+    feats = None if features is None else features.contiguous().float()
+    labs = None if classes is None else classes.contiguous().to(torch.int32).reshape(-1)
+    wsb = lib.ml3d_subsample_workspace_bytes(n, B)
+    ws = _ws(wsb, dev)
+    out_len = torch.empty(B, dtype=torch.int64, device=dev)
+    stats = torch.empty(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_subsample_count(points.data_ptr(), rs.data_ptr(), B, n, float(sampleDl), out_len.data_ptr(),
+                                      stats.data_ptr(), ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_subsample_count")
+        M, err = (int(x) for x in stats.tolist())
+        if err:
+            raise RuntimeError("subsample: a batch item spans >= 2^48 voxels at this sampleDl (unsupported)")
+        fd = 0 if feats is None else feats.shape[1]
+        op = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        of = None if feats is None else torch.empty((M, fd), dtype=torch.float32, device=dev)
+        ol = None if labs is None else torch.empty(M, dtype=torch.int32, device=dev)
+        rc = lib.ml3d_subsample_fill(points.data_ptr(), None if feats is None else feats.data_ptr(), fd,
+                                     None if labs is None else labs.data_ptr(), B, n, op.data_ptr(),
+                                     None if of is None else of.data_ptr(), None if ol is None else ol.data_ptr(),
+                                     ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_subsample_fill")
+    if max_p and max_p > 0:     # kpconv.py: keep at most max_p points per batch item
+        keep = []
+        o = 0
+        ln = out_len.tolist()
+        for b in range(B):
+            keep.append(torch.arange(o, o + min(ln[b], int(max_p)), device=dev))
+            o += ln[b]
+        keep = torch.cat(keep) if keep else torch.empty(0, dtype=torch.int64, device=dev)
+        op = op[keep]
+        of = None if of is None else of[keep]
+        ol = None if ol is None else ol[keep]
+        out_len = torch.clamp(out_len, max=int(max_p))
+    out = [op, out_len.to(torch.int32)]
+    if of is not None:
+        out.append(of)
+    if ol is not None:
+        out.append(ol)
+    return tuple(out)
+
+
+def subsample(points, features=None, classes=None, sampleDl=0.1, verbose=0):
+    """``open3d.ml.contrib.subsample`` (ml3d/datasets/utils/dataprocessing.py:32-49)."""
+    r = subsample_batch(points, [points.shape[0]], features, classes, sampleDl)
+    r = (r[0],) + tuple(r[2:])
+    return r[0] if len(r) == 1 else r

@@ -82,3 +82,46 @@ def semantickitti_batch(first_frame, batch, num_points=45056):
 def uniform_cloud(seed, n, extent=(10.0, 10.0, 2.0)):
     rng = np.random.default_rng(seed)
     return (rng.random((n, 3), dtype=np.float32) * np.asarray(extent, np.float32)).astype(np.float32)
+
+
+def kitti_sweep(frame_id):
+    """PointPillars / KITTI-shaped raw sweep: [~120k, 4] f32 = xyz + intensity U(0,1) (SURVEY.md §8d
+    frame 3).  seed = 3000 + frame_id."""
+    return lidar_sweep(3000 + int(frame_id), with_intensity=True)
+
+
+def toronto3d_sphere(frame_id, max_points=10000, radius=4.0, grid=0.08):
+    """KPConv / Toronto3D-shaped input sphere (SURVEY.md §8d frame 2): an urban mobile-laser-scan scene
+    (ground plane, two facades, poles, car-sized boxes; ~1000 pts/m^2 before subsampling) grid-subsampled
+    at ``grid`` and cropped to the ``max_points`` points nearest to the sphere centre within ``radius``.
+    Returns [n, 3] f32 centred on the sphere centre.  seed = 2000 + frame_id."""
+    rng = np.random.default_rng(2000 + int(frame_id))
+    R = radius * 1.05
+
+    def plane(n, origin, u, v):
+        a = rng.random((n, 2))
+        return origin + a[:, :1] * u + a[:, 1:] * v
+
+    parts = [plane(int(1000 * (2 * R) ** 2 * 0.6), np.array([-R, -R, 0.0]), np.array([2 * R, 0, 0]), np.array([0, 2 * R, 0]))]
+    for y in (-2.8, 3.1):                                            # facades
+        parts.append(plane(int(600 * 2 * R * 5), np.array([-R, y, 0.0]), np.array([2 * R, 0, 0]), np.array([0, 0, 5.0])))
+    for _ in range(6):                                               # poles
+        c = rng.uniform(-R, R, 2)
+        th, z = rng.uniform(0, 2 * np.pi, 1500), rng.uniform(0, 4.5, 1500)
+        parts.append(np.stack([c[0] + 0.12 * np.cos(th), c[1] + 0.12 * np.sin(th), z], 1))
+    for _ in range(3):                                               # cars
+        c = np.append(rng.uniform(-R + 1, R - 1, 2), 0.0)
+        s = np.array([rng.uniform(3.5, 4.5), rng.uniform(1.6, 1.9), rng.uniform(1.3, 1.6)])
+        parts.append(plane(6000, c + [0, 0, s[2]], [s[0], 0, 0], [0, s[1], 0]))
+        parts.append(plane(5000, c, [s[0], 0, 0], [0, 0, s[2]]))
+        parts.append(plane(5000, c + [0, s[1], 0], [s[0], 0, 0], [0, 0, s[2]]))
+    pts = np.concatenate(parts).astype(np.float32)
+    pts += rng.normal(0, 0.005, pts.shape).astype(np.float32)
+    sub = _grid_barycentre(pts, grid)
+    centre = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 1.0], np.float32)
+    d2 = ((sub - centre) ** 2).sum(1)
+    sel = np.nonzero(d2 < radius * radius)[0]
+    if sel.size > max_points:
+        sel = sel[np.argsort(d2[sel], kind="stable")[:max_points]]
+    sel = sel[rng.permutation(sel.size)]
+    return np.ascontiguousarray(sub[sel] - centre, np.float32)

@@ -81,3 +81,109 @@ def randla_forward(cfg, sd, points, feats, nbr, itp):
                                _abi.ptr_table([x.ctypes.data for x in nbr]), _abi.ptr_table([x.ctypes.data for x in itp]),
                                out.ctypes.data, ws.ctypes.data, wsb, None)
     return rc, out
+
+
+def _ws(nbytes):
+    return np.zeros(int(nbytes) + 64, np.uint8)
+
+
+def radius(points, psplits, queries, qsplits, r, dense=False, local=False, with_d2=False):
+    """-> (neighbors_index, row_splits[, d2]) ragged, or the dense [Nq, max] matrix padded with Ns."""
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    ps = np.ascontiguousarray(psplits, np.int64)
+    qs = np.ascontiguousarray(qsplits, np.int64)
+    B, ns, nq = len(ps) - 1, len(points), len(queries)
+    rs = np.zeros(nq + 1, np.int64)
+    stats = np.zeros(2, np.int64)
+    wsb = L.ml3d_radius_workspace_bytes(ns, nq, B, 0)
+    ws = _ws(wsb)
+    rc = L.ml3d_radius_count(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                             rs.ctypes.data, stats.ctypes.data, ws.ctypes.data, wsb, None)
+    assert rc == 0, rc
+    total, longest = int(stats[0]), int(stats[1])
+    assert total == rs[-1]
+    wsb2 = L.ml3d_radius_workspace_bytes(ns, nq, B, total)
+    ws2 = _ws(wsb2)
+    cols = longest if dense else 0
+    idx = np.full((nq, cols) if dense else (total,), -5, np.int32)
+    d2 = np.zeros(idx.shape, np.float32) if with_d2 else None
+    # count again into the larger buffer (a fresh numpy buffer may have a different 256-byte phase)
+    rc = L.ml3d_radius_count(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                             rs.ctypes.data, stats.ctypes.data, ws2.ctypes.data, wsb2, None)
+    assert rc == 0, rc
+    rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                            rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
+                            None if d2 is None else d2.ctypes.data, ws2.ctypes.data, wsb2, None)
+    assert rc == 0, rc
+    if dense:
+        return idx
+    return (idx, rs, d2) if with_d2 else (idx, rs)
+
+
+def ragged_to_dense(values, row_splits, cols, default):
+    L = lib()
+    values = np.ascontiguousarray(values)
+    rs = np.ascontiguousarray(row_splits, np.int64)
+    inner = values.shape[1:]
+    dv = np.ascontiguousarray(np.broadcast_to(np.asarray(default, values.dtype), inner))
+    elem = int(values.dtype.itemsize * int(np.prod(inner, dtype=np.int64)))
+    out = np.empty((len(rs) - 1, cols) + tuple(inner), values.dtype)
+    rc = L.ml3d_ragged_to_dense(values.ctypes.data, rs.ctypes.data, len(rs) - 1, cols, elem, dv.ctypes.data,
+                                out.ctypes.data, None)
+    assert rc == 0, rc
+    return out
+
+
+def voxelize(points, row_splits, vs, rmin, rmax, max_points=2**62, max_voxels=2**62):
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    rs = np.ascontiguousarray(row_splits, np.int64)
+    vs, rmin, rmax = (np.ascontiguousarray(x, np.float32) for x in (vs, rmin, rmax))
+    B, n = len(rs) - 1, len(points)
+    stride = points.shape[1]
+    wsb = L.ml3d_voxelize_workspace_bytes(n, B)
+    ws = _ws(wsb)
+    bs = np.zeros(B + 1, np.int64)
+    stats = np.zeros(2, np.int64)
+    rc = L.ml3d_voxelize_count(points.ctypes.data, stride, rs.ctypes.data, B, n, vs.ctypes.data, rmin.ctypes.data,
+                               rmax.ctypes.data, max_points, max_voxels, bs.ctypes.data, stats.ctypes.data,
+                               ws.ctypes.data, wsb, None)
+    assert rc == 0, rc
+    M, K = int(stats[0]), int(stats[1])
+    coords = np.full((M, 3), -1, np.int32)
+    pidx = np.full(K, -1, np.int64)
+    prs = np.full(M + 1, -1, np.int64)
+    rc = L.ml3d_voxelize_fill(B, n, vs.ctypes.data, rmin.ctypes.data, rmax.ctypes.data, max_points, max_voxels,
+                              bs.ctypes.data, coords.ctypes.data, pidx.ctypes.data, prs.ctypes.data, ws.ctypes.data,
+                              wsb, None)
+    assert rc == 0, rc
+    return coords, pidx, prs, bs
+
+
+def subsample_batch(points, lengths, dl, features=None, labels=None):
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    rs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    B, n = len(rs) - 1, len(points)
+    feats = None if features is None else np.ascontiguousarray(features, np.float32)
+    labs = None if labels is None else np.ascontiguousarray(labels, np.int32)
+    wsb = L.ml3d_subsample_workspace_bytes(n, B)
+    ws = _ws(wsb)
+    lens = np.zeros(B, np.int64)
+    stats = np.zeros(2, np.int64)
+    rc = L.ml3d_subsample_count(points.ctypes.data, rs.ctypes.data, B, n, dl, lens.ctypes.data, stats.ctypes.data,
+                                ws.ctypes.data, wsb, None)
+    assert rc == 0 and stats[1] == 0, (rc, stats)
+    M = int(stats[0])
+    op = np.zeros((M, 3), np.float32)
+    fd = 0 if feats is None else feats.shape[1]
+    of = None if feats is None else np.zeros((M, fd), np.float32)
+    ol = None if labs is None else np.zeros(M, np.int32)
+    rc = L.ml3d_subsample_fill(points.ctypes.data, None if feats is None else feats.ctypes.data, fd,
+                               None if labs is None else labs.ctypes.data, B, n, op.ctypes.data,
+                               None if of is None else of.ctypes.data, None if ol is None else ol.ctypes.data,
+                               ws.ctypes.data, wsb, None)
+    assert rc == 0, rc
+    return op, lens, of, ol

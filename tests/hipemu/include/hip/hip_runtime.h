@@ -210,6 +210,7 @@ static inline unsigned long long __ballot(int pred) {
         if (vw.peer_valid(l)) { int q; memcpy(&q, vw.peer(l), sizeof(int)); if (q) m |= (1ull << l); }
     return m;
 }
+static inline void __builtin_amdgcn_wave_barrier() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
 static inline int __any(int pred) { return __ballot(pred) != 0ull; }
 static inline int __all(int pred) {
     int p = pred ? 1 : 0;

@@ -1,0 +1,126 @@
+"""CPU: fixed-radius search, ragged_to_dense, voxelize and grid subsample — the SAME .hip sources the
+GPU runs, executed through the host emulator (tests/hipemu) and compared bit for bit with the oracle."""
+import numpy as np
+import pytest
+
+import emu
+import synth_data
+from oracle import ops as oops
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="clang++ for the host emulator not found")
+
+
+def _cloud(seed, n, kind="vol"):
+    rng = np.random.default_rng(seed)
+    if kind == "vol":
+        return (rng.random((n, 3), dtype=np.float32) * 4).astype(np.float32)
+    if kind == "surf":
+        return (rng.random((n, 3), dtype=np.float32) * np.array([8, 8, 0.05], np.float32)).astype(np.float32)
+    return np.repeat(rng.random((n // 4, 3), dtype=np.float32), 4, 0)     # duplicates: d2 ties
+
+
+@pytest.mark.parametrize("kind,n,r", [("vol", 3000, 0.35), ("surf", 4000, 0.3), ("dup", 800, 0.2), ("vol", 50, 10.0)])
+def test_radius_self_search_matches_oracle(kind, n, r):
+    p = _cloud(n, n, kind)
+    idx, rs, d2 = emu.radius(p, [0, n], p, [0, n], r, with_d2=True)
+    ref = oops.fixed_radius_search(p, p, r, return_distances=True)
+    assert np.array_equal(rs, ref.neighbors_row_splits)
+    assert np.array_equal(idx, ref.neighbors_index)
+    assert np.array_equal(d2, ref.neighbors_distance)
+
+
+def test_radius_batched_queries_differ_from_supports_and_empty_item():
+    p = _cloud(1, 3000)
+    q = (_cloud(2, 700) * 1.3 - 0.5).astype(np.float32)       # some queries outside the support box
+    ps, qs = [0, 1200, 1200, 3000], [0, 300, 450, 700]         # item 1 has queries but no supports
+    idx, rs = emu.radius(p, ps, q, qs, 0.4)
+    ref = oops.fixed_radius_search(p, q, 0.4, ps, qs)
+    assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
+    assert (rs[301:451] == rs[300]).all()
+
+
+def test_radius_rows_longer_than_the_lds_stage_spill_correctly():
+    p = (_cloud(3, 900) * 0.1).astype(np.float32)               # 900 points in a 0.4 box: every row ~900 long
+    idx, rs = emu.radius(p, [0, 900], p[:40], [0, 40], 1.0)
+    ref = oops.fixed_radius_search(p, p[:40], 1.0)
+    assert (np.diff(rs) > 256).all()
+    assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
+
+
+def test_radius_dense_is_batch_neighbors_of_the_reference():
+    # kpconv.py:2002-2034: ragged_to_dense(idx, splits, max_nbrs, default = Ns)
+    p = _cloud(4, 2500, "surf")
+    ps = [0, 1000, 2500]
+    dense = emu.radius(p, ps, p, ps, 0.25, dense=True)
+    ref = oops.fixed_radius_search(p, p, 0.25, ps, ps)
+    cols = int(np.diff(ref.neighbors_row_splits).max())
+    ref_dense = oops.ragged_to_dense(ref.neighbors_index.reshape(-1, 1), ref.neighbors_row_splits, cols,
+                                     np.array([2500], np.int32))[:, :, 0]
+    assert np.array_equal(dense, ref_dense)
+    assert (dense[:, 0] == np.arange(2500)).all()               # the closest neighbour of a point is itself
+
+
+def test_ragged_to_dense_matches_oracle():
+    rng = np.random.default_rng(0)
+    rs = np.concatenate([[0], np.cumsum(rng.integers(0, 9, 200))])
+    vals = rng.random((rs[-1], 4), dtype=np.float32)
+    out = emu.ragged_to_dense(vals, rs, 5, np.array([-1, -2, -3, -4], np.float32))
+    assert np.array_equal(out, oops.ragged_to_dense(vals, rs, 5, np.array([-1, -2, -3, -4], np.float32)))
+    iv = rng.integers(0, 1000, (rs[-1], 1)).astype(np.int32)
+    assert np.array_equal(emu.ragged_to_dense(iv, rs, 12, np.array([777], np.int32)),
+                          oops.ragged_to_dense(iv, rs, 12, np.array([777], np.int32)))
+
+
+def test_voxelize_upstream_docstring_example():
+    pts = np.array([[.1, .1, .1], [.5, .5, .5], [1.7, 1.7, 1.7], [1.8, 1.8, 1.8], [9.3, 9.4, 9.4]], np.float32)
+    c, pi, prs, bs = emu.voxelize(pts, [0, 5], [1, 1, 1], [0, 0, 0], [2, 2, 2])
+    assert c.tolist() == [[0, 0, 0], [1, 1, 1]] and pi.tolist() == [0, 1, 2, 3]
+    assert prs.tolist() == [0, 2, 4] and bs.tolist() == [0, 2]
+
+
+@pytest.mark.parametrize("max_points,max_voxels", [(2**62, 2**62), (5, 2**62), (32, 150), (1, 7)])
+def test_voxelize_matches_oracle_batched_with_limits(max_points, max_voxels):
+    rng = np.random.default_rng(11)
+    pts = np.concatenate([rng.random((4000, 3), dtype=np.float32) * [80, 90, 5] + [-5, -45, -3.5],
+                          rng.random((4000, 1), dtype=np.float32)], 1).astype(np.float32)   # [N,4]: stride 4
+    rs = [0, 1500, 1500, 4000]
+    vs, mn, mx = [0.16 * 8, 0.16 * 8, 4], [0, -39.68, -3], [69.12, 39.68, 1]
+    c, pi, prs, bs = emu.voxelize(pts, rs, vs, mn, mx, max_points, max_voxels)
+    ref = oops.voxelize(pts[:, :3], rs, vs, mn, mx, max_points, max_voxels)
+    assert np.array_equal(bs, ref.voxel_batch_splits)
+    assert np.array_equal(c, ref.voxel_coords)
+    assert np.array_equal(prs, ref.voxel_point_row_splits)
+    assert np.array_equal(pi, ref.voxel_point_indices)
+
+
+def test_voxelize_points_on_the_upper_range_bound_are_kept():
+    pts = np.array([[2.0, 2.0, 2.0], [0.0, 0.0, 0.0], [2.0000002, 1, 1], [-1e-7, 1, 1]], np.float32)
+    c, pi, prs, bs = emu.voxelize(pts, [0, 4], [0.5, 0.5, 0.5], [0, 0, 0], [2, 2, 2])
+    ref = oops.voxelize(pts, [0, 4], [0.5, 0.5, 0.5], [0, 0, 0], [2, 2, 2])
+    assert np.array_equal(c, ref.voxel_coords) and np.array_equal(pi, ref.voxel_point_indices)
+    assert c.tolist() == [[0, 0, 0], [4, 4, 4]]
+
+
+def test_voxelize_empty_input():
+    c, pi, prs, bs = emu.voxelize(np.zeros((0, 3), np.float32), [0, 0], [1, 1, 1], [0, 0, 0], [2, 2, 2])
+    assert c.shape == (0, 3) and pi.shape == (0,) and prs.tolist() == [0] and bs.tolist() == [0, 0]
+
+
+def test_subsample_matches_oracle_points_features_labels():
+    rng = np.random.default_rng(5)
+    pts = synth_data.semantickitti_patch(3, 6000)
+    feats = rng.random((6000, 3), dtype=np.float32)
+    labs = rng.integers(0, 6, 6000).astype(np.int32)
+    lens = [2500, 0, 3500]
+    op, ln, of, ol = emu.subsample_batch(pts, lens, 0.4, feats, labs)
+    rp, rl, rf, rlab = oops.subsample_batch(pts, lens, feats, labs, sampleDl=0.4)
+    assert np.array_equal(ln, rl)
+    assert np.array_equal(op, rp) and np.array_equal(of, rf) and np.array_equal(ol, rlab)
+    assert 0 < len(op) < 6000
+
+
+def test_subsample_negative_coordinates_and_single_points():
+    pts = np.array([[-0.31, -0.29, 0.0], [-0.3, -0.3, 0.01], [5.0, 5.0, 5.0], [-7.0, 2.0, 1.0]], np.float32)
+    op, ln, _, _ = emu.subsample_batch(pts, [4], 0.1)
+    ref = oops.subsample(pts, sampleDl=0.1)
+    assert np.array_equal(op, ref) and ln.tolist() == [len(ref)]

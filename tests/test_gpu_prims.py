@@ -1,0 +1,159 @@
+"""GPU parity (through the C ABI via ml3d.ops): fixed-radius search, ragged_to_dense, voxelize, grid
+subsample vs the CPU oracle — indices / voxel ids / row_splits / barycentres bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import synth_data
+from oracle import ops as oops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(_dev()) if dtype is None else t.to(_dev(), dtype)
+
+
+def _kpconv_sphere(seed, n=10000):
+    """Toronto3D-shaped input sphere: urban surfaces, ~0.08 m grid, radius 4 m (SURVEY.md §8d frame 2)."""
+    return synth_data.toronto3d_sphere(seed, n)
+
+
+@pytest.mark.parametrize("kind,n,r", [("sphere", 10000, 0.2), ("sphere", 10000, 0.4), ("vol", 20000, 0.5),
+                                      ("dup", 4000, 0.2), ("tiny", 5, 1.0)])
+def test_radius_ragged_bit_exact(kind, n, r):
+    from ml3d import ops
+    rng = np.random.default_rng(n)
+    if kind == "sphere":
+        p = _kpconv_sphere(1, n)
+    elif kind == "vol":
+        p = rng.random((n, 3), dtype=np.float32) * 8
+    elif kind == "dup":
+        p = np.repeat(rng.random((n // 4, 3), dtype=np.float32), 4, 0)
+    else:
+        p = rng.random((n, 3), dtype=np.float32)
+    n = len(p)
+    tp = _t(p)
+    res = ops.fixed_radius_search(tp, tp, r, return_distances=True)
+    ref = oops.fixed_radius_search(p, p, r, return_distances=True)
+    assert np.array_equal(res.neighbors_row_splits.cpu().numpy(), ref.neighbors_row_splits)
+    assert np.array_equal(res.neighbors_index.cpu().numpy(), ref.neighbors_index)
+    assert np.array_equal(res.neighbors_distance.cpu().numpy(), ref.neighbors_distance)
+
+
+def test_radius_layer_api_batched_pool_queries():
+    """FixedRadiusSearch()(supports, queries, r, s_splits, q_splits) as batch_neighbors calls it (kpconv.py:2021)."""
+    from ml3d.layers import FixedRadiusSearch
+    a, b = _kpconv_sphere(2, 9000), _kpconv_sphere(3, 7000)
+    sup = np.concatenate([a, b])
+    qa, qb = oops.subsample(a, sampleDl=0.16), oops.subsample(b, sampleDl=0.16)
+    qry = np.concatenate([qa, qb])
+    ss = torch.tensor([0, len(a), len(sup)], dtype=torch.int64)
+    qs = torch.tensor([0, len(qa), len(qry)], dtype=torch.int64)
+    res = FixedRadiusSearch()(_t(sup), _t(qry), 0.2, ss.to(_dev()), qs.to(_dev()))
+    ref = oops.fixed_radius_search(sup, qry, 0.2, ss.numpy(), qs.numpy())
+    assert res.neighbors_index.dtype == torch.int32 and res.neighbors_row_splits.dtype == torch.int64
+    assert np.array_equal(res.neighbors_row_splits.cpu().numpy(), ref.neighbors_row_splits)
+    assert np.array_equal(res.neighbors_index.cpu().numpy(), ref.neighbors_index)
+
+
+def test_radius_long_rows_spill_and_workspace_growth():
+    from ml3d import ops
+    p = (np.random.default_rng(9).random((3000, 3), dtype=np.float32) * 0.3).astype(np.float32)
+    res = ops.fixed_radius_search(_t(p), _t(p[:500]), 1.0)        # every row lists all 3000 points
+    ref = oops.fixed_radius_search(p, p[:500], 1.0)
+    assert np.array_equal(res.neighbors_row_splits.cpu().numpy(), ref.neighbors_row_splits)
+    assert np.array_equal(res.neighbors_index.cpu().numpy(), ref.neighbors_index)
+
+
+def test_batch_neighbors_dense_matches_reference_recipe():
+    from ml3d import ops
+    a, b = _kpconv_sphere(4, 10000), _kpconv_sphere(5, 6000)
+    p = np.concatenate([a, b])
+    lens = [len(a), len(b)]
+    dense = ops.radius_neighbors_dense(_t(p), _t(p), lens, lens, 0.2).cpu().numpy()
+    ref = oops.fixed_radius_search(p, p, 0.2, [0, len(a), len(p)], [0, len(a), len(p)])
+    cols = int(np.diff(ref.neighbors_row_splits).max())
+    ref_dense = oops.ragged_to_dense(ref.neighbors_index.reshape(-1, 1), ref.neighbors_row_splits, cols,
+                                     np.array([len(p)], np.int32))[:, :, 0]
+    assert dense.dtype == np.int32 and np.array_equal(dense, ref_dense)
+    # size-independent properties: self is the first neighbour; no index crosses a batch item
+    assert (dense[:, 0] == np.arange(len(p))).all()
+    real = dense[:len(a)][dense[:len(a)] < len(p)]
+    assert real.max() < len(a)
+
+
+def test_ragged_to_dense_bit_exact():
+    from ml3d import ops
+    rng = np.random.default_rng(0)
+    rs = np.concatenate([[0], np.cumsum(rng.integers(0, 40, 5000))])
+    vals = rng.random((rs[-1], 4), dtype=np.float32)
+    out = ops.ragged_to_dense(_t(vals), _t(rs), 32, torch.zeros(4))
+    assert np.array_equal(out.cpu().numpy(), oops.ragged_to_dense(vals, rs, 32, np.zeros(4, np.float32)))
+    iv = rng.integers(0, 10 ** 6, (rs[-1],)).astype(np.int64)
+    out = ops.ragged_to_dense(_t(iv), _t(rs), 20, torch.tensor(-1))
+    assert np.array_equal(out.cpu().numpy(), oops.ragged_to_dense(iv, rs, 20, np.int64(-1)))
+
+
+def test_voxelize_upstream_docstring_example():
+    from ml3d import ops
+    pts = np.array([[.1, .1, .1], [.5, .5, .5], [1.7, 1.7, 1.7], [1.8, 1.8, 1.8], [9.3, 9.4, 9.4]], np.float32)
+    r = ops.voxelize(_t(pts), torch.tensor([0, 5]), torch.tensor([1., 1, 1]), torch.tensor([0., 0, 0]),
+                     torch.tensor([2., 2, 2]))
+    assert r.voxel_coords.cpu().tolist() == [[0, 0, 0], [1, 1, 1]]
+    assert r.voxel_point_indices.cpu().tolist() == [0, 1, 2, 3]
+    assert r.voxel_point_row_splits.cpu().tolist() == [0, 2, 4] and r.voxel_batch_splits.cpu().tolist() == [0, 2]
+    assert r.voxel_coords.dtype == torch.int32 and r.voxel_point_indices.dtype == torch.int64
+
+
+@pytest.mark.parametrize("max_points,max_voxels", [(32, 40000), (32, 2000), (5, 2 ** 62), (2 ** 62, 2 ** 62)])
+def test_voxelize_kitti_sweep_bit_exact(max_points, max_voxels):
+    """pointpillars_kitti.yml: voxel 0.16 x 0.16 x 4, range [0,-39.68,-3, 69.12,39.68,1], <=32 pts, <=40000 voxels."""
+    from ml3d import ops
+    a, b = synth_data.kitti_sweep(0), synth_data.kitti_sweep(1)        # [~120k, 4] xyz + intensity
+    pts = np.concatenate([a, b])
+    rs = [0, len(a), len(pts)]
+    vs, mn, mx = [0.16, 0.16, 4.0], [0, -39.68, -3], [69.12, 39.68, 1]
+    tp = _t(pts)
+    r = ops.voxelize(tp[:, :3], torch.tensor(rs), torch.tensor(vs), torch.tensor(mn), torch.tensor(mx),
+                     max_points, max_voxels)                              # strided view, as the reference passes
+    ref = oops.voxelize(pts[:, :3], rs, vs, mn, mx, max_points, max_voxels)
+    assert np.array_equal(r.voxel_batch_splits.cpu().numpy(), ref.voxel_batch_splits)
+    assert np.array_equal(r.voxel_coords.cpu().numpy(), ref.voxel_coords)
+    assert np.array_equal(r.voxel_point_row_splits.cpu().numpy(), ref.voxel_point_row_splits)
+    assert np.array_equal(r.voxel_point_indices.cpu().numpy(), ref.voxel_point_indices)
+    assert len(ref.voxel_coords) > 1000
+
+
+def test_subsample_raw_sweep_006_bit_exact():
+    """DataProcessing.grid_subsampling(points, grid_size=0.06) on a raw ~120k-point sweep (dataprocessing.py:14-49)."""
+    from ml3d import ops
+    sweep = synth_data.kitti_sweep(2)
+    pts = np.ascontiguousarray(sweep[:, :3])
+    feats = np.ascontiguousarray(sweep[:, 3:4])
+    labs = (np.abs(pts[:, 0]) * 3).astype(np.int32) % 19
+    rp, rf, rl = oops.subsample(pts, feats, labs, sampleDl=0.06)
+    op, of, ol = ops.subsample(_t(pts), _t(feats), _t(labs), sampleDl=0.06)
+    assert np.array_equal(op.cpu().numpy(), rp) and np.array_equal(of.cpu().numpy(), rf)
+    assert np.array_equal(ol.cpu().numpy(), rl)
+    assert 0.3 * len(pts) < len(rp) < len(pts)
+
+
+def test_subsample_batch_kpconv_pooling_grid():
+    from ml3d import ops
+    a, b = _kpconv_sphere(6, 10000), _kpconv_sphere(7, 8000)
+    p = np.concatenate([a, b])
+    lens = [len(a), len(b)]
+    rp, rl = oops.subsample_batch(p, lens, sampleDl=0.16)
+    op, ol = ops.subsample_batch(_t(p), lens, sampleDl=0.16)
+    assert ol.dtype == torch.int32 and np.array_equal(ol.cpu().numpy(), rl)
+    assert np.array_equal(op.cpu().numpy(), rp)
+    # idempotence (size-independent property): barycentres of a 0.16 grid re-sampled at 0.01 are unchanged
+    op2, ol2 = ops.subsample_batch(op, ol.tolist(), sampleDl=0.01)
+    assert torch.equal(ol2, ol) and torch.equal(torch.sort(op2.sum(1))[0], torch.sort(op.sum(1))[0])
