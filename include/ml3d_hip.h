@@ -161,6 +161,59 @@ int ml3d_subsample_fill(const float* points, const float* features, int64_t feat
                         float* out_points, float* out_features, int32_t* out_labels,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-item row-vector rotation p' = p . R[b] (transpose != 0: p . R[b]^T) around the grid   */
+/* subsample of batch_grid_subsampling (random_grid_orient, kpconv.py:2059-2110); float32     */
+/* products and sums rounded one by one like the numpy expression it replaces.                */
+/* rotations [batch, 3, 3] (device), out [n_points, 3] (may not alias points).                */
+int ml3d_rotate_points(const float* points, const int64_t* row_splits, int64_t batch,
+                       int64_t n_points, const float* rotations, int transpose, float* out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* KPConv (rigid) inference blocks — BatchNorm folded by the caller            */
+/* ------------------------------------------------------------------------- */
+/* ml3d_kpconv_rigid replaces KPConv.forward, non-deformable branch            */
+/*   (ml3d/torch/models/kpconv.py:1048-1068,1105-1118,1139-1159) followed by   */
+/*   BatchNormBlock + LeakyReLU of SimpleBlock / ResnetBottleneckBlock         */
+/*   (kpconv.py:1357-1358, 1448-1449):                                         */
+/*   out[q] = act( sum_k (sum_h w[q,k,h] x[idx[q,h]]) @ W[k] + bias ),         */
+/*   w = influence(|s[idx[q,h]] - q - kp[k]|) (0 constant, 1 linear, 2 gauss). */
+/* q_pts [Nq,3], s_pts [Ns,3], neighb_inds int32 [Nq,H] (>= Ns = shadow),      */
+/* features [Ns,cin], kernel_points [15,3], weights [15*cin, cout] (the        */
+/* reference's [K,cin,cout] tensor, BN scale folded into the last axis),       */
+/* bias [cout] (may be NULL), act 0 none / 1 leaky(slope) / 2 relu.            */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_kpconv_workspace_bytes(int64_t n_queries, int cin, int cout, int num_kernel_points);
+
+int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                      int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                      const float* features, int cin, const float* kernel_points,
+                      int num_kernel_points, float kp_extent, int kp_influence_mode,
+                      const float* weights, const float* bias, int act, float slope, int cout,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ml3d_linear: out = act([gather(a) | a2] @ weights_t + bias + residual) on f32 MFMA.       */
+/* Replaces UnaryBlock (Linear + BatchNormBlock + LeakyReLU, kpconv.py:1288-1293), the       */
+/* residual add of ResnetBottleneckBlock (kpconv.py:1461) and, with a_gather = upsamples[:,0]*/
+/* and a2 = the skip features, NearestUpsampleBlock + torch.cat + UnaryBlock of the decoder  */
+/* (kpconv.py:283-286, 821-838, 1468-1481).  a [*, lda] uses k1 columns, row m of the        */
+/* product reads a[a_gather[m*a_gather_stride]] (rows >= a_rows are zeros) or a[m] when      */
+/* a_gather is NULL; a2 [m, lda2] contributes k2 more columns; weights_t [k1+k2, n].         */
+size_t ml3d_linear_workspace_bytes(int64_t m, int n, int k);
+
+int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a_gather,
+                int64_t a_gather_stride, int64_t a_rows, const float* a2, int64_t lda2, int k2,
+                const float* weights_t, const float* bias, const float* residual, int64_t ldr,
+                int act, float slope, float* out, int64_t ldc, int64_t m, int n,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ml3d_gather_pool: mode 0 = max_pool (kpconv.py:841-858, shadow rows count as zeros),     */
+/* mode 1 = closest_pool (kpconv.py:821-838, feature of the FIRST listed neighbour).         */
+int ml3d_gather_pool(const float* features, int64_t n_supports, int channels,
+                     const int32_t* inds, int64_t n_queries, int64_t max_neighbors, int mode,
+                     float* out, void* stream);
+
+
 /* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */
 /*   ml3d/torch/models/randlanet.py:218-229 for a batch of equally sized       */

@@ -1,0 +1,53 @@
+// gemm.h — f32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogue (gfx950), shared by the KPConv and
+// PointPillars forward passes.
+//
+//   C[m, n] = act( sum_k A(m, k) * B[k, n] + bias[n] + residual[m, n] )
+//
+// A is produced by a LOADER functor, so the same tile loop serves
+//   * dense rows  [M, K1]           (UnaryBlock Linear, kpconv.py:1288-1293; 1x1 convs; KPConv's
+//                                     [Nq, 15*Cin] x [15*Cin, Cout] contraction, kpconv.py:1147-1159)
+//   * gathered + concatenated rows  ([x[up_idx[m, 0]] | skip[m]]: NearestUpsampleBlock + cat + unary of
+//                                     the KPFCNN decoder, kpconv.py:283-286, 821-838)
+//   * implicit im2col of an NHWC image (3x3 / strided convs of SECOND, point_pillars.py:619-682).
+// f32-input MFMA keeps the reference's float32 arithmetic (tolerance 1e-4 on logits); roofline = the
+// f32 matrix peak 157.3 TFLOP/s.  A workgroup (256 threads = 4 waves) owns a 64 x 64 tile of C, K is
+// walked in chunks of 32 staged through LDS with register prefetch of the next chunk; small-M / deep-K
+// problems are split along K across gridDim.z into a caller-provided partial buffer and reduced by a
+// second kernel (deterministic — no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ml3d {
+
+struct Epilogue {
+    const float* bias;        // [N] or null
+    const float* residual;    // [M, ldr] or null (added before the activation)
+    int64_t ldr;
+    int act;                  // 0 none, 1 leaky relu (slope), 2 relu
+    float slope;
+};
+
+// dense / gathered / concatenated rows
+struct RowsA {
+    const float* a; int64_t lda; int k1;
+    const int32_t* gather; int64_t gather_stride; int64_t a_rows;   // optional: row = gather[m * stride]; >= a_rows -> zeros
+    const float* a2; int64_t lda2; int k2;                           // optional second block of columns
+};
+
+// implicit im2col of an NHWC image: m = (b, oy, ox), k = (ky, kx, ci), ci fastest
+struct ConvA {
+    const float* in;     // [B, H, W, C]
+    int B, H, W, C;
+    int OH, OW;
+    int KH, KW, stride, pad;
+};
+
+size_t gemm_partial_bytes(int64_t M, int N, int K);   // workspace for the split-K partials (may be 0)
+
+int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Epilogue& ep, float* C, int64_t ldc,
+              void* partial_ws, size_t partial_bytes, hipStream_t stream);
+int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws,
+              size_t partial_bytes, hipStream_t stream);
+
+}  // namespace ml3d

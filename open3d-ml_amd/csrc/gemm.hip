@@ -1,0 +1,264 @@
+// gemm.hip — tiled f32 MFMA GEMM with loader-templated A operand and fused epilogue (see gemm.h).
+#include "gemm.h"
+
+#include "ml3d_hip.h"
+
+namespace ml3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM_BM = 64;        // rows of C per workgroup
+constexpr int GM_BN = 64;        // columns of C per workgroup
+constexpr int GM_KC = 32;        // K chunk
+constexpr int GM_AP = GM_KC + 4; // LDS pitch of the A tile (b128 reads without bank conflicts)
+constexpr int GM_BP = GM_BN + 4;
+
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float gm_act(float v, int act, float slope) {
+    if (act == 1) return v > 0.f ? v : v * slope;
+    if (act == 2) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// ---- A loaders ---------------------------------------------------------------------------------------
+struct RowsLoader {
+    RowsA A;
+    int64_t M;
+    int K;
+    int vec;   // 1: every block is float4-addressable (k1, k2, lda, lda2 multiples of 4, 16-byte aligned bases)
+    struct Ctx { const float* p1; const float* p2; };
+    __device__ __forceinline__ Ctx prepare(int64_t m) const {
+        Ctx c; c.p1 = nullptr; c.p2 = nullptr;
+        if (m < M) {
+            int64_t r = m;
+            bool ok = true;
+            if (A.gather) { r = A.gather[m * A.gather_stride]; ok = r >= 0 && r < A.a_rows; }
+            if (ok) c.p1 = A.a + r * A.lda;
+            if (A.a2) c.p2 = A.a2 + m * A.lda2;
+        }
+        return c;
+    }
+    __device__ __forceinline__ float at(const Ctx& c, int k) const {
+        if (k < A.k1) return c.p1 ? c.p1[k] : 0.f;
+        if (k < K) return c.p2 ? c.p2[k - A.k1] : 0.f;
+        return 0.f;
+    }
+    __device__ __forceinline__ float4 load4(const Ctx& c, int k) const {
+        if (vec) {
+            if (k < A.k1) return c.p1 ? *reinterpret_cast<const float4*>(c.p1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K) return c.p2 ? *reinterpret_cast<const float4*>(c.p2 + (k - A.k1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return make_float4(at(c, k), at(c, k + 1), at(c, k + 2), at(c, k + 3));
+    }
+};
+
+struct ConvLoader {
+    ConvA A;
+    int64_t M;
+    int K;
+    struct Ctx { const float* img; int iy0, ix0; };
+    __device__ __forceinline__ Ctx prepare(int64_t m) const {
+        Ctx c; c.img = nullptr; c.iy0 = 0; c.ix0 = 0;
+        if (m < M) {
+            int ox = (int)(m % A.OW);
+            int64_t t = m / A.OW;
+            int oy = (int)(t % A.OH);
+            int b = (int)(t / A.OH);
+            c.img = A.in + (int64_t)b * A.H * A.W * A.C;
+            c.iy0 = oy * A.stride - A.pad;
+            c.ix0 = ox * A.stride - A.pad;
+        }
+        return c;
+    }
+    // C % 4 == 0: the 4 consecutive k share (ky, kx)
+    __device__ __forceinline__ float4 load4(const Ctx& c, int k) const {
+        if (!c.img || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        int ci = k % A.C;
+        int kk = k / A.C;
+        int kx = kk % A.KW, ky = kk / A.KW;
+        int iy = c.iy0 + ky, ix = c.ix0 + kx;
+        if (iy < 0 || iy >= A.H || ix < 0 || ix >= A.W) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(c.img + ((int64_t)iy * A.W + ix) * A.C + ci);
+    }
+};
+
+// ---- tile kernel -------------------------------------------------------------------------------------
+template <class Loader>
+__global__ void __launch_bounds__(256)
+gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, float* __restrict__ C, int64_t ldc,
+          int k_per_split, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_AP];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_KC * GM_BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    const int rt = wave & 1, ctw = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.x * GM_BM;
+    const int n0 = blockIdx.y * GM_BN;
+    const int kb = blockIdx.z * k_per_split;
+    const int ke = (kb + k_per_split < L.K) ? kb + k_per_split : L.K;
+
+    // this thread stages A rows (tid >> 3) and 32 + (tid >> 3), k offset 4 * (tid & 7);
+    // B rows (tid >> 4) and 16 + (tid >> 4), column offset 4 * (tid & 15)
+    const int ar = tid >> 3, aq = (tid & 7) * 4;
+    const int br = tid >> 4, bq = (tid & 15) * 4;
+    const typename Loader::Ctx c0 = L.prepare(m0 + ar), c1 = L.prepare(m0 + 32 + ar);
+
+    float4 ra0, ra1, rb0, rb1;
+    auto load_b = [&](int k) -> float4 {
+        const int col = n0 + bq;
+        if (k >= ke) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = Bm + (int64_t)k * N + col;
+        if (bvec && col + 3 < N) return *reinterpret_cast<const float4*>(p);
+        float4 v;
+        v.x = col + 0 < N ? p[0] : 0.f;
+        v.y = col + 1 < N ? p[1] : 0.f;
+        v.z = col + 2 < N ? p[2] : 0.f;
+        v.w = col + 3 < N ? p[3] : 0.f;
+        return v;
+    };
+    auto fetch = [&](int k0) {
+        const int ka = k0 + aq;
+        ra0 = ka < ke ? L.load4(c0, ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra1 = ka < ke ? L.load4(c1, ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb0 = load_b(k0 + br);
+        rb1 = load_b(k0 + 16 + br);
+    };
+    auto stash = [&]() {
+        *reinterpret_cast<float4*>(As + ar * GM_AP + aq) = ra0;
+        *reinterpret_cast<float4*>(As + (32 + ar) * GM_AP + aq) = ra1;
+        *reinterpret_cast<float4*>(Bs + br * GM_BP + bq) = rb0;
+        *reinterpret_cast<float4*>(Bs + (16 + br) * GM_BP + bq) = rb1;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (kb < ke) {
+        fetch(kb);
+        stash();
+        __syncthreads();
+        for (int k0 = kb; k0 < ke; k0 += GM_KC) {
+            const bool more = k0 + GM_KC < ke;
+            if (more) fetch(k0 + GM_KC);       // global loads in flight under the MFMAs
+            const float* arow = As + (rt * 32 + cl) * GM_AP + hi * (GM_KC / 2);
+            const float* brow = Bs + (hi * (GM_KC / 2)) * GM_BP + ctw * 32 + cl;
+#pragma unroll
+            for (int s4 = 0; s4 < GM_KC / 8; ++s4) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 4 * s4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, brow[(4 * s4 + 0) * GM_BP], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, brow[(4 * s4 + 1) * GM_BP], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, brow[(4 * s4 + 2) * GM_BP], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, brow[(4 * s4 + 3) * GM_BP], acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                stash();
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const int col = n0 + ctw * 32 + cl;
+    if (col >= N) return;
+    if (partial) {
+        float* P = partial + (int64_t)blockIdx.z * L.M * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + rt * 32 + mfma32_row(r, hi);
+            if (m < L.M) P[m * N + col] = acc[r];
+        }
+        return;
+    }
+    const float b = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + rt * 32 + mfma32_row(r, hi);
+        if (m < L.M) {
+            float v = acc[r] + b;
+            if (ep.residual) v += ep.residual[m * ep.ldr + col];
+            C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
+        }
+    }
+}
+
+__global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64_t M, int N, Epilogue ep,
+                            float* __restrict__ C, int64_t ldc) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N;
+        const int col = (int)(i - m * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += partial[(int64_t)z * total + i];
+        if (ep.bias) v += ep.bias[col];
+        if (ep.residual) v += ep.residual[m * ep.ldr + col];
+        C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int pick_splits(int64_t M, int N, int K) {
+    const int64_t tiles = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    if (tiles >= 256 || K < 512) return 1;
+    int64_t want = (512 + tiles - 1) / tiles;            // aim at ~2 workgroups per CU
+    int64_t maxs = K / 128;                              // at least 4 chunks per split
+    int64_t s = want < maxs ? want : maxs;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+}
+
+size_t gemm_partial_bytes(int64_t M, int N, int K) {
+    int s = pick_splits(M, N, K);
+    return s > 1 ? sizeof(float) * (size_t)s * (size_t)M * (size_t)N : 0;
+}
+
+template <class Loader>
+static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
+                       void* partial_ws, size_t partial_bytes, hipStream_t st) {
+    const int64_t M = L.M;
+    const int K = L.K;
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || !Bm || !C) return ML3D_E_INVALID;
+    int splits = pick_splits(M, N, K);
+    if (splits > 1 && (!partial_ws || partial_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N)) splits = 1;
+    // split boundaries are multiples of the K chunk (so also of 4: float4 loads never straddle one)
+    int kper = ((K + splits - 1) / splits + GM_KC - 1) / GM_KC * GM_KC;
+    splits = (K + kper - 1) / kper;
+    const int bvec = ((N & 3) == 0 && (((uintptr_t)Bm) & 15) == 0) ? 1 : 0;
+    dim3 grid((unsigned)((M + GM_BM - 1) / GM_BM), (unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)splits);
+    float* partial = splits > 1 ? (float*)partial_ws : nullptr;
+    hipLaunchKernelGGL((gemm_tile<Loader>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    if (splits > 1) {
+        int64_t total = M * N;
+        unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gemm_reduce, dim3(nb), dim3(256), 0, st, partial, splits, M, N, ep, C, ldc);
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    }
+    return 0;
+}
+
+int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Epilogue& ep, float* C, int64_t ldc,
+              void* partial_ws, size_t partial_bytes, hipStream_t stream) {
+    if (A.k1 + A.k2 != K || (A.k1 > 0 && !A.a) || (A.k2 > 0 && !A.a2)) return ML3D_E_INVALID;
+    RowsLoader L;
+    L.A = A; L.M = M; L.K = K;
+    bool v = (A.k1 & 3) == 0 && (A.lda & 3) == 0 && (((uintptr_t)A.a) & 15) == 0;
+    if (A.k2 > 0) v = v && (A.k2 & 3) == 0 && (A.lda2 & 3) == 0 && (((uintptr_t)A.a2) & 15) == 0;
+    L.vec = v ? 1 : 0;
+    return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
+}
+
+int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws,
+              size_t partial_bytes, hipStream_t stream) {
+    if (!A.in || (A.C & 3) || A.KH <= 0 || A.KW <= 0 || A.stride <= 0) return ML3D_E_INVALID;
+    ConvLoader L;
+    L.A = A;
+    L.M = (int64_t)A.B * A.OH * A.OW;
+    L.K = A.KH * A.KW * A.C;
+    return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
+}
+
+}  // namespace ml3d

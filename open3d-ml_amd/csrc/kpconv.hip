@@ -1,0 +1,302 @@
+// kpconv.hip — KPConv (rigid) inference blocks for gfx950.
+//
+// Replaces the PyTorch op chains of
+//   KPConv.forward, non-deformable branch        ml3d/torch/models/kpconv.py:1048-1068, 1105-1118, 1139-1159
+//   UnaryBlock / BatchNormBlock (eval)            kpconv.py:1213-1300
+//   max_pool / closest_pool                       kpconv.py:821-858
+//   NearestUpsampleBlock + torch.cat + UnaryBlock kpconv.py:283-286, 1468-1481  (one fused GEMM)
+// with BatchNorm folded into the weights by the host.
+//
+// KPConv = two kernels:
+//  (1) kp_weighted — "gather" half.  For each query point the influence of its H neighbours on the 15
+//      kernel points, w[k][h] = max(0, 1 - |s_h - q - kp_k| / extent), is computed once per (query,
+//      neighbour) pair into an LDS tile shared by the lanes that own the query's channels; the lanes
+//      then stream the neighbours' feature rows (contiguous [Cin] bursts, L2-resident) and accumulate
+//      wf[k][c] = sum_h w[k][h] * x[idx_h][c] in registers (15 x Cin/G accumulators per lane).  The
+//      reference materialises [N,H,15,3] differences, [N,15,H] weights and an [N,H,Cin] gather in HBM
+//      (47% of its forward is aten::gather); here only wf [N, 15*Cin] is written.
+//  (2) the [Nq, 15*Cin] x [15*Cin, Cout] contraction with the kernel weights = one f32 MFMA GEMM
+//      (gemm.hip) with bias (folded BN) + LeakyReLU in the epilogue, split along K for the deep layers.
+// Roofline: f32 vector/matrix peak 157.3 TFLOP/s; algorithmic flops per block
+//   Nq * (2*15*H*Cin + 2*15*Cin*Cout)   (SURVEY.md §8d).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.h"
+#include "grid.h"
+#include "ml3d_hip.h"
+
+namespace ml3d {
+
+constexpr int KP_K = 15;          // kernel points (every reference config)
+constexpr int KP_WP = 16;         // LDS pitch of a neighbour's 15 weights
+constexpr int KP_HC = 32;         // neighbours per LDS chunk
+
+struct KpArgs {
+    const float* q_pts; const float* s_pts;
+    const int32_t* inds; int64_t nq, ns; int h;
+    const float* x; int cin;
+    const float* kp;              // [15, 3]
+    float inv_extent; int influence;   // 0 constant, 1 linear, 2 gaussian (sigma = 0.3 * extent)
+    float gauss_den;              // 2 * sigma^2 + eps
+    float* wf;                    // [nq, 15 * cin]
+};
+
+__device__ __forceinline__ float kp_influence(float d2, const KpArgs& A) {
+    if (A.influence == 0) return 1.0f;
+    if (A.influence == 1) { float w = 1.0f - sqrtf(d2) * A.inv_extent; return w > 0.f ? w : 0.f; }
+    return expf(-d2 / A.gauss_den);
+}
+
+// G lanes per query (G in {16, 32, 64}); a wave serves 64 / G queries; J = channels per lane.
+template <int G, int J>
+__global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
+    constexpr int QW = 64 / G;
+    __shared__ __attribute__((aligned(16))) float W[4][QW][KP_HC][KP_WP];
+    __shared__ int NI[4][QW][KP_HC];
+    __shared__ float KPs[KP_K * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < KP_K * 3) KPs[tid] = A.kp[tid];
+    __syncthreads();
+    const int qi = lane / G, cg = lane % G;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * QW;   // first query of this wave
+    if (q0 >= A.nq) return;                                      // wave-uniform, no block barrier below
+    const int64_t q = q0 + qi;
+    const bool q_ok = q < A.nq;
+    float acc[KP_K][J];
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[k][j] = 0.f;
+
+    for (int h0 = 0; h0 < A.h; h0 += KP_HC) {
+        // ---- phase 1: influence weights of the chunk's (query, neighbour) pairs -> LDS -------------------
+        for (int pr = lane; pr < QW * KP_HC; pr += 64) {
+            const int pq = pr / KP_HC, ph = pr % KP_HC;
+            const int64_t qq = q0 + pq;
+            const int hh = h0 + ph;
+            int idx = -1;
+            if (qq < A.nq && hh < A.h) {
+                idx = A.inds[qq * A.h + hh];
+                if (idx < 0 || idx >= A.ns) idx = -1;            // shadow neighbour (kpconv.py:1048-1051)
+            }
+            NI[wave][pq][ph] = idx;
+            if (idx >= 0) {
+                const float* sp = A.s_pts + 3 * (int64_t)idx;
+                const float* qp = A.q_pts + 3 * qq;
+                const float nx = sp[0] - qp[0], ny = sp[1] - qp[1], nz = sp[2] - qp[2];
+#pragma unroll
+                for (int k = 0; k < KP_K; ++k) {
+                    const float dx = nx - KPs[3 * k], dy = ny - KPs[3 * k + 1], dz = nz - KPs[3 * k + 2];
+                    W[wave][pq][ph][k] = kp_influence(dx * dx + dy * dy + dz * dz, A);
+                }
+            }
+        }
+        wave_sync();
+        // ---- phase 2: stream the neighbours' feature rows --------------------------------------------------
+        const int hn = (A.h - h0) < KP_HC ? (A.h - h0) : KP_HC;
+        if (q_ok) {
+            for (int ph = 0; ph < hn; ++ph) {
+                const int idx = NI[wave][qi][ph];
+                if (idx < 0) continue;
+                const float* xr = A.x + (int64_t)idx * A.cin;
+                float xv[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int c = cg + j * G;
+                    xv[j] = c < A.cin ? xr[c] : 0.f;
+                }
+                const float4* wp = reinterpret_cast<const float4*>(&W[wave][qi][ph][0]);
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                const float wk[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) acc[k][j] = fmaf(wk[k], xv[j], acc[k][j]);
+            }
+        }
+        wave_sync();
+    }
+    if (q_ok) {
+        float* o = A.wf + q * (int64_t)(KP_K * A.cin);
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = cg + j * G;
+                if (c < A.cin) o[k * A.cin + c] = acc[k][j];
+            }
+    }
+}
+
+// tiny Cin (the first layer, in_features_dim in {1, 2, 4, 5}): one thread per query, weights on the fly
+template <int CIN>
+__global__ void __launch_bounds__(256) kp_weighted_small(KpArgs A) {
+    __shared__ float KPs[KP_K * 3];
+    if (threadIdx.x < KP_K * 3) KPs[threadIdx.x] = A.kp[threadIdx.x];
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.nq) return;
+    float acc[KP_K][CIN];
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[k][c] = 0.f;
+    const float qx = A.q_pts[3 * q], qy = A.q_pts[3 * q + 1], qz = A.q_pts[3 * q + 2];
+    for (int hh = 0; hh < A.h; ++hh) {
+        const int idx = A.inds[q * A.h + hh];
+        if (idx < 0 || idx >= A.ns) continue;
+        const float* sp = A.s_pts + 3 * (int64_t)idx;
+        const float nx = sp[0] - qx, ny = sp[1] - qy, nz = sp[2] - qz;
+        float xv[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) xv[c] = A.x[(int64_t)idx * CIN + c];
+#pragma unroll
+        for (int k = 0; k < KP_K; ++k) {
+            const float dx = nx - KPs[3 * k], dy = ny - KPs[3 * k + 1], dz = nz - KPs[3 * k + 2];
+            const float w = kp_influence(dx * dx + dy * dy + dz * dz, A);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) acc[k][c] = fmaf(w, xv[c], acc[k][c]);
+        }
+    }
+    float* o = A.wf + q * (int64_t)(KP_K * CIN);
+#pragma unroll
+    for (int k = 0; k < KP_K; ++k)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) o[k * CIN + c] = acc[k][c];
+}
+
+// max over the listed neighbours (shadow rows are zeros) / feature of the first listed neighbour
+__global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, const int32_t* __restrict__ inds,
+                              int64_t nq, int h, int mode, float* __restrict__ out) {
+    const int64_t total = nq * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / c;
+        const int ch = (int)(i - q * c);
+        float v;
+        if (mode == 1) {
+            const int idx = inds[q * h];
+            v = (idx >= 0 && idx < ns) ? x[(int64_t)idx * c + ch] : 0.f;
+        } else {
+            v = -3.0e38f;
+            for (int hh = 0; hh < h; ++hh) {
+                const int idx = inds[q * h + hh];
+                const float xv = (idx >= 0 && idx < ns) ? x[(int64_t)idx * c + ch] : 0.f;
+                v = xv > v ? xv : v;
+            }
+        }
+        out[i] = v;
+    }
+}
+
+template <int G, int J>
+static void launch_kpw(const KpArgs& a, hipStream_t st) {
+    const int qw = 64 / G;
+    unsigned nb = (unsigned)((a.nq + 4 * qw - 1) / (4 * qw));
+    hipLaunchKernelGGL((kp_weighted<G, J>), dim3(nb), dim3(256), 0, st, a);
+}
+
+static int launch_weighted(const KpArgs& a, hipStream_t st) {
+    const int c = a.cin;
+    const unsigned nbs = (unsigned)((a.nq + 255) / 256);
+    if (c == 1) hipLaunchKernelGGL(kp_weighted_small<1>, dim3(nbs), dim3(256), 0, st, a);
+    else if (c == 2) hipLaunchKernelGGL(kp_weighted_small<2>, dim3(nbs), dim3(256), 0, st, a);
+    else if (c == 3) hipLaunchKernelGGL(kp_weighted_small<3>, dim3(nbs), dim3(256), 0, st, a);
+    else if (c == 4) hipLaunchKernelGGL(kp_weighted_small<4>, dim3(nbs), dim3(256), 0, st, a);
+    else if (c == 5) hipLaunchKernelGGL(kp_weighted_small<5>, dim3(nbs), dim3(256), 0, st, a);
+    else if (c <= 16) launch_kpw<16, 1>(a, st);
+    else if (c <= 32) launch_kpw<32, 1>(a, st);
+    else if (c <= 64) launch_kpw<64, 1>(a, st);
+    else if (c <= 128) launch_kpw<64, 2>(a, st);
+    else if (c <= 256) launch_kpw<64, 4>(a, st);
+    else if (c <= 512) launch_kpw<64, 8>(a, st);
+    else return ML3D_E_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+static inline size_t kp_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace ml3d
+
+using namespace ml3d;
+
+extern "C" size_t ml3d_kpconv_workspace_bytes(int64_t n_queries, int cin, int cout, int num_kernel_points) {
+    if (n_queries < 0 || cin <= 0 || cout <= 0 || num_kernel_points != KP_K) return 0;
+    size_t b = kp_align(sizeof(float) * (size_t)(n_queries > 0 ? n_queries : 1) * KP_K * (size_t)cin);
+    b += kp_align(gemm_partial_bytes(n_queries, cout, KP_K * cin));
+    return b + 512;
+}
+
+extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                 int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                 const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
+                                 const float* weights, const float* bias, int act, float slope, int cout, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_queries < 0 || n_supports < 0 || max_neighbors < 0 || cin <= 0 || cout <= 0 || !(kp_extent > 0.f) ||
+        kp_influence_mode < 0 || kp_influence_mode > 2 || max_neighbors > 0x7fffffff)
+        return ML3D_E_INVALID;
+    if (num_kernel_points != KP_K || cin > 512) return ML3D_E_UNSUPPORTED;
+    if (n_queries == 0) return 0;
+    if (!q_pts || !kernel_points || !weights || !out || (max_neighbors > 0 && (!neighb_inds || !features || !s_pts)))
+        return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_kpconv_workspace_bytes(n_queries, cin, cout, num_kernel_points)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* wf = (float*)p;
+    p += kp_align(sizeof(float) * (size_t)n_queries * KP_K * (size_t)cin);
+    KpArgs a;
+    a.q_pts = q_pts; a.s_pts = s_pts; a.inds = neighb_inds; a.nq = n_queries; a.ns = n_supports; a.h = (int)max_neighbors;
+    a.x = features; a.cin = cin; a.kp = kernel_points;
+    a.inv_extent = 1.0f / kp_extent; a.influence = kp_influence_mode;
+    const float sigma = kp_extent * 0.3f;                       // kpconv.py:1122-1125 + radius_gaussian eps
+    a.gauss_den = 2.0f * sigma * sigma + 1e-9f;
+    a.wf = wf;
+    int rc = launch_weighted(a, st);
+    if (rc) return rc;
+    RowsA A;
+    A.a = wf; A.lda = (int64_t)KP_K * cin; A.k1 = KP_K * cin;
+    A.gather = nullptr; A.gather_stride = 0; A.a_rows = n_queries;
+    A.a2 = nullptr; A.lda2 = 0; A.k2 = 0;
+    Epilogue ep = {bias, nullptr, 0, act, slope};
+    return gemm_rows(A, weights, n_queries, cout, KP_K * cin, ep, out, cout, p,
+                     gemm_partial_bytes(n_queries, cout, KP_K * cin), st);
+}
+
+extern "C" size_t ml3d_linear_workspace_bytes(int64_t m, int n, int k) {
+    if (m < 0 || n <= 0 || k <= 0) return 0;
+    return gemm_partial_bytes(m, n, k) + 512;
+}
+
+extern "C" int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a_gather, int64_t a_gather_stride,
+                           int64_t a_rows, const float* a2, int64_t lda2, int k2, const float* weights_t,
+                           const float* bias, const float* residual, int64_t ldr, int act, float slope, float* out,
+                           int64_t ldc, int64_t m, int n, void* workspace, size_t workspace_bytes, void* stream) {
+    if (m < 0 || n <= 0 || k1 < 0 || k2 < 0 || k1 + k2 <= 0 || act < 0 || act > 2) return ML3D_E_INVALID;
+    if (m == 0) return 0;
+    if (!weights_t || !out || (k1 > 0 && !a) || (k2 > 0 && !a2) || lda < k1 || (k2 > 0 && lda2 < k2) || ldc < n ||
+        (residual && ldr < n))
+        return ML3D_E_INVALID;
+    RowsA A;
+    A.a = a; A.lda = lda; A.k1 = k1;
+    A.gather = a_gather; A.gather_stride = a_gather_stride; A.a_rows = a_rows;
+    A.a2 = a2; A.lda2 = lda2; A.k2 = k2;
+    Epilogue ep = {bias, residual, ldr, act, slope};
+    char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
+    size_t avail = workspace ? (workspace_bytes > 256 ? workspace_bytes - 256 : 0) : 0;
+    return gemm_rows(A, weights_t, m, n, k1 + k2, ep, out, ldc, p, avail, (hipStream_t)stream);
+}
+
+extern "C" int ml3d_gather_pool(const float* features, int64_t n_supports, int channels, const int32_t* inds,
+                                int64_t n_queries, int64_t max_neighbors, int mode, float* out, void* stream) {
+    if (n_supports < 0 || channels <= 0 || n_queries < 0 || max_neighbors <= 0 || (mode != 0 && mode != 1) ||
+        max_neighbors > 0x7fffffff)
+        return ML3D_E_INVALID;
+    if (n_queries == 0) return 0;
+    if (!features || !inds || !out) return ML3D_E_INVALID;
+    int64_t total = n_queries * channels;
+    unsigned nb = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(gather_pool_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, features, n_supports, channels, inds,
+                       n_queries, (int)max_neighbors, mode, out);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}

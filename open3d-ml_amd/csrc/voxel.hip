@@ -294,6 +294,26 @@ __global__ void sub_fill(const uint32_t* __restrict__ vals, const int* __restric
     }
 }
 
+// out[i, j] = (p[i,0] * R[b][0][j] + p[i,1] * R[b][1][j]) + p[i,2] * R[b][2][j]   (transpose: R[b][j][.])
+// — the row-vector rotation of batch_grid_subsampling (kpconv.py:2086-2092, 2105-2110), every product and
+// sum rounded separately like numpy's float32 `np.sum(expand_dims(p, 2) * R, axis=1)`.
+__global__ void rotate_rows_k(const float* __restrict__ pts, Segs S, int64_t n, const float* __restrict__ R,
+                              int transpose, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s; int64_t local;
+    seg_locate(S, i, s, local);
+    const float* M = R + 9 * s;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float m0 = transpose ? M[3 * j + 0] : M[0 + j];
+        const float m1 = transpose ? M[3 * j + 1] : M[3 + j];
+        const float m2 = transpose ? M[3 * j + 2] : M[6 + j];
+        out[3 * i + j] = __fadd_rn(__fadd_rn(__fmul_rn(x, m0), __fmul_rn(y, m1)), __fmul_rn(z, m2));
+    }
+}
+
 #define VX_CHECK()                                                   \
     do {                                                             \
         if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;   \
@@ -451,6 +471,18 @@ extern "C" int ml3d_subsample_fill(const float* points, const float* features, i
     hipLaunchKernelGGL(sub_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W.vals,
                        W.flags, n_points, W.hp, points, features, feature_dim, labels, out_points, out_features,
                        out_labels);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" int ml3d_rotate_points(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
+                                  const float* rotations, int transpose, float* out, void* stream) {
+    if (batch <= 0 || n_points < 0 || !row_splits || !rotations) return ML3D_E_INVALID;
+    if (n_points == 0) return 0;
+    if (!points || !out) return ML3D_E_INVALID;
+    Segs S = {row_splits, 0, 0, (int)batch};
+    hipLaunchKernelGGL(rotate_rows_k, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points,
+                       S, n_points, rotations, transpose, out);
     VX_CHECK();
     return 0;
 }

@@ -30,6 +30,12 @@ SYMBOLS = [
     "ml3d_subsample_workspace_bytes",
     "ml3d_subsample_count",
     "ml3d_subsample_fill",
+    "ml3d_rotate_points",
+    "ml3d_kpconv_workspace_bytes",
+    "ml3d_kpconv_rigid",
+    "ml3d_linear_workspace_bytes",
+    "ml3d_linear",
+    "ml3d_gather_pool",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -87,6 +93,20 @@ def bind(lib):
     lib.ml3d_subsample_count.argtypes = [vp, vp, i64, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_subsample_fill.restype = C.c_int
     lib.ml3d_subsample_fill.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_rotate_points.restype = C.c_int
+    lib.ml3d_rotate_points.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
+    lib.ml3d_kpconv_workspace_bytes.restype = sz
+    lib.ml3d_kpconv_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    lib.ml3d_kpconv_rigid.restype = C.c_int
+    lib.ml3d_kpconv_rigid.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, vp, i32, f32, i32, vp,
+                                      vp, sz, vp]
+    lib.ml3d_linear_workspace_bytes.restype = sz
+    lib.ml3d_linear_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.ml3d_linear.restype = C.c_int
+    lib.ml3d_linear.argtypes = [vp, i64, i32, vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i32, f32, vp, i64, i64, i32,
+                                vp, sz, vp]
+    lib.ml3d_gather_pool.restype = C.c_int
+    lib.ml3d_gather_pool.argtypes = [vp, i64, i32, vp, i64, i64, i32, vp, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

@@ -56,6 +56,62 @@ def reference_logits(rl, cfg, sd, pts, feats):
     return out.numpy(), inputs
 
 
+def kpconv_golden(out_path, frame_ids, max_points, weights_seed, np_seed):
+    """KPFCNN (Toronto3D config) through the REAL reference: KPConvBatch builds the batch with the oracle's
+    radius / subsample ops wired in by the shim, KPFCNN.forward runs on PyTorch-CPU."""
+    import importlib
+    from oracle import kpconv_ref as K
+    kp = importlib.import_module("ml3d.torch.models.kpconv")
+    cb = importlib.import_module("ml3d.torch.dataloaders.concat_batcher")
+    from ml3d.utils import Config
+    assert os.path.abspath(kp.__file__).startswith(os.path.abspath(ref_shim.REF_ROOT))
+    cfg = dict(K.TORONTO3D_CFG)
+    model = kp.KPFCNN(**cfg)
+    sd = K.make_state_dict(cfg, weights_seed)
+    ref_sd = model.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), (set(ref_sd) ^ set(sd))
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd)
+    model.eval()
+    spheres = [synth_data.toronto3d_sphere(f, max_points) for f in frame_ids]
+    data = dict(p_list=spheres, f_list=[s.copy() for s in spheres],
+                l_list=[np.zeros(len(s), np.int32) for s in spheres], p0_list=[np.zeros(3) for _ in spheres],
+                s_list=[np.ones(3, np.float32) for _ in spheres], R_list=[np.eye(3, dtype=np.float32) for _ in spheres],
+                r_inds_list=[np.zeros(0) for _ in spheres], r_mask_list=[np.zeros(0) for _ in spheres],
+                val_labels_list=[np.zeros(0) for _ in spheres], cfg=model.cfg)
+    model.cfg.batch_limit = 10 ** 9          # keep every sphere of the list in the batch
+    np.random.seed(np_seed)
+    batch = cb.KPConvBatch([{"data": data}])
+    with torch.no_grad():
+        logits = model(batch).numpy()
+    # the restatement, same np.random stream
+    np.random.seed(np_seed)
+    pts = np.concatenate(spheres)
+    lens = [len(s) for s in spheres]
+    seg = K.segmentation_inputs(pts, lens, cfg, rotations="random")
+    for l in range(cfg["num_layers"]):
+        assert np.array_equal(seg["points"][l], batch.points[l].numpy()), l
+        assert np.array_equal(seg["neighbors"][l], batch.neighbors[l].numpy()), l
+        assert np.array_equal(seg["pools"][l], batch.pools[l].numpy()), l
+        assert np.array_equal(seg["upsamples"][l], batch.upsamples[l].numpy()), l
+    mine = K.forward(sd, cfg, K.to_torch_batch(seg), batch.features).numpy()
+    assert np.abs(mine - logits).max() <= 1e-5, np.abs(mine - logits).max()
+    g = dict(frame_ids=np.asarray(frame_ids), max_points=max_points, weights_seed=weights_seed, np_seed=np_seed,
+             logits=logits, lengths=np.stack([np.asarray(x, np.int64) for x in seg["lengths"]]),
+             rot0=seg["rotations"][0])
+    for l in range(cfg["num_layers"]):
+        nb = seg["neighbors"][l]
+        g["nbr_shape%d" % l] = np.asarray(nb.shape)
+        g["nbr_checksum%d" % l] = np.int64((nb * (np.arange(nb.shape[1]) + 1)).sum())
+        g["points_sum%d" % l] = seg["points"][l].astype(np.float64).sum(0)
+    g["nbr0_head"] = seg["neighbors"][0][:64].astype(np.int32)
+    g["pool0_head"] = seg["pools"][0][:64].astype(np.int32)
+    g["up0_head"] = seg["upsamples"][0][:64].astype(np.int32)
+    np.savez_compressed(out_path, **g)
+    print("kpconv golden:", out_path, logits.shape, [tuple(x) for x in g["lengths"]])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cwd = os.getcwd()
@@ -96,6 +152,9 @@ def main():
                         logits_every64=logits[:, ::64], argmax=logits.argmax(-1).astype(np.int8),
                         points_sum=pts.astype(np.float64).sum(), nbr0_rowsum=nb0.sum(-1).astype(np.int64)[0, ::16],
                         nbr0_checksum=np.int64((nb0.astype(np.int64) * (np.arange(16) + 1)).sum()))
+    # 4. KPConv (Toronto3D config): one small 2-sphere batch (full logits) and one 10k-point sphere
+    kpconv_golden(os.path.join(OUT, "kpconv_small.npz"), [11, 12], 1500, 303, 1234)
+    kpconv_golden(os.path.join(OUT, "kpconv_toronto3d.npz"), [1], 10000, 303, 99)
     os.chdir(cwd)
     print("golden vectors written to", OUT)
 

@@ -1,0 +1,355 @@
+"""CPU ORACLE for the KPConv (rigid) inference path — test infrastructure, NOT product code.
+
+Restates, as plain functions over numpy / PyTorch-CPU tensors,
+  * ``KPConvBatch.segmentation_inputs``  (ml3d/torch/dataloaders/concat_batcher.py:186-305)
+  * ``batch_neighbors`` / ``batch_grid_subsampling`` (ml3d/torch/models/kpconv.py:2002-2164)
+  * ``KPFCNN.__init__`` block walk and ``KPFCNN.forward`` (ml3d/torch/models/kpconv.py:131-291)
+  * ``KPConv.forward`` rigid branch, ``UnaryBlock``, ``BatchNormBlock``, ``SimpleBlock``,
+    ``ResnetBottleneckBlock``, ``NearestUpsampleBlock``, ``max_pool``, ``closest_pool``
+    (kpconv.py:772-858, 1005-1159, 1213-1491)
+on top of the oracle's neighbour / subsample ops (oracle/ops.py).
+
+PINNED: ``oracle/gen_golden.py`` runs the REAL reference modules (KPFCNN + KPConvBatch imported from
+/root/reference through oracle/ref_shim.py) on the same seeded spheres and weights, asserts this
+restatement reproduces the batch (exact) and the logits (<= 1e-5), and stores the result in
+tests/golden/kpconv_*.npz.  Deformable blocks are out of scope.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops as oops
+
+TORONTO3D_CFG = dict(   # ml3d/configs/kpconv_toronto3d.yml:23-82 (inference-relevant keys)
+    KP_extent=1.0, KP_influence="linear", aggregation_mode="sum",
+    architecture=["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb_strided", "resnetb",
+                  "resnetb_strided", "resnetb", "resnetb_strided", "resnetb", "nearest_upsample", "unary",
+                  "nearest_upsample", "unary", "nearest_upsample", "unary", "nearest_upsample", "unary"],
+    batch_limit=10000, batch_norm_momentum=0.98, conv_radius=2.5, first_features_dim=128,
+    first_subsampling_dl=0.08, fixed_kernel_points="center", in_features_dim=1, in_points_dim=3, in_radius=4.0,
+    lbl_values=[0, 1, 2, 3, 4, 5, 6, 7, 8], ignored_label_inds=[0], max_in_points=10000, modulated=False,
+    num_classes=8, num_kernel_points=15, num_layers=5, use_batch_norm=True, reduce_fc=True, l_relu=0.2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# batcher (concat_batcher.py:186-305)
+# ---------------------------------------------------------------------------------------------------
+def create_3d_rotations(axis, angle):
+    """ml3d/datasets/utils/operations.py:10-41 (Rodrigues formula, same term order)."""
+    t1 = np.cos(angle)
+    t2 = 1 - t1
+    t3 = axis[:, 0] * axis[:, 0]
+    t6 = t2 * axis[:, 0]
+    t7 = t6 * axis[:, 1]
+    t8 = np.sin(angle)
+    t9 = t8 * axis[:, 2]
+    t11 = t6 * axis[:, 2]
+    t12 = t8 * axis[:, 1]
+    t15 = axis[:, 1] * axis[:, 1]
+    t19 = t2 * axis[:, 1] * axis[:, 2]
+    t20 = t8 * axis[:, 0]
+    t24 = axis[:, 2] * axis[:, 2]
+    R = np.stack([t1 + t2 * t3, t7 - t9, t11 + t12, t7 + t9, t1 + t2 * t15, t19 - t20, t11 - t12, t19 + t20,
+                  t1 + t2 * t24], axis=1)
+    return np.reshape(R, (-1, 3, 3))
+
+
+def random_grid_rotations(B):
+    """The np.random draws of batch_grid_subsampling (kpconv.py:2059-2080), in the same order."""
+    theta = np.random.rand(B) * 2 * np.pi
+    phi = (np.random.rand(B) - 0.5) * np.pi
+    u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+    alpha = np.random.rand(B) * 2 * np.pi
+    return create_3d_rotations(u.T, alpha).astype(np.float32)
+
+
+def rotate_rows(points, lengths, R, transpose=False):
+    """points[i0:i0+len] = sum(expand_dims(p, 2) * R[b], axis=1)  (kpconv.py:2086-2092 / 2105-2110)."""
+    out = points.copy()
+    i0 = 0
+    for b, ln in enumerate(lengths):
+        ln = int(ln)
+        M = R[b].T if transpose else R[b]
+        out[i0:i0 + ln, :] = np.sum(np.expand_dims(out[i0:i0 + ln, :], 2) * M, axis=1)
+        i0 += ln
+    return out
+
+
+def batch_grid_subsampling(points, batches_len, sampleDl, R=None):
+    """kpconv.py:2037-2111 (points only).  R = per-item rotation matrices or None (random_grid_orient=False)."""
+    pts = points if R is None else rotate_rows(points, batches_len, R)
+    s_points, s_len = oops.subsample_batch(pts, batches_len, sampleDl=sampleDl)
+    if R is not None:
+        s_points = rotate_rows(s_points, s_len, R, transpose=True)
+    return s_points, s_len
+
+
+def batch_neighbors(queries, supports, q_batches, s_batches, radius):
+    """kpconv.py:2002-2034: dense int32 [Nq, max_nbrs], shadow index = Ns."""
+    qs = np.concatenate([[0], np.cumsum(q_batches)]).astype(np.int64)
+    ss = np.concatenate([[0], np.cumsum(s_batches)]).astype(np.int64)
+    r = oops.fixed_radius_search(supports, queries, radius, ss, qs)
+    splits = r.neighbors_row_splits
+    max_nbrs = int((splits[1:] - splits[:-1]).max()) if len(splits) > 1 else 0
+    dense = oops.ragged_to_dense(r.neighbors_index.reshape(-1, 1), splits, max_nbrs,
+                                 np.array([supports.shape[0]], np.int32))
+    return dense[:, :, 0]
+
+
+def segmentation_inputs(stacked_points, stack_lengths, cfg, rotations="random"):
+    """concat_batcher.py:186-305 for rigid architectures.  ``rotations``: "random" (draw from np.random like
+    the reference), None (axis-aligned pooling grids) or a list with one [B,3,3] array per pooling layer.
+    Returns dict(points, neighbors, pools, upsamples, lengths, rotations)."""
+    r_normal = cfg["first_subsampling_dl"] * cfg["conv_radius"]
+    layer_blocks = []
+    out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], rotations=[])
+    stack_lengths = np.asarray(stack_lengths, np.int32)
+    for block in cfg["architecture"]:
+        if "deformable" in block:
+            raise NotImplementedError("deformable KPConv is out of scope")
+        if not ("pool" in block or "strided" in block or "global" in block or "upsample" in block):
+            layer_blocks.append(block)
+            continue
+        if layer_blocks:
+            conv_i = batch_neighbors(stacked_points, stacked_points, stack_lengths, stack_lengths, r_normal)
+        else:
+            conv_i = np.zeros((0, 1), np.int32)
+        if "pool" in block or "strided" in block:
+            dl = 2 * r_normal / cfg["conv_radius"]
+            li = len(out["points"])
+            if isinstance(rotations, str):
+                R = random_grid_rotations(len(stack_lengths))
+            elif rotations is None:
+                R = None
+            else:
+                R = rotations[li]
+            pool_p, pool_b = batch_grid_subsampling(stacked_points, stack_lengths, dl, R)
+            pool_i = batch_neighbors(pool_p, stacked_points, pool_b, stack_lengths, r_normal)
+            up_i = batch_neighbors(stacked_points, pool_p, stack_lengths, pool_b, 2 * r_normal)
+            out["rotations"].append(R)
+        else:
+            pool_i = np.zeros((0, 1), np.int32)
+            pool_p = np.zeros((0, 3), np.float32)
+            pool_b = np.zeros((0,), np.int32)
+            up_i = np.zeros((0, 1), np.int32)
+        out["points"].append(stacked_points)
+        out["neighbors"].append(conv_i.astype(np.int64))
+        out["pools"].append(pool_i.astype(np.int64))
+        out["upsamples"].append(up_i.astype(np.int64))
+        out["lengths"].append(stack_lengths)
+        stacked_points, stack_lengths = pool_p, pool_b
+        r_normal *= 2
+        layer_blocks = []
+        if "global" in block or "upsample" in block:
+            break
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# architecture walk (kpconv.py:131-236) -> flat list of block descriptors
+# ---------------------------------------------------------------------------------------------------
+def arch_plan(cfg):
+    """Mirrors the two loops of KPFCNN.__init__: returns (encoder, decoder, head) lists of dicts
+    {name, kind, layer, in_dim, out_dim, radius, extent}, plus encoder_skips / decoder_concats."""
+    arch = cfg["architecture"]
+    layer, r = 0, cfg["first_subsampling_dl"] * cfg["conv_radius"]
+    in_dim, out_dim = cfg["in_features_dim"], cfg["first_features_dim"]
+    enc, skips, skip_dims = [], [], []
+    for bi, block in enumerate(arch):
+        if any(t in block for t in ("pool", "strided", "upsample", "global")):
+            skips.append(bi)
+            skip_dims.append(in_dim)
+        if "upsample" in block:
+            break
+        enc.append(dict(name=block, layer=layer, in_dim=in_dim, out_dim=out_dim, radius=r,
+                        extent=r * cfg["KP_extent"] / cfg["conv_radius"]))
+        in_dim = out_dim // 2 if "simple" in block else out_dim
+        if "pool" in block or "strided" in block:
+            layer += 1
+            r *= 2
+            out_dim *= 2
+    dec, concats = [], []
+    start = next((i for i, b in enumerate(arch) if "upsample" in b), len(arch))
+    for bi, block in enumerate(arch[start:]):
+        if bi > 0 and "upsample" in arch[start + bi - 1]:
+            in_dim += skip_dims[layer]
+            concats.append(bi)
+        dec.append(dict(name=block, layer=layer, in_dim=in_dim, out_dim=out_dim, radius=r,
+                        extent=r * cfg["KP_extent"] / cfg["conv_radius"]))
+        in_dim = out_dim
+        if bi == 0 and cfg.get("reduce_fc", False):
+            out_dim = out_dim // 2
+        if "upsample" in block:
+            layer -= 1
+            r *= 0.5
+            out_dim = out_dim // 2
+    C = len(cfg["lbl_values"]) - len(cfg["ignored_label_inds"])
+    if cfg.get("reduce_fc", False):
+        head = [dict(in_dim=out_dim, out_dim=cfg["first_features_dim"] // 2, bn=True, relu=True),
+                dict(in_dim=cfg["first_features_dim"] // 2, out_dim=C, bn=False, relu=False)]
+    else:
+        head = [dict(in_dim=out_dim, out_dim=cfg["first_features_dim"], bn=False, relu=True),
+                dict(in_dim=cfg["first_features_dim"], out_dim=C, bn=False, relu=True)]
+    return dict(encoder=enc, decoder=dec, head=head, encoder_skips=skips, decoder_concats=concats)
+
+
+def synthetic_kernel_points(radius, K=15):
+    """Deterministic stand-in for load_kernels (kpconv.py:1909-1999; the reference optimises a random
+    disposition and caches it on disk): centre point + K-1 points on a Fibonacci sphere of 0.66 * radius."""
+    pts = [[0.0, 0.0, 0.0]]
+    n = K - 1
+    for i in range(n):
+        z = 1 - 2 * (i + 0.5) / n
+        rr = np.sqrt(max(0.0, 1 - z * z))
+        ph = i * np.pi * (3 - np.sqrt(5))
+        pts.append([0.66 * rr * np.cos(ph), 0.66 * rr * np.sin(ph), 0.66 * z])
+    return (np.asarray(pts) * radius).astype(np.float32)
+
+
+def make_state_dict(cfg, seed):
+    """Pseudo-trained weights with the reference's state_dict keys and shapes."""
+    g = torch.Generator().manual_seed(int(seed))
+    plan = arch_plan(cfg)
+    sd = {}
+    K = cfg["num_kernel_points"]
+
+    def rnd(*shape, scale=1.0):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+    def bn(prefix, c):
+        if cfg["use_batch_norm"]:
+            sd[prefix + ".batch_norm.weight"] = 1 + rnd(c, scale=0.3)
+            sd[prefix + ".batch_norm.bias"] = rnd(c, scale=0.3)
+            sd[prefix + ".batch_norm.running_mean"] = rnd(c, scale=0.2)
+            sd[prefix + ".batch_norm.running_var"] = 0.5 + torch.rand(c, generator=g)
+            sd[prefix + ".batch_norm.num_batches_tracked"] = torch.tensor(100)
+        else:
+            sd[prefix + ".bias"] = rnd(c, scale=0.3)
+
+    def unary(prefix, cin, cout, use_bn=True):
+        sd[prefix + ".mlp.weight"] = rnd(cout, cin, scale=(3.0 / cin) ** 0.5)
+        if use_bn and cfg["use_batch_norm"]:
+            bn(prefix + ".batch_norm", cout)
+        else:
+            sd[prefix + ".batch_norm.bias"] = rnd(cout, scale=0.3)
+
+    def kpconv(prefix, cin, cout, radius):
+        sd[prefix + ".weights"] = rnd(K, cin, cout, scale=(3.0 / (cin * 4.0)) ** 0.5)
+        sd[prefix + ".kernel_points"] = torch.from_numpy(synthetic_kernel_points(radius, K))
+
+    for i, b in enumerate(plan["encoder"]):
+        p = "encoder_blocks.%d" % i
+        if "simple" in b["name"]:
+            kpconv(p + ".KPConv", b["in_dim"], b["out_dim"] // 2, b["radius"])
+            bn(p + ".batch_norm", b["out_dim"] // 2)
+        elif "resnetb" in b["name"]:
+            mid = b["out_dim"] // 4
+            if b["in_dim"] != mid:
+                unary(p + ".unary1", b["in_dim"], mid)
+            kpconv(p + ".KPConv", mid, mid, b["radius"])
+            bn(p + ".batch_norm_conv", mid)
+            unary(p + ".unary2", mid, b["out_dim"])
+            if b["in_dim"] != b["out_dim"]:
+                unary(p + ".unary_shortcut", b["in_dim"], b["out_dim"])
+        else:
+            raise NotImplementedError(b["name"])
+    for i, b in enumerate(plan["decoder"]):
+        if b["name"] == "unary":
+            unary("decoder_blocks.%d" % i, b["in_dim"], b["out_dim"])
+    h0, h1 = plan["head"]
+    unary("head_mlp", h0["in_dim"], h0["out_dim"], use_bn=h0["bn"])
+    unary("head_softmax", h1["in_dim"], h1["out_dim"], use_bn=h1["bn"])
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward (kpconv.py:270-291 and the block classes)
+# ---------------------------------------------------------------------------------------------------
+def _bn_block(sd, prefix, x, use_bn):
+    """BatchNormBlock.forward (kpconv.py:1239-1250), eval mode."""
+    if use_bn:
+        return F.batch_norm(x, sd[prefix + ".batch_norm.running_mean"], sd[prefix + ".batch_norm.running_var"],
+                            sd[prefix + ".batch_norm.weight"], sd[prefix + ".batch_norm.bias"], False, 0.0, 1e-5)
+    return x + sd[prefix + ".bias"]
+
+
+def _unary(sd, prefix, x, cfg, use_bn=True, relu=True):
+    """UnaryBlock.forward (kpconv.py:1288-1293)."""
+    x = x @ sd[prefix + ".mlp.weight"].t()
+    x = _bn_block(sd, prefix + ".batch_norm", x, use_bn and cfg["use_batch_norm"])
+    return F.leaky_relu(x, cfg.get("l_relu", 0.1)) if relu else x
+
+
+def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
+    """KPConv.forward, non-deformable, KP_influence='linear', aggregation 'sum' (kpconv.py:1048-1159)."""
+    s_pad = torch.cat((s_pts, torch.zeros_like(s_pts[:1, :]) + 1e6), 0)
+    neighbors = s_pad[neighb_inds, :] - q_pts.unsqueeze(1)
+    differences = neighbors.unsqueeze(2) - kernel_points
+    sq = torch.sum(differences ** 2, dim=3)
+    w = torch.clamp(1 - torch.sqrt(sq) / extent, min=0.0).transpose(1, 2)
+    xp = torch.cat((x, torch.zeros_like(x[:1, :])), 0)
+    nx = xp[neighb_inds]
+    wf = torch.matmul(w, nx).permute(1, 0, 2)
+    return torch.sum(torch.matmul(wf, weights), dim=0)
+
+
+def max_pool(x, inds):
+    """kpconv.py:841-858."""
+    xp = torch.cat((x, torch.zeros_like(x[:1, :])), 0)
+    return xp[inds].max(1)[0]
+
+
+def closest_pool(x, inds):
+    """kpconv.py:821-838."""
+    xp = torch.cat((x, torch.zeros_like(x[:1, :])), 0)
+    return xp[inds[:, 0]]
+
+
+@torch.no_grad()
+def forward(sd, cfg, batch, features):
+    """KPFCNN.forward.  batch = dict(points, neighbors, pools, upsamples) of torch tensors per layer."""
+    plan = arch_plan(cfg)
+    lr = cfg.get("l_relu", 0.1)
+    ubn = cfg["use_batch_norm"]
+    x = features.clone()
+    skip_x = []
+    for i, b in enumerate(plan["encoder"]):
+        if i in plan["encoder_skips"]:
+            skip_x.append(x)
+        p = "encoder_blocks.%d" % i
+        L = b["layer"]
+        strided = "strided" in b["name"]
+        q_pts = batch["points"][L + 1] if strided else batch["points"][L]
+        s_pts = batch["points"][L]
+        inds = batch["pools"][L] if strided else batch["neighbors"][L]
+        if "simple" in b["name"]:
+            y = kpconv_rigid(q_pts, s_pts, inds, x, sd[p + ".KPConv.kernel_points"], sd[p + ".KPConv.weights"], b["extent"])
+            x = F.leaky_relu(_bn_block(sd, p + ".batch_norm", y, ubn), lr)
+        else:
+            mid = b["out_dim"] // 4
+            y = _unary(sd, p + ".unary1", x, cfg) if b["in_dim"] != mid else x
+            y = kpconv_rigid(q_pts, s_pts, inds, y, sd[p + ".KPConv.kernel_points"], sd[p + ".KPConv.weights"], b["extent"])
+            y = F.leaky_relu(_bn_block(sd, p + ".batch_norm_conv", y, ubn), lr)
+            y = _unary(sd, p + ".unary2", y, cfg, relu=False)
+            sc = max_pool(x, inds) if strided else x
+            if b["in_dim"] != b["out_dim"]:
+                sc = _unary(sd, p + ".unary_shortcut", sc, cfg, relu=False)
+            x = F.leaky_relu(y + sc, lr)
+    for i, b in enumerate(plan["decoder"]):
+        if i in plan["decoder_concats"]:
+            x = torch.cat([x, skip_x.pop()], dim=1)
+        if "upsample" in b["name"]:
+            x = closest_pool(x, batch["upsamples"][b["layer"] - 1])
+        else:
+            x = _unary(sd, "decoder_blocks.%d" % i, x, cfg)
+    h0, h1 = plan["head"]
+    x = _unary(sd, "head_mlp", x, cfg, use_bn=h0["bn"], relu=h0["relu"])
+    x = _unary(sd, "head_softmax", x, cfg, use_bn=h1["bn"], relu=h1["relu"])
+    return x
+
+
+def to_torch_batch(seg):
+    return dict(points=[torch.from_numpy(np.ascontiguousarray(p)) for p in seg["points"]],
+                neighbors=[torch.from_numpy(a) for a in seg["neighbors"]],
+                pools=[torch.from_numpy(a) for a in seg["pools"]],
+                upsamples=[torch.from_numpy(a) for a in seg["upsamples"]])

@@ -187,3 +187,56 @@ def subsample_batch(points, lengths, dl, features=None, labels=None):
                                ws.ctypes.data, wsb, None)
     assert rc == 0, rc
     return op, lens, of, ol
+
+
+def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1):
+    L = lib()
+    q_pts, s_pts, x = (np.ascontiguousarray(a, np.float32) for a in (q_pts, s_pts, x))
+    inds = np.ascontiguousarray(inds, np.int32)
+    kp = np.ascontiguousarray(kp, np.float32)
+    K, cin, cout = weights.shape
+    w = np.ascontiguousarray(weights.reshape(K * cin, cout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    nq, H = inds.shape
+    out = np.zeros((nq, cout), np.float32)
+    wsb = L.ml3d_kpconv_workspace_bytes(nq, cin, cout, K)
+    ws = _ws(wsb)
+    rc = L.ml3d_kpconv_rigid(q_pts.ctypes.data, s_pts.ctypes.data, inds.ctypes.data, nq, len(s_pts), H, x.ctypes.data,
+                             cin, kp.ctypes.data, K, extent, influence, w.ctypes.data,
+                             None if b is None else b.ctypes.data, act, slope, cout, out.ctypes.data, ws.ctypes.data, wsb,
+                             None)
+    return rc, out
+
+
+def linear(a, wt, bias=None, a2=None, gather=None, gather_stride=1, residual=None, act=0, slope=0.0, m=None):
+    L = lib()
+    a = np.ascontiguousarray(a, np.float32)
+    wt = np.ascontiguousarray(wt, np.float32)
+    k1 = a.shape[1]
+    k2 = 0 if a2 is None else a2.shape[1]
+    a2c = None if a2 is None else np.ascontiguousarray(a2, np.float32)
+    n = wt.shape[1]
+    g = None if gather is None else np.ascontiguousarray(gather, np.int32)
+    if m is None:
+        m = a.shape[0] if g is None else (g.size // gather_stride)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    out = np.zeros((m, n), np.float32)
+    wsb = L.ml3d_linear_workspace_bytes(m, n, k1 + k2)
+    ws = _ws(wsb)
+    rc = L.ml3d_linear(a.ctypes.data, k1, k1, None if g is None else g.ctypes.data, gather_stride, a.shape[0],
+                       None if a2c is None else a2c.ctypes.data, k2, k2, wt.ctypes.data,
+                       None if b is None else b.ctypes.data, None if r is None else r.ctypes.data, n, act, slope,
+                       out.ctypes.data, n, m, n, ws.ctypes.data, wsb, None)
+    return rc, out
+
+
+def gather_pool(x, inds, mode):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    inds = np.ascontiguousarray(inds, np.int32)
+    out = np.zeros((inds.shape[0], x.shape[1]), np.float32)
+    rc = L.ml3d_gather_pool(x.ctypes.data, x.shape[0], x.shape[1], inds.ctypes.data, inds.shape[0], inds.shape[1], mode,
+                            out.ctypes.data, None)
+    assert rc == 0, rc
+    return out

@@ -1,0 +1,86 @@
+"""CPU: the KPConv building blocks (kpconv.hip + gemm.hip) through the host emulator vs the oracle's
+PyTorch restatement of the reference ops (oracle/kpconv_ref.py) — float tolerance 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import emu
+import synth_data
+from oracle import kpconv_ref as K
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="clang++ for the host emulator not found")
+TOL = 1e-4
+
+
+def _layer(seed, n, r):
+    p = synth_data.toronto3d_sphere(seed, n)
+    inds = K.batch_neighbors(p, p, [len(p)], [len(p)], r)
+    return p, inds
+
+
+@pytest.mark.parametrize("cin,cout,n", [(1, 64, 700), (5, 16, 300), (32, 32, 600), (24, 40, 260), (64, 64, 300),
+                                        (128, 128, 130), (256, 64, 70)])
+def test_kpconv_rigid_matches_reference_ops(cin, cout, n):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    p, inds = _layer(21, n, 0.2)
+    x = rng.standard_normal((len(p), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, cin, cout)) * (1.0 / np.sqrt(cin * 4))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    rc, out = emu.kpconv_rigid(p, p, inds, x, kp, w, 0.08, bias=b, act=1, slope=0.2)
+    assert rc == 0
+    ref = K.kpconv_rigid(torch.from_numpy(p), torch.from_numpy(p), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08)
+    ref = torch.nn.functional.leaky_relu(ref + torch.from_numpy(b), 0.2).numpy()
+    assert np.abs(out - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_kpconv_strided_queries_and_shadow_only_rows():
+    rng = np.random.default_rng(3)
+    s = synth_data.toronto3d_sphere(22, 900)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.16)[0], [[50, 50, 50]]]).astype(np.float32)  # last: no nbrs
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], 0.2)
+    assert (inds[-1] == len(s)).all()
+    x = rng.standard_normal((len(s), 32)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, 32, 48)) * 0.1).astype(np.float32)
+    rc, out = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08)
+    ref = K.kpconv_rigid(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08).numpy()
+    assert rc == 0 and np.abs(out - ref).max() <= TOL and (out[-1] == 0).all()
+
+
+@pytest.mark.parametrize("m,k,n", [(300, 64, 128), (70, 1536, 96), (129, 15, 64), (64, 36, 8), (5, 3072, 512)])
+def test_linear_bias_act_residual(m, k, n):
+    rng = np.random.default_rng(m + k + n)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    wt = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    rc, out = emu.linear(a, wt, bias=b, residual=res, act=1, slope=0.1)
+    y = a.astype(np.float64) @ wt + b + res
+    ref = np.where(y > 0, y, 0.1 * y)
+    assert rc == 0 and np.abs(out - ref).max() <= TOL
+
+
+def test_linear_fused_upsample_concat_is_decoder_step():
+    """NearestUpsampleBlock + cat + UnaryBlock (kpconv.py:283-286): [x[up[:,0]] | skip] @ W."""
+    rng = np.random.default_rng(8)
+    xc = rng.standard_normal((40, 64)).astype(np.float32)           # coarse features
+    skip = rng.standard_normal((200, 32)).astype(np.float32)
+    up = rng.integers(0, 41, (200, 7)).astype(np.int32)              # 40 == shadow -> zeros
+    wt = (rng.standard_normal((96, 48)) * 0.1).astype(np.float32)
+    rc, out = emu.linear(xc, wt, a2=skip, gather=up, gather_stride=7, act=1, slope=0.2)
+    xs = K.closest_pool(torch.from_numpy(xc), torch.from_numpy(up).long())
+    y = torch.cat([xs, torch.from_numpy(skip)], 1) @ torch.from_numpy(wt)
+    ref = torch.nn.functional.leaky_relu(y, 0.2).numpy()
+    assert rc == 0 and np.abs(out - ref).max() <= TOL
+
+
+def test_gather_pools_match_reference_ops():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((500, 24)).astype(np.float32)
+    inds = rng.integers(0, 501, (130, 9)).astype(np.int32)
+    inds[7] = 500                                                    # a row of shadow indices only
+    assert np.array_equal(emu.gather_pool(x, inds, 0), K.max_pool(torch.from_numpy(x), torch.from_numpy(inds).long()).numpy())
+    assert np.array_equal(emu.gather_pool(x, inds, 1), K.closest_pool(torch.from_numpy(x), torch.from_numpy(inds).long()).numpy())
