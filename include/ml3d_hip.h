@@ -215,6 +215,69 @@ int ml3d_gather_pool(const float* features, int64_t n_supports, int channels,
 
 
 /* ------------------------------------------------------------------------- */
+/* PointPillars inference blocks — BatchNorm folded by the caller              */
+/* ------------------------------------------------------------------------- */
+/* ml3d_pillar_features replaces, for a whole batch, the tail of               */
+/*   PointPillarsVoxelization.forward (ragged_to_dense + feats[idx] gather +   */
+/*   out-of-bounds filter, ml3d/torch/models/point_pillars.py:359-382),        */
+/*   PillarFeatureNet.forward + PFNLayer.forward (:512-555, 417-453) and       */
+/*   PointPillarsScatter.forward (:577-616).                                   */
+/* Inputs are the ragged result of ml3d_voxelize_* (voxel_coords (x,y,z),      */
+/* point_indices, point_row_splits, batch_splits) and the raw point rows       */
+/* [N, point_stride] (first in_channels floats used, xyz first).  Pillars with */
+/* x >= nx or y >= ny are dropped as the reference does.  Layer l:             */
+/* weights_host[l] = folded Linear [c_in_l, units_l] (c_in_0 = in_channels+5,  */
+/* c_in_l = 2*units_{l-1}), bias_host[l] [units_l] (HOST arrays of DEVICE      */
+/* pointers).  x_offset = vx/2 + range_min_x, y_offset likewise.               */
+/* canvas: NHWC [batch, ny, nx, canvas_channels] f32, zeroed by this call;     */
+/* pixel (b, y, x) receives the pillar's feature (canvas_channels must equal   */
+/* units of the last layer).                                                   */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_pillar_features_workspace_bytes(int64_t n_pillars, int max_num_points,
+                                            int num_layers, const int32_t* units_host);
+
+int ml3d_pillar_features(const float* points, int64_t point_stride, int in_channels,
+                         const int32_t* voxel_coords, const int64_t* point_indices,
+                         const int64_t* point_row_splits, const int64_t* batch_splits,
+                         int64_t batch, int64_t n_pillars, int max_num_points,
+                         float vx, float vy, float x_offset, float y_offset, int nx, int ny,
+                         int num_layers, const int32_t* units_host,
+                         const float* const* weights_host, const float* const* bias_host,
+                         float* canvas, int canvas_channels,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Conv2d + folded BatchNorm + activation on an NHWC map (SECOND backbone,      */
+/*   point_pillars.py:640-682), implicit GEMM on f32 MFMA.                      */
+/* in [batch, h, w, cin] (cin % 4 == 0); weights [(ky*kw + kx)*cin + ci, cout]  */
+/* (= the reference's [cout, cin, kh, kw] tensor permuted, BN scale folded);    */
+/* out pixel (b, oy, ox) channels [0, cout) at out + pixel * out_pixel_stride.  */
+size_t ml3d_conv2d_workspace_bytes(int64_t batch, int out_h, int out_w, int cin, int cout,
+                                   int kh, int kw);
+
+int ml3d_conv2d_nhwc(const float* in, int64_t batch, int h, int w, int cin,
+                     const float* weights, const float* bias, int kh, int kw, int stride,
+                     int pad, int act, float slope, int cout, float* out,
+                     int64_t out_pixel_stride, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ConvTranspose2d with kernel == stride + folded BN + activation (SECONDFPN    */
+/*   deblocks, point_pillars.py:712-717, 749): GEMM + pixel-shuffle store.      */
+/* weights [ci, (dy*stride + dx)*cout + co] (= the reference's [cin, cout, k, k]*/
+/* permuted); out is an NHWC map [batch, h*stride, w*stride, *] with pixel      */
+/* stride out_pixel_stride — pass out + channel_offset to write one slice of    */
+/* the concatenated neck map.                                                   */
+int ml3d_deconv2d_nhwc(const float* in, int64_t batch, int h, int w, int cin,
+                       const float* weights, const float* bias, int stride, int act,
+                       float slope, int cout, float* out, int64_t out_pixel_stride,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* channel slice of an NHWC map -> NCHW tensor (the layout Anchor3DHead.forward  */
+/* returns, point_pillars.py:836-841)                                            */
+int ml3d_nhwc_to_nchw(const float* in, int64_t in_pixel_stride, int channel_offset,
+                      int channels, int64_t batch, int64_t hw, float* out, void* stream);
+
+
+/* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */
 /*   ml3d/torch/models/randlanet.py:218-229 for a batch of equally sized       */
 /*   clouds in ONE call.  Layer l has n_l = n_{l-1} / ratio[l-1] points, the   */

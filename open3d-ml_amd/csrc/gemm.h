@@ -26,6 +26,10 @@ struct Epilogue {
     int64_t ldr;
     int act;                  // 0 none, 1 leaky relu (slope), 2 relu
     float slope;
+    // pixel-shuffle store (ConvTranspose2d with kernel == stride, point_pillars.py:712-717): row m = input pixel
+    // (b, y, x) of a [B, ps_h, ps_w] map, column n = (dy, dx, co); the value goes to output pixel
+    // (b, y*ps + dy, x*ps + dx), channel co, of an NHWC map whose pixel stride is ldc.  bias is indexed by co.
+    int ps, ps_h, ps_w, ps_cout;
 };
 
 // dense / gathered / concatenated rows

@@ -172,6 +172,24 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
         }
         return;
     }
+    if (ep.ps > 0) {
+        const int co = col % ep.ps_cout, dd = col / ep.ps_cout;
+        const int dy = dd / ep.ps, dx = dd % ep.ps;
+        const float b = ep.bias ? ep.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + rt * 32 + mfma32_row(r, hi);
+            if (m < L.M) {
+                const int x = (int)(m % ep.ps_w);
+                const int64_t t = m / ep.ps_w;
+                const int y = (int)(t % ep.ps_h);
+                const int64_t bi = t / ep.ps_h;
+                const int64_t opix = (bi * ep.ps_h * ep.ps + (int64_t)y * ep.ps + dy) * ((int64_t)ep.ps_w * ep.ps) + (int64_t)x * ep.ps + dx;
+                C[opix * ldc + co] = gm_act(acc[r] + b, ep.act, ep.slope);
+            }
+        }
+        return;
+    }
     const float b = ep.bias ? ep.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -192,6 +210,18 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
         const int col = (int)(i - m * N);
         float v = 0.f;
         for (int z = 0; z < splits; ++z) v += partial[(int64_t)z * total + i];
+        if (ep.ps > 0) {
+            const int co = col % ep.ps_cout, dd = col / ep.ps_cout;
+            const int dy = dd / ep.ps, dx = dd % ep.ps;
+            if (ep.bias) v += ep.bias[co];
+            const int x = (int)(m % ep.ps_w);
+            const int64_t t = m / ep.ps_w;
+            const int y = (int)(t % ep.ps_h);
+            const int64_t bi = t / ep.ps_h;
+            const int64_t opix = (bi * ep.ps_h * ep.ps + (int64_t)y * ep.ps + dy) * ((int64_t)ep.ps_w * ep.ps) + (int64_t)x * ep.ps + dx;
+            C[opix * ldc + co] = gm_act(v, ep.act, ep.slope);
+            continue;
+        }
         if (ep.bias) v += ep.bias[col];
         if (ep.residual) v += ep.residual[m * ep.ldr + col];
         C[m * ldc + col] = gm_act(v, ep.act, ep.slope);

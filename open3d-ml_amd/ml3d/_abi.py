@@ -36,6 +36,12 @@ SYMBOLS = [
     "ml3d_linear_workspace_bytes",
     "ml3d_linear",
     "ml3d_gather_pool",
+    "ml3d_pillar_features_workspace_bytes",
+    "ml3d_pillar_features",
+    "ml3d_conv2d_workspace_bytes",
+    "ml3d_conv2d_nhwc",
+    "ml3d_deconv2d_nhwc",
+    "ml3d_nhwc_to_nchw",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -107,6 +113,19 @@ def bind(lib):
                                 vp, sz, vp]
     lib.ml3d_gather_pool.restype = C.c_int
     lib.ml3d_gather_pool.argtypes = [vp, i64, i32, vp, i64, i64, i32, vp, vp]
+    lib.ml3d_pillar_features_workspace_bytes.restype = sz
+    lib.ml3d_pillar_features_workspace_bytes.argtypes = [i64, i32, i32, vp]
+    lib.ml3d_pillar_features.restype = C.c_int
+    lib.ml3d_pillar_features.argtypes = [vp, i64, i32, vp, vp, vp, vp, i64, i64, i32, f32, f32, f32, f32, i32, i32, i32,
+                                         vp, vp, vp, vp, i32, vp, sz, vp]
+    lib.ml3d_conv2d_workspace_bytes.restype = sz
+    lib.ml3d_conv2d_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32]
+    lib.ml3d_conv2d_nhwc.restype = C.c_int
+    lib.ml3d_conv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp, sz, vp]
+    lib.ml3d_deconv2d_nhwc.restype = C.c_int
+    lib.ml3d_deconv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, f32, i32, vp, i64, vp, sz, vp]
+    lib.ml3d_nhwc_to_nchw.restype = C.c_int
+    lib.ml3d_nhwc_to_nchw.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

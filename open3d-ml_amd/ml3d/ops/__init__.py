@@ -473,3 +473,84 @@ def gather_pool(x, inds, mode):
                                   0 if mode == "max" else 1, out.data_ptr(), _stream())
     _abi.check(rc, "ml3d_gather_pool")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# PointPillars blocks
+# ---------------------------------------------------------------------------------------------------
+def pillar_features(points, vox, in_channels, max_num_points, vx, vy, x_offset, y_offset, nx, ny, layers, batch):
+    """Fused dense-gather + PillarFeatureNet + PointPillarsScatter (point_pillars.py:359-382, 512-555, 577-616).
+    ``vox``: VoxelizeResult of the whole batch; ``layers``: [(wt [cin, units], bias [units]), ...] BN-folded.
+    Returns the NHWC canvas [batch, ny, nx, units_last]."""
+    lib = _abi.get()
+    _need_gpu(points, vox.voxel_coords)
+    dev = points.device
+    if points.dtype != torch.float32 or points.dim() != 2 or points.stride(1) != 1:
+        raise RuntimeError("pillar_features: points must be float32 [N, C] rows")
+    stride = points.stride(0) if points.shape[0] > 1 else points.shape[1]
+    M = vox.voxel_coords.shape[0]
+    nl = len(layers)
+    units = (C.c_int32 * nl)(*[int(w.shape[1]) for w, _ in layers])
+    cc = int(layers[-1][0].shape[1])
+    canvas = torch.empty((int(batch), int(ny), int(nx), cc), dtype=torch.float32, device=dev)
+    wsb = lib.ml3d_pillar_features_workspace_bytes(M, int(max_num_points), nl, units)
+    ws = _ws(wsb, dev)
+    tw = _abi.ptr_table([w.data_ptr() for w, _ in layers])
+    tb = _abi.ptr_table([b.data_ptr() for _, b in layers])
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_pillar_features(points.data_ptr(), stride, int(in_channels), vox.voxel_coords.data_ptr(),
+                                      vox.voxel_point_indices.data_ptr(), vox.voxel_point_row_splits.data_ptr(),
+                                      vox.voxel_batch_splits.data_ptr(), int(batch), M, int(max_num_points), float(vx),
+                                      float(vy), float(x_offset), float(y_offset), int(nx), int(ny), nl, units, tw, tb,
+                                      canvas.data_ptr(), cc, ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_pillar_features")
+    return canvas
+
+
+def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=None, out_channel_offset=0):
+    """Conv2d + folded BN + activation on NHWC maps (SECOND, point_pillars.py:640-682)."""
+    lib = _abi.get()
+    _need_gpu(x, weights, bias)
+    B, H, W, Cin = x.shape
+    cout = weights.shape[1]
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((B, OH, OW, cout), dtype=torch.float32, device=x.device)
+    ld = out.shape[3]
+    wsb = lib.ml3d_conv2d_workspace_bytes(B, OH, OW, Cin, cout, kh, kw)
+    ws = _ws(wsb, x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ml3d_conv2d_nhwc(x.data_ptr(), B, H, W, Cin, weights.data_ptr(), None if bias is None else bias.data_ptr(),
+                                  kh, kw, stride, pad, act, slope, cout, out.data_ptr() + 4 * out_channel_offset, ld,
+                                  ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_conv2d_nhwc")
+    return out
+
+
+def deconv2d_nhwc(x, weights, bias, stride, cout, act=2, slope=0.0, out=None, out_channel_offset=0):
+    """ConvTranspose2d(kernel == stride) + folded BN + activation (SECONDFPN, point_pillars.py:712-717, 749)."""
+    lib = _abi.get()
+    _need_gpu(x, weights, bias)
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H * stride, W * stride, cout), dtype=torch.float32, device=x.device)
+    ld = out.shape[3]
+    wsb = lib.ml3d_conv2d_workspace_bytes(B, H, W, Cin, stride * stride * cout, 1, 1)
+    ws = _ws(wsb, x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ml3d_deconv2d_nhwc(x.data_ptr(), B, H, W, Cin, weights.data_ptr(),
+                                    None if bias is None else bias.data_ptr(), stride, act, slope, cout,
+                                    out.data_ptr() + 4 * out_channel_offset, ld, ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_deconv2d_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, channel_offset, channels):
+    lib = _abi.get()
+    _need_gpu(x)
+    B, H, W, ld = x.shape
+    out = torch.empty((B, channels, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ml3d_nhwc_to_nchw(x.data_ptr(), ld, int(channel_offset), int(channels), B, H * W, out.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_nhwc_to_nchw")
+    return out

@@ -1,0 +1,289 @@
+"""PointPillars (inference forward) on MI355X — host-side mirror of the reference model.
+
+Same constructor arguments, module/parameter names and state_dict layout as the reference
+``ml3d/torch/models/point_pillars.py:43-98,309-841``, so
+``ml3d/configs/pointpillars_*.yml`` and published checkpoints load unchanged.  The module tree only OWNS
+parameters; ``forward`` folds eval-mode BatchNorm once and runs hand-written HIP kernels through the C ABI:
+batched voxelize -> fused pillar gather + PillarFeatureNet + scatter into an NHWC canvas -> SECOND / SECONDFPN /
+Anchor3DHead as f32-MFMA implicit GEMMs -> the reference's three NCHW head tensors.
+There is no CPU execution path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class PFNLayer(nn.Module):
+    """point_pillars.py:385-415 (parameters only)."""
+
+    def __init__(self, in_channels, out_channels, last_layer=False, mode='max'):
+        super().__init__()
+        if mode != 'max':
+            raise NotImplementedError("PFNLayer (MI355X build): mode='max' only")
+        self.last_vfe = last_layer
+        self.units = out_channels if last_layer else out_channels // 2
+        self.norm = nn.BatchNorm1d(self.units, eps=1e-3, momentum=0.01)
+        self.linear = nn.Linear(in_channels, self.units, bias=False)
+
+
+class PillarFeatureNet(nn.Module):
+    """point_pillars.py:456-510."""
+
+    def __init__(self, in_channels=4, feat_channels=(64,), voxel_size=(0.16, 0.16, 4),
+                 point_cloud_range=(0, -40.0, -3, 70.0, 40.0, 1)):
+        super().__init__()
+        self.raw_channels = in_channels
+        self.in_channels = in_channels + 5
+        chans = [self.in_channels] + list(feat_channels)
+        self.pfn_layers = nn.ModuleList([PFNLayer(chans[i], chans[i + 1], last_layer=(i == len(chans) - 2))
+                                         for i in range(len(chans) - 1)])
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+
+
+class PointPillarsVoxelization(nn.Module):
+    """point_pillars.py:309-382 — GPU voxelize; ``forward`` returns the reference's (voxels, coords zyx, num_points)."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points=32, max_voxels=[16000, 40000]):
+        super().__init__()
+        self.voxel_size = torch.Tensor(voxel_size)
+        self.point_cloud_range = point_cloud_range
+        self.points_range_min = torch.Tensor(point_cloud_range[:3])
+        self.points_range_max = torch.Tensor(point_cloud_range[3:])
+        self.max_num_points = max_num_points
+        self.max_voxels = list(max_voxels) if isinstance(max_voxels, (tuple, list)) else [max_voxels, max_voxels]
+
+    def num_voxels(self):
+        return ((self.points_range_max - self.points_range_min) / self.voxel_size).type(torch.int32)
+
+    def voxelize_batch(self, points_list):
+        """One batched ``voxelize`` over all samples (row_splits), eval-mode max_voxels."""
+        dev = points_list[0].device
+        lens = [int(p.shape[0]) for p in points_list]
+        pts = points_list[0] if len(points_list) == 1 else torch.cat(points_list, 0)
+        pts = pts.float().contiguous()
+        rs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=dev)
+        mv = self.max_voxels[0] if self.training else self.max_voxels[1]
+        vox = ops.voxelize(pts[:, :3], rs, self.voxel_size, self.points_range_min, self.points_range_max,
+                           self.max_num_points, mv)
+        return pts, vox
+
+    def forward(self, points_feats):
+        """API parity with the reference layer for ONE sample [N, 3+C]: dense voxels [M, P, 3+C], coords (z,y,x),
+        points per voxel — built from the GPU voxelize + ragged_to_dense ops (the fused model path skips this)."""
+        pts, ans = self.voxelize_batch([points_feats])
+        nv = self.num_voxels()
+        feats = torch.cat([torch.zeros_like(pts[0:1, :]), pts])
+        dense = ops.ragged_to_dense(ans.voxel_point_indices, ans.voxel_point_row_splits, self.max_num_points,
+                                    torch.tensor(-1)) + 1
+        out_voxels = feats[dense]
+        out_coords = ans.voxel_coords[:, [2, 1, 0]].contiguous()
+        out_num = ans.voxel_point_row_splits[1:] - ans.voxel_point_row_splits[:-1]
+        inb = torch.logical_and(out_coords[:, 2] < int(nv[0]), out_coords[:, 1] < int(nv[1]))
+        return out_voxels[inb], out_coords[inb], out_num[inb]
+
+
+class PointPillarsScatter(nn.Module):
+    def __init__(self, in_channels=64, output_shape=[496, 432]):
+        super().__init__()
+        self.output_shape = output_shape
+        self.ny, self.nx = output_shape[0], output_shape[1]
+        self.in_channels = in_channels
+
+
+class SECOND(nn.Module):
+    """point_pillars.py:619-664 (parameter layout: Sequential(conv, bn, relu, ...))."""
+
+    def __init__(self, in_channels=64, out_channels=[64, 128, 256], layer_nums=[3, 5, 5], layer_strides=[2, 2, 2]):
+        super().__init__()
+        self.layer_strides = list(layer_strides)
+        in_filters = [in_channels, *out_channels[:-1]]
+        blocks = []
+        for i, layer_num in enumerate(layer_nums):
+            block = [nn.Conv2d(in_filters[i], out_channels[i], 3, bias=False, stride=layer_strides[i], padding=1),
+                     nn.BatchNorm2d(out_channels[i], eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)]
+            for _ in range(layer_num):
+                block += [nn.Conv2d(out_channels[i], out_channels[i], 3, bias=False, padding=1),
+                          nn.BatchNorm2d(out_channels[i], eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)]
+            blocks.append(nn.Sequential(*block))
+        self.blocks = nn.ModuleList(blocks)
+
+
+class SECONDFPN(nn.Module):
+    """point_pillars.py:685-737."""
+
+    def __init__(self, in_channels=[64, 128, 256], out_channels=[128, 128, 128], upsample_strides=[1, 2, 4],
+                 use_conv_for_no_stride=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.upsample_strides = list(in_channels), list(out_channels), list(upsample_strides)
+        deblocks = []
+        for i, oc in enumerate(out_channels):
+            s = upsample_strides[i]
+            if not (s > 1 or (s == 1 and not use_conv_for_no_stride)) or int(s) != s:
+                raise NotImplementedError("SECONDFPN (MI355X build): integer upsample strides via ConvTranspose2d only")
+            up = nn.ConvTranspose2d(in_channels[i], oc, kernel_size=int(s), stride=int(s), bias=False)
+            deblocks.append(nn.Sequential(up, nn.BatchNorm2d(oc, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(deblocks)
+
+
+class Anchor3DHead(nn.Module):
+    """point_pillars.py:758-841 (forward part)."""
+
+    def __init__(self, num_classes=1, in_channels=384, feat_channels=384, nms_pre=100, score_thr=0.1, dir_offset=0,
+                 ranges=[[0, -40.0, -3, 70.0, 40.0, 1]], sizes=[[0.6, 1.0, 1.5]], rotations=[0, 1.57],
+                 iou_thr=[[0.35, 0.5]]):
+        super().__init__()
+        self.num_classes, self.in_channels, self.feat_channels = num_classes, in_channels, feat_channels
+        self.nms_pre, self.score_thr, self.dir_offset = nms_pre, score_thr, dir_offset
+        self.ranges, self.sizes, self.rotations, self.iou_thr = ranges, sizes, rotations, iou_thr
+        self.num_anchors = len(sizes) * len(rotations)
+        self.box_code_size = 7
+        self.conv_cls = nn.Conv2d(feat_channels, self.num_anchors * num_classes, 1)
+        self.conv_reg = nn.Conv2d(feat_channels, self.num_anchors * self.box_code_size, 1)
+        self.conv_dir_cls = nn.Conv2d(feat_channels, self.num_anchors * 2, 1)
+
+
+def _bn_affine(bn):
+    s = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+    return s, bn.bias.detach().double().cpu() - bn.running_mean.detach().double().cpu() * s
+
+
+class PointPillars(nn.Module):
+
+    def __init__(self, name="PointPillars", device="cuda", point_cloud_range=[0, -40.0, -3, 70.0, 40.0, 1],
+                 classes=['car'], voxelize={}, voxel_encoder={}, scatter={}, backbone={}, neck={}, head={}, loss={},
+                 **kwargs):
+        super().__init__()
+        self.cfg = _Cfg(name=name, point_cloud_range=point_cloud_range, classes=classes, voxelize=voxelize,
+                        voxel_encoder=voxel_encoder, scatter=scatter, backbone=backbone, neck=neck, head=head, **kwargs)
+        self.point_cloud_range = point_cloud_range
+        self.classes = classes
+        self.name2lbl = {n: i for i, n in enumerate(classes)}
+        self.lbl2name = {i: n for i, n in enumerate(classes)}
+        self.voxel_layer = PointPillarsVoxelization(point_cloud_range=point_cloud_range, **voxelize)
+        self.voxel_encoder = PillarFeatureNet(point_cloud_range=point_cloud_range, **voxel_encoder)
+        self.middle_encoder = PointPillarsScatter(**scatter)
+        self.backbone = SECOND(**backbone)
+        self.neck = SECONDFPN(**neck)
+        self.bbox_head = Anchor3DHead(num_classes=len(self.classes), **head)
+        self.device = torch.device(device) if isinstance(device, str) else device
+        self._packed = None
+        self.eval()
+
+    # ---- BatchNorm folding -------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def packed_params(self, dev):
+        if self._packed is None or self._packed[0] != dev:
+            P = dict(pfn=[], blocks=[], deblocks=[])
+            for l in self.voxel_encoder.pfn_layers:
+                s, t = _bn_affine(l.norm)
+                wt = (l.linear.weight.detach().double().cpu() * s[:, None]).t().contiguous()
+                P['pfn'].append((wt.float().to(dev), t.float().to(dev)))
+            for blk in self.backbone.blocks:
+                convs = []
+                mods = list(blk)
+                for i in range(0, len(mods), 3):
+                    conv, bn = mods[i], mods[i + 1]
+                    s, t = _bn_affine(bn)
+                    w = conv.weight.detach().double().cpu() * s[:, None, None, None]          # [co, ci, ky, kx]
+                    co, ci, kh, kw = w.shape
+                    wk = w.permute(2, 3, 1, 0).reshape(kh * kw * ci, co).contiguous()          # [(ky,kx,ci), co]
+                    convs.append(dict(w=wk.float().to(dev), b=t.float().to(dev), stride=conv.stride[0], k=kh,
+                                      pad=conv.padding[0]))
+                P['blocks'].append(convs)
+            for db in self.neck.deblocks:
+                up, bn = db[0], db[1]
+                s, t = _bn_affine(bn)
+                w = up.weight.detach().double().cpu() * s[None, :, None, None]                # [ci, co, k, k]
+                ci, co, k, _ = w.shape
+                wk = w.permute(0, 2, 3, 1).reshape(ci, k * k * co).contiguous()                # [ci, (dy,dx,co)]
+                P['deblocks'].append(dict(w=wk.float().to(dev), b=t.float().to(dev), stride=k, cout=co))
+            h = self.bbox_head
+            ws, bs = [], []
+            for conv in (h.conv_cls, h.conv_reg, h.conv_dir_cls):
+                ws.append(conv.weight.detach().double().cpu()[:, :, 0, 0].t())                # [cin, co]
+                bs.append(conv.bias.detach().double().cpu())
+            P['head_w'] = torch.cat(ws, 1).contiguous().float().to(dev)
+            P['head_b'] = torch.cat(bs).float().to(dev)
+            P['head_split'] = [w.shape[1] for w in ws]
+            self._packed = (dev, P)
+        return self._packed[1]
+
+    # ---- inference --------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def voxelize(self, points):
+        """Reference API (point_pillars.py:113-131): (voxels, num_points, coors with the sample id prepended)."""
+        voxels, coors, num_points = [], [], []
+        for i, res in enumerate(points):
+            v, c, n = self.voxel_layer(res.to(self.device))
+            voxels.append(v)
+            coors.append(torch.nn.functional.pad(c, (1, 0), mode='constant', value=i))
+            num_points.append(n)
+        return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
+
+    def extract_feats(self, points):
+        """NHWC neck feature map [B, H, W, sum(out_channels)] (the reference returns NCHW)."""
+        dev = self.device
+        P = self.packed_params(dev)
+        pts_list = [p.to(dev, torch.float32) for p in points]
+        pts, vox = self.voxel_layer.voxelize_batch(pts_list)
+        ve, vl = self.voxel_encoder, self.voxel_layer
+        nv = vl.num_voxels()
+        ny, nx = self.middle_encoder.ny, self.middle_encoder.nx
+        x = ops.pillar_features(pts, vox, ve.raw_channels, vl.max_num_points, ve.vx, ve.vy, ve.x_offset, ve.y_offset,
+                                min(nx, int(nv[0])), min(ny, int(nv[1])), P['pfn'], len(pts_list))
+        if x.shape[1] != ny or x.shape[2] != nx:      # canvas allocated with the in-bounds limits; pad if they differ
+            full = torch.zeros((x.shape[0], ny, nx, x.shape[3]), dtype=x.dtype, device=dev)
+            full[:, :x.shape[1], :x.shape[2]] = x
+            x = full
+        outs = []
+        for convs in P['blocks']:
+            for c in convs:
+                x = ops.conv2d_nhwc(x, c['w'], c['b'], c['k'], c['k'], c['stride'], c['pad'], act=2)
+            outs.append(x)
+        ctot = sum(d['cout'] for d in P['deblocks'])
+        d0 = P['deblocks'][0]
+        B, H0, W0 = outs[0].shape[0], outs[0].shape[1] * d0['stride'], outs[0].shape[2] * d0['stride']
+        neck = torch.empty((B, H0, W0, ctot), dtype=torch.float32, device=dev)
+        off = 0
+        for o, d in zip(outs, P['deblocks']):
+            if o.shape[1] * d['stride'] != H0 or o.shape[2] * d['stride'] != W0:
+                raise RuntimeError("SECONDFPN: upsampled maps do not share one size")
+            ops.deconv2d_nhwc(o, d['w'], d['b'], d['stride'], d['cout'], act=2, out=neck, out_channel_offset=off)
+            off += d['cout']
+        return neck
+
+    def forward(self, inputs):
+        """``inputs.point``: list of [N_i, 3+C] clouds (point_pillars.py:133-138).  Returns (cls_score, bbox_pred,
+        dir_cls_preds) as NCHW tensors like ``Anchor3DHead.forward``."""
+        if self.training:
+            raise RuntimeError("PointPillars (MI355X build) implements the inference forward only; call .eval()")
+        if self.device.type != 'cuda':
+            raise RuntimeError("PointPillars.forward needs an MI355X device; there is no CPU fallback")
+        points = inputs.point if hasattr(inputs, 'point') else inputs
+        neck = self.extract_feats(points)
+        P = self.packed_params(self.device)
+        B, H, W, Cn = neck.shape
+        heads = ops.linear(neck.view(B * H * W, Cn), P['head_w'], P['head_b']).view(B, H, W, -1)
+        outs, off = [], 0
+        for c in P['head_split']:
+            outs.append(ops.nhwc_to_nchw(heads, off, c))
+            off += c
+        return tuple(outs)

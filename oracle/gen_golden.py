@@ -112,6 +112,49 @@ def kpconv_golden(out_path, frame_ids, max_points, weights_seed, np_seed):
     print("kpconv golden:", out_path, logits.shape, [tuple(x) for x in g["lengths"]])
 
 
+def pointpillars_golden(out_path, cfg_name, frame_ids, weights_seed, stride):
+    """PointPillars through the REAL reference module (voxelize / ragged_to_dense come from the oracle via the
+    shim); stores the three head maps subsampled by `stride` plus per-map checksums."""
+    import importlib
+    from oracle import pointpillars_ref as P
+    pp = importlib.import_module("ml3d.torch.models.point_pillars")
+    assert os.path.abspath(pp.__file__).startswith(os.path.abspath(ref_shim.REF_ROOT))
+    cfg = getattr(P, cfg_name)
+    model = pp.PointPillars(device="cpu", augment={}, **cfg)
+    sd = P.make_state_dict(cfg, weights_seed)
+    ref_sd = model.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), sorted(set(ref_sd) ^ set(sd))[:10]
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd)
+    model.eval()
+    clouds = [P.crop_for_cfg(synth_data.kitti_sweep(f), cfg) for f in frame_ids]
+    pts = [torch.from_numpy(c) for c in clouds]
+
+    class _In:
+        point = pts
+    with torch.no_grad():
+        voxels, num_points, coors = model.voxelize(pts)
+        outs = model(_In())
+    (mc, mr, md), aux = P.forward(sd, cfg, pts)
+    assert torch.equal(aux["coors"], coors) and torch.equal(aux["num_points"], num_points)
+    assert torch.equal(aux["voxels"], voxels)
+    for a, b in zip(outs, (mc, mr, md)):
+        assert (a - b).abs().max() <= 1e-5, (a - b).abs().max()
+    g = dict(frame_ids=np.asarray(frame_ids), weights_seed=weights_seed, stride=stride,
+             n_points=np.asarray([len(c) for c in clouds]), n_pillars=np.int64(len(coors)),
+             coors_checksum=np.int64((coors.long() * torch.tensor([1000003, 10007, 101, 1])).sum()),
+             num_points_sum=np.int64(num_points.sum()), coors_head=coors[:256].numpy().astype(np.int32))
+    for name, t in zip(("cls", "reg", "dir"), outs):
+        a = t.numpy()
+        g[name] = a[:, :, ::stride, ::stride].copy()
+        g[name + "_sum"] = a.astype(np.float64).sum()
+        g[name + "_abssum"] = np.abs(a.astype(np.float64)).sum()
+        g[name + "_shape"] = np.asarray(a.shape)
+    np.savez_compressed(out_path, **g)
+    print("pointpillars golden:", out_path, [tuple(t.shape) for t in outs], "pillars", len(coors))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cwd = os.getcwd()
@@ -155,6 +198,9 @@ def main():
     # 4. KPConv (Toronto3D config): one small 2-sphere batch (full logits) and one 10k-point sphere
     kpconv_golden(os.path.join(OUT, "kpconv_small.npz"), [11, 12], 1500, 303, 1234)
     kpconv_golden(os.path.join(OUT, "kpconv_toronto3d.npz"), [1], 10000, 303, 99)
+    # 5. PointPillars: small 2-PFN-layer config, 2 samples, full maps; KITTI config, 1 sample, every 6th pixel
+    pointpillars_golden(os.path.join(OUT, "pointpillars_small.npz"), "SMALL_CFG", [5, 6], 404, 1)
+    pointpillars_golden(os.path.join(OUT, "pointpillars_kitti.npz"), "KITTI_CFG", [0], 404, 6)
     os.chdir(cwd)
     print("golden vectors written to", OUT)
 

@@ -1,0 +1,210 @@
+"""CPU ORACLE for the PointPillars inference forward — test infrastructure, NOT product code.
+
+Functional PyTorch-CPU restatement of
+  * ``PointPillarsVoxelization.forward``  ml3d/torch/models/point_pillars.py:328-382
+  * ``PillarFeatureNet.forward`` / ``PFNLayer.forward``          :512-555, 417-453
+  * ``PointPillarsScatter.forward``                              :577-616
+  * ``SECOND.forward`` / ``SECONDFPN.forward`` / ``Anchor3DHead.forward``   :619-841
+  * ``PointPillars.voxelize`` / ``extract_feats`` / ``forward``  :102-138
+on top of the oracle's voxelize / ragged_to_dense (oracle/ops.py).
+
+PINNED: ``oracle/gen_golden.py`` runs the REAL reference PointPillars module (imported from /root/reference
+through oracle/ref_shim.py) with the same weights and clouds, asserts this restatement agrees (<= 1e-5) and
+writes tests/golden/pointpillars_*.npz.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops as oops
+
+KITTI_CFG = dict(   # ml3d/configs/pointpillars_kitti.yml:7-66 (inference-relevant keys)
+    point_cloud_range=[0, -39.68, -3, 69.12, 39.68, 1], classes=["Pedestrian", "Cyclist", "Car"],
+    voxelize=dict(max_num_points=32, voxel_size=[0.16, 0.16, 4], max_voxels=[16000, 40000]),
+    voxel_encoder=dict(in_channels=4, feat_channels=[64], voxel_size=[0.16, 0.16, 4]),
+    scatter=dict(in_channels=64, output_shape=[496, 432]),
+    backbone=dict(in_channels=64, out_channels=[64, 128, 256], layer_nums=[3, 5, 5], layer_strides=[2, 2, 2]),
+    neck=dict(in_channels=[64, 128, 256], out_channels=[128, 128, 128], upsample_strides=[1, 2, 4],
+              use_conv_for_no_stride=False),
+    head=dict(in_channels=384, feat_channels=384, nms_pre=100, score_thr=0.1,
+              ranges=[[0, -39.68, -0.6, 70.4, 39.68, -0.6], [0, -39.68, -0.6, 70.4, 39.68, -0.6],
+                      [0, -39.68, -1.78, 70.4, 39.68, -1.78]],
+              sizes=[[0.6, 0.8, 1.73], [0.6, 1.76, 1.73], [1.6, 3.9, 1.56]], rotations=[0, 1.57],
+              iou_thr=[[0.35, 0.5], [0.35, 0.5], [0.45, 0.6]]))
+
+# a small two-PFN-layer, 3-channel-point variant (the argoverse / nuscenes shape family) on a 64 x 48 canvas
+SMALL_CFG = dict(
+    point_cloud_range=[0, -9.6, -3, 25.6, 9.6, 1], classes=["Car", "Pedestrian"],
+    voxelize=dict(max_num_points=20, voxel_size=[0.4, 0.4, 4], max_voxels=[3000, 3000]),
+    voxel_encoder=dict(in_channels=3, feat_channels=[64, 64], voxel_size=[0.4, 0.4, 4]),
+    scatter=dict(in_channels=64, output_shape=[48, 64]),
+    backbone=dict(in_channels=64, out_channels=[32, 64, 96], layer_nums=[1, 2, 1], layer_strides=[1, 2, 2]),
+    neck=dict(in_channels=[32, 64, 96], out_channels=[32, 32, 32], upsample_strides=[1, 2, 4],
+              use_conv_for_no_stride=False),
+    head=dict(in_channels=96, feat_channels=96, nms_pre=100, score_thr=0.1,
+              ranges=[[0, -9.6, -0.6, 25.6, 9.6, -0.6], [0, -9.6, -1.78, 25.6, 9.6, -1.78]],
+              sizes=[[0.6, 0.8, 1.73], [1.6, 3.9, 1.56]], rotations=[0, 1.57], iou_thr=[[0.35, 0.5], [0.45, 0.6]]))
+
+
+def make_state_dict(cfg, seed):
+    """Pseudo-trained weights with the reference's state_dict keys and shapes."""
+    g = torch.Generator().manual_seed(int(seed))
+    sd = {}
+
+    def rnd(*shape, scale=1.0):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = 1 + rnd(c, scale=0.3)
+        sd[prefix + ".bias"] = rnd(c, scale=0.3)
+        sd[prefix + ".running_mean"] = rnd(c, scale=0.2)
+        sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(100)
+
+    ve = cfg["voxel_encoder"]
+    chans = [ve["in_channels"] + 5] + list(ve["feat_channels"])
+    for i in range(len(chans) - 1):
+        last = i == len(chans) - 2
+        units = chans[i + 1] if last else chans[i + 1] // 2
+        sd["voxel_encoder.pfn_layers.%d.linear.weight" % i] = rnd(units, chans[i], scale=(3.0 / chans[i]) ** 0.5)
+        bn("voxel_encoder.pfn_layers.%d.norm" % i, units)
+    bb = cfg["backbone"]
+    cin = [bb["in_channels"]] + list(bb["out_channels"][:-1])
+    for i, ln in enumerate(bb["layer_nums"]):
+        co = bb["out_channels"][i]
+        sd["backbone.blocks.%d.0.weight" % i] = rnd(co, cin[i], 3, 3, scale=(3.0 / (9 * cin[i])) ** 0.5 * 1.4)
+        bn("backbone.blocks.%d.1" % i, co)
+        for j in range(ln):
+            sd["backbone.blocks.%d.%d.weight" % (i, 3 + 3 * j)] = rnd(co, co, 3, 3, scale=(3.0 / (9 * co)) ** 0.5 * 1.4)
+            bn("backbone.blocks.%d.%d" % (i, 4 + 3 * j), co)
+    nk = cfg["neck"]
+    for i, co in enumerate(nk["out_channels"]):
+        s = nk["upsample_strides"][i]
+        ci = nk["in_channels"][i]
+        sd["neck.deblocks.%d.0.weight" % i] = rnd(ci, co, s, s, scale=(3.0 / ci) ** 0.5)     # ConvTranspose2d [Cin,Cout,k,k]
+        bn("neck.deblocks.%d.1" % i, co)
+    hd = cfg["head"]
+    na = len(hd["sizes"]) * len(hd["rotations"])
+    nc = len(cfg["classes"])
+    fc = hd["feat_channels"]
+    for name, co in (("conv_cls", na * nc), ("conv_reg", na * 7), ("conv_dir_cls", na * 2)):
+        sd["bbox_head.%s.weight" % name] = rnd(co, fc, 1, 1, scale=(3.0 / fc) ** 0.5)
+        sd["bbox_head.%s.bias" % name] = rnd(co, scale=0.5)
+    return sd
+
+
+def voxelization(points_feats, cfg, training=False):
+    """PointPillarsVoxelization.forward (point_pillars.py:328-382) for one sample [N, 3+C]."""
+    vz = cfg["voxelize"]
+    pcr = cfg["point_cloud_range"]
+    voxel_size = torch.Tensor(vz["voxel_size"])
+    rmin, rmax = torch.Tensor(pcr[:3]), torch.Tensor(pcr[3:])
+    mv = vz["max_voxels"]
+    max_voxels = (mv[0] if training else mv[1]) if isinstance(mv, (list, tuple)) else mv
+    num_voxels = ((rmax - rmin) / voxel_size).type(torch.int32)
+    pts = points_feats[:, :3].contiguous().numpy()
+    ans = oops.voxelize(pts, np.array([0, pts.shape[0]], np.int64), voxel_size.numpy(), rmin.numpy(), rmax.numpy(),
+                        vz["max_num_points"], max_voxels)
+    feats = torch.cat([torch.zeros_like(points_feats[0:1, :]), points_feats])
+    dense = oops.ragged_to_dense(ans.voxel_point_indices, ans.voxel_point_row_splits, vz["max_num_points"],
+                                 np.int64(-1)) + 1
+    out_voxels = feats[torch.from_numpy(dense)]
+    out_coords = torch.from_numpy(ans.voxel_coords[:, [2, 1, 0]].copy())
+    prs = torch.from_numpy(ans.voxel_point_row_splits)
+    out_num = prs[1:] - prs[:-1]
+    inb = torch.logical_and(out_coords[:, 2] < num_voxels[0], out_coords[:, 1] < num_voxels[1])
+    return out_voxels[inb], out_coords[inb], out_num[inb]
+
+
+def _bn(sd, prefix, x, eps=1e-3):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], False, 0.0, eps)
+
+
+def pillar_feature_net(sd, cfg, features, num_points, coors):
+    """PillarFeatureNet.forward (point_pillars.py:512-555) + PFNLayer.forward (:417-453)."""
+    ve = cfg["voxel_encoder"]
+    pcr = cfg["point_cloud_range"]
+    vx, vy = ve["voxel_size"][0], ve["voxel_size"][1]
+    x_off, y_off = vx / 2 + pcr[0], vy / 2 + pcr[1]
+    mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_points.type_as(features).view(-1, 1, 1)
+    f_cluster = features[:, :, :3] - mean
+    f_center = features[:, :, :2].clone()
+    f_center[:, :, 0] = f_center[:, :, 0] - (coors[:, 3].type_as(features).unsqueeze(1) * vx + x_off)
+    f_center[:, :, 1] = f_center[:, :, 1] - (coors[:, 2].type_as(features).unsqueeze(1) * vy + y_off)
+    f = torch.cat([features, f_cluster, f_center], dim=-1)
+    n = f.shape[1]
+    mask = (num_points.view(-1, 1).int() > torch.arange(n, dtype=torch.int).view(1, -1)).unsqueeze(-1).type_as(f)
+    f = f * mask
+    nl = len(ve["feat_channels"])
+    for i in range(nl):
+        p = "voxel_encoder.pfn_layers.%d" % i
+        x = F.linear(f, sd[p + ".linear.weight"])
+        x = _bn(sd, p + ".norm", x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = F.relu(x)
+        x_max = torch.max(x, dim=1, keepdim=True)[0]
+        if i == nl - 1:
+            f = x_max
+        else:
+            f = torch.cat([x, x_max.repeat(1, n, 1)], dim=2)
+    return f.squeeze(dim=1)
+
+
+def scatter(cfg, voxel_features, coors, batch_size):
+    """PointPillarsScatter.forward (point_pillars.py:577-616)."""
+    ny, nx = cfg["scatter"]["output_shape"]
+    C = cfg["scatter"]["in_channels"]
+    out = []
+    for b in range(batch_size):
+        canvas = torch.zeros(C, nx * ny, dtype=voxel_features.dtype)
+        m = coors[:, 0] == b
+        tc = coors[m, :]
+        idx = (tc[:, 2] * nx + tc[:, 3]).long()
+        canvas[:, idx] = voxel_features[m, :].t()
+        out.append(canvas)
+    return torch.stack(out, 0).view(batch_size, C, ny, nx)
+
+
+def backbone_neck_head(sd, cfg, x):
+    """SECOND.forward, SECONDFPN.forward, Anchor3DHead.forward (point_pillars.py:666-682, 739-755, 827-841)."""
+    bb, nk = cfg["backbone"], cfg["neck"]
+    outs = []
+    for i, ln in enumerate(bb["layer_nums"]):
+        x = F.relu(_bn(sd, "backbone.blocks.%d.1" % i,
+                       F.conv2d(x, sd["backbone.blocks.%d.0.weight" % i], stride=bb["layer_strides"][i], padding=1)))
+        for j in range(ln):
+            x = F.relu(_bn(sd, "backbone.blocks.%d.%d" % (i, 4 + 3 * j),
+                           F.conv2d(x, sd["backbone.blocks.%d.%d.weight" % (i, 3 + 3 * j)], padding=1)))
+        outs.append(x)
+    ups = []
+    for i in range(len(nk["out_channels"])):
+        s = nk["upsample_strides"][i]
+        y = F.conv_transpose2d(outs[i], sd["neck.deblocks.%d.0.weight" % i], stride=s)
+        ups.append(F.relu(_bn(sd, "neck.deblocks.%d.1" % i, y)))
+    feat = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+    return tuple(F.conv2d(feat, sd["bbox_head.%s.weight" % n], sd["bbox_head.%s.bias" % n])
+                 for n in ("conv_cls", "conv_reg", "conv_dir_cls"))
+
+
+@torch.no_grad()
+def forward(sd, cfg, points_list):
+    """PointPillars.forward (point_pillars.py:102-138) for a list of [N_i, 3+C] clouds -> (cls, reg, dir)."""
+    voxels, coors, nums = [], [], []
+    for i, pts in enumerate(points_list):
+        v, c, n = voxelization(pts, cfg)
+        voxels.append(v)
+        coors.append(F.pad(c, (1, 0), mode="constant", value=i))
+        nums.append(n)
+    voxels, coors, nums = torch.cat(voxels), torch.cat(coors), torch.cat(nums)
+    vf = pillar_feature_net(sd, cfg, voxels, nums, coors)
+    x = scatter(cfg, vf, coors, len(points_list))
+    return backbone_neck_head(sd, cfg, x), dict(voxels=voxels, coors=coors, num_points=nums, pillar_features=vf)
+
+
+def crop_for_cfg(sweep, cfg):
+    """Keep the points of a synthetic sweep that fall inside the config's range (what ObjectRangeFilter /
+    the dataset crop hands to the model); float32 [N, 3 + C]."""
+    r = cfg["point_cloud_range"]
+    c = cfg["voxel_encoder"]["in_channels"]
+    m = np.all((sweep[:, :3] >= np.array(r[:3], np.float32)) & (sweep[:, :3] <= np.array(r[3:], np.float32)), 1)
+    return np.ascontiguousarray(sweep[m][:, :c], np.float32)

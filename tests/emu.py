@@ -240,3 +240,66 @@ def gather_pool(x, inds, mode):
                             out.ctypes.data, None)
     assert rc == 0, rc
     return out
+
+
+def pillar_features(points, vox, in_ch, P, vx, vy, x_off, y_off, nx, ny, layers, batch):
+    """vox = (coords, pidx, prs, bs) from voxelize(); layers = [(wt [cin, units], bias [units]), ...]."""
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    coords, pidx, prs, bs = vox
+    units = (C.c_int32 * len(layers))(*[int(w.shape[1]) for w, _ in layers])
+    ws_ = [np.ascontiguousarray(w, np.float32) for w, _ in layers]
+    bs_ = [np.ascontiguousarray(b, np.float32) for _, b in layers]
+    cc = ws_[-1].shape[1]
+    canvas = np.full((batch, ny, nx, cc), 7.0, np.float32)
+    M = len(coords)
+    wsb = L.ml3d_pillar_features_workspace_bytes(M, P, len(layers), units)
+    ws = _ws(wsb)
+    rc = L.ml3d_pillar_features(points.ctypes.data, points.shape[1], in_ch, coords.ctypes.data, pidx.ctypes.data,
+                                prs.ctypes.data, bs.ctypes.data, batch, M, P, vx, vy, x_off, y_off, nx, ny, len(layers),
+                                units, _abi.ptr_table([w.ctypes.data for w in ws_]),
+                                _abi.ptr_table([b.ctypes.data for b in bs_]), canvas.ctypes.data, cc, ws.ctypes.data, wsb,
+                                None)
+    return rc, canvas
+
+
+def conv2d_nhwc(x, w, bias, stride, pad, act=2, kh=3, kw=3):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    B, H, W, Cin = x.shape
+    w = np.ascontiguousarray(w, np.float32)
+    cout = w.shape[1]
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = np.zeros((B, OH, OW, cout), np.float32)
+    b = np.ascontiguousarray(bias, np.float32)
+    wsb = L.ml3d_conv2d_workspace_bytes(B, OH, OW, Cin, cout, kh, kw)
+    ws = _ws(wsb)
+    rc = L.ml3d_conv2d_nhwc(x.ctypes.data, B, H, W, Cin, w.ctypes.data, b.ctypes.data, kh, kw, stride, pad, act, 0.0, cout,
+                            out.ctypes.data, cout, ws.ctypes.data, wsb, None)
+    return rc, out
+
+
+def deconv2d_nhwc(x, w, bias, stride, cout, out=None, ch_off=0, act=2):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    B, H, W, Cin = x.shape
+    w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(bias, np.float32)
+    if out is None:
+        out = np.zeros((B, H * stride, W * stride, cout), np.float32)
+    ld = out.shape[3]
+    wsb = L.ml3d_conv2d_workspace_bytes(B, H, W, Cin, stride * stride * cout, 1, 1)
+    ws = _ws(wsb)
+    rc = L.ml3d_deconv2d_nhwc(x.ctypes.data, B, H, W, Cin, w.ctypes.data, b.ctypes.data, stride, act, 0.0, cout,
+                              out.ctypes.data + 4 * ch_off, ld, ws.ctypes.data, wsb, None)
+    return rc, out
+
+
+def nhwc_to_nchw(x, c0, c):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    B, H, W, ld = x.shape
+    out = np.zeros((B, c, H, W), np.float32)
+    rc = L.ml3d_nhwc_to_nchw(x.ctypes.data, ld, c0, c, B, H * W, out.ctypes.data, None)
+    assert rc == 0, rc
+    return out
