@@ -37,6 +37,11 @@ struct RowsA {
     const float* a; int64_t lda; int k1;
     const int32_t* gather; int64_t gather_stride; int64_t a_rows;   // optional: row = gather[m * stride]; >= a_rows -> zeros
     const float* a2; int64_t lda2; int k2;                           // optional second block of columns
+    // gather variants: gather_on_a2 != 0 applies the row gather to the SECOND block instead of the first;
+    // g_rows_per_item > 0 makes the gathered index item-local: source row =
+    // (m / g_rows_per_item) * g_src_rows_per_item + gather[m * stride]   (RandLA nearest_interpolation)
+    int gather_on_a2;
+    int64_t g_rows_per_item, g_src_rows_per_item;
 };
 
 // implicit im2col of an NHWC image: m = (b, oy, ox), k = (ky, kx, ci), ci fastest

@@ -33,9 +33,18 @@ struct RowsLoader {
         if (m < M) {
             int64_t r = m;
             bool ok = true;
-            if (A.gather) { r = A.gather[m * A.gather_stride]; ok = r >= 0 && r < A.a_rows; }
-            if (ok) c.p1 = A.a + r * A.lda;
-            if (A.a2) c.p2 = A.a2 + m * A.lda2;
+            if (A.gather) {
+                r = A.gather[m * A.gather_stride];
+                ok = r >= 0 && r < A.a_rows;
+                if (A.g_rows_per_item > 0) r += (m / A.g_rows_per_item) * A.g_src_rows_per_item;
+            }
+            if (!A.gather_on_a2) {
+                if (ok) c.p1 = A.a + r * A.lda;
+                if (A.a2) c.p2 = A.a2 + m * A.lda2;
+            } else {
+                c.p1 = A.a + m * A.lda;
+                if (A.a2 && ok) c.p2 = A.a2 + r * A.lda2;
+            }
         }
         return c;
     }

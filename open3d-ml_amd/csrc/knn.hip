@@ -65,10 +65,9 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
 }
 
 template <int K>
-__global__ void __launch_bounds__(256)
-knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int32_t* __restrict__ out_idx,
-          float* __restrict__ out_d2) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
+                                        const Segs& support_segs, int32_t* __restrict__ out_idx,
+                                        float* __restrict__ out_d2, int64_t t) {
     if (t >= Q.n_total) return;
     int s; int64_t local;
     float qx, qy, qz;
@@ -145,6 +144,56 @@ knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int
             if (out_d2) out_d2[out_row * k + j] = ok ? __uint_as_float((unsigned)(key >> 32)) : __uint_as_float(0x7f800000u);
         }
     }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int32_t* __restrict__ out_idx,
+          float* __restrict__ out_d2) {
+    knn_one<K>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Several independent searches in ONE launch (the levels of the RandLA pyramid): the small levels are
+// latency-bound (one thread per query, a few thousand queries), so running them back to back leaves
+// the chip idle; side by side they hide under the largest level.  Jobs are ordered largest first.
+constexpr int KNN_MAX_JOBS = 8;
+struct KnnJob {
+    GridView G;
+    QuerySrc Q;
+    Segs support;
+    int32_t* out_idx;
+    unsigned block_begin;
+};
+struct KnnJobs {
+    KnnJob j[KNN_MAX_JOBS];
+    int n;
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) knn_query_multi(KnnJobs J, int k, int index_local) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < KNN_MAX_JOBS; ++i)
+        if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
+    const KnnJob& jb = J.j[ji];
+    knn_one<K>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+               (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
+}
+
+static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
+    unsigned blocks = 0;
+    for (int i = 0; i < J.n; ++i) {
+        J.j[i].block_begin = blocks;
+        blocks += (unsigned)((J.j[i].Q.n_total + 255) / 256);
+    }
+    if (blocks == 0) return 0;
+    if (k == 1) hipLaunchKernelGGL(knn_query_multi<1>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 8) hipLaunchKernelGGL(knn_query_multi<8>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 16) hipLaunchKernelGGL(knn_query_multi<16>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 32) hipLaunchKernelGGL(knn_query_multi<32>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 64) hipLaunchKernelGGL(knn_query_multi<64>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else return ML3D_E_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
 static int launch_query(const GridView& G, const QuerySrc& Q, int k, int index_local, Segs support_segs,
@@ -272,6 +321,11 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
             return ML3D_E_LAUNCH;
         te(100 + l);
     }
+    // all k-NN searches (level l onto itself, randlanet.py:220) in one launch, all 1-NN interpolation
+    // searches (level l in level l+1, randlanet.py:224) in a second one
+    KnnJobs Jk, J1;
+    Jk.n = 0; J1.n = 0;
+    const bool merged = num_layers <= KNN_MAX_JOBS && !getenv("ML3D_KNN_SEPARATE");
     for (int l = 0; l < num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
@@ -281,21 +335,39 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
         Q.raw = points;
         Q.segs = S;
         Q.n_total = n[l] * batch;
-        // k-NN of level l onto itself (randlanet.py:220)
-        tb(2 * l);
-        int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
-        te(2 * l);
-        if (rc) return rc;
-        // 1-NN of level l in level l+1 (randlanet.py:224)
+        if (merged) {
+            KnnJob& a = Jk.j[Jk.n++];
+            a.G = grid_view(ws[l]); a.Q = Q; a.support = S; a.out_idx = neighbor_idx_host[l]; a.block_begin = 0;
+        } else {
+            tb(2 * l);
+            int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
+            te(2 * l);
+            if (rc) return rc;
+        }
         if (n[l + 1] > 0) {
             Segs S1 = {nullptr, n0, n[l + 1], (int)batch};
-            tb(2 * l + 1);
-            rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
-            te(2 * l + 1);
-            if (rc) return rc;
+            if (merged) {
+                KnnJob& a = J1.j[J1.n++];
+                a.G = grid_view(ws[l + 1]); a.Q = Q; a.support = S1; a.out_idx = interp_idx_host[l]; a.block_begin = 0;
+            } else {
+                tb(2 * l + 1);
+                int rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
+                te(2 * l + 1);
+                if (rc) return rc;
+            }
         } else {
             (void)hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
         }
+    }
+    if (merged) {
+        tb(0);
+        int rc = launch_query_multi(Jk, k, 1, st);
+        te(0);
+        if (rc) return rc;
+        tb(1);
+        rc = launch_query_multi(J1, 1, 1, st);
+        te(1);
+        if (rc) return rc;
     }
     return 0;
 }

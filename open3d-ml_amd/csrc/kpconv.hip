@@ -258,6 +258,7 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
     A.a = wf; A.lda = (int64_t)KP_K * cin; A.k1 = KP_K * cin;
     A.gather = nullptr; A.gather_stride = 0; A.a_rows = n_queries;
     A.a2 = nullptr; A.lda2 = 0; A.k2 = 0;
+    A.gather_on_a2 = 0; A.g_rows_per_item = 0; A.g_src_rows_per_item = 0;
     Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
     return gemm_rows(A, weights, n_queries, cout, KP_K * cin, ep, out, cout, p,
                      gemm_partial_bytes(n_queries, cout, KP_K * cin), st);
@@ -281,6 +282,7 @@ extern "C" int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a
     A.a = a; A.lda = lda; A.k1 = k1;
     A.gather = a_gather; A.gather_stride = a_gather_stride; A.a_rows = a_rows;
     A.a2 = a2; A.lda2 = lda2; A.k2 = k2;
+    A.gather_on_a2 = 0; A.g_rows_per_item = 0; A.g_src_rows_per_item = 0;
     Epilogue ep = {bias, residual, ldr, act, slope, 0, 0, 0, 0};
     char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
     size_t avail = workspace ? (workspace_bytes > 256 ? workspace_bytes - 256 : 0) : 0;

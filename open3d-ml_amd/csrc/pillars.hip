@@ -283,6 +283,7 @@ extern "C" int ml3d_deconv2d_nhwc(const float* in, int64_t batch, int h, int w, 
     A.a = in; A.lda = cin; A.k1 = cin;
     A.gather = nullptr; A.gather_stride = 0; A.a_rows = batch * h * w;
     A.a2 = nullptr; A.lda2 = 0; A.k2 = 0;
+    A.gather_on_a2 = 0; A.g_rows_per_item = 0; A.g_src_rows_per_item = 0;
     Epilogue ep = {bias, nullptr, 0, act, slope, stride, h, w, cout};
     char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
     size_t avail = workspace && workspace_bytes > 256 ? workspace_bytes - 256 : 0;

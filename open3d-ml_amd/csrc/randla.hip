@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "gemm.h"
 #include "ml3d_hip.h"
 
 namespace ml3d {
@@ -120,7 +121,28 @@ struct LfaArgs {
     const float* feat_in;      // [m, d_in]     (stage 2: LFA input, for the shortcut)
     int d_in;
     float* out;                // stage 1: p1 [m, h]; stage 2: enc [m, 2d]
+    int64_t xcd_chunk;         // > 0: XCD-aware tile walk, tiles per chunk (see xcd_tile)
 };
+
+// XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, observed), and each XCD has its
+// own 4 MiB L2.  The neighbour gathers of a tile touch random rows of the tile's own cloud (RandLA points are
+// shuffled), so the tiles are cut into chunks of ~one cloud (or a fraction of one) and chunk c is walked only
+// by the workgroups of XCD c % 8: an XCD's L2 then holds one cloud's feature rows instead of all of them.
+// i = index among this XCD's tiles; returns the tile, -1 when the XCD is done, or >= tiles for a hole.
+__device__ __forceinline__ int64_t xcd_tile(int64_t i, int xcd, int64_t chunk, int64_t tiles) {
+    const int64_t ci = i / chunk;
+    const int64_t c = ci * 8 + xcd;
+    if (c * chunk >= tiles) return -1;
+    return c * chunk + (i - ci * chunk);
+}
+
+static int64_t xcd_chunk_tiles(int64_t tiles, int64_t batch) {
+    if (batch <= 0 || tiles < 64) return 0;
+    int64_t nch = batch;
+    while (nch < 32) nch *= 2;                  // >= 4 chunks per XCD keeps the XCDs balanced
+    int64_t chunk = (tiles + nch - 1) / nch;
+    return chunk > 0 ? chunk : 0;
+}
 
 template <int D>
 struct LfaCfg {
@@ -326,14 +348,16 @@ __global__ void __launch_bounds__(LFA_THREADS) lfa_stage(LfaArgs A) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int D>
+template <int D, int TPS = 0>
 struct MfmaCfg {
     static constexpr int H = D / 2;
     static constexpr int NT = D / 32;                        // score column tiles
     static constexpr int NT2 = (H + 31) / 32;                // lse2 column tiles
     static constexpr int WAVES = NT > 4 ? NT : 4;
     static constexpr int THREADS = WAVES * 64;
-    static constexpr int TP = D <= 64 ? 8 : (D == 128 ? 4 : 2);   // points per tile
+    // points per tile; TPS = 1: half-size tiles -> half the LDS per workgroup -> twice the resident workgroups,
+    // whose gather / VALU / MFMA phases then overlap on a CU
+    static constexpr int TP = TPS ? (D <= 64 ? 4 : 2) : (D <= 64 ? 8 : (D == 128 ? 4 : 2));
     static constexpr int ROWS = TP * RK;
     static constexpr int RT = ROWS / 32;                     // 32-row MFMA tiles
     static constexpr int RG = WAVES / NT;                    // waves sharing a column tile take different row tiles
@@ -359,9 +383,9 @@ __device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/
     return acc;
 }
 
-template <int D, int STAGE>
-__global__ void __launch_bounds__(MfmaCfg<D>::THREADS) lfa_attn_mfma(LfaArgs A) {
-    using C = MfmaCfg<D>;
+template <int D, int STAGE, int TPS>
+__global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaArgs A) {
+    using C = MfmaCfg<D, TPS>;
     constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
     HIP_DYNAMIC_SHARED(float, smem)
     float* X = smem;                                              // [ROWS][XP]
@@ -394,7 +418,15 @@ __global__ void __launch_bounds__(MfmaCfg<D>::THREADS) lfa_attn_mfma(LfaArgs A) 
     const float b1 = A.lse1_b[cc];
 
     const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const bool xw = A.xcd_chunk > 0;
+    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+    for (int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;; wi += w_step) {
+        int64_t tile = wi;
+        if (xw) {
+            tile = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
+            if (tile < 0) break;
+            if (tile >= tiles) continue;
+        } else if (tile >= tiles) break;
         const int64_t m_base = tile * C::TP;
         // ---- P1: relative-position inputs + neighbour rows -------------------------------------
         for (int e = tid; e < ROWS; e += THREADS) {
@@ -466,7 +498,7 @@ __global__ void __launch_bounds__(MfmaCfg<D>::THREADS) lfa_attn_mfma(LfaArgs A) 
                 float sum = 0.f, ag = 0.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    float e = expf(acc[8 * pt + r] - mx);
+                    float e = __expf(acc[8 * pt + r] - mx);
                     sum += e;
                     ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
                 }
@@ -481,27 +513,36 @@ __global__ void __launch_bounds__(MfmaCfg<D>::THREADS) lfa_attn_mfma(LfaArgs A) 
     }
 }
 
-template <int D, int STAGE>
+template <int D, int STAGE, int TPS>
 static size_t mfma_smem_bytes() {
-    using C = MfmaCfg<D>;
+    using C = MfmaCfg<D, TPS>;
     return ((size_t)C::ROWS * C::XP + (STAGE == 2 ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
            (size_t)C::ROWS * 4;
 }
 
 // launches the attention part of one stage; `a.out` receives agg [m, D]
-template <int D, int STAGE>
-static int launch_attn_mfma(const LfaArgs& a, hipStream_t st) {
-    using C = MfmaCfg<D>;
+template <int D, int STAGE, int TPS>
+static int launch_attn_mfma_t(LfaArgs a, hipStream_t st, int grid_cap) {
+    using C = MfmaCfg<D, TPS>;
     int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
-    unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);     // persistent-ish: weights load once per block
-    size_t sm = mfma_smem_bytes<D, STAGE>();
+    unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
+    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+    size_t sm = mfma_smem_bytes<D, STAGE, TPS>();
     if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE, TPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
         return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
+    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE, TPS>), dim3(grid), dim3(C::THREADS), sm, st, a);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+template <int D, int STAGE>
+static int launch_attn_mfma(const LfaArgs& a, hipStream_t st) {
+    static const int tps = getenv("ML3D_ATTN_TPS") ? atoi(getenv("ML3D_ATTN_TPS")) : 0;      // tuning knobs
+    static const int cap = getenv("ML3D_ATTN_GRID") ? atoi(getenv("ML3D_ATTN_GRID")) : 2560;
+    return tps ? launch_attn_mfma_t<D, STAGE, 1>(a, st, cap) : launch_attn_mfma_t<D, STAGE, 0>(a, st, cap);
+}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -529,7 +570,15 @@ __global__ void __launch_bounds__(256) lfa_attn_mfma16(LfaArgs A) {
     for (int s = 0; s < 4; ++s) bs[s] = A.score_wt[(4 * g + s) * D + col];
     const float sbias = A.score_b[col];
     const int64_t tiles = (A.m_total + A16_TP - 1) / A16_TP;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const bool xw = A.xcd_chunk > 0;
+    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+    for (int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;; wi += w_step) {
+        int64_t tile = wi;
+        if (xw) {
+            tile = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
+            if (tile < 0) break;
+            if (tile >= tiles) continue;
+        } else if (tile >= tiles) break;
         const int64_t m_base = tile * A16_TP;
         {   // ---- build: thread = (point p, neighbour k) -------------------------------------------
             const int p = tid >> 4, k = tid & 15;
@@ -593,7 +642,7 @@ __global__ void __launch_bounds__(256) lfa_attn_mfma16(LfaArgs A) {
             float sum = 0.f, ag = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float e = expf(acc[r] - mx);
+                float e = __expf(acc[r] - mx);
                 sum += e;
                 ag = fmaf(e, Xp[(4 * g + r) * A16_XP + col], ag);
             }
@@ -607,9 +656,13 @@ __global__ void __launch_bounds__(256) lfa_attn_mfma16(LfaArgs A) {
 }
 
 template <int STAGE>
-static int launch_attn_mfma16(const LfaArgs& a, hipStream_t st) {
+static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
     int64_t tiles = (a.m_total + A16_TP - 1) / A16_TP;
-    unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
+    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+    static const int cap = getenv("ML3D_ATTN16_GRID") ? atoi(getenv("ML3D_ATTN16_GRID")) : 4096;
+    unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     hipLaunchKernelGGL((lfa_attn_mfma16<STAGE>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
@@ -837,7 +890,18 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 }
 
 static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
-    const char* e = getenv("ML3D_RANDLA_LINEAR");                  // A/B knob: "valu" forces the scalar kernel
+    // default: the register-prefetching tile GEMM of gemm.hip; A/B knobs: "chain" = single-layer launch of
+    // mlp_chain_mfma (no prefetch), "valu" = the scalar kernel
+    const char* e = getenv("ML3D_RANDLA_LINEAR");
+    if (!(e && (e[0] == 'c' || e[0] == 'v')) && a.c0 + a.c1 >= 8 && !a.bias2) {
+        RowsA A;
+        A.a = a.a0; A.lda = a.c0; A.k1 = a.c0;
+        A.gather = a.a1 ? a.gather : nullptr; A.gather_stride = 1; A.a_rows = a.a1_rows_per_item;
+        A.a2 = a.a1; A.lda2 = a.c1; A.k2 = a.a1 ? a.c1 : 0;
+        A.gather_on_a2 = 1; A.g_rows_per_item = a.rows_per_item; A.g_src_rows_per_item = a.a1_rows_per_item;
+        Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0};
+        return gemm_rows(A, a.wt, a.m_total, a.cout, a.c0 + A.k2, ep, a.out, a.cout, nullptr, 0, st);
+    }
     if (!(e && e[0] == 'v') && a.c0 + a.c1 >= 8) {
         ChainArgs c = {};
         c.a0 = a.a0; c.c0 = a.c0; c.a1 = a.a1; c.c1 = a.a1 ? a.c1 : 0; c.gather = a.gather;
@@ -970,6 +1034,9 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
     const Tracer T = {trace, st};
     const char* path_env = getenv("ML3D_RANDLA_PATH");          // A/B knob: "valu" forces the v1 kernels
     const bool force_valu = path_env && path_env[0] == 'v';
+    const bool no_fuse = path_env && path_env[0] == 'u';       // "unfused": one launch per Linear
+    const char* fr_env = getenv("ML3D_RANDLA_FUSE_ROWS");      // tuning/test knob: rows from which pool2+mlp2 fuse
+    const int64_t fuse_rows = fr_env ? atoll(fr_env) : 64 * 1024;
     const int Lr = d->num_layers;
     const int64_t B = d->batch;
     int64_t n[ML3D_RANDLA_MAX_LAYERS + 1];
@@ -1049,18 +1116,33 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             }
             T.end(8 * l + 2);
             if (rc) return rc;
-            {   // pool2.mlp: SharedMLP(d, d) lrelu 0.2
-                LinArgs a = {};
-                a.a0 = agg; a.c0 = dd; a.wt = P(sb + 12); a.bias = P(sb + 13); a.out = p2;
-                a.m_total = M; a.cout = dd; a.act = 1; a.slope = 0.2f;
-                T.begin(8 * l + 5); rc = launch_linear_auto(a, st); T.end(8 * l + 5); if (rc) return rc;
-            }
-            {   // lrelu_0.01(mlp2(p2) + shortcut(feat)) as ONE linear over [p2 | feat]   (randlanet.py:692)
-                LinArgs a = {};
-                a.a0 = p2; a.c0 = dd; a.a1 = feat; a.c1 = d_in; a.wt = P(sb + 14);
-                a.bias = P(sb + 16); a.bias2 = P(sb + 17); a.out = enc;
-                a.m_total = M; a.cout = 2 * dd; a.act = 1; a.slope = 0.01f;
-                T.begin(8 * l + 6); rc = launch_linear_auto(a, st); T.end(8 * l + 6); if (rc) return rc;
+            // pool2.mlp: SharedMLP(d, d) lrelu 0.2, then lrelu_0.01(mlp2(p2) + shortcut(feat)) as ONE linear over
+            // [p2 | feat] (randlanet.py:639, 692).  With enough rows to fill the chip the two run back to back in
+            // one launch (p2 stays in LDS); small levels keep two launches so the column passes spread over CUs.
+            ChainArgs ch = {};
+            ch.a0 = agg; ch.c0 = dd; ch.n_layers = 2;
+            ch.L[0].wt = P(sb + 12); ch.L[0].bias = P(sb + 13); ch.L[0].cin = dd; ch.L[0].cout = dd;
+            ch.L[0].act = 1; ch.L[0].slope = 0.2f;
+            ch.cat = feat; ch.cat_c = d_in; ch.cat_layer = 1;
+            ch.L[1].wt = P(sb + 14); ch.L[1].bias = P(sb + 16); ch.L[1].bias2 = P(sb + 17);
+            ch.L[1].cin = dd + d_in; ch.L[1].cout = 2 * dd; ch.L[1].act = 1; ch.L[1].slope = 0.01f;
+            ch.out = enc; ch.m_total = M;
+            if (!no_fuse && M >= fuse_rows && chain_supported(ch)) {
+                T.begin(8 * l + 5); rc = launch_chain(ch, st); T.end(8 * l + 5); if (rc) return rc;
+            } else {
+                {
+                    LinArgs a = {};
+                    a.a0 = agg; a.c0 = dd; a.wt = P(sb + 12); a.bias = P(sb + 13); a.out = p2;
+                    a.m_total = M; a.cout = dd; a.act = 1; a.slope = 0.2f;
+                    T.begin(8 * l + 5); rc = launch_linear_auto(a, st); T.end(8 * l + 5); if (rc) return rc;
+                }
+                {
+                    LinArgs a = {};
+                    a.a0 = p2; a.c0 = dd; a.a1 = feat; a.c1 = d_in; a.wt = P(sb + 14);
+                    a.bias = P(sb + 16); a.bias2 = P(sb + 17); a.out = enc;
+                    a.m_total = M; a.cout = 2 * dd; a.act = 1; a.slope = 0.01f;
+                    T.begin(8 * l + 6); rc = launch_linear_auto(a, st); T.end(8 * l + 6); if (rc) return rc;
+                }
             }
         } else {
             switch (dd) {
@@ -1123,12 +1205,23 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         LinArgs a = {};
         a.a0 = cur; a.c0 = cprev; a.wt = P(slot); a.bias = P(slot + 1); a.out = t0;
         a.m_total = B * n[0]; a.cout = 64; a.act = 1; a.slope = 0.2f;
-        T.begin(1200); int rc = launch_linear_auto(a, st); T.end(1200); if (rc) return rc;
-        a.a0 = t0; a.c0 = 64; a.wt = P(slot + 2); a.bias = P(slot + 3); a.out = t1; a.cout = 32;
-        T.begin(1201); rc = launch_linear_auto(a, st); T.end(1201); if (rc) return rc;
-        a.a0 = t1; a.c0 = 32; a.wt = P(slot + 4); a.bias = P(slot + 5); a.out = out_scores;
-        a.cout = d->num_classes; a.act = 0;
-        T.begin(1202); rc = launch_linear_auto(a, st); T.end(1202); if (rc) return rc;
+        ChainArgs ch = {};
+        ch.a0 = cur; ch.c0 = cprev; ch.n_layers = 3;
+        ch.L[0].wt = P(slot); ch.L[0].bias = P(slot + 1); ch.L[0].cin = cprev; ch.L[0].cout = 64; ch.L[0].act = 1; ch.L[0].slope = 0.2f;
+        ch.L[1].wt = P(slot + 2); ch.L[1].bias = P(slot + 3); ch.L[1].cin = 64; ch.L[1].cout = 32; ch.L[1].act = 1; ch.L[1].slope = 0.2f;
+        ch.L[2].wt = P(slot + 4); ch.L[2].bias = P(slot + 5); ch.L[2].cin = 32; ch.L[2].cout = d->num_classes; ch.L[2].act = 0;
+        ch.out = out_scores; ch.m_total = B * n[0];
+        if (!no_fuse && !force_valu && chain_supported(ch)) {
+            // fc1.0 -> fc1.1 -> fc1.3 back to back: the 64- and 32-wide activations never leave LDS
+            T.begin(1200); int rc = launch_chain(ch, st); T.end(1200); if (rc) return rc;
+        } else {
+            T.begin(1200); int rc = launch_linear_auto(a, st); T.end(1200); if (rc) return rc;
+            a.a0 = t0; a.c0 = 64; a.wt = P(slot + 2); a.bias = P(slot + 3); a.out = t1; a.cout = 32;
+            T.begin(1201); rc = launch_linear_auto(a, st); T.end(1201); if (rc) return rc;
+            a.a0 = t1; a.c0 = 32; a.wt = P(slot + 4); a.bias = P(slot + 5); a.out = out_scores;
+            a.cout = d->num_classes; a.act = 0;
+            T.begin(1202); rc = launch_linear_auto(a, st); T.end(1202); if (rc) return rc;
+        }
     }
     return 0;
 }

@@ -98,6 +98,23 @@ def test_randla_forward_matches_oracle(ci, B, N):
     assert np.abs(out - ref).max() <= 1e-4
 
 
+def test_randla_forward_fused_and_unfused_linear_chains_agree(monkeypatch):
+    """pool2.mlp + (mlp2 | shortcut) as one 2-layer chain launch (large levels) vs one launch per Linear."""
+    cfg = CFGS[0]
+    pts = synth_data.uniform_cloud(4, 2 * 1024).reshape(2, 1024, 3)
+    sd = R.make_state_dict(cfg, 12)
+    inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
+    ref = R.forward(sd, cfg, inp).numpy()
+    nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
+    itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
+    monkeypatch.setenv("ML3D_RANDLA_FUSE_ROWS", "1")
+    rc, fused = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+    assert rc == 0 and np.abs(fused - ref).max() <= 1e-4
+    monkeypatch.setenv("ML3D_RANDLA_PATH", "unfused")
+    rc, unfused = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+    assert rc == 0 and np.abs(unfused - ref).max() <= 1e-4
+
+
 def test_randla_forward_against_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "randlanet_small.npz"))
     cfg = dict(num_neighbors=16, num_layers=3, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
