@@ -278,6 +278,22 @@ int ml3d_nhwc_to_nchw(const float* in, int64_t in_pixel_stride, int channel_offs
 
 
 /* ------------------------------------------------------------------------- */
+/* rotated-BEV NMS — replaces open3d.ml.torch.ops.nms                          */
+/*   ml3d/torch/utils/objdet_helper.py:346 (multiclass_nms, called from        */
+/*   Anchor3DHead.get_bboxes_single, ml3d/torch/models/point_pillars.py:1004). */
+/* boxes [n,5] (x0,y0,x1,y1,r) f32, scores [n] f32.  Greedy by descending      */
+/* score (ties: lower index first), a box is suppressed when its rotated IoU   */
+/* with a kept box is > iou_threshold.  out_keep int64[n] receives the kept    */
+/* indices in descending-score order, out_count int64[1] their number          */
+/* (n <= 65536).                                                               */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_nms_workspace_bytes(int64_t n);
+
+int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_threshold,
+             int64_t* out_keep, int64_t* out_count, void* workspace, size_t workspace_bytes,
+             void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */
 /*   ml3d/torch/models/randlanet.py:218-229 for a batch of equally sized       */
 /*   clouds in ONE call.  Layer l has n_l = n_{l-1} / ratio[l-1] points, the   */

@@ -42,6 +42,8 @@ SYMBOLS = [
     "ml3d_conv2d_nhwc",
     "ml3d_deconv2d_nhwc",
     "ml3d_nhwc_to_nchw",
+    "ml3d_nms_workspace_bytes",
+    "ml3d_nms",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -126,6 +128,10 @@ def bind(lib):
     lib.ml3d_deconv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, f32, i32, vp, i64, vp, sz, vp]
     lib.ml3d_nhwc_to_nchw.restype = C.c_int
     lib.ml3d_nhwc_to_nchw.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp]
+    lib.ml3d_nms_workspace_bytes.restype = sz
+    lib.ml3d_nms_workspace_bytes.argtypes = [i64]
+    lib.ml3d_nms.restype = C.c_int
+    lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

@@ -554,3 +554,25 @@ def nhwc_to_nchw(x, channel_offset, channels):
         rc = lib.ml3d_nhwc_to_nchw(x.data_ptr(), ld, int(channel_offset), int(channels), B, H * W, out.data_ptr(), _stream())
     _abi.check(rc, "ml3d_nhwc_to_nchw")
     return out
+
+
+def nms(boxes, scores, nms_overlap_thresh):
+    """``open3d.ml.torch.ops.nms`` (ml3d/torch/utils/objdet_helper.py:346): rotated-BEV NMS on boxes
+    [N, 5] = (x0, y0, x1, y1, r); returns the kept indices (int64) in descending-score order."""
+    lib = _abi.get()
+    _need_gpu(boxes, scores)
+    boxes = boxes.detach().contiguous().float()
+    scores = scores.detach().contiguous().float()
+    n = boxes.shape[0]
+    dev = boxes.device
+    if boxes.dim() != 2 or boxes.shape[1] != 5 or scores.numel() != n:
+        raise RuntimeError("nms: boxes must be [N, 5] and scores [N]")
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    wsb = lib.ml3d_nms_workspace_bytes(n)
+    ws = _ws(wsb, dev)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_nms(boxes.data_ptr(), scores.data_ptr(), n, float(nms_overlap_thresh), keep.data_ptr(),
+                          count.data_ptr(), ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_nms")
+    return keep[:int(count.item())]

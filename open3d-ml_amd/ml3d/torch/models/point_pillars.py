@@ -150,6 +150,75 @@ class Anchor3DHead(nn.Module):
         self.conv_dir_cls = nn.Conv2d(feat_channels, self.num_anchors * 2, 1)
 
 
+    # ---- box decoding + NMS (point_pillars.py:945-1025; objdet_helper.py:164-244, 286-350) -----------------
+    def grid_anchors(self, featmap_size, device):
+        """[H*W*sizes*rotations, 7] anchors in (y, x, size, rotation) order, like Anchor3DRangeGenerator."""
+        H, W = featmap_size
+        rots = torch.tensor(self.rotations, dtype=torch.float32, device=device)
+        ranges = self.ranges if len(self.ranges) == len(self.sizes) else list(self.ranges) * len(self.sizes)
+        out = []
+        for rng, size in zip(ranges, self.sizes):
+            r = torch.tensor(rng, dtype=torch.float32, device=device)
+            a = torch.zeros((1, H, W, 1, len(self.rotations), 7), dtype=torch.float32, device=device)
+            a[..., 0] = torch.linspace(r[0], r[3], W, device=device).view(1, 1, W, 1, 1)
+            a[..., 1] = torch.linspace(r[1], r[4], H, device=device).view(1, H, 1, 1, 1)
+            a[..., 2] = torch.linspace(r[2], r[5], 1, device=device).view(1, 1, 1, 1, 1)
+            a[..., 3:6] = torch.tensor(size, dtype=torch.float32, device=device)
+            a[..., 6] = rots.view(1, 1, 1, 1, -1)
+            out.append(a)
+        return torch.cat(out, dim=-3).reshape(-1, 7)
+
+    @staticmethod
+    def decode(anchors, deltas):
+        xa, ya, za, wa, la, ha, ra = torch.split(anchors, 1, dim=-1)
+        xt, yt, zt, wt, lt, ht, rt = torch.split(deltas, 1, dim=-1)
+        za = za + ha / 2
+        diagonal = torch.sqrt(la ** 2 + wa ** 2)
+        hg = torch.exp(ht) * ha
+        return torch.cat([xt * diagonal + xa, yt * diagonal + ya, zt * ha + za - hg / 2, torch.exp(wt) * wa,
+                          torch.exp(lt) * la, hg, rt + ra], dim=-1)
+
+    @torch.no_grad()
+    def get_bboxes_single(self, cls_scores, bbox_preds, dir_preds):
+        """One sample's [C, H, W] head maps -> (bboxes [M, 7], scores [M], labels [M]); the rotated-BEV NMS
+        of every class runs in the HIP kernel ``ml3d_nms``."""
+        dev = cls_scores.device
+        nc = self.num_classes
+        anchors = self.grid_anchors(cls_scores.shape[-2:], dev)
+        dir_scores = torch.max(dir_preds.permute(1, 2, 0).reshape(-1, 2), dim=-1)[1]
+        scores = cls_scores.permute(1, 2, 0).reshape(-1, nc).sigmoid()
+        bbox_preds = bbox_preds.permute(1, 2, 0).reshape(-1, self.box_code_size)
+        if scores.shape[0] > self.nms_pre:
+            max_scores, _ = scores.max(dim=1)
+            _, topk = max_scores.topk(self.nms_pre)
+            anchors, bbox_preds, scores, dir_scores = anchors[topk], bbox_preds[topk], scores[topk], dir_scores[topk]
+        bboxes = self.decode(anchors, bbox_preds)
+        idxs = []
+        for i in range(nc):
+            m = scores[:, i] > self.score_thr
+            orig = torch.nonzero(m).reshape(-1)
+            if orig.numel() == 0:
+                idxs.append(orig)
+                continue
+            b = bboxes[orig][:, [0, 1, 3, 4, 6]]
+            hw, hh = b[:, 2] / 2, b[:, 3] / 2
+            bev = torch.stack([b[:, 0] - hw, b[:, 1] - hh, b[:, 0] + hw, b[:, 1] + hh, b[:, 4]], 1)
+            idxs.append(orig[ops.nms(bev, scores[orig, i], 0.01)])
+        labels = torch.cat([torch.full((len(idxs[i]),), i, dtype=torch.long, device=dev) for i in range(nc)])
+        sc = torch.cat([scores[idxs[i], i] for i in range(nc)])
+        idx = torch.cat(idxs)
+        bboxes, dir_scores = bboxes[idx], dir_scores[idx]
+        if bboxes.shape[0] > 0:
+            val = bboxes[..., 6] - self.dir_offset
+            dir_rot = val - torch.floor(val / np.pi + 1) * np.pi
+            bboxes[..., 6] = dir_rot + self.dir_offset + np.pi * dir_scores.to(bboxes.dtype)
+        return bboxes, sc, labels
+
+    def get_bboxes(self, cls_scores, bbox_preds, dir_preds):
+        out = [self.get_bboxes_single(c, b, d) for c, b, d in zip(cls_scores, bbox_preds, dir_preds)]
+        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+
 def _bn_affine(bn):
     s = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
     return s, bn.bias.detach().double().cpu() - bn.running_mean.detach().double().cpu() * s

@@ -141,7 +141,14 @@ def pointpillars_golden(out_path, cfg_name, frame_ids, weights_seed, stride):
     assert torch.equal(aux["voxels"], voxels)
     for a, b in zip(outs, (mc, mr, md)):
         assert (a - b).abs().max() <= 1e-5, (a - b).abs().max()
-    g = dict(frame_ids=np.asarray(frame_ids), weights_seed=weights_seed, stride=stride,
+    # box decoding + NMS: the reference head's own get_bboxes vs the restatement (exact: same torch ops, same nms)
+    rb, rs, rl = model.bbox_head.get_bboxes(*outs)
+    dec = {}
+    for i in range(len(clouds)):
+        b, s_, l = P.get_bboxes_single(cfg, outs[0][i], outs[1][i], outs[2][i])
+        assert torch.equal(l, rl[i]) and torch.equal(s_, rs[i]) and torch.allclose(b, rb[i], atol=1e-6), i
+        dec["boxes%d" % i], dec["scores%d" % i], dec["labels%d" % i] = rb[i].numpy(), rs[i].numpy(), rl[i].numpy()
+    g = dict(frame_ids=np.asarray(frame_ids), weights_seed=weights_seed, stride=stride, **dec,
              n_points=np.asarray([len(c) for c in clouds]), n_pillars=np.int64(len(coors)),
              coors_checksum=np.int64((coors.long() * torch.tensor([1000003, 10007, 101, 1])).sum()),
              num_points_sum=np.int64(num_points.sum()), coors_head=coors[:256].numpy().astype(np.int32))

@@ -208,3 +208,83 @@ def crop_for_cfg(sweep, cfg):
     c = cfg["voxel_encoder"]["in_channels"]
     m = np.all((sweep[:, :3] >= np.array(r[:3], np.float32)) & (sweep[:, :3] <= np.array(r[3:], np.float32)), 1)
     return np.ascontiguousarray(sweep[m][:, :c], np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# box decoding + NMS (Anchor3DHead.get_bboxes, point_pillars.py:945-1025; objdet_helper.py:53-350)
+# ---------------------------------------------------------------------------------------------------
+def grid_anchors(cfg, featmap_size):
+    """Anchor3DRangeGenerator.grid_anchors (objdet_helper.py:164-244): [H*W*sizes*rots, 7], order (y, x, size, rot)."""
+    hd = cfg["head"]
+    H, W = featmap_size
+    rots = torch.tensor(hd["rotations"], dtype=torch.float32)
+    out = []
+    ranges = hd["ranges"] if len(hd["ranges"]) == len(hd["sizes"]) else hd["ranges"] * len(hd["sizes"])
+    for rng, size in zip(ranges, hd["sizes"]):
+        r = torch.tensor(rng, dtype=torch.float32)
+        zc = torch.linspace(r[2], r[5], 1)
+        yc = torch.linspace(r[1], r[4], H)
+        xc = torch.linspace(r[0], r[3], W)
+        a = torch.zeros((1, H, W, 1, len(rots), 7))
+        a[..., 0] = xc.view(1, 1, W, 1, 1)
+        a[..., 1] = yc.view(1, H, 1, 1, 1)
+        a[..., 2] = zc.view(1, 1, 1, 1, 1)
+        a[..., 3:6] = torch.tensor(size, dtype=torch.float32)
+        a[..., 6] = rots.view(1, 1, 1, 1, -1)
+        out.append(a)
+    return torch.cat(out, dim=-3).reshape(-1, 7)
+
+
+def decode(anchors, deltas):
+    """BBoxCoder.decode (objdet_helper.py:286-313)."""
+    xa, ya, za, wa, la, ha, ra = torch.split(anchors, 1, dim=-1)
+    xt, yt, zt, wt, lt, ht, rt = torch.split(deltas, 1, dim=-1)
+    za = za + ha / 2
+    diagonal = torch.sqrt(la ** 2 + wa ** 2)
+    xg, yg, zg = xt * diagonal + xa, yt * diagonal + ya, zt * ha + za
+    lg, wg, hg = torch.exp(lt) * la, torch.exp(wt) * wa, torch.exp(ht) * ha
+    return torch.cat([xg, yg, zg - hg / 2, wg, lg, hg, rt + ra], dim=-1)
+
+
+def bev_xyxyr(boxes):
+    """xywhr_to_xyxyr(box3d_to_bev(boxes)) (objdet_helper.py:69-100)."""
+    b = boxes[:, [0, 1, 3, 4, 6]]
+    out = torch.zeros_like(b)
+    hw, hh = b[:, 2] / 2, b[:, 3] / 2
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4] = b[:, 0] - hw, b[:, 1] - hh, b[:, 0] + hw, b[:, 1] + hh, b[:, 4]
+    return out
+
+
+@torch.no_grad()
+def get_bboxes_single(cfg, cls_scores, bbox_preds, dir_preds, nms_fn=None):
+    """Anchor3DHead.get_bboxes_single (point_pillars.py:965-1025) for one sample's [C, H, W] maps."""
+    hd = cfg["head"]
+    nc = len(cfg["classes"])
+    nms_fn = nms_fn or (lambda b, s, t: torch.from_numpy(oops.nms(b.numpy(), s.numpy(), t)))
+    anchors = grid_anchors(cfg, cls_scores.shape[-2:])
+    dir_scores = torch.max(dir_preds.permute(1, 2, 0).reshape(-1, 2), dim=-1)[1]
+    scores = cls_scores.permute(1, 2, 0).reshape(-1, nc).sigmoid()
+    bbox_preds = bbox_preds.permute(1, 2, 0).reshape(-1, 7)
+    if scores.shape[0] > hd["nms_pre"]:
+        max_scores, _ = scores.max(dim=1)
+        _, topk = max_scores.topk(hd["nms_pre"])
+        anchors, bbox_preds, scores, dir_scores = anchors[topk], bbox_preds[topk], scores[topk], dir_scores[topk]
+    bboxes = decode(anchors, bbox_preds)
+    idxs = []
+    for i in range(nc):
+        m = scores[:, i] > hd["score_thr"]
+        if not m.any():
+            idxs.append(torch.tensor([], dtype=torch.long))
+            continue
+        orig = torch.arange(m.shape[0])[m]
+        idxs.append(orig[nms_fn(bev_xyxyr(bboxes[m]), scores[m, i], 0.01)])
+    labels = torch.cat([torch.full((len(idxs[i]),), i, dtype=torch.long) for i in range(nc)])
+    sc = torch.cat([scores[idxs[i], i] for i in range(nc)])
+    idx = torch.cat(idxs)
+    bboxes, dir_scores = bboxes[idx], dir_scores[idx]
+    if bboxes.shape[0] > 0:
+        off = hd.get("dir_offset", 0)
+        val = bboxes[..., 6] - off
+        dir_rot = val - torch.floor(val / np.pi + 1) * np.pi
+        bboxes[..., 6] = dir_rot + off + np.pi * dir_scores.to(bboxes.dtype)
+    return bboxes, sc, labels

@@ -303,3 +303,18 @@ def nhwc_to_nchw(x, c0, c):
     rc = L.ml3d_nhwc_to_nchw(x.ctypes.data, ld, c0, c, B, H * W, out.ctypes.data, None)
     assert rc == 0, rc
     return out
+
+
+def nms(boxes, scores, thr):
+    L = lib()
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    scores = np.ascontiguousarray(scores, np.float32)
+    n = len(boxes)
+    keep = np.full(max(n, 1), -1, np.int64)
+    cnt = np.zeros(1, np.int64)
+    wsb = L.ml3d_nms_workspace_bytes(n)
+    ws = _ws(wsb)
+    rc = L.ml3d_nms(boxes.ctypes.data, scores.ctypes.data, n, thr, keep.ctypes.data, cnt.ctypes.data, ws.ctypes.data, wsb,
+                    None)
+    assert rc == 0, rc
+    return keep[:int(cnt[0])]

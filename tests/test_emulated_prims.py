@@ -124,3 +124,21 @@ def test_subsample_negative_coordinates_and_single_points():
     op, ln, _, _ = emu.subsample_batch(pts, [4], 0.1)
     ref = oops.subsample(pts, sampleDl=0.1)
     assert np.array_equal(op, ref) and ln.tolist() == [len(ref)]
+
+
+def _boxes(seed, n, spread):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 2), dtype=np.float32) * spread
+    wh = 0.5 + rng.random((n, 2), dtype=np.float32) * 3
+    r = (rng.random(n, dtype=np.float32) * 2 - 1) * np.pi
+    b = np.concatenate([c - wh / 2, c + wh / 2, r[:, None]], 1).astype(np.float32)
+    s = rng.random(n, dtype=np.float32)
+    if n:
+        s[::7] = s[0]                               # score ties: lower index first
+    return b, s
+
+
+@pytest.mark.parametrize("n,spread,thr", [(100, 12.0, 0.01), (300, 20.0, 0.5), (70, 4.0, 0.01), (1, 1.0, 0.1), (0, 1.0, 0.1)])
+def test_rotated_nms_matches_oracle(n, spread, thr):
+    b, s = _boxes(n, n, spread)
+    assert np.array_equal(emu.nms(b, s, thr), oops.nms(b, s, thr))

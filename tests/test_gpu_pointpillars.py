@@ -80,3 +80,17 @@ def test_waymo_stride_pattern_and_three_channel_points():
     outs = _model(cfg, sd)([torch.from_numpy(c).cuda() for c in clouds])
     for a, b in zip(outs, ref):
         assert (a.cpu() - b).abs().max().item() <= TOL
+
+
+def test_get_bboxes_decode_and_hip_nms_match_reference_golden(golden_dir):
+    """Anchor3DHead.get_bboxes on the reference's own head maps (full maps are stored for the small config)."""
+    g = np.load(os.path.join(golden_dir, "pointpillars_small.npz"))
+    cfg = P.SMALL_CFG
+    m = _model(cfg, P.make_state_dict(cfg, int(g["weights_seed"])))
+    dev = torch.device("cuda:0")
+    cls, reg, dr = (torch.from_numpy(g[k]).to(dev) for k in ("cls", "reg", "dir"))
+    boxes, scores, labels = m.bbox_head.get_bboxes(cls, reg, dr)
+    for i in range(cls.shape[0]):
+        assert np.array_equal(labels[i].cpu().numpy(), g["labels%d" % i])
+        assert np.abs(scores[i].cpu().numpy() - g["scores%d" % i]).max() <= 1e-6
+        assert np.abs(boxes[i].cpu().numpy() - g["boxes%d" % i]).max() <= 1e-4

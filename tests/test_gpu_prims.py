@@ -157,3 +157,25 @@ def test_subsample_batch_kpconv_pooling_grid():
     # idempotence (size-independent property): barycentres of a 0.16 grid re-sampled at 0.01 are unchanged
     op2, ol2 = ops.subsample_batch(op, ol.tolist(), sampleDl=0.01)
     assert torch.equal(ol2, ol) and torch.equal(torch.sort(op2.sum(1))[0], torch.sort(op.sum(1))[0])
+
+
+def _boxes(seed, n, spread):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 2), dtype=np.float32) * spread
+    wh = 0.5 + rng.random((n, 2), dtype=np.float32) * 3
+    r = (rng.random(n, dtype=np.float32) * 2 - 1) * np.pi
+    b = np.concatenate([c - wh / 2, c + wh / 2, r[:, None]], 1).astype(np.float32)
+    s = rng.random(n, dtype=np.float32)
+    if n:
+        s[::7] = s[0]
+    return b, s
+
+
+@pytest.mark.parametrize("n,spread,thr", [(100, 12.0, 0.01), (1000, 40.0, 0.01), (4096, 90.0, 0.3), (65, 3.0, 0.5), (0, 1.0, 0.1)])
+def test_rotated_nms_matches_oracle(n, spread, thr):
+    """open3d.ml.torch.ops.nms as multiclass_nms calls it (objdet_helper.py:346); nms_pre is 100..4096 in the configs."""
+    from ml3d import ops
+    b, s = _boxes(n, n, spread)
+    keep = ops.nms(_t(b), _t(s), thr)
+    assert keep.dtype == torch.int64
+    assert np.array_equal(keep.cpu().numpy(), oops.nms(b, s, thr))
