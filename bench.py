@@ -38,17 +38,15 @@ DOMINANT_FWD_TAG = int(os.environ.get("ML3D_BENCH_TRACE_TAG", 8 * 1 + 2))
 
 
 def lfa_flops(cfg, layer, stage, n_points):
-    """Algorithmic flops of one LocalFeatureAggregation stage (2 x MACs of the reference's matmuls,
-    SURVEY.md §8d): stage 1 = lse1 MLP + score Linear + weighted sum + pool1 MLP; stage 2 = lse2 MLP +
-    score Linear + weighted sum + pool2 MLP + mlp2 + shortcut."""
+    """Algorithmic flops of what ONE attention-kernel launch computes (2 x MACs of the reference's matmuls,
+    SURVEY.md §8d), per point with K neighbours: stage 1 = lse1 MLP (10 -> h) + score Linear (d x d) +
+    softmax-weighted sum (d); stage 2 = lse2 MLP (h x h) + score Linear + weighted sum.  The re-computation of
+    lse1 inside the stage-2 kernel is NOT counted (the reference computes it once); the pool / mlp2 / shortcut
+    Linears run in separate GEMM launches and are not part of this kernel."""
     d = cfg["dim_output"][layer]
     h = d // 2
-    d_in = cfg["dim_features"] if layer == 0 else 2 * cfg["dim_output"][layer - 1]
     K = cfg["num_neighbors"]
-    if stage == 1:
-        mac = K * 10 * h + K * d * d + K * d + d * h
-    else:
-        mac = K * h * h + K * d * d + K * d + d * d + d * 2 * d + d_in * 2 * d
+    mac = K * (10 * h if stage == 1 else h * h) + K * d * d + K * d
     return 2.0 * mac * n_points
 
 
@@ -175,11 +173,14 @@ def main():
         n_l = eng.n[layer] * B
         flops = lfa_flops(CFG, layer, stage, n_l)
         achieved = flops / (dom_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, KiB -> bytes; profiles/r01_*_pmc_{fetch,write}.csv), scaled to this run's frames per step
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("lfa_stage_dominant_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj["dominant_bytes_per_launch_per_frame"] * B
             except Exception:
                 traffic = None
         # secondary: the merged 16-NN query launch (all pyramid levels) against the HBM roofline (algorithmic bytes)

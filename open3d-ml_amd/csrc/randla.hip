@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gemm.h"
+#include "grid.h"
 #include "ml3d_hip.h"
 
 namespace ml3d {
@@ -411,11 +412,14 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
         for (int s = 0; s < H / 2; ++s) b2[s] = col2 < H ? A.lse2_wt[(hi * (H / 2) + s) * H + col2] : 0.f;
         l2bias = col2 < H ? A.lse2_b[col2] : 0.f;
     }
-    const int cc = tid % H;                                       // r1 channel of this thread
-    float w1[10];
+    // lse1 (10 -> H) also runs on MFMA: K padded to 12, split 6 + 6 between the wave halves
+    float w1b[6];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) w1[j] = A.lse1_wt[j * H + cc];
-    const float b1 = A.lse1_b[cc];
+    for (int s6 = 0; s6 < 6; ++s6) {
+        const int kk = hi * 6 + s6;
+        w1b[s6] = (kk < 10 && col2 < H) ? A.lse1_wt[kk * H + col2] : 0.f;
+    }
+    const float b1 = col2 < H ? A.lse1_b[col2] : 0.f;
 
     const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
     const bool xw = A.xcd_chunk > 0;
@@ -448,6 +452,7 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
                 for (int j = 0; j < 10; ++j) r[j] = 0.f;
                 NROW[e] = 0;
             }
+            r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
         }
         __syncthreads();
         // ---- P2a: gather neighbour feature rows (16-byte bursts) -> X[:, 0:H] ---------------------
@@ -456,14 +461,29 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
             float4 v = *reinterpret_cast<const float4*>(A.gfeat + (int64_t)NROW[row] * H + 4 * q);
             *reinterpret_cast<float4*>(X + row * XP + 4 * q) = v;
         }
-        // ---- P2b: r1 = lrelu(lse1(rel))  -> X[:, H:] (stage 1) or R1 (stage 2) ---------------------
-        for (int row = tid / H; row < ROWS; row += THREADS / H) {
-            const float* r = REL + row * 12;
-            float v = b1;
+        // ---- P2b: r1 = lrelu(lse1(rel)) on MFMA (K = 12) -> X[:, H:] (stage 1) or R1 (stage 2) -------
+        for (int rt = rg2; rt < C::RT; rt += C::RG2) {
+            f32x16 acc;
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v = fmaf(r[j], w1[j], v);
-            v = lrelu(v, 0.2f);
-            if (STAGE == 1) X[row * XP + H + cc] = v; else R1[row * RP + cc] = v;
+            for (int r = 0; r < 16; ++r) acc[r] = b1;
+            const float* ar = REL + (rt * 32 + col) * 12 + hi * 6;
+            const float2 a01 = *reinterpret_cast<const float2*>(ar);
+            const float2 a23 = *reinterpret_cast<const float2*>(ar + 2);
+            const float2 a45 = *reinterpret_cast<const float2*>(ar + 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, w1b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, w1b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, w1b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, w1b[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, w1b[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, w1b[5], acc, 0, 0, 0);
+            if (col2 < H) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + mfma_row(r, hi);
+                    const float v = lrelu(acc[r], 0.2f);
+                    if (STAGE == 1) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
+                }
+            }
         }
         __syncthreads();
         if constexpr (STAGE == 2) {
@@ -821,6 +841,7 @@ static int launch_chain(ChainArgs a, hipStream_t st) {
     hipLaunchKernelGGL(mlp_chain_mfma, dim3(gx, gy), dim3(256), sm, st, a);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
+
 
 // one Linear described by LinArgs: MFMA chain kernel when the shapes allow, VALU kernel otherwise
 static int launch_linear_auto(const LinArgs& a, hipStream_t st);
