@@ -104,10 +104,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    from ml3d import dist as mdist
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        mdist.init("nccl", dev)
 
     import synth_data
     from ml3d.engine import RandLAInferenceEngine, make_trace
@@ -131,13 +131,12 @@ def main():
     pts = torch.from_numpy(frames).to(dev)
     feats = pts.clone()   # in_channels = 3: features are the xyz themselves (randlanet.py:208-209)
     labels = torch.empty((B, N), dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(labels) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def one_step(knn_trace=None, fwd_trace=None):
         scores = eng.step(pts, feats, knn_trace, fwd_trace)
-        if world > 1:
+        if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
             labels.copy_(torch.argmax(scores, dim=2))
-            dist.gather(labels, gathered, dst=0)
+            mdist.gather_predictions(labels, dst=0)
 
     for _ in range(args.warmup):
         one_step()
