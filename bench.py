@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("ML3D_BENCH_BATCH", 64)))
     ap.add_argument("--distinct-frames", type=int, default=8,
                     help="distinct synthetic frames generated per rank (tiled with seeded rigid transforms)")
+    ap.add_argument("--workload", choices=["randlanet", "kpconv", "pointpillars"], default="randlanet",
+                    help="randlanet = BASELINE.json configs[1] (the headline metric); the other two are configs[2] / [3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
     args = ap.parse_args()
@@ -108,6 +110,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         mdist.init("nccl", dev)
+
+    if args.workload != "randlanet":
+        import bench_models
+        fn = bench_models.run_kpconv if args.workload == "kpconv" else bench_models.run_pointpillars
+        out = fn(args, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
 
     import synth_data
     from ml3d.engine import RandLAInferenceEngine, make_trace

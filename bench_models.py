@@ -1,0 +1,189 @@
+"""bench.py --workload kpconv | pointpillars — the other two model paths of BASELINE.json (configs[2], configs[3]).
+
+Same JSON contract as the RandLA-Net line (bench.py): `value` = units/s with inputs resident in HBM, `roofline` for
+the dominant op timed live with HIP events on the launch stream (torch's current stream: these ops are launched
+from Python through the C ABI on it), `cpu_baseline` = the CPU oracle (port of the reference path) on a bounded
+sample.  Units: KPConv = input spheres (batch build on the GPU + forward), PointPillars = sweeps (voxelize +
+pillar features + backbone + heads).
+"""
+import time
+
+import numpy as np
+import torch
+
+PEAK_F32_TFLOPS = 157.3
+
+
+class _CallTimer:
+    """Wraps one function of ml3d.ops and brackets its `which`-th call of every step with HIP events."""
+
+    def __init__(self, ops, name, which):
+        self.ops, self.name, self.which = ops, name, which
+        self.orig = getattr(ops, name)
+        self.count = 0
+        self.events = []
+        self.shapes = None
+        setattr(ops, name, self)
+
+    def new_step(self):
+        self.count = 0
+
+    def __call__(self, *a, **k):
+        if self.count == self.which:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(*a, **k)
+            e1.record()
+            self.events.append((e0, e1))
+            self.shapes = (a, r)
+        else:
+            r = self.orig(*a, **k)
+        self.count += 1
+        return r
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else None
+
+    def restore(self):
+        setattr(self.ops, self.name, self.orig)
+
+
+def _timed(step, K, W, world, dist, dev):
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def run_pointpillars(args, rank, world, dev, dist):
+    import synth_data
+    from ml3d import ops
+    from ml3d import dist as mdist
+    from ml3d.torch.models.point_pillars import PointPillars
+    from oracle import pointpillars_ref as P
+    cfg = P.KITTI_CFG
+    B = args.frames_per_step if args.frames_per_step != 64 else 4
+    sd = P.make_state_dict(cfg, 2024)
+    m = PointPillars(device=dev, **cfg)
+    m.load_state_dict(sd)
+    clouds_np = [P.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
+    clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]
+    timer = _CallTimer(ops, "conv2d_nhwc", 1)       # 2nd conv of a step: 3x3 64->64 stride 1 on the 248 x 216 map
+    nbox = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+
+    def step():
+        timer.new_step()
+        outs = m(clouds)
+        if world > 1:       # predictions only: per-sweep count of confident anchors stands in for the box list
+            nbox.copy_((outs[0].flatten(1) > 0).sum(1, keepdim=True))
+            mdist.gather_predictions(nbox, dst=0)
+    dt = _timed(step, args.steps, args.warmup, world, dist, dev)
+    timer.restore()
+    if rank != 0:
+        return None
+    (x, w, *_), y = timer.shapes
+    Bm, OH, OW, Co = y.shape
+    flops = 2.0 * Bm * OH * OW * Co * w.shape[0]
+    ms = timer.mean_ms()
+    out = {"metric": "point-cloud frames/sec (PointPillars KITTI inference: voxelize + pillar features + BEV backbone + heads)",
+           "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "PointPillars KITTI detection, %d synthetic KITTI-shaped sweeps per step per GPU "
+                                  "(pointpillars_kitti.yml)" % B, "frames_per_step_per_gpu": B,
+                      "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
+           "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
+                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                        "flops_per_launch": flops}}
+    if not args.no_cpu_baseline and world == 1:
+        pts = [torch.from_numpy(c) for c in clouds_np[:1]]
+        P.forward(sd, cfg, pts)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 15 and n < 8:
+            P.forward(sd, cfg, pts)
+            n += 1
+        out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "frames/s",
+                               "cores": int(torch.get_num_threads()), "kind": "port",
+                               "sample": "%d passes over 1 sweep, oracle voxelize + PyTorch-CPU forward restating the reference" % n}
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def run_kpconv(args, rank, world, dev, dist):
+    import synth_data
+    from ml3d import ops
+    from ml3d import dist as mdist
+    from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+    from oracle import kpconv_ref as K
+    cfg = dict(K.TORONTO3D_CFG)
+    B = args.frames_per_step if args.frames_per_step != 64 else 8
+    sd = K.make_state_dict(cfg, 2024)
+    m = KPFCNN(**cfg, device=dev)
+    m.load_state_dict(sd)
+    spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
+    lens = [len(s) for s in spheres]
+    pts = torch.from_numpy(np.concatenate(spheres)).to(dev)
+    timer = _CallTimer(ops, "kpconv_rigid", 1)      # first resnet block: 32 -> 32 on the full-resolution layer
+    labels = torch.zeros((1, sum(lens)), dtype=torch.int32, device=dev)
+    np.random.seed(0)
+
+    def step():
+        timer.new_step()
+        batch = KPConvBatch(pts, lens, cfg, device=dev)
+        logits = m(batch)
+        if world > 1:
+            labels.copy_(torch.argmax(logits, 1).view(1, -1))
+            mdist.gather_predictions(labels, dst=0)
+    dt = _timed(step, args.steps, args.warmup, world, dist, dev)
+    timer.restore()
+    if rank != 0:
+        return None
+    (q, s, inds, x, kp, w, *_), y = timer.shapes
+    nq, H, cin, cout = q.shape[0], inds.shape[1], x.shape[1], y.shape[1]
+    flops = nq * (2.0 * 15 * H * cin + 2.0 * 15 * cin * cout)
+    ms = timer.mean_ms()
+    out = {"metric": "point-cloud spheres/sec (KPConv rigid Toronto3D inference: GPU batch build + forward)",
+           "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "KPConv (rigid) Toronto3D inference, %d synthetic 10000-point input spheres per step per "
+                                  "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward" % B,
+                      "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "parallelism": "frame-parallel x%d" % world},
+           "roofline": {"bound": "mfma", "kernel": "kp_weighted<32,1> + gemm_tile (KPConv %d->%d, %d queries x %d neighbours)" % (cin, cout, nq, H),
+                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                        "flops_per_launch": flops}}
+    if not args.no_cpu_baseline and world == 1:
+        sp = spheres[0]
+        feats = torch.ones((len(sp), 1))
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 15 and n < 8:
+            seg = K.segmentation_inputs(sp, [len(sp)], cfg)
+            K.forward(sd, cfg, K.to_torch_batch(seg), feats)
+            n += 1
+        out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "frames/s",
+                               "cores": int(torch.get_num_threads()), "kind": "port",
+                               "sample": "%d passes over 1 sphere, oracle radius search / subsample (OpenMP) + PyTorch-CPU "
+                                         "forward restating the reference" % n}
+    else:
+        out["cpu_baseline"] = None
+    return out
