@@ -25,7 +25,7 @@
 namespace ml3d {
 
 typedef unsigned long long u64;
-constexpr u64 KEY_EMPTY = ~0ull;
+constexpr u64 KEY_EMPTY = 0x7ff0000000000000ull;   // +inf as a double: above every real key
 
 // Where queries come from:
 //  sorted_q != nullptr : query t = sorted_q[t] (xyz + local index) of grid `qsegs` (packed order)
@@ -38,29 +38,33 @@ struct QuerySrc {
     int64_t n_total;
 };
 
+// The best-k list is kept as K doubles whose BIT PATTERNS are the packed keys bits(d2) << 32 | index: for
+// finite non-negative d2 the IEEE-754 double order of those patterns equals their unsigned integer order
+// (exponent+mantissa are compared like an integer; a pattern is NaN/inf only when the float d2 is), so one
+// compare-exchange of (d2, index) pairs is v_min_f64 + v_max_f64 instead of a 64-bit compare and four selects.
+// d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on gfx950).
 template <int K>
-__device__ __forceinline__ void topk_insert(u64 (&best)[K], u64 key) {
+__device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
     if (key < best[K - 1]) {
         best[K - 1] = key;
 #pragma unroll
         for (int j = K - 1; j > 0; --j) {
-            u64 a = best[j - 1], b = best[j];
-            bool sw = b < a;
-            best[j - 1] = sw ? b : a;
-            best[j] = sw ? a : b;
+            const double a = best[j - 1], b = best[j];
+            best[j - 1] = fmin(a, b);
+            best[j] = fmax(a, b);
         }
     }
 }
 
 template <int K>
 __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
-                                         float qz, u64 (&best)[K]) {
+                                         float qz, double (&best)[K]) {
     int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
     for (int p = p0; p < p1; ++p) {
         float4 c = G.sorted[p];
         float d2 = dist2_canon(qx, qy, qz, c.x, c.y, c.z);
         u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
-        topk_insert<K>(best, key);
+        topk_insert<K>(best, __longlong_as_double((long long)key));
     }
 }
 
@@ -83,9 +87,9 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
     int64_t out_row = seg_begin_packed(Q.segs, s) + local;
 
     const GridSeg g = G.segs[s];
-    u64 best[K];
+    double best[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = KEY_EMPTY;
+    for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
 
     if (g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
@@ -122,11 +126,11 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             if (cz - r > 0) gd = fminf(gd, qz - (g.lo[2] + (float)(cz - r) * g.c));
             if (cz + r < dzm) gd = fminf(gd, (g.lo[2] + (float)(cz + r + 1) * g.c) - qz);
             gd -= g.margin;
-            u64 kth = best[K - 1];
+            u64 kth = (u64)__double_as_longlong(best[K - 1]);
             if (k < K) {
                 // fewer than K requested: the k-th entry decides
 #pragma unroll
-                for (int j = 0; j < K; ++j) if (j == k - 1) kth = best[j];
+                for (int j = 0; j < K; ++j) if (j == k - 1) kth = (u64)__double_as_longlong(best[j]);
             }
             if (kth != KEY_EMPTY && gd > 0.f) {
                 float dk = __uint_as_float((unsigned)(kth >> 32));
@@ -138,7 +142,7 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (j < k) {
-            u64 key = best[j];
+            u64 key = (u64)__double_as_longlong(best[j]);
             bool ok = key != KEY_EMPTY;
             out_idx[out_row * k + j] = ok ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
             if (out_d2) out_d2[out_row * k + j] = ok ? __uint_as_float((unsigned)(key >> 32)) : __uint_as_float(0x7f800000u);

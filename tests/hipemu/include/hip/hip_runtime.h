@@ -313,6 +313,8 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+static inline double __longlong_as_double(long long i) { double d; memcpy(&d, &i, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long i; memcpy(&i, &d, 8); return i; }
 static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
