@@ -143,16 +143,32 @@ def main():
     eng = RandLAInferenceEngine(CFG, sd, B, N, dev)
     pts = torch.from_numpy(frames).to(dev)
     feats = pts.clone()   # in_channels = 3: features are the xyz themselves (randlanet.py:208-209)
-    labels = torch.empty((B, N), dtype=torch.int32, device=dev)
+    # predicted labels travel as uint8 (19 classes); two buffers so the gather of step i overlaps step i + 1
+    lab_dtype = torch.uint8 if CFG["num_classes"] <= 256 else torch.int32
+    labels = [torch.empty((B, N), dtype=lab_dtype, device=dev) for _ in range(2)]
+    recv = [[torch.empty_like(labels[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
 
     def one_step(knn_trace=None, fwd_trace=None):
         scores = eng.step(pts, feats, knn_trace, fwd_trace)
         if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
-            labels.copy_(torch.argmax(scores, dim=2))
-            mdist.gather_predictions(labels, dst=0)
+            i = step_no[0] & 1
+            step_no[0] += 1
+            if pending[i] is not None:
+                pending[i].wait()
+            labels[i].copy_(torch.argmax(scores, dim=2))
+            _, pending[i] = mdist.gather_predictions(labels[i], dst=0, out=recv[i], async_op=True)
+
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
+        pending[0] = pending[1] = None
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     K = args.steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -167,6 +183,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         one_step(ktraces[i], traces[i])
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -35,13 +35,23 @@ def shard_range(n_items, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_predictions(labels, dst=0):
+def gather_predictions(labels, dst=0, out=None, async_op=False):
     """labels: this rank's [B_local, N] tensor (same shape on every rank).  Returns the list of every rank's
     tensor on ``dst`` (rank order = cloud order for ``shard_range`` blocks of equal size), None elsewhere.
-    A no-op list of one tensor when no process group is initialised."""
+    A no-op list of one tensor when no process group is initialised.  ``out``: preallocated receive list on
+    ``dst``.  ``async_op=True`` returns (list, work): the collective runs on the backend's own stream so the next
+    step's kernels overlap it; call ``work.wait()`` before reusing ``labels`` / reading the list."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return [labels]
+        return ([labels], None) if async_op else [labels]
     rank, world = dist.get_rank(), dist.get_world_size()
-    out = [torch.empty_like(labels) for _ in range(world)] if rank == dst else None
-    dist.gather(labels, out, dst=dst)
-    return out
+    if rank == dst and out is None:
+        out = [torch.empty_like(labels) for _ in range(world)]
+    work = dist.gather(labels, out if rank == dst else None, dst=dst, async_op=async_op)
+    res = out if rank == dst else None
+    return (res, work) if async_op else res
+
+
+def compact_labels(scores):
+    """argmax over classes as the smallest integer type that holds it (uint8 for <= 256 classes): what travels."""
+    lab = torch.argmax(scores, dim=-1)
+    return lab.to(torch.uint8 if scores.shape[-1] <= 256 else torch.int32)

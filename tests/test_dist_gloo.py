@@ -27,6 +27,13 @@ def _worker(rank, world, port, n_frames, n_points, out_path):
     frames = torch.arange(b, e).view(-1, 1)
     labels = ((frames * 7 + torch.arange(n_points).view(1, -1) * 3) % 19).to(torch.int32)
     got = mdist.gather_predictions(labels, dst=0)
+    # async variant with a preallocated receive list (what bench.py overlaps with the next step)
+    u8 = labels.to(torch.uint8)
+    pre = [torch.empty_like(u8) for _ in range(world)] if rank == 0 else None
+    res, work = mdist.gather_predictions(u8, dst=0, out=pre, async_op=True)
+    work.wait()
+    if rank == 0:
+        assert torch.equal(torch.cat(res, 0), torch.cat(got, 0).to(torch.uint8))
     if rank == 0:
         np.save(out_path, torch.cat(got, 0).numpy())
     else:
