@@ -85,35 +85,50 @@ grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox
     seg_locate(S, last, s1, l1);
     const bool one_item = (s0 == s1);            // block-uniform
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    int cur = -1;
-    int64_t i = first + threadIdx.x;
-    for (int it = 0; it < 4; ++it, i += 256) {
-        if (i >= n_total) break;
-        int s; int64_t local;
-        if (one_item) { s = s0; local = l0 + (i - first); } else seg_locate(S, i, s, local);
-        const float* p = pts + 3 * (seg_begin_global(S, s) + local);
-        float x = p[0], y = p[1], z = p[2];
-        if (!one_item && s != cur) {
-            if (cur >= 0)
-                for (int a = 0; a < 3; ++a) {
-                    atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
-                    atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
+    if (!one_item) {
+        // straddling block (batched calls with short items): every wave-step covers 64 consecutive points —
+        // when they share one item the wave reduces and issues 6 atomics, only the wave-step that contains
+        // an item boundary falls back to per-lane atomics
+        int64_t i = first + threadIdx.x;
+        for (int it = 0; it < 4; ++it, i += 256) {
+            const bool valid = i < n_total;
+            int s = -1; int64_t local = 0;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (valid) {
+                seg_locate(S, i, s, local);
+                const float* p = pts + 3 * (seg_begin_global(S, s) + local);
+                x = p[0]; y = p[1]; z = p[2];
+            }
+            const int s_first = __builtin_amdgcn_readfirstlane(s);
+            if (__all(!valid || s == s_first)) {
+                if (__any(valid)) {
+                    const float v[6] = {wave_min(valid ? x : 3.0e38f), wave_min(valid ? y : 3.0e38f), wave_min(valid ? z : 3.0e38f),
+                                        wave_max(valid ? x : -3.0e38f), wave_max(valid ? y : -3.0e38f), wave_max(valid ? z : -3.0e38f)};
+                    if ((threadIdx.x & 63) == 0 && s_first >= 0) {
+                        for (int a = 0; a < 3; ++a) {
+                            atomicMin(&bbox[6 * s_first + a], f2ord(v[a]));
+                            atomicMax(&bbox[6 * s_first + 3 + a], f2ord(v[3 + a]));
+                        }
+                    }
                 }
-            mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
-        } else {
+            } else if (valid) {
+                atomicMin(&bbox[6 * s + 0], f2ord(x)); atomicMax(&bbox[6 * s + 3], f2ord(x));
+                atomicMin(&bbox[6 * s + 1], f2ord(y)); atomicMax(&bbox[6 * s + 4], f2ord(y));
+                atomicMin(&bbox[6 * s + 2], f2ord(z)); atomicMax(&bbox[6 * s + 5], f2ord(z));
+            }
+        }
+        return;
+    }
+    {
+        int64_t i = first + threadIdx.x;
+        for (int it = 0; it < 4; ++it, i += 256) {
+            if (i >= n_total) break;
+            const float* p = pts + 3 * (seg_begin_global(S, s0) + l0 + (i - first));
+            const float x = p[0], y = p[1], z = p[2];
             mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         }
-        cur = s;
-    }
-    if (!one_item) {
-        if (cur >= 0)
-            for (int a = 0; a < 3; ++a) {
-                atomicMin(&bbox[6 * cur + a], f2ord(mn[a]));
-                atomicMax(&bbox[6 * cur + 3 + a], f2ord(mx[a]));
-            }
-        return;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
