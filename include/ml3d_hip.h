@@ -294,6 +294,27 @@ int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_thres
              void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* patch sampler / vote accumulation                         */
+/* ml3d_nearest_to_center: the k points nearest to a centre, ascending         */
+/*   (d2, index) — replaces search_tree.query(center_point, k=num_points) of   */
+/*   SemSegSpatiallyRegularSampler (ml3d/datasets/samplers/                    */
+/*   semseg_spatially_regular.py:90-91); k may be as large as n_points.        */
+/*   center_host: HOST float[3].  out_dist2 may be NULL.                       */
+/* ml3d_vote_update: probs[inds[i]] = smooth*probs[inds[i]] + (1-smooth)*      */
+/*   softmax(logits[i]) on a float16 accumulator [n_cloud, classes] with the   */
+/*   numpy promotion of ml3d/torch/models/randlanet.py:420-421, 457-462        */
+/*   (float16 product, float32 sum, float16 store).  inds must be distinct.    */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points);
+
+int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host,
+                           int64_t k, int32_t* out_index, float* out_dist2,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, int num_classes,
+                     float smooth, void* probs_f16, int64_t n_cloud, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */
 /*   ml3d/torch/models/randlanet.py:218-229 for a batch of equally sized       */
 /*   clouds in ONE call.  Layer l has n_l = n_{l-1} / ratio[l-1] points, the   */

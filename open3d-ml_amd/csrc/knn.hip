@@ -375,3 +375,103 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Patch sampler support: the num_points nearest points to a centre
+//   search_tree.query(center_point, k=num_points)   ml3d/datasets/samplers/semseg_spatially_regular.py:90-91
+// and the test-time vote accumulation
+//   test_probs[inds] = smooth * test_probs[inds] + (1 - smooth) * softmax(logits)
+//   ml3d/torch/models/randlanet.py:420-421, 457-462 (float16 accumulator, numpy promotion rules).
+// k is the patch size (45 056), far beyond a register-resident best-k list: the whole cloud is keyed by
+// (d2, index) and radix-sorted (sort.hip), the first k entries are the answer in canonical order.
+// ---------------------------------------------------------------------------------------------------
+#include <hip/hip_fp16.h>
+
+#include "sort.h"
+
+namespace ml3d {
+
+__global__ void center_keys(const float* __restrict__ pts, int64_t n, float cx, float cy, float cz, u64* __restrict__ keys,
+                            uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d2 = dist2_canon(cx, cy, cz, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    keys[i] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)i;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void center_take(const u64* __restrict__ keys, int64_t k, int32_t* __restrict__ out_idx, float* __restrict__ out_d2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const u64 key = keys[i];
+    out_idx[i] = (int32_t)(key & 0xffffffffull);
+    if (out_d2) out_d2[i] = __uint_as_float((unsigned)(key >> 32));
+}
+
+// one wave per patch point: softmax over the C classes (lanes stride the classes), then the float16 vote update
+__global__ void __launch_bounds__(256)
+vote_update(const float* __restrict__ logits, const int32_t* __restrict__ inds, int64_t n, int C, float smooth,
+            __half* __restrict__ probs, int64_t n_cloud) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* row = logits + i * C;
+    float mx = -3.0e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const int64_t dst = inds[i];
+    if (dst < 0 || dst >= n_cloud) return;
+    const __half hs = __float2half(smooth);                     // numpy: python float * float16 array -> float16
+    const float w_new = 1.0f - smooth;
+    for (int c = lane; c < C; c += 64) {
+        const float p = expf(row[c] - mx) / sum;
+        const __half old = probs[dst * C + c];
+        const __half keep = __float2half(__half2float(hs) * __half2float(old));     // float16 product, one rounding
+        probs[dst * C + c] = __float2half(__half2float(keep) + w_new * p);          // float32 sum -> float16 store
+    }
+}
+
+}  // namespace ml3d
+
+extern "C" size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points) {
+    if (n_points < 0) return 0;
+    const int64_t m = n_points > 0 ? n_points : 1;
+    return ((sizeof(u64) * (size_t)m + 255) & ~(size_t)255) + ((sizeof(uint32_t) * (size_t)m + 255) & ~(size_t)255) +
+           sort_ws_bytes(m) + 512;
+}
+
+extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host, int64_t k,
+                                      int32_t* out_index, float* out_dist2, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (n_points < 0 || k < 0 || k > n_points || !center_host || n_points > 0x7ffffff0ll) return ML3D_E_INVALID;
+    if (k == 0) return 0;
+    if (!points || !out_index) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_nearest_to_center_workspace_bytes(n_points)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    u64* keys = (u64*)p;            p += (sizeof(u64) * (size_t)n_points + 255) & ~(size_t)255;
+    uint32_t* vals = (uint32_t*)p;  p += (sizeof(uint32_t) * (size_t)n_points + 255) & ~(size_t)255;
+    SortWs sw;
+    if (!sort_ws_carve(p, sort_ws_bytes(n_points), n_points, &sw)) return ML3D_E_WORKSPACE;
+    hipLaunchKernelGGL(center_keys, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, points, n_points,
+                       center_host[0], center_host[1], center_host[2], keys, vals);
+    if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    if (sort_pairs_u64(keys, vals, n_points, 64, sw, st)) return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL(center_take, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, keys, k, out_index, out_dist2);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, int num_classes, float smooth,
+                                void* probs_f16, int64_t n_cloud, void* stream) {
+    if (n < 0 || num_classes <= 0 || n_cloud < 0) return ML3D_E_INVALID;
+    if (n == 0) return 0;
+    if (!logits || !point_inds || !probs_f16) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(vote_update, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, point_inds, n,
+                       num_classes, smooth, (__half*)probs_f16, n_cloud);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}

@@ -44,6 +44,9 @@ SYMBOLS = [
     "ml3d_nhwc_to_nchw",
     "ml3d_nms_workspace_bytes",
     "ml3d_nms",
+    "ml3d_nearest_to_center_workspace_bytes",
+    "ml3d_nearest_to_center",
+    "ml3d_vote_update",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -132,6 +135,12 @@ def bind(lib):
     lib.ml3d_nms_workspace_bytes.argtypes = [i64]
     lib.ml3d_nms.restype = C.c_int
     lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_nearest_to_center_workspace_bytes.restype = sz
+    lib.ml3d_nearest_to_center_workspace_bytes.argtypes = [i64]
+    lib.ml3d_nearest_to_center.restype = C.c_int
+    lib.ml3d_nearest_to_center.argtypes = [vp, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.ml3d_vote_update.restype = C.c_int
+    lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

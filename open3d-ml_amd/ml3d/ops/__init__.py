@@ -576,3 +576,48 @@ def nms(boxes, scores, nms_overlap_thresh):
                           count.data_ptr(), ws.data_ptr(), wsb, _stream())
     _abi.check(rc, "ml3d_nms")
     return keep[:int(count.item())]
+
+
+# ---------------------------------------------------------------------------------------------------
+# patch sampler / vote accumulation
+# ---------------------------------------------------------------------------------------------------
+def nearest_to_center(points, center, k, return_distances=False):
+    """The ``k`` points nearest to ``center`` in ascending (d2, index) order — the
+    ``search_tree.query(center_point, k=num_points)`` of SemSegSpatiallyRegularSampler
+    (ml3d/datasets/samplers/semseg_spatially_regular.py:90-91).  int32 indices [k]."""
+    lib = _abi.get()
+    _need_gpu(points)
+    points = points.contiguous().float()
+    n = points.shape[0]
+    dev = points.device
+    c = torch.as_tensor(center, dtype=torch.float32).detach().cpu().reshape(-1).contiguous()
+    if c.numel() != 3 or not (0 <= int(k) <= n):
+        raise RuntimeError("nearest_to_center: center must have 3 elements and 0 <= k <= n_points")
+    idx = torch.empty(int(k), dtype=torch.int32, device=dev)
+    d2 = torch.empty(int(k), dtype=torch.float32, device=dev) if return_distances else None
+    wsb = lib.ml3d_nearest_to_center_workspace_bytes(n)
+    ws = _ws(wsb, dev)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_nearest_to_center(points.data_ptr(), n, c.data_ptr(), int(k), idx.data_ptr(),
+                                        None if d2 is None else d2.data_ptr(), ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_nearest_to_center")
+    return (idx, d2) if return_distances else idx
+
+
+def vote_update(test_probs, point_inds, logits, smooth=0.95):
+    """In place: ``test_probs[inds] = smooth * test_probs[inds] + (1 - smooth) * softmax(logits)`` on the float16
+    vote accumulator [N_cloud, classes] (ml3d/torch/models/randlanet.py:420-421, 457-462)."""
+    lib = _abi.get()
+    _need_gpu(test_probs, point_inds, logits)
+    if test_probs.dtype != torch.float16 or not test_probs.is_contiguous() or test_probs.dim() != 2:
+        raise RuntimeError("vote_update: test_probs must be a contiguous float16 [N, classes] tensor")
+    C_ = test_probs.shape[1]
+    lg = logits.reshape(-1, C_).contiguous().float()
+    inds = point_inds.reshape(-1).to(torch.int32).contiguous()
+    if inds.numel() != lg.shape[0]:
+        raise RuntimeError("vote_update: one index per logits row")
+    with torch.cuda.device(test_probs.device):
+        rc = lib.ml3d_vote_update(lg.data_ptr(), inds.data_ptr(), lg.shape[0], C_, float(smooth), test_probs.data_ptr(),
+                                  test_probs.shape[0], _stream())
+    _abi.check(rc, "ml3d_vote_update")
+    return test_probs

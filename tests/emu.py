@@ -318,3 +318,29 @@ def nms(boxes, scores, thr):
                     None)
     assert rc == 0, rc
     return keep[:int(cnt[0])]
+
+
+def nearest_to_center(points, center, k):
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    c = np.ascontiguousarray(center, np.float32)
+    n = len(points)
+    idx = np.full(k, -1, np.int32)
+    d2 = np.zeros(k, np.float32)
+    wsb = L.ml3d_nearest_to_center_workspace_bytes(n)
+    ws = _ws(wsb)
+    rc = L.ml3d_nearest_to_center(points.ctypes.data, n, c.ctypes.data, k, idx.ctypes.data, d2.ctypes.data, ws.ctypes.data,
+                                  wsb, None)
+    assert rc == 0, rc
+    return idx, d2
+
+
+def vote_update(probs16, inds, logits, smooth):
+    L = lib()
+    probs16 = np.ascontiguousarray(probs16, np.float16).copy()
+    inds = np.ascontiguousarray(inds, np.int32)
+    logits = np.ascontiguousarray(logits, np.float32)
+    rc = L.ml3d_vote_update(logits.ctypes.data, inds.ctypes.data, len(inds), probs16.shape[1], smooth, probs16.ctypes.data,
+                            probs16.shape[0], None)
+    assert rc == 0, rc
+    return probs16

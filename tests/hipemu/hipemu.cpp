@@ -34,6 +34,7 @@ static void run_block(Block* b) {
     int nw = (n + WAVE - 1) / WAVE;
     for (int w = 0; w < nw; ++w) {
         memset(b->waves[w].valid, 0, sizeof(b->waves[w].valid));
+        memset(b->waves[w].pub, 0, sizeof(b->waves[w].pub));
         memset(b->waves[w].gen, 0, sizeof(b->waves[w].gen));
     }
     for (int t = 0; t < n; ++t) {
@@ -55,12 +56,7 @@ static void run_block(Block* b) {
             set_tid(b, t);
             swapcontext(&b->sched, &f.ctx);
             progress = true;
-            if (f.state == DONE) {
-                --live;
-                WaveScratch& W = b->waves[t / WAVE];
-                W.valid[0][t % WAVE] = 0;
-                W.valid[1][t % WAVE] = 0;
-            }
+            if (f.state == DONE) --live;     // its last published slot stays readable (see WaveView::peer_valid)
         }
         // block barrier: every live fiber must be AT_BARRIER
         {

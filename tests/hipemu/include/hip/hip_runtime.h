@@ -90,6 +90,7 @@ struct WaveScratch {
     // two generations of per-lane 64-byte slots (enough for a + b + flag)
     alignas(16) unsigned char slot[2][WAVE][80];
     unsigned char valid[2][WAVE];
+    unsigned pub[2][WAVE];   // ordinal of the collective the slot was published for
     unsigned gen[WAVE];
 };
 
@@ -129,8 +130,12 @@ struct WaveView {
     WaveScratch* w;
     int g;     // generation parity used
     int lane;
+    unsigned ord;   // ordinal of this collective (per lane count of collectives so far)
     const void* peer(int l) const { return w->slot[g][l]; }
-    bool peer_valid(int l) const { return w->valid[g][l] != 0; }
+    // a peer's slot counts only if it was published for THIS collective: a lane that has exited (or, after a
+    // divergent exit, simply does not take part any more) leaves its last slot readable for the lanes that
+    // are still returning from that same rendezvous, and is invisible to every later collective
+    bool peer_valid(int l) const { return w->valid[g][l] != 0 && w->pub[g][l] == ord; }
 };
 
 inline WaveView wave_exchange(const void* data, size_t n) {
@@ -139,15 +144,14 @@ inline WaveView wave_exchange(const void* data, size_t n) {
     int wv = t / WAVE, lane = t % WAVE;
     WaveScratch& W = b->waves[wv];
     int g = (int)(W.gen[lane] & 1u);
-    W.gen[lane]++;
+    const unsigned ord = ++W.gen[lane];
     if (n > 80) { fprintf(stderr, "hipemu: exchange too large\n"); abort(); }
     memcpy(W.slot[g][lane], data, n);
     W.valid[g][lane] = 1;
+    W.pub[g][lane] = ord;
     b->fibers[t].state = AT_WAVE;
     yield_to_sched();
-    // clear the OTHER generation's valid flag of this lane so exited lanes read as invalid later
-    W.valid[g ^ 1][lane] = 0;
-    return WaveView{&W, g, lane};
+    return WaveView{&W, g, lane, ord};
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);

@@ -142,3 +142,31 @@ def _boxes(seed, n, spread):
 def test_rotated_nms_matches_oracle(n, spread, thr):
     b, s = _boxes(n, n, spread)
     assert np.array_equal(emu.nms(b, s, thr), oops.nms(b, s, thr))
+
+
+def test_nearest_to_center_is_the_sampler_query_in_canonical_order():
+    pts = synth_data.semantickitti_patch(9, 5000)
+    c = pts[123]
+    idx, d2 = emu.nearest_to_center(pts, c, 2048)
+    ref, rd = oops.knn_search(pts, c[None], 2048, brute=True, return_distances=True)
+    assert np.array_equal(idx, ref[0]) and np.array_equal(d2, rd[0]) and idx[0] == 123
+    idx_all, _ = emu.nearest_to_center(pts, c, 5000)
+    assert np.array_equal(np.sort(idx_all), np.arange(5000))
+
+
+def test_vote_update_follows_numpy_float16_promotion():
+    """randlanet.py:457-462: test_probs (float16) = 0.95 * test_probs + 0.05 * softmax(logits) (float32)."""
+    import torch
+    rng = np.random.default_rng(4)
+    probs = rng.random((300, 19)).astype(np.float16)
+    inds = rng.permutation(300)[:120].astype(np.int32)
+    logits = (rng.standard_normal((120, 19)) * 3).astype(np.float32)
+    out = emu.vote_update(probs, inds, logits, 0.95)
+    ref = probs.copy()
+    p = torch.softmax(torch.from_numpy(logits), -1).numpy()
+    ref[inds] = 0.95 * ref[inds] + (1 - 0.95) * p
+    assert ref.dtype == np.float16
+    d = np.abs(out.astype(np.float32) - ref.astype(np.float32))
+    assert d.max() <= 2 ** -10 and (d == 0).mean() > 0.99          # at most one float16 ulp, almost always none
+    untouched = np.setdiff1d(np.arange(300), inds)
+    assert np.array_equal(out[untouched], probs[untouched])

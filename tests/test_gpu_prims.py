@@ -179,3 +179,27 @@ def test_rotated_nms_matches_oracle(n, spread, thr):
     keep = ops.nms(_t(b), _t(s), thr)
     assert keep.dtype == torch.int64
     assert np.array_equal(keep.cpu().numpy(), oops.nms(b, s, thr))
+
+
+def test_sampler_patch_query_and_projection_and_votes():
+    """the 45 056-NN patch query, the 1-NN projection of raw points onto the sub-cloud and the
+    float16 vote update."""
+    from ml3d import ops
+    sweep = synth_data.lidar_sweep(77)
+    sub = oops.subsample(sweep, sampleDl=0.06)
+    c = sub[4321]
+    idx, d2 = ops.nearest_to_center(_t(sub), c, 45056, return_distances=True)
+    ref, rd = oops.knn_search(sub, c[None], 45056, brute=True, return_distances=True)
+    assert np.array_equal(idx.cpu().numpy(), ref[0]) and np.array_equal(d2.cpu().numpy(), rd[0])
+    # proj_inds = search_tree.query(points) (randlanet.py:147-150): 1-NN of every raw point in the sub-cloud
+    proj = ops.knn_search(_t(sub), _t(sweep), 1).neighbors_index[:, 0].cpu().numpy()
+    assert np.array_equal(proj, oops.knn_search(sub, sweep, 1)[:, 0])
+    rng = np.random.default_rng(1)
+    probs = rng.random((len(sub), 19)).astype(np.float16)
+    logits = (rng.standard_normal((45056, 19)) * 3).astype(np.float32)
+    out = ops.vote_update(_t(probs), idx, _t(logits), 0.95).cpu().numpy()
+    ref_p = probs.copy()
+    ii = ref[0]
+    ref_p[ii] = 0.95 * ref_p[ii] + (1 - 0.95) * torch.softmax(torch.from_numpy(logits), -1).numpy()
+    d = np.abs(out.astype(np.float32) - ref_p.astype(np.float32))
+    assert d.max() <= 2 ** -10 and (d == 0).mean() > 0.99
