@@ -26,8 +26,9 @@ for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
 import numpy as np
 import torch
 
-CFG = dict(num_neighbors=16, num_layers=4, num_points=45056, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4],
-           in_channels=3, dim_features=8, dim_output=[16, 64, 128, 256])  # randlanet_semantickitti.yml:17-33
+import synth_weights
+
+CFG = dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG)  # randlanet_semantickitti.yml:17-33
 
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -124,7 +125,6 @@ def main():
 
     import synth_data
     from ml3d.engine import RandLAInferenceEngine, make_trace
-    from oracle import randlanet_ref as R  # weights generator only (deterministic pseudo-trained state_dict)
 
     B, N = args.frames_per_step, CFG["num_points"]
     # ---- synthetic frames: distinct sweeps per rank, tiled by seeded z-rotations to fill the batch
@@ -139,7 +139,7 @@ def main():
             rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
             f = (f @ rot.T)[rng.permutation(N)]
         frames[b] = f
-    sd = R.make_state_dict(CFG, 2024)
+    sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
     eng = RandLAInferenceEngine(CFG, sd, B, N, dev)
     pts = torch.from_numpy(frames).to(dev)
     feats = pts.clone()   # in_channels = 3: features are the xyz themselves (randlanet.py:208-209)

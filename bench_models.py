@@ -75,13 +75,13 @@ def run_pointpillars(args, rank, world, dev, dist):
     from ml3d import ops
     from ml3d import dist as mdist
     from ml3d.torch.models.point_pillars import PointPillars
-    from oracle import pointpillars_ref as P
-    cfg = P.KITTI_CFG
+    import synth_weights as W
+    cfg = W.POINTPILLARS_KITTI_CFG
     B = args.frames_per_step if args.frames_per_step != 64 else 4
-    sd = P.make_state_dict(cfg, 2024)
+    sd = W.pointpillars_state_dict(cfg, 2024)
     m = PointPillars(device=dev, **cfg)
     m.load_state_dict(sd)
-    clouds_np = [P.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
+    clouds_np = [W.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
     clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]
     timer = _CallTimer(ops, "conv2d_nhwc", 1)       # 2nd conv of a step: 3x3 64->64 stride 1 on the 248 x 216 map
     nbox = torch.zeros((B, 1), dtype=torch.int32, device=dev)
@@ -112,6 +112,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
                         "flops_per_launch": flops}}
     if not args.no_cpu_baseline and world == 1:
+        from oracle import pointpillars_ref as P          # the checker, used here only as the timed CPU baseline
         pts = [torch.from_numpy(c) for c in clouds_np[:1]]
         P.forward(sd, cfg, pts)
         t0 = time.perf_counter()
@@ -132,10 +133,10 @@ def run_kpconv(args, rank, world, dev, dist):
     from ml3d import ops
     from ml3d import dist as mdist
     from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
-    from oracle import kpconv_ref as K
-    cfg = dict(K.TORONTO3D_CFG)
+    import synth_weights as W
+    cfg = dict(W.TORONTO3D_CFG)
     B = args.frames_per_step if args.frames_per_step != 64 else 8
-    sd = K.make_state_dict(cfg, 2024)
+    sd = W.kpconv_state_dict(cfg, 2024)
     m = KPFCNN(**cfg, device=dev)
     m.load_state_dict(sd)
     spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
@@ -172,6 +173,7 @@ def run_kpconv(args, rank, world, dev, dist):
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
                         "flops_per_launch": flops}}
     if not args.no_cpu_baseline and world == 1:
+        from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline
         sp = spheres[0]
         feats = torch.ones((len(sp), 1))
         t0 = time.perf_counter()

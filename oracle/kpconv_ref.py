@@ -19,16 +19,9 @@ import torch
 import torch.nn.functional as F
 
 from . import ops as oops
+from synth_weights import (TORONTO3D_CFG, arch_plan, synthetic_kernel_points,  # noqa: F401  (input generation)
+                           kpconv_state_dict as make_state_dict)
 
-TORONTO3D_CFG = dict(   # ml3d/configs/kpconv_toronto3d.yml:23-82 (inference-relevant keys)
-    KP_extent=1.0, KP_influence="linear", aggregation_mode="sum",
-    architecture=["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb_strided", "resnetb",
-                  "resnetb_strided", "resnetb", "resnetb_strided", "resnetb", "nearest_upsample", "unary",
-                  "nearest_upsample", "unary", "nearest_upsample", "unary", "nearest_upsample", "unary"],
-    batch_limit=10000, batch_norm_momentum=0.98, conv_radius=2.5, first_features_dim=128,
-    first_subsampling_dl=0.08, fixed_kernel_points="center", in_features_dim=1, in_points_dim=3, in_radius=4.0,
-    lbl_values=[0, 1, 2, 3, 4, 5, 6, 7, 8], ignored_label_inds=[0], max_in_points=10000, modulated=False,
-    num_classes=8, num_kernel_points=15, num_layers=5, use_batch_norm=True, reduce_fc=True, l_relu=0.2)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -143,123 +136,6 @@ def segmentation_inputs(stacked_points, stack_lengths, cfg, rotations="random"):
         if "global" in block or "upsample" in block:
             break
     return out
-
-
-# ---------------------------------------------------------------------------------------------------
-# architecture walk (kpconv.py:131-236) -> flat list of block descriptors
-# ---------------------------------------------------------------------------------------------------
-def arch_plan(cfg):
-    """Mirrors the two loops of KPFCNN.__init__: returns (encoder, decoder, head) lists of dicts
-    {name, kind, layer, in_dim, out_dim, radius, extent}, plus encoder_skips / decoder_concats."""
-    arch = cfg["architecture"]
-    layer, r = 0, cfg["first_subsampling_dl"] * cfg["conv_radius"]
-    in_dim, out_dim = cfg["in_features_dim"], cfg["first_features_dim"]
-    enc, skips, skip_dims = [], [], []
-    for bi, block in enumerate(arch):
-        if any(t in block for t in ("pool", "strided", "upsample", "global")):
-            skips.append(bi)
-            skip_dims.append(in_dim)
-        if "upsample" in block:
-            break
-        enc.append(dict(name=block, layer=layer, in_dim=in_dim, out_dim=out_dim, radius=r,
-                        extent=r * cfg["KP_extent"] / cfg["conv_radius"]))
-        in_dim = out_dim // 2 if "simple" in block else out_dim
-        if "pool" in block or "strided" in block:
-            layer += 1
-            r *= 2
-            out_dim *= 2
-    dec, concats = [], []
-    start = next((i for i, b in enumerate(arch) if "upsample" in b), len(arch))
-    for bi, block in enumerate(arch[start:]):
-        if bi > 0 and "upsample" in arch[start + bi - 1]:
-            in_dim += skip_dims[layer]
-            concats.append(bi)
-        dec.append(dict(name=block, layer=layer, in_dim=in_dim, out_dim=out_dim, radius=r,
-                        extent=r * cfg["KP_extent"] / cfg["conv_radius"]))
-        in_dim = out_dim
-        if bi == 0 and cfg.get("reduce_fc", False):
-            out_dim = out_dim // 2
-        if "upsample" in block:
-            layer -= 1
-            r *= 0.5
-            out_dim = out_dim // 2
-    C = len(cfg["lbl_values"]) - len(cfg["ignored_label_inds"])
-    if cfg.get("reduce_fc", False):
-        head = [dict(in_dim=out_dim, out_dim=cfg["first_features_dim"] // 2, bn=True, relu=True),
-                dict(in_dim=cfg["first_features_dim"] // 2, out_dim=C, bn=False, relu=False)]
-    else:
-        head = [dict(in_dim=out_dim, out_dim=cfg["first_features_dim"], bn=False, relu=True),
-                dict(in_dim=cfg["first_features_dim"], out_dim=C, bn=False, relu=True)]
-    return dict(encoder=enc, decoder=dec, head=head, encoder_skips=skips, decoder_concats=concats)
-
-
-def synthetic_kernel_points(radius, K=15):
-    """Deterministic stand-in for load_kernels (kpconv.py:1909-1999; the reference optimises a random
-    disposition and caches it on disk): centre point + K-1 points on a Fibonacci sphere of 0.66 * radius."""
-    pts = [[0.0, 0.0, 0.0]]
-    n = K - 1
-    for i in range(n):
-        z = 1 - 2 * (i + 0.5) / n
-        rr = np.sqrt(max(0.0, 1 - z * z))
-        ph = i * np.pi * (3 - np.sqrt(5))
-        pts.append([0.66 * rr * np.cos(ph), 0.66 * rr * np.sin(ph), 0.66 * z])
-    return (np.asarray(pts) * radius).astype(np.float32)
-
-
-def make_state_dict(cfg, seed):
-    """Pseudo-trained weights with the reference's state_dict keys and shapes."""
-    g = torch.Generator().manual_seed(int(seed))
-    plan = arch_plan(cfg)
-    sd = {}
-    K = cfg["num_kernel_points"]
-
-    def rnd(*shape, scale=1.0):
-        return (torch.rand(*shape, generator=g) * 2 - 1) * scale
-
-    def bn(prefix, c):
-        if cfg["use_batch_norm"]:
-            sd[prefix + ".batch_norm.weight"] = 1 + rnd(c, scale=0.3)
-            sd[prefix + ".batch_norm.bias"] = rnd(c, scale=0.3)
-            sd[prefix + ".batch_norm.running_mean"] = rnd(c, scale=0.2)
-            sd[prefix + ".batch_norm.running_var"] = 0.5 + torch.rand(c, generator=g)
-            sd[prefix + ".batch_norm.num_batches_tracked"] = torch.tensor(100)
-        else:
-            sd[prefix + ".bias"] = rnd(c, scale=0.3)
-
-    def unary(prefix, cin, cout, use_bn=True):
-        sd[prefix + ".mlp.weight"] = rnd(cout, cin, scale=(3.0 / cin) ** 0.5)
-        if use_bn and cfg["use_batch_norm"]:
-            bn(prefix + ".batch_norm", cout)
-        else:
-            sd[prefix + ".batch_norm.bias"] = rnd(cout, scale=0.3)
-
-    def kpconv(prefix, cin, cout, radius):
-        sd[prefix + ".weights"] = rnd(K, cin, cout, scale=(3.0 / (cin * 4.0)) ** 0.5)
-        sd[prefix + ".kernel_points"] = torch.from_numpy(synthetic_kernel_points(radius, K))
-
-    for i, b in enumerate(plan["encoder"]):
-        p = "encoder_blocks.%d" % i
-        if "simple" in b["name"]:
-            kpconv(p + ".KPConv", b["in_dim"], b["out_dim"] // 2, b["radius"])
-            bn(p + ".batch_norm", b["out_dim"] // 2)
-        elif "resnetb" in b["name"]:
-            mid = b["out_dim"] // 4
-            if b["in_dim"] != mid:
-                unary(p + ".unary1", b["in_dim"], mid)
-            kpconv(p + ".KPConv", mid, mid, b["radius"])
-            bn(p + ".batch_norm_conv", mid)
-            unary(p + ".unary2", mid, b["out_dim"])
-            if b["in_dim"] != b["out_dim"]:
-                unary(p + ".unary_shortcut", b["in_dim"], b["out_dim"])
-        else:
-            raise NotImplementedError(b["name"])
-    for i, b in enumerate(plan["decoder"]):
-        if b["name"] == "unary":
-            unary("decoder_blocks.%d" % i, b["in_dim"], b["out_dim"])
-    h0, h1 = plan["head"]
-    unary("head_mlp", h0["in_dim"], h0["out_dim"], use_bn=h0["bn"])
-    unary("head_softmax", h1["in_dim"], h1["out_dim"], use_bn=h1["bn"])
-    return sd
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -17,81 +17,8 @@ import torch
 import torch.nn.functional as F
 
 from . import ops as oops
-
-KITTI_CFG = dict(   # ml3d/configs/pointpillars_kitti.yml:7-66 (inference-relevant keys)
-    point_cloud_range=[0, -39.68, -3, 69.12, 39.68, 1], classes=["Pedestrian", "Cyclist", "Car"],
-    voxelize=dict(max_num_points=32, voxel_size=[0.16, 0.16, 4], max_voxels=[16000, 40000]),
-    voxel_encoder=dict(in_channels=4, feat_channels=[64], voxel_size=[0.16, 0.16, 4]),
-    scatter=dict(in_channels=64, output_shape=[496, 432]),
-    backbone=dict(in_channels=64, out_channels=[64, 128, 256], layer_nums=[3, 5, 5], layer_strides=[2, 2, 2]),
-    neck=dict(in_channels=[64, 128, 256], out_channels=[128, 128, 128], upsample_strides=[1, 2, 4],
-              use_conv_for_no_stride=False),
-    head=dict(in_channels=384, feat_channels=384, nms_pre=100, score_thr=0.1,
-              ranges=[[0, -39.68, -0.6, 70.4, 39.68, -0.6], [0, -39.68, -0.6, 70.4, 39.68, -0.6],
-                      [0, -39.68, -1.78, 70.4, 39.68, -1.78]],
-              sizes=[[0.6, 0.8, 1.73], [0.6, 1.76, 1.73], [1.6, 3.9, 1.56]], rotations=[0, 1.57],
-              iou_thr=[[0.35, 0.5], [0.35, 0.5], [0.45, 0.6]]))
-
-# a small two-PFN-layer, 3-channel-point variant (the argoverse / nuscenes shape family) on a 64 x 48 canvas
-SMALL_CFG = dict(
-    point_cloud_range=[0, -9.6, -3, 25.6, 9.6, 1], classes=["Car", "Pedestrian"],
-    voxelize=dict(max_num_points=20, voxel_size=[0.4, 0.4, 4], max_voxels=[3000, 3000]),
-    voxel_encoder=dict(in_channels=3, feat_channels=[64, 64], voxel_size=[0.4, 0.4, 4]),
-    scatter=dict(in_channels=64, output_shape=[48, 64]),
-    backbone=dict(in_channels=64, out_channels=[32, 64, 96], layer_nums=[1, 2, 1], layer_strides=[1, 2, 2]),
-    neck=dict(in_channels=[32, 64, 96], out_channels=[32, 32, 32], upsample_strides=[1, 2, 4],
-              use_conv_for_no_stride=False),
-    head=dict(in_channels=96, feat_channels=96, nms_pre=100, score_thr=0.1,
-              ranges=[[0, -9.6, -0.6, 25.6, 9.6, -0.6], [0, -9.6, -1.78, 25.6, 9.6, -1.78]],
-              sizes=[[0.6, 0.8, 1.73], [1.6, 3.9, 1.56]], rotations=[0, 1.57], iou_thr=[[0.35, 0.5], [0.45, 0.6]]))
-
-
-def make_state_dict(cfg, seed):
-    """Pseudo-trained weights with the reference's state_dict keys and shapes."""
-    g = torch.Generator().manual_seed(int(seed))
-    sd = {}
-
-    def rnd(*shape, scale=1.0):
-        return (torch.rand(*shape, generator=g) * 2 - 1) * scale
-
-    def bn(prefix, c):
-        sd[prefix + ".weight"] = 1 + rnd(c, scale=0.3)
-        sd[prefix + ".bias"] = rnd(c, scale=0.3)
-        sd[prefix + ".running_mean"] = rnd(c, scale=0.2)
-        sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=g)
-        sd[prefix + ".num_batches_tracked"] = torch.tensor(100)
-
-    ve = cfg["voxel_encoder"]
-    chans = [ve["in_channels"] + 5] + list(ve["feat_channels"])
-    for i in range(len(chans) - 1):
-        last = i == len(chans) - 2
-        units = chans[i + 1] if last else chans[i + 1] // 2
-        sd["voxel_encoder.pfn_layers.%d.linear.weight" % i] = rnd(units, chans[i], scale=(3.0 / chans[i]) ** 0.5)
-        bn("voxel_encoder.pfn_layers.%d.norm" % i, units)
-    bb = cfg["backbone"]
-    cin = [bb["in_channels"]] + list(bb["out_channels"][:-1])
-    for i, ln in enumerate(bb["layer_nums"]):
-        co = bb["out_channels"][i]
-        sd["backbone.blocks.%d.0.weight" % i] = rnd(co, cin[i], 3, 3, scale=(3.0 / (9 * cin[i])) ** 0.5 * 1.4)
-        bn("backbone.blocks.%d.1" % i, co)
-        for j in range(ln):
-            sd["backbone.blocks.%d.%d.weight" % (i, 3 + 3 * j)] = rnd(co, co, 3, 3, scale=(3.0 / (9 * co)) ** 0.5 * 1.4)
-            bn("backbone.blocks.%d.%d" % (i, 4 + 3 * j), co)
-    nk = cfg["neck"]
-    for i, co in enumerate(nk["out_channels"]):
-        s = nk["upsample_strides"][i]
-        ci = nk["in_channels"][i]
-        sd["neck.deblocks.%d.0.weight" % i] = rnd(ci, co, s, s, scale=(3.0 / ci) ** 0.5)     # ConvTranspose2d [Cin,Cout,k,k]
-        bn("neck.deblocks.%d.1" % i, co)
-    hd = cfg["head"]
-    na = len(hd["sizes"]) * len(hd["rotations"])
-    nc = len(cfg["classes"])
-    fc = hd["feat_channels"]
-    for name, co in (("conv_cls", na * nc), ("conv_reg", na * 7), ("conv_dir_cls", na * 2)):
-        sd["bbox_head.%s.weight" % name] = rnd(co, fc, 1, 1, scale=(3.0 / fc) ** 0.5)
-        sd["bbox_head.%s.bias" % name] = rnd(co, scale=0.5)
-    return sd
-
+from synth_weights import (POINTPILLARS_KITTI_CFG as KITTI_CFG, POINTPILLARS_SMALL_CFG as SMALL_CFG,  # noqa: F401
+                           pointpillars_state_dict as make_state_dict, crop_for_cfg)
 
 def voxelization(points_feats, cfg, training=False):
     """PointPillarsVoxelization.forward (point_pillars.py:328-382) for one sample [N, 3+C]."""
@@ -201,13 +128,6 @@ def forward(sd, cfg, points_list):
     return backbone_neck_head(sd, cfg, x), dict(voxels=voxels, coors=coors, num_points=nums, pillar_features=vf)
 
 
-def crop_for_cfg(sweep, cfg):
-    """Keep the points of a synthetic sweep that fall inside the config's range (what ObjectRangeFilter /
-    the dataset crop hands to the model); float32 [N, 3 + C]."""
-    r = cfg["point_cloud_range"]
-    c = cfg["voxel_encoder"]["in_channels"]
-    m = np.all((sweep[:, :3] >= np.array(r[:3], np.float32)) & (sweep[:, :3] <= np.array(r[3:], np.float32)), 1)
-    return np.ascontiguousarray(sweep[m][:, :c], np.float32)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -16,95 +16,9 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from synth_weights import encoder_dims, param_shapes, randlanet_state_dict as make_state_dict  # noqa: F401  (input generation)
+
 BN_EPS = 1e-6  # randlanet.py:77,499
-
-
-def encoder_dims(cfg):
-    """encoder_dim_list of randlanet.py:81-91."""
-    out = []
-    for i in range(cfg["num_layers"]):
-        d = 2 * cfg["dim_output"][i]
-        if i == 0:
-            out.append(d)
-        out.append(d)
-    return out
-
-
-def _conv(shapes, name, cin, cout, bn=True, transpose=False):
-    shapes[name + ".conv.weight"] = (cin, cout, 1, 1) if transpose else (cout, cin, 1, 1)
-    shapes[name + ".conv.bias"] = (cout,)
-    if bn:
-        _bn(shapes, name + ".batch_norm", cout)
-
-
-def _bn(shapes, name, c):
-    shapes[name + ".weight"] = (c,)
-    shapes[name + ".bias"] = (c,)
-    shapes[name + ".running_mean"] = (c,)
-    shapes[name + ".running_var"] = (c,)
-    shapes[name + ".num_batches_tracked"] = ()
-
-
-def param_shapes(cfg):
-    """state_dict keys/shapes of the reference RandLANet."""
-    s = OrderedDict()
-    s["fc0.weight"] = (cfg["dim_features"], cfg["in_channels"])
-    s["fc0.bias"] = (cfg["dim_features"],)
-    _bn(s, "bn0", cfg["dim_features"])
-    d_in = cfg["dim_features"]
-    for l in range(cfg["num_layers"]):
-        d = cfg["dim_output"][l]
-        p = "encoder.%d." % l
-        _conv(s, p + "mlp1", d_in, d // 2)
-        _conv(s, p + "lse1.mlp", 10, d // 2)
-        s[p + "pool1.score_fn.0.weight"] = (d, d)
-        s[p + "pool1.score_fn.0.bias"] = (d,)
-        _conv(s, p + "pool1.mlp", d, d // 2)
-        _conv(s, p + "lse2.mlp", d // 2, d // 2)
-        s[p + "pool2.score_fn.0.weight"] = (d, d)
-        s[p + "pool2.score_fn.0.bias"] = (d,)
-        _conv(s, p + "pool2.mlp", d, d)
-        _conv(s, p + "mlp2", d, 2 * d)
-        _conv(s, p + "shortcut", d_in, 2 * d)
-        d_in = 2 * d
-    _conv(s, "mlp", d_in, d_in)
-    ed = encoder_dims(cfg)
-    prev = d_in
-    for i in range(cfg["num_layers"]):
-        skip = ed[-i - 2]
-        _conv(s, "decoder.%d" % i, skip + prev, skip, transpose=True)
-        prev = skip
-    _conv(s, "fc1.0", prev, 64)
-    _conv(s, "fc1.1", 64, 32)
-    _conv(s, "fc1.3", 32, cfg["num_classes"], bn=False)
-    return s
-
-
-def make_state_dict(cfg, seed):
-    """Deterministic pseudo-trained weights (numpy Generator, independent of torch's RNG):
-    He-style conv/linear weights, non-trivial BatchNorm affine + running statistics."""
-    rng = np.random.default_rng(seed)
-    sd = OrderedDict()
-    for name, shape in param_shapes(cfg).items():
-        if name.endswith("num_batches_tracked"):
-            sd[name] = torch.tensor(100, dtype=torch.int64)
-            continue
-        if name.endswith("running_var"):
-            v = rng.uniform(0.5, 1.5, shape)
-        elif name.endswith("running_mean"):
-            v = rng.normal(0.0, 0.1, shape)
-        elif ".batch_norm.weight" in name or name == "bn0.weight":
-            v = rng.uniform(0.7, 1.3, shape)
-        elif name.endswith(".bias"):
-            v = rng.normal(0.0, 0.05, shape)
-        else:
-            if len(shape) == 4:
-                fan_in = shape[0] if name.startswith("decoder.") else shape[1]
-            else:
-                fan_in = shape[1]
-            v = rng.normal(0.0, 1.0, shape) * np.sqrt(1.2 / fan_in)
-        sd[name] = torch.from_numpy(np.asarray(v, np.float32).reshape(shape))
-    return sd
 
 
 # --------------------------------------------------------------------------------------------

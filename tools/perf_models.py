@@ -25,11 +25,11 @@ def timeit(fn, iters):
 
 
 def kpconv(iters, nspheres=4):
-    from oracle import kpconv_ref as K
+    import synth_weights as W
     from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
-    cfg = dict(K.TORONTO3D_CFG)
+    cfg = dict(W.TORONTO3D_CFG)
     m = KPFCNN(**cfg, device="cuda:0")
-    m.load_state_dict(K.make_state_dict(cfg, 1))
+    m.load_state_dict(W.kpconv_state_dict(cfg, 1))
     spheres = [synth_data.toronto3d_sphere(100 + i) for i in range(nspheres)]
     pts = torch.from_numpy(np.concatenate(spheres)).cuda()
     lens = [len(s) for s in spheres]
@@ -42,12 +42,12 @@ def kpconv(iters, nspheres=4):
 
 
 def pointpillars(iters, nframes=2):
-    from oracle import pointpillars_ref as P
+    import synth_weights as W
     from ml3d.torch.models.point_pillars import PointPillars
-    cfg = P.KITTI_CFG
+    cfg = W.POINTPILLARS_KITTI_CFG
     m = PointPillars(device="cuda:0", **cfg)
-    m.load_state_dict(P.make_state_dict(cfg, 1))
-    clouds = [torch.from_numpy(P.crop_for_cfg(synth_data.kitti_sweep(i), cfg)).cuda() for i in range(nframes)]
+    m.load_state_dict(W.pointpillars_state_dict(cfg, 1))
+    clouds = [torch.from_numpy(W.crop_for_cfg(synth_data.kitti_sweep(i), cfg)).cuda() for i in range(nframes)]
     t = timeit(lambda: m(clouds), iters)
     print("pointpillars: %d frames (%s pts): forward %.3f ms -> %.1f frames/s" %
           (nframes, [len(c) for c in clouds], t, nframes / t * 1e3))
