@@ -93,6 +93,9 @@ def main():
                     help="distinct synthetic frames generated per rank (tiled with seeded rigid transforms)")
     ap.add_argument("--workload", choices=["randlanet", "kpconv", "pointpillars"], default="randlanet",
                     help="randlanet = BASELINE.json configs[1] (the headline metric); the other two are configs[2] / [3]")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the neighbour pyramid and the forward of a batch back to back on one stream instead of "
+                         "overlapping batch i+1's pyramid with batch i's forward on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
     args = ap.parse_args()
@@ -124,7 +127,7 @@ def main():
         return out
 
     import synth_data
-    from ml3d.engine import RandLAInferenceEngine, make_trace
+    from ml3d.engine import PipelinedRandLAEngine, RandLAInferenceEngine, make_trace
 
     B, N = args.frames_per_step, CFG["num_points"]
     # ---- synthetic frames: distinct sweeps per rank, tiled by seeded z-rotations to fill the batch
@@ -140,7 +143,8 @@ def main():
             f = (f @ rot.T)[rng.permutation(N)]
         frames[b] = f
     sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
-    eng = RandLAInferenceEngine(CFG, sd, B, N, dev)
+    overlap = not args.no_overlap
+    eng = PipelinedRandLAEngine(CFG, sd, B, N, dev) if overlap else RandLAInferenceEngine(CFG, sd, B, N, dev)
     pts = torch.from_numpy(frames).to(dev)
     feats = pts.clone()   # in_channels = 3: features are the xyz themselves (randlanet.py:208-209)
     # predicted labels travel as uint8 (19 classes); two buffers so the gather of step i overlaps step i + 1
@@ -151,7 +155,12 @@ def main():
     step_no = [0]
 
     def one_step(knn_trace=None, fwd_trace=None):
-        scores = eng.step(pts, feats, knn_trace, fwd_trace)
+        if overlap:
+            scores = eng.submit(pts, feats, knn_trace, fwd_trace)
+            if world > 1:
+                torch.cuda.current_stream().wait_stream(eng.compute)
+        else:
+            scores = eng.step(pts, feats, knn_trace, fwd_trace)
         if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
             i = step_no[0] & 1
             step_no[0] += 1
@@ -161,6 +170,8 @@ def main():
             _, pending[i] = mdist.gather_predictions(labels[i], dst=0, out=recv[i], async_op=True)
 
     def drain():
+        if overlap:
+            eng.synchronize()
         for w in pending:
             if w is not None:
                 w.wait()
@@ -236,11 +247,12 @@ def main():
             a.record(); b.record()
             tags_f = [1000] + [8 * l + s for l in range(CFG["num_layers"]) for s in range(4)] + [1001] + \
                      [1100 + i for i in range(CFG["num_layers"])] + [1200, 1201, 1202]
+            e1 = eng.eng[0] if overlap else eng        # kernels timed one at a time, nothing else on the GPU
             for tg in tags_f:
-                eng.step(pts, feats, None, make_trace(tg, a, b)); torch.cuda.synchronize()
+                e1.step(pts, feats, None, make_trace(tg, a, b)); torch.cuda.synchronize()
                 bd["fwd:%d" % tg] = a.elapsed_time(b)
             for tg in [100 + l for l in range(CFG["num_layers"] + 1)] + list(range(2 * CFG["num_layers"])):
-                eng.step(pts, feats, make_trace(tg, a, b), None); torch.cuda.synchronize()
+                e1.step(pts, feats, make_trace(tg, a, b), None); torch.cuda.synchronize()
                 bd["knn:%d" % tg] = a.elapsed_time(b)
             out["breakdown_ms"] = bd
         if not args.no_cpu_baseline and world == 1:

@@ -76,6 +76,52 @@ class RandLAInferenceEngine:
             return self.forward(points, features, fwd_trace)
 
 
+class PipelinedRandLAEngine:
+    """Two engines in ping-pong on two HIP streams: the neighbour pyramid of batch i+1 (VALU-bound grid search)
+    runs on the search stream while the forward of batch i (MFMA / LDS-bound) runs on the compute stream, so the
+    two kinds of kernels share the CUs.  Every batch still gets its own pyramid and its own forward; only the
+    ORDER of independent work changes.  ``submit`` returns the scores tensor of that batch, valid once the
+    compute stream (``self.compute``) has been synchronised or waited for."""
+
+    def __init__(self, cfg, state_dict, batch, num_points, device):
+        self.eng = [RandLAInferenceEngine(cfg, state_dict, batch, num_points, device) for _ in range(2)]
+        self.eng[1].params = self.eng[0].params            # one weight replica
+        self.device = self.eng[0].device
+        with torch.cuda.device(self.device):
+            self.search = torch.cuda.Stream()
+            self.compute = torch.cuda.Stream()
+            self.knn_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.fwd_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.i = 0
+        self.n = self.eng[0].n
+
+    def submit(self, points, features, knn_trace=None, fwd_trace=None):
+        e = self.eng[self.i & 1]
+        slot = self.i & 1
+        self.i += 1
+        e._check(points, features)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            self.search.wait_stream(cur)          # inputs were produced on the caller's stream
+            self.compute.wait_stream(cur)
+            points.record_stream(self.search)     # ... and must outlive the side-stream kernels that read them
+            points.record_stream(self.compute)
+            features.record_stream(self.compute)
+            with torch.cuda.stream(self.search):
+                self.search.wait_event(self.fwd_done[slot])      # the forward that last read these index buffers
+                e.neighbors(points, knn_trace)
+                self.knn_done[slot].record(self.search)
+            with torch.cuda.stream(self.compute):
+                self.compute.wait_event(self.knn_done[slot])
+                out = e.forward(points, features, fwd_trace)
+                self.fwd_done[slot].record(self.compute)
+        return out
+
+    def synchronize(self):
+        self.search.synchronize()
+        self.compute.synchronize()
+
+
 def make_trace(tag, ev_start, ev_stop):
     """Trace record from two ``torch.cuda.Event(enable_timing=True)`` objects (must be created on
     the current device; ``.record()`` once beforehand materialises the underlying hipEvent_t)."""
