@@ -580,7 +580,7 @@ constexpr int A16_TP = 16;           // points per tile (256 rows = 256 threads)
 constexpr int A16_XP = 20;           // X row pitch
 
 template <int STAGE>
-__global__ void __launch_bounds__(256) lfa_attn_mfma16(LfaArgs A) {
+__global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
     constexpr int D = 16, H = 8;
     __shared__ __attribute__((aligned(16))) float X[A16_TP * RK * A16_XP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
