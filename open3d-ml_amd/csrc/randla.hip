@@ -365,6 +365,10 @@ struct MfmaCfg {
     static constexpr int RG2 = WAVES / NT2;
     static constexpr int XP = D + 4;                         // LDS row pitch of X
     static constexpr int RP = H + 4;                         // LDS row pitch of R1
+    // H <= 32: one wave owns all H columns of its row tile, so lse2 can run IN PLACE on X[:, H:] (its A operand is
+    // in registers before its result is stored) and the separate R1 tile (ROWS x RP floats of LDS) disappears:
+    // 60 -> 41 KB per workgroup at D = 64, i.e. three resident workgroups per CU instead of two
+    static constexpr bool INPLACE = NT2 == 1;
 };
 
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -385,13 +389,13 @@ __device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/
 }
 
 template <int D, int STAGE, int TPS>
-__global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaArgs A) {
+__global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D, TPS>::THREADS / 256))) lfa_attn_mfma(LfaArgs A) {
     using C = MfmaCfg<D, TPS>;
     constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
     HIP_DYNAMIC_SHARED(float, smem)
     float* X = smem;                                              // [ROWS][XP]
-    float* R1 = X + ROWS * XP;                                    // [ROWS][RP]   (stage 2)
-    float* REL = R1 + (STAGE == 2 ? ROWS * RP : 0);               // [ROWS][12]
+    float* R1 = X + ROWS * XP;                                    // [ROWS][RP]   (stage 2, unless in place)
+    float* REL = R1 + ((STAGE == 2 && !C::INPLACE) ? ROWS * RP : 0);   // [ROWS][12]
     int* NROW = reinterpret_cast<int*>(REL + ROWS * 12);          // [ROWS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + mfma_row(r, hi);
                     const float v = lrelu(acc[r], 0.2f);
-                    if (STAGE == 1) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
+                    if (STAGE == 1 || C::INPLACE) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
                 }
             }
         }
@@ -492,7 +496,8 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = l2bias;
-                acc = mfma_rows<H, RP>(R1 + (rt * 32 + col) * RP + hi * (H / 2), b2, acc);
+                if constexpr (C::INPLACE) acc = mfma_rows<H, XP>(X + (rt * 32 + col) * XP + H + hi * (H / 2), b2, acc);
+                else acc = mfma_rows<H, RP>(R1 + (rt * 32 + col) * RP + hi * (H / 2), b2, acc);
                 if (col2 < H) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -536,7 +541,7 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS)) lfa_attn_mfma(LfaA
 template <int D, int STAGE, int TPS>
 static size_t mfma_smem_bytes() {
     using C = MfmaCfg<D, TPS>;
-    return ((size_t)C::ROWS * C::XP + (STAGE == 2 ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
+    return ((size_t)C::ROWS * C::XP + ((STAGE == 2 && !C::INPLACE) ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
            (size_t)C::ROWS * 4;
 }
 
