@@ -349,16 +349,14 @@ __global__ void __launch_bounds__(LFA_THREADS) lfa_stage(LfaArgs A) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int D, int TPS = 0>
+template <int D>
 struct MfmaCfg {
     static constexpr int H = D / 2;
     static constexpr int NT = D / 32;                        // score column tiles
     static constexpr int NT2 = (H + 31) / 32;                // lse2 column tiles
     static constexpr int WAVES = NT > 4 ? NT : 4;
     static constexpr int THREADS = WAVES * 64;
-    // points per tile; TPS = 1: half-size tiles -> half the LDS per workgroup -> twice the resident workgroups,
-    // whose gather / VALU / MFMA phases then overlap on a CU
-    static constexpr int TP = TPS ? (D <= 64 ? 4 : 2) : (D <= 64 ? 8 : (D == 128 ? 4 : 2));
+    static constexpr int TP = D <= 64 ? 8 : (D == 128 ? 4 : 2);   // points per tile (half-size tiles measured slower)
     static constexpr int ROWS = TP * RK;
     static constexpr int RT = ROWS / 32;                     // 32-row MFMA tiles
     static constexpr int RG = WAVES / NT;                    // waves sharing a column tile take different row tiles
@@ -388,9 +386,9 @@ __device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/
     return acc;
 }
 
-template <int D, int STAGE, int TPS>
-__global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D, TPS>::THREADS / 256))) lfa_attn_mfma(LfaArgs A) {
-    using C = MfmaCfg<D, TPS>;
+template <int D, int STAGE>
+__global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D>::THREADS / 256))) lfa_attn_mfma(LfaArgs A) {
+    using C = MfmaCfg<D>;
     constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
     HIP_DYNAMIC_SHARED(float, smem)
     float* X = smem;                                              // [ROWS][XP]
@@ -538,35 +536,29 @@ __global__ void __launch_bounds__((MfmaCfg<D, TPS>::THREADS), (D <= 64 ? 3 : (Mf
     }
 }
 
-template <int D, int STAGE, int TPS>
+template <int D, int STAGE>
 static size_t mfma_smem_bytes() {
-    using C = MfmaCfg<D, TPS>;
+    using C = MfmaCfg<D>;
     return ((size_t)C::ROWS * C::XP + ((STAGE == 2 && !C::INPLACE) ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
            (size_t)C::ROWS * 4;
 }
 
 // launches the attention part of one stage; `a.out` receives agg [m, D]
-template <int D, int STAGE, int TPS>
-static int launch_attn_mfma_t(LfaArgs a, hipStream_t st, int grid_cap) {
-    using C = MfmaCfg<D, TPS>;
+template <int D, int STAGE>
+static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
+    using C = MfmaCfg<D>;
+    static const int grid_cap = getenv("ML3D_ATTN_GRID") ? atoi(getenv("ML3D_ATTN_GRID")) : 2560;   // tuning knob
     int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
     unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
     static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    size_t sm = mfma_smem_bytes<D, STAGE, TPS>();
+    size_t sm = mfma_smem_bytes<D, STAGE>();
     if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE, TPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
         return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE, TPS>), dim3(grid), dim3(C::THREADS), sm, st, a);
+    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-}
-
-template <int D, int STAGE>
-static int launch_attn_mfma(const LfaArgs& a, hipStream_t st) {
-    static const int tps = getenv("ML3D_ATTN_TPS") ? atoi(getenv("ML3D_ATTN_TPS")) : 0;      // tuning knobs
-    static const int cap = getenv("ML3D_ATTN_GRID") ? atoi(getenv("ML3D_ATTN_GRID")) : 2560;
-    return tps ? launch_attn_mfma_t<D, STAGE, 1>(a, st, cap) : launch_attn_mfma_t<D, STAGE, 0>(a, st, cap);
 }
 
 
