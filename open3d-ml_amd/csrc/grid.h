@@ -98,6 +98,26 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// the same rendezvous for LDS traffic ONLY: a wave's LDS instructions execute in issue order, so a ds_write is
+// visible to a later ds_read of any lane of the same wave without draining the memory counters -- outstanding
+// global loads (prefetches) and stores stay in flight across it.  (wave_sync's workgroup fence waits vmcnt(0).)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full workgroup fence: it drains vmcnt too,
+// i.e. every wave sits at the barrier until its outstanding global loads have landed and its global stores are
+// acknowledged.  Kernels whose cross-wave communication is all in LDS use this one instead, so prefetches and
+// output stores stay in flight across the barrier.
+__device__ __forceinline__ void block_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 inline GridView grid_view(const GridWs& ws) {
     GridView v;
     v.segs = ws.segs;

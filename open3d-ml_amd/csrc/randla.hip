@@ -349,6 +349,12 @@ __global__ void __launch_bounds__(LFA_THREADS) lfa_stage(LfaArgs A) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef ML3D_ATTN_FULLSYNC
+#define SYNC_ATTN() __syncthreads()
+#else
+#define SYNC_ATTN() block_sync_lds()
+#endif
+
 template <int D>
 struct MfmaCfg {
     static constexpr int H = D / 2;
@@ -383,6 +389,9 @@ __device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * s4 + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * s4 + 3], acc, 0, 0, 0);
     }
+#ifdef ML3D_ATTN_IGLP
+    __builtin_amdgcn_iglp_opt(0);
+#endif
     return acc;
 }
 
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             }
             r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
         }
-        __syncthreads();
+        SYNC_ATTN();
         // ---- P2a: gather neighbour feature rows (16-byte bursts) -> X[:, 0:H] ---------------------
         for (int e = tid; e < ROWS * (H / 4); e += THREADS) {
             int row = e / (H / 4), q = e % (H / 4);
@@ -487,7 +496,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                 }
             }
         }
-        __syncthreads();
+        SYNC_ATTN();
         if constexpr (STAGE == 2) {
             // ---- P2c: r2 = lrelu(lse2(r1)) on MFMA -> X[:, H:] -------------------------------------
             for (int rt = rg2; rt < C::RT; rt += C::RG2) {
@@ -502,15 +511,22 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                         X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu(acc[r], 0.2f);
                 }
             }
-            __syncthreads();
+            SYNC_ATTN();
         }
         // ---- P3: scores on MFMA, softmax over the 16 neighbours, weighted sum ----------------------
         for (int rt = rg; rt < C::RT; rt += C::RG) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias;
-            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
             const float* xc = X + (rt * 32) * XP + ct * 32 + col;
+#ifdef ML3D_ATTN_XV
+            // the lane's 16 feature values for the weighted sum are independent of the scores: request them
+            // up front so their LDS latency runs under the MFMA chain
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = xc[mfma_row(r, hi) * XP];
+#endif
+            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
             float agg_mine = 0.f;
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
@@ -523,7 +539,11 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                 for (int r = 0; r < 8; ++r) {
                     float e = __expf(acc[8 * pt + r] - mx);
                     sum += e;
+#ifdef ML3D_ATTN_XV
+                    ag = fmaf(e, xv[8 * pt + r], ag);
+#else
                     ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
+#endif
                 }
                 sum += __shfl_xor(sum, 32);
                 ag += __shfl_xor(ag, 32);
@@ -532,7 +552,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
             if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
         }
-        __syncthreads();
+        SYNC_ATTN();
     }
 }
 
@@ -641,7 +661,7 @@ __global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) dst[q4] = make_float4(xr[4 * q4], xr[4 * q4 + 1], xr[4 * q4 + 2], xr[4 * q4 + 3]);
         }
-        __syncthreads();
+        SYNC_ATTN();
         // ---- MFMA: wave w owns points 4w .. 4w+3 of the tile ------------------------------------------
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
@@ -668,7 +688,7 @@ __global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
             const int64_t m = m_base + p;
             if (g == 0 && m < A.m_total) A.out[m * D + col] = ag / sum;
         }
-        __syncthreads();
+        SYNC_ATTN();
     }
 }
 
@@ -839,6 +859,233 @@ static int launch_chain(ChainArgs a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// mlp_wave — narrow per-point MLP chains (layer inputs <= 96 wide, hidden outputs <= 64, all weights
+// <= 20k floats: fc1 32->64->32->19, pool2 + (mlp2 | shortcut) of the first two encoder layers) with
+// NO workgroup barrier in the row loop.  All layers' weights (zero-padded to 32-column tiles) sit in
+// LDS for the whole persistent kernel; each WAVE owns 32-row tiles end to end: its input rows go
+// HBM -> registers (requested one tile ahead) -> a wave-private LDS patch, every layer's MFMAs read A
+// from the patch (ds_read_b128) and B from the weight image, a layer's 32 x N result goes to the
+// wave's second patch (plus the `cat` columns of the next layer), and only the last layer's rows
+// are written to HBM.  K loops are runtime loops over LDS, so the kernel stays at a few dozen VGPRs
+// and many waves per SIMD hide each other's latencies.
+// ------------------------------------------------------------------------------------------------
+struct WaveMlpMeta {                         // host-computed LDS layout (floats)
+    int w_off[CH_MAX], npad[CH_MAX], b_off[CH_MAX];
+    int patch_off;                           // per wave: [32][pit0] then [32][pit1]
+    int pit0, pit1;
+    int total;
+};
+
+// one 32x32 output tile's K loop with compile-time trip count and weight pitch (mlp_wave)
+template <int KH, int NP>
+__device__ __forceinline__ f32x16 wave_k_loop(const float* __restrict__ arow, const float* __restrict__ Bc, f32x16 acc) {
+#pragma unroll
+    for (int s4 = 0; s4 < KH; s4 += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + s4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Bc[(s4 + 0) * NP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Bc[(s4 + 1) * NP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, Bc[(s4 + 2) * NP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, Bc[(s4 + 3) * NP], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_iglp_opt(0);
+    return acc;
+}
+
+template <int PRE>                           // float4 loads per lane for one tile of first-layer input rows
+__global__ void __launch_bounds__(256, 2) mlp_wave(ChainArgs A, WaveMlpMeta M) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    for (int l = 0; l < A.n_layers; ++l) {
+        const ChainLayer Ly = A.L[l];
+        const int np = M.npad[l];
+#pragma unroll 8
+        for (int e = tid; e < Ly.cin * np; e += 256) {
+            const int k = e / np, c = e - k * np;
+            smem[M.w_off[l] + e] = c < Ly.cout ? Ly.wt[(int64_t)k * Ly.cout + c] : 0.f;
+        }
+        for (int c = tid; c < np; c += 256) {
+            float b = 0.f;
+            if (c < Ly.cout) { b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
+            smem[M.b_off[l] + c] = b;
+        }
+    }
+    __syncthreads();
+    float* P0 = smem + M.patch_off + wave * 32 * (M.pit0 + M.pit1);
+    float* P1 = P0 + 32 * M.pit0;
+    const int64_t tiles = (A.m_total + 31) / 32;
+    const int64_t t_step = (int64_t)gridDim.x * 4;
+    const int K0 = A.L[0].cin, Q0 = K0 >> 2;            // float4 pieces per row
+
+    float4 pre[PRE];
+    auto fetch0 = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = lane + 64 * i;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 32 * Q0) {
+                const int r = e / Q0, k = (e - r * Q0) * 4;
+                const int64_t m = t * 32 + r;
+                if (m < A.m_total) {
+                    if (k < A.c0) pre[i] = *reinterpret_cast<const float4*>(A.a0 + m * A.c0 + k);
+                    else {
+                        int64_t grow = m;
+                        if (A.gather) grow = (m / A.rows_per_item) * A.a1_rows_per_item + A.gather[m];
+                        pre[i] = *reinterpret_cast<const float4*>(A.a1 + grow * A.c1 + (k - A.c0));
+                    }
+                }
+            }
+        }
+    };
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t < tiles) fetch0(t);
+    for (; t < tiles; t += t_step) {
+        // ---- this tile's input rows: registers -> patch 0; next tile's rows requested ---------------------
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = lane + 64 * i;
+            if (e < 32 * Q0) {
+                const int r = e / Q0, k = (e - r * Q0) * 4;
+                *reinterpret_cast<float4*>(P0 + r * M.pit0 + k) = pre[i];
+            }
+        }
+        if (t + t_step < tiles) fetch0(t + t_step);
+        wave_lds_sync();
+        const int64_t m_row0 = t * 32;
+        for (int l = 0; l < A.n_layers; ++l) {
+            const ChainLayer Ly = A.L[l];
+            const float* in = (l & 1) ? P1 : P0;
+            float* outp = (l & 1) ? P0 : P1;
+            const int pin = (l & 1) ? M.pit1 : M.pit0, pout = (l & 1) ? M.pit0 : M.pit1;
+            const int KH = Ly.cin >> 1, np = M.npad[l];
+            const bool last = l == A.n_layers - 1;
+            const float* arow = in + cl * pin + hi * KH;
+            const float* W = smem + M.w_off[l] + (hi * KH) * np + cl;
+            for (int ct = 0; ct * 32 < np; ++ct) {
+                f32x16 acc;
+                const float b = smem[M.b_off[l] + ct * 32 + cl];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = b;
+                const float* Bc = W + ct * 32;
+                // the shapes of the shipped configs get fully unrolled K loops (straight-line code lets the scheduler
+                // run the LDS reads ahead of the MFMAs); anything else takes the runtime loop
+                switch (KH * 1024 + np) {
+                    case 8 * 1024 + 32: acc = wave_k_loop<8, 32>(arow, Bc, acc); break;
+                    case 12 * 1024 + 32: acc = wave_k_loop<12, 32>(arow, Bc, acc); break;
+                    case 16 * 1024 + 32: acc = wave_k_loop<16, 32>(arow, Bc, acc); break;
+                    case 16 * 1024 + 64: acc = wave_k_loop<16, 64>(arow, Bc, acc); break;
+                    case 32 * 1024 + 32: acc = wave_k_loop<32, 32>(arow, Bc, acc); break;
+                    case 32 * 1024 + 64: acc = wave_k_loop<32, 64>(arow, Bc, acc); break;
+                    case 48 * 1024 + 128: acc = wave_k_loop<48, 128>(arow, Bc, acc); break;
+                    default:
+                        for (int s4 = 0; s4 < KH; s4 += 4) {
+                            const float4 a = *reinterpret_cast<const float4*>(arow + s4);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Bc[(s4 + 0) * np], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Bc[(s4 + 1) * np], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, Bc[(s4 + 2) * np], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, Bc[(s4 + 3) * np], acc, 0, 0, 0);
+                        }
+                }
+                const int col = ct * 32 + cl;
+                if (col < Ly.cout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mfma_row(r, hi);
+                        float v = acc[r];
+                        if (Ly.act) v = lrelu(v, Ly.slope);
+                        if (last) {
+                            const int64_t m = m_row0 + row;
+                            if (m < A.m_total) A.out[m * Ly.cout + col] = v;
+                        } else {
+                            outp[row * pout + col] = v;
+                        }
+                    }
+                }
+            }
+            if (!last) {
+                if (A.cat && l + 1 == A.cat_layer) {            // the next layer's extra input columns
+                    const int qc = A.cat_c >> 2;
+                    for (int e = lane; e < 32 * qc; e += 64) {
+                        const int r = e / qc, k = (e - r * qc) * 4;
+                        const int64_t m = m_row0 + r;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < A.m_total) v = *reinterpret_cast<const float4*>(A.cat + m * A.cat_c + k);
+                        *reinterpret_cast<float4*>(outp + r * pout + Ly.cout + k) = v;
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+        wave_lds_sync();          // patch 0 is rewritten at the top of the next tile
+    }
+}
+
+static bool wave_mlp_supported(const ChainArgs& a, WaveMlpMeta* M, int* pre) {
+    if (!chain_supported(a)) return false;
+    int off = 0, w0 = 0, w1 = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const ChainLayer& Ly = a.L[l];
+        if (Ly.cin > 96 || Ly.cout > 128) return false;
+        if (l + 1 < a.n_layers && Ly.cout > 64) return false;
+        int& wd = (l & 1) ? w1 : w0;
+        wd = Ly.cin > wd ? Ly.cin : wd;
+        M->npad[l] = (Ly.cout + 31) & ~31;
+        M->w_off[l] = off; off += Ly.cin * M->npad[l];
+        M->b_off[l] = off; off += M->npad[l];
+    }
+    for (int l = a.n_layers; l < CH_MAX; ++l) { M->npad[l] = 0; M->w_off[l] = 0; M->b_off[l] = 0; }
+    if (off > 20 * 1024) return false;
+    M->pit0 = w0 + 4;
+    M->pit1 = (w1 > 0 ? w1 : 4) + 4;
+    M->patch_off = (off + 3) & ~3;
+    M->total = M->patch_off + 4 * 32 * (M->pit0 + M->pit1);
+    const int need = (32 * (a.L[0].cin / 4) + 63) / 64;
+    *pre = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 12));
+    return need <= 12;
+}
+
+static int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        cus = 256;
+    return cus;
+}
+
+template <int PRE>
+static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream_t st) {
+    const size_t sm = sizeof(float) * (size_t)M.total;
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)mlp_wave<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    const int64_t tiles = (a.m_total + 31) / 32;
+    // persistent: exactly the resident workgroups, so the weight image is staged once per CU slot
+    static const int cus = device_cu_count();
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)mlp_wave<PRE>, 256, sm) != hipSuccess || occ < 1) occ = 1;
+    static const int cap_env = getenv("ML3D_WAVE_MLP_GRID") ? atoi(getenv("ML3D_WAVE_MLP_GRID")) : 0;
+    const int64_t cap = cap_env > 0 ? cap_env : (int64_t)occ * cus;
+    const unsigned grid = (unsigned)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
+    hipLaunchKernelGGL((mlp_wave<PRE>), dim3(grid), dim3(256), sm, st, a, M);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+// multi-layer chains: the barrier-free per-wave kernel when the layers are narrow, the tile kernel otherwise
+static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
+    static const bool on = !(getenv("ML3D_RANDLA_WAVE_MLP") && getenv("ML3D_RANDLA_WAVE_MLP")[0] == '0');
+    WaveMlpMeta M;
+    int pre = 0;
+    if (a.m_total > 0 && on && wave_mlp_supported(a, &M, &pre)) {
+        if (pre == 2) return launch_wave_mlp_t<2>(a, M, st);
+        if (pre == 4) return launch_wave_mlp_t<4>(a, M, st);
+        if (pre == 8) return launch_wave_mlp_t<8>(a, M, st);
+        return launch_wave_mlp_t<12>(a, M, st);
+    }
+    return launch_chain(a, st);
+}
 
 // one Linear described by LinArgs: MFMA chain kernel when the shapes allow, VALU kernel otherwise
 static int launch_linear_auto(const LinArgs& a, hipStream_t st);
@@ -1146,7 +1393,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             ch.L[1].cin = dd + d_in; ch.L[1].cout = 2 * dd; ch.L[1].act = 1; ch.L[1].slope = 0.01f;
             ch.out = enc; ch.m_total = M;
             if (!no_fuse && M >= fuse_rows && chain_supported(ch)) {
-                T.begin(8 * l + 5); rc = launch_chain(ch, st); T.end(8 * l + 5); if (rc) return rc;
+                T.begin(8 * l + 5); rc = launch_chain_auto(ch, st); T.end(8 * l + 5); if (rc) return rc;
             } else {
                 {
                     LinArgs a = {};
@@ -1231,7 +1478,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         ch.out = out_scores; ch.m_total = B * n[0];
         if (!no_fuse && !force_valu && chain_supported(ch)) {
             // fc1.0 -> fc1.1 -> fc1.3 back to back: the 64- and 32-wide activations never leave LDS
-            T.begin(1200); int rc = launch_chain(ch, st); T.end(1200); if (rc) return rc;
+            T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200); if (rc) return rc;
         } else {
             T.begin(1200); int rc = launch_linear_auto(a, st); T.end(1200); if (rc) return rc;
             a.a0 = t0; a.c0 = 64; a.wt = P(slot + 2); a.bias = P(slot + 3); a.out = t1; a.cout = 32;

@@ -72,6 +72,11 @@ typedef void* hipEvent_t;
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+// the emulated device: 4 CUs, 2 resident workgroups each (keeps persistent kernels multi-tile per wave in tests)
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return 0; }
 
 namespace hipemu {
 
@@ -169,6 +174,7 @@ void trace(const char* name);
     (hipemu::trace(#kernel), hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); }))
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
@@ -214,6 +220,11 @@ static inline unsigned long long __ballot(int pred) {
         if (vw.peer_valid(l)) { int q; memcpy(&q, vw.peer(l), sizeof(int)); if (q) m |= (1ull << l); }
     return m;
 }
+static inline void __builtin_amdgcn_fence(int, const char*) {}
+static inline void __builtin_amdgcn_fence(int, const char*, const char*) {}
+static inline void __builtin_amdgcn_iglp_opt(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_wave_barrier() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
 static inline int __any(int pred) { return __ballot(pred) != 0ull; }
 static inline int __all(int pred) {
