@@ -31,6 +31,9 @@ constexpr int XROW = 20;      // LDS row pitch of the K-slab: 16 + 4 pad floats 
 constexpr int LFA_THREADS = 256;
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// the same value in two instructions (v_mul, v_max) when 0 < slope < 1: max(v, slope * v) picks v for v > 0
+// (v_med3 with +inf as the third operand = max without fmaxf's operand canonicalisation)
+__device__ __forceinline__ float lrelu_max(float v, float slope) { return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff()); }
 
 // ------------------------------------------------------------------------------------------------
 // generic per-point linear layer with optional [a0 | a1[gather]] concat input
@@ -349,6 +352,14 @@ __global__ void __launch_bounds__(LFA_THREADS) lfa_stage(LfaArgs A) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+static int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        cus = 256;
+    return cus;
+}
+
 #ifdef ML3D_ATTN_FULLSYNC
 #define SYNC_ATTN() __syncthreads()
 #else
@@ -563,6 +574,510 @@ static size_t mfma_smem_bytes() {
            (size_t)C::ROWS * 4;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// lfa_attn_pf — the same attention stage with the NEXT tile's global traffic in flight under the
+// current tile's MFMA phases.  A tile needs three dependent global hops (neighbour index -> neighbour
+// xyz / neighbour feature row); in lfa_attn_mfma every workgroup sits through them at the top of each
+// tile (~3.5 us of a ~12 us tile).  Here each thread owns, across tiles, the same slots of the tile's
+// inputs: G float4 pieces of the gathered feature rows and (threads < ROWS) one (point, neighbour) row of
+// relative positions.  Schedule per tile t:
+//     registers -> LDS: X[:, 0:H] <- feature pieces, REL <- relative positions          (loads of t landed)
+//     request the neighbour indices of t+1                                             (hop 1)
+//     barrier; lse1 [; lse2]                                                           (MFMA)
+//     request xyz + feature pieces of t+1 through those indices                        (hops 2, 3)
+//     barrier; scores, softmax, weighted sum (the long MFMA phase); barrier
+// The barriers are block_sync_lds (LDS only), so the requests stay in flight across them.  lse1/lse2
+// weights move from registers to LDS (B operand by ds_read) to make room for the in-flight registers,
+// and with lse2 in place (H <= 32) the lse1 -> lse2 hand-off is inside one wave: 3 barriers per tile.
+// ------------------------------------------------------------------------------------------------
+template <int D, int STAGE>
+__global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D>::THREADS / 256))) lfa_attn_pf(LfaArgs A) {
+    using C = MfmaCfg<D>;
+    constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
+    constexpr int HP = C::NT2 * 32;                               // lse weight pitch (column tiles, zero padded)
+    constexpr int Q = H / 4;                                      // float4 pieces per gathered row
+    constexpr int G = ROWS * Q / THREADS;                         // pieces per thread
+    static_assert(ROWS * Q % THREADS == 0 && ROWS <= THREADS, "tile shape");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* X = smem;                                              // [ROWS][XP]
+    float* R1 = X + ROWS * XP;                                    // [ROWS][RP]   (stage 2, unless in place)
+    float* REL = R1 + ((STAGE == 2 && !C::INPLACE) ? ROWS * RP : 0);   // [ROWS][12]
+    float* W1 = REL + ROWS * 12;                                  // [12][HP]
+    float* W2 = W1 + 12 * HP;                                     // [H][HP]      (stage 2)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+
+    const int ct = wave % C::NT, rg = wave / C::NT;
+    float bs[D / 2];
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) bs[s] = A.score_wt[(hi * (D / 2) + s) * D + ct * 32 + col];
+    const float sbias = A.score_b[ct * 32 + col];
+    const int ct2 = wave % C::NT2, rg2 = wave / C::NT2;
+    const int col2 = ct2 * 32 + col;
+    for (int e = tid; e < 12 * HP; e += THREADS) {
+        const int k = e / HP, c = e - k * HP;
+        W1[e] = (k < 10 && c < H) ? A.lse1_wt[k * H + c] : 0.f;
+    }
+    float l2bias = 0.f;
+    if constexpr (STAGE == 2) {
+        for (int e = tid; e < H * HP; e += THREADS) {
+            const int k = e / HP, c = e - k * HP;
+            W2[e] = c < H ? A.lse2_wt[k * H + c] : 0.f;
+        }
+        l2bias = col2 < H ? A.lse2_b[col2] : 0.f;
+    }
+    const float b1 = col2 < H ? A.lse1_b[col2] : 0.f;
+
+    const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
+    const bool xw = A.xcd_chunk > 0;
+    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+    int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    auto next_tile = [&]() -> int64_t {
+        for (;;) {
+            int64_t t = wi;
+            if (xw) t = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
+            wi += w_step;
+            if (t < 0) return -1;
+            if (t < tiles) return t;
+            if (!xw) return -1;
+        }
+    };
+
+    // ---- this thread's slots of a tile's inputs ---------------------------------------------------
+    int gi[G], nb_mine = 0;              // hop 1: neighbour rows (item-local)
+    float4 gq[G];                        // hop 3: gathered feature pieces
+    float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;   // hop 2
+    bool mine_valid = false;
+    auto request_idx = [&](int64_t tile) {
+        const int32_t* nb = A.nidx + tile * C::TP * RK;            // the tile's (point, neighbour) rows are contiguous
+        const int64_t lim = (A.m_total - tile * C::TP) * RK;       // rows of the tile that exist
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int row = (tid + i * THREADS) / Q;
+            gi[i] = row < lim ? nb[row] : -1;
+        }
+        if (tid < ROWS) nb_mine = tid < lim ? nb[tid] : -1;
+    };
+    auto request_data = [&](int64_t tile) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = tid + i * THREADS;
+            const int row = e / Q, q = e - row * Q;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef ABL_NOLOAD
+            if (false) {
+#else
+            if (gi[i] >= 0) {
+#endif
+                const int64_t m = tile * C::TP + row / RK;
+                const int64_t b = m / A.n;
+                gq[i] = *reinterpret_cast<const float4*>(A.gfeat + (b * A.n + gi[i]) * H + 4 * q);
+            }
+        }
+        if (tid < ROWS) {
+            mine_valid = nb_mine >= 0;
+#ifdef ABL_NOLOAD
+            if (false) {
+#else
+            if (mine_valid) {
+#endif
+                const int64_t m = tile * C::TP + tid / RK;
+                const int64_t b = m / A.n, nl = m - b * A.n;
+                const float* qp = A.xyz + 3 * (b * A.n0 + nl);
+                const float* sp = A.xyz + 3 * (b * A.n0 + nb_mine);
+                qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
+            }
+        }
+    };
+
+    int64_t cur = next_tile();
+    if (cur >= 0) { request_idx(cur); request_data(cur); }
+    block_sync_lds();                                            // W1 / W2 staged
+    while (cur >= 0) {
+        const int64_t nxt = next_tile();
+        const int64_t m_base = cur * C::TP;
+        // ---- registers -> LDS -----------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = tid + i * THREADS;
+            const int row = e / Q, q = e - row * Q;
+            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = gq[i];
+        }
+        if (tid < ROWS) {
+            float* r = REL + tid * 12;
+            if (mine_valid) {
+                const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) r[j] = 0.f;
+            }
+            r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
+        }
+        if (nxt >= 0) request_idx(nxt);
+        block_sync_lds();
+        // ---- r1 = lrelu(lse1(rel)) on MFMA (K = 12) -> X[:, H:] (stage 1 / in place) or R1 -----------------
+        for (int rt = rg2; rt < C::RT; rt += C::RG2) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = b1;
+            const float* ar = REL + (rt * 32 + col) * 12 + hi * 6;
+            const float* wb = W1 + hi * 6 * HP + col2;
+            const float2 a01 = *reinterpret_cast<const float2*>(ar);
+            const float2 a23 = *reinterpret_cast<const float2*>(ar + 2);
+            const float2 a45 = *reinterpret_cast<const float2*>(ar + 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, wb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, wb[HP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, wb[2 * HP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, wb[3 * HP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, wb[4 * HP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, wb[5 * HP], acc, 0, 0, 0);
+            if (col2 < H) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + mfma_row(r, hi);
+                    const float v = lrelu(acc[r], 0.2f);
+                    if (STAGE == 1 || C::INPLACE) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
+                }
+            }
+        }
+        if constexpr (STAGE == 2) {
+            // in place the row tile's r1 was written by this very wave; otherwise other waves' columns are needed
+            if constexpr (C::INPLACE) wave_lds_sync(); else block_sync_lds();
+            // ---- r2 = lrelu(lse2(r1)) on MFMA -> X[:, H:] ------------------------------------------------
+            for (int rt = rg2; rt < C::RT; rt += C::RG2) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = l2bias;
+                const float* ar = C::INPLACE ? X + (rt * 32 + col) * XP + H + hi * (H / 2)
+                                             : R1 + (rt * 32 + col) * RP + hi * (H / 2);
+                const float* wb = W2 + hi * (H / 2) * HP + col2;
+#pragma unroll
+                for (int s4 = 0; s4 < H / 8; ++s4) {
+                    const float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wb[(4 * s4 + 0) * HP], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wb[(4 * s4 + 1) * HP], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wb[(4 * s4 + 2) * HP], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wb[(4 * s4 + 3) * HP], acc, 0, 0, 0);
+                }
+                if (col2 < H) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu(acc[r], 0.2f);
+                }
+            }
+        }
+        if (nxt >= 0) request_data(nxt);
+        block_sync_lds();
+        // ---- scores on MFMA, softmax over the 16 neighbours, weighted sum ------------------------------
+        for (int rt = rg; rt < C::RT; rt += C::RG) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = sbias;
+#ifndef ABL_NOMFMA3
+            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
+#endif
+            const float* xc = X + (rt * 32) * XP + ct * 32 + col;
+            float agg_mine = 0.f;
+#ifdef ABL_NOSOFTMAX
+            agg_mine = acc[0] + acc[8] + xc[0];
+#else
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                float mx = acc[8 * pt];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[8 * pt + r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f, ag = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float e = __expf(acc[8 * pt + r] - mx);
+                    sum += e;
+                    ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
+                }
+                sum += __shfl_xor(sum, 32);
+                ag += __shfl_xor(ag, 32);
+                if (pt == hi) agg_mine = ag / sum;
+            }
+#endif
+            int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
+            if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
+        }
+        block_sync_lds();
+        cur = nxt;
+    }
+}
+
+template <int D, int STAGE>
+static size_t pf_smem_bytes() {
+    using C = MfmaCfg<D>;
+    constexpr int HP = C::NT2 * 32;
+    return ((size_t)C::ROWS * C::XP + ((STAGE == 2 && !C::INPLACE) ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12 +
+            12 * HP + (STAGE == 2 ? (size_t)C::H * HP : 0)) * 4;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// lfa_attn_wave (D <= 64) — the attention stage with NO workgroup barrier in the tile loop.
+// In lfa_attn_mfma / lfa_attn_pf a workgroup's waves split the column tiles of one 128-row tile, so
+// they meet at 3-4 barriers per tile; with one wave of each resident workgroup per SIMD, any wave that
+// queues behind another workgroup's MFMAs stalls its three siblings on the other SIMDs (measured:
+// removing the score MFMAs, 74 % of the MFMA work, removes more time than they take at peak, i.e. the
+// phases do not overlap).  Here ALL weights sit in LDS once per workgroup (score D x D, lse2, lse1: 21.5 KB
+// at D = 64) as the MFMA B operand, and every WAVE owns whole 32-row tiles (2 points x 16 neighbours)
+// end to end in its private LDS patch: gather + relative positions (requested one tile ahead, as in
+// lfa_attn_pf), lse1, lse2 in place, scores for all column tiles, softmax, weighted sum.  Waves only
+// synchronise with themselves (wave_lds_sync), drift freely, and with no weights in registers 12 waves
+// fit per CU (LDS-bound: 10.2 KB patch each).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct WaveAttnCfg {
+    static constexpr int H = D / 2;
+    static constexpr int NT = D / 32;
+    static constexpr int XP = D + 4;
+    static constexpr int Q = H / 4;                  // float4 pieces per gathered row
+    static constexpr int G = 32 * Q / 64;            // pieces per lane
+    static constexpr int W = D == 64 ? 12 : 16;      // waves per workgroup
+    static constexpr int PATCH = 32 * XP + 32 * 12;  // floats per wave
+    static constexpr int WFLOATS = D * D + H * 32 + 12 * 32;
+};
+
+template <int D, int STAGE>
+__global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArgs A) {
+    using C = WaveAttnCfg<D>;
+    constexpr int H = C::H, XP = C::XP, Q = C::Q, G = C::G, NT = C::NT;
+    static_assert(H <= 32 && (32 * Q) % 64 == 0, "lfa_attn_wave: D in {32, 64}");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* WS = smem;                                 // [D][D]   score weights (transposed Linear: [in][out])
+    float* W2 = WS + D * D;                           // [H][32]  lse2 (zero padded columns)
+    float* W1 = W2 + H * 32;                          // [12][32] lse1 (K padded 10 -> 12)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    float* X = W1 + 12 * 32 + wave * C::PATCH;        // [32][XP]  this wave's tile
+    float* REL = X + 32 * XP;                         // [32][12]
+
+    for (int e = tid; e < D * D; e += C::W * 64) WS[e] = A.score_wt[e];
+    for (int e = tid; e < H * 32; e += C::W * 64) {
+        const int k = e >> 5, c = e & 31;
+        W2[e] = (STAGE == 2 && c < H) ? A.lse2_wt[k * H + c] : 0.f;
+    }
+    for (int e = tid; e < 12 * 32; e += C::W * 64) {
+        const int k = e >> 5, c = e & 31;
+        // K slot 10 carries the bias (REL[:, 10] = 1), slot 11 is zero
+        W1[e] = c < H ? (k < 10 ? A.lse1_wt[k * H + c] : (k == 10 ? A.lse1_b[c] : 0.f)) : 0.f;
+    }
+    float sbias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sbias[t] = A.score_b[t * 32 + col];
+    const float l2bias = (STAGE == 2 && col < H) ? A.lse2_b[col] : 0.f;
+    __syncthreads();                                  // the only workgroup barrier
+
+    // Everything about a tile except the lane's own row is wave-uniform and kept in SGPRs (the wave index is made
+    // scalar explicitly): the f32 MFMAs and the VALU share the SIMD's issue cycles on gfx950 (tools/micro), so
+    // every vector instruction outside the MFMAs is paid in full.  Point indices fit 32 bits (launcher checks).
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t tiles = (uint32_t)((A.m_total + 1) / 2);       // 2 points per wave tile
+    const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
+    const bool xw = A.xcd_chunk > 0;
+    const uint32_t w_step = (xw ? (gridDim.x >> 3) : gridDim.x) * C::W;
+    uint32_t wi = (xw ? (blockIdx.x >> 3) : blockIdx.x) * C::W + swave;
+    auto next_tile = [&]() -> int64_t {
+        for (;;) {
+            int64_t t = wi;
+            if (xw) t = xcd_tile((int64_t)wi, (int)(blockIdx.x & 7), A.xcd_chunk, (int64_t)tiles);
+            wi += w_step;
+            if (t < 0) return -1;
+            if (t < (int64_t)tiles) return t;
+            if (!xw) return -1;
+        }
+    };
+
+    int gi[G], nb_mine = -1;
+    float4 gq[G];
+    float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    bool mine_valid = false;
+    auto request_idx = [&](uint32_t tile) {
+        const int32_t* nb = A.nidx + (int64_t)tile * 2 * RK;      // 32 contiguous (point, neighbour) rows
+        const uint32_t lim = (m_tot - tile * 2) >= 2 ? 32u : 16u; // rows of the tile that exist
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
+            gi[i] = row < lim ? nb[row] : -1;
+        }
+        nb_mine = (uint32_t)lane < lim ? nb[lane] : -1;           // (lanes 32-63: unused duplicates of rows 0-31's upper half)
+    };
+    auto request_data = [&](uint32_t tile) {
+        // the tile's two points: cloud b0 / local index l0, and its successor (possibly the next cloud's first point)
+        const uint32_t m0 = tile * 2;
+        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;
+        const bool wrap = l0 + 1 == n_pts;
+        const uint32_t b1 = wrap ? b0 + 1 : b0, l1 = wrap ? 0u : l0 + 1;
+        const float* f0 = A.gfeat + (int64_t)b0 * n_pts * H;      // scalar bases, 32-bit lane offsets
+        const float* f1 = A.gfeat + (int64_t)b1 * n_pts * H;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / Q, q = e - row * Q;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gi[i] >= 0) gq[i] = *reinterpret_cast<const float4*>((row < RK ? f0 : f1) + (uint32_t)gi[i] * H + 4 * q);
+        }
+        mine_valid = lane < 32 && nb_mine >= 0;
+        if (mine_valid) {
+            const bool p1 = lane >= RK;
+            const float* xb = A.xyz + 3 * ((int64_t)(p1 ? b1 : b0) * A.n0);
+            const float* qp = xb + 3 * (p1 ? l1 : l0);
+            const float* sp = xb + 3 * (uint32_t)nb_mine;
+            qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
+        }
+    };
+
+    int64_t cur = next_tile();
+    if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
+    while (cur >= 0) {
+        const int64_t nxt = next_tile();
+        // ---- registers -> the wave's patch ---------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / Q, q = e - row * Q;
+            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = gq[i];
+        }
+        if (lane < 32) {
+            float* r = REL + lane * 12;
+            if (mine_valid) {
+                const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) r[j] = 0.f;
+            }
+            r[10] = 1.f; r[11] = 0.f;                             // bias slot, K padding
+        }
+        if (nxt >= 0) request_idx((uint32_t)nxt);
+        wave_lds_sync();
+        // ---- r1 = lrelu(lse1(rel)) (K = 12) -> X[:, H:] ---------------------------------------------------
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ar = REL + col * 12 + hi * 6;
+            const float* wb = W1 + hi * 6 * 32 + col;
+            const float2 a01 = *reinterpret_cast<const float2*>(ar);
+            const float2 a23 = *reinterpret_cast<const float2*>(ar + 2);
+            const float2 a45 = *reinterpret_cast<const float2*>(ar + 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, wb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, wb[32], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, wb[64], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, wb[96], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, wb[128], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, wb[160], acc, 0, 0, 0);
+            if (col < H) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X[mfma_row(r, hi) * XP + H + col] = lrelu_max(acc[r], 0.2f);
+            }
+        }
+        wave_lds_sync();
+        if constexpr (STAGE == 2) {
+            // ---- r2 = lrelu(lse2(r1)) in place on X[:, H:] (every A read precedes the first write: the MFMAs sit between)
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = l2bias;          // loop-invariant image: the first MFMA reads it as srcC
+            const float* ar = X + col * XP + H + hi * (H / 2);
+            const float* wb = W2 + hi * (H / 2) * 32 + col;
+#pragma unroll
+            for (int s4 = 0; s4 < H / 8; ++s4) {
+                const float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wb[(4 * s4 + 0) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wb[(4 * s4 + 1) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wb[(4 * s4 + 2) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wb[(4 * s4 + 3) * 32], acc, 0, 0, 0);
+            }
+            wave_lds_sync();
+            if (col < H) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X[mfma_row(r, hi) * XP + H + col] = lrelu_max(acc[r], 0.2f);
+            }
+            wave_lds_sync();
+        }
+        if (nxt >= 0) request_data((uint32_t)nxt);
+        // ---- scores for all column tiles (A read once), softmax over the 16 neighbours, weighted sum --------
+        f32x16 sc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[t][r] = sbias[t];
+        {
+            const float* ar = X + col * XP + hi * (D / 2);
+            const float* wb = WS + hi * (D / 2) * D + col;
+#pragma unroll
+            for (int s4 = 0; s4 < D / 8; ++s4) {
+                const float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wb[(4 * s4 + 0) * D + 32 * t], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wb[(4 * s4 + 1) * D + 32 * t], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wb[(4 * s4 + 2) * D + 32 * t], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wb[(4 * s4 + 3) * D + 32 * t], sc[t], 0, 0, 0);
+                }
+            }
+#ifdef ML3D_WAVE_IGLP
+            __builtin_amdgcn_iglp_opt(0);
+#endif
+        }
+        const uint32_t m = (uint32_t)cur * 2 + hi;               // half 0 stores point 0, half 1 point 1
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* xc = X + 32 * t + col;
+            // softmax over the 16 neighbours of each of the tile's two points (8 values in this lane, 8 in lane ^ 32),
+            // exp(s - max) as exp2(s * log2e - max * log2e): one v_fma + one v_exp per score
+            constexpr float LOG2E = 1.4426950408889634f;
+            float num[2], den[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                float mx = sc[t][8 * pt];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, sc[t][8 * pt + r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float nmx = -mx * LOG2E;
+                float sum = 0.f, ag = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[t][8 * pt + r], LOG2E, nmx));
+                    sum += e;
+                    ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
+                }
+                num[pt] = ag + __shfl_xor(ag, 32);
+                den[pt] = sum + __shfl_xor(sum, 32);
+            }
+            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
+            if (m < m_tot) A.out[(int64_t)m * D + 32 * t + col] = agg_mine;
+        }
+        wave_lds_sync();                                          // the patch is rewritten at the top of the loop
+        cur = nxt;
+    }
+}
+
+template <int D, int STAGE>
+static int launch_attn_wave(LfaArgs a, hipStream_t st) {
+    using C = WaveAttnCfg<D>;
+    const int64_t tiles = (a.m_total + 1) / 2;
+    static const int cus = device_cu_count();
+    int64_t blocks = (tiles + C::W - 1) / C::W;
+    unsigned grid = (unsigned)(blocks < cus ? blocks : cus);     // one 12/16-wave workgroup per CU (LDS-bound)
+    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+    const size_t sm = sizeof(float) * ((size_t)C::WFLOATS + (size_t)C::W * C::PATCH);
+    if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL((lfa_attn_wave<D, STAGE>), dim3(grid), dim3(C::W * 64), sm, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
 // launches the attention part of one stage; `a.out` receives agg [m, D]
 template <int D, int STAGE>
 static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
@@ -573,6 +1088,19 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+    static const bool wave_on = !(getenv("ML3D_ATTN_WAVE") && getenv("ML3D_ATTN_WAVE")[0] == '0');   // A/B knob
+    if constexpr (D <= 64) {
+        if (wave_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30) return launch_attn_wave<D, STAGE>(a, st);
+    }
+    static const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
+    if (pf_on) {
+        size_t sm = pf_smem_bytes<D, STAGE>();
+        if (sm > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL((lfa_attn_pf<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
     size_t sm = mfma_smem_bytes<D, STAGE>();
     if (sm > 48 * 1024 &&
         hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
@@ -1045,14 +1573,6 @@ static bool wave_mlp_supported(const ChainArgs& a, WaveMlpMeta* M, int* pre) {
     const int need = (32 * (a.L[0].cin / 4) + 63) / 64;
     *pre = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 12));
     return need <= 12;
-}
-
-static int device_cu_count() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
-        cus = 256;
-    return cus;
 }
 
 template <int PRE>
