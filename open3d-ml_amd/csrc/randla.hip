@@ -650,50 +650,48 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
     float4 gq[G];                        // hop 3: gathered feature pieces
     float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;   // hop 2
     bool mine_valid = false;
-    auto request_idx = [&](int64_t tile) {
-        const int32_t* nb = A.nidx + tile * C::TP * RK;            // the tile's (point, neighbour) rows are contiguous
-        const int64_t lim = (A.m_total - tile * C::TP) * RK;       // rows of the tile that exist
+    // (per-tile bookkeeping is wave-uniform and 32-bit: f32 MFMA and VALU share the SIMD's issue cycles on gfx950, so a
+    //  64-bit division per lane per tile costs as much as two MFMAs; the launcher guarantees m_total, n0 < 2^30, n >= TP)
+    const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
+    auto request_idx = [&](uint32_t tile) {
+        const int32_t* nb = A.nidx + (int64_t)tile * (C::TP * RK);  // the tile's (point, neighbour) rows are contiguous
+        const uint32_t have = m_tot - tile * C::TP;                 // points of the tile that exist
+        const uint32_t lim = (have < (uint32_t)C::TP ? have : (uint32_t)C::TP) * RK;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int row = (tid + i * THREADS) / Q;
+            const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
             gi[i] = row < lim ? nb[row] : -1;
         }
-        if (tid < ROWS) nb_mine = tid < lim ? nb[tid] : -1;
+        if (tid < ROWS) nb_mine = (uint32_t)tid < lim ? nb[tid] : -1;
     };
-    auto request_data = [&](int64_t tile) {
+    auto request_data = [&](uint32_t tile) {
+        const uint32_t m0 = tile * C::TP;
+        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;      // scalar; point p of the tile is (b0, l0 + p) or wraps once
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int e = tid + i * THREADS;
             const int row = e / Q, q = e - row * Q;
             gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef ABL_NOLOAD
-            if (false) {
-#else
             if (gi[i] >= 0) {
-#endif
-                const int64_t m = tile * C::TP + row / RK;
-                const int64_t b = m / A.n;
-                gq[i] = *reinterpret_cast<const float4*>(A.gfeat + (b * A.n + gi[i]) * H + 4 * q);
+                const uint32_t b = b0 + ((l0 + (uint32_t)(row / RK) >= n_pts) ? 1u : 0u);
+                gq[i] = *reinterpret_cast<const float4*>(A.gfeat + ((int64_t)b * n_pts + (uint32_t)gi[i]) * H + 4 * q);
             }
         }
         if (tid < ROWS) {
             mine_valid = nb_mine >= 0;
-#ifdef ABL_NOLOAD
-            if (false) {
-#else
             if (mine_valid) {
-#endif
-                const int64_t m = tile * C::TP + tid / RK;
-                const int64_t b = m / A.n, nl = m - b * A.n;
-                const float* qp = A.xyz + 3 * (b * A.n0 + nl);
-                const float* sp = A.xyz + 3 * (b * A.n0 + nb_mine);
+                const uint32_t lp = l0 + (uint32_t)(tid / RK);
+                const bool wrap = lp >= n_pts;
+                const float* xb = A.xyz + 3 * ((int64_t)(b0 + (wrap ? 1u : 0u)) * A.n0);
+                const float* qp = xb + 3 * (wrap ? lp - n_pts : lp);
+                const float* sp = xb + 3 * (uint32_t)nb_mine;
                 qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
             }
         }
     };
 
     int64_t cur = next_tile();
-    if (cur >= 0) { request_idx(cur); request_data(cur); }
+    if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
     block_sync_lds();                                            // W1 / W2 staged
     while (cur >= 0) {
         const int64_t nxt = next_tile();
@@ -717,7 +715,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             }
             r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
         }
-        if (nxt >= 0) request_idx(nxt);
+        if (nxt >= 0) request_idx((uint32_t)nxt);
         block_sync_lds();
         // ---- r1 = lrelu(lse1(rel)) on MFMA (K = 12) -> X[:, H:] (stage 1 / in place) or R1 -----------------
         for (int rt = rg2; rt < C::RT; rt += C::RG2) {
@@ -739,7 +737,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + mfma_row(r, hi);
-                    const float v = lrelu(acc[r], 0.2f);
+                    const float v = lrelu_max(acc[r], 0.2f);
                     if (STAGE == 1 || C::INPLACE) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
                 }
             }
@@ -766,43 +764,39 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                 if (col2 < H) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu(acc[r], 0.2f);
+                        X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu_max(acc[r], 0.2f);
                 }
             }
         }
-        if (nxt >= 0) request_data(nxt);
+        if (nxt >= 0) request_data((uint32_t)nxt);
         block_sync_lds();
         // ---- scores on MFMA, softmax over the 16 neighbours, weighted sum ------------------------------
         for (int rt = rg; rt < C::RT; rt += C::RG) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias;
-#ifndef ABL_NOMFMA3
             acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
-#endif
             const float* xc = X + (rt * 32) * XP + ct * 32 + col;
-            float agg_mine = 0.f;
-#ifdef ABL_NOSOFTMAX
-            agg_mine = acc[0] + acc[8] + xc[0];
-#else
+            constexpr float LOG2E = 1.4426950408889634f;          // exp(s - max) = exp2(s * log2e - max * log2e)
+            float num[2], den[2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 float mx = acc[8 * pt];
 #pragma unroll
                 for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[8 * pt + r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float nmx = -mx * LOG2E;
                 float sum = 0.f, ag = 0.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    float e = __expf(acc[8 * pt + r] - mx);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(acc[8 * pt + r], LOG2E, nmx));
                     sum += e;
                     ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
                 }
-                sum += __shfl_xor(sum, 32);
-                ag += __shfl_xor(ag, 32);
-                if (pt == hi) agg_mine = ag / sum;
+                num[pt] = ag + __shfl_xor(ag, 32);
+                den[pt] = sum + __shfl_xor(sum, 32);
             }
-#endif
+            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
             int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
             if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
         }
@@ -1093,7 +1087,7 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
         if (wave_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30) return launch_attn_wave<D, STAGE>(a, st);
     }
     static const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
-    if (pf_on) {
+    if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
         size_t sm = pf_smem_bytes<D, STAGE>();
         if (sm > 48 * 1024 &&
             hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
@@ -1124,8 +1118,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int A16_TP = 16;           // points per tile (256 rows = 256 threads)
 constexpr int A16_XP = 20;           // X row pitch
 
+// (the lse weights arrive as separate __restrict__ kernel arguments: with `noalias` the compiler may read them with
+//  scalar loads inside the tile loop -- SGPR operands of the packed FMAs -- instead of one uniform VECTOR load per
+//  16 bytes of weights per tile, which is what it must do for pointers that could alias the stores to A.out)
 template <int STAGE>
-__global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
+__global__ void __launch_bounds__(256, 6)
+lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __restrict__ lse1_b,
+                const float* __restrict__ lse2_wt, const float* __restrict__ lse2_b) {
     constexpr int D = 16, H = 8;
     __shared__ __attribute__((aligned(16))) float X[A16_TP * RK * A16_XP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1134,67 +1133,117 @@ __global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) bs[s] = A.score_wt[(4 * g + s) * D + col];
     const float sbias = A.score_b[col];
-    const int64_t tiles = (A.m_total + A16_TP - 1) / A16_TP;
+    // tile bookkeeping is wave-uniform and 32-bit (launcher: m_total, n0 < 2^30, n >= 16): the VALU shares the SIMD's
+    // issue cycles with the f32 MFMAs on gfx950, a 64-bit division per lane would cost more than the tile's MFMAs
+    const uint32_t tiles = (uint32_t)((A.m_total + A16_TP - 1) / A16_TP);
+    const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
     const bool xw = A.xcd_chunk > 0;
-    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
-    for (int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;; wi += w_step) {
-        int64_t tile = wi;
-        if (xw) {
-            tile = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
-            if (tile < 0) break;
-            if (tile >= tiles) continue;
-        } else if (tile >= tiles) break;
-        const int64_t m_base = tile * A16_TP;
-        {   // ---- build: thread = (point p, neighbour k) -------------------------------------------
-            const int p = tid >> 4, k = tid & 15;
-            const int64_t m = m_base + p;
+    const uint32_t w_step = xw ? (gridDim.x >> 3) : gridDim.x;
+    uint32_t wi = xw ? (blockIdx.x >> 3) : blockIdx.x;
+    auto next_tile = [&]() -> int64_t {
+        for (;;) {
+            int64_t t = wi;
+            if (xw) t = xcd_tile((int64_t)wi, (int)(blockIdx.x & 7), A.xcd_chunk, (int64_t)tiles);
+            wi += w_step;
+            if (t < 0) return -1;
+            if (t < (int64_t)tiles) return t;
+            if (!xw) return -1;
+        }
+    };
+    // rows 64w .. 64w+63 of a tile (points 4w .. 4w+3) are built AND consumed by wave w: no workgroup barrier
+    float* Xw = X + wave * 64 * A16_XP;
+    const uint32_t p = tid >> 4;                                              // thread = (point p, neighbour tid & 15) row
+    // this thread's row of the NEXT tile is requested while the current one is computed: its neighbour index during the
+    // build phase, then (through that index) the two xyz triples and the 8-float feature row during the MFMA phase
+    uint32_t nb = 0;
+    bool valid = false;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    auto request_idx = [&](uint32_t tile) {
+        valid = tile * A16_TP + p < m_tot;
+        if (valid) nb = (uint32_t)A.nidx[(int64_t)tile * (A16_TP * RK) + tid];
+    };
+    auto request_data = [&](uint32_t tile) {
+        if (valid) {
+            const uint32_t m_base = tile * A16_TP;
+            const uint32_t b0 = m_base / n_pts, l0 = m_base - b0 * n_pts;     // scalar
+            const uint32_t lp = l0 + p;
+            const bool wrap = lp >= n_pts;                                    // the tile may cross into the next cloud once
+            const uint32_t b = b0 + (wrap ? 1u : 0u), nl = wrap ? lp - n_pts : lp;
+            const float* xb = A.xyz + 3 * ((int64_t)b * A.n0);
+            const float* q = xb + 3 * nl;
+            const float* sp = xb + 3 * nb;
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
+            const float4* gf = reinterpret_cast<const float4*>(A.gfeat + ((int64_t)b * n_pts + nb) * H);
+            g0 = gf[0]; g1 = gf[1];
+        }
+    };
+    int64_t cur = next_tile();
+    if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
+    while (cur >= 0) {
+        const int64_t nxt = next_tile();
+        const uint32_t m_base = (uint32_t)cur * A16_TP;
+        {   // ---- build this thread's X row ---------------------------------------------------------
             float xr[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) xr[c] = 0.f;
-            if (m < A.m_total) {
-                int64_t b = m / A.n, nl = m - b * A.n;
-                int nb = A.nidx[m * RK + k];
-                const float* q = A.xyz + 3 * (b * A.n0 + nl);
-                const float* sp = A.xyz + 3 * (b * A.n0 + nb);
-                float rel[10];
-                rel[4] = q[0]; rel[5] = q[1]; rel[6] = q[2]; rel[7] = sp[0]; rel[8] = sp[1]; rel[9] = sp[2];
+            const bool have = valid;
+            float rel[10];
+            rel[4] = q0; rel[5] = q1; rel[6] = q2; rel[7] = s0; rel[8] = s1; rel[9] = s2;
+            xr[0] = g0.x; xr[1] = g0.y; xr[2] = g0.z; xr[3] = g0.w;
+            xr[4] = g1.x; xr[5] = g1.y; xr[6] = g1.z; xr[7] = g1.w;
+            if (nxt >= 0) request_idx((uint32_t)nxt);
+            if (have) {
                 rel[1] = rel[4] - rel[7]; rel[2] = rel[5] - rel[8]; rel[3] = rel[6] - rel[9];
                 rel[0] = sqrtf(rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
-                float r1[H];
+                // lse1 (10 -> 8) and lse2 (8 -> 8) as packed-f32 FMAs (v_pk_fma_f32: two output channels per instruction,
+                // weight pairs straight from SGPRs) -- the same rate as the f32 MFMA without its 16-column granularity
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f* w1 = reinterpret_cast<const v2f*>(lse1_wt);
+                const v2f* bb1 = reinterpret_cast<const v2f*>(lse1_b);
+                v2f r1[H / 2];
 #pragma unroll
-                for (int c = 0; c < H; ++c) {
-                    float v = A.lse1_b[c];
+                for (int c = 0; c < H / 2; ++c) {
+                    v2f v = bb1[c];
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) v = fmaf(rel[j], A.lse1_wt[j * H + c], v);
-                    r1[c] = lrelu(v, 0.2f);
+                    for (int j = 0; j < 10; ++j) v = __builtin_elementwise_fma((v2f){rel[j], rel[j]}, w1[j * (H / 2) + c], v);
+                    const v2f sv = v * 0.2f;
+                    r1[c] = (v2f){__builtin_amdgcn_fmed3f(v.x, sv.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, sv.y, __builtin_inff())};
                 }
                 if (STAGE == 2) {
+                    const v2f* w2 = reinterpret_cast<const v2f*>(lse2_wt);
+                    const v2f* bb2 = reinterpret_cast<const v2f*>(lse2_b);
 #pragma unroll
-                    for (int c = 0; c < H; ++c) {
-                        float v = A.lse2_b[c];
+                    for (int c = 0; c < H / 2; ++c) {
+                        v2f v = bb2[c];
 #pragma unroll
-                        for (int j = 0; j < H; ++j) v = fmaf(r1[j], A.lse2_wt[j * H + c], v);
-                        xr[H + c] = lrelu(v, 0.2f);
+                        for (int j = 0; j < H; ++j) {
+                            const float rj = (j & 1) ? r1[j >> 1].y : r1[j >> 1].x;
+                            v = __builtin_elementwise_fma((v2f){rj, rj}, w2[j * (H / 2) + c], v);
+                        }
+                        const v2f sv = v * 0.2f;
+                        xr[H + 2 * c] = __builtin_amdgcn_fmed3f(v.x, sv.x, __builtin_inff());
+                        xr[H + 2 * c + 1] = __builtin_amdgcn_fmed3f(v.y, sv.y, __builtin_inff());
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < H; ++c) xr[H + c] = r1[c];
+                    for (int c = 0; c < H / 2; ++c) { xr[H + 2 * c] = r1[c].x; xr[H + 2 * c + 1] = r1[c].y; }
                 }
-                const float4* gf = reinterpret_cast<const float4*>(A.gfeat + (b * A.n + nb) * H);
-                float4 g0 = gf[0], g1 = gf[1];
-                xr[0] = g0.x; xr[1] = g0.y; xr[2] = g0.z; xr[3] = g0.w;
-                xr[4] = g1.x; xr[5] = g1.y; xr[6] = g1.z; xr[7] = g1.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < H; ++c) xr[c] = 0.f;
             }
             float4* dst = reinterpret_cast<float4*>(X + tid * A16_XP);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) dst[q4] = make_float4(xr[4 * q4], xr[4 * q4 + 1], xr[4 * q4 + 2], xr[4 * q4 + 3]);
         }
-        SYNC_ATTN();
+        wave_lds_sync();
+        if (nxt >= 0) request_data((uint32_t)nxt);
         // ---- MFMA: wave w owns points 4w .. 4w+3 of the tile ------------------------------------------
+        constexpr float LOG2E = 1.4426950408889634f;                         // exp(s - max) = exp2(s * log2e - max * log2e)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            const int p = 4 * wave + pp;
-            const float* Xp = X + p * RK * A16_XP;
+            const float* Xp = Xw + pp * RK * A16_XP;
             float4 a = *reinterpret_cast<const float4*>(Xp + col * A16_XP + 4 * g);
             f32x4 acc = {sbias, sbias, sbias, sbias};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bs[0], acc, 0, 0, 0);
@@ -1204,19 +1253,21 @@ __global__ void __launch_bounds__(256, 5) lfa_attn_mfma16(LfaArgs A) {
             float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float nmx = -mx * LOG2E;
             float sum = 0.f, ag = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float e = __expf(acc[r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(acc[r], LOG2E, nmx));
                 sum += e;
                 ag = fmaf(e, Xp[(4 * g + r) * A16_XP + col], ag);
             }
             sum += __shfl_xor(sum, 16); ag += __shfl_xor(ag, 16);
             sum += __shfl_xor(sum, 32); ag += __shfl_xor(ag, 32);
-            const int64_t m = m_base + p;
-            if (g == 0 && m < A.m_total) A.out[m * D + col] = ag / sum;
+            const uint32_t m = m_base + 4 * wave + pp;
+            if (g == 0 && m < m_tot) A.out[(int64_t)m * D + col] = ag / sum;
         }
-        SYNC_ATTN();
+        wave_lds_sync();
+        cur = nxt;
     }
 }
 
@@ -1228,7 +1279,7 @@ static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
     static const int cap = getenv("ML3D_ATTN16_GRID") ? atoi(getenv("ML3D_ATTN16_GRID")) : 4096;
     unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    hipLaunchKernelGGL((lfa_attn_mfma16<STAGE>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_attn_mfma16<STAGE>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
@@ -1869,7 +1920,9 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         s2.mlp2_wt = P(sb + 14); s2.mlp2_b = P(sb + 16); s2.short_wt = P(sb + 15); s2.short_b = P(sb + 17);
         s2.feat_in = feat; s2.out = enc;
         int rc = 0;
-        const bool mfma_ok = (dd == 16 || dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu;
+        // (the MFMA kernels keep point indices in 32 bits; a > 2^30-point batch level takes the generic VALU kernel)
+        const bool mfma_ok = (dd == 16 || dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu &&
+                             (dd != 16 || (M < ((int64_t)1 << 30) && s1.n0 < ((int64_t)1 << 30)));
         if (mfma_ok) {
             float* agg = take(M * dd);
             float* p2 = take(M * dd);
