@@ -30,6 +30,7 @@ struct Epilogue {
     // (b, y, x) of a [B, ps_h, ps_w] map, column n = (dy, dx, co); the value goes to output pixel
     // (b, y*ps + dy, x*ps + dx), channel co, of an NHWC map whose pixel stride is ldc.  bias is indexed by co.
     int ps, ps_h, ps_w, ps_cout;
+    const float* bias2;       // [N] or null: a second bias (two Linears summed into one GEMM over concatenated inputs)
 };
 
 // dense / gathered / concatenated rows

@@ -199,7 +199,8 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
         }
         return;
     }
-    const float b = ep.bias ? ep.bias[col] : 0.f;
+    float b = ep.bias ? ep.bias[col] : 0.f;
+    if (ep.bias2) b += ep.bias2[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + rt * 32 + mfma32_row(r, hi);
@@ -231,7 +232,7 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
             C[opix * ldc + co] = gm_act(v, ep.act, ep.slope);
             continue;
         }
-        if (ep.bias) v += ep.bias[col];
+        if (ep.bias) v += ep.bias2 ? ep.bias[col] + ep.bias2[col] : ep.bias[col];
         if (ep.residual) v += ep.residual[m * ep.ldr + col];
         C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
     }

@@ -1626,6 +1626,219 @@ static bool wave_mlp_supported(const ChainArgs& a, WaveMlpMeta* M, int* pre) {
     return need <= 12;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// mlp_wave_s — mlp_wave with the chain's SHAPE as a compile-time parameter, for the shapes RandLA-Net ships
+// (fc1 with the last decoder stage in front of it; the pool2 + mlp2|shortcut chains of the first two encoder
+// layers).  The runtime-shaped kernel spends more VALU instructions on index arithmetic (runtime pitches,
+// 64-bit row addresses, divisions by runtime widths) than on its epilogues, and on gfx950 every VALU
+// instruction is issue time taken from the f32 MFMAs.  Here every pitch, K trip count and LDS offset is a
+// constant, the tile index is scalar, rows are addressed as scalar base + 32-bit lane offset, and the K loops
+// are straight-line code.  Same numerics, same LDS-resident weight image, same barrier-free per-wave tiles.
+// ------------------------------------------------------------------------------------------------
+template <int C0_, int C1_, int CATL_, int CATC_, int NL_, int N0_, int N1_, int N2_, int N3_>
+struct MlpShape {
+    static constexpr int C0 = C0_, C1 = C1_, CATL = CATL_, CATC = CATC_, NL = NL_;
+    static constexpr int n(int l) { return l == 0 ? N0_ : l == 1 ? N1_ : l == 2 ? N2_ : N3_; }          // real widths (last: upper bound)
+    static constexpr int np(int l) { return (n(l) + 31) & ~31; }
+    static constexpr int cin(int l) { return l == 0 ? C0 + C1 : n(l - 1) + (l == CATL ? CATC : 0); }
+    static constexpr int w_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += cin(i) * np(i) + np(i); return o; }
+    static constexpr int b_off(int l) { return w_off(l) + cin(l) * np(l); }
+    static constexpr int w_total() { return (w_off(NL) + 3) & ~3; }
+    static constexpr int pit(int par) { int w = 4; for (int l = par; l < NL; l += 2) w = cin(l) > w ? cin(l) : w; return w + 4; }
+    static constexpr int patch() { return 32 * (pit(0) + pit(1)); }
+};
+
+template <class S, int L>
+__device__ __forceinline__ void mlp_s_layer(const ChainArgs& A, float* smem, float* P0, float* P1, uint32_t m_row0, uint32_t m_tot,
+                                            int hi, int cl, int lane) {
+    constexpr int CIN = S::cin(L), NP = S::np(L), KH = CIN / 2;
+    constexpr int PIN = S::pit(L & 1), POUT = S::pit((L + 1) & 1);
+    constexpr bool LAST = L == S::NL - 1;
+    const float* in = (L & 1) ? P1 : P0;
+    float* outp = (L & 1) ? P0 : P1;
+    const ChainLayer& Ly = A.L[L];
+    const float* arow = in + cl * PIN + hi * KH;
+#pragma unroll
+    for (int ct = 0; ct < NP / 32; ++ct) {
+        const float* Bc = smem + S::w_off(L) + (hi * KH) * NP + ct * 32 + cl;
+        f32x16 acc;
+        const float b = smem[S::b_off(L) + ct * 32 + cl];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+        acc = wave_k_loop<KH, NP>(arow, Bc, acc);
+        const int col = ct * 32 + cl;
+        if (LAST) {
+            if (col < Ly.cout) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = m_row0 + mfma_row(r, hi);
+                    float v = acc[r];
+                    if (Ly.act) v = lrelu_max(v, Ly.slope);
+                    if (m < m_tot) A.out[(int64_t)m * Ly.cout + col] = v;
+                }
+            }
+        } else {
+            // (hidden widths are the compile-time ones; columns >= n(L) of a padded tile are never read back)
+            if (S::n(L) % 32 == 0 || col < S::n(L)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) outp[mfma_row(r, hi) * POUT + col] = lrelu_max(acc[r], Ly.slope);
+            }
+        }
+    }
+    if constexpr (!LAST) {
+        if constexpr (L + 1 == S::CATL) {                                   // the next layer's extra input columns
+            constexpr int QC = S::CATC / 4;
+#pragma unroll
+            for (int i = 0; i < (32 * QC + 63) / 64; ++i) {
+                const int e = lane + 64 * i;
+                if (32 * QC % 64 == 0 || e < 32 * QC) {
+                    const int r = e / QC, k = (e - r * QC) * 4;
+                    const uint32_t m = m_row0 + r;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < m_tot) v = *reinterpret_cast<const float4*>(A.cat + (int64_t)m * S::CATC + k);
+                    *reinterpret_cast<float4*>(outp + r * POUT + S::n(L) + k) = v;
+                }
+            }
+        }
+        wave_lds_sync();
+        mlp_s_layer<S, L + 1>(A, smem, P0, P1, m_row0, m_tot, hi, cl, lane);
+    }
+}
+
+template <class S, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) mlp_wave_s(ChainArgs A) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    // ---- weight image (zero-padded 32-column tiles) + biases ------------------------------------------------
+#pragma unroll
+    for (int l = 0; l < S::NL; ++l) {
+        const ChainLayer Ly = A.L[l];
+        const int np = S::np(l), cin = S::cin(l);
+        for (int e = tid; e < cin * np; e += NW * 64) {
+            const int k = e / np, c = e - k * np;
+            smem[S::w_off(l) + e] = c < Ly.cout ? Ly.wt[k * Ly.cout + c] : 0.f;
+        }
+        for (int c = tid; c < np; c += NW * 64) {
+            float b = 0.f;
+            if (c < Ly.cout) { b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
+            smem[S::b_off(l) + c] = b;
+        }
+    }
+    __syncthreads();
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    float* P0 = smem + S::w_total() + swave * S::patch();
+    float* P1 = P0 + 32 * S::pit(0);
+    const uint32_t m_tot = (uint32_t)A.m_total;
+    const uint32_t tiles = (m_tot + 31) / 32;
+    const uint32_t t_step = gridDim.x * NW;
+    constexpr int Q0 = (S::C0 + S::C1) / 4, QA = S::C0 / 4;
+    constexpr int PRE = (32 * Q0 + 63) / 64;
+    const uint32_t rpi = (uint32_t)A.rows_per_item, srpi = (uint32_t)A.a1_rows_per_item;
+
+    // first-layer input rows of the NEXT tile are requested while the current one is computed; gathered rows
+    // ([skip | nearest_interpolation(coarser)] of the decoder) take their index one step earlier still
+    float4 pre[PRE];
+    int gix[PRE];
+    auto request_idx = [&](uint32_t t) {
+        if constexpr (S::C1 > 0) {
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = lane + 64 * i;
+                const int r = e / Q0, q = e - r * Q0;
+                const uint32_t m = t * 32 + r;
+                gix[i] = -1;
+                if ((32 * Q0 % 64 == 0 || e < 32 * Q0) && q >= QA && m < m_tot) gix[i] = A.gather ? A.gather[m] : (int)m;
+            }
+        }
+    };
+    auto request_rows = [&](uint32_t t) {
+        const uint32_t m0 = t * 32;
+        uint32_t it0 = 0, l0 = m0;                                         // item of the tile's first row (scalar)
+        if (S::C1 > 0 && A.gather) { it0 = m0 / rpi; l0 = m0 - it0 * rpi; }
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = lane + 64 * i;
+            const int r = e / Q0, q = e - r * Q0;
+            const uint32_t m = m0 + r;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((32 * Q0 % 64 == 0 || e < 32 * Q0) && m < m_tot) {
+                if (S::C1 == 0 || q < QA) {
+                    pre[i] = *reinterpret_cast<const float4*>(A.a0 + (int64_t)m * S::C0 + 4 * q);
+                } else {
+                    int64_t grow = gix[i];
+                    if (A.gather) grow += (int64_t)(it0 + ((l0 + r >= rpi) ? 1u : 0u)) * srpi;   // a tile crosses items at most once
+                    pre[i] = *reinterpret_cast<const float4*>(A.a1 + grow * S::C1 + 4 * (q - QA));
+                }
+            }
+        }
+    };
+    uint32_t t = blockIdx.x * NW + swave;
+    if (t < tiles) { request_idx(t); request_rows(t); }
+    if (t + t_step < tiles) request_idx(t + t_step);
+    for (; t < tiles; t += t_step) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = lane + 64 * i;
+            if (32 * Q0 % 64 == 0 || e < 32 * Q0) {
+                const int r = e / Q0, q = e - r * Q0;
+                *reinterpret_cast<float4*>(P0 + r * S::pit(0) + 4 * q) = pre[i];
+            }
+        }
+        if (t + t_step < tiles) {
+            request_rows(t + t_step);
+            if (t + 2 * t_step < tiles) request_idx(t + 2 * t_step);
+        }
+        wave_lds_sync();
+        mlp_s_layer<S, 0>(A, smem, P0, P1, t * 32, m_tot, hi, cl, lane);
+        wave_lds_sync();          // patch 0 is rewritten at the top of the next tile
+    }
+}
+
+// the shapes with a compiled instance (last entry of each: upper bound of the final width, any cout below it works)
+typedef MlpShape<32, 32, -1, 0, 4, 32, 64, 32, 32> ShapeDecFc1;     // [skip 32 | interp 32] -> 32 -> 64 -> 32 -> classes
+typedef MlpShape<32, 0, -1, 0, 3, 64, 32, 32, 0> ShapeFc1;          // 32 -> 64 -> 32 -> classes
+typedef MlpShape<64, 0, 1, 32, 2, 64, 128, 0, 0> ShapeEnc64;        // pool2 64 -> 64, [. | feat 32] -> 128
+typedef MlpShape<16, 0, 1, 8, 2, 16, 32, 0, 0> ShapeEnc16;          // pool2 16 -> 16, [. | feat 8] -> 32
+
+// single narrow Linears over the finest levels (memory-bound: what matters is one pass, no 64-column tile padding)
+typedef MlpShape<16, 0, -1, 0, 1, 8, 0, 0, 0> ShapeLin16x8;         // pool1.mlp of the first encoder layer
+typedef MlpShape<8, 0, -1, 0, 1, 8, 0, 0, 0> ShapeLin8x8;           // mlp1 of the first encoder layer
+typedef MlpShape<64, 0, -1, 0, 1, 32, 0, 0, 0> ShapeLin64x32;       // pool1.mlp of the second
+typedef MlpShape<32, 0, -1, 0, 1, 32, 0, 0, 0> ShapeLin32x32;       // mlp1 of the second
+
+template <class S>
+static bool mlp_shape_matches(const ChainArgs& a) {
+    if (a.n_layers != S::NL || a.c0 != S::C0 || (a.a1 ? a.c1 : 0) != S::C1) return false;
+    if (S::CATL >= 0 ? !(a.cat && a.cat_layer == S::CATL && a.cat_c == S::CATC) : (a.cat != nullptr)) return false;
+    for (int l = 0; l < S::NL; ++l) {
+        if (a.L[l].cin != S::cin(l)) return false;
+        if (l + 1 < S::NL ? a.L[l].cout != S::n(l) : a.L[l].cout > S::n(l)) return false;
+        if (l + 1 < S::NL && !(a.L[l].act && a.L[l].slope > 0.f && a.L[l].slope < 1.f)) return false;
+    }
+    const ChainLayer& last = a.L[S::NL - 1];
+    if (last.act && !(last.slope > 0.f && last.slope < 1.f)) return false;
+    if (a.m_total >= ((int64_t)1 << 30)) return false;
+    if (S::C1 > 0 && a.gather && (a.rows_per_item < 32 || a.rows_per_item >= ((int64_t)1 << 30))) return false;
+    return true;
+}
+
+template <class S, int NW>
+static int launch_mlp_wave_s(const ChainArgs& a, hipStream_t st) {
+    const size_t sm = sizeof(float) * ((size_t)S::w_total() + (size_t)NW * S::patch());
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)mlp_wave_s<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    static const int cus = device_cu_count();
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)mlp_wave_s<S, NW>, NW * 64, sm) != hipSuccess || occ < 1) occ = 1;
+    const int64_t tiles = (a.m_total + 31) / 32;
+    const int64_t want = (tiles + NW - 1) / NW, cap = (int64_t)occ * cus;
+    hipLaunchKernelGGL((mlp_wave_s<S, NW>), dim3((unsigned)(want < cap ? want : cap)), dim3(NW * 64), sm, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
 template <int PRE>
 static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream_t st) {
     const size_t sm = sizeof(float) * (size_t)M.total;
@@ -1647,6 +1860,13 @@ static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream
 // multi-layer chains: the barrier-free per-wave kernel when the layers are narrow, the tile kernel otherwise
 static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
     static const bool on = !(getenv("ML3D_RANDLA_WAVE_MLP") && getenv("ML3D_RANDLA_WAVE_MLP")[0] == '0');
+    static const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
+    if (a.m_total > 0 && on && shaped) {
+        if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
+        if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
+        if (mlp_shape_matches<ShapeEnc64>(a)) return launch_mlp_wave_s<ShapeEnc64, 4>(a, st);
+        if (mlp_shape_matches<ShapeEnc16>(a)) return launch_mlp_wave_s<ShapeEnc16, 8>(a, st);
+    }
     WaveMlpMeta M;
     int pre = 0;
     if (a.m_total > 0 && on && wave_mlp_supported(a, &M, &pre)) {
@@ -1729,13 +1949,27 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
     // default: the register-prefetching tile GEMM of gemm.hip; A/B knobs: "chain" = single-layer launch of
     // mlp_chain_mfma (no prefetch), "valu" = the scalar kernel
     const char* e = getenv("ML3D_RANDLA_LINEAR");
-    if (!(e && (e[0] == 'c' || e[0] == 'v')) && a.c0 + a.c1 >= 8 && !a.bias2) {
+    static const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
+    const char* fr_env = getenv("ML3D_RANDLA_FUSE_ROWS");           // (tests lower the row threshold to cover this path)
+    if (!e && shaped && !a.a1 && a.m_total >= (fr_env ? atoll(fr_env) : 64 * 1024)) {
+        // narrow Linears over many rows: the barrier-free per-wave kernel with a compiled shape
+        ChainArgs c = {};
+        c.a0 = a.a0; c.c0 = a.c0; c.n_layers = 1;
+        c.L[0].wt = a.wt; c.L[0].bias = a.bias; c.L[0].bias2 = a.bias2; c.L[0].cin = a.c0; c.L[0].cout = a.cout;
+        c.L[0].act = a.act; c.L[0].slope = a.slope;
+        c.out = a.out; c.m_total = a.m_total;
+        if (a.cout == 8 && mlp_shape_matches<ShapeLin16x8>(c)) return launch_mlp_wave_s<ShapeLin16x8, 8>(c, st);
+        if (a.cout == 8 && mlp_shape_matches<ShapeLin8x8>(c)) return launch_mlp_wave_s<ShapeLin8x8, 8>(c, st);
+        if (a.cout == 32 && mlp_shape_matches<ShapeLin64x32>(c)) return launch_mlp_wave_s<ShapeLin64x32, 8>(c, st);
+        if (a.cout == 32 && mlp_shape_matches<ShapeLin32x32>(c)) return launch_mlp_wave_s<ShapeLin32x32, 8>(c, st);
+    }
+    if (!(e && (e[0] == 'c' || e[0] == 'v')) && a.c0 + a.c1 >= 8) {
         RowsA A;
         A.a = a.a0; A.lda = a.c0; A.k1 = a.c0;
         A.gather = a.a1 ? a.gather : nullptr; A.gather_stride = 1; A.a_rows = a.a1_rows_per_item;
         A.a2 = a.a1; A.lda2 = a.c1; A.k2 = a.a1 ? a.c1 : 0;
         A.gather_on_a2 = 1; A.g_rows_per_item = a.rows_per_item; A.g_src_rows_per_item = a.a1_rows_per_item;
-        Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0};
+        Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0, a.bias2};
         return gemm_rows(A, a.wt, a.m_total, a.cout, a.c0 + A.k2, ep, a.out, a.cout, nullptr, 0, st);
     }
     if (!(e && e[0] == 'v') && a.c0 + a.c1 >= 8) {
@@ -1965,7 +2199,12 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             ch.L[1].wt = P(sb + 14); ch.L[1].bias = P(sb + 16); ch.L[1].bias2 = P(sb + 17);
             ch.L[1].cin = dd + d_in; ch.L[1].cout = 2 * dd; ch.L[1].act = 1; ch.L[1].slope = 0.01f;
             ch.out = enc; ch.m_total = M;
-            if (!no_fuse && M >= fuse_rows && chain_supported(ch)) {
+            // (wide layers -- weights beyond the LDS image of mlp_wave -- run faster as two tile GEMMs than through the
+            //  barrier-per-layer chain kernel: 0.69 -> 0.35 ms at 128 channels; ML3D_RANDLA_CHAIN_WIDE=1 restores the chain)
+            static const bool chain_wide = getenv("ML3D_RANDLA_CHAIN_WIDE") && getenv("ML3D_RANDLA_CHAIN_WIDE")[0] == '1';
+            WaveMlpMeta wm_probe;
+            int pre_probe = 0;
+            if (!no_fuse && M >= fuse_rows && chain_supported(ch) && (chain_wide || wave_mlp_supported(ch, &wm_probe, &pre_probe))) {
                 T.begin(8 * l + 5); rc = launch_chain_auto(ch, st); T.end(8 * l + 5); if (rc) return rc;
             } else {
                 {
@@ -2032,6 +2271,24 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         a.rows_per_item = n[lev]; a.a1_rows_per_item = n[lev + 1];
         a.wt = P(slot); a.bias = P(slot + 1); a.out = outp;
         a.m_total = B * n[lev]; a.cout = skip_c; a.act = 1; a.slope = 0.2f;
+        if (i == Lr - 1 && !no_fuse && !force_valu) {
+            // the last decoder stage feeds only fc1: run [skip | interp] -> decoder -> fc1.0 -> fc1.1 -> fc1.3 as ONE
+            // per-wave chain when the shape has a compiled instance (the N0 x 32 decoder output never exists in HBM)
+            ChainArgs ch = {};
+            ch.a0 = a.a0; ch.c0 = a.c0; ch.a1 = a.a1; ch.c1 = a.c1; ch.gather = a.gather;
+            ch.rows_per_item = a.rows_per_item; ch.a1_rows_per_item = a.a1_rows_per_item;
+            ch.n_layers = 4;
+            ch.L[0].wt = a.wt; ch.L[0].bias = a.bias; ch.L[0].cin = a.c0 + a.c1; ch.L[0].cout = skip_c; ch.L[0].act = 1; ch.L[0].slope = 0.2f;
+            ch.L[1].wt = P(slot + 2); ch.L[1].bias = P(slot + 3); ch.L[1].cin = skip_c; ch.L[1].cout = 64; ch.L[1].act = 1; ch.L[1].slope = 0.2f;
+            ch.L[2].wt = P(slot + 4); ch.L[2].bias = P(slot + 5); ch.L[2].cin = 64; ch.L[2].cout = 32; ch.L[2].act = 1; ch.L[2].slope = 0.2f;
+            ch.L[3].wt = P(slot + 6); ch.L[3].bias = P(slot + 7); ch.L[3].cin = 32; ch.L[3].cout = d->num_classes; ch.L[3].act = 0;
+            ch.out = out_scores; ch.m_total = a.m_total;
+            static const bool dec_fuse = !(getenv("ML3D_RANDLA_DEC_FC1") && getenv("ML3D_RANDLA_DEC_FC1")[0] == '0');
+            if (dec_fuse && mlp_shape_matches<ShapeDecFc1>(ch)) {
+                T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200);
+                return rc;
+            }
+        }
         T.begin(1100 + i); int rc = launch_linear_auto(a, st); T.end(1100 + i); if (rc) return rc;
         slot += 2;
         cur = outp;
