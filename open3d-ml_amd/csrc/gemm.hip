@@ -1,6 +1,7 @@
 // gemm.hip — tiled f32 MFMA GEMM with loader-templated A operand and fused epilogue (see gemm.h).
 #include "gemm.h"
 
+#include "grid.h"
 #include "ml3d_hip.h"
 
 namespace ml3d {
@@ -148,7 +149,7 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     if (kb < ke) {
         fetch(kb);
         stash();
-        __syncthreads();
+        block_sync_lds();
         for (int k0 = kb; k0 < ke; k0 += GM_KC) {
             const bool more = k0 + GM_KC < ke;
             if (more) fetch(k0 + GM_KC);       // global loads in flight under the MFMAs
@@ -162,10 +163,11 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, brow[(4 * s4 + 2) * GM_BP], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, brow[(4 * s4 + 3) * GM_BP], acc, 0, 0, 0);
             }
-            __syncthreads();
+            // (LDS-only barriers: the next chunk's global loads stay in flight across them)
+            block_sync_lds();
             if (more) {
                 stash();
-                __syncthreads();
+                block_sync_lds();
             }
         }
     }

@@ -7,7 +7,7 @@ NAME=$1; SRC=$2; shift 2
 OUT=$ROOT/open3d-ml_amd/ml3d/lib
 mkdir -p $OUT/variants
 make -s -C $ROOT/open3d-ml_amd/csrc >/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$ROOT/include \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form -I$ROOT/include \
   -I$ROOT/open3d-ml_amd/csrc -Wno-unused-function "$@" -c $ROOT/open3d-ml_amd/csrc/$SRC -o $OUT/variants/$NAME.o
 OBJS=$(ls $OUT/obj/*.o | grep -v "/${SRC%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/variants/$NAME.so $OBJS $OUT/variants/$NAME.o
