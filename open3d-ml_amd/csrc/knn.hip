@@ -43,16 +43,23 @@ struct QuerySrc {
 // (exponent+mantissa are compared like an integer; a pattern is NaN/inf only when the float d2 is), so one
 // compare-exchange of (d2, index) pairs is v_min_f64 + v_max_f64 instead of a 64-bit compare and four selects.
 // d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on gfx950).
+// fmin()/fmax() would first canonicalise each operand (v_max_f64 x, x, x: signalling-NaN quieting the IEEE mode asks
+// for) -- three instructions per slot instead of two.  The keys are never NaN, so the raw instructions are exact.
+__device__ __forceinline__ void key_minmax(double a, double b, double& lo, double& hi) {
+#ifdef ML3D_HIPEMU
+    lo = fmin(a, b); hi = fmax(a, b);
+#else
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+#endif
+}
+
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
     if (key < best[K - 1]) {
         best[K - 1] = key;
 #pragma unroll
-        for (int j = K - 1; j > 0; --j) {
-            const double a = best[j - 1], b = best[j];
-            best[j - 1] = fmin(a, b);
-            best[j] = fmax(a, b);
-        }
+        for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
     }
 }
 

@@ -220,6 +220,7 @@ static inline unsigned long long __ballot(int pred) {
         if (vw.peer_valid(l)) { int q; memcpy(&q, vw.peer(l), sizeof(int)); if (q) m |= (1ull << l); }
     return m;
 }
+#define ML3D_HIPEMU 1   // lets a kernel swap an inline-asm instruction for its portable equivalent
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_fence(int, const char*, const char*) {}
 static inline void __builtin_amdgcn_iglp_opt(int) {}
