@@ -108,6 +108,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 
+// max WITHOUT operand canonicalisation: fmaxf() first quiets possible signalling NaNs (v_max_f32 x, x, x), 3
+// instructions for one max.  median(a, b, HUGE) = max(a, b) for a, b < HUGE is ONE v_med3_f32 (compiler-generated,
+// so MFMA -> VALU hazards are still handled -- hand-written asm here raced with the MFMA results it consumed).
+// On gfx950 every VALU instruction is issue time the f32 MFMAs cannot use, so the hot epilogues use this.
+__device__ __forceinline__ float fmax_raw(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
+
 // workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full workgroup fence: it drains vmcnt too,
 // i.e. every wave sits at the barrier until its outstanding global loads have landed and its global stores are
 // acknowledged.  Kernels whose cross-wave communication is all in LDS use this one instead, so prefetches and

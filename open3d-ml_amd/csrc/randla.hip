@@ -32,8 +32,7 @@ constexpr int LFA_THREADS = 256;
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 // the same value in two instructions (v_mul, v_max) when 0 < slope < 1: max(v, slope * v) picks v for v > 0
-// (v_med3 with +inf as the third operand = max without fmaxf's operand canonicalisation)
-__device__ __forceinline__ float lrelu_max(float v, float slope) { return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff()); }
+__device__ __forceinline__ float lrelu_max(float v, float slope) { return fmax_raw(v, v * slope); }
 
 // ------------------------------------------------------------------------------------------------
 // generic per-point linear layer with optional [a0 | a1[gather]] concat input
@@ -783,8 +782,8 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             for (int pt = 0; pt < 2; ++pt) {
                 float mx = acc[8 * pt];
 #pragma unroll
-                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[8 * pt + r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                for (int r = 1; r < 8; ++r) mx = fmax_raw(mx, acc[8 * pt + r]);
+                mx = fmax_raw(mx, __shfl_xor(mx, 32));
                 const float nmx = -mx * LOG2E;
                 float sum = 0.f, ag = 0.f;
 #pragma unroll
@@ -1034,8 +1033,8 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
             for (int pt = 0; pt < 2; ++pt) {
                 float mx = sc[t][8 * pt];
 #pragma unroll
-                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, sc[t][8 * pt + r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                for (int r = 1; r < 8; ++r) mx = fmax_raw(mx, sc[t][8 * pt + r]);
+                mx = fmax_raw(mx, __shfl_xor(mx, 32));
                 const float nmx = -mx * LOG2E;
                 float sum = 0.f, ag = 0.f;
 #pragma unroll
@@ -1208,7 +1207,7 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
 #pragma unroll
                     for (int j = 0; j < 10; ++j) v = __builtin_elementwise_fma((v2f){rel[j], rel[j]}, w1[j * (H / 2) + c], v);
                     const v2f sv = v * 0.2f;
-                    r1[c] = (v2f){__builtin_amdgcn_fmed3f(v.x, sv.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, sv.y, __builtin_inff())};
+                    r1[c] = (v2f){fmax_raw(v.x, sv.x), fmax_raw(v.y, sv.y)};
                 }
                 if (STAGE == 2) {
                     const v2f* w2 = reinterpret_cast<const v2f*>(lse2_wt);
@@ -1222,8 +1221,8 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
                             v = __builtin_elementwise_fma((v2f){rj, rj}, w2[j * (H / 2) + c], v);
                         }
                         const v2f sv = v * 0.2f;
-                        xr[H + 2 * c] = __builtin_amdgcn_fmed3f(v.x, sv.x, __builtin_inff());
-                        xr[H + 2 * c + 1] = __builtin_amdgcn_fmed3f(v.y, sv.y, __builtin_inff());
+                        xr[H + 2 * c] = fmax_raw(v.x, sv.x);
+                        xr[H + 2 * c + 1] = fmax_raw(v.y, sv.y);
                     }
                 } else {
 #pragma unroll
@@ -1250,9 +1249,9 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bs[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bs[2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bs[3], acc, 0, 0, 0);
-            float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float mx = fmax_raw(fmax_raw(acc[0], acc[1]), fmax_raw(acc[2], acc[3]));
+            mx = fmax_raw(mx, __shfl_xor(mx, 16));
+            mx = fmax_raw(mx, __shfl_xor(mx, 32));
             const float nmx = -mx * LOG2E;
             float sum = 0.f, ag = 0.f;
 #pragma unroll
