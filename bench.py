@@ -233,7 +233,7 @@ def main():
             "config": {"workload": "RandLA-Net SemanticKITTI inference, %d synthetic 45056-point frames per step per GPU "
                                    "(randlanet_semantickitti.yml), GPU kNN pyramid + fused forward" % B,
                        "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "lfa_attn_mfma<%d,%d> (layer %d)" % (CFG["dim_output"][layer], stage, layer),
+            "roofline": {"bound": "mfma", "kernel": "lfa_attn_wave<%d,%d> (layer %d)" % (CFG["dim_output"][layer], stage, layer),
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic, "avg_launch_ms": dom_ms,
                          "flops_per_launch": flops},
