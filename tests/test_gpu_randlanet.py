@@ -21,6 +21,11 @@ FIVE = dict(num_neighbors=16, num_layers=5, num_classes=13, sub_sampling_ratio=[
             dim_features=8, dim_output=[16, 64, 128, 256, 512])
 
 
+# level sizes 1100 / 275 / 68 / 17 per cloud: attention tiles (16, 2 and 4 points) straddle cloud boundaries
+RAGGED = dict(num_neighbors=16, num_layers=3, num_classes=7, sub_sampling_ratio=[4, 4, 4], in_channels=3,
+              dim_features=8, dim_output=[16, 64, 128])
+
+
 def _model(cfg, sd):
     from ml3d.torch.models.randlanet import RandLANet
     assert torch.cuda.is_available()
@@ -37,7 +42,7 @@ def _run(cfg, sd, pts, feats):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg,B,N,seed", [(KITTI, 2, 4096, 1), (SMALL, 3, 1030, 2), (FIVE, 1, 8192, 3)])
+@pytest.mark.parametrize("cfg,B,N,seed", [(KITTI, 2, 4096, 1), (SMALL, 3, 1030, 2), (FIVE, 1, 8192, 3), (RAGGED, 3, 1100, 4)])
 def test_forward_matches_oracle(cfg, B, N, seed):
     rng = np.random.default_rng(seed)
     pts = np.stack([synth_data.semantickitti_patch(50 + seed * 10 + b, N) for b in range(B)])
