@@ -54,7 +54,9 @@ struct RowsLoader {
         if (k < K) return c.p2 ? c.p2[k - A.k1] : 0.f;
         return 0.f;
     }
-    __device__ __forceinline__ float4 load4(const Ctx& c, int k) const {
+    // k0 = the K chunk's first column (wave-uniform), kq = this thread's offset inside the chunk
+    __device__ __forceinline__ float4 load4(const Ctx& c, int k0, int kq) const {
+        const int k = k0 + kq;
         if (vec) {
             if (k < A.k1) return c.p1 ? *reinterpret_cast<const float4*>(c.p1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < K) return c.p2 ? *reinterpret_cast<const float4*>(c.p2 + (k - A.k1)) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -68,6 +70,7 @@ struct ConvLoader {
     ConvA A;
     int64_t M;
     int K;
+    int chunk_uniform;   // 1: C % 32 == 0, so a 32-wide K chunk lies inside ONE (ky, kx) tap and the tap is wave-uniform
     struct Ctx { const float* img; int iy0, ix0; };
     __device__ __forceinline__ Ctx prepare(int64_t m) const {
         Ctx c; c.img = nullptr; c.iy0 = 0; c.ix0 = 0;
@@ -83,10 +86,17 @@ struct ConvLoader {
         return c;
     }
     // C % 4 == 0: the 4 consecutive k share (ky, kx)
-    __device__ __forceinline__ float4 load4(const Ctx& c, int k) const {
+    __device__ __forceinline__ float4 load4(const Ctx& c, int k0, int kq) const {
+        const int k = k0 + kq;
         if (!c.img || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        int ci = k % A.C;
-        int kk = k / A.C;
+        int ci, kk;
+        if (chunk_uniform) {          // tap from the chunk origin only: scalar arithmetic, no per-lane divisions
+            kk = k0 / A.C;
+            ci = k0 - kk * A.C + kq;
+        } else {
+            ci = k % A.C;
+            kk = k / A.C;
+        }
         int kx = kk % A.KW, ky = kk / A.KW;
         int iy = c.iy0 + ky, ix = c.ix0 + kx;
         if (iy < 0 || iy >= A.H || ix < 0 || ix >= A.W) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,8 +140,8 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     };
     auto fetch = [&](int k0) {
         const int ka = k0 + aq;
-        ra0 = ka < ke ? L.load4(c0, ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ra1 = ka < ke ? L.load4(c1, ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra0 = ka < ke ? L.load4(c0, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra1 = ka < ke ? L.load4(c1, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
         rb0 = load_b(k0 + br);
         rb1 = load_b(k0 + 16 + br);
     };
@@ -300,6 +310,7 @@ int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float*
     L.A = A;
     L.M = (int64_t)A.B * A.OH * A.OW;
     L.K = A.KH * A.KW * A.C;
+    L.chunk_uniform = (A.C % GM_KC) == 0 ? 1 : 0;
     return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
 }
 
