@@ -127,6 +127,29 @@ def main():
     c = cpu_ms(lambda: oops.nms(bx, sc, 0.3))
     report("nms(4096 boxes)", "latency-bound; bytes = boxes + bit mask", n * 24 + n * n // 8, g, c)
 
+    # ---- raw-sweep front end (row f3): subsample 0.06 + features/labels + raw->sub 1-NN projection ----------------
+    from ml3d.datasets import preprocess_sweep
+    rng = np.random.default_rng(9)
+    data = {"point": sweep[:, :3], "feat": rng.random((len(sweep), 1), dtype=np.float32),
+            "label": rng.integers(0, 20, len(sweep)).astype(np.int32)}
+    o = preprocess_sweep(data, 0.06, "test")
+    g = gpu_ms(lambda: preprocess_sweep(data, 0.06, "test"), max(3, iters // 4))
+
+    def cpu_front():
+        sp_, sf_, sl_ = oops.subsample(data["point"], features=data["feat"], classes=data["label"], sampleDl=0.06)
+        return oops.knn_search(sp_, data["point"], 1)
+    c = cpu_ms(cpu_front)
+    report("preprocess_sweep (f3, incl. H2D/D2H of the sweep)", "%d -> %d points + proj_inds" % (len(sweep), o["point"].shape[0]),
+           len(sweep) * (12 + 4 + 4 + 4) + o["point"].shape[0] * 20, g, c)
+
+    # ---- patch sampler query (row f1): the 45 056 nearest points to a centre -----------------------------------------
+    subp = t(o["point"])
+    ctr = torch.tensor(o["point"][len(o["point"]) // 2])
+    if subp.shape[0] >= 45056:
+        g = gpu_ms(lambda: ops.nearest_to_center(subp, ctr, 45056), iters)
+        c = cpu_ms(lambda: oops.knn_search(o["point"], o["point"][len(o["point"]) // 2][None], 45056))
+        report("nearest_to_center(k=45056) (f1)", "%d sub-sampled points" % subp.shape[0], subp.shape[0] * 12 + 45056 * 4, g, c)
+
 
 if __name__ == "__main__":
     main()
