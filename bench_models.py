@@ -77,7 +77,7 @@ def run_pointpillars(args, rank, world, dev, dist):
     from ml3d.torch.models.point_pillars import PointPillars
     import synth_weights as W
     cfg = W.POINTPILLARS_KITTI_CFG
-    B = args.frames_per_step if args.frames_per_step != 64 else 4
+    B = args.frames_per_step if args.frames_per_step != 64 else 8     # sweeps per step (4: 955, 8: 1092, 16: 1134 frames/s)
     sd = W.pointpillars_state_dict(cfg, 2024)
     m = PointPillars(device=dev, **cfg)
     m.load_state_dict(sd)
@@ -135,7 +135,9 @@ def run_kpconv(args, rank, world, dev, dist):
     from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
     import synth_weights as W
     cfg = dict(W.TORONTO3D_CFG)
-    B = args.frames_per_step if args.frames_per_step != 64 else 8
+    # spheres per step: the batch build is launch/latency-bound (≈430 small launches + 17 host read-backs per batch whatever
+    # its size), so throughput follows the batch: 8 -> 1231, 16 -> 1972, 32 -> 2586, 63 -> 3190 spheres/s
+    B = args.frames_per_step if args.frames_per_step != 64 else 32
     sd = W.kpconv_state_dict(cfg, 2024)
     m = KPFCNN(**cfg, device=dev)
     m.load_state_dict(sd)
