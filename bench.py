@@ -245,7 +245,7 @@ def main():
             bd = {}
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); b.record()
-            tags_f = [1000] + [8 * l + s for l in range(CFG["num_layers"]) for s in range(7)] + [1001] + \
+            tags_f = [1000] + [8 * l + s for l in range(CFG["num_layers"]) for s in range(8)] + [1001] + \
                      [1100 + i for i in range(CFG["num_layers"])] + [1200, 1201, 1202]
             e1 = eng.eng[0] if overlap else eng        # kernels timed one at a time, nothing else on the GPU
             for tg in tags_f:

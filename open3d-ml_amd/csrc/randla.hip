@@ -125,6 +125,7 @@ struct LfaArgs {
     int d_in;
     float* out;                // stage 1: p1 [m, h]; stage 2: enc [m, 2d]
     int64_t xcd_chunk;         // > 0: XCD-aware tile walk, tiles per chunk (see xcd_tile)
+    const float* gscore;       // optional [m, d]: gfeat . score_WT[0:h, :] per POINT (see lfa_attn_pf<.., SPLIT>)
 };
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, observed), and each XCD has its
@@ -622,7 +623,13 @@ static size_t mfma_smem_bytes() {
 // weights move from registers to LDS (B operand by ds_read) to make room for the in-flight registers,
 // and with lse2 in place (H <= 32) the lse1 -> lse2 hand-off is inside one wave: 3 barriers per tile.
 // ------------------------------------------------------------------------------------------------
-template <int D, int STAGE>
+// SPLIT: the score Linear acts on X = [gathered neighbour features | encoded positions], and its first half is linear
+// in a PER-POINT quantity: W . [f[nb] ; r] = (W_top . f)[nb] + W_bot . r.  With A.gscore = f . W_top^T precomputed
+// per point by one small GEMM (1/16 of the work it replaces), the kernel gathers the neighbour's gscore row straight
+// into the accumulator layout (32 lanes read 128 contiguous bytes of a row) and runs the MFMAs over K = H instead
+// of D: half the score MFMAs and half the resident weight registers.  f[nb] is still gathered into X for the
+// weighted sum.  Used for D >= 128, where the extra D floats per neighbour are small next to the MFMA time saved.
+template <int D, int STAGE, bool SPLIT>
 __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D>::THREADS / 256))) lfa_attn_pf(LfaArgs A) {
     using C = MfmaCfg<D>;
     constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
@@ -636,14 +643,16 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
     float* REL = R1 + ((STAGE == 2 && !C::INPLACE) ? ROWS * RP : 0);   // [ROWS][12]
     float* W1 = REL + ROWS * 12;                                  // [12][HP]
     float* W2 = W1 + 12 * HP;                                     // [H][HP]      (stage 2)
+    uint32_t* NROWG = reinterpret_cast<uint32_t*>(W2 + (STAGE == 2 ? H * HP : 0));   // [ROWS] global neighbour row (SPLIT)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
 
     const int ct = wave % C::NT, rg = wave / C::NT;
-    float bs[D / 2];
+    constexpr int KS = SPLIT ? H : D, K0 = SPLIT ? H : 0;         // score MFMAs run over input channels [K0, K0 + KS)
+    float bs[KS / 2];
 #pragma unroll
-    for (int s = 0; s < D / 2; ++s) bs[s] = A.score_wt[(hi * (D / 2) + s) * D + ct * 32 + col];
+    for (int s = 0; s < KS / 2; ++s) bs[s] = A.score_wt[(K0 + hi * (KS / 2) + s) * D + ct * 32 + col];
     const float sbias = A.score_b[ct * 32 + col];
     const int ct2 = wave % C::NT2, rg2 = wave / C::NT2;
     const int col2 = ct2 * 32 + col;
@@ -681,6 +690,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
     float4 gq[G];                        // hop 3: gathered feature pieces
     float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;   // hop 2
     bool mine_valid = false;
+    uint32_t grow_mine = 0;              // global row of this thread's neighbour (SPLIT)
     // (per-tile bookkeeping is wave-uniform and 32-bit: f32 MFMA and VALU share the SIMD's issue cycles on gfx950, so a
     //  64-bit division per lane per tile costs as much as two MFMAs; the launcher guarantees m_total, n0 < 2^30, n >= TP)
     const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
@@ -713,6 +723,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             if (mine_valid) {
                 const uint32_t lp = l0 + (uint32_t)(tid / RK);
                 const bool wrap = lp >= n_pts;
+                grow_mine = (b0 + (wrap ? 1u : 0u)) * n_pts + (uint32_t)nb_mine;
                 const float* xb = A.xyz + 3 * ((int64_t)(b0 + (wrap ? 1u : 0u)) * A.n0);
                 const float* qp = xb + 3 * (wrap ? lp - n_pts : lp);
                 const float* sp = xb + 3 * (uint32_t)nb_mine;
@@ -745,6 +756,9 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                 for (int j = 0; j < 10; ++j) r[j] = 0.f;
             }
             r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
+            // byte offset of the neighbour's gscore row (the launcher keeps m * D * 4 below 2^32); rows past the end of
+            // the data read row 0 -- their scores feed outputs that are never stored
+            if constexpr (SPLIT) NROWG[tid] = mine_valid ? grow_mine * (uint32_t)(D * 4) : 0u;
         }
         if (nxt >= 0) request_idx((uint32_t)nxt);
         block_sync_lds();
@@ -806,7 +820,25 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias;
-            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
+            float gs[SPLIT ? 16 : 1];
+            if constexpr (SPLIT) {
+                // the neighbours' per-point score halves, requested before the MFMA chain and added after it
+                const char* gbase = reinterpret_cast<const char*>(A.gscore + ct * 32);    // wave-uniform base
+                const uint32_t col4 = 4u * col;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const uint4 nr = *reinterpret_cast<const uint4*>(NROWG + rt * 32 + 8 * q4 + 4 * hi);   // rows mfma_row(4 q4 .. 4 q4 + 3)
+                    gs[4 * q4 + 0] = *reinterpret_cast<const float*>(gbase + (nr.x + col4));
+                    gs[4 * q4 + 1] = *reinterpret_cast<const float*>(gbase + (nr.y + col4));
+                    gs[4 * q4 + 2] = *reinterpret_cast<const float*>(gbase + (nr.z + col4));
+                    gs[4 * q4 + 3] = *reinterpret_cast<const float*>(gbase + (nr.w + col4));
+                }
+            }
+            acc = mfma_rows<KS, XP>(X + (rt * 32 + col) * XP + K0 + hi * (KS / 2), bs, acc);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += gs[r];
+            }
             const float* xc = X + (rt * 32) * XP + ct * 32 + col;
             float num[2], den[2];
             // point pt of the row tile: rows 16 pt + 4 hi + {0..3, 8..11}
@@ -826,7 +858,7 @@ static size_t pf_smem_bytes() {
     using C = MfmaCfg<D>;
     constexpr int HP = C::NT2 * 32;
     return ((size_t)C::ROWS * C::XP + ((STAGE == 2 && !C::INPLACE) ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12 +
-            12 * HP + (STAGE == 2 ? (size_t)C::H * HP : 0)) * 4;
+            12 * HP + (STAGE == 2 ? (size_t)C::H * HP : 0) + (size_t)C::ROWS) * 4;
 }
 
 
@@ -1096,9 +1128,18 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
         size_t sm = pf_smem_bytes<D, STAGE>();
         if (sm > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
             return ML3D_E_LAUNCH;
-        hipLaunchKernelGGL((lfa_attn_pf<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
+        if constexpr (D >= 128) {
+            if (a.gscore) {
+                if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE, true>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+                    return ML3D_E_LAUNCH;
+                hipLaunchKernelGGL((lfa_attn_pf<D, STAGE, true>), dim3(grid), dim3(C::THREADS), sm, st, a);
+                return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL((lfa_attn_pf<D, STAGE, false>), dim3(grid), dim3(C::THREADS), sm, st, a);
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
     size_t sm = mfma_smem_bytes<D, STAGE>();
@@ -2167,6 +2208,20 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             float* agg = take(M * dd);
             float* p2 = take(M * dd);
             LfaArgs q1 = s1; q1.out = agg;
+            // D >= 128: the feature half of the score Linear once per POINT (gscore = f . W_top^T, into the p2 scratch,
+            // which is otherwise idle until pool2), gathered by the attention kernel instead of recomputed per neighbour
+            static const bool split_on = !(getenv("ML3D_ATTN_SPLIT") && getenv("ML3D_ATTN_SPLIT")[0] == '0');
+            const bool split = split_on && dd >= 128 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32);
+            auto point_scores = [&](const float* gfeat, const float* score_wt, int tag) -> int {
+                RowsA Ar = {};
+                Ar.a = gfeat; Ar.lda = h; Ar.k1 = h;
+                Epilogue ep = {};
+                T.begin(tag);
+                const int r = gemm_rows(Ar, score_wt, M, dd, h, ep, p2, dd, nullptr, 0, st);   // first h rows of [d][d]
+                T.end(tag);
+                return r;
+            };
+            if (split) { rc = point_scores(f1, s1.score_wt, 8 * l + 7); if (rc) return rc; q1.gscore = p2; }
             T.begin(8 * l + 1);
             switch (dd) {
                 case 16: rc = launch_attn_mfma16<1>(q1, st); break;
@@ -2184,6 +2239,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
                 T.begin(8 * l + 4); rc = launch_linear_auto(a, st); T.end(8 * l + 4); if (rc) return rc;
             }
             LfaArgs q2 = s2; q2.out = agg;
+            if (split) { rc = point_scores(p1, s2.score_wt, 8 * l + 7); if (rc) return rc; q2.gscore = p2; }
             T.begin(8 * l + 2);
             switch (dd) {
                 case 16: rc = launch_attn_mfma16<2>(q2, st); break;
