@@ -883,11 +883,14 @@ struct WaveAttnCfg {
     static constexpr int Q = H / 4;                  // float4 pieces per gathered row
     static constexpr int G = 32 * Q / 64;            // pieces per lane
     static constexpr int W = D == 64 ? 12 : 16;      // waves per workgroup
-    static constexpr int PATCH = 32 * XP + 32 * 12;  // floats per wave
+    static constexpr int PATCH = 32 * XP + 32 * 12 + 32;  // floats per wave: X, relative positions, gscore row offsets
     static constexpr int WFLOATS = D * D + H * 32 + 12 * 32;
 };
 
-template <int D, int STAGE>
+// SPLIT (see lfa_attn_pf): A.gscore = f . W_top^T + score bias per POINT; the neighbours' rows are gathered straight
+// into the score accumulators (requested before the lse phases, so they land under those MFMAs) and the score MFMAs
+// run over the position half of X only (K = H): 32 instead of 64 MFMAs per tile at D = 64.
+template <int D, int STAGE, bool SPLIT>
 __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArgs A) {
     using C = WaveAttnCfg<D>;
     constexpr int H = C::H, XP = C::XP, Q = C::Q, G = C::G, NT = C::NT;
@@ -900,8 +903,10 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
     const int hi = lane >> 5, col = lane & 31;
     float* X = W1 + 12 * 32 + wave * C::PATCH;        // [32][XP]  this wave's tile
     float* REL = X + 32 * XP;                         // [32][12]
+    uint32_t* GOFF = reinterpret_cast<uint32_t*>(REL + 32 * 12);   // [32] byte offset of each row's gscore row (SPLIT)
+    constexpr int KS = SPLIT ? H : D, K0 = SPLIT ? H : 0;          // score MFMAs run over input channels [K0, K0 + KS)
 
-    for (int e = tid; e < D * D; e += C::W * 64) WS[e] = A.score_wt[e];
+    for (int e = tid; e < KS * D; e += C::W * 64) WS[e] = A.score_wt[K0 * D + e];
     for (int e = tid; e < H * 32; e += C::W * 64) {
         const int k = e >> 5, c = e & 31;
         W2[e] = (STAGE == 2 && c < H) ? A.lse2_wt[k * H + c] : 0.f;
@@ -913,7 +918,7 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
     }
     float sbias[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sbias[t] = A.score_b[t * 32 + col];
+    for (int t = 0; t < NT; ++t) sbias[t] = SPLIT ? 0.f : A.score_b[t * 32 + col];    // (SPLIT: the bias is inside gscore)
     const float l2bias = (STAGE == 2 && col < H) ? A.lse2_b[col] : 0.f;
     __syncthreads();                                  // the only workgroup barrier
 
@@ -941,6 +946,7 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
     float4 gq[G];
     float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     bool mine_valid = false;
+    uint32_t goff_mine = 0;
     auto request_idx = [&](uint32_t tile) {
         const int32_t* nb = A.nidx + (int64_t)tile * 2 * RK;      // 32 contiguous (point, neighbour) rows
         const uint32_t lim = (m_tot - tile * 2) >= 2 ? 32u : 16u; // rows of the tile that exist
@@ -969,6 +975,7 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
         mine_valid = lane < 32 && nb_mine >= 0;
         if (mine_valid) {
             const bool p1 = lane >= RK;
+            goff_mine = ((p1 ? b1 : b0) * n_pts + (uint32_t)nb_mine) * (uint32_t)(D * 4);
             const float* xb = A.xyz + 3 * ((int64_t)(p1 ? b1 : b0) * A.n0);
             const float* qp = xb + 3 * (p1 ? l1 : l0);
             const float* sp = xb + 3 * (uint32_t)nb_mine;
@@ -998,9 +1005,27 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
                 for (int j = 0; j < 10; ++j) r[j] = 0.f;
             }
             r[10] = 1.f; r[11] = 0.f;                             // bias slot, K padding
+            if constexpr (SPLIT) GOFF[lane] = mine_valid ? goff_mine : 0u;    // (rows past the data read row 0: never stored)
         }
         if (nxt >= 0) request_idx((uint32_t)nxt);
         wave_lds_sync();
+        f32x16 sc[NT];
+        if constexpr (SPLIT) {
+            // the neighbours' per-point score halves become the accumulators' initial value
+            const char* gbase = reinterpret_cast<const char*>(A.gscore);
+            const uint32_t col4 = 4u * col;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const uint4 go = *reinterpret_cast<const uint4*>(GOFF + 8 * q4 + 4 * hi);     // rows mfma_row(4 q4 .. 4 q4 + 3)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    sc[t][4 * q4 + 0] = *reinterpret_cast<const float*>(gbase + (go.x + col4 + 128u * t));
+                    sc[t][4 * q4 + 1] = *reinterpret_cast<const float*>(gbase + (go.y + col4 + 128u * t));
+                    sc[t][4 * q4 + 2] = *reinterpret_cast<const float*>(gbase + (go.z + col4 + 128u * t));
+                    sc[t][4 * q4 + 3] = *reinterpret_cast<const float*>(gbase + (go.w + col4 + 128u * t));
+                }
+            }
+        }
         // ---- r1 = lrelu(lse1(rel)) (K = 12) -> X[:, H:] ---------------------------------------------------
         {
             f32x16 acc;
@@ -1055,16 +1080,17 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
         }
         if (nxt >= 0) request_data((uint32_t)nxt);
         // ---- scores for all column tiles (A read once), softmax over the 16 neighbours, weighted sum --------
-        f32x16 sc[NT];
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[t][r] = sbias[t];
+                for (int r = 0; r < 16; ++r) sc[t][r] = sbias[t];
+        }
         {
-            const float* ar = X + col * XP + hi * (D / 2);
-            const float* wb = WS + hi * (D / 2) * D + col;
+            const float* ar = X + col * XP + K0 + hi * (KS / 2);
+            const float* wb = WS + hi * (KS / 2) * D + col;
 #pragma unroll
-            for (int s4 = 0; s4 < D / 8; ++s4) {
+            for (int s4 = 0; s4 < KS / 8; ++s4) {
                 const float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -1104,9 +1130,15 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     const size_t sm = sizeof(float) * ((size_t)C::WFLOATS + (size_t)C::W * C::PATCH);
-    if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL((lfa_attn_wave<D, STAGE>), dim3(grid), dim3(C::W * 64), sm, st, a);
+    if (a.gscore) {
+        if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL((lfa_attn_wave<D, STAGE, true>), dim3(grid), dim3(C::W * 64), sm, st, a);
+    } else {
+        if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL((lfa_attn_wave<D, STAGE, false>), dim3(grid), dim3(C::W * 64), sm, st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
@@ -1535,7 +1567,7 @@ __global__ void __launch_bounds__(256, 2) mlp_wave(ChainArgs A, WaveMlpMeta M) {
         }
         for (int c = tid; c < np; c += 256) {
             float b = 0.f;
-            if (c < Ly.cout) { b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
+            if (c < Ly.cout) { if (Ly.bias) b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
             smem[M.b_off[l] + c] = b;
         }
     }
@@ -1769,7 +1801,7 @@ __global__ void __launch_bounds__(NW * 64, 2) mlp_wave_s(ChainArgs A) {
         }
         for (int c = tid; c < np; c += NW * 64) {
             float b = 0.f;
-            if (c < Ly.cout) { b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
+            if (c < Ly.cout) { if (Ly.bias) b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
             smem[S::b_off(l) + c] = b;
         }
     }
@@ -1854,6 +1886,7 @@ typedef MlpShape<16, 0, -1, 0, 1, 8, 0, 0, 0> ShapeLin16x8;         // pool1.mlp
 typedef MlpShape<8, 0, -1, 0, 1, 8, 0, 0, 0> ShapeLin8x8;           // mlp1 of the first encoder layer
 typedef MlpShape<64, 0, -1, 0, 1, 32, 0, 0, 0> ShapeLin64x32;       // pool1.mlp of the second
 typedef MlpShape<32, 0, -1, 0, 1, 32, 0, 0, 0> ShapeLin32x32;       // mlp1 of the second
+typedef MlpShape<32, 0, -1, 0, 1, 64, 0, 0, 0> ShapeLin32x64;       // per-point score half (gscore) of the second
 
 template <class S>
 static bool mlp_shape_matches(const ChainArgs& a) {
@@ -2009,6 +2042,7 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         if (a.cout == 8 && mlp_shape_matches<ShapeLin8x8>(c)) return launch_mlp_wave_s<ShapeLin8x8, 8>(c, st);
         if (a.cout == 32 && mlp_shape_matches<ShapeLin64x32>(c)) return launch_mlp_wave_s<ShapeLin64x32, 8>(c, st);
         if (a.cout == 32 && mlp_shape_matches<ShapeLin32x32>(c)) return launch_mlp_wave_s<ShapeLin32x32, 8>(c, st);
+        if (a.cout == 64 && mlp_shape_matches<ShapeLin32x64>(c)) return launch_mlp_wave_s<ShapeLin32x64, 8>(c, st);
     }
     if (!(e && (e[0] == 'c' || e[0] == 'v')) && a.c0 + a.c1 >= 8) {
         RowsA A;
@@ -2211,17 +2245,19 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             // D >= 128: the feature half of the score Linear once per POINT (gscore = f . W_top^T, into the p2 scratch,
             // which is otherwise idle until pool2), gathered by the attention kernel instead of recomputed per neighbour
             static const bool split_on = !(getenv("ML3D_ATTN_SPLIT") && getenv("ML3D_ATTN_SPLIT")[0] == '0');
-            const bool split = split_on && dd >= 128 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32);
-            auto point_scores = [&](const float* gfeat, const float* score_wt, int tag) -> int {
-                RowsA Ar = {};
-                Ar.a = gfeat; Ar.lda = h; Ar.k1 = h;
-                Epilogue ep = {};
+            const bool split = split_on && dd >= 32 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32) &&
+                               M < ((int64_t)1 << 30);
+            // (the per-wave kernels of D <= 64 take the score bias inside gscore, the workgroup kernels add it themselves)
+            auto point_scores = [&](const float* gfeat, const float* score_wt, const float* score_b, int tag) -> int {
+                LinArgs ga = {};
+                ga.a0 = gfeat; ga.c0 = h; ga.wt = score_wt; ga.bias = dd <= 64 ? score_b : nullptr; ga.out = p2;   // first h rows of [d][d]
+                ga.m_total = M; ga.cout = dd; ga.act = 0;
                 T.begin(tag);
-                const int r = gemm_rows(Ar, score_wt, M, dd, h, ep, p2, dd, nullptr, 0, st);   // first h rows of [d][d]
+                const int r = launch_linear_auto(ga, st);
                 T.end(tag);
                 return r;
             };
-            if (split) { rc = point_scores(f1, s1.score_wt, 8 * l + 7); if (rc) return rc; q1.gscore = p2; }
+            if (split) { rc = point_scores(f1, s1.score_wt, s1.score_b, 8 * l + 7); if (rc) return rc; q1.gscore = p2; }
             T.begin(8 * l + 1);
             switch (dd) {
                 case 16: rc = launch_attn_mfma16<1>(q1, st); break;
@@ -2239,7 +2275,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
                 T.begin(8 * l + 4); rc = launch_linear_auto(a, st); T.end(8 * l + 4); if (rc) return rc;
             }
             LfaArgs q2 = s2; q2.out = agg;
-            if (split) { rc = point_scores(p1, s2.score_wt, 8 * l + 7); if (rc) return rc; q2.gscore = p2; }
+            if (split) { rc = point_scores(p1, s2.score_wt, s2.score_b, 8 * l + 7); if (rc) return rc; q2.gscore = p2; }
             T.begin(8 * l + 2);
             switch (dd) {
                 case 16: rc = launch_attn_mfma16<2>(q2, st); break;
