@@ -51,6 +51,18 @@ def lfa_flops(cfg, layer, stage, n_points):
     return 2.0 * mac * n_points
 
 
+def lfa_flops_executed(cfg, layer, stage, n_points):
+    """Flops the attention kernel EXECUTES for the same result: the feature half of the score Linear is linear in a
+    per-point quantity, W . [f[nb] ; r] = (W_top . f)[nb] + W_bot . r, so the kernel gathers a precomputed per-point
+    row and multiplies only the position half (K x h x d); stage 2 re-computes lse1 (K x 10 x h).  The per-point GEMM
+    (h x d per point, 1/16 of what it replaces) runs in its own launch and is not part of this kernel's time."""
+    d = cfg["dim_output"][layer]
+    h = d // 2
+    K = cfg["num_neighbors"]
+    mac = K * 10 * h + (K * h * h if stage == 2 else 0) + K * h * d + K * d
+    return 2.0 * mac * n_points
+
+
 def knn_bytes(cfg, n0):
     """Algorithmic HBM bytes of the neighbour pyramid per frame (SURVEY.md §8d row a1, int32 indices)."""
     n, tot = n0, 0
@@ -212,6 +224,7 @@ def main():
         layer, stage = DOMINANT_FWD_TAG // 8, DOMINANT_FWD_TAG % 8
         n_l = eng.n[layer] * B
         flops = lfa_flops(CFG, layer, stage, n_l)
+        flops_exec = lfa_flops_executed(CFG, layer, stage, n_l)
         achieved = flops / (dom_ms * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 gfx950 correction +
         # WRITE_SIZE, KiB -> bytes; profiles/r01_*_pmc_{fetch,write}.csv), scaled to this run's frames per step
@@ -236,7 +249,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "lfa_attn_wave<%d,%d> (layer %d)" % (CFG["dim_output"][layer], stage, layer),
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic, "avg_launch_ms": dom_ms,
-                         "flops_per_launch": flops},
+                         "flops_per_launch": flops,
+                         # same launch priced on the flops it executes after the algebraic split of the score Linear
+                         "executed_flops_per_launch": flops_exec,
+                         "frac_executed": flops_exec / (dom_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
             "roofline_knn": {"bound": "hbm", "kernel": "knn_query_multi<16> (all pyramid levels)", "achieved": kb / (knn_ms * 1e-3) / 1e9,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kb / (knn_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                              "avg_launch_ms": knn_ms, "bytes_per_launch": kb, "traffic": None},

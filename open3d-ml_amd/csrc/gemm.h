@@ -31,6 +31,11 @@ struct Epilogue {
     // (b, y*ps + dy, x*ps + dx), channel co, of an NHWC map whose pixel stride is ldc.  bias is indexed by co.
     int ps, ps_h, ps_w, ps_cout;
     const float* bias2;       // [N] or null: a second bias (two Linears summed into one GEMM over concatenated inputs)
+    // gathered residual: when set, the residual row of output row m is
+    //   (m / rg_rows_per_item) * rg_src_rows_per_item + res_gather[m]      (rg_rows_per_item >= 64)
+    // -- the per-COARSE-point half of "nearest upsample + concat + Linear" added back through the upsampling index
+    const int32_t* res_gather;
+    int64_t rg_rows_per_item, rg_src_rows_per_item;
 };
 
 // dense / gathered / concatenated rows

@@ -213,12 +213,25 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     }
     float b = ep.bias ? ep.bias[col] : 0.f;
     if (ep.bias2) b += ep.bias2[col];
+    // gathered residual: the tile's first row fixes the item (scalar division); a 64-row tile crosses items at most once
+    int64_t rg_base = 0, rg_l0 = 0;
+    if (ep.res_gather) {
+        const int64_t item0 = m0 / ep.rg_rows_per_item;
+        rg_l0 = m0 - item0 * ep.rg_rows_per_item;
+        rg_base = item0 * ep.rg_src_rows_per_item;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + rt * 32 + mfma32_row(r, hi);
+        const int lr = rt * 32 + mfma32_row(r, hi);
+        const int64_t m = m0 + lr;
         if (m < L.M) {
             float v = acc[r] + b;
-            if (ep.residual) v += ep.residual[m * ep.ldr + col];
+            if (ep.residual) {
+                int64_t rr = m;
+                if (ep.res_gather)
+                    rr = rg_base + (rg_l0 + lr >= ep.rg_rows_per_item ? ep.rg_src_rows_per_item : 0) + ep.res_gather[m];
+                v += ep.residual[rr * ep.ldr + col];
+            }
             C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
         }
     }
@@ -245,7 +258,11 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
             continue;
         }
         if (ep.bias) v += ep.bias2 ? ep.bias[col] + ep.bias2[col] : ep.bias[col];
-        if (ep.residual) v += ep.residual[m * ep.ldr + col];
+        if (ep.residual) {
+            int64_t rr = m;
+            if (ep.res_gather) rr = (m / ep.rg_rows_per_item) * ep.rg_src_rows_per_item + ep.res_gather[m];
+            v += ep.residual[rr * ep.ldr + col];
+        }
         C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
     }
 }

@@ -2142,7 +2142,10 @@ static size_t fwd_ws_floats(const ml3d_randla_desc* d) {
     f += al(B * n[d->num_layers] * Dm);
     int ed[ML3D_RANDLA_MAX_LAYERS + 1];
     enc_dims(d, ed);
-    for (int i = 0; i < d->num_layers; ++i) f += al(B * n[d->num_layers - 1 - i] * ed[d->num_layers + 1 - i - 2]);
+    for (int i = 0; i < d->num_layers; ++i) {
+        const int lev = d->num_layers - 1 - i, skip_c = ed[d->num_layers + 1 - i - 2];
+        f += al(B * n[lev] * skip_c) + al(B * n[lev + 1] * skip_c);    // stage output + per-coarse-point half (decoder split)
+    }
     f += al(B * n[0] * 64) + al(B * n[0] * 32);
     return (size_t)f;
 }
@@ -2387,7 +2390,27 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
                 return rc;
             }
         }
-        T.begin(1100 + i); int rc = launch_linear_auto(a, st); T.end(1100 + i); if (rc) return rc;
+        // W . [skip ; up[idx]] = W_skip . skip + (W_up . up)[idx]: the upsampled half is linear in a per-COARSE-point
+        // quantity, computed once per coarse point (1/ratio of the rows) and added back through the interpolation index
+        // as a gathered residual of the skip GEMM
+        static const bool dec_split = !(getenv("ML3D_DEC_SPLIT") && getenv("ML3D_DEC_SPLIT")[0] == '0');
+        if (dec_split && !force_valu && n[lev] >= 64 && (skip_c & 3) == 0 && (cprev & 3) == 0 && skip_c >= 8) {
+            float* up = take(B * n[lev + 1] * skip_c);
+            RowsA Au = {};
+            Au.a = cur; Au.lda = cprev; Au.k1 = cprev;
+            Epilogue e0 = {};
+            T.begin(1100 + i);
+            int rc = gemm_rows(Au, a.wt + (int64_t)skip_c * skip_c, B * n[lev + 1], skip_c, cprev, e0, up, skip_c, nullptr, 0, st);
+            if (rc) return rc;
+            RowsA As = {};
+            As.a = a.a0; As.lda = skip_c; As.k1 = skip_c;
+            Epilogue e1 = {a.bias, up, skip_c, 1, 0.2f, 0, 0, 0, 0, nullptr, a.gather, n[lev], n[lev + 1]};
+            rc = gemm_rows(As, a.wt, a.m_total, skip_c, skip_c, e1, outp, skip_c, nullptr, 0, st);
+            T.end(1100 + i);
+            if (rc) return rc;
+        } else {
+            T.begin(1100 + i); int rc = launch_linear_auto(a, st); T.end(1100 + i); if (rc) return rc;
+        }
         slot += 2;
         cur = outp;
         cprev = skip_c;
