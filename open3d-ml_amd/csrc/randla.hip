@@ -953,9 +953,9 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
-            gi[i] = row < lim ? nb[row] : -1;
+            gi[i] = row < lim ? __builtin_nontemporal_load(nb + row) : -1;
         }
-        nb_mine = (uint32_t)lane < lim ? nb[lane] : -1;           // (lanes 32-63: unused duplicates of rows 0-31's upper half)
+        nb_mine = (uint32_t)lane < lim ? __builtin_nontemporal_load(nb + lane) : -1;
     };
     auto request_data = [&](uint32_t tile) {
         // the tile's two points: cloud b0 / local index l0, and its successor (possibly the next cloud's first point)
@@ -1112,7 +1112,9 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
             softmax_wsum8<XP>(sc[t], 0, xc + (4 * hi) * XP, num[0], den[0]);
             softmax_wsum8<XP>(sc[t], 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
             const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
-            if (m < m_tot) A.out[(int64_t)m * D + 32 * t + col] = agg_mine;
+            // streaming data (the output rows, the neighbour indices) goes around the L2's LRU: the XCD's 4 MB are for the
+            // cloud's gathered rows (features + gscore), which every tile re-reads at random
+            if (m < m_tot) __builtin_nontemporal_store(agg_mine, A.out + (int64_t)m * D + 32 * t + col);
         }
         wave_lds_sync();                                          // the patch is rewritten at the top of the loop
         cur = nxt;

@@ -224,6 +224,7 @@ static inline unsigned long long __ballot(int pred) {
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_fence(int, const char*, const char*) {}
 static inline void __builtin_amdgcn_iglp_opt(int) {}
+// (clang provides __builtin_nontemporal_load/store on the host as well)
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_wave_barrier() { int z = 0; (void)hipemu::wave_exchange(&z, sizeof(z)); }
