@@ -360,11 +360,7 @@ static int device_cu_count() {
     return cus;
 }
 
-#ifdef ML3D_ATTN_FULLSYNC
-#define SYNC_ATTN() __syncthreads()
-#else
-#define SYNC_ATTN() block_sync_lds()
-#endif
+#define SYNC_ATTN() block_sync_lds()   // LDS-only workgroup barrier (grid.h): global loads / stores stay in flight
 
 template <int D>
 struct MfmaCfg {
@@ -400,9 +396,6 @@ __device__ __forceinline__ f32x16 mfma_rows(const float* a_row /* &A[row][hi*KD/
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * s4 + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * s4 + 3], acc, 0, 0, 0);
     }
-#ifdef ML3D_ATTN_IGLP
-    __builtin_amdgcn_iglp_opt(0);
-#endif
     return acc;
 }
 
@@ -562,13 +555,6 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias;
             const float* xc = X + (rt * 32) * XP + ct * 32 + col;
-#ifdef ML3D_ATTN_XV
-            // the lane's 16 feature values for the weighted sum are independent of the scores: request them
-            // up front so their LDS latency runs under the MFMA chain
-            float xv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = xc[mfma_row(r, hi) * XP];
-#endif
             acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
             float agg_mine = 0.f;
 #pragma unroll
@@ -582,11 +568,7 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
                 for (int r = 0; r < 8; ++r) {
                     float e = __expf(acc[8 * pt + r] - mx);
                     sum += e;
-#ifdef ML3D_ATTN_XV
-                    ag = fmaf(e, xv[8 * pt + r], ag);
-#else
                     ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
-#endif
                 }
                 sum += __shfl_xor(sum, 32);
                 ag += __shfl_xor(ag, 32);
@@ -1100,9 +1082,6 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
                     sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wb[(4 * s4 + 3) * D + 32 * t], sc[t], 0, 0, 0);
                 }
             }
-#ifdef ML3D_WAVE_IGLP
-            __builtin_amdgcn_iglp_opt(0);
-#endif
         }
         const uint32_t m = (uint32_t)cur * 2 + hi;               // half 0 stores point 0, half 1 point 1
 #pragma unroll
@@ -1128,7 +1107,7 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     static const int cus = device_cu_count();
     int64_t blocks = (tiles + C::W - 1) / C::W;
     unsigned grid = (unsigned)(blocks < cus ? blocks : cus);     // one 12/16-wave workgroup per CU (LDS-bound)
-    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     const size_t sm = sizeof(float) * ((size_t)C::WFLOATS + (size_t)C::W * C::PATCH);
@@ -1151,14 +1130,14 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     static const int grid_cap = getenv("ML3D_ATTN_GRID") ? atoi(getenv("ML3D_ATTN_GRID")) : 2560;   // tuning knob
     int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
     unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
-    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    static const bool wave_on = !(getenv("ML3D_ATTN_WAVE") && getenv("ML3D_ATTN_WAVE")[0] == '0');   // A/B knob
+    const bool wave_on = !(getenv("ML3D_ATTN_WAVE") && getenv("ML3D_ATTN_WAVE")[0] == '0');   // A/B knob
     if constexpr (D <= 64) {
         if (wave_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30) return launch_attn_wave<D, STAGE>(a, st);
     }
-    static const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
+    const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
     if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
         size_t sm = pf_smem_bytes<D, STAGE>();
         if (sm > 48 * 1024 &&
@@ -1355,7 +1334,7 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
 template <int STAGE>
 static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
     int64_t tiles = (a.m_total + A16_TP - 1) / A16_TP;
-    static const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     static const int cap = getenv("ML3D_ATTN16_GRID") ? atoi(getenv("ML3D_ATTN16_GRID")) : 4096;
     unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
@@ -1941,8 +1920,8 @@ static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream
 
 // multi-layer chains: the barrier-free per-wave kernel when the layers are narrow, the tile kernel otherwise
 static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
-    static const bool on = !(getenv("ML3D_RANDLA_WAVE_MLP") && getenv("ML3D_RANDLA_WAVE_MLP")[0] == '0');
-    static const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
+    const bool on = !(getenv("ML3D_RANDLA_WAVE_MLP") && getenv("ML3D_RANDLA_WAVE_MLP")[0] == '0');
+    const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
     if (a.m_total > 0 && on && shaped) {
         if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
         if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
@@ -2031,7 +2010,7 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
     // default: the register-prefetching tile GEMM of gemm.hip; A/B knobs: "chain" = single-layer launch of
     // mlp_chain_mfma (no prefetch), "valu" = the scalar kernel
     const char* e = getenv("ML3D_RANDLA_LINEAR");
-    static const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
+    const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
     const char* fr_env = getenv("ML3D_RANDLA_FUSE_ROWS");           // (tests lower the row threshold to cover this path)
     if (!e && shaped && !a.a1 && a.m_total >= (fr_env ? atoll(fr_env) : 64 * 1024)) {
         // narrow Linears over many rows: the barrier-free per-wave kernel with a compiled shape
@@ -2249,7 +2228,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             LfaArgs q1 = s1; q1.out = agg;
             // D >= 128: the feature half of the score Linear once per POINT (gscore = f . W_top^T, into the p2 scratch,
             // which is otherwise idle until pool2), gathered by the attention kernel instead of recomputed per neighbour
-            static const bool split_on = !(getenv("ML3D_ATTN_SPLIT") && getenv("ML3D_ATTN_SPLIT")[0] == '0');
+            const bool split_on = !(getenv("ML3D_ATTN_SPLIT") && getenv("ML3D_ATTN_SPLIT")[0] == '0');
             const bool split = split_on && dd >= 32 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32) &&
                                M < ((int64_t)1 << 30);
             // (the per-wave kernels of D <= 64 take the score bias inside gscore, the workgroup kernels add it themselves)
@@ -2304,7 +2283,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             ch.out = enc; ch.m_total = M;
             // (wide layers -- weights beyond the LDS image of mlp_wave -- run faster as two tile GEMMs than through the
             //  barrier-per-layer chain kernel: 0.69 -> 0.35 ms at 128 channels; ML3D_RANDLA_CHAIN_WIDE=1 restores the chain)
-            static const bool chain_wide = getenv("ML3D_RANDLA_CHAIN_WIDE") && getenv("ML3D_RANDLA_CHAIN_WIDE")[0] == '1';
+            const bool chain_wide = getenv("ML3D_RANDLA_CHAIN_WIDE") && getenv("ML3D_RANDLA_CHAIN_WIDE")[0] == '1';
             WaveMlpMeta wm_probe;
             int pre_probe = 0;
             if (!no_fuse && M >= fuse_rows && chain_supported(ch) && (chain_wide || wave_mlp_supported(ch, &wm_probe, &pre_probe))) {
@@ -2386,7 +2365,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
             ch.L[2].wt = P(slot + 4); ch.L[2].bias = P(slot + 5); ch.L[2].cin = 64; ch.L[2].cout = 32; ch.L[2].act = 1; ch.L[2].slope = 0.2f;
             ch.L[3].wt = P(slot + 6); ch.L[3].bias = P(slot + 7); ch.L[3].cin = 32; ch.L[3].cout = d->num_classes; ch.L[3].act = 0;
             ch.out = out_scores; ch.m_total = a.m_total;
-            static const bool dec_fuse = !(getenv("ML3D_RANDLA_DEC_FC1") && getenv("ML3D_RANDLA_DEC_FC1")[0] == '0');
+            const bool dec_fuse = !(getenv("ML3D_RANDLA_DEC_FC1") && getenv("ML3D_RANDLA_DEC_FC1")[0] == '0');
             if (dec_fuse && mlp_shape_matches<ShapeDecFc1>(ch)) {
                 T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200);
                 return rc;
@@ -2395,7 +2374,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         // W . [skip ; up[idx]] = W_skip . skip + (W_up . up)[idx]: the upsampled half is linear in a per-COARSE-point
         // quantity, computed once per coarse point (1/ratio of the rows) and added back through the interpolation index
         // as a gathered residual of the skip GEMM
-        static const bool dec_split = !(getenv("ML3D_DEC_SPLIT") && getenv("ML3D_DEC_SPLIT")[0] == '0');
+        const bool dec_split = !(getenv("ML3D_DEC_SPLIT") && getenv("ML3D_DEC_SPLIT")[0] == '0');
         if (dec_split && !force_valu && n[lev] >= 64 && (skip_c & 3) == 0 && (cprev & 3) == 0 && skip_c >= 8) {
             float* up = take(B * n[lev + 1] * skip_c);
             RowsA Au = {};

@@ -120,6 +120,33 @@ def test_randla_forward_fused_and_unfused_linear_chains_agree(monkeypatch, ci, B
     assert rc == 0 and np.abs(unfused - ref).max() <= 1e-4
 
 
+@pytest.mark.parametrize("knobs", [
+    {"ML3D_ATTN_SPLIT": "0"},                                    # score Linear un-split (gathered features through the MFMAs)
+    {"ML3D_ATTN_WAVE": "0"},                                     # D <= 64 on the workgroup-tile prefetching kernel
+    {"ML3D_ATTN_WAVE": "0", "ML3D_ATTN_PF": "0"},                # the round's first attention kernel (reference path)
+    {"ML3D_ATTN_WAVE": "0", "ML3D_ATTN_SPLIT": "0"},
+    {"ML3D_DEC_SPLIT": "0", "ML3D_RANDLA_DEC_FC1": "0"},         # decoder as one gather+concat GEMM per stage, separate fc1
+    {"ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # runtime-shaped per-wave MLP kernel
+    {"ML3D_RANDLA_WAVE_MLP": "0", "ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # barrier-per-layer chain kernel
+    {"ML3D_ATTN_XCD": "0"},                                      # plain tile order
+])
+def test_randla_forward_kernel_variants_agree_with_oracle(monkeypatch, knobs):
+    """Every A/B knob selects a different kernel for the same math: each variant must meet the same 1e-4 gate."""
+    cfg = CFGS[0]
+    B, N = 2, 1024
+    pts = synth_data.uniform_cloud(9, B * N).reshape(B, N, 3)
+    sd = R.make_state_dict(cfg, 13)
+    inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
+    ref = R.forward(sd, cfg, inp).numpy()
+    nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
+    itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rc, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+    assert rc == 0
+    assert np.abs(out - ref).max() <= 1e-4
+
+
 def test_randla_forward_against_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "randlanet_small.npz"))
     cfg = dict(num_neighbors=16, num_layers=3, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
