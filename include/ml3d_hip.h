@@ -418,6 +418,29 @@ int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch, int64_t n
                                    void* workspace, size_t workspace_bytes, void* stream,
                                    const ml3d_trace* trace_host);
 
+/* Optional spatial tile order for the forward's attention kernels.                                  */
+/* ml3d_randla_knn_pyramid_ordered additionally writes, for every level l < num_layers whose entry of  */
+/* tile_order_host is non-NULL, tile_order[l] [batch * n_l] i32 = the point rows of level l in the     */
+/* cell-sorted order of that level's search grid (cloud-major; a permutation of 0 .. batch*n_l - 1).   */
+/* ml3d_randla_forward_ordered walks each level's attention tiles in that order (entries may be NULL): */
+/* same outputs -- the per-point arithmetic does not depend on which points share a tile -- but        */
+/* consecutive tiles gather neighbouring rows (RandLA point order inside a cloud is random,            */
+/* randlanet.py:218-229, so the natural row order has no locality).                                    */
+int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batch, int64_t n0, int num_layers,
+                                    const int32_t* ratios_host, int k,
+                                    int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
+                                    int32_t* const* tile_order_host,
+                                    void* workspace, size_t workspace_bytes, void* stream,
+                                    const ml3d_trace* trace_host);
+
+int ml3d_randla_forward_ordered(const ml3d_randla_desc* desc_host, const float* params,
+                                const float* features, const float* points,
+                                const int32_t* const* neighbor_idx_host,
+                                const int32_t* const* interp_idx_host,
+                                const int32_t* const* tile_order_host, float* out_scores,
+                                void* workspace, size_t workspace_bytes, void* stream,
+                                const ml3d_trace* trace_host);
+
 #ifdef __cplusplus
 }
 #endif

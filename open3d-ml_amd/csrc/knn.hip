@@ -226,6 +226,14 @@ static int launch_query(const GridView& G, const QuerySrc& Q, int k, int index_l
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+// tile order for the forward's attention kernels: the grid's cell-sorted (packed, cloud-major) sequence of point rows
+__global__ void order_from_grid(const float4* __restrict__ sorted, int64_t n_total, int64_t n_per_item,
+                                int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    out[i] = (int32_t)((i / n_per_item) * n_per_item + (int64_t)__float_as_int(sorted[i].w));
+}
+
 static float tuning_occ() {
     const char* e = getenv("ML3D_KNN_OCC");  // tuning knob only; speed, never results
     return e ? (float)atof(e) : 0.f;
@@ -302,6 +310,15 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
                                               int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
                                               void* workspace, size_t workspace_bytes, void* stream,
                                               const ml3d_trace* tr) {
+    return ml3d_randla_knn_pyramid_ordered(points, batch, n0, num_layers, ratios_host, k, neighbor_idx_host,
+                                           interp_idx_host, nullptr, workspace, workspace_bytes, stream, tr);
+}
+
+extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batch, int64_t n0, int num_layers,
+                                               const int32_t* ratios_host, int k,
+                                               int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
+                                               int32_t* const* tile_order_host, void* workspace,
+                                               size_t workspace_bytes, void* stream, const ml3d_trace* tr) {
     auto tb = [&](int tag) { if (tr && tr->tag == tag && tr->ev_start) (void)hipEventRecord((hipEvent_t)tr->ev_start, (hipStream_t)stream); };
     auto te = [&](int tag) { if (tr && tr->tag == tag && tr->ev_stop) (void)hipEventRecord((hipEvent_t)tr->ev_stop, (hipStream_t)stream); };
     if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > 15 || !ratios_host || k <= 0 ||
@@ -330,6 +347,12 @@ extern "C" int ml3d_randla_knn_pyramid_traced(const float* points, int64_t batch
         // level 0 probes the cloud; the thinner prefix levels reuse its box and dimension estimate
         if (l == 0 ? grid_build(points, S, ws[l], occ, st) : grid_build_derived(points, S, ws[l], ws[0], st))
             return ML3D_E_LAUNCH;
+        if (tile_order_host && l < num_layers && tile_order_host[l]) {
+            const int64_t nt = n[l] * batch;
+            hipLaunchKernelGGL(order_from_grid, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ws[l].sorted, nt, n[l],
+                               tile_order_host[l]);
+            if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+        }
         te(100 + l);
     }
     // all k-NN searches (level l onto itself, randlanet.py:220) in one launch, all 1-NN interpolation

@@ -126,6 +126,10 @@ struct LfaArgs {
     float* out;                // stage 1: p1 [m, h]; stage 2: enc [m, 2d]
     int64_t xcd_chunk;         // > 0: XCD-aware tile walk, tiles per chunk (see xcd_tile)
     const float* gscore;       // optional [m, d]: gfeat . score_WT[0:h, :] per POINT (see lfa_attn_pf<.., SPLIT>)
+    // optional [m]: a permutation of the point rows (cloud-major, spatially sorted inside a cloud -- the cell order of
+    // the neighbour pyramid's grid).  Tile t then works on points order[t * TP .. ] instead of rows t * TP ..: the
+    // results are identical, but consecutive tiles share neighbour rows in L1/L2 (ORD template variants).
+    const int32_t* order;
 };
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, observed), and each XCD has its
@@ -611,7 +615,7 @@ static size_t mfma_smem_bytes() {
 // into the accumulator layout (32 lanes read 128 contiguous bytes of a row) and runs the MFMAs over K = H instead
 // of D: half the score MFMAs and half the resident weight registers.  f[nb] is still gathered into X for the
 // weighted sum.  Used for D >= 128, where the extra D floats per neighbour are small next to the MFMA time saved.
-template <int D, int STAGE, bool SPLIT>
+template <int D, int STAGE, bool SPLIT, bool ORD>
 __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D>::THREADS / 256))) lfa_attn_pf(LfaArgs A) {
     using C = MfmaCfg<D>;
     constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
@@ -676,38 +680,72 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
     // (per-tile bookkeeping is wave-uniform and 32-bit: f32 MFMA and VALU share the SIMD's issue cycles on gfx950, so a
     //  64-bit division per lane per tile costs as much as two MFMAs; the launcher guarantees m_total, n0 < 2^30, n >= TP)
     const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
+    uint32_t gmp[ORD ? G : 1], mp_mine = 0, m_first = 0;     // ORD: point rows of this thread's slots / of the tile's first point
     auto request_idx = [&](uint32_t tile) {
-        const int32_t* nb = A.nidx + (int64_t)tile * (C::TP * RK);  // the tile's (point, neighbour) rows are contiguous
         const uint32_t have = m_tot - tile * C::TP;                 // points of the tile that exist
         const uint32_t lim = (have < (uint32_t)C::TP ? have : (uint32_t)C::TP) * RK;
+        if constexpr (ORD) {
+            const int32_t* ord = A.order + tile * C::TP;
+            m_first = (uint32_t)ord[0];
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
-            gi[i] = row < lim ? nb[row] : -1;
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
+                gi[i] = -1;
+                if (row < lim) {
+                    gmp[i] = (uint32_t)ord[row / RK];
+                    gi[i] = A.nidx[(int64_t)gmp[i] * RK + (row & (RK - 1))];
+                }
+            }
+            if (tid < ROWS) {
+                nb_mine = -1;
+                if ((uint32_t)tid < lim) {
+                    mp_mine = (uint32_t)ord[tid / RK];
+                    nb_mine = A.nidx[(int64_t)mp_mine * RK + (tid & (RK - 1))];
+                }
+            }
+        } else {
+            const int32_t* nb = A.nidx + (int64_t)tile * (C::TP * RK);  // the tile's (point, neighbour) rows are contiguous
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
+                gi[i] = row < lim ? nb[row] : -1;
+            }
+            if (tid < ROWS) nb_mine = (uint32_t)tid < lim ? nb[tid] : -1;
         }
-        if (tid < ROWS) nb_mine = (uint32_t)tid < lim ? nb[tid] : -1;
     };
     auto request_data = [&](uint32_t tile) {
-        const uint32_t m0 = tile * C::TP;
-        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;      // scalar; point p of the tile is (b0, l0 + p) or wraps once
+        // scalar: the cloud of the tile's first point; the tile's other points are in it or in the next one (ORD: the
+        // order is cloud-major, so the same holds for order[t * TP ..])
+        const uint32_t m0 = ORD ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m_first) : tile * C::TP;
+        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int e = tid + i * THREADS;
             const int row = e / Q, q = e - row * Q;
             gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gi[i] >= 0) {
-                const uint32_t b = b0 + ((l0 + (uint32_t)(row / RK) >= n_pts) ? 1u : 0u);
+                uint32_t b;
+                if constexpr (ORD) b = b0 + (gmp[i] >= (b0 + 1) * n_pts ? 1u : 0u);
+                else b = b0 + ((l0 + (uint32_t)(row / RK) >= n_pts) ? 1u : 0u);
                 gq[i] = *reinterpret_cast<const float4*>(A.gfeat + ((int64_t)b * n_pts + (uint32_t)gi[i]) * H + 4 * q);
             }
         }
         if (tid < ROWS) {
             mine_valid = nb_mine >= 0;
             if (mine_valid) {
-                const uint32_t lp = l0 + (uint32_t)(tid / RK);
-                const bool wrap = lp >= n_pts;
-                grow_mine = (b0 + (wrap ? 1u : 0u)) * n_pts + (uint32_t)nb_mine;
-                const float* xb = A.xyz + 3 * ((int64_t)(b0 + (wrap ? 1u : 0u)) * A.n0);
-                const float* qp = xb + 3 * (wrap ? lp - n_pts : lp);
+                uint32_t b, l;
+                if constexpr (ORD) {
+                    b = b0 + (mp_mine >= (b0 + 1) * n_pts ? 1u : 0u);
+                    l = mp_mine - b * n_pts;
+                } else {
+                    const uint32_t lp = l0 + (uint32_t)(tid / RK);
+                    const bool wrap = lp >= n_pts;
+                    b = b0 + (wrap ? 1u : 0u);
+                    l = wrap ? lp - n_pts : lp;
+                }
+                grow_mine = b * n_pts + (uint32_t)nb_mine;
+                const float* xb = A.xyz + 3 * ((int64_t)b * A.n0);
+                const float* qp = xb + 3 * l;
                 const float* sp = xb + 3 * (uint32_t)nb_mine;
                 qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
             }
@@ -828,7 +866,10 @@ __global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg
             softmax_wsum8<XP>(acc, 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
             const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
             int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
-            if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
+            if (m < A.m_total) {
+                if constexpr (ORD) m = A.order[m];               // the point's row in the cloud-major spatial order
+                A.out[m * D + ct * 32 + col] = agg_mine;
+            }
         }
         block_sync_lds();
         cur = nxt;
@@ -872,7 +913,7 @@ struct WaveAttnCfg {
 // SPLIT (see lfa_attn_pf): A.gscore = f . W_top^T + score bias per POINT; the neighbours' rows are gathered straight
 // into the score accumulators (requested before the lse phases, so they land under those MFMAs) and the score MFMAs
 // run over the position half of X only (K = H): 32 instead of 64 MFMAs per tile at D = 64.
-template <int D, int STAGE, bool SPLIT>
+template <int D, int STAGE, bool SPLIT, bool ORD>
 __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArgs A) {
     using C = WaveAttnCfg<D>;
     constexpr int H = C::H, XP = C::XP, Q = C::Q, G = C::G, NT = C::NT;
@@ -929,22 +970,44 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
     float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     bool mine_valid = false;
     uint32_t goff_mine = 0;
+    uint32_t mo0 = 0, mo1 = 0;           // ORD: the tile's two point rows (order[2 t], order[2 t + 1]; wave-uniform values)
     auto request_idx = [&](uint32_t tile) {
-        const int32_t* nb = A.nidx + (int64_t)tile * 2 * RK;      // 32 contiguous (point, neighbour) rows
         const uint32_t lim = (m_tot - tile * 2) >= 2 ? 32u : 16u; // rows of the tile that exist
+        if constexpr (ORD) {
+            mo0 = (uint32_t)A.order[tile * 2];
+            mo1 = lim == 32u ? (uint32_t)A.order[tile * 2 + 1] : mo0;
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
-            gi[i] = row < lim ? __builtin_nontemporal_load(nb + row) : -1;
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
+                gi[i] = row < lim ? __builtin_nontemporal_load(A.nidx + (int64_t)(row < RK ? mo0 : mo1) * RK + (row & (RK - 1))) : -1;
+            }
+            nb_mine = (uint32_t)lane < lim
+                          ? __builtin_nontemporal_load(A.nidx + (int64_t)(lane < RK ? mo0 : mo1) * RK + (lane & (RK - 1))) : -1;
+        } else {
+            const int32_t* nb = A.nidx + (int64_t)tile * 2 * RK;  // 32 contiguous (point, neighbour) rows
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
+                gi[i] = row < lim ? __builtin_nontemporal_load(nb + row) : -1;
+            }
+            nb_mine = (uint32_t)lane < lim ? __builtin_nontemporal_load(nb + lane) : -1;
         }
-        nb_mine = (uint32_t)lane < lim ? __builtin_nontemporal_load(nb + lane) : -1;
     };
     auto request_data = [&](uint32_t tile) {
-        // the tile's two points: cloud b0 / local index l0, and its successor (possibly the next cloud's first point)
-        const uint32_t m0 = tile * 2;
-        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;
-        const bool wrap = l0 + 1 == n_pts;
-        const uint32_t b1 = wrap ? b0 + 1 : b0, l1 = wrap ? 0u : l0 + 1;
+        // the tile's two points: cloud b0 / local index l0, and its successor (possibly the next cloud's first point);
+        // ORD: two arbitrary rows, each located by its own scalar division
+        uint32_t b0, l0, b1, l1;
+        if constexpr (ORD) {
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mo0);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mo1);
+            b0 = m0 / n_pts; l0 = m0 - b0 * n_pts;
+            b1 = m1 / n_pts; l1 = m1 - b1 * n_pts;
+        } else {
+            const uint32_t m0 = tile * 2;
+            b0 = m0 / n_pts; l0 = m0 - b0 * n_pts;
+            const bool wrap = l0 + 1 == n_pts;
+            b1 = wrap ? b0 + 1 : b0; l1 = wrap ? 0u : l0 + 1;
+        }
         const float* f0 = A.gfeat + (int64_t)b0 * n_pts * H;      // scalar bases, 32-bit lane offsets
         const float* f1 = A.gfeat + (int64_t)b1 * n_pts * H;
 #pragma unroll
@@ -969,6 +1032,7 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
     if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
     while (cur >= 0) {
         const int64_t nxt = next_tile();
+        const uint32_t mo0_cur = mo0, mo1_cur = mo1;             // (request_idx(nxt) overwrites them)
         // ---- registers -> the wave's patch ---------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -1083,7 +1147,8 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
                 }
             }
         }
-        const uint32_t m = (uint32_t)cur * 2 + hi;               // half 0 stores point 0, half 1 point 1
+        const uint32_t mi = (uint32_t)cur * 2 + hi;              // half 0 stores point 0, half 1 point 1
+        const uint32_t m = ORD ? (hi ? mo1_cur : mo0_cur) : mi;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float* xc = X + 32 * t + col;
@@ -1093,7 +1158,7 @@ __global__ void __launch_bounds__((WaveAttnCfg<D>::W * 64)) lfa_attn_wave(LfaArg
             const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
             // streaming data (the output rows, the neighbour indices) goes around the L2's LRU: the XCD's 4 MB are for the
             // cloud's gathered rows (features + gscore), which every tile re-reads at random
-            if (m < m_tot) __builtin_nontemporal_store(agg_mine, A.out + (int64_t)m * D + 32 * t + col);
+            if (mi < m_tot) __builtin_nontemporal_store(agg_mine, A.out + (int64_t)m * D + 32 * t + col);
         }
         wave_lds_sync();                                          // the patch is rewritten at the top of the loop
         cur = nxt;
@@ -1111,16 +1176,14 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     const size_t sm = sizeof(float) * ((size_t)C::WFLOATS + (size_t)C::W * C::PATCH);
-    if (a.gscore) {
-        if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+    auto go = [&](auto kern) -> int {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
             return ML3D_E_LAUNCH;
-        hipLaunchKernelGGL((lfa_attn_wave<D, STAGE, true>), dim3(grid), dim3(C::W * 64), sm, st, a);
-    } else {
-        if (hipFuncSetAttribute((const void*)lfa_attn_wave<D, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-            return ML3D_E_LAUNCH;
-        hipLaunchKernelGGL((lfa_attn_wave<D, STAGE, false>), dim3(grid), dim3(C::W * 64), sm, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::W * 64), sm, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    };
+    if (a.gscore) return a.order ? go(lfa_attn_wave<D, STAGE, true, true>) : go(lfa_attn_wave<D, STAGE, true, false>);
+    return a.order ? go(lfa_attn_wave<D, STAGE, false, true>) : go(lfa_attn_wave<D, STAGE, false, false>);
 }
 
 // launches the attention part of one stage; `a.out` receives agg [m, D]
@@ -1140,20 +1203,18 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
     if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
         size_t sm = pf_smem_bytes<D, STAGE>();
-        if (sm > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-            return ML3D_E_LAUNCH;
+        auto go = [&](auto kern) -> int {
+            if (sm > 48 * 1024 &&
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+                return ML3D_E_LAUNCH;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), sm, st, a);
+            return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+        };
         if constexpr (D >= 128) {
-            if (a.gscore) {
-                if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)lfa_attn_pf<D, STAGE, true>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-                    return ML3D_E_LAUNCH;
-                hipLaunchKernelGGL((lfa_attn_pf<D, STAGE, true>), dim3(grid), dim3(C::THREADS), sm, st, a);
-                return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-            }
+            if (a.gscore) return a.order ? go(lfa_attn_pf<D, STAGE, true, true>) : go(lfa_attn_pf<D, STAGE, true, false>);
         }
-        hipLaunchKernelGGL((lfa_attn_pf<D, STAGE, false>), dim3(grid), dim3(C::THREADS), sm, st, a);
-        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+        if (a.order) return go(lfa_attn_pf<D, STAGE, false, true>);
+        return go(lfa_attn_pf<D, STAGE, false, false>);
     }
     size_t sm = mfma_smem_bytes<D, STAGE>();
     if (sm > 48 * 1024 &&
@@ -1181,7 +1242,7 @@ constexpr int A16_XP = 20;           // X row pitch
 // (the lse weights arrive as separate __restrict__ kernel arguments: with `noalias` the compiler may read them with
 //  scalar loads inside the tile loop -- SGPR operands of the packed FMAs -- instead of one uniform VECTOR load per
 //  16 bytes of weights per tile, which is what it must do for pointers that could alias the stores to A.out)
-template <int STAGE>
+template <int STAGE, bool ORD>
 __global__ void __launch_bounds__(256, 6)
 lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __restrict__ lse1_b,
                 const float* __restrict__ lse2_wt, const float* __restrict__ lse2_b) {
@@ -1216,20 +1277,39 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
     // this thread's row of the NEXT tile is requested while the current one is computed: its neighbour index during the
     // build phase, then (through that index) the two xyz triples and the 8-float feature row during the MFMA phase
     uint32_t nb = 0;
+    uint32_t mrow = 0;                   // ORD: this thread's point row (order[tile * 16 + p])
     bool valid = false;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
     auto request_idx = [&](uint32_t tile) {
         valid = tile * A16_TP + p < m_tot;
-        if (valid) nb = (uint32_t)A.nidx[(int64_t)tile * (A16_TP * RK) + tid];
+        if constexpr (ORD) {
+            if (valid) {
+                mrow = (uint32_t)A.order[tile * A16_TP + p];
+                nb = (uint32_t)A.nidx[(int64_t)mrow * RK + (tid & 15)];
+            }
+        } else {
+            if (valid) nb = (uint32_t)A.nidx[(int64_t)tile * (A16_TP * RK) + tid];
+        }
     };
     auto request_data = [&](uint32_t tile) {
+        // ORD: the wave's 4 points are consecutive in a cloud-major order, so they lie in at most two clouds: the
+        // first lane's cloud by one scalar division (all lanes take part in the broadcast), the rest by a compare
+        uint32_t b0o = 0;
+        if constexpr (ORD) b0o = (uint32_t)__builtin_amdgcn_readfirstlane((int)mrow) / n_pts;
         if (valid) {
-            const uint32_t m_base = tile * A16_TP;
-            const uint32_t b0 = m_base / n_pts, l0 = m_base - b0 * n_pts;     // scalar
-            const uint32_t lp = l0 + p;
-            const bool wrap = lp >= n_pts;                                    // the tile may cross into the next cloud once
-            const uint32_t b = b0 + (wrap ? 1u : 0u), nl = wrap ? lp - n_pts : lp;
+            uint32_t b, nl;
+            if constexpr (ORD) {
+                b = b0o + (mrow >= (b0o + 1) * n_pts ? 1u : 0u);
+                nl = mrow - b * n_pts;
+            } else {
+                const uint32_t m_base = tile * A16_TP;
+                const uint32_t b0 = m_base / n_pts, l0 = m_base - b0 * n_pts; // scalar
+                const uint32_t lp = l0 + p;
+                const bool wrap = lp >= n_pts;                                // the tile may cross into the next cloud once
+                b = b0 + (wrap ? 1u : 0u);
+                nl = wrap ? lp - n_pts : lp;
+            }
             const float* xb = A.xyz + 3 * ((int64_t)b * A.n0);
             const float* q = xb + 3 * nl;
             const float* sp = xb + 3 * nb;
@@ -1243,6 +1323,7 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
     while (cur >= 0) {
         const int64_t nxt = next_tile();
         const uint32_t m_base = (uint32_t)cur * A16_TP;
+        const uint32_t mrow_cur = mrow;                                       // (request_idx(nxt) below overwrites mrow)
         {   // ---- build this thread's X row ---------------------------------------------------------
             float xr[D];
 #pragma unroll
@@ -1323,8 +1404,10 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
             }
             sum += __shfl_xor(sum, 16); ag += __shfl_xor(ag, 16);
             sum += __shfl_xor(sum, 32); ag += __shfl_xor(ag, 32);
-            const uint32_t m = m_base + 4 * wave + pp;
-            if (g == 0 && m < m_tot) A.out[(int64_t)m * D + col] = ag / sum;
+            const uint32_t mi = m_base + 4 * wave + pp;                       // position of the point in the walk
+            // ORD: the point's row is held by the lanes that built its X rows (lanes 16 pp .. 16 pp + 15 of this wave)
+            const uint32_t m = ORD ? (uint32_t)__builtin_amdgcn_readlane((int)mrow_cur, 16 * pp) : mi;
+            if (g == 0 && mi < m_tot) A.out[(int64_t)m * D + col] = ag / sum;
         }
         wave_lds_sync();
         cur = nxt;
@@ -1339,7 +1422,10 @@ static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
     static const int cap = getenv("ML3D_ATTN16_GRID") ? atoi(getenv("ML3D_ATTN16_GRID")) : 4096;
     unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    hipLaunchKernelGGL((lfa_attn_mfma16<STAGE>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
+    if (a.order)
+        hipLaunchKernelGGL((lfa_attn_mfma16<STAGE, true>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
+    else
+        hipLaunchKernelGGL((lfa_attn_mfma16<STAGE, false>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
@@ -2161,6 +2247,15 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
                                           const float* points, const int32_t* const* neighbor_idx,
                                           const int32_t* const* interp_idx, float* out_scores, void* workspace,
                                           size_t workspace_bytes, void* stream, const ml3d_trace* trace) {
+    return ml3d_randla_forward_ordered(d, params, features, points, neighbor_idx, interp_idx, nullptr, out_scores,
+                                       workspace, workspace_bytes, stream, trace);
+}
+
+extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const float* params, const float* features,
+                                           const float* points, const int32_t* const* neighbor_idx,
+                                           const int32_t* const* interp_idx, const int32_t* const* tile_order,
+                                           float* out_scores, void* workspace, size_t workspace_bytes, void* stream,
+                                           const ml3d_trace* trace) {
     if (!desc_ok(d) || !params || !features || !points || !neighbor_idx || !interp_idx || !out_scores)
         return ML3D_E_INVALID;
     if (d->num_neighbors != RK) return ML3D_E_UNSUPPORTED;
@@ -2213,6 +2308,7 @@ extern "C" int ml3d_randla_forward_traced(const ml3d_randla_desc* d, const float
         s1.gfeat = f1; s1.lse1_wt = P(sb + 2); s1.lse1_b = P(sb + 3);
         s1.score_wt = P(sb + 4); s1.score_b = P(sb + 5); s1.pool_wt = P(sb + 6); s1.pool_b = P(sb + 7);
         s1.d_in = d_in; s1.out = p1;
+        s1.order = tile_order ? tile_order[l] : nullptr;
         LfaArgs s2 = s1;
         s2.gfeat = p1; s2.lse2_wt = P(sb + 8); s2.lse2_b = P(sb + 9);
         s2.score_wt = P(sb + 10); s2.score_b = P(sb + 11); s2.pool_wt = P(sb + 12); s2.pool_b = P(sb + 13);

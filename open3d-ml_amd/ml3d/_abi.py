@@ -54,6 +54,8 @@ SYMBOLS = [
     "ml3d_randla_forward",
     "ml3d_randla_forward_traced",
     "ml3d_randla_knn_pyramid_traced",
+    "ml3d_randla_knn_pyramid_ordered",
+    "ml3d_randla_forward_ordered",
 ]
 
 
@@ -155,6 +157,11 @@ def bind(lib):
     lib.ml3d_randla_forward_traced.argtypes = [C.POINTER(RandlaDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Trace)]
     lib.ml3d_randla_knn_pyramid_traced.restype = C.c_int
     lib.ml3d_randla_knn_pyramid_traced.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, sz, vp, C.POINTER(Trace)]
+    lib.ml3d_randla_knn_pyramid_ordered.restype = C.c_int
+    lib.ml3d_randla_knn_pyramid_ordered.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp, C.POINTER(Trace)]
+    lib.ml3d_randla_forward_ordered.restype = C.c_int
+    lib.ml3d_randla_forward_ordered.argtypes = [C.POINTER(RandlaDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp,
+                                                C.POINTER(Trace)]
     return lib
 
 

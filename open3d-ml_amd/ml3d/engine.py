@@ -7,6 +7,7 @@ calls of RandLANet.transform, reference randlanet.py:218-229) and ``ml3d_randla_
 (replaces RandLANet.forward, randlanet.py:241-298) — with no host synchronisation.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -17,8 +18,14 @@ from .torch.models import _randla_pack
 
 class RandLAInferenceEngine:
 
-    def __init__(self, cfg, state_dict, batch, num_points, device):
+    def __init__(self, cfg, state_dict, batch, num_points, device, tile_order=None):
+        """``tile_order``: walk the attention tiles of every level in the cell-sorted order of the neighbour pyramid's
+        grids (same scores, better locality of the neighbour gathers); default from ``ML3D_TILE_ORDER`` (off: the
+        variant is parity-tested but has not been timed on an MI355X yet)."""
         self.lib = _abi.get()
+        if tile_order is None:
+            tile_order = os.environ.get("ML3D_TILE_ORDER", "0") == "1"
+        self.tile_order = bool(tile_order)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -43,6 +50,9 @@ class RandLAInferenceEngine:
         self.fwd_ws = torch.empty(self.fwd_ws_bytes, dtype=torch.uint8, device=dev)
         self._t_n = _abi.ptr_table([t.data_ptr() for t in self.nbr])
         self._t_i = _abi.ptr_table([t.data_ptr() for t in self.itp])
+        self.order = [torch.empty(self.B * self.n[l], dtype=torch.int32, device=dev) for l in range(self.L)] \
+            if self.tile_order else None
+        self._t_o = _abi.ptr_table([t.data_ptr() for t in self.order]) if self.tile_order else None
 
     def _check(self, points, features):
         if tuple(points.shape) != (self.B, self.N, 3) or points.dtype != torch.float32 or \
@@ -54,17 +64,18 @@ class RandLAInferenceEngine:
 
     def neighbors(self, points, trace=None):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = self.lib.ml3d_randla_knn_pyramid_traced(points.data_ptr(), self.B, self.N, self.L, self.ratios, self.K,
-                                                     self._t_n, self._t_i, self.pyr_ws.data_ptr(),
-                                                     self.pyr_ws_bytes, st, trace)
+        rc = self.lib.ml3d_randla_knn_pyramid_ordered(points.data_ptr(), self.B, self.N, self.L, self.ratios, self.K,
+                                                      self._t_n, self._t_i, self._t_o, self.pyr_ws.data_ptr(),
+                                                      self.pyr_ws_bytes, st, trace)
         _abi.check(rc, "ml3d_randla_knn_pyramid")
         return self.nbr, self.itp
 
     def forward(self, points, features, trace=None):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = self.lib.ml3d_randla_forward_traced(C.byref(self.desc), self.params.data_ptr(), features.data_ptr(),
-                                                 points.data_ptr(), self._t_n, self._t_i, self.scores.data_ptr(),
-                                                 self.fwd_ws.data_ptr(), self.fwd_ws_bytes, st, trace)
+        rc = self.lib.ml3d_randla_forward_ordered(C.byref(self.desc), self.params.data_ptr(), features.data_ptr(),
+                                                  points.data_ptr(), self._t_n, self._t_i, self._t_o,
+                                                  self.scores.data_ptr(), self.fwd_ws.data_ptr(), self.fwd_ws_bytes, st,
+                                                  trace)
         _abi.check(rc, "ml3d_randla_forward")
         return self.scores
 

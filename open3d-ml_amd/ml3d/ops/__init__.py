@@ -75,10 +75,12 @@ def pyramid_sizes(n0, ratios):
     return n
 
 
-def randla_knn_pyramid(points, ratios, k, out=None, workspace=None):
+def randla_knn_pyramid(points, ratios, k, out=None, workspace=None, tile_order=None):
     """All neighbour searches of ``RandLANet.transform`` (ml3d/torch/models/randlanet.py:218-229)
     for a batch [B, N, 3] in one call.  Returns (neighbor_idx[l] [B,n_l,k], interp_idx[l] [B,n_l,1]),
-    int32, item-local.  ``sub_idx[l]`` of the reference is ``neighbor_idx[l][:, :n_{l+1}]``."""
+    int32, item-local.  ``sub_idx[l]`` of the reference is ``neighbor_idx[l][:, :n_{l+1}]``.
+    ``tile_order``: optional list of int32 [B * n_l] tensors (one per level) that receive the levels' cell-sorted
+    point order for ``randla_forward(..., tile_order=...)``."""
     lib = _abi.get()
     _need_gpu(points)
     if points.dim() != 3 or points.shape[2] != 3 or points.dtype != torch.float32 or not points.is_contiguous():
@@ -102,14 +104,24 @@ def randla_knn_pyramid(points, ratios, k, out=None, workspace=None):
     t_n = _abi.ptr_table([t.data_ptr() for t in nbr])
     t_i = _abi.ptr_table([t.data_ptr() for t in itp])
     with torch.cuda.device(dev):
-        rc = lib.ml3d_randla_knn_pyramid(points.data_ptr(), B, n0, L, r, int(k), t_n, t_i, ws.data_ptr(),
-                                         ws.numel(), _stream())
+        if tile_order is not None:
+            if len(tile_order) != L or any(t.dtype != torch.int32 or t.numel() != B * n[l] or not t.is_contiguous()
+                                           for l, t in enumerate(tile_order)):
+                raise RuntimeError("randla_knn_pyramid: tile_order must be one contiguous int32 [B * n_l] tensor per level")
+            t_o = _abi.ptr_table([t.data_ptr() for t in tile_order])
+            rc = lib.ml3d_randla_knn_pyramid_ordered(points.data_ptr(), B, n0, L, r, int(k), t_n, t_i, t_o, ws.data_ptr(),
+                                                     ws.numel(), _stream(), None)
+        else:
+            rc = lib.ml3d_randla_knn_pyramid(points.data_ptr(), B, n0, L, r, int(k), t_n, t_i, ws.data_ptr(),
+                                             ws.numel(), _stream())
     _abi.check(rc, "ml3d_randla_knn_pyramid")
     return nbr, itp
 
 
-def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out=None, workspace=None):
-    """Fused RandLA-Net forward (ml3d/torch/models/randlanet.py:241-298) -> scores [B, N, classes]."""
+def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out=None, workspace=None, tile_order=None):
+    """Fused RandLA-Net forward (ml3d/torch/models/randlanet.py:241-298) -> scores [B, N, classes].
+    ``tile_order`` (optional, from ``randla_knn_pyramid``): walk each level's attention tiles in that point order
+    (same result, better cache locality of the neighbour gathers)."""
     lib = _abi.get()
     _need_gpu(params, features, points, *neighbor_idx, *interp_idx)
     dev = points.device
@@ -131,8 +143,16 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
     t_n = _abi.ptr_table([t.data_ptr() for t in neighbor_idx])
     t_i = _abi.ptr_table([t.data_ptr() for t in interp_idx])
     with torch.cuda.device(dev):
-        rc = lib.ml3d_randla_forward(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
-                                     t_n, t_i, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        if tile_order is not None:
+            for t in tile_order:
+                if t.dtype != torch.int32 or not t.is_contiguous() or t.device != dev:
+                    raise RuntimeError("randla_forward: tile_order tensors must be contiguous int32 on the same device")
+            t_o = _abi.ptr_table([t.data_ptr() for t in tile_order])
+            rc = lib.ml3d_randla_forward_ordered(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
+                                                 t_n, t_i, t_o, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), None)
+        else:
+            rc = lib.ml3d_randla_forward(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
+                                         t_n, t_i, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _abi.check(rc, "ml3d_randla_forward")
     return out
 

@@ -46,6 +46,28 @@ def knn(points, psplits, queries=None, qsplits=None, k=16, local=False):
     return idx, d2
 
 
+def pyramid_ordered(points_bn3, ratios, k=16):
+    """-> (nbr, itp, order): order[l] = the level's cell-sorted point rows [B * n_l] (ml3d_randla_knn_pyramid_ordered)."""
+    L = lib()
+    pts = np.ascontiguousarray(points_bn3, np.float32)
+    B, n0, _ = pts.shape
+    nl = len(ratios)
+    r = (C.c_int32 * nl)(*ratios)
+    n = [n0]
+    for x in ratios:
+        n.append(n[-1] // x)
+    wsb = L.ml3d_randla_pyramid_workspace_bytes(B, n0, nl, r)
+    ws = np.zeros(wsb, np.uint8)
+    nbr = [np.full((B, n[l], k), -9, np.int32) for l in range(nl)]
+    itp = [np.full((B, n[l], 1), -9, np.int32) for l in range(nl)]
+    order = [np.full(B * n[l], -9, np.int32) for l in range(nl)]
+    rc = L.ml3d_randla_knn_pyramid_ordered(pts.ctypes.data, B, n0, nl, r, k, _abi.ptr_table([x.ctypes.data for x in nbr]),
+                                           _abi.ptr_table([x.ctypes.data for x in itp]),
+                                           _abi.ptr_table([x.ctypes.data for x in order]), ws.ctypes.data, wsb, None, None)
+    assert rc == 0, rc
+    return nbr, itp, order
+
+
 def pyramid(points_bn3, ratios, k=16):
     L = lib()
     pts = np.ascontiguousarray(points_bn3, np.float32)
@@ -65,7 +87,7 @@ def pyramid(points_bn3, ratios, k=16):
     return nbr, itp
 
 
-def randla_forward(cfg, sd, points, feats, nbr, itp):
+def randla_forward(cfg, sd, points, feats, nbr, itp, order=None):
     from ml3d.torch.models import _randla_pack
     L = lib()
     B, N, _ = points.shape
@@ -77,6 +99,14 @@ def randla_forward(cfg, sd, points, feats, nbr, itp):
     out = np.zeros((B, N, cfg["num_classes"]), np.float32)
     points = np.ascontiguousarray(points, np.float32)
     feats = np.ascontiguousarray(feats, np.float32)
+    if order is not None:
+        order = [np.ascontiguousarray(o, np.int32) for o in order]
+        rc = L.ml3d_randla_forward_ordered(C.byref(desc), params.ctypes.data, feats.ctypes.data, points.ctypes.data,
+                                           _abi.ptr_table([x.ctypes.data for x in nbr]),
+                                           _abi.ptr_table([x.ctypes.data for x in itp]),
+                                           _abi.ptr_table([x.ctypes.data for x in order]), out.ctypes.data, ws.ctypes.data,
+                                           wsb, None, None)
+        return rc, out
     rc = L.ml3d_randla_forward(C.byref(desc), params.ctypes.data, feats.ctypes.data, points.ctypes.data,
                                _abi.ptr_table([x.ctypes.data for x in nbr]), _abi.ptr_table([x.ctypes.data for x in itp]),
                                out.ctypes.data, ws.ctypes.data, wsb, None)

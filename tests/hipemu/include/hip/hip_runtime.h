@@ -252,6 +252,12 @@ static inline T hipemu_readfirstlane(T v) {
     return v;
 }
 #define __builtin_amdgcn_readfirstlane(x) hipemu_readfirstlane(x)
+static inline int __builtin_amdgcn_readlane(int v, int lane) {
+    auto vw = hipemu::wave_exchange(&v, sizeof(int));
+    int r = v;
+    if (vw.peer_valid(lane)) memcpy(&r, vw.peer(lane), sizeof(int));
+    return r;
+}
 
 // ---- f32-input MFMA (layouts per /opt/skills/guides/cdna_hip_programming.md §3) ---------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));

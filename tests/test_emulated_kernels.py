@@ -147,6 +147,48 @@ def test_randla_forward_kernel_variants_agree_with_oracle(monkeypatch, knobs):
     assert np.abs(out - ref).max() <= 1e-4
 
 
+def test_tile_order_is_a_cloud_major_spatial_permutation():
+    pts = np.stack([synth_data.semantickitti_patch(i, 2048) for i in range(3)])
+    nbr, itp, order = emu.pyramid_ordered(pts, [4, 4])
+    n = [2048, 512]
+    for l in range(2):
+        o = order[l].reshape(3, n[l])
+        for b in range(3):
+            assert np.array_equal(np.sort(o[b]), np.arange(b * n[l], (b + 1) * n[l]))      # a permutation inside each cloud
+        # spatial: consecutive points of the order are much closer than consecutive points of the (random) row order
+        p = pts[0, :n[l]]
+        d_ord = np.linalg.norm(np.diff(p[o[0]], axis=0), axis=1).mean()
+        d_row = np.linalg.norm(np.diff(p, axis=0), axis=1).mean()
+        assert d_ord < 0.5 * d_row
+    a, b = emu.pyramid(pts, [4, 4])
+    assert all(np.array_equal(x, y) for x, y in zip(nbr + itp, a + b))                   # the searches are unaffected
+
+
+@pytest.mark.parametrize("ci,B,N,kind", [(0, 2, 1024, "grid"), (2, 3, 1100, "grid"), (2, 3, 1100, "reversed"),
+                                         (0, 2, 1024, "random")])
+def test_randla_forward_with_a_tile_order_is_bit_identical(ci, B, N, kind):
+    """The tile order only changes which points share a tile: per-point arithmetic, hence every logit, is unchanged --
+    for the grid's order and for ANY cloud-major permutation (incl. tiles straddling clouds, cfg 2)."""
+    cfg = CFGS[ci]
+    pts = synth_data.uniform_cloud(21, B * N).reshape(B, N, 3)
+    sd = R.make_state_dict(cfg, 17)
+    ratios = cfg["sub_sampling_ratio"]
+    nbr, itp, order = emu.pyramid_ordered(pts, ratios)
+    if kind != "grid":
+        rng = np.random.default_rng(4)
+        n = N
+        order = []
+        for r in ratios:
+            o = np.arange(B * n, dtype=np.int32).reshape(B, n)
+            o = o[:, ::-1] if kind == "reversed" else np.stack([rng.permutation(row) for row in o])
+            order.append(np.ascontiguousarray(o.reshape(-1)))
+            n //= r
+    rc0, base = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+    rc1, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp, order=order)
+    assert rc0 == 0 and rc1 == 0
+    assert np.array_equal(out, base)
+
+
 def test_randla_forward_against_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "randlanet_small.npz"))
     cfg = dict(num_neighbors=16, num_layers=3, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
