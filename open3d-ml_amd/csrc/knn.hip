@@ -63,15 +63,29 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
     }
 }
 
+#ifndef KNN_GROUP
+#define KNN_GROUP 3
+#endif
+
 template <int K>
 __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
                                          float qz, double (&best)[K]) {
     int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
-    for (int p = p0; p < p1; ++p) {
-        float4 c = G.sorted[p];
-        float d2 = dist2_canon(qx, qy, qz, c.x, c.y, c.z);
-        u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
-        topk_insert<K>(best, __longlong_as_double((long long)key));
+    // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
+    // per group instead of one per candidate -- the loop is latency-bound: lane-per-query gathers, ~5 waves per SIMD);
+    // indices past the run are clamped to its last point and skipped
+    for (int p = p0; p < p1; p += KNN_GROUP) {
+        float4 c[KNN_GROUP];
+#pragma unroll
+        for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
+#pragma unroll
+        for (int j = 0; j < KNN_GROUP; ++j) {
+            if (p + j < p1) {
+                float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
+                u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
+                topk_insert<K>(best, __longlong_as_double((long long)key));
+            }
+        }
     }
 }
 
