@@ -75,6 +75,14 @@ def test_writer_reader_round_trip(tmp_path):
     assert np.array_equal(load_label_kitti(path, fmt.remap_lut_val), pred + 1)
 
 
+def test_preprocess_sweep_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_preprocess_sweep_matches_oracle")
+    with pytest.raises(RuntimeError):
+        preprocess_sweep({"point": np.zeros((10, 3), np.float32)}, 0.06, "test")
+
+
 @pytest.mark.gpu
 def test_preprocess_sweep_matches_oracle():
     import torch
