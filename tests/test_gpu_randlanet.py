@@ -139,3 +139,26 @@ def test_pipelined_engine_matches_sequential_engine():
     torch.cuda.synchronize()
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="the ORD kernel variants were finished after the round's GPU budget was spent: "
+                                        "bit-identical on the emulator, first hardware run happens here")
+def test_tile_order_engine_is_bit_identical():
+    """ML3D_TILE_ORDER: walking the attention tiles in the grids' spatial order must not change a single logit."""
+    from ml3d.engine import RandLAInferenceEngine
+    B, N = 3, 45056
+    frames = np.stack([synth_data.semantickitti_patch(300 + i, N) for i in range(B)])
+    sd = R.make_state_dict(KITTI, 7)
+    t = torch.from_numpy(frames).cuda()
+    plain = RandLAInferenceEngine(dict(KITTI, num_points=N), sd, B, N, "cuda:0", tile_order=False)
+    a = plain.step(t, t.clone()).clone()
+    ordered = RandLAInferenceEngine(dict(KITTI, num_points=N), sd, B, N, "cuda:0", tile_order=True)
+    b = ordered.step(t, t.clone()).clone()
+    torch.cuda.synchronize()
+    for l in range(len(ordered.order)):
+        o = ordered.order[l].cpu().numpy().reshape(B, -1)
+        n_l = o.shape[1]
+        for i in range(B):
+            assert np.array_equal(np.sort(o[i]), np.arange(i * n_l, (i + 1) * n_l))
+    assert torch.equal(a, b)
