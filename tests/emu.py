@@ -21,7 +21,9 @@ def available():
 def lib():
     global _LIB
     if _LIB is None:
-        so = subprocess.check_output([os.path.join(HERE, "hipemu", "build_emu.sh")]).decode().strip().splitlines()[-1]
+        so = os.environ.get("ML3D_EMU_LIB")          # e.g. the AddressSanitizer build of tools/emu_asan.sh
+        if not so:
+            so = subprocess.check_output([os.path.join(HERE, "hipemu", "build_emu.sh")]).decode().strip().splitlines()[-1]
         _LIB = _abi.bind(C.CDLL(so))
     return _LIB
 
