@@ -1,0 +1,24 @@
+// gfx950_ops.h — single gfx950 instructions the compiler will not pick on its own.
+// (The host emulator of the test-suite shadows this header with portable equivalents: tests/hipemu/include.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+// register budget of a kernel: exactly n waves per SIMD (512 / n VGPRs per lane)
+#define ML3D_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+namespace ml3d {
+
+// Compare-exchange of two packed (d2, index) keys held as doubles (see knn.hip): v_min_f64 + v_max_f64.
+// fmin()/fmax() would first canonicalise each operand (v_max_f64 x, x, x: signalling-NaN quieting the IEEE mode asks
+// for) -- three instructions per slot instead of two.  The keys are never NaN, so the raw instructions are exact.
+__device__ __forceinline__ void key_minmax(double a, double b, double& lo, double& hi) {
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ double key_min(double a, double b) {
+    double lo;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    return lo;
+}
+
+}  // namespace ml3d

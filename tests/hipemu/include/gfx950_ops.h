@@ -1,0 +1,13 @@
+// Host-emulator stand-in for open3d-ml_amd/csrc/gfx950_ops.h (TEST INFRASTRUCTURE ONLY): the same operations in
+// portable C++.  This directory precedes the product sources on the emulator's include path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#define ML3D_WAVES_PER_SIMD(n)
+
+namespace ml3d {
+static inline void key_minmax(double a, double b, double& lo, double& hi) { lo = std::fmin(a, b); hi = std::fmax(a, b); }
+static inline double key_min(double a, double b) { return std::fmin(a, b); }
+}  // namespace ml3d
