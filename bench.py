@@ -1,20 +1,24 @@
 #!/usr/bin/env python
 """bench.py — RandLA-Net SemanticKITTI inference frames/s on MI355X (BASELINE.json configs[1]).
 
-A step = one pass of the hot path over one batch of synthetic SemanticKITTI-shaped frames
-already resident in HBM: GPU neighbour pyramid (4x 16-NN + 4x 1-NN, replaces the CPU
-knn_search calls of RandLANet.transform) + fused RandLA-Net forward -> logits [B, 45056, 19].
-N > 1: one process per GPU (torchrun), frames sharded across ranks (weak scaling), and the
-only collective is an RCCL gather of the predicted labels to rank 0 inside the timed region.
+A step = one pass of the hot path over one batch of synthetic SemanticKITTI-shaped frames: upload of the batch's xyz
+from pinned host memory (inside the timed region, on a copy stream), GPU neighbour pyramid (4x 16-NN +
+4x 1-NN, replaces the CPU knn_search calls of RandLANet.transform) and the fused RandLA-Net forward -> logits
+[B, 45056, 19].  N > 1: one process per GPU (torchrun), frames sharded across ranks (weak scaling); the only collective
+is an RCCL gather of the predicted labels to rank 0 inside the timed region (ml3d.dist.PredictionGather).
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, timed live with
-HIP events recorded by the library around that kernel's launch, on the launch stream) and
-`cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores on
-a bounded sample of the same frames).
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline        the kernel with the longest average launch among the traced ones (k-NN tile kernel, layer-0 and layer-1
+                  attention kernels), timed live with HIP events recorded by the library around that kernel's launch on the
+                  launch stream; `roofline_other` carries the rest.  MFMA kernels: `frac` prices the flops the kernel
+                  EXECUTES, `frac_reference_formulation` the flops of the reference's formulation of the same result.
+  cpu_baseline    the CPU oracle (port of the reference path) on this box's host cores, best of a thread sweep.
+  workloads       BASELINE.json configs[2] / [3] (KPConv Toronto3D, PointPillars KITTI) measured in the same run (N = 1).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -33,17 +37,15 @@ CFG = dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG)  # randlanet_semantickitti
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 
-# the kernel the per-round rocprof summary (profiles/) shows as dominant:
-#   forward tag 8*layer + {1: lfa_stage<D,1>, 2: lfa_stage<D,2>}
-DOMINANT_FWD_TAG = int(os.environ.get("ML3D_BENCH_TRACE_TAG", 8 * 1 + 2))
+# kernels traced live (library tag -> description).  k-NN tags: 0 = merged 16-NN launch, 1 = merged 1-NN launch;
+# forward tags: 8 * layer + stage (1 / 2 = the two attention kernels of the layer)
+TRACED = [("knn", 0), ("fwd", 8 * 0 + 1), ("fwd", 8 * 1 + 2)]
 
 
 def lfa_flops(cfg, layer, stage, n_points):
-    """Algorithmic flops of what ONE attention-kernel launch computes (2 x MACs of the reference's matmuls,
-    SURVEY.md §8d), per point with K neighbours: stage 1 = lse1 MLP (10 -> h) + score Linear (d x d) +
-    softmax-weighted sum (d); stage 2 = lse2 MLP (h x h) + score Linear + weighted sum.  The re-computation of
-    lse1 inside the stage-2 kernel is NOT counted (the reference computes it once); the pool / mlp2 / shortcut
-    Linears run in separate GEMM launches and are not part of this kernel."""
+    """Algorithmic flops of what ONE attention-kernel launch computes in the REFERENCE's formulation (2 x MACs of its
+    matmuls), per point with K neighbours: stage 1 = lse1 MLP (10 -> h) + score Linear (d x d) +
+    softmax-weighted sum (d); stage 2 = lse2 MLP (h x h) + score Linear + weighted sum."""
     d = cfg["dim_output"][layer]
     h = d // 2
     K = cfg["num_neighbors"]
@@ -54,8 +56,7 @@ def lfa_flops(cfg, layer, stage, n_points):
 def lfa_flops_executed(cfg, layer, stage, n_points):
     """Flops the attention kernel EXECUTES for the same result: the feature half of the score Linear is linear in a
     per-point quantity, W . [f[nb] ; r] = (W_top . f)[nb] + W_bot . r, so the kernel gathers a precomputed per-point
-    row and multiplies only the position half (K x h x d); stage 2 re-computes lse1 (K x 10 x h).  The per-point GEMM
-    (h x d per point, 1/16 of what it replaces) runs in its own launch and is not part of this kernel's time."""
+    row and multiplies only the position half (K x h x d); stage 2 re-computes lse1 (K x 10 x h)."""
     d = cfg["dim_output"][layer]
     h = d // 2
     K = cfg["num_neighbors"]
@@ -63,73 +64,105 @@ def lfa_flops_executed(cfg, layer, stage, n_points):
     return 2.0 * mac * n_points
 
 
-def knn_bytes(cfg, n0):
-    """Algorithmic HBM bytes of the neighbour pyramid per frame (SURVEY.md §8d row a1, int32 indices)."""
-    n, tot = n0, 0
-    for r in cfg["sub_sampling_ratio"]:
-        tot += 12 * n + 4 * cfg["num_neighbors"] * n          # self k-NN: xyz read + idx write
-        tot += 12 * (n + n // r) + 4 * n                      # 1-NN interp: xyz of both levels + idx write
-        n //= r
-    return tot
+def knn_bytes_16nn(cfg, n_levels, batch):
+    """Algorithmic HBM bytes of the merged 16-NN launch: 12 B of xyz read + 4 * k B of int32
+    indices written per query, all pyramid levels."""
+    return sum((12 + 4 * cfg["num_neighbors"]) * n for n in n_levels[:cfg["num_layers"]]) * batch
 
 
-def cpu_baseline(frames, sd, budget_s=20.0, max_frames=6, gpu_labels=None):
-    """The CPU oracle (port of the reference path: kd-tree knn_search + PyTorch-CPU forward), timed
-    on a bounded sample of the same frames."""
+def _traffic(kernel_key, batch):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json: per-frame figures)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return float(tj["kernels"][kernel_key]["bytes_per_launch_per_frame"]) * batch
+    except Exception:
+        return None
+
+
+def cpu_baseline(frames, sd, budget_s=24.0, max_frames=6, gpu_labels=None):
+    """The CPU oracle (port of the reference path: kd-tree knn_search + PyTorch-CPU forward), timed on a bounded sample
+    of the same frames.  Thread count: best of a sweep on one frame (oversubscribing a big host slows torch's small
+    per-layer matmuls down), then the sample is timed at that setting."""
     from oracle import ops as oops
     from oracle import randlanet_ref as R
-    done, t_total = 0, 0.0
+    ncpu = os.cpu_count() or 1
     R.forward(sd, CFG, R.build_inputs(frames[:1, :2048].copy(), frames[:1, :2048].copy(), CFG, oops.knn_search))
-    cpu_labels = []
-    for i in range(min(max_frames, frames.shape[0])):
+
+    def one(i):
         f = frames[i:i + 1]
         t0 = time.perf_counter()
-        inp = R.build_inputs(f, f.copy(), CFG, oops.knn_search)
-        logits = R.forward(sd, CFG, inp)
-        t_total += time.perf_counter() - t0
-        done += 1
-        try:
-            cpu_labels.append(np.asarray(logits.argmax(-1)).reshape(-1))
-        except Exception:
-            cpu_labels = None
-        if t_total > budget_s:
+        logits = R.forward(sd, CFG, R.build_inputs(f, f.copy(), CFG, oops.knn_search))
+        return time.perf_counter() - t0, logits
+
+    sweep = {}
+    t_sweep0 = time.perf_counter()
+    for nt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(nt)
+        sweep[nt] = one(0)[0]
+        if time.perf_counter() - t_sweep0 > budget_s * 0.5:
             break
-    out = {"value": done / t_total, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-           "sample": "%d frames of the same synthetic batch, oracle kd-tree kNN (OpenMP, %d threads) + "
-                     "PyTorch-CPU forward restating the reference (%d threads)"
-                     % (done, oops.num_threads(), torch.get_num_threads())}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    done, t_total, cpu_labels = 0, 0.0, []
+    for i in range(min(max_frames, frames.shape[0])):
+        dt, logits = one(i)
+        t_total += dt
+        done += 1
+        cpu_labels.append(np.asarray(logits.argmax(-1)).reshape(-1))
+        if t_total > budget_s * 0.5:
+            break
+    out = {"value": done / t_total, "unit": "frames/s", "cores": int(best), "kind": "port",
+           "host_threads_available": int(ncpu),
+           "thread_sweep_s_per_frame": {str(k): round(v, 3) for k, v in sweep.items()},
+           "sample": "%d frames of the same synthetic batch: oracle kd-tree kNN (OpenMP, %d threads) + PyTorch-CPU forward "
+                     "restating the reference, torch threads = %d (best of the sweep)" % (done, oops.num_threads(), best)}
     # second half of the headline metric ("+ mIoU parity vs CPU ref"): the labels of the GPU path against the oracle's
     # on the sampled frames (SemSegMetric-style IoU per class from the confusion matrix, mean over the classes present)
-    try:
-        if gpu_labels is not None and cpu_labels:
-            g = np.concatenate([np.asarray(gpu_labels[i]).reshape(-1) for i in range(len(cpu_labels))]).astype(np.int64)
-            c = np.concatenate(cpu_labels).astype(np.int64)
-            nc = int(CFG["num_classes"])
-            conf = np.bincount(c * nc + g, minlength=nc * nc).reshape(nc, nc).astype(np.float64)
-            tp = np.diag(conf)
-            denom = conf.sum(0) + conf.sum(1) - tp
-            present = denom > 0
-            out["miou_vs_cpu_oracle"] = float((tp[present] / denom[present]).mean())
-            out["label_agreement"] = float((g == c).mean())
-    except Exception:
-        pass
+    if gpu_labels is not None and cpu_labels:
+        g = np.concatenate([np.asarray(gpu_labels[i]).reshape(-1) for i in range(len(cpu_labels))]).astype(np.int64)
+        c = np.concatenate(cpu_labels).astype(np.int64)
+        nc = int(CFG["num_classes"])
+        conf = np.bincount(c * nc + g, minlength=nc * nc).reshape(nc, nc).astype(np.float64)
+        tp = np.diag(conf)
+        denom = conf.sum(0) + conf.sum(1) - tp
+        present = denom > 0
+        out["miou_vs_cpu_oracle"] = float((tp[present] / denom[present]).mean())
+        out["label_agreement"] = float((g == c).mean())
     return out
+
+
+def synthetic_batch(rank, B, N, nd):
+    """Distinct synthetic sweeps per rank, tiled by seeded z-rotations + re-shuffles to fill the batch."""
+    import synth_data
+    nd = max(1, min(nd, B))
+    base = np.stack([synth_data.semantickitti_patch(rank * 1000 + i, N) for i in range(nd)])
+    rng = np.random.default_rng(77 + rank)
+    frames = np.empty((B, N, 3), np.float32)
+    for b in range(B):
+        f = base[b % nd]
+        if b >= nd:
+            a = rng.uniform(0, 2 * np.pi)
+            rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+            f = (f @ rot.T)[rng.permutation(N)]
+        frames[b] = f
+    return frames
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("ML3D_BENCH_BATCH", 64)))
     ap.add_argument("--distinct-frames", type=int, default=8,
                     help="distinct synthetic frames generated per rank (tiled with seeded rigid transforms)")
     ap.add_argument("--workload", choices=["randlanet", "kpconv", "pointpillars"], default="randlanet",
                     help="randlanet = BASELINE.json configs[1] (the headline metric); the other two are configs[2] / [3]")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="run the neighbour pyramid and the forward of a batch back to back on one stream instead of "
-                         "overlapping batch i+1's pyramid with batch i's forward on two streams")
+                    help="upload, neighbour pyramid and forward of a batch back to back on one stream instead of the "
+                         "three-stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the KPConv / PointPillars side measurements")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
     args = ap.parse_args()
 
@@ -159,74 +192,45 @@ def main():
             dist.destroy_process_group()
         return out
 
-    import synth_data
-    from ml3d.engine import PipelinedRandLAEngine, RandLAInferenceEngine, make_trace
+    from ml3d.engine import RandLAFrameStream, make_trace
 
     B, N = args.frames_per_step, CFG["num_points"]
-    # ---- synthetic frames: distinct sweeps per rank, tiled by seeded z-rotations to fill the batch
-    nd = max(1, min(args.distinct_frames, B))
-    base = np.stack([synth_data.semantickitti_patch(rank * 1000 + i, N) for i in range(nd)])
-    rng = np.random.default_rng(77 + rank)
-    frames = np.empty((B, N, 3), np.float32)
-    for b in range(B):
-        f = base[b % nd]
-        if b >= nd:
-            a = rng.uniform(0, 2 * np.pi)
-            rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
-            f = (f @ rot.T)[rng.permutation(N)]
-        frames[b] = f
+    frames = synthetic_batch(rank, B, N, args.distinct_frames)
     sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
     overlap = not args.no_overlap
-    eng = PipelinedRandLAEngine(CFG, sd, B, N, dev) if overlap else RandLAInferenceEngine(CFG, sd, B, N, dev)
-    pts = torch.from_numpy(frames).to(dev)
-    feats = pts.clone()   # in_channels = 3: features are the xyz themselves (randlanet.py:208-209)
-    # predicted labels travel as uint8 (19 classes); two buffers so the gather of step i overlaps step i + 1
-    lab_dtype = torch.uint8 if CFG["num_classes"] <= 256 else torch.int32
-    labels = [torch.empty((B, N), dtype=lab_dtype, device=dev) for _ in range(2)]
-    recv = [[torch.empty_like(labels[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
+    stream = RandLAFrameStream(CFG, sd, B, N, dev, overlap=overlap)
+    host = torch.from_numpy(frames).pin_memory()          # what a data loader hands over: host xyz (in_channels = 3)
+    gather = mdist.PredictionGather(B, N, CFG["num_classes"], dev)
 
-    def one_step(knn_trace=None, fwd_trace=None):
-        if overlap:
-            scores = eng.submit(pts, feats, knn_trace, fwd_trace)
-            if world > 1:
-                torch.cuda.current_stream().wait_stream(eng.compute)
-        else:
-            scores = eng.step(pts, feats, knn_trace, fwd_trace)
+    def one_step(knn_trace=None, fwd_trace=None, done=None):
+        scores = stream.submit(host, None, knn_trace, fwd_trace, done)
         if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
-            i = step_no[0] & 1
-            step_no[0] += 1
-            if pending[i] is not None:
-                pending[i].wait()
-            labels[i].copy_(torch.argmax(scores, dim=2))
-            _, pending[i] = mdist.gather_predictions(labels[i], dst=0, out=recv[i], async_op=True)
+            if overlap:
+                torch.cuda.current_stream().wait_stream(stream.compute_stream)
+            gather.push(scores)
 
     def drain():
-        if overlap:
-            eng.synchronize()
-        for w in pending:
-            if w is not None:
-                w.wait()
-        pending[0] = pending[1] = None
+        stream.synchronize()
+        gather.drain()
 
     for _ in range(args.warmup):
         one_step()
     drain()
     K = args.steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for a, b in ev + kev:
+    tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    done_ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    for a, b in tev:
         a.record(); b.record()           # materialise the hipEvent_t handles
-    traces = [make_trace(DOMINANT_FWD_TAG, a, b) for a, b in ev]
-    ktraces = [make_trace(0, a, b) for a, b in kev]   # tag 0: 16-NN query kernel of level 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    done_ev[0].record(stream.compute_stream)
     t0 = time.perf_counter()
     for i in range(K):
-        one_step(ktraces[i], traces[i])
+        kind, tag = TRACED[i % len(TRACED)]
+        tr = make_trace(tag, *tev[i])
+        one_step(tr if kind == "knn" else None, tr if kind == "fwd" else None, done_ev[i + 1])
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -237,46 +241,50 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    dom_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    knn_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
 
     out = None
     if rank == 0:
-        layer, stage = DOMINANT_FWD_TAG // 8, DOMINANT_FWD_TAG % 8
-        n_l = eng.n[layer] * B
-        flops = lfa_flops(CFG, layer, stage, n_l)
-        flops_exec = lfa_flops_executed(CFG, layer, stage, n_l)
-        achieved = flops / (dom_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE, KiB -> bytes; profiles/r01_*_pmc_{fetch,write}.csv), scaled to this run's frames per step
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj["dominant_bytes_per_launch_per_frame"] * B
-            except Exception:
-                traffic = None
-        # secondary: the merged 16-NN query launch (all pyramid levels) against the HBM roofline (algorithmic bytes)
-        kb = sum((12 + 4 * 16) * n_l for n_l in eng.n[:CFG["num_layers"]]) * B
+        n_lv = stream.n
+        # per-step intervals on the compute stream (completion of step i-1 -> completion of step i)
+        iv = np.array([done_ev[i].elapsed_time(done_ev[i + 1]) for i in range(K)])
+        per_tag = {}
+        for i in range(K):
+            per_tag.setdefault(TRACED[i % len(TRACED)], []).append(tev[i][0].elapsed_time(tev[i][1]))
+        cands = []
+        for (kind, tag), ts in per_tag.items():
+            ms = float(np.mean(ts))
+            if kind == "knn":
+                kb = knn_bytes_16nn(CFG, n_lv, B)
+                cands.append({"bound": "hbm", "kernel": "knn_tile<16> (16-NN of all pyramid levels, one launch)",
+                              "achieved": kb / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_tile<16>", B),
+                              "avg_launch_ms": ms, "bytes_per_launch": kb,
+                              "note": "algorithmic bytes = 76 B per query (SURVEY.md §8d); the kernel is VALU-bound: the exact "
+                                      "16-of-N selection costs ~12 instructions per candidate and lane, see DESIGN.md §3.2"})
+            else:
+                layer, stage = tag // 8, tag % 8
+                d = CFG["dim_output"][layer]
+                fl_ref = lfa_flops(CFG, layer, stage, n_lv[layer] * B)
+                fl_ex = lfa_flops_executed(CFG, layer, stage, n_lv[layer] * B)
+                name = ("lfa_attn_mfma16<%d>" % stage) if d == 16 else ("lfa_attn_wave<%d,%d>" % (d, stage))
+                cands.append({"bound": "mfma", "kernel": "%s (layer %d)" % (name, layer),
+                              "achieved": fl_ex / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                              "frac": fl_ex / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                              "frac_reference_formulation": fl_ref / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                              "traffic": _traffic(name, B), "avg_launch_ms": ms, "executed_flops_per_launch": fl_ex,
+                              "reference_flops_per_launch": fl_ref})
+        cands.sort(key=lambda c: -c["avg_launch_ms"])
         out = {
-            "metric": "point-cloud frames/sec (RandLA-Net SemanticKITTI inference: kNN pyramid + forward)",
+            "metric": "point-cloud frames/sec (RandLA-Net SemanticKITTI inference: H2D + kNN pyramid + forward)",
             "value": B * K * world / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / K * 1e3, "step_ms_median": float(np.median(iv)), "step_ms_p95": float(np.percentile(iv, 95)),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RandLA-Net SemanticKITTI inference, %d synthetic 45056-point frames per step per GPU "
-                                   "(randlanet_semantickitti.yml), GPU kNN pyramid + fused forward" % B,
-                       "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "lfa_attn_wave<%d,%d> (layer %d)" % (CFG["dim_output"][layer], stage, layer),
-                         "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic, "avg_launch_ms": dom_ms,
-                         "flops_per_launch": flops,
-                         # same launch priced on the flops it executes after the algebraic split of the score Linear
-                         "executed_flops_per_launch": flops_exec,
-                         "frac_executed": flops_exec / (dom_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
-            "roofline_knn": {"bound": "hbm", "kernel": "knn_query_multi<16> (all pyramid levels)", "achieved": kb / (knn_ms * 1e-3) / 1e9,
-                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kb / (knn_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                             "avg_launch_ms": knn_ms, "bytes_per_launch": kb, "traffic": None},
+                                   "(randlanet_semantickitti.yml): host->device upload of xyz + GPU kNN pyramid + fused forward" % B,
+                       "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world,
+                       "h2d_in_timed_region": True, "streams": 3 if overlap else 1},
+            "roofline": cands[0], "roofline_other": cands[1:],
         }
         if args.breakdown:
             bd = {}
@@ -284,26 +292,35 @@ def main():
             a.record(); b.record()
             tags_f = [1000] + [8 * l + s for l in range(CFG["num_layers"]) for s in range(8)] + [1001] + \
                      [1100 + i for i in range(CFG["num_layers"])] + [1200, 1201, 1202]
-            e1 = eng.eng[0] if overlap else eng        # kernels timed one at a time, nothing else on the GPU
+            e1 = stream.single_engine()           # kernels timed one at a time, nothing else on the GPU
+            pts = stream.pts[0]
             for tg in tags_f:
-                e1.step(pts, feats, None, make_trace(tg, a, b)); torch.cuda.synchronize()
+                e1.step(pts, pts, None, make_trace(tg, a, b)); torch.cuda.synchronize()
                 bd["fwd:%d" % tg] = a.elapsed_time(b)
-            for tg in [100 + l for l in range(CFG["num_layers"] + 1)] + list(range(2 * CFG["num_layers"])):
-                e1.step(pts, feats, make_trace(tg, a, b), None); torch.cuda.synchronize()
+            for tg in [100 + l for l in range(CFG["num_layers"] + 1)] + [0, 1]:
+                e1.step(pts, pts, make_trace(tg, a, b), None); torch.cuda.synchronize()
                 bd["knn:%d" % tg] = a.elapsed_time(b)
             out["breakdown_ms"] = bd
         if not args.no_cpu_baseline and world == 1:
-            gpu_labels = None
-            try:        # labels of the first frames of the batch from one more (untimed) pass of the same engine
-                e1 = eng.eng[0] if overlap else eng
-                sc = e1.step(pts, feats)
-                torch.cuda.synchronize()
-                gpu_labels = torch.argmax(sc[:6], dim=2).cpu().numpy()
-            except Exception:
-                gpu_labels = None
+            e1 = stream.single_engine()           # labels of the first frames from one more (untimed) pass
+            sc = e1.step(stream.pts[0], stream.pts[0])
+            torch.cuda.synchronize()
+            gpu_labels = torch.argmax(sc[:6], dim=2).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(frames, sd, gpu_labels=gpu_labels)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_workloads:
+            import bench_models
+            wl = {}
+            del stream
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(steps=8, warmup=2, frames_per_step=64, no_cpu_baseline=args.no_cpu_baseline)
+            for name, fn in (("kpconv", bench_models.run_kpconv), ("pointpillars", bench_models.run_pointpillars)):
+                try:
+                    wl[name] = fn(sub, 0, 1, dev, None)
+                except Exception as e:      # a side measurement must never take the headline line down
+                    wl[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["workloads"] = wl
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -294,6 +294,21 @@ int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_thres
              void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* pairwise rotated box IoU for the detection metric —       */
+/* replaces open3d.ml.contrib.iou_bev_{cpu,cuda} / iou_3d_{cpu,cuda}           */
+/*   ml3d/metrics/mAP.py:85-88, ml3d/metrics/__init__.py:3-9,                  */
+/*   ml3d/datasets/utils/operations.py:7.                                      */
+/* iou_bev: boxes [n,5] / [m,5] = (x, z, w, l, yaw): centre and size in the    */
+/*   ground plane of the camera frame.  iou_3d: boxes [n,7] / [m,7] =          */
+/*   (x, y, z, w, h, l, yaw), y = bottom face (the y axis points down: the box */
+/*   spans [y - h, y]).  out_iou float32 [n, m] row-major.  The rotated        */
+/*   intersection is the NMS's (same corner / clipping arithmetic).            */
+/* ------------------------------------------------------------------------- */
+int ml3d_iou_bev(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m, float* out_iou, void* stream);
+
+int ml3d_iou_3d(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m, float* out_iou, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* patch sampler / vote accumulation                         */
 /* ml3d_nearest_to_center: the k points nearest to a centre, ascending         */
 /*   (d2, index) — replaces search_tree.query(center_point, k=num_points) of   */

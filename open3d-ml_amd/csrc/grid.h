@@ -77,40 +77,6 @@ int grid_build_derived(const float* points, Segs segs, const GridWs& ws, const G
 // Build with a caller-chosen cell size (fixed-radius search: cell ~ radius, so a query's box is 3x3x3
 // cells); skips the occupancy probe.  The size is grown until the dense table fits.
 int grid_build_fixed(const float* points, Segs segs, const GridWs& ws, float cell, hipStream_t stream);
-// ---- tile order --------------------------------------------------------------------------------------------------
-// The k-NN kernel works on TILES of 64 queries that are close in space (one wave per tile, candidates shared by the
-// whole wave).  The order comes from a second, much coarser counting sort of the points: bricks of BRICK^3 grid cells,
-// numbered boustrophedon (x reverses on odd brick rows, y on odd brick slabs) so consecutive bricks always touch; the
-// order of the points inside a brick is arbitrary.  64 consecutive entries of `qorder` then span one or two
-// neighbouring bricks.  The order affects speed only.
-constexpr int BRICK = 4;
-constexpr int BRICK_CAP = 2;     // brick table: at most BRICK_CAP * n + 64 bricks per segment
-
-struct BrickSeg {
-    int f;           // brick edge in grid cells (>= BRICK; grown until the table fits)
-    int dims[3];
-    int base;        // first brick of this segment in the brick table
-};
-
-struct TileOrderWs {
-    BrickSeg* bsegs;     // [batch]
-    int* table;          // brick table, total_bricks + 2
-    int* block_sums;     // scan scratch
-    int* tile_splits;    // [batch + 1] first tile of every segment (tiles never straddle segments)
-    float4* qorder;      // [n_total] (x, y, z, bits(local index)) in tile order, segment-contiguous
-    int64_t total_bricks;
-    int64_t n_total;
-    int batch;
-};
-
-size_t tile_order_ws_bytes(int64_t n_total, int64_t batch);
-bool tile_order_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, TileOrderWs* out);
-// brick-sort `points` (layout `segs`) using the cell geometry of the built grid `gsegs` (same batch items; points outside
-// that grid's box are clamped to its boundary bricks)
-int tile_order_build(const float* points, Segs segs, const GridSeg* gsegs, const TileOrderWs& ws, hipStream_t stream);
-// upper bound of the number of 64-query tiles (host side, for the launch)
-inline int64_t tile_count_bound(int64_t n_total, int64_t batch) { return (n_total + 63) / 64 + batch; }
-
 // bounding boxes only: bbox[6*s + {0..2}] = ordered-uint(min), [3..5] = ordered-uint(max)
 int bbox_compute(const float* points, Segs segs, int64_t n_total, unsigned* bbox, unsigned* occ_scratch,
                  hipStream_t stream);

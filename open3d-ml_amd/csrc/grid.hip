@@ -560,113 +560,4 @@ int grid_build_derived(const float* points, Segs S, const GridWs& ws, const Grid
     return grid_sort(points, S, ws, stream);
 }
 
-// ---- tile order: counting sort by boustrophedon brick id ------------------------------------------------------------
-static void tile_order_sizes(int64_t n_total, int64_t batch, int64_t* total_bricks, int64_t* n_blocks) {
-    *total_bricks = (int64_t)BRICK_CAP * n_total + (int64_t)GRID_SLACK * batch;
-    *n_blocks = (*total_bricks + 2 + 1023) / 1024 + 1;
-}
-
-size_t tile_order_ws_bytes(int64_t n_total, int64_t batch) {
-    int64_t tb, nb;
-    tile_order_sizes(n_total, batch, &tb, &nb);
-    size_t b = 0;
-    b += align_up(sizeof(BrickSeg) * (size_t)batch);
-    b += align_up(sizeof(int) * (size_t)(tb + 2));
-    b += align_up(sizeof(int) * (size_t)nb);
-    b += align_up(sizeof(int) * (size_t)(batch + 1));
-    b += align_up(sizeof(float4) * (size_t)(n_total > 0 ? n_total : 1));
-    return b + 256;
-}
-
-bool tile_order_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, TileOrderWs* out) {
-    if (bytes < tile_order_ws_bytes(n_total, batch)) return false;
-    int64_t tb, nb;
-    tile_order_sizes(n_total, batch, &tb, &nb);
-    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    out->bsegs = (BrickSeg*)p;     p += align_up(sizeof(BrickSeg) * (size_t)batch);
-    out->table = (int*)p;          p += align_up(sizeof(int) * (size_t)(tb + 2));
-    out->block_sums = (int*)p;     p += align_up(sizeof(int) * (size_t)nb);
-    out->tile_splits = (int*)p;    p += align_up(sizeof(int) * (size_t)(batch + 1));
-    out->qorder = (float4*)p;
-    out->total_bricks = tb;
-    out->n_total = n_total;
-    out->batch = (int)batch;
-    return true;
-}
-
-__global__ void brick_setup(Segs S, const GridSeg* __restrict__ gsegs, BrickSeg* bsegs, int* tile_splits, int batch) {
-    // single thread: the per-segment brick geometry and the tile prefix (batch is a few thousand at most)
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int tiles = 0;
-    for (int s = 0; s < batch; ++s) {
-        const GridSeg g = gsegs[s];
-        const int64_t n = seg_len(S, s);
-        const int64_t pb = seg_begin_packed(S, s);
-        const int64_t cap = (int64_t)BRICK_CAP * n + GRID_SLACK;
-        BrickSeg b;
-        b.f = BRICK;
-        for (int it = 0; it < 32; ++it) {
-            int64_t prod = 1;
-            for (int a = 0; a < 3; ++a) { b.dims[a] = (g.dims[a] + b.f - 1) / b.f; prod *= b.dims[a]; }
-            if (prod <= cap) break;
-            b.f *= 2;
-        }
-        b.base = (int)((int64_t)BRICK_CAP * pb + (int64_t)GRID_SLACK * s);
-        bsegs[s] = b;
-        tile_splits[s] = tiles;
-        tiles += (int)((n + 63) / 64);
-    }
-    tile_splits[batch] = tiles;
-}
-
-__device__ __forceinline__ int point_brick(const GridSeg* g, const BrickSeg* b, float x, float y, float z) {
-    int bx = cell_coord(x, g->lo[0], g->inv_c, g->dims[0]) / b->f;
-    int by = cell_coord(y, g->lo[1], g->inv_c, g->dims[1]) / b->f;
-    int bz = cell_coord(z, g->lo[2], g->inv_c, g->dims[2]) / b->f;
-    if (bz & 1) by = b->dims[1] - 1 - by;                       // consecutive bricks always share a face
-    if ((by + bz * b->dims[1]) & 1) bx = b->dims[0] - 1 - bx;
-    return b->base + bx + b->dims[0] * (by + b->dims[1] * bz);
-}
-
-__global__ void brick_hist(const float* __restrict__ pts, Segs S, int64_t n_total, const GridSeg* __restrict__ gsegs,
-                           const BrickSeg* __restrict__ bsegs, int* table) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    int s; int64_t local;
-    seg_locate(S, i, s, local);
-    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
-    atomicAdd(&table[point_brick(&gsegs[s], &bsegs[s], p[0], p[1], p[2]) + 2], 1);
-}
-
-__global__ void brick_scatter(const float* __restrict__ pts, Segs S, int64_t n_total, const GridSeg* __restrict__ gsegs,
-                              const BrickSeg* __restrict__ bsegs, int* table, float4* qorder) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    int s; int64_t local;
-    seg_locate(S, i, s, local);
-    const float* p = pts + 3 * (seg_begin_global(S, s) + local);
-    const float x = p[0], y = p[1], z = p[2];
-    int pos = atomicAdd(&table[point_brick(&gsegs[s], &bsegs[s], x, y, z) + 1], 1);
-    qorder[pos] = make_float4(x, y, z, __int_as_float((int)local));
-}
-
-int tile_order_build(const float* points, Segs S, const GridSeg* gsegs, const TileOrderWs& ws, hipStream_t stream) {
-    const int B = ws.batch;
-    if (B <= 0) return 0;
-    const int64_t n = ws.n_total;
-    (void)hipMemsetAsync(ws.table, 0, sizeof(int) * (size_t)(ws.total_bricks + 2), stream);
-    hipLaunchKernelGGL(brick_setup, dim3(1), dim3(64), 0, stream, S, gsegs, ws.bsegs, ws.tile_splits, B);
-    ML3D_LAUNCH_CHECK();
-    if (n > 0) {
-        const int nb = (int)((n + 255) / 256);
-        hipLaunchKernelGGL(brick_hist, dim3(nb), dim3(256), 0, stream, points, S, n, gsegs, ws.bsegs, ws.table);
-        ML3D_LAUNCH_CHECK();
-        if (scan_inclusive_i32(ws.table + 2, ws.total_bricks, ws.block_sums, stream)) return -3;
-        hipLaunchKernelGGL(brick_scatter, dim3(nb), dim3(256), 0, stream, points, S, n, gsegs, ws.bsegs, ws.table,
-                           ws.qorder);
-        ML3D_LAUNCH_CHECK();
-    }
-    return 0;
-}
-
 }  // namespace ml3d

@@ -45,7 +45,8 @@ struct QuerySrc {
 // (exponent+mantissa are compared like an integer; a pattern is NaN/inf only when the float d2 is), so one
 // compare-exchange of (d2, index) pairs is v_min_f64 + v_max_f64 (key_minmax, gfx950_ops.h) instead of a 64-bit compare
 // and four selects.  d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on
-// gfx950).
+// gfx950).  Measured (tools/micro/valu_rates.hip, profiles/r02_micro_valu_rates.log): v_min_f64 / v_max_f64 issue at the
+// rate of v_min_u32; the integer form (v_cmp_lt_u64 + 4 v_cndmask) is 7.6x slower.
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
     if (key < best[K - 1]) {
@@ -60,9 +61,8 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
 #endif
 
 template <int K>
-__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
-                                         float qz, double (&best)[K]) {
-    int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
+__device__ __forceinline__ void scan_range(const GridView& G, int p0, int p1, float qx, float qy, float qz,
+                                           double (&best)[K]) {
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
     // per group instead of one per candidate -- the loop is latency-bound: lane-per-query gathers, ~5 waves per SIMD);
     // indices past the run are clamped to its last point and skipped
@@ -79,6 +79,12 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
             }
         }
     }
+}
+
+template <int K>
+__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
+                                         float qz, double (&best)[K]) {
+    scan_range<K>(G, G.cell_start[cell_a], G.cell_start[cell_b + 1], qx, qy, qz, best);
 }
 
 template <int K>
@@ -113,6 +119,23 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             int xa = max(cx - r, 0), xb = min(cx + r, dxm);
             int ya = max(cy - r, 0), yb = min(cy + r, dym);
             int za = max(cz - r, 0), zb = min(cz + r, dzm);
+#ifndef KNN_NO_ROW_PREFETCH
+            if (r == 1) {
+                // the 3 x 3 rows of the first block: all 18 row bounds are requested before the first one is used (the
+                // cell table does not fit the L2 -- one exposed memory latency instead of nine in a row)
+                int p0[9], p1[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int y = cy - 1 + i % 3, z = cz - 1 + i / 3;
+                    const bool in = y >= 0 && y <= dym && z >= 0 && z <= dzm;
+                    const int row = g.cell_base + g.dims[0] * ((in ? y : cy) + g.dims[1] * (in ? z : cz));
+                    p0[i] = G.cell_start[row + xa];
+                    p1[i] = in ? G.cell_start[row + xb + 1] : p0[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) scan_range<K>(G, p0[i], p1[i], qx, qy, qz, best);
+            } else
+#endif
             for (int z = za; z <= zb; ++z) {
                 int az = z > cz ? z - cz : cz - z;
                 for (int y = ya; y <= yb; ++y) {
@@ -170,15 +193,60 @@ knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int
     knn_one<K>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// Several independent searches share ONE launch (the levels of the RandLA pyramid): the small levels alone cannot fill
-// the chip; side by side they hide under the largest level.  Jobs are ordered largest first.
+// Several independent searches in ONE launch (the levels of the RandLA pyramid): the small levels are
+// latency-bound (one thread per query, a few thousand queries), so running them back to back leaves
+// the chip idle; side by side they hide under the largest level.  Jobs are ordered largest first.
 constexpr int KNN_MAX_JOBS = 8;
+struct KnnJob {
+    GridView G;
+    QuerySrc Q;
+    Segs support;
+    int32_t* out_idx;
+    unsigned block_begin;
+};
+struct KnnJobs {
+    KnnJob j[KNN_MAX_JOBS];
+    int n;
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) knn_query_multi(KnnJobs J, int k, int index_local) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < KNN_MAX_JOBS; ++i)
+        if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
+    const KnnJob& jb = J.j[ji];
+    knn_one<K>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+               (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
+}
+
+static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
+    unsigned blocks = 0;
+    for (int i = 0; i < J.n; ++i) {
+        J.j[i].block_begin = blocks;
+        blocks += (unsigned)((J.j[i].Q.n_total + 255) / 256);
+    }
+    if (blocks == 0) return 0;
+    if (k == 1) hipLaunchKernelGGL(knn_query_multi<1>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 8) hipLaunchKernelGGL(knn_query_multi<8>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 16) hipLaunchKernelGGL(knn_query_multi<16>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 32) hipLaunchKernelGGL(knn_query_multi<32>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 64) hipLaunchKernelGGL(knn_query_multi<64>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else return ML3D_E_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
 
 static int launch_query(const GridView& G, const QuerySrc& Q, int k, int index_local, Segs support_segs,
                         int32_t* out_idx, float* out_d2, hipStream_t stream) {
     if (Q.n_total <= 0) return 0;
     dim3 grid((unsigned)((Q.n_total + 255) / 256)), block(256);
-    if (k <= 32)
+    if (k == 1)
+        hipLaunchKernelGGL(knn_query<1>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 8)
+        hipLaunchKernelGGL(knn_query<8>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 16)
+        hipLaunchKernelGGL(knn_query<16>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
+    else if (k <= 32)
         hipLaunchKernelGGL(knn_query<32>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
     else if (k <= 64)
         hipLaunchKernelGGL(knn_query<64>, grid, block, 0, stream, G, Q, k, index_local, support_segs, out_idx, out_d2);
@@ -187,371 +255,12 @@ static int launch_query(const GridView& G, const QuerySrc& Q, int k, int index_l
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
-// =====================================================================================================================
-// Tile kernel (k <= 16): ONE WAVE = 64 queries that are close in space (a "tile": 64 consecutive entries of the brick
-// order, grid.h).  The wave stages the support points of the cells around the tile's bounding box into LDS once
-// (coalesced float4 loads, a cell row = one contiguous run of the sorted array) and EVERY lane scans the same candidate
-// list from LDS (broadcast reads): no per-lane cell walk, no divergent trip counts, no exposed global latency in the
-// scan.  Candidates are consumed 16 at a time: 16 keys -> 60-comparator sorting network -> half-cleaner against the
-// sorted best-16 (min(best[i], new[15 - i])) -> 4-stage bitonic merge; every compare-exchange is v_min_f64 + v_max_f64
-// on the packed keys.  ~200 instructions per 16 candidates whatever the data (the per-lane insertion it replaces cost
-// ~34 per candidate as soon as ONE lane of the wave accepted it).
-//
-// Exactness: pass 1 scans bbox(tile) + a small halo; a lane is final once its k-th distance is strictly inside the
-// scanned box (same face-distance test as the shell search).  The k-th distances found so far bound the true ones from
-// above, so pass 2 scans exactly the cells of the hull of the still-open lanes' balls minus what was scanned -- and is
-// final for every lane that had k candidates.  Lanes with fewer than k (tiny / far-away supports) double the box.
-// =====================================================================================================================
-constexpr int TILE_CH = 256;                // candidates staged per chunk and wave (4 KB of LDS)
-constexpr int PAD_IDX = 0x7fffffff;         // index of the (+inf, +inf, +inf) filler candidates
-
-struct TileJob {
-    GridView G;                 // support grid
-    const float4* qorder;       // queries in tile order (x, y, z, bits(local index)), segment-contiguous
-    const int* tile_splits;     // [batch + 1] first tile of every segment (used when qsegs.splits != nullptr)
-    Segs qsegs;                 // layout of the queries / output rows
-    Segs support;               // layout of the support items (global index base)
-    int32_t* out_idx;
-    float* out_d2;
-    unsigned tile_begin;        // first tile of this job in the launch
-    unsigned n_tiles;           // upper bound of this job's tile count
-};
-struct TileJobs {
-    TileJob j[KNN_MAX_JOBS];
-    int n;
-};
-
-#ifdef ML3D_KNN_STATS
-// emulator-only instrumentation (tests/hipemu build with -DML3D_KNN_STATS): tiles, candidates, blocks merged / skipped, passes
-unsigned long long g_knn_stats[8];
-extern "C" unsigned long long* ml3d_knn_stats() { return g_knn_stats; }
-#define KNN_STAT(i, v) do { if (lane == 0) atomicAdd(&g_knn_stats[i], (unsigned long long)(v)); } while (0)
-#else
-#define KNN_STAT(i, v) do { } while (0)
-#endif
-
-struct CellBox { int xa, xb, ya, yb, za, zb; };
-
-// wave reductions; the result is handed back through readfirstlane so the compiler KNOWS it is wave-uniform (SGPR):
-// everything derived from it -- the cell box, loop bounds, branches -- then runs on the scalar unit
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return uni(v);
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return uni(v);
-}
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return uni(v);
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return uni(v);
-}
-__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
-
-#define KCE(i, j) key_minmax(v[i], v[j], v[i], v[j])
-// 60-comparator, 10-layer sorting network for 16 keys (ascending); verified exhaustively (0-1 principle) by
-// tests/test_host_logic.py::test_sort16_network
-__device__ __forceinline__ void sort16(double (&v)[16]) {
-    KCE(0, 13); KCE(1, 12); KCE(2, 15); KCE(3, 14); KCE(4, 8); KCE(5, 6); KCE(7, 11); KCE(9, 10);
-    KCE(0, 5); KCE(1, 7); KCE(2, 9); KCE(3, 4); KCE(6, 13); KCE(8, 14); KCE(10, 15); KCE(11, 12);
-    KCE(0, 1); KCE(2, 3); KCE(4, 5); KCE(6, 8); KCE(7, 9); KCE(10, 11); KCE(12, 13); KCE(14, 15);
-    KCE(0, 2); KCE(1, 3); KCE(4, 10); KCE(5, 11); KCE(6, 7); KCE(8, 9); KCE(12, 14); KCE(13, 15);
-    KCE(1, 2); KCE(3, 12); KCE(4, 6); KCE(5, 7); KCE(8, 10); KCE(9, 11); KCE(13, 14);
-    KCE(1, 4); KCE(2, 6); KCE(5, 8); KCE(7, 10); KCE(9, 13); KCE(11, 14);
-    KCE(2, 4); KCE(3, 6); KCE(9, 12); KCE(11, 13);
-    KCE(3, 5); KCE(6, 8); KCE(7, 9); KCE(10, 12);
-    KCE(3, 4); KCE(5, 6); KCE(7, 8); KCE(9, 10); KCE(11, 12);
-    KCE(6, 7); KCE(8, 9);
-}
-// best (sorted) <- the 16 smallest of best U fresh (fresh sorted): half-cleaner + bitonic merge
-__device__ __forceinline__ void merge16(double (&v)[16], const double (&fresh)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = key_min(v[i], fresh[15 - i]);
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1)
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if ((i & d) == 0) KCE(i, i + d);
-}
-#undef KCE
-
-__device__ __forceinline__ double pack_key(float d2, float idx_bits) {
-    return __longlong_as_double((long long)(((u64)__float_as_uint(d2) << 32) | (u64)__float_as_uint(idx_bits)));
-}
-
-template <int K>
-__global__ void __launch_bounds__(256) ML3D_WAVES_PER_SIMD(3) knn_tile(TileJobs J, int k, int index_local) {
-    static_assert(K == 1 || K == 16, "tile kernel: k = 1 or k <= 16");
-    __shared__ float4 s_cand[4][TILE_CH];
-    __shared__ int s_rstart[4][64];
-    __shared__ int s_roff[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4* cand = s_cand[wv];
-    int* rstart = s_rstart[wv];
-    int* roff = s_roff[wv];
-
-    const unsigned tile_g = blockIdx.x * 4 + wv;
-    int ji = 0;
-#pragma unroll
-    for (int i = 1; i < KNN_MAX_JOBS; ++i)
-        if (i < J.n && tile_g >= J.j[i].tile_begin) ji = i;
-    const TileJob& jb = J.j[ji];
-    const unsigned t = tile_g - jb.tile_begin;
-    if (t >= jb.n_tiles) return;
-
-    // ---- which queries (wave-uniform) ----------------------------------------------------------------------------
-    int s, cnt;
-    int64_t first;
-    if (!jb.qsegs.splits) {
-        const int64_t nu = jb.qsegs.n_uniform;
-        const unsigned tps = (unsigned)((nu + 63) / 64);
-        if (tps == 0) return;
-        s = (int)(t / tps);
-        if (s >= jb.qsegs.batch) return;
-        const int64_t tl = (int64_t)(t - (unsigned)s * tps) * 64;
-        first = (int64_t)s * nu + tl;
-        cnt = (int)min((int64_t)64, nu - tl);
-    } else {
-        const int B = jb.qsegs.batch;
-        if ((int)t >= jb.tile_splits[B]) return;
-        int lo = 0, hi = B;                       // largest s with tile_splits[s] <= t (never an empty item)
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (jb.tile_splits[mid] <= (int)t) lo = mid; else hi = mid;
-        }
-        s = lo;
-        const int64_t tl = (int64_t)((int)t - jb.tile_splits[s]) * 64;
-        first = jb.qsegs.splits[s] + tl;
-        cnt = (int)min((int64_t)64, jb.qsegs.splits[s + 1] - jb.qsegs.splits[s] - tl);
-    }
-    const bool valid = lane < cnt;
-    const float4 q4 = jb.qorder[first + (valid ? lane : cnt - 1)];   // idle lanes shadow the tile's last query
-    const float qx = q4.x, qy = q4.y, qz = q4.z;
-    const GridSeg g = jb.G.segs[s];
-
-    double best[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
-
-    if (g.n > 0) {
-        const int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
-        // ---- pass-1 box: the tile's bounding box plus a small halo, in cells ---------------------------------------
-        const float h0 = g.c * (K == 1 ? 0.25f : 0.5f);
-        CellBox R, Rold = {0, -1, 0, -1, 0, -1};
-        R.xa = uni(cell_coord(wave_min_f(qx) - h0, g.lo[0], g.inv_c, g.dims[0]));
-        R.xb = uni(cell_coord(wave_max_f(qx) + h0, g.lo[0], g.inv_c, g.dims[0]));
-        R.ya = uni(cell_coord(wave_min_f(qy) - h0, g.lo[1], g.inv_c, g.dims[1]));
-        R.yb = uni(cell_coord(wave_max_f(qy) + h0, g.lo[1], g.inv_c, g.dims[1]));
-        R.za = uni(cell_coord(wave_min_f(qz) - h0, g.lo[2], g.inv_c, g.dims[2]));
-        R.zb = uni(cell_coord(wave_max_f(qz) + h0, g.lo[2], g.inv_c, g.dims[2]));
-        bool has_old = false;
-        KNN_STAT(0, 1);
-
-        for (int pass = 0;; ++pass) {
-            KNN_STAT(5, 1);
-            // ---- scan the cells of R that are not in Rold --------------------------------------------------------
-            // work items: one x-run of cells per (y, z) row of R -- two when the row also crosses Rold (left / right part)
-            const int ny = R.yb - R.ya + 1, nz = R.zb - R.za + 1;
-            const int parts = has_old ? 2 : 1;
-            const int items = ny * nz * parts;
-            int item_base = 0, total = 0, e = 0, fill = 0;
-            bool input_done = false;
-            for (;;) {
-                if (!input_done && e == total) {
-                    if (item_base >= items) {
-                        input_done = true;
-                    } else {
-                        // next 64 runs: (start, length) per lane, exclusive offsets by a wave scan
-                        const int it = item_base + lane;
-                        int start = 0, len = 0;
-                        if (it < items) {
-                            const int part = has_old ? (it & 1) : 0;
-                            const int r = has_old ? (it >> 1) : it;
-                            const int y = R.ya + r % ny, z = R.za + r / ny;
-                            int x0 = R.xa, x1 = R.xb;
-                            if (has_old) {
-                                const bool inside = y >= Rold.ya && y <= Rold.yb && z >= Rold.za && z <= Rold.zb;
-                                if (inside) {
-                                    if (part == 0) x1 = Rold.xa - 1; else x0 = Rold.xb + 1;
-                                } else if (part == 1) {
-                                    x1 = x0 - 1;
-                                }
-                            }
-                            if (x0 <= x1) {
-                                const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                                start = jb.G.cell_start[row + x0];
-                                len = jb.G.cell_start[row + x1 + 1] - start;
-                            }
-                        }
-                        const int incl = wave_incl_scan_i(len, lane);
-                        total = __builtin_amdgcn_readlane(incl, 63);
-                        rstart[lane] = start;
-                        roff[lane] = incl - len;
-                        wave_lds_sync();
-                        e = 0;
-                        item_base += 64;
-                    }
-                }
-                if (!input_done) {
-                    // copy elements [e, e + take) of this round's concatenated runs to cand[fill ..)
-                    const int take = min(total - e, TILE_CH - fill);
-                    for (int i = lane; i < take; i += 64) {
-                        const int gi = e + i;
-                        int lo = 0;                      // largest r with roff[r] <= gi (zero-length runs never win)
-#pragma unroll
-                        for (int st = 32; st > 0; st >>= 1)
-                            if (roff[lo + st] <= gi) lo += st;
-                        cand[fill + i] = jb.G.sorted[rstart[lo] + (gi - roff[lo])];
-                    }
-                    fill += take;
-                    e += take;
-                    if (fill < TILE_CH) continue;
-                } else if (fill == 0) {
-                    break;
-                }
-                // ---- consume the staged chunk -------------------------------------------------------------------
-                const int nc = (fill + 15) & ~15;
-                if (lane < nc - fill) cand[fill + lane] = make_float4(__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u),
-                                                                       __uint_as_float(0x7f800000u), __int_as_float(PAD_IDX));
-                wave_lds_sync();
-                KNN_STAT(1, fill);
-                if constexpr (K == 1) {
-                    for (int c0 = 0; c0 < nc; c0 += 4) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float4 c = cand[c0 + j];
-                            best[0] = key_min(best[0], pack_key(dist2_canon(qx, qy, qz, c.x, c.y, c.z), c.w));
-                        }
-                    }
-                } else {
-                    for (int c0 = 0; c0 < nc; c0 += 16) {
-                        double fresh[16];
-                        unsigned dmin = 0xffffffffu;
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const float4 c = cand[c0 + j];
-                            const float d2 = dist2_canon(qx, qy, qz, c.x, c.y, c.z);
-                            dmin = min(dmin, __float_as_uint(d2));
-                            fresh[j] = pack_key(d2, c.w);
-                        }
-                        // nothing in this block can enter any lane's list: skip the networks (d2 >= 0: uint order)
-                        const unsigned kth_hi = (unsigned)((u64)__double_as_longlong(best[K - 1]) >> 32);
-                        if (!__any(dmin <= kth_hi)) { KNN_STAT(3, 1); continue; }
-                        KNN_STAT(2, 1);
-                        sort16(fresh);
-                        merge16(best, fresh);
-                    }
-                }
-                wave_lds_sync();      // every lane is done with the chunk before it is refilled
-                fill = 0;
-                if (input_done) break;
-            }
-
-            // ---- which lanes are final? --------------------------------------------------------------------------
-            u64 kth = (u64)__double_as_longlong(best[K - 1]);
-            if (K > 1 && k < K) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) if (j == k - 1) kth = (u64)__double_as_longlong(best[j]);
-            }
-            const bool all = R.xa <= 0 && R.xb >= dxm && R.ya <= 0 && R.yb >= dym && R.za <= 0 && R.zb >= dzm;
-            if (all) break;
-            float gd = 3.0e38f;
-            if (R.xa > 0) gd = fminf(gd, qx - (g.lo[0] + (float)R.xa * g.c));
-            if (R.xb < dxm) gd = fminf(gd, (g.lo[0] + (float)(R.xb + 1) * g.c) - qx);
-            if (R.ya > 0) gd = fminf(gd, qy - (g.lo[1] + (float)R.ya * g.c));
-            if (R.yb < dym) gd = fminf(gd, (g.lo[1] + (float)(R.yb + 1) * g.c) - qy);
-            if (R.za > 0) gd = fminf(gd, qz - (g.lo[2] + (float)R.za * g.c));
-            if (R.zb < dzm) gd = fminf(gd, (g.lo[2] + (float)(R.zb + 1) * g.c) - qz);
-            gd -= g.margin;
-            const float dk = __uint_as_float((unsigned)(kth >> 32));       // NaN pattern when the slot is empty
-            const bool found = kth != KEY_EMPTY && (unsigned)(kth >> 32) < 0x7f800000u;
-            const bool exact = found && gd > 0.f && dk < gd * gd * 0.999999f;
-            if (__all(exact)) break;
-            // ---- next box: hull of the open lanes' balls (upper bounds), or twice the box for lanes still short of k --
-            CellBox W = R;
-            if (!exact) {
-                if (found) {
-                    const float dn = sqrtf(dk) * 1.000001f + 2.0f * g.margin;
-                    W.xa = min(W.xa, cell_coord(qx - dn, g.lo[0], g.inv_c, g.dims[0]));
-                    W.xb = max(W.xb, cell_coord(qx + dn, g.lo[0], g.inv_c, g.dims[0]));
-                    W.ya = min(W.ya, cell_coord(qy - dn, g.lo[1], g.inv_c, g.dims[1]));
-                    W.yb = max(W.yb, cell_coord(qy + dn, g.lo[1], g.inv_c, g.dims[1]));
-                    W.za = min(W.za, cell_coord(qz - dn, g.lo[2], g.inv_c, g.dims[2]));
-                    W.zb = max(W.zb, cell_coord(qz + dn, g.lo[2], g.inv_c, g.dims[2]));
-                } else {
-                    const int wx = R.xb - R.xa + 1, wy = R.yb - R.ya + 1, wz = R.zb - R.za + 1;
-                    W.xa = R.xa - wx; W.xb = R.xb + wx;
-                    W.ya = R.ya - wy; W.yb = R.yb + wy;
-                    W.za = R.za - wz; W.zb = R.zb + wz;
-                }
-            }
-            CellBox Nx;
-            Nx.xa = max(wave_min_i(W.xa), 0); Nx.xb = min(wave_max_i(W.xb), dxm);
-            Nx.ya = max(wave_min_i(W.ya), 0); Nx.yb = min(wave_max_i(W.yb), dym);
-            Nx.za = max(wave_min_i(W.za), 0); Nx.zb = min(wave_max_i(W.zb), dzm);
-            if (Nx.xa == R.xa && Nx.xb == R.xb && Nx.ya == R.ya && Nx.yb == R.yb && Nx.za == R.za && Nx.zb == R.zb) {
-                // rounding left the hull where it was: grow by one cell (the box is not the whole grid here)
-                Nx.xa = max(R.xa - 1, 0); Nx.xb = min(R.xb + 1, dxm);
-                Nx.ya = max(R.ya - 1, 0); Nx.yb = min(R.yb + 1, dym);
-                Nx.za = max(R.za - 1, 0); Nx.zb = min(R.zb + 1, dzm);
-            }
-            Rold = R;
-            R = Nx;
-            has_old = true;
-        }
-    }
-
-    if (!valid) return;
-    const int64_t row = seg_begin_packed(jb.qsegs, s) + (int64_t)__float_as_int(q4.w);
-    const int64_t base = index_local ? 0 : seg_begin_global(jb.support, s);
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < k) {
-            const u64 key = (u64)__double_as_longlong(best[j]);
-            const bool ok = key != KEY_EMPTY && (unsigned)(key & 0xffffffffull) != (unsigned)PAD_IDX;
-            jb.out_idx[row * k + j] = ok ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
-            if (jb.out_d2) jb.out_d2[row * k + j] = ok ? __uint_as_float((unsigned)(key >> 32)) : __uint_as_float(0x7f800000u);
-        }
-    }
-}
-
-static int launch_tiles(TileJobs& J, int k, int index_local, hipStream_t stream) {
-    unsigned tiles = 0;
-    for (int i = 0; i < J.n; ++i) {
-        J.j[i].tile_begin = tiles;
-        tiles += J.j[i].n_tiles;
-    }
-    if (tiles == 0) return 0;
-    const unsigned blocks = (tiles + 3) / 4;
-    if (k == 1) hipLaunchKernelGGL(knn_tile<1>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 16) hipLaunchKernelGGL(knn_tile<16>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else return ML3D_E_UNSUPPORTED;
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-}
-
-// tile order for the forward's attention kernels: the brick-sorted (packed, cloud-major) sequence of point rows
-__global__ void order_from_qorder(const float4* __restrict__ qorder, int64_t n_total, int64_t n_per_item,
-                                  int32_t* __restrict__ out) {
+// tile order for the forward's attention kernels: the grid's cell-sorted (packed, cloud-major) sequence of point rows
+__global__ void order_from_grid(const float4* __restrict__ sorted, int64_t n_total, int64_t n_per_item,
+                                int32_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
-    out[i] = (int32_t)((i / n_per_item) * n_per_item + (int64_t)__float_as_int(qorder[i].w));
+    out[i] = (int32_t)((i / n_per_item) * n_per_item + (int64_t)__float_as_int(sorted[i].w));
 }
 
 static float tuning_occ() {
@@ -567,7 +276,8 @@ using namespace ml3d;
 extern "C" int ml3d_abi_version(void) { return 1; }
 
 extern "C" size_t ml3d_knn_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch) {
-    return grid_ws_bytes(n_points, batch) + tile_order_ws_bytes(n_queries, batch) + 256;
+    (void)n_queries;
+    return grid_ws_bytes(n_points, batch);
 }
 
 extern "C" int ml3d_knn_search(const float* points, const int64_t* points_row_splits, const float* queries,
@@ -575,43 +285,27 @@ extern "C" int ml3d_knn_search(const float* points, const int64_t* points_row_sp
                                int64_t n_queries, int k, int index_local, int32_t* out_index,
                                float* out_dist2, void* workspace, size_t workspace_bytes, void* stream) {
     if (!points_row_splits || !queries_row_splits || batch <= 0 || k <= 0 || n_points < 0 || n_queries < 0 ||
-        n_points > 0x7fffffffll / GRID_CAP - 4096 || n_queries > 0x7fffffffll / GRID_CAP - 4096)
+        n_points > 0x7fffffffll / GRID_CAP - 4096 || n_queries > 0x7fffffffll)
         return ML3D_E_INVALID;
     if (k > 64) return ML3D_E_UNSUPPORTED;
     if (n_queries == 0) return 0;
     if (!out_index || (n_points > 0 && !points) || !queries) return ML3D_E_INVALID;
-    if (workspace_bytes < ml3d_knn_workspace_bytes(n_points, n_queries, batch)) return ML3D_E_WORKSPACE;
     GridWs ws;
-    const size_t gbytes = grid_ws_bytes(n_points, batch);
-    if (!grid_ws_carve(workspace, gbytes, n_points, batch, &ws)) return ML3D_E_WORKSPACE;
+    if (!grid_ws_carve(workspace, workspace_bytes, n_points, batch, &ws)) return ML3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Segs ps = {points_row_splits, 0, 0, (int)batch};
     Segs qs = {queries_row_splits, 0, 0, (int)batch};
     int rc = grid_build(points, ps, ws, tuning_occ(), st);
     if (rc) return ML3D_E_LAUNCH;
     GridView G = grid_view(ws);
-    if (k > 16) {
-        // long lists: lane-per-query shell search (the register-resident sorting networks of the tile kernel stop at 16)
-        QuerySrc Q;
-        bool self = (queries == points) && (queries_row_splits == points_row_splits) && (n_queries == n_points);
-        Q.sorted_q = self ? ws.sorted : nullptr;
-        Q.qsegs = ws.segs;
-        Q.raw = queries;
-        Q.segs = qs;
-        Q.n_total = n_queries;
-        return launch_query(G, Q, k, index_local, ps, out_index, out_dist2, st);
-    }
-    TileOrderWs tw;
-    if (!tile_order_ws_carve((char*)workspace + gbytes, workspace_bytes - gbytes, n_queries, batch, &tw))
-        return ML3D_E_WORKSPACE;
-    if (tile_order_build(queries, qs, ws.segs, tw, st)) return ML3D_E_LAUNCH;
-    TileJobs J;
-    J.n = 1;
-    TileJob& a = J.j[0];
-    a.G = G; a.qorder = tw.qorder; a.tile_splits = tw.tile_splits; a.qsegs = qs; a.support = ps;
-    a.out_idx = out_index; a.out_d2 = out_dist2; a.tile_begin = 0;
-    a.n_tiles = (unsigned)tile_count_bound(n_queries, batch);
-    return launch_tiles(J, k, index_local, st);
+    QuerySrc Q;
+    bool self = (queries == points) && (queries_row_splits == points_row_splits) && (n_queries == n_points);
+    Q.sorted_q = self ? ws.sorted : nullptr;
+    Q.qsegs = ws.segs;
+    Q.raw = queries;
+    Q.segs = qs;
+    Q.n_total = n_queries;
+    return launch_query(G, Q, k, index_local, ps, out_index, out_dist2, st);
 }
 
 static int pyramid_sizes(int64_t n0, int num_layers, const int32_t* ratios, int64_t* n /* L+1 */) {
@@ -630,7 +324,6 @@ extern "C" size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0,
     if (pyramid_sizes(n0, num_layers, ratios_host, n)) return 0;
     size_t b = 0;
     for (int l = 0; l <= num_layers; ++l) b += grid_ws_bytes(n[l] * batch, batch) + 256;
-    for (int l = 0; l < num_layers; ++l) b += tile_order_ws_bytes(n[l] * batch, batch) + 256;
     return b;
 }
 
@@ -669,20 +362,14 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
         return ML3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     GridWs ws[17];
-    TileOrderWs tw[16];
     char* p = (char*)workspace;
     for (int l = 0; l <= num_layers; ++l) {
         size_t bytes = grid_ws_bytes(n[l] * batch, batch) + 256;
         if (!grid_ws_carve(p, bytes, n[l] * batch, batch, &ws[l])) return ML3D_E_WORKSPACE;
         p += bytes;
     }
-    for (int l = 0; l < num_layers; ++l) {
-        size_t bytes = tile_order_ws_bytes(n[l] * batch, batch) + 256;
-        if (!tile_order_ws_carve(p, bytes, n[l] * batch, batch, &tw[l])) return ML3D_E_WORKSPACE;
-        p += bytes;
-    }
     float occ = tuning_occ();
-    // grids of every level: level l = prefix [:n_l] of each cloud (randlanet.py:222); plus the level's tile order
+    // grids of every level: level l = prefix [:n_l] of each cloud (randlanet.py:222)
     for (int l = 0; l <= num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
@@ -690,46 +377,63 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
         // level 0 probes the cloud; the thinner prefix levels reuse its box and dimension estimate
         if (l == 0 ? grid_build(points, S, ws[l], occ, st) : grid_build_derived(points, S, ws[l], ws[0], st))
             return ML3D_E_LAUNCH;
-        if (l < num_layers) {
-            if (tile_order_build(points, S, ws[l].segs, tw[l], st)) return ML3D_E_LAUNCH;
-            if (tile_order_host && tile_order_host[l]) {
-                const int64_t nt = n[l] * batch;
-                hipLaunchKernelGGL(order_from_qorder, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tw[l].qorder, nt,
-                                   n[l], tile_order_host[l]);
-                if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
-            }
+        if (tile_order_host && l < num_layers && tile_order_host[l]) {
+            const int64_t nt = n[l] * batch;
+            hipLaunchKernelGGL(order_from_grid, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ws[l].sorted, nt, n[l],
+                               tile_order_host[l]);
+            if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
         }
         te(100 + l);
     }
     // all k-NN searches (level l onto itself, randlanet.py:220) in one launch, all 1-NN interpolation
     // searches (level l in level l+1, randlanet.py:224) in a second one
-    if (num_layers > KNN_MAX_JOBS) return ML3D_E_UNSUPPORTED;
-    TileJobs Jk, J1;
+    KnnJobs Jk, J1;
     Jk.n = 0; J1.n = 0;
+    const bool merged = num_layers <= KNN_MAX_JOBS;
     for (int l = 0; l < num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
-        const unsigned nt = (unsigned)(((n[l] + 63) / 64) * batch);
-        TileJob& a = Jk.j[Jk.n++];
-        a.G = grid_view(ws[l]); a.qorder = tw[l].qorder; a.tile_splits = nullptr; a.qsegs = S; a.support = S;
-        a.out_idx = neighbor_idx_host[l]; a.out_d2 = nullptr; a.tile_begin = 0; a.n_tiles = nt;
+        QuerySrc Q;
+        Q.sorted_q = ws[l].sorted;
+        Q.qsegs = ws[l].segs;
+        Q.raw = points;
+        Q.segs = S;
+        Q.n_total = n[l] * batch;
+        if (merged) {
+            KnnJob& a = Jk.j[Jk.n++];
+            a.G = grid_view(ws[l]); a.Q = Q; a.support = S; a.out_idx = neighbor_idx_host[l]; a.block_begin = 0;
+        } else {
+            tb(2 * l);
+            int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
+            te(2 * l);
+            if (rc) return rc;
+        }
         if (n[l + 1] > 0) {
             Segs S1 = {nullptr, n0, n[l + 1], (int)batch};
-            TileJob& c = J1.j[J1.n++];
-            c.G = grid_view(ws[l + 1]); c.qorder = tw[l].qorder; c.tile_splits = nullptr; c.qsegs = S; c.support = S1;
-            c.out_idx = interp_idx_host[l]; c.out_d2 = nullptr; c.tile_begin = 0; c.n_tiles = nt;
+            if (merged) {
+                KnnJob& a = J1.j[J1.n++];
+                a.G = grid_view(ws[l + 1]); a.Q = Q; a.support = S1; a.out_idx = interp_idx_host[l]; a.block_begin = 0;
+            } else {
+                tb(2 * l + 1);
+                int rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
+                te(2 * l + 1);
+                if (rc) return rc;
+            }
         } else {
             (void)hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
         }
     }
-    tb(0);
-    int rc = launch_tiles(Jk, k, 1, st);
-    te(0);
-    if (rc) return rc;
-    tb(1);
-    rc = launch_tiles(J1, 1, 1, st);
-    te(1);
-    return rc;
+    if (merged) {
+        tb(0);
+        int rc = launch_query_multi(Jk, k, 1, st);
+        te(0);
+        if (rc) return rc;
+        tb(1);
+        rc = launch_query_multi(J1, 1, 1, st);
+        te(1);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

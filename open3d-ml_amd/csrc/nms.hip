@@ -78,6 +78,52 @@ __device__ __forceinline__ float iou_bev(const float* a, const P2* ca, const flo
     return un > 1e-8f ? __fdiv_rn(ia, un) : 0.f;
 }
 
+// ---- pairwise box IoU for the detection metric ---------------------------------------------------
+// iou_bev(boxes_a [N,5], boxes_b [M,5]) / iou_3d(boxes_a [N,7], boxes_b [M,7]) -> [N,M]
+//   ml3d/metrics/mAP.py:85-88: iou_bev(bbox[:, [0, 2, 3, 5, 6]]) = (x, z, w, l, yaw) in the camera frame,
+//                               iou_3d(bbox[:, :7])               = (x, y, z, w, h, l, yaw), y = bottom face.
+// A centre/size box is turned into the (x0, y0, x1, y1, r) form of the NMS above and clipped by the same routine, so the
+// two ops share one definition of the rotated intersection; one thread per (a, b) pair.
+__device__ __forceinline__ void center_to_corner_form(float cx, float cy, float dx, float dy, float r, float* o) {
+    const float hx = __fmul_rn(0.5f, dx), hy = __fmul_rn(0.5f, dy);
+    o[0] = __fsub_rn(cx, hx); o[1] = __fsub_rn(cy, hy); o[2] = __fadd_rn(cx, hx); o[3] = __fadd_rn(cy, hy); o[4] = r;
+}
+
+__global__ void __launch_bounds__(256)
+iou_pairs(const float* __restrict__ A, const float* __restrict__ B, int64_t n, int64_t m, int mode3d, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * m) return;
+    const int64_t i = t / m, j = t - i * m;
+    float a[5], b[5];
+    if (!mode3d) {
+        const float* pa = A + 5 * i; const float* pb = B + 5 * j;
+        center_to_corner_form(pa[0], pa[1], pa[2], pa[3], pa[4], a);
+        center_to_corner_form(pb[0], pb[1], pb[2], pb[3], pb[4], b);
+    } else {
+        const float* pa = A + 7 * i; const float* pb = B + 7 * j;
+        center_to_corner_form(pa[0], pa[2], pa[3], pa[5], pa[6], a);       // ground plane of the camera frame: (x, z)
+        center_to_corner_form(pb[0], pb[2], pb[3], pb[5], pb[6], b);
+    }
+    P2 ca[4], cb[4];
+    box_corners(a, ca);
+    box_corners(b, cb);
+    const float inter = poly_intersection_area(ca, cb);
+    const float aa = __fmul_rn(__fsub_rn(a[2], a[0]), __fsub_rn(a[3], a[1]));
+    const float ab = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
+    float num = inter, den;
+    if (!mode3d) {
+        den = __fsub_rn(__fadd_rn(aa, ab), inter);
+    } else {
+        // y axis points down: the box spans [y - h, y]
+        const float* pa = A + 7 * i; const float* pb = B + 7 * j;
+        const float top = fmaxf(__fsub_rn(pa[1], pa[4]), __fsub_rn(pb[1], pb[4])), bot = fminf(pa[1], pb[1]);
+        const float oh = fmaxf(__fsub_rn(bot, top), 0.f);
+        num = __fmul_rn(inter, oh);
+        den = __fsub_rn(__fadd_rn(__fmul_rn(aa, pa[4]), __fmul_rn(ab, pb[4])), num);
+    }
+    out[t] = den > 1e-8f ? __fdiv_rn(num, den) : 0.f;
+}
+
 // key = ~ordered(score) << 32 | index : ascending key == descending score, ties by ascending index
 __global__ void nms_keys(const float* __restrict__ scores, int64_t n, u64* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,5 +224,23 @@ extern "C" int ml3d_nms(const float* boxes, const float* scores, int64_t n, floa
                        words, mask);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64), 0, st, mask, order, n, words, out_keep, out_count);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_iou_bev(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m, float* out_iou, void* stream) {
+    if (n < 0 || m < 0) return ML3D_E_INVALID;
+    if (n == 0 || m == 0) return 0;
+    if (!boxes_a || !boxes_b || !out_iou) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(ml3d::iou_pairs, dim3((unsigned)((n * m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, boxes_b,
+                       n, m, 0, out_iou);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_iou_3d(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m, float* out_iou, void* stream) {
+    if (n < 0 || m < 0) return ML3D_E_INVALID;
+    if (n == 0 || m == 0) return 0;
+    if (!boxes_a || !boxes_b || !out_iou) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(ml3d::iou_pairs, dim3((unsigned)((n * m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, boxes_b,
+                       n, m, 1, out_iou);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }

@@ -44,6 +44,8 @@ SYMBOLS = [
     "ml3d_nhwc_to_nchw",
     "ml3d_nms_workspace_bytes",
     "ml3d_nms",
+    "ml3d_iou_bev",
+    "ml3d_iou_3d",
     "ml3d_nearest_to_center_workspace_bytes",
     "ml3d_nearest_to_center",
     "ml3d_vote_update",
@@ -137,6 +139,10 @@ def bind(lib):
     lib.ml3d_nms_workspace_bytes.argtypes = [i64]
     lib.ml3d_nms.restype = C.c_int
     lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_iou_bev.restype = C.c_int
+    lib.ml3d_iou_bev.argtypes = [vp, vp, i64, i64, vp, vp]
+    lib.ml3d_iou_3d.restype = C.c_int
+    lib.ml3d_iou_3d.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.ml3d_nearest_to_center_workspace_bytes.restype = sz
     lib.ml3d_nearest_to_center_workspace_bytes.argtypes = [i64]
     lib.ml3d_nearest_to_center.restype = C.c_int

@@ -55,3 +55,48 @@ def compact_labels(scores):
     """argmax over classes as the smallest integer type that holds it (uint8 for <= 256 classes): what travels."""
     lab = torch.argmax(scores, dim=-1)
     return lab.to(torch.uint8 if scores.shape[-1] <= 256 else torch.int32)
+
+
+class PredictionGather:
+    """The N > 1 data path of the inference loop: argmax of a step's scores into one of ``depth`` label buffers, then an
+    ASYNCHRONOUS gather of that buffer to ``dst`` so the collective of step i overlaps the kernels of step i + 1.  A
+    buffer is reused only after its previous gather has completed (``work.wait()``).  Works on any backend (``nccl`` =
+    RCCL over xGMI on the GPUs, ``gloo`` in the CPU tests); with no process group it degenerates to the local argmax."""
+
+    def __init__(self, batch, num_points, num_classes, device, depth=2, dst=0):
+        self.dst = dst
+        self.depth = int(depth)
+        dt = torch.uint8 if int(num_classes) <= 256 else torch.int32
+        self.labels = [torch.empty((batch, num_points), dtype=dt, device=device) for _ in range(self.depth)]
+        on = dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+        self.recv = [[torch.empty_like(self.labels[0]) for _ in range(self.world)] if (on and self.rank == dst) else None
+                     for _ in range(self.depth)]
+        self.pending = [None] * self.depth
+        self.step = 0
+
+    def push(self, scores):
+        """scores [B, N, C] of this rank's frames -> slot index of the label buffer / receive list used for this step."""
+        i = self.step % self.depth
+        self.step += 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()
+            self.pending[i] = None
+        self.labels[i].copy_(torch.argmax(scores, dim=2))
+        if self.world > 1:
+            _, self.pending[i] = gather_predictions(self.labels[i], dst=self.dst, out=self.recv[i], async_op=True)
+        return i
+
+    def gathered(self, slot):
+        """On ``dst``: the list of every rank's label tensor of that slot's last step (call after ``drain`` or after the
+        slot's work has been waited for); elsewhere / single process: this rank's labels."""
+        if self.world > 1 and self.rank == self.dst:
+            return self.recv[slot]
+        return [self.labels[slot]]
+
+    def drain(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None

@@ -106,15 +106,21 @@ class PipelinedRandLAEngine:
         self.i = 0
         self.n = self.eng[0].n
 
-    def submit(self, points, features, knn_trace=None, fwd_trace=None):
+    def submit(self, points, features, knn_trace=None, fwd_trace=None, ready=None):
+        """``ready``: event after which ``points`` / ``features`` are valid (e.g. recorded on a copy stream); default:
+        everything already enqueued on the caller's current stream."""
         e = self.eng[self.i & 1]
         slot = self.i & 1
         self.i += 1
         e._check(points, features)
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
-            self.search.wait_stream(cur)          # inputs were produced on the caller's stream
-            self.compute.wait_stream(cur)
+            if ready is not None:
+                self.search.wait_event(ready)
+                self.compute.wait_event(ready)
+            else:
+                self.search.wait_stream(cur)          # inputs were produced on the caller's stream
+                self.compute.wait_stream(cur)
             points.record_stream(self.search)     # ... and must outlive the side-stream kernels that read them
             points.record_stream(self.compute)
             features.record_stream(self.compute)
@@ -131,6 +137,73 @@ class PipelinedRandLAEngine:
     def synchronize(self):
         self.search.synchronize()
         self.compute.synchronize()
+
+
+class RandLAFrameStream:
+    """Host batches in, scores out: what ``bench.py`` times.  Three HIP streams: the pinned host batch of step i + 1 is
+    uploaded on the copy stream (two device buffers) while the neighbour pyramid of step i + 1 runs on the search stream
+    and the forward of step i on the compute stream (``PipelinedRandLAEngine``); ``overlap=False`` keeps everything on
+    the caller's stream in program order.  ``in_channels == 3``: the features ARE the coordinates
+    (randlanet.py:208-209), one upload serves both."""
+
+    def __init__(self, cfg, state_dict, batch, num_points, device, overlap=True):
+        self.device = torch.device(device)
+        self.overlap = bool(overlap)
+        self.cin = int(cfg["in_channels"])
+        self.B, self.N = int(batch), int(num_points)
+        self.engine = PipelinedRandLAEngine(cfg, state_dict, batch, num_points, device) if overlap else \
+            RandLAInferenceEngine(cfg, state_dict, batch, num_points, device)
+        self.n = self.engine.n
+        with torch.cuda.device(self.device):
+            self.h2d = torch.cuda.Stream() if overlap else None
+            self.pts = [torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self.feat = self.pts if self.cin == 3 else \
+                [torch.empty((self.B, self.N, self.cin), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self.uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+            self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.k = 0
+
+    @property
+    def compute_stream(self):
+        return self.engine.compute if self.overlap else torch.cuda.current_stream(self.device)
+
+    def single_engine(self):
+        return self.engine.eng[0] if self.overlap else self.engine
+
+    def submit(self, host_points, host_features=None, knn_trace=None, fwd_trace=None, done=None):
+        """host tensors (pinned for a truly asynchronous copy) -> the scores tensor of this step, valid once
+        ``compute_stream`` has reached ``done`` (an event recorded there when given) / has been synchronised."""
+        slot = self.k & 1
+        self.k += 1
+        if self.cin != 3 and host_features is None:
+            raise RuntimeError("RandLAFrameStream: in_channels = %d needs host_features" % self.cin)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            up = self.h2d if self.overlap else cur
+            with torch.cuda.stream(up):
+                up.wait_event(self.consumed[slot])       # the step that last read this buffer pair has finished
+                self.pts[slot].copy_(host_points, non_blocking=True)
+                if self.cin != 3:
+                    self.feat[slot].copy_(host_features, non_blocking=True)
+                self.uploaded[slot].record(up)
+            if self.overlap:
+                out = self.engine.submit(self.pts[slot], self.feat[slot], knn_trace, fwd_trace, ready=self.uploaded[slot])
+                self.consumed[slot].record(self.engine.compute)
+                if done is not None:
+                    done.record(self.engine.compute)
+            else:
+                out = self.engine.step(self.pts[slot], self.feat[slot], knn_trace, fwd_trace)
+                self.consumed[slot].record(cur)
+                if done is not None:
+                    done.record(cur)
+        return out
+
+    def synchronize(self):
+        if self.overlap:
+            self.h2d.synchronize()
+            self.engine.synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
 
 
 def make_trace(tag, ev_start, ev_stop):

@@ -601,6 +601,32 @@ def nms(boxes, scores, nms_overlap_thresh):
 # ---------------------------------------------------------------------------------------------------
 # patch sampler / vote accumulation
 # ---------------------------------------------------------------------------------------------------
+def _iou(fn_name, boxes_a, boxes_b, cols):
+    lib = _abi.get()
+    _need_gpu(boxes_a, boxes_b)
+    a = boxes_a.contiguous().float()
+    b = boxes_b.contiguous().float()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != cols or b.shape[1] != cols:
+        raise RuntimeError("%s: boxes must be float32 [N, %d] / [M, %d]" % (fn_name, cols, cols))
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = getattr(lib, fn_name)(a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0], out.data_ptr(), _stream())
+    _abi.check(rc, fn_name)
+    return out
+
+
+def iou_bev(boxes_a, boxes_b):
+    """``open3d.ml.contrib.iou_bev_*`` (ml3d/metrics/mAP.py:85): rotated bird's-eye-view IoU of every pair;
+    boxes [N, 5] / [M, 5] = (x, z, w, l, yaw) -> float32 [N, M]."""
+    return _iou("ml3d_iou_bev", boxes_a, boxes_b, 5)
+
+
+def iou_3d(boxes_a, boxes_b):
+    """``open3d.ml.contrib.iou_3d_*`` (ml3d/metrics/mAP.py:87): 3-D IoU of every pair; boxes [N, 7] / [M, 7] =
+    (x, y, z, w, h, l, yaw) with y the bottom face (camera frame, y down) -> float32 [N, M]."""
+    return _iou("ml3d_iou_3d", boxes_a, boxes_b, 7)
+
+
 def nearest_to_center(points, center, k, return_distances=False):
     """The ``k`` points nearest to ``center`` in ascending (d2, index) order — the
     ``search_tree.query(center_point, k=num_points)`` of SemSegSpatiallyRegularSampler

@@ -320,6 +320,198 @@ class KPFCNN(nn.Module):
         return self._unary(P['head'][1], x)
 
 
+    # ---- the reference's data path around forward (kpconv.py:353-633), on the GPU ops ---------------------------------
+    def preprocess(self, data, attr):
+        """kpconv.py:353-396: grid subsample at ``first_subsampling_dl``, search structure, raw -> sub projection."""
+        from ._datapath import preprocess_segmentation
+        return preprocess_segmentation(data, attr, self.cfg.first_subsampling_dl, self.device,
+                                       proj_splits=("test", "testing", "validation", "valid"))
+
+    def augmentation_transform(self, points, normals=None, verbose=False, is_test=False):
+        """kpconv.py:647-744 with the same ``np.random`` draw sequence; at test time the points come back untouched
+        (the draws still advance the generator, like the reference)."""
+        from ._datapath import create_3D_rotations
+        R = np.eye(points.shape[1])
+        if points.shape[1] == 3:
+            if self.cfg.augment_rotation == 'vertical':
+                theta = np.random.rand() * 2 * np.pi
+                c, s = np.cos(theta), np.sin(theta)
+                R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+            elif self.cfg.augment_rotation == 'all':
+                theta = np.random.rand() * 2 * np.pi
+                phi = (np.random.rand() - 0.5) * np.pi
+                u = np.array([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+                alpha = np.random.rand() * 2 * np.pi
+                R = create_3D_rotations(np.reshape(u, (1, -1)), np.reshape(alpha, (1, -1)))[0]
+        R = R.astype(np.float32)
+        min_s, max_s = self.cfg.augment_scale_min, self.cfg.augment_scale_max
+        if self.cfg.augment_scale_anisotropic:
+            scale = np.random.rand(points.shape[1]) * (max_s - min_s) + min_s
+        else:
+            scale = np.random.rand() * (max_s - min_s) - min_s
+        symmetries = np.array(self.cfg.augment_symmetries).astype(np.int32)
+        symmetries *= np.random.randint(2, size=points.shape[1])
+        scale = (scale * (1 - symmetries * 2)).astype(np.float32)
+        noise = (np.random.randn(points.shape[0], points.shape[1]) * self.cfg.augment_noise).astype(np.float32)
+        if is_test:
+            return points, scale, R
+        raise NotImplementedError("KPFCNN (MI355X build): inference only; training augmentation stays on the reference")
+
+    def transform(self, data, attr, is_test=False):
+        """kpconv.py:398-533: crop input spheres around the sampler's centres until ``min_in_points`` are collected,
+        recentre / normalise, assemble [xyz | features]; returns the reference's dict of lists (numpy).  The lists are what
+        ``KPConvBatch`` (this module: GPU neighbour / pooling build) or the reference's ``ConcatBatcher`` consume."""
+        points, sem_labels, feat, search_tree = data['point'], data['label'], data['feat'], data['search_tree']
+        result = {k_: [] for k_ in ('p_list', 'f_list', 'l_list', 'p0_list', 's_list', 'R_list', 'r_inds_list', 'r_mask_list',
+                                    'val_labels_list')}
+        result['cfg'] = self.cfg
+        curr_num_points = 0
+        max_num_points = min(self.cfg.batch_limit, self.cfg.max_in_points)
+        min_in_points = min(self.cfg.get('min_in_points', 3), self.cfg.max_in_points)
+        sampler = getattr(self, 'trans_point_sampler', None)
+        if sampler is None:
+            raise RuntimeError("KPFCNN.transform: set model.trans_point_sampler (the pipeline takes it from the dataset "
+                               "split's sampler) or use inference_begin()")
+        while curr_num_points < min_in_points:
+            new_points = points.copy()
+            curr_new_points, mask_inds, p0 = sampler(pc=new_points, feat=feat, label=sem_labels, search_tree=search_tree,
+                                                     num_points=min_in_points, radius=self.cfg.in_radius)
+            curr_sem_labels = sem_labels[mask_inds]
+            o_labels = sem_labels.astype(np.int32)
+            curr_new_points = curr_new_points - p0
+            t_normalize = self.cfg.get('t_normalize', {})
+            dim = t_normalize.get('recentering', [0, 1, 2])          # trans_normalize (ml3d/datasets/utils/transforms.py:7-26)
+            curr_new_points[:, dim] = curr_new_points[:, dim] - curr_new_points.mean(0)[dim]
+            curr_feat = feat
+            if t_normalize.get('method', None) == 'linear':
+                if t_normalize.get('normalize_points', False):
+                    curr_new_points -= curr_new_points.mean()
+                    curr_new_points /= (curr_new_points.max(0) - curr_new_points.min(0)).max()
+                if curr_feat is not None:
+                    curr_feat -= t_normalize.get('feat_bias', 0)
+                    curr_feat /= t_normalize.get('feat_scale', 1)
+            elif t_normalize.get('method', None) == 'coords_only':
+                curr_feat = None
+            in_fts = curr_new_points.copy() if curr_feat is None else np.hstack((curr_new_points, curr_feat[mask_inds, :]))
+            in_pts, in_lbls = curr_new_points, curr_sem_labels
+            n = in_pts.shape[0]
+            residual = max_num_points - curr_num_points
+            if n > residual:
+                input_inds = np.random.choice(n, size=residual, replace=False)
+                in_pts, in_fts, in_lbls = in_pts[input_inds, :], in_fts[input_inds, :], in_lbls[input_inds]
+                mask_inds = mask_inds[input_inds]
+                n = input_inds.shape[0]
+            curr_num_points += n
+            proj_inds = data['proj_inds'] if attr['split'] in ['test'] else np.zeros((0,))
+            in_pts, scale, R = self.augmentation_transform(in_pts, is_test=is_test)
+            if np.random.rand() > self.cfg.augment_color:
+                in_fts[:, 3:] *= 0
+            result['p_list'] += [in_pts]
+            result['f_list'] += [in_fts]
+            result['l_list'] += [np.squeeze(in_lbls)]
+            result['p0_list'] += [p0]
+            result['s_list'] += [scale]
+            result['R_list'] += [R]
+            result['r_inds_list'] += [proj_inds]
+            result['r_mask_list'] += [mask_inds]
+            result['val_labels_list'] += [o_labels]
+        return result
+
+    def make_batch(self, transformed):
+        """``ConcatBatcher.collate_fn`` for ONE transformed cloud (concat_batcher.py:120-184 feature selection +
+        ``segmentation_inputs``), with the neighbour / pooling matrices built on the GPU (``KPConvBatch``)."""
+        pts = np.concatenate(transformed['p_list'], 0).astype(np.float32)
+        fts = np.concatenate(transformed['f_list'], 0).astype(np.float32)
+        lens = [int(p.shape[0]) for p in transformed['p_list']]
+        ones = np.ones_like(pts[:, :1], dtype=np.float32)
+        d = self.cfg.in_features_dim
+        if d == 1:
+            feats = ones
+        elif d == 2:
+            feats = np.hstack((ones, fts[:, 2:3]))
+        elif d == 3:
+            feats = fts[:, 3:6]
+        elif d == 4:
+            feats = np.hstack((ones, fts[:, 3:6]))
+        elif d == 5:
+            feats = np.hstack((ones, fts[:, 2:3], fts[:, 3:6]))
+        elif d >= 6:
+            feats = np.hstack((ones, fts))
+        else:
+            raise ValueError("in_features_dim must be >= 1")
+        b = KPConvBatch(pts, lens, self.cfg, features=feats, device=self.device)
+        b.labels = torch.from_numpy(np.concatenate([np.atleast_1d(l) for l in transformed['l_list']]).astype(np.int64))
+        b.reproj_inds, b.reproj_masks = transformed['r_inds_list'], transformed['r_mask_list']
+        b.val_labels = transformed['val_labels_list']
+        return b
+
+    def update_probs(self, inputs, results, test_probs):
+        """kpconv.py:560-587: per input sphere, smooth the votes of the points it covers (float16 accumulator)."""
+        self.test_smooth = 0.95
+        batch = inputs['data']
+        lengths = batch.lengths[0].cpu().numpy() if isinstance(batch.lengths[0], torch.Tensor) else np.asarray(batch.lengths[0])
+        dev = self.device
+        on_host = isinstance(test_probs, np.ndarray)
+        tp = torch.from_numpy(np.ascontiguousarray(test_probs)).to(dev) if on_host else test_probs
+        logits = results.to(dev, torch.float32).contiguous()
+        i0 = 0
+        for b_i, length in enumerate(lengths):
+            length = int(length)
+            mask = torch.as_tensor(np.asarray(batch.reproj_masks[b_i]), dtype=torch.int32).to(dev)
+            ops.vote_update(tp, mask, logits[i0:i0 + length], self.test_smooth)
+            i0 += length
+        return tp.cpu().numpy() if on_host else tp
+
+    def inference_begin(self, data):
+        self.test_smooth = 0.98
+        attr = {'split': 'test'}
+        self.inference_ori_data = data
+        self.inference_data = self.preprocess(data, attr)
+        self.inference_proj_inds = self.inference_data['proj_inds']
+        num_points = self.inference_data['search_tree'].data.shape[0]
+        self.possibility = np.random.rand(num_points) * 1e-3
+        self.test_probs = torch.zeros((num_points, self.cfg.num_classes), dtype=torch.float16, device=self.device)
+        if getattr(self, 'trans_point_sampler', None) is None:
+            self.trans_point_sampler = self._possibility_sampler
+
+    def _possibility_sampler(self, pc, feat, label, search_tree, num_points, radius=None):
+        """Radius-based spatially regular sampler on ``self.possibility`` (semseg_spatially_regular.py:62-108)."""
+        n = 0
+        while n < 2:
+            center_id = int(np.argmin(self.possibility))
+            center_point = pc[center_id, :].reshape(1, -1)
+            idxs = search_tree.query_radius(center_point, r=radius)[0]
+            n = len(idxs)
+            if n < 2:
+                self.possibility[center_id] += 0.001
+        idxs = np.random.permutation(idxs)
+        pc = pc[idxs]
+        dists = np.sum(np.square((pc - center_point).astype(np.float32)), axis=1)
+        self.possibility[idxs] += np.square(1 - dists / np.max(dists))
+        return pc, idxs, center_point
+
+    def inference_preprocess(self):
+        attr = {'split': 'test'}
+        data = self.transform(self.inference_data, attr, is_test=True)
+        self.inference_input = {'data': self.make_batch(data), 'attr': attr}
+        return self.inference_input
+
+    def inference_end(self, inputs, results):
+        self.update_probs(inputs, results, self.test_probs)
+        if np.min(self.possibility) > 0.5:
+            probs = self.test_probs.cpu().numpy()
+            pred_labels = np.argmax(probs, 1)[self.inference_proj_inds]
+            self.inference_result = {'predict_labels': pred_labels, 'predict_scores': probs[self.inference_proj_inds]}
+            return True
+        return False
+
+    def get_optimizer(self, cfg_pipeline):
+        raise NotImplementedError("KPFCNN (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+
+    def get_loss(self, Loss, results, inputs, device):
+        raise NotImplementedError("KPFCNN (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+
+
 class KPConvBatch:
     """GPU construction of the network inputs of ``KPConvBatch.segmentation_inputs``
     (ml3d/torch/dataloaders/concat_batcher.py:186-305): per layer the stacked points, conv neighbours

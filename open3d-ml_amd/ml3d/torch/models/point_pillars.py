@@ -356,3 +356,93 @@ class PointPillars(nn.Module):
             outs.append(ops.nhwc_to_nchw(heads, off, c))
             off += c
         return tuple(outs)
+
+    # ---- the reference's data path around forward (point_pillars.py:206-300) -------------------------------------------
+    def preprocess(self, data, attr):
+        """point_pillars.py:206-250 for the inference splits: keep xyz + intensity of the points inside
+        ``point_cloud_range`` (min inclusive, max exclusive).  Training-time augmentation stays on the reference."""
+        if attr['split'] not in ['test', 'testing', 'val', 'validation']:
+            raise NotImplementedError("PointPillars (MI355X build): inference preprocess only (SURVEY.md §8 f4)")
+
+        def crop(p):
+            p = np.array(p[:, 0:4], dtype=np.float32)
+            mn, mx = np.array(self.point_cloud_range[:3]), np.array(self.point_cloud_range[3:])
+            return p[np.where(np.all(np.logical_and(p[:, :3] >= mn, p[:, :3] < mx), axis=-1))]
+
+        new_data = {'point': crop(data['point']), 'calib': data.get('calib', None)}
+        if attr['split'] not in ['test', 'testing']:
+            new_data['bbox_objs'] = data['bounding_boxes']
+        if 'full_point' in data:
+            new_data['full_point'] = crop(data['full_point'])
+        return new_data
+
+    def transform(self, data, attr):
+        """point_pillars.py:252-267"""
+        t_data = {'point': data['point'], 'calib': data['calib']}
+        if attr['split'] not in ['test', 'testing']:
+            t_data['bbox_objs'] = data['bbox_objs']
+            t_data['labels'] = np.array([self.name2lbl.get(bb.label_class, len(self.classes)) for bb in data['bbox_objs']],
+                                        dtype=np.int64)
+            t_data['bboxes'] = np.array([bb.to_xyzwhlr() for bb in data['bbox_objs']], dtype=np.float32)
+        return t_data
+
+    def inference_end(self, results, inputs):
+        """point_pillars.py:269-297: decode + rotated NMS on the GPU (``Anchor3DHead.get_bboxes``), then one box object per
+        detection.  With an Open3D-ML checkout on the path the objects are its ``BEVBox3D`` (what the pipeline's metrics
+        and ``save_test_result`` expect); standalone they are ``DetectedBox`` records with the same fields."""
+        bboxes_b, scores_b, labels_b = self.bbox_head.get_bboxes(*results)
+        try:
+            from ml3d.datasets.utils import BEVBox3D as Box       # the reference's class when a checkout is importable
+        except Exception:
+            Box = DetectedBox
+        calibs = getattr(inputs, 'calib', None) or [None] * len(bboxes_b)
+        inference_result = []
+        for _calib, _bboxes, _scores, _labels in zip(calibs, bboxes_b, scores_b, labels_b):
+            bboxes = _bboxes.cpu().detach().numpy()
+            scores = _scores.cpu().detach().numpy()
+            labels = _labels.cpu().detach().numpy()
+            inference_result.append([])
+            world_cam, cam_img = None, None
+            if _calib is not None:
+                world_cam = _calib.get('world_cam', None)
+                cam_img = _calib.get('cam_img', None)
+            for bbox, score, label in zip(bboxes, scores, labels):
+                dim = bbox[[3, 5, 4]]
+                pos = bbox[:3] + [0, 0, dim[1] / 2]
+                yaw = bbox[-1]
+                name = self.lbl2name.get(int(label), "ignore")
+                inference_result[-1].append(Box(pos, dim, yaw, name, score, world_cam, cam_img))
+        return inference_result
+
+    def inference_begin(self, data):
+        raise NotImplementedError("PointPillars: the reference drives detection through its pipeline (run_inference), "
+                                  "not through inference_begin (point_pillars.py has none either)")
+
+    inference_preprocess = inference_begin
+
+    def get_optimizer(self, cfg):
+        raise NotImplementedError("PointPillars (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+
+    def get_loss(self, results, inputs):
+        raise NotImplementedError("PointPillars (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+
+
+class DetectedBox:
+    """Stand-alone result record of ``PointPillars.inference_end`` with the fields of the reference's ``BEVBox3D``
+    (ml3d/datasets/utils/bev_box.py): centre [x, y, z], size [w, h, l], yaw, class name, confidence, calibration."""
+
+    def __init__(self, center, size, yaw, label_class, confidence, world_cam=None, cam_img=None):
+        self.center = np.asarray(center, dtype=np.float32)
+        self.size = np.asarray(size, dtype=np.float32)
+        self.yaw = float(yaw)
+        self.label_class = label_class
+        self.confidence = float(confidence)
+        self.world_cam, self.cam_img = world_cam, cam_img
+
+    def to_xyzwhlr(self):
+        """[x, y, z(bottom), w, l, h, yaw] like ``BEVBox3D.to_xyzwhlr`` (bev_box.py)."""
+        b = np.zeros((7,), dtype=np.float32)
+        b[0:3] = self.center - [0, 0, self.size[1] / 2]
+        b[3:6] = np.array(self.size)[[0, 2, 1]]
+        b[6] = self.yaw
+        return b

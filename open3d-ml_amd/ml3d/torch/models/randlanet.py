@@ -15,6 +15,7 @@ import torch.nn as nn
 from ... import _abi
 from ... import ops
 from . import _randla_pack
+from ._datapath import GpuSearchTree, preprocess_segmentation   # noqa: F401
 
 
 class SharedMLP(nn.Module):
@@ -145,3 +146,145 @@ class RandLANet(nn.Module):
         B, N, _ = pts.shape
         desc = _abi.make_desc(self.cfg, B, N)
         return ops.randla_forward(desc, self.packed_params(dev), feat, pts, nbr, itp)
+
+    # ---- the reference's data path around forward (randlanet.py:115-239, 382-465), on the GPU ops ------------------
+    def preprocess(self, data, attr):
+        """Grid-subsample the raw cloud (barycentres, mean features, majority labels), build the search structure and,
+        for test splits, project every raw point onto its nearest sub-cloud point (randlanet.py:115-154)."""
+        return preprocess_segmentation(data, attr, self.cfg.grid_size, self.device)
+
+    def _validation_augment(self, pc, feat):
+        """The two augmentations the reference applies to EVERY split (randlanet.py:185-191;
+        ml3d/datasets/augment/augmentation.py:16-60): recenter and normalize.  In place, like the reference."""
+        aug = self.cfg.get('augment', {}) or {}
+        if 'recenter' in aug and aug['recenter']:
+            dim = aug['recenter'].get('dim', [0, 1, 2])
+            pc[:, dim] = pc[:, dim] - pc.mean(0)[dim]
+        if 'normalize' in aug and aug['normalize']:
+            c = aug['normalize']
+            if 'points' in c:
+                if c['points'].get('method', 'linear') != 'linear':
+                    raise ValueError(f"Unsupported method : {c['points'].get('method')}")
+                pc -= pc.mean(0)
+                pc /= (pc.max(0) - pc.min(0)).max()
+            if 'feat' in c and feat is not None:
+                cf = c['feat']
+                if cf.get('method', 'linear') != 'linear':
+                    raise ValueError(f"Unsupported method : {cf.get('method')}")
+                bias, scale = cf.get('bias', 0), cf.get('scale', 1)
+                feat -= bias
+                feat /= scale
+
+    def transform(self, data, attr, min_possibility_idx=None):
+        """Patch crop by the pipeline's point sampler, recentring, feature assembly and the neighbour pyramid
+        (randlanet.py:156-239).  The 8 ``knn_search`` calls of the reference run as ONE GPU pyramid call; the index lists
+        come back as int32 DEVICE tensors (``forward`` consumes them in place; ``.cpu().long()`` gives the reference's
+        arrays), everything else as numpy like the reference."""
+        cfg = self.cfg
+        if attr['split'] in ['training', 'train']:
+            raise NotImplementedError("RandLANet (MI355X build): inference transform only (SURVEY.md §8 f4)")
+        pc = data['point'].copy()
+        label = data['label'].copy()
+        feat = data['feat'].copy() if data['feat'] is not None else None
+        tree = data['search_tree']
+        sampler = getattr(self, 'trans_point_sampler', None)
+        if sampler is None:
+            raise RuntimeError("RandLANet.transform: set model.trans_point_sampler (the pipeline takes it from the dataset "
+                               "split's sampler, semantic_segmentation.py:156) or use inference_begin()")
+        pc, selected_idxs, center_point = sampler(pc=pc, feat=feat, label=label, search_tree=tree,
+                                                  num_points=cfg.num_points)
+        label = label[selected_idxs]
+        if feat is not None:
+            feat = feat[selected_idxs]
+        self._validation_augment(pc, feat)
+        feat = pc.copy() if feat is None else np.concatenate([pc, feat], axis=1)
+        if cfg.in_channels != feat.shape[1]:
+            raise RuntimeError("Wrong feature dimension, please update in_channels(3 + feature_dimension) in config")
+        dpts = torch.from_numpy(np.ascontiguousarray(pc, dtype=np.float32)).to(self.device)
+        nbr, itp = ops.randla_knn_pyramid(dpts[None], cfg.sub_sampling_ratio, cfg.num_neighbors)
+        inputs = dict()
+        coords, n = [], pc.shape[0]
+        for i in range(cfg.num_layers):
+            coords.append(pc[:n])
+            n = n // cfg.sub_sampling_ratio[i]
+        inputs['coords'] = coords
+        inputs['neighbor_indices'] = [t[0] for t in nbr]
+        inputs['sub_idx'] = [nbr[i][0, :pc.shape[0] // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))]
+                             for i in range(cfg.num_layers)]
+        inputs['interp_idx'] = [t[0] for t in itp]
+        inputs['features'] = feat
+        inputs['point_inds'] = selected_idxs
+        inputs['labels'] = label.astype(np.int64)
+        return inputs
+
+    def update_probs(self, inputs, results, test_probs):
+        """Vote accumulation of ``semantic_segmentation.py:293-297`` / randlanet.py:441-465: batch items applied IN ORDER
+        (a point that two patches of a batch share is smoothed twice), float16 accumulator, softmax + update on the GPU
+        (``ml3d_vote_update``).  ``test_probs``: numpy float16 [num_points, classes] (returned updated, like the
+        reference) or a float16 device tensor (updated in place and returned: no host round trip per patch)."""
+        self.test_smooth = 0.95
+        dev = self.device
+        on_host = isinstance(test_probs, np.ndarray)
+        tp = torch.from_numpy(np.ascontiguousarray(test_probs)).to(dev) if on_host else test_probs
+        inds_all = inputs['data']['point_inds']
+        for b in range(results.size()[0]):
+            logits = torch.reshape(results[b], (-1, self.cfg.num_classes)).to(dev, torch.float32).contiguous()
+            inds = torch.as_tensor(np.asarray(inds_all[b].cpu() if isinstance(inds_all[b], torch.Tensor) else inds_all[b]),
+                                   dtype=torch.int32).to(dev)
+            ops.vote_update(tp, inds, logits, self.test_smooth)
+        return tp.cpu().numpy() if on_host else tp
+
+    # ---- legacy single-cloud API (randlanet.py:382-439): the pipeline does not use it, but it is part of BaseModel ----
+    def inference_begin(self, data):
+        self.test_smooth = 0.95
+        attr = {'split': 'test'}
+        self.inference_ori_data = data
+        self.inference_data = self.preprocess(data, attr)
+        self.inference_proj_inds = self.inference_data['proj_inds']
+        num_points = self.inference_data['search_tree'].data.shape[0]
+        self.possibility = self.rng.random(num_points) * 1e-3
+        self.test_probs = torch.zeros((num_points, self.cfg.num_classes), dtype=torch.float16, device=self.device)
+        if getattr(self, 'trans_point_sampler', None) is None:
+            self.trans_point_sampler = self._possibility_sampler
+
+    def _possibility_sampler(self, pc, feat, label, search_tree, num_points):
+        """Spatially regular patch sampler on ``self.possibility`` (the reference's
+        ``SemSegSpatiallyRegularSampler._random_centered_gen``, semseg_spatially_regular.py:62-108, with this model's own
+        seeded generator in place of the global ``random`` module)."""
+        center_id = int(np.argmin(self.possibility))
+        center_point = pc[center_id, :].reshape(1, -1)
+        if pc.shape[0] < num_points:
+            idxs = np.arange(pc.shape[0])
+            idxs = np.concatenate([idxs, self.rng.choice(idxs, num_points - pc.shape[0])])
+        else:
+            idxs = search_tree.query(center_point, k=num_points)[1][0]
+        idxs = self.rng.permutation(idxs)
+        pc = pc[idxs]
+        dists = np.sum(np.square((pc - center_point).astype(np.float32)), axis=1)
+        delta = np.square(1 - dists / np.max(dists))
+        np.add.at(self.possibility, idxs, delta) if pc.shape[0] > search_tree.data.shape[0] else \
+            self.possibility.__setitem__(idxs, self.possibility[idxs] + delta)
+        return pc, idxs, center_point
+
+    def inference_preprocess(self):
+        attr = {'split': 'test'}
+        data = self.transform(self.inference_data, attr, int(np.argmin(self.possibility)))
+        batch = {k: ([t[None] if isinstance(t, torch.Tensor) else torch.as_tensor(t)[None] for t in v]
+                     if isinstance(v, list) else torch.as_tensor(v)[None]) for k, v in data.items()}
+        self.inference_input = {'data': batch, 'attr': attr}
+        return self.inference_input
+
+    def inference_end(self, inputs, results):
+        self.update_probs(inputs, results, self.test_probs)
+        if np.min(self.possibility) > 0.5:
+            probs = self.test_probs.cpu().numpy()
+            pred_labels = np.argmax(probs, 1)[self.inference_proj_inds]
+            self.inference_result = {'predict_labels': pred_labels, 'predict_scores': probs[self.inference_proj_inds]}
+            return True
+        return False
+
+    def get_optimizer(self, cfg_pipeline):
+        raise NotImplementedError("RandLANet (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+
+    def get_loss(self, Loss, results, inputs, device):
+        raise NotImplementedError("RandLANet (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")

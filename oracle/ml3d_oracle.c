@@ -590,6 +590,13 @@ float ml3d_oracle_iou_bev(const float* a, const float* b) {
     return un > 1e-8f ? ia / un : 0.f;
 }
 
+/* area of the rotated intersection only (the 3-D IoU multiplies it by the height overlap) */
+float ml3d_oracle_inter_bev(const float* a, const float* b) {
+    pt2_t ca[4], cb[4];
+    box_corners(a, ca); box_corners(b, cb);
+    return poly_intersection_area(ca, cb);
+}
+
 int64_t ml3d_oracle_nms(const float* boxes, const float* scores, int64_t n, float thr,
                         int64_t* keep) {
     int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));

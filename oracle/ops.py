@@ -207,3 +207,45 @@ def nms(boxes, scores, nms_overlap_thresh):
     m = lib().ml3d_oracle_nms(_p(boxes), _p(scores), C.c_int64(n), C.c_float(float(nms_overlap_thresh)),
                               _p(keep))
     return keep[:m].copy()
+
+
+def _corner_form(cx, cy, dx, dy, r):
+    hx, hy = np.float32(0.5) * dx, np.float32(0.5) * dy
+    return np.stack([cx - hx, cy - hy, cx + hx, cy + hy, r], -1).astype(np.float32)
+
+
+def iou_bev(boxes_a, boxes_b):
+    """Pairwise rotated BEV IoU, boxes (x, z, w, l, yaw) -- restates the call ml3d/metrics/mAP.py:85 makes into
+    open3d.ml.contrib.iou_bev_*; the rotated intersection is the NMS oracle's (ml3d_oracle_iou_bev)."""
+    a, b = _f32(boxes_a).reshape(-1, 5), _f32(boxes_b).reshape(-1, 5)
+    ca = _corner_form(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4])
+    cb = _corner_form(b[:, 0], b[:, 1], b[:, 2], b[:, 3], b[:, 4])
+    out = np.zeros((len(a), len(b)), np.float32)
+    L = lib()
+    for i in range(len(a)):
+        for j in range(len(b)):
+            out[i, j] = L.ml3d_oracle_iou_bev(_p(np.ascontiguousarray(ca[i])), _p(np.ascontiguousarray(cb[j])))
+    return out
+
+
+def iou_3d(boxes_a, boxes_b):
+    """Pairwise 3-D IoU, boxes (x, y, z, w, h, l, yaw), y = bottom face, y axis down (ml3d/metrics/mAP.py:87)."""
+    a, b = _f32(boxes_a).reshape(-1, 7), _f32(boxes_b).reshape(-1, 7)
+    ca = _corner_form(a[:, 0], a[:, 2], a[:, 3], a[:, 5], a[:, 6])
+    cb = _corner_form(b[:, 0], b[:, 2], b[:, 3], b[:, 5], b[:, 6])
+    L = lib()
+    L.ml3d_oracle_inter_bev.restype = C.c_float
+    out = np.zeros((len(a), len(b)), np.float32)
+    f = np.float32
+    for i in range(len(a)):
+        for j in range(len(b)):
+            inter = f(L.ml3d_oracle_inter_bev(_p(np.ascontiguousarray(ca[i])), _p(np.ascontiguousarray(cb[j]))))
+            aa = f(f(ca[i, 2] - ca[i, 0]) * f(ca[i, 3] - ca[i, 1]))
+            ab = f(f(cb[j, 2] - cb[j, 0]) * f(cb[j, 3] - cb[j, 1]))
+            top = max(f(a[i, 1] - a[i, 4]), f(b[j, 1] - b[j, 4]))
+            bot = min(a[i, 1], b[j, 1])
+            oh = max(f(bot - top), f(0))
+            num = f(inter * oh)
+            den = f(f(f(aa * a[i, 4]) + f(ab * b[j, 4])) - num)
+            out[i, j] = f(num / den) if den > 1e-8 else 0.0
+    return out

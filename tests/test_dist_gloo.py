@@ -66,3 +66,56 @@ def test_single_process_gather_is_identity():
     from ml3d.dist import gather_predictions
     x = torch.arange(12).view(3, 4)
     assert gather_predictions(x)[0] is x
+
+
+def _gather_worker(rank, world, port, steps, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ml3d import dist as mdist
+    mdist.init("gloo")
+    B, N, C = 3, 129, 19
+    g = mdist.PredictionGather(B, N, C, "cpu")
+    got = {}
+    for step in range(steps):
+        # every rank's scores of this step are a pure function of (rank, step): rank 0 can rebuild what it must receive
+        gen = torch.Generator().manual_seed(1000 * rank + step)
+        scores = torch.rand((B, N, C), generator=gen)
+        slot = g.push(scores)
+        assert slot == step % 2
+        if step >= 1:
+            # the buffer of the PREVIOUS step is complete once its work has been waited for; bench.py reads results only
+            # after drain(), here we check the double buffering step by step
+            prev = (step - 1) % 2
+            if g.pending[prev] is not None:
+                g.pending[prev].wait()
+            if rank == 0:
+                got[step - 1] = torch.cat([t.clone() for t in g.gathered(prev)], 0)
+    g.drain()
+    if rank == 0:
+        got[steps - 1] = torch.cat([t.clone() for t in g.gathered((steps - 1) % 2)], 0)
+        np.save(out_path, torch.stack([got[s] for s in range(steps)]).numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_prediction_gather_pipeline_two_ranks(tmp_path):
+    """bench.py's N > 1 step logic (argmax -> uint8 labels -> async gather, two buffers) with real tensors over gloo."""
+    world, steps = 2, 5
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_gather_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape == (steps, world * 3, 129) and got.dtype == np.uint8
+    for step in range(steps):
+        for r in range(world):
+            gen = torch.Generator().manual_seed(1000 * r + step)
+            want = torch.rand((3, 129, 19), generator=gen).argmax(2).numpy()
+            assert np.array_equal(got[step, 3 * r:3 * r + 3], want)
+
+
+def test_prediction_gather_single_process():
+    from ml3d.dist import PredictionGather
+    g = PredictionGather(2, 5, 300, "cpu")          # > 256 classes: int32 labels
+    s = torch.rand((2, 5, 300))
+    slot = g.push(s)
+    g.drain()
+    assert g.gathered(slot)[0].dtype == torch.int32 and torch.equal(g.gathered(slot)[0].long(), s.argmax(2))

@@ -141,12 +141,9 @@ def test_pipelined_engine_matches_sequential_engine():
         assert torch.equal(a, b)
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("ML3D_TEST_TILE_ORDER") != "1",
-                    reason="opt-in: the ORD kernel variants were finished after the round's GPU budget was spent (bit-identical "
-                           "on the emulator); their first hardware run is done by hand, not inside the gating suite")
 def test_tile_order_engine_is_bit_identical():
-    """ML3D_TILE_ORDER: walking the attention tiles in the grids' spatial order must not change a single logit."""
+    """tile_order=True: walking the attention tiles in the neighbour pyramid's brick order must not change a single logit
+    (first hardware run: round 2, green)."""
     from ml3d.engine import RandLAInferenceEngine
     B, N = 3, 45056
     frames = np.stack([synth_data.semantickitti_patch(300 + i, N) for i in range(B)])
@@ -163,3 +160,38 @@ def test_tile_order_engine_is_bit_identical():
         for i in range(B):
             assert np.array_equal(np.sort(o[i]), np.arange(i * n_l, (i + 1) * n_l))
     assert torch.equal(a, b)
+
+
+def test_bench_configuration_frame_stream_b64_matches_oracle():
+    """The object bench.py times, at the bench configuration: B = 64 frames of 45056 points through RandLAFrameStream
+    (pinned-host upload on the copy stream, pyramid on the search stream, forward on the compute stream, both ping-pong
+    slots used).  Frames {0, 7, 31, 63}: neighbour / interpolation indices exact, logits <= 1e-4 vs the CPU oracle."""
+    import bench
+    from ml3d.engine import RandLAFrameStream
+    cfg = dict(bench.CFG)
+    B, N = 64, cfg["num_points"]
+    frames = bench.synthetic_batch(0, B, N, 8)
+    sd = R.make_state_dict(cfg, 11)
+    dev = torch.device("cuda:0")
+    stream = RandLAFrameStream(cfg, sd, B, N, dev, overlap=True)
+    host = torch.from_numpy(frames).pin_memory()
+    check = [0, 7, 31, 63]
+    ref_in = {i: R.build_inputs(frames[i:i + 1], frames[i:i + 1].copy(), cfg, oops.knn_search) for i in check}
+    ref = {i: R.forward(sd, cfg, ref_in[i]).numpy()[0] for i in check}
+    outs = []
+    for step in range(3):                      # slots 0, 1, 0: the third submit reuses the first slot's buffers
+        sc = stream.submit(host)
+        torch.cuda.current_stream().wait_stream(stream.compute_stream)
+        outs.append(sc[check].clone())
+    stream.synchronize()
+    torch.cuda.synchronize()
+    for step, got in enumerate(outs):
+        for j, i in enumerate(check):
+            assert np.abs(got[j].cpu().numpy() - ref[i]).max() <= TOL, "step %d frame %d" % (step, i)
+    for slot, eng in enumerate(stream.engine.eng):
+        for l in range(cfg["num_layers"]):
+            nb = eng.nbr[l][check].cpu().long()
+            it = eng.itp[l][check].cpu().long()
+            for j, i in enumerate(check):
+                assert torch.equal(nb[j], ref_in[i]["neighbor_indices"][l][0]), "slot %d layer %d frame %d" % (slot, l, i)
+                assert torch.equal(it[j], ref_in[i]["interp_idx"][l][0]), "slot %d layer %d frame %d" % (slot, l, i)
