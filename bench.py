@@ -8,7 +8,7 @@ from pinned host memory (inside the timed region, on a copy stream, SURVEY.md §
 is an RCCL gather of the predicted labels to rank 0 inside the timed region (ml3d.dist.PredictionGather).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline        the kernel with the longest average launch among the traced ones (k-NN tile kernel, layer-0 and layer-1
+  roofline        the kernel with the longest average launch among the traced ones (the neighbour-search launch, layer-0 and layer-1
                   attention kernels), timed live with HIP events recorded by the library around that kernel's launch on the
                   launch stream; `roofline_other` carries the rest.  MFMA kernels: `frac` prices the flops the kernel
                   EXECUTES, `frac_reference_formulation` the flops of the reference's formulation of the same result.
@@ -37,7 +37,7 @@ CFG = dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG)  # randlanet_semantickitti
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 
-# kernels traced live (library tag -> description).  k-NN tags: 0 = merged 16-NN launch, 1 = merged 1-NN launch;
+# kernels traced live (library tag -> description).  k-NN tag 0 = the merged neighbour-search launch;
 # forward tags: 8 * layer + stage (1 / 2 = the two attention kernels of the layer)
 TRACED = [("knn", 0), ("fwd", 8 * 0 + 1), ("fwd", 8 * 1 + 2)]
 
@@ -64,10 +64,16 @@ def lfa_flops_executed(cfg, layer, stage, n_points):
     return 2.0 * mac * n_points
 
 
-def knn_bytes_16nn(cfg, n_levels, batch):
-    """Algorithmic HBM bytes of the merged 16-NN launch: 12 B of xyz read + 4 * k B of int32
-    indices written per query, all pyramid levels."""
-    return sum((12 + 4 * cfg["num_neighbors"]) * n for n in n_levels[:cfg["num_layers"]]) * batch
+def knn_bytes(cfg, n_levels, batch):
+    """Algorithmic HBM bytes of the neighbour-search launch (SURVEY.md §8d row a1, int32 indices): per level the self
+    k-NN (12 B of xyz read + 4 * k B written per query) and the 1-NN interpolation search (xyz of both levels read, 4 B
+    written per query) -- 5.69 MB per 45056-point frame."""
+    tot = 0
+    for l in range(cfg["num_layers"]):
+        n, nn = n_levels[l], n_levels[l + 1]
+        tot += 12 * n + 4 * cfg["num_neighbors"] * n
+        tot += 12 * (n + nn) + 4 * n
+    return tot * batch
 
 
 def _traffic(kernel_key, batch):
@@ -254,13 +260,13 @@ def main():
         for (kind, tag), ts in per_tag.items():
             ms = float(np.mean(ts))
             if kind == "knn":
-                kb = knn_bytes_16nn(CFG, n_lv, B)
-                cands.append({"bound": "hbm", "kernel": "knn_tile<16> (16-NN of all pyramid levels, one launch)",
+                kb = knn_bytes(CFG, n_lv, B)
+                cands.append({"bound": "hbm", "kernel": "knn_query_multi<16, true> (16-NN + prefix 1-NN of all pyramid levels, one launch)",
                               "achieved": kb / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_tile<16>", B),
+                              "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_query_multi<16, true>", B),
                               "avg_launch_ms": ms, "bytes_per_launch": kb,
-                              "note": "algorithmic bytes = 76 B per query (SURVEY.md §8d); the kernel is VALU-bound: the exact "
-                                      "16-of-N selection costs ~12 instructions per candidate and lane, see DESIGN.md §3.2"})
+                              "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU / latency-bound "
+                                      "(~150 candidates x ~45 instructions per query), not HBM-bound: DESIGN.md §3.2"})
             else:
                 layer, stage = tag // 8, tag % 8
                 d = CFG["dim_output"][layer]
@@ -297,7 +303,7 @@ def main():
             for tg in tags_f:
                 e1.step(pts, pts, None, make_trace(tg, a, b)); torch.cuda.synchronize()
                 bd["fwd:%d" % tg] = a.elapsed_time(b)
-            for tg in [100 + l for l in range(CFG["num_layers"] + 1)] + [0, 1]:
+            for tg in [100 + l for l in range(CFG["num_layers"])] + [0]:
                 e1.step(pts, pts, make_trace(tg, a, b), None); torch.cuda.synchronize()
                 bd["knn:%d" % tg] = a.elapsed_time(b)
             out["breakdown_ms"] = bd

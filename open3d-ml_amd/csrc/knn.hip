@@ -60,9 +60,12 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
 #define KNN_GROUP 3
 #endif
 
-template <int K>
-__device__ __forceinline__ void scan_range(const GridView& G, int p0, int p1, float qx, float qy, float qz,
-                                           double (&best)[K]) {
+// SUB: also track the nearest candidate whose index is below n_sub -- the RandLA pyramid's 1-NN interpolation target
+// (level l + 1 is the prefix [:n_sub] of level l, randlanet.py:222-224), found in the same scan as the k-NN
+template <int K, bool SUB>
+__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
+                                         float qz, double (&best)[K], int n_sub, double& best1) {
+    int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
     // per group instead of one per candidate -- the loop is latency-bound: lane-per-query gathers, ~5 waves per SIMD);
     // indices past the run are clamped to its last point and skipped
@@ -75,22 +78,19 @@ __device__ __forceinline__ void scan_range(const GridView& G, int p0, int p1, fl
             if (p + j < p1) {
                 float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
                 u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
-                topk_insert<K>(best, __longlong_as_double((long long)key));
+                const double kd = __longlong_as_double((long long)key);
+                if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
+                topk_insert<K>(best, kd);
             }
         }
     }
 }
 
-template <int K>
-__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
-                                         float qz, double (&best)[K]) {
-    scan_range<K>(G, G.cell_start[cell_a], G.cell_start[cell_b + 1], qx, qy, qz, best);
-}
-
-template <int K>
+template <int K, bool SUB>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
-                                        float* __restrict__ out_d2, int64_t t) {
+                                        float* __restrict__ out_d2, int64_t t, int n_sub = 0,
+                                        int32_t* __restrict__ out_sub = nullptr) {
     if (t >= Q.n_total) return;
     int s; int64_t local;
     float qx, qy, qz;
@@ -109,6 +109,7 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
     double best[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
+    double best1 = __longlong_as_double((long long)KEY_EMPTY);
 
     if (g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
@@ -119,33 +120,16 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             int xa = max(cx - r, 0), xb = min(cx + r, dxm);
             int ya = max(cy - r, 0), yb = min(cy + r, dym);
             int za = max(cz - r, 0), zb = min(cz + r, dzm);
-#ifndef KNN_NO_ROW_PREFETCH
-            if (r == 1) {
-                // the 3 x 3 rows of the first block: all 18 row bounds are requested before the first one is used (the
-                // cell table does not fit the L2 -- one exposed memory latency instead of nine in a row)
-                int p0[9], p1[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const int y = cy - 1 + i % 3, z = cz - 1 + i / 3;
-                    const bool in = y >= 0 && y <= dym && z >= 0 && z <= dzm;
-                    const int row = g.cell_base + g.dims[0] * ((in ? y : cy) + g.dims[1] * (in ? z : cz));
-                    p0[i] = G.cell_start[row + xa];
-                    p1[i] = in ? G.cell_start[row + xb + 1] : p0[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 9; ++i) scan_range<K>(G, p0[i], p1[i], qx, qy, qz, best);
-            } else
-#endif
             for (int z = za; z <= zb; ++z) {
                 int az = z > cz ? z - cz : cz - z;
                 for (int y = ya; y <= yb; ++y) {
                     int ay = y > cy ? y - cy : cy - y;
                     int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
                     if (r == 1 || az == r || ay == r) {
-                        scan_run<K>(G, row + xa, row + xb, qx, qy, qz, best);
+                        scan_run<K, SUB>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1);
                     } else {
-                        if (cx - r >= 0) scan_run<K>(G, row + cx - r, row + cx - r, qx, qy, qz, best);
-                        if (cx + r <= dxm) scan_run<K>(G, row + cx + r, row + cx + r, qx, qy, qz, best);
+                        if (cx - r >= 0) scan_run<K, SUB>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1);
+                        if (cx + r <= dxm) scan_run<K, SUB>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1);
                     }
                 }
             }
@@ -170,11 +154,20 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             }
             if (kth != KEY_EMPTY && gd > 0.f) {
                 float dk = __uint_as_float((unsigned)(kth >> 32));
+                if (SUB) {
+                    // both answers must be final: the nearest prefix point may lie beyond the k-th neighbour
+                    const u64 k1 = (u64)__double_as_longlong(best1);
+                    if (k1 != KEY_EMPTY) dk = fmaxf(dk, __uint_as_float((unsigned)(k1 >> 32))); else dk = 3.0e38f;
+                }
                 if (dk < gd * gd * 0.999999f) break;
             }
         }
     }
     int64_t base = index_local ? 0 : seg_begin_global(support_segs, s);
+    if (SUB) {
+        const u64 k1 = (u64)__double_as_longlong(best1);
+        out_sub[out_row] = k1 != KEY_EMPTY ? (int32_t)(unsigned)(k1 & 0xffffffffull) : -1;
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (j < k) {
@@ -190,7 +183,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int32_t* __restrict__ out_idx,
           float* __restrict__ out_d2) {
-    knn_one<K>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    knn_one<K, false>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Several independent searches in ONE launch (the levels of the RandLA pyramid): the small levels are
@@ -202,6 +195,8 @@ struct KnnJob {
     QuerySrc Q;
     Segs support;
     int32_t* out_idx;
+    int32_t* out_sub;     // 1-NN among the prefix [:n_sub] of the support (nullptr: not asked for)
+    int n_sub;
     unsigned block_begin;
 };
 struct KnnJobs {
@@ -209,17 +204,18 @@ struct KnnJobs {
     int n;
 };
 
-template <int K>
+template <int K, bool SUB>
 __global__ void __launch_bounds__(256) knn_query_multi(KnnJobs J, int k, int index_local) {
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
-    knn_one<K>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
-               (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
+    knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub);
 }
 
+template <bool SUB>
 static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
     unsigned blocks = 0;
     for (int i = 0; i < J.n; ++i) {
@@ -227,11 +223,11 @@ static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t st
         blocks += (unsigned)((J.j[i].Q.n_total + 255) / 256);
     }
     if (blocks == 0) return 0;
-    if (k == 1) hipLaunchKernelGGL(knn_query_multi<1>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 8) hipLaunchKernelGGL(knn_query_multi<8>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 16) hipLaunchKernelGGL(knn_query_multi<16>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 32) hipLaunchKernelGGL(knn_query_multi<32>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 64) hipLaunchKernelGGL(knn_query_multi<64>, dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 16) hipLaunchKernelGGL((knn_query_multi<16, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
     else return ML3D_E_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
@@ -323,7 +319,7 @@ extern "C" size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0,
     int64_t n[17];
     if (pyramid_sizes(n0, num_layers, ratios_host, n)) return 0;
     size_t b = 0;
-    for (int l = 0; l <= num_layers; ++l) b += grid_ws_bytes(n[l] * batch, batch) + 256;
+    for (int l = 0; l < num_layers; ++l) b += grid_ws_bytes(n[l] * batch, batch) + 256;
     return b;
 }
 
@@ -363,21 +359,21 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
     hipStream_t st = (hipStream_t)stream;
     GridWs ws[17];
     char* p = (char*)workspace;
-    for (int l = 0; l <= num_layers; ++l) {
+    for (int l = 0; l < num_layers; ++l) {
         size_t bytes = grid_ws_bytes(n[l] * batch, batch) + 256;
         if (!grid_ws_carve(p, bytes, n[l] * batch, batch, &ws[l])) return ML3D_E_WORKSPACE;
         p += bytes;
     }
     float occ = tuning_occ();
-    // grids of every level: level l = prefix [:n_l] of each cloud (randlanet.py:222)
-    for (int l = 0; l <= num_layers; ++l) {
+    // grids of the searched levels: level l = prefix [:n_l] of each cloud (randlanet.py:222)
+    for (int l = 0; l < num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
         tb(100 + l);
         // level 0 probes the cloud; the thinner prefix levels reuse its box and dimension estimate
         if (l == 0 ? grid_build(points, S, ws[l], occ, st) : grid_build_derived(points, S, ws[l], ws[0], st))
             return ML3D_E_LAUNCH;
-        if (tile_order_host && l < num_layers && tile_order_host[l]) {
+        if (tile_order_host && tile_order_host[l]) {
             const int64_t nt = n[l] * batch;
             hipLaunchKernelGGL(order_from_grid, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ws[l].sorted, nt, n[l],
                                tile_order_host[l]);
@@ -385,11 +381,13 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
         }
         te(100 + l);
     }
-    // all k-NN searches (level l onto itself, randlanet.py:220) in one launch, all 1-NN interpolation
-    // searches (level l in level l+1, randlanet.py:224) in a second one
-    KnnJobs Jk, J1;
-    Jk.n = 0; J1.n = 0;
-    const bool merged = num_layers <= KNN_MAX_JOBS;
+    // ONE launch for all levels and both searches of a level: the k-NN of level l onto itself (randlanet.py:220) and the
+    // 1-NN of level l in level l + 1 (randlanet.py:224).  Level l + 1 is the prefix [:n_{l+1}] of level l, so the
+    // interpolation target is simply the nearest scanned candidate with index < n_{l+1}: it rides along in the k-NN scan
+    // (one extra key per lane) instead of eight searches on five grids.
+    if (num_layers > KNN_MAX_JOBS) return ML3D_E_UNSUPPORTED;
+    KnnJobs Jk;
+    Jk.n = 0;
     for (int l = 0; l < num_layers; ++l) {
         if (n[l] == 0) continue;
         Segs S = {nullptr, n0, n[l], (int)batch};
@@ -399,41 +397,15 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
         Q.raw = points;
         Q.segs = S;
         Q.n_total = n[l] * batch;
-        if (merged) {
-            KnnJob& a = Jk.j[Jk.n++];
-            a.G = grid_view(ws[l]); a.Q = Q; a.support = S; a.out_idx = neighbor_idx_host[l]; a.block_begin = 0;
-        } else {
-            tb(2 * l);
-            int rc = launch_query(grid_view(ws[l]), Q, k, 1, S, neighbor_idx_host[l], nullptr, st);
-            te(2 * l);
-            if (rc) return rc;
-        }
-        if (n[l + 1] > 0) {
-            Segs S1 = {nullptr, n0, n[l + 1], (int)batch};
-            if (merged) {
-                KnnJob& a = J1.j[J1.n++];
-                a.G = grid_view(ws[l + 1]); a.Q = Q; a.support = S1; a.out_idx = interp_idx_host[l]; a.block_begin = 0;
-            } else {
-                tb(2 * l + 1);
-                int rc = launch_query(grid_view(ws[l + 1]), Q, 1, 1, S1, interp_idx_host[l], nullptr, st);
-                te(2 * l + 1);
-                if (rc) return rc;
-            }
-        } else {
-            (void)hipMemsetAsync(interp_idx_host[l], 0xff, sizeof(int32_t) * (size_t)(n[l] * batch), st);
-        }
+        KnnJob& a = Jk.j[Jk.n++];
+        a.G = grid_view(ws[l]); a.Q = Q; a.support = S; a.out_idx = neighbor_idx_host[l]; a.block_begin = 0;
+        a.out_sub = interp_idx_host[l];
+        a.n_sub = (int)n[l + 1];          // 0: every interpolation index comes out -1 (no coarser level)
     }
-    if (merged) {
-        tb(0);
-        int rc = launch_query_multi(Jk, k, 1, st);
-        te(0);
-        if (rc) return rc;
-        tb(1);
-        rc = launch_query_multi(J1, 1, 1, st);
-        te(1);
-        if (rc) return rc;
-    }
-    return 0;
+    tb(0);
+    int rc = launch_query_multi<true>(Jk, k, 1, st);
+    te(0);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------

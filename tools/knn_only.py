@@ -32,7 +32,7 @@ pts = torch.from_numpy(frames).to(dev)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); b.record()
 out = {}
-for tag in [0, 1, 100, 101, 102, 103, 104]:
+for tag in [0, 100, 101, 102, 103]:
     ts = []
     for _ in range(reps):
         eng.neighbors(pts, make_trace(tag, a, b))
@@ -40,23 +40,3 @@ for tag in [0, 1, 100, 101, 102, 103, 104]:
         ts.append(a.elapsed_time(b))
     out[tag] = float(np.median(ts))
 print("knn_only", " ".join("%d=%.3f" % kv for kv in out.items()))
-import ctypes as C
-try:
-    lib = eng.lib
-    fn = lib.ml3d_knn_prof_read
-    fn.argtypes = [C.c_void_p, C.c_int]
-    print("prof reset rc", lib.ml3d_knn_prof_reset())
-    eng.neighbors(pts)
-    torch.cuda.synchronize()
-    W = 59840
-    buf = (C.c_uint * (8 * W))()
-    print("prof read rc", fn(C.cast(buf, C.c_void_p), W))
-    v = np.frombuffer(buf, dtype=np.uint32).reshape(W, 8).astype(np.float64)
-    names = ["prologue", "precount", "pass(stage+consume)", "consume", "pass-end", "fallback", "total"]
-    for nm, sl in (("16-NN", slice(0, W)),):
-        x = v[sl]
-        x = x[x[:, 7] > 0]
-        print("knn_prof %s: %d waves, mean cycles per wave:" % (nm, len(x)), " ".join("%s=%.0f" % (names[i], x[:, i].mean()) for i in range(7)),
-              "| total p50=%.0f p95=%.0f max=%.0f" % tuple(np.percentile(x[:, 6], [50, 95, 100])))
-except AttributeError:
-    pass
