@@ -1,6 +1,8 @@
 // gemm.hip — tiled f32 MFMA GEMM with loader-templated A operand and fused epilogue (see gemm.h).
 #include "gemm.h"
 
+#include <stdlib.h>
+
 #include "grid.h"
 #include "ml3d_hip.h"
 
@@ -237,6 +239,177 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     }
 }
 
+// ---- 128-row tile kernel: register-blocked MFMA ----------------------------------------------------------------------
+// The 64 x 64 kernel above gives every wave ONE 32 x 32 accumulator: each MFMA needs its own A and B value from LDS and the
+// loader's address arithmetic is paid per 16 MFMAs.  On gfx950 the f32 MFMAs do not overlap VALU / LDS issue
+// (tools/micro/mfma_valu_overlap.hip), so those instructions are lost matrix time: 0.5 of peak.  Here a workgroup owns
+// 128 rows x BN columns and a wave a 2 x 2 (BN = 128) or 2 x 1 (BN = 64) block of 32 x 32 accumulators: an A value feeds
+// two MFMAs, a B value two more, and the per-chunk loader work (same per staged element) is spread over 4x / 2x the
+// MFMAs.  The conv loader keeps ONE int per staged row (element offset of the receptive field's corner) and a 9-bit mask
+// of the taps that fall inside the image; a K chunk lies inside one tap (C % 32 == 0), so per chunk a staged float4
+// costs a bit test and an add.  Interior rows never see a branch.
+constexpr int G2_BM = 128;
+
+struct ConvLoader2 {
+    ConvA A;
+    int64_t M;
+    int K;
+    struct Ctx { int off; unsigned taps; };     // off: element offset of (b, iy0, ix0, 0) (may be negative); taps: valid (ky, kx)
+    __device__ __forceinline__ Ctx prepare(int64_t m) const {
+        Ctx c; c.off = 0; c.taps = 0u;
+        if (m < M) {
+            const int ox = (int)(m % A.OW);
+            const int64_t t = m / A.OW;
+            const int oy = (int)(t % A.OH);
+            const int b = (int)(t / A.OH);
+            const int iy0 = oy * A.stride - A.pad, ix0 = ox * A.stride - A.pad;
+            c.off = ((b * A.H + iy0) * A.W + ix0) * A.C;
+            for (int ky = 0; ky < A.KH; ++ky)
+                for (int kx = 0; kx < A.KW; ++kx)
+                    if (iy0 + ky >= 0 && iy0 + ky < A.H && ix0 + kx >= 0 && ix0 + kx < A.W) c.taps |= 1u << (ky * A.KW + kx);
+        }
+        return c;
+    }
+    // k0: the chunk's first column (uniform) -> tap and channel origin on the scalar unit
+    __device__ __forceinline__ float4 load4(const Ctx& c, int k0, int kq) const {
+        const int tap = k0 / A.C;
+        const int ci = k0 - tap * A.C + kq;
+        const int ky = tap / A.KW, kx = tap - ky * A.KW;
+        if (!((c.taps >> tap) & 1u)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(A.in + (c.off + (ky * A.W + kx) * A.C + ci));
+    }
+};
+
+template <class Loader, int BN, int KC>
+__global__ void __launch_bounds__(256)
+gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __restrict__ C, int64_t ldc) {
+    constexpr int BP = BN + 4;
+    constexpr int RT = 2;                       // 32-row tiles per wave
+    constexpr int CT = BN / 64;                 // 32-column tiles per wave (BN = 128: 2, BN = 64: 1)
+    constexpr int AP = KC + 4;                  // LDS pitch of the A tile
+    constexpr int NA4 = KC / 8;                 // A float4 per thread and chunk (128 rows x KC / 256 threads / 4)
+    constexpr int NB4 = KC * BN / 1024;         // B float4 per thread and chunk
+    __shared__ __attribute__((aligned(16))) float As[G2_BM * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    const int wr = wave & 1, wc = wave >> 1;     // wave's 64-row half / column half
+    const int64_t m0 = (int64_t)blockIdx.x * G2_BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = L.K;
+
+    // staging: A rows (tid / (KC / 4)) + (1024 / KC) j, k offset 4 (tid % (KC / 4));  B rows (tid / (BN / 4)) + (1024 / BN) j,
+    // column 4 (tid % (BN / 4))
+    constexpr int ATH = KC / 4;                  // threads per A row
+    constexpr int ARS = 256 / ATH;               // A rows per pass
+    const int ar = tid / ATH, aq = (tid % ATH) * 4;
+    constexpr int BTH = BN / 4;                  // threads per B row
+    const int br = tid / BTH, bq = (tid % BTH) * 4;
+    constexpr int NROW = 128 / ARS;              // staged A rows per thread
+    static_assert(NROW == NA4, "A staging");
+    typename Loader::Ctx cx[NROW];
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) cx[j] = L.prepare(m0 + ar + ARS * j);
+    const bool bcol_ok = n0 + bq + 3 < N;
+
+    float4 ra[NA4], rb[NB4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) ra[j] = L.load4(cx[j], k0, aq);
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) {
+            const int k = k0 + br + (256 / BTH) * j;
+            rb[j] = (bcol_ok && k < K) ? *reinterpret_cast<const float4*>(Bm + (int64_t)k * N + n0 + bq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) *reinterpret_cast<float4*>(As + (ar + ARS * j) * AP + aq) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) *reinterpret_cast<float4*>(Bs + (br + (256 / BTH) * j) * BP + bq) = rb[j];
+    };
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch(0);
+    stash();
+    block_sync_lds();
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const bool more = k0 + KC < K;
+        if (more) fetch(k0 + KC);           // global loads in flight under the MFMAs
+        const float* arow = As + (wr * 64 + cl) * AP + hi * (KC / 2);
+        const float* brow = Bs + (hi * (KC / 2)) * BP + wc * (32 * CT) + cl;
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 8; ++s4) {
+            float4 a[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const float4*>(arow + i * 32 * AP + 4 * s4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float b[CT];
+#pragma unroll
+                for (int j = 0; j < CT; ++j) b[j] = brow[(4 * s4 + kk) * BP + 32 * j];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const float av = kk == 0 ? a[i].x : (kk == 1 ? a[i].y : (kk == 2 ? a[i].z : a[i].w));
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        block_sync_lds();
+        if (more) {
+            stash();
+            block_sync_lds();
+        }
+    }
+    // ---- epilogue (bias + residual + activation, or the pixel-shuffle store) ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = n0 + wc * (32 * CT) + 32 * j + cl;
+        if (col >= N) continue;
+        if (ep.ps > 0) {
+            const int co = col % ep.ps_cout, dd = col / ep.ps_cout;
+            const int dy = dd / ep.ps, dx = dd % ep.ps;
+            const float b = ep.bias ? ep.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
+                    if (m < L.M) {
+                        const int x = (int)(m % ep.ps_w);
+                        const int64_t t = m / ep.ps_w;
+                        const int y = (int)(t % ep.ps_h);
+                        const int64_t bi = t / ep.ps_h;
+                        const int64_t opix = (bi * ep.ps_h * ep.ps + (int64_t)y * ep.ps + dy) * ((int64_t)ep.ps_w * ep.ps) + (int64_t)x * ep.ps + dx;
+                        C[opix * ldc + co] = gm_act(acc[i][j][r] + b, ep.act, ep.slope);
+                    }
+                }
+            continue;
+        }
+        float b = ep.bias ? ep.bias[col] : 0.f;
+        if (ep.bias2) b += ep.bias2[col];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
+                if (m < L.M) {
+                    float v = acc[i][j][r] + b;
+                    if (ep.residual) v += ep.residual[m * ep.ldr + col];
+                    C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
+                }
+            }
+    }
+}
+
 __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64_t M, int N, Epilogue ep,
                             float* __restrict__ C, int64_t ldc) {
     const int64_t total = M * N;
@@ -283,6 +456,68 @@ size_t gemm_partial_bytes(int64_t M, int N, int K) {
     return s > 1 ? sizeof(float) * (size_t)s * (size_t)M * (size_t)N : 0;
 }
 
+// The register-blocked kernel takes the problems it is built for: no split-K, float4-addressable operands, no gathered
+// residual, and enough 128-row tiles to fill the 256 CUs -- medium problems (the 62 x 54 and 31 x 27 maps of SECOND's deeper
+// blocks at 8 sweeps) fill the chip better with the 64 x 64 tiles of gemm_tile.  Returns the column-tile width to use, 0 = no.
+static int big_bn(int64_t M, int N, int K, const float* Bm, const Epilogue& ep) {
+    // ML3D_GEMM_BIG_MIN_TILES (read once, at the first call): workgroups below which gemm_tile keeps the problem; the
+    // emulator tests set 1 to push small problems through this kernel, A/B runs a huge value to switch it off
+    static const int64_t min_tiles = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_TILES"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+    if ((N & 3) || (K % GM_KC) != 0 || (((uintptr_t)Bm) & 15) != 0 || ep.res_gather) return 0;
+    const int64_t rows = (M + G2_BM - 1) / G2_BM;
+    if (N > 64 && rows * ((N + 127) / 128) >= 2 * min_tiles) return 128;
+    if (rows * ((N + 63) / 64) >= min_tiles) return (N > 64 && rows * ((N + 127) / 128) >= min_tiles) ? 128 : 64;
+    return 0;
+}
+
+template <class L2>
+static void launch_big(const L2& L, const float* Bm, int N, int bn, int kc, const Epilogue& ep, float* C, int64_t ldc,
+                       hipStream_t st) {
+    const unsigned gm = (unsigned)((L.M + G2_BM - 1) / G2_BM);
+    if (bn == 128) {
+        const dim3 g(gm, (unsigned)((N + 127) / 128));
+        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 128, 64>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        else hipLaunchKernelGGL((gemm_tile2<L2, 128, 32>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+    } else {
+        const dim3 g(gm, (unsigned)((N + 63) / 64));
+        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 64, 64>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        else hipLaunchKernelGGL((gemm_tile2<L2, 64, 32>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+    }
+}
+
+// K chunk: 64 for the 128-column tiles when the operands allow it (half the barriers per MFMA, twice the matrix time to
+// hide the next chunk's global loads under: SECOND's 128- and 256-channel convs), 32 for the 64-column tiles (measured:
+// 3x3 64 -> 64 conv 0.328 ms at 32 vs 0.362 ms at 64).  ML3D_GEMM_BIG_KC (read once) pins it for A/B runs.
+static int big_kc(int K, int c_or_zero, int bn) {
+    static const int pin = [] { const char* e = getenv("ML3D_GEMM_BIG_KC"); return e ? atoi(e) : 0; }();
+    const bool ok64 = (K % 64) == 0 && (c_or_zero == 0 || (c_or_zero % 64) == 0);
+    if (pin == 32 || !ok64) return 32;
+    if (pin == 64) return 64;
+    return bn == 128 ? 64 : 32;
+}
+
+static bool gemm_launch_big(const ConvLoader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
+                            hipStream_t st) {
+    const ConvA& A = L.A;
+    const int bn = big_bn(L.M, N, L.K, Bm, ep);
+    if (!bn || (A.C % GM_KC) != 0 || A.KH * A.KW > 32 ||
+        (int64_t)A.B * A.H * A.W * A.C >= 0x7fffffffll - (int64_t)(A.pad + 1) * (A.W + 1) * A.C)
+        return false;
+    ConvLoader2 L2;
+    L2.A = A; L2.M = L.M; L2.K = L.K;
+    launch_big(L2, Bm, N, bn, big_kc(L.K, A.C, bn), ep, C, ldc, st);
+    return true;
+}
+
+static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
+                            hipStream_t st) {
+    const int bn = big_bn(L.M, N, L.K, Bm, ep);
+    if (!bn || !L.vec) return false;
+    // a chunk may straddle the boundary of the two concatenated operands only at a multiple of 4 (float4 loads): any KC works
+    launch_big(L, Bm, N, bn, big_kc(L.K, 0, bn), ep, C, ldc, st);
+    return true;
+}
+
 template <class Loader>
 static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
                        void* partial_ws, size_t partial_bytes, hipStream_t st) {
@@ -292,6 +527,7 @@ static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& 
     if (K <= 0 || !Bm || !C) return ML3D_E_INVALID;
     int splits = pick_splits(M, N, K);
     if (splits > 1 && (!partial_ws || partial_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N)) splits = 1;
+    if (splits == 1 && gemm_launch_big(L, Bm, N, ep, C, ldc, st)) return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     // split boundaries are multiples of the K chunk (so also of 4: float4 loads never straddle one)
     int kper = ((K + splits - 1) / splits + GM_KC - 1) / GM_KC * GM_KC;
     splits = (K + kper - 1) / kper;

@@ -19,13 +19,18 @@ from .torch.models import _randla_pack
 class RandLAInferenceEngine:
 
     def __init__(self, cfg, state_dict, batch, num_points, device, tile_order=None):
-        """``tile_order``: walk the attention tiles of every level in the cell-sorted order of the neighbour pyramid's
-        grids (same scores, better locality of the neighbour gathers); default from ``ML3D_TILE_ORDER`` (off: the
-        variant is parity-tested but has not been timed on an MI355X yet)."""
+        """``tile_order``: walk the attention tiles in the cell-sorted order of the neighbour pyramid's grids (same
+        scores bit for bit, better locality of the neighbour gathers).  False / 0 = off, True = every level, an int n =
+        the n finest levels only.  Default: the two finest levels (measured at 64 frames of 45 056 points, two runs each:
+        5290 / 5273 frames/s off, 5483 / 5483 every level, 5563 / 5555 two levels -- the gather sets of the coarse levels
+        fit the L2 anyway and their kernels lose 7 % to the indirection); ``ML3D_TILE_ORDER`` = 0 / 1 (all) / n overrides."""
         self.lib = _abi.get()
         if tile_order is None:
-            tile_order = os.environ.get("ML3D_TILE_ORDER", "0") == "1"
-        self.tile_order = bool(tile_order)
+            tile_order = int(os.environ.get("ML3D_TILE_ORDER", "2") or 0)
+            if tile_order == 1:
+                tile_order = True
+        self.tile_levels = (int(cfg["num_layers"]) if tile_order is True else int(tile_order or 0))
+        self.tile_order = self.tile_levels > 0
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -50,9 +55,9 @@ class RandLAInferenceEngine:
         self.fwd_ws = torch.empty(self.fwd_ws_bytes, dtype=torch.uint8, device=dev)
         self._t_n = _abi.ptr_table([t.data_ptr() for t in self.nbr])
         self._t_i = _abi.ptr_table([t.data_ptr() for t in self.itp])
-        self.order = [torch.empty(self.B * self.n[l], dtype=torch.int32, device=dev) for l in range(self.L)] \
-            if self.tile_order else None
-        self._t_o = _abi.ptr_table([t.data_ptr() for t in self.order]) if self.tile_order else None
+        self.order = [torch.empty(self.B * self.n[l], dtype=torch.int32, device=dev) if l < self.tile_levels else None
+                      for l in range(self.L)] if self.tile_order else None
+        self._t_o = _abi.ptr_table([0 if t is None else t.data_ptr() for t in self.order]) if self.tile_order else None
 
     def _check(self, points, features):
         if tuple(points.shape) != (self.B, self.N, 3) or points.dtype != torch.float32 or \

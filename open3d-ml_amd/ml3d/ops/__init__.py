@@ -134,6 +134,22 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
     for t in list(neighbor_idx) + list(interp_idx):
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise RuntimeError("randla_forward: index tensors must be contiguous int32")
+    # the C ABI receives bare pointers and derives every extent from the descriptor: the list lengths and the shape of
+    # every level are checked HERE (a short list or a wrong K would be an out-of-bounds device read, not an error)
+    L, K = int(desc.num_layers), int(desc.num_neighbors)
+    sizes = pyramid_sizes(n0, [int(desc.sub_sampling_ratio[i]) for i in range(L)])
+    if len(neighbor_idx) != L or len(interp_idx) != L:
+        raise RuntimeError("randla_forward: need %d neighbour and %d interpolation index tensors (got %d / %d)"
+                           % (L, L, len(neighbor_idx), len(interp_idx)))
+    for l in range(L):
+        if tuple(neighbor_idx[l].shape) != (B, sizes[l], K):
+            raise RuntimeError("randla_forward: neighbor_idx[%d] must be [%d, %d, %d], got %s"
+                               % (l, B, sizes[l], K, tuple(neighbor_idx[l].shape)))
+        if tuple(interp_idx[l].shape) not in ((B, sizes[l], 1), (B, sizes[l])):
+            raise RuntimeError("randla_forward: interp_idx[%d] must be [%d, %d, 1], got %s"
+                               % (l, B, sizes[l], tuple(interp_idx[l].shape)))
+        if tile_order is not None and (l >= len(tile_order) or tile_order[l].numel() != B * sizes[l]):
+            raise RuntimeError("randla_forward: tile_order[%d] must hold %d rows" % (l, B * sizes[l]))
     if out is None:
         out = torch.empty((B, n0, desc.num_classes), dtype=torch.float32, device=dev)
     wsb = lib.ml3d_randla_forward_workspace_bytes(C.byref(desc))
@@ -652,7 +668,11 @@ def nearest_to_center(points, center, k, return_distances=False):
 
 def vote_update(test_probs, point_inds, logits, smooth=0.95):
     """In place: ``test_probs[inds] = smooth * test_probs[inds] + (1 - smooth) * softmax(logits)`` on the float16
-    vote accumulator [N_cloud, classes] (ml3d/torch/models/randlanet.py:420-421, 457-462)."""
+    vote accumulator [N_cloud, classes] (ml3d/torch/models/randlanet.py:420-421, 457-462).
+    ONE batch item per call: every wave does an unsynchronised read-modify-write of its point's row, so the indices of a
+    call must be unique (a patch never lists a point twice).  Patches of a batch that share points are applied by calling
+    this once per item, in order, on one stream -- what ``RandLANet.update_probs`` / ``KPFCNN.update_probs`` do and what
+    the reference's sequential loop (randlanet.py:455-463) means."""
     lib = _abi.get()
     _need_gpu(test_probs, point_inds, logits)
     if test_probs.dtype != torch.float16 or not test_probs.is_contiguous() or test_probs.dim() != 2:

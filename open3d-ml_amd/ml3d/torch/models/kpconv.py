@@ -171,6 +171,11 @@ class KPFCNN(nn.Module):
                 self.encoder_skip_dims.append(in_dim)
             if 'upsample' in block:
                 break
+            if block == 'unary':
+                # the reference's block_decider accepts it here; none of its configs has one and the fused encoder walk
+                # below (KPConv block -> gather / GEMM epilogues) has no slot for it: refuse at construction, not at run time
+                raise NotImplementedError("KPFCNN (MI355X build): a 'unary' block in the ENCODER is not supported "
+                                          "(no reference config uses one)")
             self.encoder_blocks.append(_block_decider(block, r, in_dim, out_dim, layer, cfg))
             in_dim = out_dim // 2 if 'simple' in block else out_dim
             if 'pool' in block or 'strided' in block:

@@ -141,6 +141,13 @@ class RandLANet(nn.Module):
         if 'neighbor_indices' in inputs and 'interp_idx' in inputs:
             nbr = [t.to(dev).to(torch.int32).contiguous() for t in inputs['neighbor_indices']]
             itp = [t.to(dev).to(torch.int32).contiguous() for t in inputs['interp_idx']]
+            if 'sub_idx' in inputs:
+                # random_sample (randlanet.py:300-327) pools through sub_idx; the kernels take it as the PREFIX of the
+                # level's neighbour matrix, which is what transform builds (randlanet.py:222-223).  Anything else is refused.
+                for l, (sub, nb) in enumerate(zip(inputs['sub_idx'], nbr)):
+                    sub = sub.to(dev)
+                    if sub.shape[-2] > nb.shape[-2] or not torch.equal(sub.to(torch.int32), nb[..., :sub.shape[-2], :]):
+                        raise RuntimeError("RandLANet.forward: sub_idx[%d] is not the prefix of neighbor_indices[%d]" % (l, l))
         else:
             nbr, itp = self.neighbor_pyramid(pts)
         B, N, _ = pts.shape

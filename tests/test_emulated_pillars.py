@@ -76,3 +76,62 @@ def test_deconv_pixel_shuffle_into_concat_slice(stride):
 def test_nhwc_to_nchw_slices():
     x = np.random.default_rng(0).standard_normal((2, 7, 9, 72)).astype(np.float32)
     assert np.array_equal(emu.nhwc_to_nchw(x, 18, 42), x[..., 18:60].transpose(0, 3, 1, 2))
+
+
+def _run_in_subprocess_with_big_gemm(code):
+    """The register-blocked 128-row GEMM only takes problems that fill the chip; ML3D_GEMM_BIG_MIN_TILES (read once when
+    the library is first used) lowers the bar, so the check runs in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    env = dict(os.environ, ML3D_GEMM_BIG_MIN_TILES="1",
+               PYTHONPATH=os.pathsep.join([here, root, os.path.join(root, "open3d-ml_amd")]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "OK" in r.stdout
+
+
+def test_register_blocked_gemm_kernel_conv_deconv_linear():
+    """gemm_tile2 (128 x {64, 128} tiles, 2 x 2 / 2 x 1 MFMA blocks, tap-mask conv loader): 3x3 convs with stride 1 / 2
+    at image borders, a ragged last row tile, the pixel-shuffle (transposed conv) store, and dense rows with a
+    concatenated second operand + residual -- against torch."""
+    _run_in_subprocess_with_big_gemm(r'''
+import numpy as np, torch, torch.nn.functional as F
+import emu
+rng = np.random.default_rng(0)
+for cin, cout, stride, hw in [(32, 64, 1, (13, 11)), (64, 128, 2, (12, 14)), (32, 192, 1, (9, 16)), (64, 64, 1, (10, 13))]:
+    x = rng.standard_normal((2, cin) + hw).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=1))
+    wk = w.transpose(2, 3, 1, 0).reshape(9 * cin, cout)
+    rc, out = emu.conv2d_nhwc(x.transpose(0, 2, 3, 1), wk, b, stride, 1)
+    assert rc == 0
+    assert np.abs(out.transpose(0, 3, 1, 2) - ref.numpy()).max() < 2e-4, (cin, cout, stride)
+# transposed conv, kernel == stride == 2: N = 4 * 32 = 128 columns, pixel-shuffle store into a wider map
+cin, cout, s = 32, 32, 2
+x = rng.standard_normal((1, cin, 12, 11)).astype(np.float32)
+w = (rng.standard_normal((cin, cout, s, s)) * 0.1).astype(np.float32)
+b = rng.standard_normal(cout).astype(np.float32)
+ref = F.relu(F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=s)).numpy()
+wk = w.transpose(0, 2, 3, 1).reshape(cin, s * s * cout)
+big = np.zeros((1, 24, 22, 72), np.float32)
+rc, out = emu.deconv2d_nhwc(x.transpose(0, 2, 3, 1), wk, b, s, cout, out=big, ch_off=40)
+assert rc == 0 and np.abs(out[..., 40:72].transpose(0, 3, 1, 2) - ref).max() < 2e-4
+# dense rows: [a | a2] @ W + bias + residual, leaky relu; 300 rows (ragged last tile), 64 + 32 -> 64
+a = rng.standard_normal((300, 64)).astype(np.float32); a2 = rng.standard_normal((300, 32)).astype(np.float32)
+wt = (rng.standard_normal((96, 64)) * 0.1).astype(np.float32); bias = rng.standard_normal(64).astype(np.float32)
+res = rng.standard_normal((300, 64)).astype(np.float32)
+rc, out = emu.linear(a, wt, bias, a2=a2, residual=res, act=1, slope=0.1)
+want = np.concatenate([a, a2], 1) @ wt + bias + res
+want = np.where(want > 0, want, 0.1 * want)
+assert rc == 0 and np.abs(out - want).max() < 2e-4
+# a head-like GEMM: N = 72 is not a multiple of the 64 / 128 column tiles (the last tile is ragged)
+a = rng.standard_normal((200, 64)).astype(np.float32)
+wt = (rng.standard_normal((64, 72)) * 0.1).astype(np.float32); bias = rng.standard_normal(72).astype(np.float32)
+rc, out = emu.linear(a, wt, bias)
+assert rc == 0 and np.abs(out - (a @ wt + bias)).max() < 2e-4
+print("OK")
+''')

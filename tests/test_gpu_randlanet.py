@@ -154,6 +154,10 @@ def test_tile_order_engine_is_bit_identical():
     ordered = RandLAInferenceEngine(dict(KITTI, num_points=N), sd, B, N, "cuda:0", tile_order=True)
     b = ordered.step(t, t.clone()).clone()
     torch.cuda.synchronize()
+    two = RandLAInferenceEngine(dict(KITTI, num_points=N), sd, B, N, "cuda:0", tile_order=2)     # finest two levels only
+    c = two.step(t, t.clone()).clone()
+    torch.cuda.synchronize()
+    assert two.order[2] is None and two.order[3] is None and torch.equal(a, c)
     for l in range(len(ordered.order)):
         o = ordered.order[l].cpu().numpy().reshape(B, -1)
         n_l = o.shape[1]
