@@ -120,12 +120,13 @@ class PipelinedRandLAEngine:
         e._check(points, features)
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
+            # everything the caller has enqueued comes first: its inputs, and its READS of the scores buffer this engine
+            # slot is about to overwrite (bench.py's argmax of two steps ago runs on the caller's stream)
+            self.search.wait_stream(cur)
+            self.compute.wait_stream(cur)
             if ready is not None:
                 self.search.wait_event(ready)
                 self.compute.wait_event(ready)
-            else:
-                self.search.wait_stream(cur)          # inputs were produced on the caller's stream
-                self.compute.wait_stream(cur)
             points.record_stream(self.search)     # ... and must outlive the side-stream kernels that read them
             points.record_stream(self.compute)
             features.record_stream(self.compute)

@@ -60,6 +60,40 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
 #define KNN_GROUP 3
 #endif
 
+#ifdef ML3D_KNN_STATS
+// emulator-only instrumentation (tests/hipemu build with -DML3D_KNN_STATS): [0] waves, [1] waves on the LDS path, [2] staged candidates
+unsigned long long g_knn_stats[8];
+extern "C" unsigned long long* ml3d_knn_stats() { return g_knn_stats; }
+#define KNN_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_STAT(i, v) do { } while (0)
+#endif
+
+#ifndef KNN_LDS_CAND
+#define KNN_LDS_CAND 512
+#endif
+constexpr int LDS_CAND = KNN_LDS_CAND;       // candidates one wave stages for its first block of cells (8 KB of LDS)
+
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int K, bool SUB>
+__device__ __forceinline__ void consume(const float4 c, float qx, float qy, float qz, double (&best)[K], int n_sub, double& best1) {
+    const float d2 = dist2_canon(qx, qy, qz, c.x, c.y, c.z);
+    const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
+    const double kd = __longlong_as_double((long long)key);
+    if (SUB) best1 = key_min(best1, __float_as_int(c.w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
+    topk_insert<K>(best, kd);
+}
+
 // SUB: also track the nearest candidate whose index is below n_sub -- the RandLA pyramid's 1-NN interpolation target
 // (level l + 1 is the prefix [:n_sub] of level l, randlanet.py:222-224), found in the same scan as the k-NN
 template <int K, bool SUB>
@@ -75,23 +109,27 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
         for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) {
-            if (p + j < p1) {
-                float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
-                u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
-                const double kd = __longlong_as_double((long long)key);
-                if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
-                topk_insert<K>(best, kd);
-            }
+            if (p + j < p1) consume<K, SUB>(c[j], qx, qy, qz, best, n_sub, best1);
         }
     }
 }
 
-template <int K, bool SUB>
+// LDS = true (the pyramid's self searches: the queries ARE the grid's cell-sorted points, 64 consecutive ones per wave): the
+// wave's queries occupy a contiguous run [c_first, c_last] of the linear cell order, so the 3 x 3 x 3 blocks of all of them
+// lie in NINE contiguous cell runs -- that run shifted by (dy, dz) rows / slabs and widened by one cell -- i.e. nine
+// contiguous slices of the sorted array.  The wave stages them in LDS with coalesced loads; every lane requests the 18 row
+// bounds of its own block together and scans the block from LDS: ONE exposed global latency for the loop that visits two
+// thirds of the candidates (the global path pays one per row and one per group of three candidates).
+// Shells r >= 2 (and waves whose slices do not fit) keep the global path.
+template <int K, bool SUB, bool LDS>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
-                                        float* __restrict__ out_d2, int64_t t, int n_sub = 0,
-                                        int32_t* __restrict__ out_sub = nullptr) {
-    if (t >= Q.n_total) return;
+                                        float* __restrict__ out_d2, int64_t t_in, int n_sub = 0,
+                                        int32_t* __restrict__ out_sub = nullptr, float4* s_c = nullptr, int* s_pos = nullptr,
+                                        int* s_meta = nullptr) {
+    const bool valid = t_in < Q.n_total;
+    if (!LDS && !valid) return;
+    const int64_t t = valid ? t_in : Q.n_total - 1;       // idle lanes of the last wave shadow the last query
     int s; int64_t local;
     float qx, qy, qz;
     seg_locate(Q.segs, t, s, local);
@@ -111,6 +149,97 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
     for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
     double best1 = __longlong_as_double((long long)KEY_EMPTY);
 
+    bool first_done = false;          // the r = 1 block was scanned from LDS
+    if (LDS) {
+        const int lane = threadIdx.x & 63;
+        const int dimx = g.dims[0], dimy = g.dims[1], dimz = g.dims[2];
+        const int cx0 = cell_coord(qx, g.lo[0], g.inv_c, dimx), cy0 = cell_coord(qy, g.lo[1], g.inv_c, dimy),
+                  cz0 = cell_coord(qz, g.lo[2], g.inv_c, dimz);
+        const int lin = cx0 + dimx * (cy0 + dimy * cz0);
+        const int s0 = __builtin_amdgcn_readfirstlane(s);
+        const bool same = __all(s == s0) != 0;               // (segment-uniform wave: the GridSeg above is then uniform too)
+        const int c_first = wave_min_int(lin), c_last = wave_max_int(lin);
+#ifdef KNN_NO_LDS
+        bool use = false;
+#else
+        bool use = same && g.n > 0;
+#endif
+        int total = 0;
+        KNN_STAT(0, 1);
+        if (use) {
+            // lanes 0..8 describe the nine slices: first cell, number of cells, first slot, length
+            const int ncell = dimx * dimy * dimz;
+            int sl_lo = 0, sl_cells = 0, sl_start = 0, sl_n = 0;
+            if (lane < 9) {
+                const int dy = lane % 3 - 1, dz = lane / 3 - 1;
+                const int shift = dy * dimx + dz * dimx * dimy;
+                const int lo = max(c_first + shift - 1, 0), hi = min(c_last + shift + 1, ncell - 1);
+                if (lo <= hi) {
+                    sl_lo = lo; sl_cells = hi - lo + 1;
+                    sl_start = G.cell_start[g.cell_base + lo];
+                    sl_n = G.cell_start[g.cell_base + hi + 1] - sl_start;
+                }
+            }
+            int incl = sl_n;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            total = __builtin_amdgcn_readlane(incl, 8);
+            use = total <= LDS_CAND;
+            if (!use) { KNN_STAT(4, 1); KNN_STAT(6, total); }
+            if (use && lane < 9) {
+                s_meta[4 * lane + 0] = sl_lo;
+                s_meta[4 * lane + 1] = sl_cells;
+                s_meta[4 * lane + 2] = sl_start;
+                s_meta[4 * lane + 3] = incl - sl_n;          // first LDS slot of the slice
+            }
+        }
+        if (use) {
+            KNN_STAT(1, 1);
+            KNN_STAT(2, total);
+            wave_lds_sync();
+            // this lane's nine cell runs: 18 row bounds requested together (ONE exposed latency), turned into LDS slots
+            const int xa = max(cx0 - 1, 0), xb = min(cx0 + 1, dimx - 1);
+            int ga[9], gb[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int dy = i % 3 - 1, dz = i / 3 - 1;
+                const int y = cy0 + dy, z = cz0 + dz;
+                const bool in = y >= 0 && y < dimy && z >= 0 && z < dimz;
+                const int ca = g.cell_base + (in ? lin + dy * dimx + dz * dimx * dimy + (xa - cx0) : lin);
+                ga[i] = G.cell_start[ca];
+                gb[i] = in ? G.cell_start[ca + (xb - xa) + 1] : ga[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int adj = s_meta[4 * i + 3] - s_meta[4 * i + 2];       // LDS slot - sorted slot of slice i
+                s_pos[(2 * i) * 64 + lane] = ga[i] + adj;
+                s_pos[(2 * i + 1) * 64 + lane] = gb[i] + adj;
+            }
+            // the candidates: slot e belongs to the last slice whose first slot is <= e
+            for (int e = lane; e < total; e += 64) {
+                int sj = 0;                  // (slices without cells share their first slot with the next one: skipped)
+#pragma unroll
+                for (int q = 1; q < 9; ++q)
+                    if (s_meta[4 * q + 1] > 0 && e >= s_meta[4 * q + 3]) sj = q;
+                s_c[e] = G.sorted[s_meta[4 * sj + 2] + (e - s_meta[4 * sj + 3])];
+            }
+            wave_lds_sync();
+            if (valid) {
+#pragma unroll 1
+                for (int i = 0; i < 9; ++i) {
+                    const int p0 = s_pos[(2 * i) * 64 + lane], p1 = s_pos[(2 * i + 1) * 64 + lane];
+                    for (int p = p0; p < p1; ++p) consume<K, SUB>(s_c[p], qx, qy, qz, best, n_sub, best1);
+                }
+            }
+            first_done = true;
+            wave_lds_sync();          // the next use of this wave's LDS (none in this kernel) would wait here
+        }
+        if (!valid) return;
+    }
+
     if (g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
         int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
@@ -120,6 +249,7 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             int xa = max(cx - r, 0), xb = min(cx + r, dxm);
             int ya = max(cy - r, 0), yb = min(cy + r, dym);
             int za = max(cz - r, 0), zb = min(cz + r, dzm);
+            if (!(r == 1 && first_done))
             for (int z = za; z <= zb; ++z) {
                 int az = z > cz ? z - cz : cz - z;
                 for (int y = ya; y <= yb; ++y) {
@@ -183,7 +313,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 knn_query(GridView G, QuerySrc Q, int k, int index_local, Segs support_segs, int32_t* __restrict__ out_idx,
           float* __restrict__ out_d2) {
-    knn_one<K, false>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    knn_one<K, false, false>(G, Q, k, index_local, support_segs, out_idx, out_d2, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Several independent searches in ONE launch (the levels of the RandLA pyramid): the small levels are
@@ -204,22 +334,20 @@ struct KnnJobs {
     int n;
 };
 
-#ifndef KNN_WAVES
-#define KNN_WAVES 0
-#endif
 template <int K, bool SUB>
-__global__ void __launch_bounds__(256)
-#if KNN_WAVES > 0
-ML3D_WAVES_PER_SIMD(KNN_WAVES)
-#endif
-knn_query_multi(KnnJobs J, int k, int index_local) {
+__global__ void __launch_bounds__(256) knn_query_multi(KnnJobs J, int k, int index_local) {
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
-    knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
-                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub);
+    __shared__ float4 s_c[SUB ? 4 : 1][SUB ? LDS_CAND : 1];          // (only the pyramid instantiation stages through LDS)
+    __shared__ int s_pos[SUB ? 4 : 1][SUB ? 18 * 64 : 1];
+    __shared__ int s_meta[SUB ? 4 : 1][40];
+    const int wv = threadIdx.x >> 6;
+    knn_one<K, SUB, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+                         (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub,
+                         s_c[SUB ? wv : 0], s_pos[SUB ? wv : 0], s_meta[SUB ? wv : 0]);
 }
 
 template <bool SUB>
