@@ -280,7 +280,7 @@ struct ConvLoader2 {
     }
 };
 
-template <class Loader, int BN, int KC>
+template <class Loader, int BN, int KC, bool PF2>
 __global__ void __launch_bounds__(256)
 gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __restrict__ C, int64_t ldc) {
     constexpr int BP = BN + 4;
@@ -312,8 +312,12 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
     for (int j = 0; j < NROW; ++j) cx[j] = L.prepare(m0 + ar + ARS * j);
     const bool bcol_ok = n0 + bq + 3 < N;
 
-    float4 ra[NA4], rb[NB4];
-    auto fetch = [&](int k0) {
+    // two register sets for the staged chunks: the loads of chunk c + 2 are issued before the MFMAs of chunk c, so they have
+    // TWO chunks of matrix time to land.  Measured on SECOND's 3x3 64 -> 64 conv (32-deep chunks, 64-column tiles): 0.353 ms
+    // against 0.328 ms with ONE set -- the extra registers cost more than the latency they hide -- so every instantiation the
+    // dispatcher uses today has PF2 = false; the path stays for wider tiles.
+    float4 ra0[NA4], rb0[NB4], ra1[PF2 ? NA4 : 1], rb1[PF2 ? NB4 : 1];
+    auto fetch = [&](float4* ra, float4* rb, int k0) {
 #pragma unroll
         for (int j = 0; j < NA4; ++j) ra[j] = L.load4(cx[j], k0, aq);
 #pragma unroll
@@ -322,7 +326,7 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
             rb[j] = (bcol_ok && k < K) ? *reinterpret_cast<const float4*>(Bm + (int64_t)k * N + n0 + bq) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](const float4* ra, const float4* rb) {
 #pragma unroll
         for (int j = 0; j < NA4; ++j) *reinterpret_cast<float4*>(As + (ar + ARS * j) * AP + aq) = ra[j];
 #pragma unroll
@@ -337,14 +341,9 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    fetch(0);
-    stash();
-    block_sync_lds();
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        const bool more = k0 + KC < K;
-        if (more) fetch(k0 + KC);           // global loads in flight under the MFMAs
-        const float* arow = As + (wr * 64 + cl) * AP + hi * (KC / 2);
-        const float* brow = Bs + (hi * (KC / 2)) * BP + wc * (32 * CT) + cl;
+    const float* arow = As + (wr * 64 + cl) * AP + hi * (KC / 2);
+    const float* brow = Bs + (hi * (KC / 2)) * BP + wc * (32 * CT) + cl;
+    auto mfma_chunk = [&]() {
 #pragma unroll
         for (int s4 = 0; s4 < KC / 8; ++s4) {
             float4 a[RT];
@@ -363,9 +362,38 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
                 }
             }
         }
-        block_sync_lds();
-        if (more) {
-            stash();
+    };
+
+    fetch(ra0, rb0, 0);
+    stash(ra0, rb0);
+    block_sync_lds();
+    if constexpr (!PF2) {
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            const bool more = k0 + KC < K;
+            if (more) fetch(ra0, rb0, k0 + KC);           // global loads in flight under the MFMAs
+            mfma_chunk();
+            block_sync_lds();
+            if (more) {
+                stash(ra0, rb0);
+                block_sync_lds();
+            }
+        }
+    } else {
+        if (KC < K) fetch(ra0, rb0, KC);                  // chunk 1 -> set 0
+        for (int k0 = 0; k0 < K; k0 += 2 * KC) {
+            // LDS holds chunk k0, set 0 chunk k0 + KC: request chunk k0 + 2 KC into set 1
+            if (k0 + 2 * KC < K) fetch(ra1, rb1, k0 + 2 * KC);
+            mfma_chunk();
+            block_sync_lds();
+            if (k0 + KC >= K) break;
+            stash(ra0, rb0);
+            block_sync_lds();
+            // LDS holds chunk k0 + KC, set 1 chunk k0 + 2 KC: request chunk k0 + 3 KC into set 0
+            if (k0 + 3 * KC < K) fetch(ra0, rb0, k0 + 3 * KC);
+            mfma_chunk();
+            block_sync_lds();
+            if (k0 + 2 * KC >= K) break;
+            stash(ra1, rb1);
             block_sync_lds();
         }
     }
@@ -476,12 +504,12 @@ static void launch_big(const L2& L, const float* Bm, int N, int bn, int kc, cons
     const unsigned gm = (unsigned)((L.M + G2_BM - 1) / G2_BM);
     if (bn == 128) {
         const dim3 g(gm, (unsigned)((N + 127) / 128));
-        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 128, 64>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
-        else hipLaunchKernelGGL((gemm_tile2<L2, 128, 32>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 128, 64, false>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        else hipLaunchKernelGGL((gemm_tile2<L2, 128, 32, false>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
     } else {
         const dim3 g(gm, (unsigned)((N + 63) / 64));
-        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 64, 64>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
-        else hipLaunchKernelGGL((gemm_tile2<L2, 64, 32>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        if (kc == 64) hipLaunchKernelGGL((gemm_tile2<L2, 64, 64, false>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
+        else hipLaunchKernelGGL((gemm_tile2<L2, 64, 32, false>), g, dim3(256), 0, st, L, Bm, N, ep, C, ldc);
     }
 }
 

@@ -72,6 +72,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// segment of a packed row, found by the whole wave at once when the batch is small: lane i looks at splits[i + 1] (ONE
+// coalesced load, a ballot and a popcount) instead of a binary search of log2(batch) DEPENDENT global loads -- a 1024-point
+// workgroup of the box / occupancy passes did two such searches before its first useful load (10 latencies for 32 items:
+// most of the 35-60 us these launches took in the KPConv batch build)
+__device__ __forceinline__ void seg_locate_wave(const Segs& S, int64_t packed, int& s, int64_t& local) {
+    if (!S.splits || S.batch > 64) { seg_locate(S, packed, s, local); return; }
+    const int lane = threadIdx.x & 63;
+    const int64_t e = lane < S.batch ? S.splits[lane + 1] : (int64_t)0x7fffffffffffffffll;
+    s = __popcll(__ballot(e <= packed));            // items whose end is at or before the row (empty items included)
+    s = s < S.batch ? s : S.batch - 1;
+    local = packed - S.splits[s];
+}
+
 __global__ void __launch_bounds__(256)
 grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox) {
     // A block covers 1024 consecutive packed points.  When they all belong to one batch item (the
@@ -81,8 +94,8 @@ grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox
     const int64_t first = (int64_t)blockIdx.x * 1024;
     const int64_t last = first + 1023 < n_total ? first + 1023 : n_total - 1;
     int s0, s1; int64_t l0, l1;
-    seg_locate(S, first, s0, l0);
-    seg_locate(S, last, s1, l1);
+    seg_locate_wave(S, first, s0, l0);
+    seg_locate_wave(S, last, s1, l1);
     const bool one_item = (s0 == s1);            // block-uniform
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     if (!one_item) {
@@ -94,8 +107,20 @@ grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox
             const bool valid = i < n_total;
             int s = -1; int64_t local = 0;
             float x = 0.f, y = 0.f, z = 0.f;
+            // the wave-step's first row is located by the whole wave at once; the other 63 rows start from that item and
+            // step over the (rare) boundaries instead of 64 binary searches of dependent loads -- the few workgroups
+            // that straddle items used to be the launch's critical path (35 us for 320 k points)
+            int sa; int64_t la;
+            seg_locate_wave(S, (first + it * 256 + (threadIdx.x & ~63)) < n_total ? first + it * 256 + (threadIdx.x & ~63) : n_total - 1,
+                            sa, la);
             if (valid) {
-                seg_locate(S, i, s, local);
+                s = sa;
+                if (S.splits) {
+                    while (s + 1 < S.batch && i >= S.splits[s + 1]) ++s;
+                    local = i - S.splits[s];
+                } else {
+                    seg_locate(S, i, s, local);
+                }
                 const float* p = pts + 3 * (seg_begin_global(S, s) + local);
                 x = p[0]; y = p[1]; z = p[2];
             }
@@ -210,8 +235,8 @@ grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total, const Gri
     const int64_t first = (int64_t)blockIdx.x * blockDim.x;
     const int64_t last = first + blockDim.x - 1 < n_total ? first + blockDim.x - 1 : n_total - 1;
     int s0, s1; int64_t l0, l1;
-    seg_locate(S, first, s0, l0);
-    seg_locate(S, last, s1, l1);
+    seg_locate_wave(S, first, s0, l0);
+    seg_locate_wave(S, last, s1, l1);
     const bool one_item = (s0 == s1);            // block-uniform
     if (threadIdx.x < GRID_LEVELS) cnt[threadIdx.x] = 0u;
     __syncthreads();

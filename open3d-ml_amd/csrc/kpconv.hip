@@ -190,6 +190,33 @@ __global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, co
     }
 }
 
+// the same for C % 4 == 0: a thread owns FOUR channels of one query (16-byte gathers; the neighbour index is read once per
+// four outputs instead of once per output), the query's threads are adjacent lanes reading one contiguous row
+__global__ void __launch_bounds__(256)
+gather_pool_v4(const float4* __restrict__ x, int64_t ns, int c4, const int32_t* __restrict__ inds, int64_t nq, int h, int mode,
+               float4* __restrict__ out) {
+    const int64_t total = nq * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / c4;
+        const int cq = (int)(i - q * c4);
+        const int32_t* row = inds + q * h;
+        float4 v;
+        if (mode == 1) {
+            const int idx = row[0];
+            v = (idx >= 0 && idx < ns) ? x[(int64_t)idx * c4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            v = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            for (int hh = 0; hh < h; ++hh) {
+                const int idx = row[hh];
+                const float4 xv = (idx >= 0 && idx < ns) ? x[(int64_t)idx * c4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v.x = xv.x > v.x ? xv.x : v.x; v.y = xv.y > v.y ? xv.y : v.y;
+                v.z = xv.z > v.z ? xv.z : v.z; v.w = xv.w > v.w ? xv.w : v.w;
+            }
+        }
+        out[i] = v;
+    }
+}
+
 template <int G, int J>
 static void launch_kpw(const KpArgs& a, hipStream_t st) {
     const int qw = 64 / G;
@@ -296,6 +323,13 @@ extern "C" int ml3d_gather_pool(const float* features, int64_t n_supports, int c
         return ML3D_E_INVALID;
     if (n_queries == 0) return 0;
     if (!features || !inds || !out) return ML3D_E_INVALID;
+    if ((channels & 3) == 0 && (((uintptr_t)features | (uintptr_t)out) & 15) == 0) {
+        const int64_t total = n_queries * (channels / 4);
+        unsigned nb = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+        hipLaunchKernelGGL(gather_pool_v4, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4*)features, n_supports,
+                           channels / 4, inds, n_queries, (int)max_neighbors, mode, (float4*)out);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
     int64_t total = n_queries * channels;
     unsigned nb = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     hipLaunchKernelGGL(gather_pool_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, features, n_supports, channels, inds,

@@ -26,6 +26,47 @@
 
 namespace ml3d {
 
+// A/B switches (speed, never results): every ML3D_* variable this file understands is read ONCE, at the first forward call
+// of the process; the library keeps no other state.  (The variant tests run one process per setting.)
+struct Knobs {
+    bool attn_xcd, attn_wave, attn_pf, attn_split, dec_split, dec_fc1, wave_mlp, mlp_shaped, chain_wide;
+    bool force_valu, no_fuse;         // ML3D_RANDLA_PATH = valu | unfused
+    int linear;                       // ML3D_RANDLA_LINEAR: 0 default, 1 = chain, 2 = valu
+    int attn_grid, attn16_grid, wave_mlp_grid;
+    long long fuse_rows;
+};
+static bool knob_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
+static const Knobs& knobs() {
+    static const Knobs k = [] {
+        Knobs v;
+        v.attn_xcd = !knob_off("ML3D_ATTN_XCD");
+        v.attn_wave = !knob_off("ML3D_ATTN_WAVE");
+        v.attn_pf = !knob_off("ML3D_ATTN_PF");
+        v.attn_split = !knob_off("ML3D_ATTN_SPLIT");
+        v.dec_split = !knob_off("ML3D_DEC_SPLIT");
+        v.dec_fc1 = !knob_off("ML3D_RANDLA_DEC_FC1");
+        v.wave_mlp = !knob_off("ML3D_RANDLA_WAVE_MLP");
+        v.mlp_shaped = !knob_off("ML3D_RANDLA_MLP_SHAPED");
+        const char* e = getenv("ML3D_RANDLA_CHAIN_WIDE");
+        v.chain_wide = e && e[0] == '1';
+        e = getenv("ML3D_RANDLA_PATH");
+        v.force_valu = e && e[0] == 'v';
+        v.no_fuse = e && e[0] == 'u';
+        e = getenv("ML3D_RANDLA_LINEAR");
+        v.linear = !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'v' ? 2 : 3));
+        e = getenv("ML3D_ATTN_GRID");
+        v.attn_grid = e ? atoi(e) : 2560;
+        e = getenv("ML3D_ATTN16_GRID");
+        v.attn16_grid = e ? atoi(e) : 4096;
+        e = getenv("ML3D_WAVE_MLP_GRID");
+        v.wave_mlp_grid = e ? atoi(e) : 0;
+        e = getenv("ML3D_RANDLA_FUSE_ROWS");
+        v.fuse_rows = e ? atoll(e) : 64 * 1024;
+        return v;
+    }();
+    return k;
+}
+
 constexpr int RK = 16;        // neighbours per point (num_neighbors in every reference config)
 constexpr int XROW = 20;      // LDS row pitch of the K-slab: 16 + 4 pad floats keeps b128 reads conflict-free
 constexpr int LFA_THREADS = 256;
@@ -1172,7 +1213,7 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     static const int cus = device_cu_count();
     int64_t blocks = (tiles + C::W - 1) / C::W;
     unsigned grid = (unsigned)(blocks < cus ? blocks : cus);     // one 12/16-wave workgroup per CU (LDS-bound)
-    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = knobs().attn_xcd;
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     const size_t sm = sizeof(float) * ((size_t)C::WFLOATS + (size_t)C::W * C::PATCH);
@@ -1190,17 +1231,17 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
 template <int D, int STAGE>
 static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     using C = MfmaCfg<D>;
-    static const int grid_cap = getenv("ML3D_ATTN_GRID") ? atoi(getenv("ML3D_ATTN_GRID")) : 2560;   // tuning knob
+    const int grid_cap = knobs().attn_grid;   // tuning knob
     int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
     unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
-    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = knobs().attn_xcd;
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    const bool wave_on = !(getenv("ML3D_ATTN_WAVE") && getenv("ML3D_ATTN_WAVE")[0] == '0');   // A/B knob
+    const bool wave_on = knobs().attn_wave;   // A/B knob
     if constexpr (D <= 64) {
         if (wave_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30) return launch_attn_wave<D, STAGE>(a, st);
     }
-    const bool pf_on = !(getenv("ML3D_ATTN_PF") && getenv("ML3D_ATTN_PF")[0] == '0');   // A/B knob
+    const bool pf_on = knobs().attn_pf;   // A/B knob
     if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
         size_t sm = pf_smem_bytes<D, STAGE>();
         auto go = [&](auto kern) -> int {
@@ -1417,9 +1458,9 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
 template <int STAGE>
 static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
     int64_t tiles = (a.m_total + A16_TP - 1) / A16_TP;
-    const bool xcd_on = !(getenv("ML3D_ATTN_XCD") && getenv("ML3D_ATTN_XCD")[0] == '0');
+    const bool xcd_on = knobs().attn_xcd;
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
-    static const int cap = getenv("ML3D_ATTN16_GRID") ? atoi(getenv("ML3D_ATTN16_GRID")) : 4096;
+    const int cap = knobs().attn16_grid;
     unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
     if (a.order)
@@ -1997,7 +2038,7 @@ static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream
     static const int cus = device_cu_count();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)mlp_wave<PRE>, 256, sm) != hipSuccess || occ < 1) occ = 1;
-    static const int cap_env = getenv("ML3D_WAVE_MLP_GRID") ? atoi(getenv("ML3D_WAVE_MLP_GRID")) : 0;
+    const int cap_env = knobs().wave_mlp_grid;
     const int64_t cap = cap_env > 0 ? cap_env : (int64_t)occ * cus;
     const unsigned grid = (unsigned)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
     hipLaunchKernelGGL((mlp_wave<PRE>), dim3(grid), dim3(256), sm, st, a, M);
@@ -2006,8 +2047,8 @@ static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream
 
 // multi-layer chains: the barrier-free per-wave kernel when the layers are narrow, the tile kernel otherwise
 static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
-    const bool on = !(getenv("ML3D_RANDLA_WAVE_MLP") && getenv("ML3D_RANDLA_WAVE_MLP")[0] == '0');
-    const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
+    const bool on = knobs().wave_mlp;
+    const bool shaped = knobs().mlp_shaped;
     if (a.m_total > 0 && on && shaped) {
         if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
         if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
@@ -2118,10 +2159,9 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
     // default: the register-prefetching tile GEMM of gemm.hip; A/B knobs: "chain" = single-layer launch of
     // mlp_chain_mfma (no prefetch), "valu" = the scalar kernel
-    const char* e = getenv("ML3D_RANDLA_LINEAR");
-    const bool shaped = !(getenv("ML3D_RANDLA_MLP_SHAPED") && getenv("ML3D_RANDLA_MLP_SHAPED")[0] == '0');
-    const char* fr_env = getenv("ML3D_RANDLA_FUSE_ROWS");           // (tests lower the row threshold to cover this path)
-    if (!e && shaped && !a.a1 && a.m_total >= (fr_env ? atoll(fr_env) : 64 * 1024)) {
+    const int lin_mode = knobs().linear;                  // 0 default, 1 "chain", 2 "valu"
+    const bool shaped = knobs().mlp_shaped;
+    if (lin_mode == 0 && shaped && !a.a1 && a.m_total >= knobs().fuse_rows) {     // (tests lower the row threshold)
         // narrow Linears over many rows: the barrier-free per-wave kernel with a compiled shape
         ChainArgs c = {};
         c.a0 = a.a0; c.c0 = a.c0; c.n_layers = 1;
@@ -2134,7 +2174,7 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         if (a.cout == 32 && mlp_shape_matches<ShapeLin32x32>(c)) return launch_mlp_wave_s<ShapeLin32x32, 8>(c, st);
         if (a.cout == 64 && mlp_shape_matches<ShapeLin32x64>(c)) return launch_mlp_wave_s<ShapeLin32x64, 8>(c, st);
     }
-    if (!(e && (e[0] == 'c' || e[0] == 'v')) && a.c0 + a.c1 >= 8) {
+    if (lin_mode != 1 && lin_mode != 2 && a.c0 + a.c1 >= 8) {
         RowsA A;
         A.a = a.a0; A.lda = a.c0; A.k1 = a.c0;
         A.gather = a.a1 ? a.gather : nullptr; A.gather_stride = 1; A.a_rows = a.a1_rows_per_item;
@@ -2143,7 +2183,7 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0, a.bias2};
         return gemm_rows(A, a.wt, a.m_total, a.cout, a.c0 + A.k2, ep, a.out, a.cout, nullptr, 0, st);
     }
-    if (!(e && e[0] == 'v') && a.c0 + a.c1 >= 8) {
+    if (lin_mode != 2 && a.c0 + a.c1 >= 8) {
         ChainArgs c = {};
         c.a0 = a.a0; c.c0 = a.c0; c.a1 = a.a1; c.c1 = a.a1 ? a.c1 : 0; c.gather = a.gather;
         c.rows_per_item = a.rows_per_item; c.a1_rows_per_item = a.a1_rows_per_item;
@@ -2285,11 +2325,9 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     if (workspace_bytes < ml3d_randla_forward_workspace_bytes(d)) return ML3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Tracer T = {trace, st};
-    const char* path_env = getenv("ML3D_RANDLA_PATH");          // A/B knob: "valu" forces the v1 kernels
-    const bool force_valu = path_env && path_env[0] == 'v';
-    const bool no_fuse = path_env && path_env[0] == 'u';       // "unfused": one launch per Linear
-    const char* fr_env = getenv("ML3D_RANDLA_FUSE_ROWS");      // tuning/test knob: rows from which pool2+mlp2 fuse
-    const int64_t fuse_rows = fr_env ? atoll(fr_env) : 64 * 1024;
+    const bool force_valu = knobs().force_valu;                // A/B knob ML3D_RANDLA_PATH: "valu" forces the v1 kernels,
+    const bool no_fuse = knobs().no_fuse;                      // "unfused": one launch per Linear
+    const int64_t fuse_rows = knobs().fuse_rows;               // tuning/test knob: rows from which pool2+mlp2 fuse
     const int Lr = d->num_layers;
     const int64_t B = d->batch;
     int64_t n[ML3D_RANDLA_MAX_LAYERS + 1];
@@ -2347,7 +2385,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             LfaArgs q1 = s1; q1.out = agg;
             // D >= 128: the feature half of the score Linear once per POINT (gscore = f . W_top^T, into the p2 scratch,
             // which is otherwise idle until pool2), gathered by the attention kernel instead of recomputed per neighbour
-            const bool split_on = !(getenv("ML3D_ATTN_SPLIT") && getenv("ML3D_ATTN_SPLIT")[0] == '0');
+            const bool split_on = knobs().attn_split;
             const bool split = split_on && dd >= 32 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32) &&
                                M < ((int64_t)1 << 30);
             // (the per-wave kernels of D <= 64 take the score bias inside gscore, the workgroup kernels add it themselves)
@@ -2402,7 +2440,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             ch.out = enc; ch.m_total = M;
             // (wide layers -- weights beyond the LDS image of mlp_wave -- run faster as two tile GEMMs than through the
             //  barrier-per-layer chain kernel: 0.69 -> 0.35 ms at 128 channels; ML3D_RANDLA_CHAIN_WIDE=1 restores the chain)
-            const bool chain_wide = getenv("ML3D_RANDLA_CHAIN_WIDE") && getenv("ML3D_RANDLA_CHAIN_WIDE")[0] == '1';
+            const bool chain_wide = knobs().chain_wide;
             WaveMlpMeta wm_probe;
             int pre_probe = 0;
             if (!no_fuse && M >= fuse_rows && chain_supported(ch) && (chain_wide || wave_mlp_supported(ch, &wm_probe, &pre_probe))) {
@@ -2493,7 +2531,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             ch.L[2].wt = P(slot + 4); ch.L[2].bias = P(slot + 5); ch.L[2].cin = 64; ch.L[2].cout = 32; ch.L[2].act = 1; ch.L[2].slope = 0.2f;
             ch.L[3].wt = P(slot + 6); ch.L[3].bias = P(slot + 7); ch.L[3].cin = 32; ch.L[3].cout = d->num_classes; ch.L[3].act = 0;
             ch.out = out_scores; ch.m_total = a.m_total;
-            const bool dec_fuse = !(getenv("ML3D_RANDLA_DEC_FC1") && getenv("ML3D_RANDLA_DEC_FC1")[0] == '0');
+            const bool dec_fuse = knobs().dec_fc1;
             if (dec_fuse && mlp_shape_matches<ShapeDecFc1>(ch)) {
                 T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200);
                 return rc;
@@ -2502,7 +2540,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         // W . [skip ; up[idx]] = W_skip . skip + (W_up . up)[idx]: the upsampled half is linear in a per-COARSE-point
         // quantity, computed once per coarse point (1/ratio of the rows) and added back through the interpolation index
         // as a gathered residual of the skip GEMM
-        const bool dec_split = !(getenv("ML3D_DEC_SPLIT") && getenv("ML3D_DEC_SPLIT")[0] == '0');
+        const bool dec_split = knobs().dec_split;
         if (dec_split && !force_valu && n[lev] >= 64 && (skip_c & 3) == 0 && (cprev & 3) == 0 && skip_c >= 8) {
             float* up = take(B * n[lev + 1] * skip_c);
             RowsA Au = {};

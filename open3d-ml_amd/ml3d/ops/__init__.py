@@ -190,7 +190,9 @@ def _splits(rs, n, dev):
 class _RadiusPlan:
     """Phase 1 of the fixed-radius search: grid + per-query counts (kept on the device)."""
 
-    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits):
+    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits, defer=False):
+        """``defer=True`` leaves the two sizes on the device: read them with ``resolve()`` -- or with ONE host read-back for
+        several plans through ``resolve_plans`` (the KPConv batch build has two independent searches per layer)."""
         lib = _abi.get()
         _need_gpu(points, queries)
         self.points = points.contiguous().float()
@@ -215,7 +217,15 @@ class _RadiusPlan:
                                        self.row_splits.data_ptr(), self.stats.data_ptr(), self.ws.data_ptr(), self.wsb,
                                        _stream())
         _abi.check(rc, "ml3d_radius_count")
-        self.total, self.longest = (int(x) for x in self.stats.tolist())     # the one host sync (the reference's .item())
+        self.total = self.longest = None
+        if not defer:
+            self.resolve()
+
+    def resolve(self, values=None):
+        """the one host sync of a search (the reference's ``.item()``, kpconv.py:2028) unless ``values`` are handed in"""
+        if self.total is None:
+            self.total, self.longest = (int(x) for x in (self.stats.tolist() if values is None else values))
+        return self
 
     def fill(self, dense_cols=0, pad_value=0, index_local=False, return_distances=False):
         lib = _abi.get()
@@ -240,6 +250,15 @@ class _RadiusPlan:
         return idx, d2
 
 
+def resolve_plans(*plans):
+    """One read-back for the sizes of several deferred plans (anything with ``.stats`` [2] int64 and ``.resolve``)."""
+    todo = [p for p in plans if p is not None and p.total is None]
+    if todo:
+        vals = torch.cat([p.stats for p in todo]).tolist()
+        for i, p in enumerate(todo):
+            p.resolve(vals[2 * i:2 * i + 2])
+
+
 def fixed_radius_search(points, queries, radius, points_row_splits=None, queries_row_splits=None,
                         return_distances=False):
     """Functional form of ``open3d.ml.torch.layers.FixedRadiusSearch`` (ml3d/torch/models/kpconv.py:2021-2026):
@@ -247,6 +266,27 @@ def fixed_radius_search(points, queries, radius, points_row_splits=None, queries
     plan = _RadiusPlan(points, queries, radius, points_row_splits, queries_row_splits)
     idx, d2 = plan.fill(return_distances=return_distances)
     return RadiusResult(idx, plan.row_splits, d2 if d2 is not None else torch.empty(0, device=idx.device))
+
+
+def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius):
+    """Deferred first half of ``radius_neighbors_dense``: grid + counts enqueued, sizes not read yet."""
+    dev = supports.device
+    qs = torch.zeros(len(q_lengths) + 1, dtype=torch.int64)
+    ss = torch.zeros(len(s_lengths) + 1, dtype=torch.int64)
+    qs[1:] = torch.cumsum(torch.as_tensor(q_lengths, dtype=torch.int64).cpu(), 0)
+    ss[1:] = torch.cumsum(torch.as_tensor(s_lengths, dtype=torch.int64).cpu(), 0)
+    return _RadiusPlan(supports, queries, radius, ss.to(dev), qs.to(dev), defer=True)
+
+
+def radius_fill_dense(plan, n_supports, max_cols=None):
+    """Second half: the dense int32 [Nq, longest] matrix padded with the shadow index."""
+    plan.resolve()
+    dev = plan.points.device
+    cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
+    if plan.nq == 0 or cols == 0:
+        return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
+    idx, _ = plan.fill(dense_cols=cols, pad_value=n_supports)
+    return idx
 
 
 def radius_neighbors_dense(queries, supports, q_lengths, s_lengths, radius, max_cols=None):

@@ -547,7 +547,9 @@ class KPConvBatch:
             if not ('pool' in block or 'strided' in block or 'global' in block or 'upsample' in block):
                 layer_blocks.append(block)
                 continue
-            conv_i = ops.radius_neighbors_dense(pts, pts, lens, lens, r_normal) if layer_blocks else e_i
+            # the conv search's sizes are read together with the subsample's (one host sync instead of two), the pool and
+            # upsample searches' together as well: 2 read-backs per layer
+            conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_normal) if layer_blocks else None
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / cfg['conv_radius']
                 li = len(self.points)
@@ -559,11 +561,22 @@ class KPConvBatch:
                     R = rotations[li]
                 Rt = None if R is None else torch.as_tensor(R, dtype=torch.float32).to(dev)
                 pool_p, pool_b = ops.batch_grid_subsampling(pts, lens, dl, Rt)
-                pool_lens = [int(v) for v in pool_b.tolist()]
-                pool_i = ops.radius_neighbors_dense(pool_p, pts, pool_lens, lens, r_normal)
-                up_i = ops.radius_neighbors_dense(pts, pool_p, lens, pool_lens, 2 * r_normal)
+                if conv_plan is not None:          # pooled lengths + the conv search's two sizes in one read-back
+                    vals = torch.cat([pool_b.to(torch.int64), conv_plan.stats]).tolist()
+                    pool_lens = [int(v) for v in vals[:len(lens)]]
+                    conv_plan.resolve(vals[len(lens):])
+                    conv_i = ops.radius_fill_dense(conv_plan, pts.shape[0])
+                else:
+                    pool_lens = [int(v) for v in pool_b.tolist()]
+                    conv_i = e_i
+                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_normal)
+                up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_normal)
+                ops.resolve_plans(pool_plan, up_plan)
+                pool_i = ops.radius_fill_dense(pool_plan, pts.shape[0])
+                up_i = ops.radius_fill_dense(up_plan, pool_p.shape[0])
                 self.rotations.append(R)
             else:
+                conv_i = ops.radius_fill_dense(conv_plan, pts.shape[0]) if conv_plan is not None else e_i
                 pool_p = torch.empty((0, 3), dtype=torch.float32, device=dev)
                 pool_lens, pool_i, up_i = [], e_i, e_i
             self.points.append(pts)

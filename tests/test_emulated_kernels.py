@@ -101,23 +101,49 @@ def test_randla_forward_matches_oracle(ci, B, N):
     assert np.abs(out - ref).max() <= 1e-4
 
 
+_VARIANT_CODE = r'''
+import sys
+import numpy as np
+import emu, synth_data
+from oracle import ops as oops
+from oracle import randlanet_ref as R
+import test_emulated_kernels as T
+ci, B, N, seed_pts, seed_w = (int(v) for v in sys.argv[1:6])
+cfg = T.CFGS[ci]
+pts = synth_data.uniform_cloud(seed_pts, B * N).reshape(B, N, 3)
+sd = R.make_state_dict(cfg, seed_w)
+inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
+ref = R.forward(sd, cfg, inp).numpy()
+nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
+itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
+rc, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+assert rc == 0, rc
+err = float(np.abs(out - ref).max())
+assert err <= 1e-4, err
+print("VARIANT_OK", err)
+'''
+
+
+def _run_variant(knobs, ci, B, N, seed_pts, seed_w):
+    """The library reads its ML3D_* A/B switches once per process (randla.hip: knobs()), so every setting gets its own
+    interpreter."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    env = dict(os.environ, **knobs)
+    env["PYTHONPATH"] = os.pathsep.join([here, root, os.path.join(root, "open3d-ml_amd")])
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CODE, str(ci), str(B), str(N), str(seed_pts), str(seed_w)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("ci,B,N", [(0, 2, 1024), (2, 3, 1100)])
-def test_randla_forward_fused_and_unfused_linear_chains_agree(monkeypatch, ci, B, N):
+def test_randla_forward_fused_and_unfused_linear_chains_agree(ci, B, N):
     """pool2.mlp + (mlp2 | shortcut) as one 2-layer chain launch (large levels) vs one launch per Linear; with the row
     threshold at 1 the shape-compiled per-wave kernels (incl. decoder-last + fc1) run at these small sizes too."""
-    cfg = CFGS[ci]
-    pts = synth_data.uniform_cloud(4, B * N).reshape(B, N, 3)
-    sd = R.make_state_dict(cfg, 12)
-    inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
-    ref = R.forward(sd, cfg, inp).numpy()
-    nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
-    itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
-    monkeypatch.setenv("ML3D_RANDLA_FUSE_ROWS", "1")
-    rc, fused = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
-    assert rc == 0 and np.abs(fused - ref).max() <= 1e-4
-    monkeypatch.setenv("ML3D_RANDLA_PATH", "unfused")
-    rc, unfused = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
-    assert rc == 0 and np.abs(unfused - ref).max() <= 1e-4
+    _run_variant({"ML3D_RANDLA_FUSE_ROWS": "1"}, ci, B, N, 4, 12)
+    _run_variant({"ML3D_RANDLA_FUSE_ROWS": "1", "ML3D_RANDLA_PATH": "unfused"}, ci, B, N, 4, 12)
 
 
 @pytest.mark.parametrize("knobs", [
@@ -130,21 +156,9 @@ def test_randla_forward_fused_and_unfused_linear_chains_agree(monkeypatch, ci, B
     {"ML3D_RANDLA_WAVE_MLP": "0", "ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # barrier-per-layer chain kernel
     {"ML3D_ATTN_XCD": "0"},                                      # plain tile order
 ])
-def test_randla_forward_kernel_variants_agree_with_oracle(monkeypatch, knobs):
+def test_randla_forward_kernel_variants_agree_with_oracle(knobs):
     """Every A/B knob selects a different kernel for the same math: each variant must meet the same 1e-4 gate."""
-    cfg = CFGS[0]
-    B, N = 2, 1024
-    pts = synth_data.uniform_cloud(9, B * N).reshape(B, N, 3)
-    sd = R.make_state_dict(cfg, 13)
-    inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
-    ref = R.forward(sd, cfg, inp).numpy()
-    nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
-    itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    rc, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
-    assert rc == 0
-    assert np.abs(out - ref).max() <= 1e-4
+    _run_variant(knobs, 0, 2, 1024, 9, 13)
 
 
 def test_tile_order_is_a_cloud_major_spatial_permutation():
