@@ -76,6 +76,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // coalesced load, a ballot and a popcount) instead of a binary search of log2(batch) DEPENDENT global loads -- a 1024-point
 // workgroup of the box / occupancy passes did two such searches before its first useful load (10 latencies for 32 items:
 // most of the 35-60 us these launches took in the KPConv batch build)
+// (first, last) rows of a workgroup located from ONE load of the splits: no second dependent access for the item starts
+__device__ __forceinline__ void seg_locate_wave2(const Segs& S, int64_t r0, int64_t r1, int& s0, int64_t& l0, int& s1, int64_t& l1) {
+    if (!S.splits || S.batch > 63) { seg_locate(S, r0, s0, l0); seg_locate(S, r1, s1, l1); return; }
+    const int lane = threadIdx.x & 63;
+    const int64_t e = lane <= S.batch ? S.splits[lane] : (int64_t)0x7fffffffffffffffll;      // lane i: START of item i (i = batch: total)
+    // item of a row = (number of starts <= row) - 1, clamped to the last item; empty items share their start with the next
+    const int c0 = __popcll(__ballot(lane <= S.batch && e <= r0)), c1 = __popcll(__ballot(lane <= S.batch && e <= r1));
+    s0 = min(max(c0 - 1, 0), S.batch - 1);
+    s1 = min(max(c1 - 1, 0), S.batch - 1);
+    l0 = r0 - __shfl(e, s0);
+    l1 = r1 - __shfl(e, s1);
+}
+
 __device__ __forceinline__ void seg_locate_wave(const Segs& S, int64_t packed, int& s, int64_t& local) {
     if (!S.splits || S.batch > 64) { seg_locate(S, packed, s, local); return; }
     const int lane = threadIdx.x & 63;
@@ -94,8 +107,7 @@ grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox
     const int64_t first = (int64_t)blockIdx.x * 1024;
     const int64_t last = first + 1023 < n_total ? first + 1023 : n_total - 1;
     int s0, s1; int64_t l0, l1;
-    seg_locate_wave(S, first, s0, l0);
-    seg_locate_wave(S, last, s1, l1);
+    seg_locate_wave2(S, first, last, s0, l0, s1, l1);
     const bool one_item = (s0 == s1);            // block-uniform
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     if (!one_item) {
@@ -136,23 +148,53 @@ grid_bbox(const float* __restrict__ pts, Segs S, int64_t n_total, unsigned* bbox
                         }
                     }
                 }
-            } else if (valid) {
-                atomicMin(&bbox[6 * s + 0], f2ord(x)); atomicMax(&bbox[6 * s + 3], f2ord(x));
-                atomicMin(&bbox[6 * s + 1], f2ord(y)); atomicMax(&bbox[6 * s + 4], f2ord(y));
-                atomicMin(&bbox[6 * s + 2], f2ord(z)); atomicMax(&bbox[6 * s + 5], f2ord(z));
+            } else {
+                // several items in one wave-step (short items: the coarse levels of a KPConv batch): the lanes of an item are
+                // contiguous, so a SEGMENTED reduction (shuffle down while the partner is in the same item) leaves each
+                // item's box in its first lane -- 6 atomics per item and wave-step, not 6 per point (7800 atomics on 192
+                // words made the 1300-point levels as slow as the 320 k-point one)
+                const int lane = threadIdx.x & 63;
+                const int sv = valid ? s : -2 - lane;               // idle lanes: items of their own
+                float lo[3] = {x, y, z}, hi[3] = {x, y, z};
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int so = __shfl_down(sv, o);
+                    float l2[3], h2[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { l2[a] = __shfl_down(lo[a], o); h2[a] = __shfl_down(hi[a], o); }
+                    // contiguous items: if the lane `o` further on is in my item, so is everything in between
+                    if (lane + o < 64 && so == sv) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], l2[a]); hi[a] = fmaxf(hi[a], h2[a]); }
+                    }
+                }
+                const int sp = __shfl_up(sv, 1);
+                if (valid && (lane == 0 || sp != sv)) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        atomicMin(&bbox[6 * s + a], f2ord(lo[a]));
+                        atomicMax(&bbox[6 * s + 3 + a], f2ord(hi[a]));
+                    }
+                }
             }
         }
         return;
     }
     {
-        int64_t i = first + threadIdx.x;
-        for (int it = 0; it < 4; ++it, i += 256) {
-            if (i >= n_total) break;
-            const float* p = pts + 3 * (seg_begin_global(S, s0) + l0 + (i - first));
-            const float x = p[0], y = p[1], z = p[2];
-            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
-            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
-            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        // the item's rows are contiguous: row (first + j) of the block is point (global start of the item + l0 + j).  The four
+        // strided loads per lane are requested together (clamped index, masked use): one exposed latency, not four
+        const float* base = pts + 3 * (S.splits ? first : (int64_t)s0 * S.stride + l0);
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int64_t j = min((int64_t)(threadIdx.x + 256 * it), last - first);
+            x[it] = base[3 * j]; y[it] = base[3 * j + 1]; z[it] = base[3 * j + 2];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            mn[0] = fminf(mn[0], x[it]); mx[0] = fmaxf(mx[0], x[it]);
+            mn[1] = fminf(mn[1], y[it]); mx[1] = fmaxf(mx[1], y[it]);
+            mn[2] = fminf(mn[2], z[it]); mx[2] = fmaxf(mx[2], z[it]);
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -48,26 +48,44 @@ __device__ __forceinline__ float kp_influence(float d2, const KpArgs& A) {
     return expf(-d2 / A.gauss_den);
 }
 
+typedef float kp_v2f __attribute__((ext_vector_type(2)));
+
+// the influences of TWO kernel points at once on packed f32 (v_pk_add / v_pk_mul / v_pk_fma): the 15 x (3 sub, 3 mul, 2 add,
+// sqrt, fma, max) per (query, neighbour) pair are 40 % of the gather kernel's instructions
+__device__ __forceinline__ kp_v2f kp_influence2(kp_v2f dx, kp_v2f dy, kp_v2f dz, const KpArgs& A) {
+    const kp_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+    if (A.influence == 0) return (kp_v2f){1.0f, 1.0f};
+    if (A.influence == 1) {
+        const kp_v2f d = (kp_v2f){sqrtf(d2.x), sqrtf(d2.y)};
+        const kp_v2f w = __builtin_elementwise_fma(d, (kp_v2f){-A.inv_extent, -A.inv_extent}, (kp_v2f){1.0f, 1.0f});
+        return (kp_v2f){w.x > 0.f ? w.x : 0.f, w.y > 0.f ? w.y : 0.f};
+    }
+    return (kp_v2f){expf(-d2.x / A.gauss_den), expf(-d2.y / A.gauss_den)};
+}
+
 // G lanes per query (G in {16, 32, 64}); a wave serves 64 / G queries; J = channels per lane.
 template <int G, int J>
 __global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
     constexpr int QW = 64 / G;
     __shared__ __attribute__((aligned(16))) float W[4][QW][KP_HC][KP_WP];
     __shared__ int NI[4][QW][KP_HC];
-    __shared__ float KPs[KP_K * 3];
+    __shared__ float KPs[KP_WP * 3];                 // x[16] | y[16] | z[16]; the sixteenth point is padding
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < KP_K * 3) KPs[tid] = A.kp[tid];
+    if (tid < KP_WP * 3) KPs[tid] = (tid % KP_WP) < KP_K ? A.kp[3 * (tid % KP_WP) + tid / KP_WP] : 0.f;
     __syncthreads();
     const int qi = lane / G, cg = lane % G;
     const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * QW;   // first query of this wave
     if (q0 >= A.nq) return;                                      // wave-uniform, no block barrier below
     const int64_t q = q0 + qi;
     const bool q_ok = q < A.nq;
-    float acc[KP_K][J];
+    // accumulators as PAIRS of kernel points (v_pk_fma_f32: two multiply-adds per lane and instruction -- the f32 matrix
+    // rate without the MFMA's 16 / 32-row granularity; the sixteenth slot of the last pair is padding, never stored)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc[KP_WP / 2][J];
 #pragma unroll
-    for (int k = 0; k < KP_K; ++k)
+    for (int k = 0; k < KP_WP / 2; ++k)
 #pragma unroll
-        for (int j = 0; j < J; ++j) acc[k][j] = 0.f;
+        for (int j = 0; j < J; ++j) acc[k][j] = (v2f){0.f, 0.f};
 
     for (int h0 = 0; h0 < A.h; h0 += KP_HC) {
         // ---- phase 1: influence weights of the chunk's (query, neighbour) pairs -> LDS -------------------
@@ -85,11 +103,14 @@ __global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
                 const float* sp = A.s_pts + 3 * (int64_t)idx;
                 const float* qp = A.q_pts + 3 * qq;
                 const float nx = sp[0] - qp[0], ny = sp[1] - qp[1], nz = sp[2] - qp[2];
+                const kp_v2f* kx = reinterpret_cast<const kp_v2f*>(KPs);
+                const kp_v2f* ky = reinterpret_cast<const kp_v2f*>(KPs + KP_WP);
+                const kp_v2f* kz = reinterpret_cast<const kp_v2f*>(KPs + 2 * KP_WP);
+                kp_v2f* wrow = reinterpret_cast<kp_v2f*>(&W[wave][pq][ph][0]);
 #pragma unroll
-                for (int k = 0; k < KP_K; ++k) {
-                    const float dx = nx - KPs[3 * k], dy = ny - KPs[3 * k + 1], dz = nz - KPs[3 * k + 2];
-                    W[wave][pq][ph][k] = kp_influence(dx * dx + dy * dy + dz * dz, A);
-                }
+                for (int k = 0; k < KP_WP / 2; ++k)
+                    wrow[k] = kp_influence2((kp_v2f){nx, nx} - kx[k], (kp_v2f){ny, ny} - ky[k], (kp_v2f){nz, nz} - kz[k], A);
+                W[wave][pq][ph][KP_K] = 0.f;                     // the padding slot of the last pair
             }
         }
         wave_sync();
@@ -108,12 +129,12 @@ __global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
                 }
                 const float4* wp = reinterpret_cast<const float4*>(&W[wave][qi][ph][0]);
                 const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-                const float wk[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                const v2f wk[8] = {(v2f){w0.x, w0.y}, (v2f){w0.z, w0.w}, (v2f){w1.x, w1.y}, (v2f){w1.z, w1.w},
+                                   (v2f){w2.x, w2.y}, (v2f){w2.z, w2.w}, (v2f){w3.x, w3.y}, (v2f){w3.z, w3.w}};
 #pragma unroll
-                for (int k = 0; k < KP_K; ++k)
+                for (int k = 0; k < KP_WP / 2; ++k)
 #pragma unroll
-                    for (int j = 0; j < J; ++j) acc[k][j] = fmaf(wk[k], xv[j], acc[k][j]);
+                    for (int j = 0; j < J; ++j) acc[k][j] = __builtin_elementwise_fma(wk[k], (v2f){xv[j], xv[j]}, acc[k][j]);
             }
         }
         wave_sync();
@@ -125,7 +146,7 @@ __global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int c = cg + j * G;
-                if (c < A.cin) o[k * A.cin + c] = acc[k][j];
+                if (c < A.cin) o[k * A.cin + c] = (k & 1) ? acc[k >> 1][j].y : acc[k >> 1][j].x;
             }
     }
 }
