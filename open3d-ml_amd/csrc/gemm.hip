@@ -491,7 +491,10 @@ static int big_bn(int64_t M, int N, int K, const float* Bm, const Epilogue& ep) 
     // ML3D_GEMM_BIG_MIN_TILES (read once, at the first call): workgroups below which gemm_tile keeps the problem; the
     // emulator tests set 1 to push small problems through this kernel, A/B runs a huge value to switch it off
     static const int64_t min_tiles = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_TILES"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
-    if ((N & 3) || (K % GM_KC) != 0 || (((uintptr_t)Bm) & 15) != 0 || ep.res_gather) return 0;
+    // shallow K (RandLA's per-point Linears, K = 32 .. 128): one or two chunks -- nothing to pipeline, and the 64-register
+    // accumulator block makes prologue + epilogue the whole kernel; they stay on gemm_tile.  ML3D_GEMM_BIG_MIN_K (read once).
+    static const int min_k = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_K"); return e ? atoi(e) : 256; }();
+    if ((N & 3) || (K % GM_KC) != 0 || K < min_k || (((uintptr_t)Bm) & 15) != 0 || ep.res_gather) return 0;
     const int64_t rows = (M + G2_BM - 1) / G2_BM;
     if (N > 64 && rows * ((N + 127) / 128) >= 2 * min_tiles) return 128;
     if (rows * ((N + 63) / 64) >= min_tiles) return (N > 64 && rows * ((N + 127) / 128) >= min_tiles) ? 128 : 64;

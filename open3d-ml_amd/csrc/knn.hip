@@ -205,8 +205,8 @@ struct KnnJobs {
 };
 
 #ifndef KNN_WAVES
-#define KNN_WAVES 0
-#endif
+#define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
+#endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
 template <int K, bool SUB>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0

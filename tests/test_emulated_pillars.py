@@ -86,7 +86,7 @@ def _run_in_subprocess_with_big_gemm(code):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
-    env = dict(os.environ, ML3D_GEMM_BIG_MIN_TILES="1",
+    env = dict(os.environ, ML3D_GEMM_BIG_MIN_TILES="1", ML3D_GEMM_BIG_MIN_K="0",
                PYTHONPATH=os.pathsep.join([here, root, os.path.join(root, "open3d-ml_amd")]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
