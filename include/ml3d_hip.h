@@ -72,8 +72,13 @@ int ml3d_knn_search(const float* points, const int64_t* points_row_splits,
 /* index_local != 0.                                                           */
 /*  count: builds the grid in `workspace`, writes neighbors_row_splits         */
 /*         int64[n_queries + 1] and out_stats int64[2] = {total, longest row}. */
-/*  fill : must get the SAME workspace contents back (grown to                 */
-/*         ml3d_radius_workspace_bytes(.., total) if the grid part is copied). */
+/*         The scan of the counts is int32: 2^31 or more neighbours in one     */
+/*         call set out_stats[1] = 2^63 (an impossible row length) -- callers   */
+/*         must treat that as ML3D_E_UNSUPPORTED and split the batch.           */
+/*  fill : must get the SAME workspace (address and contents) back.  Rows      */
+/*         longer than the LDS buffer sort in `spill` (>= 8 * total + 8 bytes); */
+/*         spill == NULL puts that scratch at the tail of a workspace of       */
+/*         ml3d_radius_workspace_bytes(.., total) bytes instead.               */
 /*         dense_cols == 0 -> ragged out_index[total];                         */
 /*         dense_cols  > 0 -> the ragged_to_dense of kpconv.py:2030-2032 fused */
 /*         in: out_index[n_queries, dense_cols], rows truncated / padded with  */
@@ -93,7 +98,8 @@ int ml3d_radius_fill(const float* points, const int64_t* points_row_splits,
                      int64_t batch, int64_t n_points, int64_t n_queries, float radius,
                      const int64_t* row_splits, int64_t total_neighbors, int index_local,
                      int64_t dense_cols, int32_t pad_value, int32_t* out_index, float* out_dist2,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     void* workspace, size_t workspace_bytes, void* spill, size_t spill_bytes,
+                     void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* ragged_to_dense — replaces open3d.ml.torch.ops.ragged_to_dense              */

@@ -542,7 +542,12 @@ static bool gemm_launch_big(const ConvLoader& L, const float* Bm, int N, const E
 
 static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
                             hipStream_t st) {
-    const int bn = big_bn(L.M, N, L.K, Bm, ep);
+    // Row-major (Linear) problems stay on gemm_tile unless ML3D_GEMM_BIG_ROWS=1 (read once): measured on all three workloads
+    // (profiles/r02_gemm_ab.log) the 128-row kernel LOSES there -- RandLA 5657 vs 5787 frames/s, KPConv 2753 vs 2796 spheres/s,
+    // PointPillars 1137 vs 1165 frames/s: the Linears have K <= 1024 with an A operand that is read once (no 9-tap reuse out
+    // of L2 as in the convolutions), so the deeper register block buys nothing and its lower occupancy costs.
+    static const bool rows_on = [] { const char* e = getenv("ML3D_GEMM_BIG_ROWS"); return e ? atoi(e) != 0 : false; }();
+    const int bn = rows_on ? big_bn(L.M, N, L.K, Bm, ep) : 0;
     if (!bn || !L.vec) return false;
     // a chunk may straddle the boundary of the two concatenated operands only at a multiple of 4 (float4 loads): any KC works
     launch_big(L, Bm, N, bn, big_kc(L.K, 0, bn), ep, C, ldc, st);

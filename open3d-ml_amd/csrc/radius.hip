@@ -104,7 +104,13 @@ __global__ void radius_splits(const int* __restrict__ c, int64_t nq, int64_t* __
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long len = 0ull;
     if (i <= nq) row_splits[i] = (int64_t)c[i];
-    if (i < nq) len = (unsigned long long)(c[i + 1] - c[i]);
+    if (i < nq) {
+        // the scan runs in int32: 2^31 neighbours or more wrap it, which shows as a DECREASE somewhere along the scanned
+        // counts (every per-query count is < 2^31).  Flag it -- stats[1] = 2^63: the host sees an impossible longest row and
+        // raises instead of sizing its buffers from a wrapped total.
+        if (c[i + 1] < c[i]) atomicMax(&stats[1], 1ull << 63);
+        else len = (unsigned long long)(c[i + 1] - c[i]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {       // wave max, one atomic per wave
         unsigned long long other = __shfl_xor(len, o);
@@ -276,15 +282,21 @@ extern "C" int ml3d_radius_fill(const float* points, const int64_t* points_row_s
                                 const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
                                 int64_t n_queries, float radius, const int64_t* row_splits, int64_t total_neighbors,
                                 int index_local, int64_t dense_cols, int32_t pad_value, int32_t* out_index,
-                                float* out_dist2, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* out_dist2, void* workspace, size_t workspace_bytes, void* spill,
+                                size_t spill_bytes, void* stream) {
     int rc = rad_args(points, points_row_splits, queries, queries_row_splits, batch, n_points, n_queries, radius);
     if (rc) return rc;
     if (!row_splits || total_neighbors < 0 || dense_cols < 0) return ML3D_E_INVALID;
     if (n_queries == 0) return 0;
     if (!out_index) return ML3D_E_INVALID;
-    if (workspace_bytes < ml3d_radius_workspace_bytes(n_points, n_queries, batch, total_neighbors)) return ML3D_E_WORKSPACE;
+    // rows longer than the LDS buffer are sorted in a u64[total] scratch: the caller's `spill` when it hands one in (so the
+    // workspace that carries the grid never has to grow or move between the two phases), else the tail of the workspace
+    if (spill ? spill_bytes < sizeof(u64) * (size_t)total_neighbors + 8
+              : workspace_bytes < ml3d_radius_workspace_bytes(n_points, n_queries, batch, total_neighbors))
+        return ML3D_E_WORKSPACE;
     RadWs W;
     if (!rad_carve(workspace, workspace_bytes, n_points, n_queries, batch, &W)) return ML3D_E_WORKSPACE;
+    if (spill) W.spill = (u64*)(((uintptr_t)spill + 7) & ~(uintptr_t)7);
     hipStream_t st = (hipStream_t)stream;
     RadArgs A;
     A.G = grid_view(W.grid);

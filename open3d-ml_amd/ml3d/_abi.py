@@ -93,7 +93,7 @@ def bind(lib):
     lib.ml3d_radius_count.restype = C.c_int
     lib.ml3d_radius_count.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_radius_fill.restype = C.c_int
-    lib.ml3d_radius_fill.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, i64, i32, i64, C.c_int32, vp, vp, vp, sz, vp]
+    lib.ml3d_radius_fill.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, i64, i32, i64, C.c_int32, vp, vp, vp, sz, vp, sz, vp]
     lib.ml3d_ragged_to_dense.restype = C.c_int
     lib.ml3d_ragged_to_dense.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
     lib.ml3d_voxelize_workspace_bytes.restype = sz

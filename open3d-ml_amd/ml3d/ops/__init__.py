@@ -225,18 +225,16 @@ class _RadiusPlan:
         """the one host sync of a search (the reference's ``.item()``, kpconv.py:2028) unless ``values`` are handed in"""
         if self.total is None:
             self.total, self.longest = (int(x) for x in (self.stats.tolist() if values is None else values))
+            if self.longest < 0 or self.longest >= 2 ** 62:       # the library's overflow flag (int32 scan of the counts wrapped)
+                raise RuntimeError("fixed_radius_search: 2^31 or more neighbours in one call (unsupported): split the batch")
         return self
 
     def fill(self, dense_cols=0, pad_value=0, index_local=False, return_distances=False):
         lib = _abi.get()
         dev = self.points.device
-        if self.total > self.ws_total:       # grow: the grid part of the workspace is relocatable
-            wsb = lib.ml3d_radius_workspace_bytes(self.ns, self.nq, self.batch, self.total)
-            ws = _ws(wsb, dev)
-            ws[:self.wsb].copy_(self.ws)
-            if (ws.data_ptr() - self.ws.data_ptr()) % 256:
-                raise RuntimeError("fixed_radius_search: allocator returned a differently aligned workspace")
-            self.ws, self.wsb, self.ws_total = ws, wsb, self.total
+        # the workspace that carries the grid goes back in untouched; when the result is larger than the spill area it was
+        # sized for, long rows sort in a separate buffer (no relocation of the grid -- ml3d_hip.h, ml3d_radius_fill)
+        spill = _ws(8 * self.total + 8, dev) if self.total > self.ws_total else None
         shape = (self.nq, int(dense_cols)) if dense_cols > 0 else (self.total,)
         idx = torch.empty(shape, dtype=torch.int32, device=dev)
         d2 = torch.empty(shape, dtype=torch.float32, device=dev) if return_distances else None
@@ -245,7 +243,8 @@ class _RadiusPlan:
                                       self.qrs.data_ptr(), self.batch, self.ns, self.nq, self.radius,
                                       self.row_splits.data_ptr(), self.total, 1 if index_local else 0, int(dense_cols),
                                       int(pad_value), idx.data_ptr(), d2.data_ptr() if d2 is not None else None,
-                                      self.ws.data_ptr(), self.wsb, _stream())
+                                      self.ws.data_ptr(), self.wsb, spill.data_ptr() if spill is not None else None,
+                                      8 * self.total + 8 if spill is not None else 0, _stream())
         _abi.check(rc, "ml3d_radius_fill")
         return idx, d2
 

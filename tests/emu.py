@@ -119,7 +119,7 @@ def _ws(nbytes):
     return np.zeros(int(nbytes) + 64, np.uint8)
 
 
-def radius(points, psplits, queries, qsplits, r, dense=False, local=False, with_d2=False):
+def radius(points, psplits, queries, qsplits, r, dense=False, local=False, with_d2=False, spill_phase=0):
     """-> (neighbors_index, row_splits[, d2]) ragged, or the dense [Nq, max] matrix padded with Ns."""
     L = lib()
     points = np.ascontiguousarray(points, np.float32)
@@ -136,18 +136,15 @@ def radius(points, psplits, queries, qsplits, r, dense=False, local=False, with_
     assert rc == 0, rc
     total, longest = int(stats[0]), int(stats[1])
     assert total == rs[-1]
-    wsb2 = L.ml3d_radius_workspace_bytes(ns, nq, B, total)
-    ws2 = _ws(wsb2)
     cols = longest if dense else 0
     idx = np.full((nq, cols) if dense else (total,), -5, np.int32)
     d2 = np.zeros(idx.shape, np.float32) if with_d2 else None
-    # count again into the larger buffer (a fresh numpy buffer may have a different 256-byte phase)
-    rc = L.ml3d_radius_count(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
-                             rs.ctypes.data, stats.ctypes.data, ws2.ctypes.data, wsb2, None)
-    assert rc == 0, rc
+    # the workspace of the count phase (it carries the grid) goes back in untouched; long rows sort in a separate spill buffer
+    spill = np.zeros(total + 2, np.uint64)
     rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
                             rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
-                            None if d2 is None else d2.ctypes.data, ws2.ctypes.data, wsb2, None)
+                            None if d2 is None else d2.ctypes.data, ws.ctypes.data, wsb, spill.ctypes.data + spill_phase,
+                            8 * total + 8, None)
     assert rc == 0, rc
     if dense:
         return idx

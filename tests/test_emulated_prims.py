@@ -47,6 +47,32 @@ def test_radius_rows_longer_than_the_lds_stage_spill_correctly():
     assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
 
 
+def test_radius_spill_buffer_is_separate_from_the_grid_workspace():
+    """the fill phase gets the count phase's workspace back untouched (sized for ZERO neighbours) and a separate spill buffer
+    at an arbitrary 8-byte phase: no relocation of the grid, whatever the result size (ml3d_hip.h, ml3d_radius_fill)"""
+    p = (_cloud(4, 700) * 0.1).astype(np.float32)
+    ref = oops.fixed_radius_search(p, p[:30], 1.0)
+    for phase in (0, 8):
+        idx, rs = emu.radius(p, [0, 700], p[:30], [0, 30], 1.0, spill_phase=phase)
+        assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
+
+
+def test_radius_overflow_flag_raises_on_the_host():
+    """2^31 neighbours wrap the int32 scan: the library flags it in stats[1] (radius.hip, radius_splits) and the host wrapper
+    raises instead of sizing buffers from the wrapped total (checked on the host logic; 2^31 pairs do not fit a unit test)"""
+    import pytest
+    from ml3d.ops import _RadiusPlan
+    plan = _RadiusPlan.__new__(_RadiusPlan)
+    plan.total = plan.longest = None
+    with pytest.raises(RuntimeError, match="2\\^31"):
+        plan.resolve(values=(12345, 1 << 63))
+    plan.total = plan.longest = None
+    with pytest.raises(RuntimeError, match="2\\^31"):
+        plan.resolve(values=(12345, -(1 << 63)))          # the same flag read back as a signed int64
+    plan.total = plan.longest = None
+    assert plan.resolve(values=(7, 3)).total == 7
+
+
 def test_radius_dense_is_batch_neighbors_of_the_reference():
     # kpconv.py:2002-2034: ragged_to_dense(idx, splits, max_nbrs, default = Ns)
     p = _cloud(4, 2500, "surf")

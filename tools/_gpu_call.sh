@@ -1,12 +1,20 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2u
-LIB=open3d-ml_amd/ml3d/lib
-cp $LIB/libml3d_hip.so /tmp/base.so
+mkdir -p gpurun_out/r2v
+rm -f gpurun_out/r2v/ab2.log
 for rep in 1 2; do
-for v in base knn_w6g2 knn_w6 knn_g2; do
-  if [ "$v" = base ]; then cp /tmp/base.so $LIB/libml3d_hip.so; else cp $LIB/variants/$v.so $LIB/libml3d_hip.so; fi
-  echo "== $v $(timeout 120 python tools/knn_only.py 7 2>&1 | grep knn_only)" >> gpurun_out/r2u/abl.log
+for e in "ML3D_GEMM_BIG_ROWS=0" "ML3D_GEMM_BIG_ROWS=1"; do
+  env $e timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-workloads 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('$e randla frames/s %.0f median %.3f' % (d['value'], d['step_ms_median']))" >> gpurun_out/r2v/ab2.log
 done
 done
-cp /tmp/base.so $LIB/libml3d_hip.so
-cat gpurun_out/r2u/abl.log
+for rep in 1 2 3; do
+for e in "ML3D_GEMM_BIG_ROWS=0" "ML3D_GEMM_BIG_ROWS=1" "ML3D_GEMM_BIG_ROWS=1 ML3D_GEMM_BIG_MIN_K=0"; do
+  env $e timeout 300 python bench.py --workload kpconv --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('$e kpconv spheres/s %.0f block %.3f ms frac %.3f' % (d['value'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))" >> gpurun_out/r2v/ab2.log
+done
+done
+for e in "ML3D_GEMM_BIG_ROWS=0" "ML3D_GEMM_BIG_ROWS=1"; do
+  env $e timeout 300 python bench.py --workload pointpillars --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('$e pointpillars frames/s %.0f' % d['value'])" >> gpurun_out/r2v/ab2.log
+done
+cat gpurun_out/r2v/ab2.log
