@@ -29,10 +29,10 @@ namespace ml3d {
 // A/B switches (speed, never results): every ML3D_* variable this file understands is read ONCE, at the first forward call
 // of the process; the library keeps no other state.  (The variant tests run one process per setting.)
 struct Knobs {
-    bool attn_xcd, attn_wave, attn_pf, attn_split, dec_split, dec_fc1, wave_mlp, mlp_shaped, chain_wide;
+    bool attn_xcd, attn_split, dec_split, dec_fc1, mlp_shaped;
     bool force_valu, no_fuse;         // ML3D_RANDLA_PATH = valu | unfused
-    int linear;                       // ML3D_RANDLA_LINEAR: 0 default, 1 = chain, 2 = valu
-    int attn_grid, attn16_grid, wave_mlp_grid;
+    int linear;                       // ML3D_RANDLA_LINEAR: 0 default, 2 = valu
+    int attn_grid, attn16_grid;
     long long fuse_rows;
 };
 static bool knob_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
@@ -40,26 +40,19 @@ static const Knobs& knobs() {
     static const Knobs k = [] {
         Knobs v;
         v.attn_xcd = !knob_off("ML3D_ATTN_XCD");
-        v.attn_wave = !knob_off("ML3D_ATTN_WAVE");
-        v.attn_pf = !knob_off("ML3D_ATTN_PF");
         v.attn_split = !knob_off("ML3D_ATTN_SPLIT");
         v.dec_split = !knob_off("ML3D_DEC_SPLIT");
         v.dec_fc1 = !knob_off("ML3D_RANDLA_DEC_FC1");
-        v.wave_mlp = !knob_off("ML3D_RANDLA_WAVE_MLP");
         v.mlp_shaped = !knob_off("ML3D_RANDLA_MLP_SHAPED");
-        const char* e = getenv("ML3D_RANDLA_CHAIN_WIDE");
-        v.chain_wide = e && e[0] == '1';
-        e = getenv("ML3D_RANDLA_PATH");
+        const char* e = getenv("ML3D_RANDLA_PATH");
         v.force_valu = e && e[0] == 'v';
         v.no_fuse = e && e[0] == 'u';
         e = getenv("ML3D_RANDLA_LINEAR");
-        v.linear = !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'v' ? 2 : 3));
+        v.linear = (e && e[0] == 'v') ? 2 : 0;
         e = getenv("ML3D_ATTN_GRID");
         v.attn_grid = e ? atoi(e) : 2560;
         e = getenv("ML3D_ATTN16_GRID");
         v.attn16_grid = e ? atoi(e) : 4096;
-        e = getenv("ML3D_WAVE_MLP_GRID");
-        v.wave_mlp_grid = e ? atoi(e) : 0;
         e = getenv("ML3D_RANDLA_FUSE_ROWS");
         v.fuse_rows = e ? atoll(e) : 64 * 1024;
         return v;
@@ -108,7 +101,7 @@ __global__ void __launch_bounds__(256) linear_act(LinArgs A) {
 #pragma unroll
     for (int r = 0; r < LIN_RM; ++r) {
         int64_t m = m0 + r < A.m_total ? m0 + r : A.m_total - 1;
-        acc[r] = A.bias2 ? A.bias[o] + A.bias2[o] : A.bias[o];
+        acc[r] = (A.bias ? A.bias[o] : 0.f) + (A.bias2 ? A.bias2[o] : 0.f);
         r0[r] = A.a0 + m * A.c0;
         r1[r] = nullptr;
         if (A.a1) {
@@ -475,164 +468,6 @@ __device__ __forceinline__ void softmax_wsum8(const ACC& sc, int o /* 0 or 8 */,
     num = ag + __shfl_xor(ag, 32);
     den = sum + __shfl_xor(sum, 32);
 }
-
-template <int D, int STAGE>
-__global__ void __launch_bounds__((MfmaCfg<D>::THREADS), (D <= 64 ? 3 : (MfmaCfg<D>::THREADS / 256))) lfa_attn_mfma(LfaArgs A) {
-    using C = MfmaCfg<D>;
-    constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, RP = C::RP, THREADS = C::THREADS;
-    HIP_DYNAMIC_SHARED(float, smem)
-    float* X = smem;                                              // [ROWS][XP]
-    float* R1 = X + ROWS * XP;                                    // [ROWS][RP]   (stage 2, unless in place)
-    float* REL = R1 + ((STAGE == 2 && !C::INPLACE) ? ROWS * RP : 0);   // [ROWS][12]
-    int* NROW = reinterpret_cast<int*>(REL + ROWS * 12);          // [ROWS]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, col = lane & 31;
-
-    // ---- weights that stay in registers for the whole kernel ---------------------------------
-    const int ct = wave % C::NT, rg = wave / C::NT;
-    float bs[D / 2];
-#pragma unroll
-    for (int s = 0; s < D / 2; ++s) bs[s] = A.score_wt[(hi * (D / 2) + s) * D + ct * 32 + col];
-    const float sbias = A.score_b[ct * 32 + col];
-    const int ct2 = wave % C::NT2, rg2 = wave / C::NT2;
-    const int col2 = ct2 * 32 + col;
-    float b2[STAGE == 2 ? H / 2 : 1];
-    float l2bias = 0.f;
-    if constexpr (STAGE == 2) {
-#pragma unroll
-        for (int s = 0; s < H / 2; ++s) b2[s] = col2 < H ? A.lse2_wt[(hi * (H / 2) + s) * H + col2] : 0.f;
-        l2bias = col2 < H ? A.lse2_b[col2] : 0.f;
-    }
-    // lse1 (10 -> H) also runs on MFMA: K padded to 12, split 6 + 6 between the wave halves
-    float w1b[6];
-#pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6) {
-        const int kk = hi * 6 + s6;
-        w1b[s6] = (kk < 10 && col2 < H) ? A.lse1_wt[kk * H + col2] : 0.f;
-    }
-    const float b1 = col2 < H ? A.lse1_b[col2] : 0.f;
-
-    const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
-    const bool xw = A.xcd_chunk > 0;
-    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
-    for (int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;; wi += w_step) {
-        int64_t tile = wi;
-        if (xw) {
-            tile = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
-            if (tile < 0) break;
-            if (tile >= tiles) continue;
-        } else if (tile >= tiles) break;
-        const int64_t m_base = tile * C::TP;
-        // ---- P1: relative-position inputs + neighbour rows -------------------------------------
-        for (int e = tid; e < ROWS; e += THREADS) {
-            int p = e / RK, k = e % RK;
-            int64_t m = m_base + p;
-            float* r = REL + e * 12;
-            if (m < A.m_total) {
-                int64_t b = m / A.n, nl = m - b * A.n;
-                int nb = A.nidx[m * RK + k];
-                const float* q = A.xyz + 3 * (b * A.n0 + nl);
-                const float* sp = A.xyz + 3 * (b * A.n0 + nb);
-                float qx = q[0], qy = q[1], qz = q[2], sx = sp[0], sy = sp[1], sz = sp[2];
-                float dx = qx - sx, dy = qy - sy, dz = qz - sz;
-                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
-                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
-                NROW[e] = (int)(b * A.n + nb);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 10; ++j) r[j] = 0.f;
-                NROW[e] = 0;
-            }
-            r[10] = 0.f; r[11] = 0.f;                              // K padding of the lse1 MFMA
-        }
-        SYNC_ATTN();
-        // ---- P2a: gather neighbour feature rows (16-byte bursts) -> X[:, 0:H] ---------------------
-        for (int e = tid; e < ROWS * (H / 4); e += THREADS) {
-            int row = e / (H / 4), q = e % (H / 4);
-            float4 v = *reinterpret_cast<const float4*>(A.gfeat + (int64_t)NROW[row] * H + 4 * q);
-            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = v;
-        }
-        // ---- P2b: r1 = lrelu(lse1(rel)) on MFMA (K = 12) -> X[:, H:] (stage 1) or R1 (stage 2) -------
-        for (int rt = rg2; rt < C::RT; rt += C::RG2) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = b1;
-            const float* ar = REL + (rt * 32 + col) * 12 + hi * 6;
-            const float2 a01 = *reinterpret_cast<const float2*>(ar);
-            const float2 a23 = *reinterpret_cast<const float2*>(ar + 2);
-            const float2 a45 = *reinterpret_cast<const float2*>(ar + 4);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, w1b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, w1b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, w1b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, w1b[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, w1b[4], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, w1b[5], acc, 0, 0, 0);
-            if (col2 < H) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + mfma_row(r, hi);
-                    const float v = lrelu(acc[r], 0.2f);
-                    if (STAGE == 1 || C::INPLACE) X[row * XP + H + col2] = v; else R1[row * RP + col2] = v;
-                }
-            }
-        }
-        SYNC_ATTN();
-        if constexpr (STAGE == 2) {
-            // ---- P2c: r2 = lrelu(lse2(r1)) on MFMA -> X[:, H:] -------------------------------------
-            for (int rt = rg2; rt < C::RT; rt += C::RG2) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = l2bias;
-                if constexpr (C::INPLACE) acc = mfma_rows<H, XP>(X + (rt * 32 + col) * XP + H + hi * (H / 2), b2, acc);
-                else acc = mfma_rows<H, RP>(R1 + (rt * 32 + col) * RP + hi * (H / 2), b2, acc);
-                if (col2 < H) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        X[(rt * 32 + mfma_row(r, hi)) * XP + H + col2] = lrelu(acc[r], 0.2f);
-                }
-            }
-            SYNC_ATTN();
-        }
-        // ---- P3: scores on MFMA, softmax over the 16 neighbours, weighted sum ----------------------
-        for (int rt = rg; rt < C::RT; rt += C::RG) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = sbias;
-            const float* xc = X + (rt * 32) * XP + ct * 32 + col;
-            acc = mfma_rows<D, XP>(X + (rt * 32 + col) * XP + hi * (D / 2), bs, acc);
-            float agg_mine = 0.f;
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                float mx = acc[8 * pt];
-#pragma unroll
-                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[8 * pt + r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float sum = 0.f, ag = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float e = __expf(acc[8 * pt + r] - mx);
-                    sum += e;
-                    ag = fmaf(e, xc[mfma_row(8 * pt + r, hi) * XP], ag);
-                }
-                sum += __shfl_xor(sum, 32);
-                ag += __shfl_xor(ag, 32);
-                if (pt == hi) agg_mine = ag / sum;
-            }
-            int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0, half 1 point 1
-            if (m < A.m_total) A.out[m * D + ct * 32 + col] = agg_mine;
-        }
-        SYNC_ATTN();
-    }
-}
-
-template <int D, int STAGE>
-static size_t mfma_smem_bytes() {
-    using C = MfmaCfg<D>;
-    return ((size_t)C::ROWS * C::XP + ((STAGE == 2 && !C::INPLACE) ? (size_t)C::ROWS * C::RP : 0) + (size_t)C::ROWS * 12) * 4 +
-           (size_t)C::ROWS * 4;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // lfa_attn_pf — the same attention stage with the NEXT tile's global traffic in flight under the
@@ -1227,23 +1062,26 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     return a.order ? go(lfa_attn_wave<D, STAGE, false, true>) : go(lfa_attn_wave<D, STAGE, false, false>);
 }
 
-// launches the attention part of one stage; `a.out` receives agg [m, D]
+// launches the attention part of one stage; `a.out` receives agg [m, D].  D <= 64: the per-wave kernel, D >= 128: the
+// workgroup-tile prefetching kernel.  (Preconditions -- 32-bit point indices, at least one full tile per cloud -- are checked
+// by the caller, which sends everything else to the generic VALU kernel lfa_stage.)
+template <int D>
+static bool attn_mfma_fits(const LfaArgs& a) {
+    return a.m_total < ((int64_t)1 << 30) && a.n0 < ((int64_t)1 << 30) && (D <= 64 || a.n >= MfmaCfg<D>::TP);
+}
+
 template <int D, int STAGE>
 static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
-    using C = MfmaCfg<D>;
-    const int grid_cap = knobs().attn_grid;   // tuning knob
-    int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
-    unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
-    const bool xcd_on = knobs().attn_xcd;
-    a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
-    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    const bool wave_on = knobs().attn_wave;   // A/B knob
     if constexpr (D <= 64) {
-        if (wave_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30) return launch_attn_wave<D, STAGE>(a, st);
-    }
-    const bool pf_on = knobs().attn_pf;   // A/B knob
-    if (pf_on && a.m_total < (int64_t)1 << 30 && a.n0 < (int64_t)1 << 30 && a.n >= C::TP) {
-        size_t sm = pf_smem_bytes<D, STAGE>();
+        return launch_attn_wave<D, STAGE>(a, st);
+    } else {
+        using C = MfmaCfg<D>;
+        const int grid_cap = knobs().attn_grid;   // tuning knob
+        int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
+        unsigned grid = (unsigned)(tiles < grid_cap ? tiles : grid_cap);   // persistent-ish: weights load once per block
+        a.xcd_chunk = knobs().attn_xcd ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+        if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+        const size_t sm = pf_smem_bytes<D, STAGE>();
         auto go = [&](auto kern) -> int {
             if (sm > 48 * 1024 &&
                 hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
@@ -1251,18 +1089,9 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), sm, st, a);
             return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
         };
-        if constexpr (D >= 128) {
-            if (a.gscore) return a.order ? go(lfa_attn_pf<D, STAGE, true, true>) : go(lfa_attn_pf<D, STAGE, true, false>);
-        }
-        if (a.order) return go(lfa_attn_pf<D, STAGE, false, true>);
-        return go(lfa_attn_pf<D, STAGE, false, false>);
+        if (a.gscore) return a.order ? go(lfa_attn_pf<D, STAGE, true, true>) : go(lfa_attn_pf<D, STAGE, true, false>);
+        return a.order ? go(lfa_attn_pf<D, STAGE, false, true>) : go(lfa_attn_pf<D, STAGE, false, false>);
     }
-    size_t sm = mfma_smem_bytes<D, STAGE>();
-    if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)lfa_attn_mfma<D, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL((lfa_attn_mfma<D, STAGE>), dim3(grid), dim3(C::THREADS), sm, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
 
@@ -1471,19 +1300,13 @@ static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// mlp_chain_mfma — up to 4 per-point Linear(+folded BN)+activation layers back to back on
-// v_mfma_f32_32x32x2_f32.  A workgroup owns 64 rows; the first layer streams its input rows from
-// HBM in K-chunks of 32 (optionally [a0 | a1[gather]] = nearest_interpolation + cat of the decoder,
-// randlanet.py:288-291), intermediate activations stay in LDS, only the last layer's output is
-// written.  One optional extra input `cat` is appended to the input of layer `cat_layer`
-// (mlp2(p2) + shortcut(feat) = one Linear over [p2 | feat], randlanet.py:692).
-// HBM traffic = first-layer inputs + last-layer outputs (+ weights from L2).
+// Per-point MLP chains: up to 4 Linear(+folded BN)+activation layers back to back, intermediate activations in LDS.
+// First-layer input rows may be [a0 | a1[gather]] (nearest_interpolation + cat of the decoder, randlanet.py:288-291); one
+// optional extra input `cat` is appended to the input of layer `cat_layer` (mlp2(p2) + shortcut(feat) = one Linear over
+// [p2 | feat], randlanet.py:692).  Chains run fused only when their shape has a compiled mlp_wave_s instance below; every
+// other shape runs one tile GEMM (gemm.hip) per Linear.
 // ------------------------------------------------------------------------------------------------
 constexpr int CH_MAX = 4;
-constexpr int CH_BM = 64;      // rows per workgroup
-constexpr int CH_KC = 32;      // K chunk
-constexpr int CH_AP = CH_KC + 4;
-constexpr int CH_BN = 64;      // columns per pass (2 MFMA column tiles)
 
 struct ChainLayer {
     const float* wt;     // [cin][cout]
@@ -1504,148 +1327,9 @@ struct ChainArgs {
     ChainLayer L[CH_MAX];
     float* out;
     int64_t m_total;
-    int act_pitch;       // floats, LDS pitch of the intermediate activations (max width + 4)
-    int n_act_buf;       // 0, 1 or 2
 };
 
-__global__ void __launch_bounds__(256) mlp_chain_mfma(ChainArgs A) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    float* As = smem;                               // [64][CH_AP]
-    float* Bs = As + CH_BM * CH_AP;                 // [CH_KC][CH_BN]
-    float* ACT0 = Bs + CH_KC * CH_BN;               // [64][act_pitch]
-    float* ACT1 = ACT0 + (A.n_act_buf > 1 ? CH_BM * A.act_pitch : 0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, cl = lane & 31;
-    const int rt = wave & 1, ctw = wave >> 1;
-    const int64_t m_base = (int64_t)blockIdx.x * CH_BM;
-
-    for (int li = 0; li < A.n_layers; ++li) {
-        const ChainLayer Ly = A.L[li];
-        const float* act_in = (li & 1) ? ACT0 : ACT1;       // layer li reads what layer li-1 wrote
-        float* act_out = (li & 1) ? ACT1 : ACT0;
-        if (A.n_act_buf < 2) { act_in = ACT0; act_out = ACT0; }
-        const bool last = (li == A.n_layers - 1);
-        const int prev_c = li == 0 ? 0 : A.L[li - 1].cout;
-        const int n_pass = (Ly.cout + CH_BN - 1) / CH_BN;
-        // single-layer launches spread the column passes over blockIdx.y
-        const int p_begin = A.n_layers == 1 ? blockIdx.y : 0;
-        const int p_step = A.n_layers == 1 ? gridDim.y : 1;
-        for (int cp = p_begin; cp < n_pass; cp += p_step) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int k0 = 0; k0 < Ly.cin; k0 += CH_KC) {
-                // ---- stage A chunk [64][32] ---------------------------------------------------
-                for (int e = tid; e < CH_BM * (CH_KC / 4); e += 256) {
-                    int row = e / (CH_KC / 4), q = e % (CH_KC / 4);
-                    int k = k0 + 4 * q;
-                    int64_t m = m_base + row;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < A.m_total && k < Ly.cin) {
-                        if (li == 0) {
-                            if (k < A.c0) {
-                                v = *reinterpret_cast<const float4*>(A.a0 + m * A.c0 + k);
-                            } else {
-                                int64_t grow = m;
-                                if (A.gather) grow = (m / A.rows_per_item) * A.a1_rows_per_item + A.gather[m];
-                                v = *reinterpret_cast<const float4*>(A.a1 + grow * A.c1 + (k - A.c0));
-                            }
-                        } else if (k < prev_c) {
-                            v = *reinterpret_cast<const float4*>(act_in + row * A.act_pitch + k);
-                        } else {
-                            v = *reinterpret_cast<const float4*>(A.cat + m * A.cat_c + (k - prev_c));
-                        }
-                    }
-                    *reinterpret_cast<float4*>(As + row * CH_AP + 4 * q) = v;
-                }
-                // ---- stage B chunk [32][64] ---------------------------------------------------
-                for (int e = tid; e < CH_KC * CH_BN; e += 256) {
-                    int kk = e / CH_BN, c = e % CH_BN;
-                    int k = k0 + kk, col = cp * CH_BN + c;
-                    Bs[e] = (k < Ly.cin && col < Ly.cout) ? Ly.wt[(int64_t)k * Ly.cout + col] : 0.f;
-                }
-                __syncthreads();
-                const float* ar = As + (rt * 32 + cl) * CH_AP + hi * (CH_KC / 2);
-                const float* br = Bs + (hi * (CH_KC / 2)) * CH_BN + ctw * 32 + cl;
-#pragma unroll
-                for (int s4 = 0; s4 < CH_KC / 8; ++s4) {
-                    float4 a = *reinterpret_cast<const float4*>(ar + 4 * s4);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, br[(4 * s4 + 0) * CH_BN], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, br[(4 * s4 + 1) * CH_BN], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, br[(4 * s4 + 2) * CH_BN], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, br[(4 * s4 + 3) * CH_BN], acc, 0, 0, 0);
-                }
-                __syncthreads();
-            }
-            // ---- epilogue ---------------------------------------------------------------------
-            const int col = cp * CH_BN + ctw * 32 + cl;
-            if (col < Ly.cout) {
-                float b = Ly.bias[col];
-                if (Ly.bias2) b += Ly.bias2[col];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = rt * 32 + mfma_row(r, hi);
-                    float v = acc[r] + b;
-                    if (Ly.act) v = lrelu(v, Ly.slope);
-                    if (last) {
-                        int64_t m = m_base + row;
-                        if (m < A.m_total) A.out[m * Ly.cout + col] = v;
-                    } else {
-                        act_out[row * A.act_pitch + col] = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-static bool chain_supported(const ChainArgs& a) {
-    if (a.n_layers < 1 || a.n_layers > CH_MAX) return false;
-    if ((a.c0 & 3) || (a.a1 && (a.c1 & 3)) || (a.cat && (a.cat_c & 3))) return false;
-    for (int i = 0; i + 1 < a.n_layers; ++i)
-        if (a.L[i].cout & 3) return false;
-    return true;
-}
-
-static int launch_chain(ChainArgs a, hipStream_t st) {
-    if (a.m_total <= 0) return 0;
-    int maxw = 0;
-    for (int i = 0; i + 1 < a.n_layers; ++i) maxw = a.L[i].cout > maxw ? a.L[i].cout : maxw;
-    a.act_pitch = maxw + 4;
-    a.n_act_buf = a.n_layers == 1 ? 0 : (a.n_layers == 2 ? 1 : 2);
-    size_t sm = ((size_t)CH_BM * CH_AP + (size_t)CH_KC * CH_BN + (size_t)a.n_act_buf * CH_BM * a.act_pitch) * 4;
-    if (sm > 160 * 1024) return ML3D_E_UNSUPPORTED;
-    if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)mlp_chain_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    unsigned gx = (unsigned)((a.m_total + CH_BM - 1) / CH_BM);
-    unsigned gy = a.n_layers == 1 ? (unsigned)((a.L[0].cout + CH_BN - 1) / CH_BN) : 1u;
-    hipLaunchKernelGGL(mlp_chain_mfma, dim3(gx, gy), dim3(256), sm, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// mlp_wave — narrow per-point MLP chains (layer inputs <= 96 wide, hidden outputs <= 64, all weights
-// <= 20k floats: fc1 32->64->32->19, pool2 + (mlp2 | shortcut) of the first two encoder layers) with
-// NO workgroup barrier in the row loop.  All layers' weights (zero-padded to 32-column tiles) sit in
-// LDS for the whole persistent kernel; each WAVE owns 32-row tiles end to end: its input rows go
-// HBM -> registers (requested one tile ahead) -> a wave-private LDS patch, every layer's MFMAs read A
-// from the patch (ds_read_b128) and B from the weight image, a layer's 32 x N result goes to the
-// wave's second patch (plus the `cat` columns of the next layer), and only the last layer's rows
-// are written to HBM.  K loops are runtime loops over LDS, so the kernel stays at a few dozen VGPRs
-// and many waves per SIMD hide each other's latencies.
-// ------------------------------------------------------------------------------------------------
-struct WaveMlpMeta {                         // host-computed LDS layout (floats)
-    int w_off[CH_MAX], npad[CH_MAX], b_off[CH_MAX];
-    int patch_off;                           // per wave: [32][pit0] then [32][pit1]
-    int pit0, pit1;
-    int total;
-};
-
-// one 32x32 output tile's K loop with compile-time trip count and weight pitch (mlp_wave)
+// one 32x32 output tile's K loop with compile-time trip count and weight pitch
 template <int KH, int NP>
 __device__ __forceinline__ f32x16 wave_k_loop(const float* __restrict__ arow, const float* __restrict__ Bc, f32x16 acc) {
 #pragma unroll
@@ -1659,160 +1343,6 @@ __device__ __forceinline__ f32x16 wave_k_loop(const float* __restrict__ arow, co
     __builtin_amdgcn_iglp_opt(0);
     return acc;
 }
-
-template <int PRE>                           // float4 loads per lane for one tile of first-layer input rows
-__global__ void __launch_bounds__(256, 2) mlp_wave(ChainArgs A, WaveMlpMeta M) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, cl = lane & 31;
-    for (int l = 0; l < A.n_layers; ++l) {
-        const ChainLayer Ly = A.L[l];
-        const int np = M.npad[l];
-#pragma unroll 8
-        for (int e = tid; e < Ly.cin * np; e += 256) {
-            const int k = e / np, c = e - k * np;
-            smem[M.w_off[l] + e] = c < Ly.cout ? Ly.wt[(int64_t)k * Ly.cout + c] : 0.f;
-        }
-        for (int c = tid; c < np; c += 256) {
-            float b = 0.f;
-            if (c < Ly.cout) { if (Ly.bias) b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
-            smem[M.b_off[l] + c] = b;
-        }
-    }
-    __syncthreads();
-    float* P0 = smem + M.patch_off + wave * 32 * (M.pit0 + M.pit1);
-    float* P1 = P0 + 32 * M.pit0;
-    const int64_t tiles = (A.m_total + 31) / 32;
-    const int64_t t_step = (int64_t)gridDim.x * 4;
-    const int K0 = A.L[0].cin, Q0 = K0 >> 2;            // float4 pieces per row
-
-    float4 pre[PRE];
-    auto fetch0 = [&](int64_t t) {
-#pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int e = lane + 64 * i;
-            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < 32 * Q0) {
-                const int r = e / Q0, k = (e - r * Q0) * 4;
-                const int64_t m = t * 32 + r;
-                if (m < A.m_total) {
-                    if (k < A.c0) pre[i] = *reinterpret_cast<const float4*>(A.a0 + m * A.c0 + k);
-                    else {
-                        int64_t grow = m;
-                        if (A.gather) grow = (m / A.rows_per_item) * A.a1_rows_per_item + A.gather[m];
-                        pre[i] = *reinterpret_cast<const float4*>(A.a1 + grow * A.c1 + (k - A.c0));
-                    }
-                }
-            }
-        }
-    };
-    int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    if (t < tiles) fetch0(t);
-    for (; t < tiles; t += t_step) {
-        // ---- this tile's input rows: registers -> patch 0; next tile's rows requested ---------------------
-#pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int e = lane + 64 * i;
-            if (e < 32 * Q0) {
-                const int r = e / Q0, k = (e - r * Q0) * 4;
-                *reinterpret_cast<float4*>(P0 + r * M.pit0 + k) = pre[i];
-            }
-        }
-        if (t + t_step < tiles) fetch0(t + t_step);
-        wave_lds_sync();
-        const int64_t m_row0 = t * 32;
-        for (int l = 0; l < A.n_layers; ++l) {
-            const ChainLayer Ly = A.L[l];
-            const float* in = (l & 1) ? P1 : P0;
-            float* outp = (l & 1) ? P0 : P1;
-            const int pin = (l & 1) ? M.pit1 : M.pit0, pout = (l & 1) ? M.pit0 : M.pit1;
-            const int KH = Ly.cin >> 1, np = M.npad[l];
-            const bool last = l == A.n_layers - 1;
-            const float* arow = in + cl * pin + hi * KH;
-            const float* W = smem + M.w_off[l] + (hi * KH) * np + cl;
-            for (int ct = 0; ct * 32 < np; ++ct) {
-                f32x16 acc;
-                const float b = smem[M.b_off[l] + ct * 32 + cl];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = b;
-                const float* Bc = W + ct * 32;
-                // the shapes of the shipped configs get fully unrolled K loops (straight-line code lets the scheduler
-                // run the LDS reads ahead of the MFMAs); anything else takes the runtime loop
-                switch (KH * 1024 + np) {
-                    case 8 * 1024 + 32: acc = wave_k_loop<8, 32>(arow, Bc, acc); break;
-                    case 12 * 1024 + 32: acc = wave_k_loop<12, 32>(arow, Bc, acc); break;
-                    case 16 * 1024 + 32: acc = wave_k_loop<16, 32>(arow, Bc, acc); break;
-                    case 16 * 1024 + 64: acc = wave_k_loop<16, 64>(arow, Bc, acc); break;
-                    case 32 * 1024 + 32: acc = wave_k_loop<32, 32>(arow, Bc, acc); break;
-                    case 32 * 1024 + 64: acc = wave_k_loop<32, 64>(arow, Bc, acc); break;
-                    case 48 * 1024 + 128: acc = wave_k_loop<48, 128>(arow, Bc, acc); break;
-                    default:
-                        for (int s4 = 0; s4 < KH; s4 += 4) {
-                            const float4 a = *reinterpret_cast<const float4*>(arow + s4);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Bc[(s4 + 0) * np], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Bc[(s4 + 1) * np], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, Bc[(s4 + 2) * np], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, Bc[(s4 + 3) * np], acc, 0, 0, 0);
-                        }
-                }
-                const int col = ct * 32 + cl;
-                if (col < Ly.cout) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = mfma_row(r, hi);
-                        float v = acc[r];
-                        if (Ly.act) v = lrelu(v, Ly.slope);
-                        if (last) {
-                            const int64_t m = m_row0 + row;
-                            if (m < A.m_total) A.out[m * Ly.cout + col] = v;
-                        } else {
-                            outp[row * pout + col] = v;
-                        }
-                    }
-                }
-            }
-            if (!last) {
-                if (A.cat && l + 1 == A.cat_layer) {            // the next layer's extra input columns
-                    const int qc = A.cat_c >> 2;
-                    for (int e = lane; e < 32 * qc; e += 64) {
-                        const int r = e / qc, k = (e - r * qc) * 4;
-                        const int64_t m = m_row0 + r;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (m < A.m_total) v = *reinterpret_cast<const float4*>(A.cat + m * A.cat_c + k);
-                        *reinterpret_cast<float4*>(outp + r * pout + Ly.cout + k) = v;
-                    }
-                }
-                wave_lds_sync();
-            }
-        }
-        wave_lds_sync();          // patch 0 is rewritten at the top of the next tile
-    }
-}
-
-static bool wave_mlp_supported(const ChainArgs& a, WaveMlpMeta* M, int* pre) {
-    if (!chain_supported(a)) return false;
-    int off = 0, w0 = 0, w1 = 0;
-    for (int l = 0; l < a.n_layers; ++l) {
-        const ChainLayer& Ly = a.L[l];
-        if (Ly.cin > 96 || Ly.cout > 128) return false;
-        if (l + 1 < a.n_layers && Ly.cout > 64) return false;
-        int& wd = (l & 1) ? w1 : w0;
-        wd = Ly.cin > wd ? Ly.cin : wd;
-        M->npad[l] = (Ly.cout + 31) & ~31;
-        M->w_off[l] = off; off += Ly.cin * M->npad[l];
-        M->b_off[l] = off; off += M->npad[l];
-    }
-    for (int l = a.n_layers; l < CH_MAX; ++l) { M->npad[l] = 0; M->w_off[l] = 0; M->b_off[l] = 0; }
-    if (off > 20 * 1024) return false;
-    M->pit0 = w0 + 4;
-    M->pit1 = (w1 > 0 ? w1 : 4) + 4;
-    M->patch_off = (off + 3) & ~3;
-    M->total = M->patch_off + 4 * 32 * (M->pit0 + M->pit1);
-    const int need = (32 * (a.L[0].cin / 4) + 63) / 64;
-    *pre = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 12));
-    return need <= 12;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // mlp_wave_s — mlp_wave with the chain's SHAPE as a compile-time parameter, for the shapes RandLA-Net ships
@@ -2027,46 +1557,22 @@ static int launch_mlp_wave_s(const ChainArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
-template <int PRE>
-static int launch_wave_mlp_t(const ChainArgs& a, const WaveMlpMeta& M, hipStream_t st) {
-    const size_t sm = sizeof(float) * (size_t)M.total;
-    if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)mlp_wave<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    const int64_t tiles = (a.m_total + 31) / 32;
-    // persistent: exactly the resident workgroups, so the weight image is staged once per CU slot
-    static const int cus = device_cu_count();
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)mlp_wave<PRE>, 256, sm) != hipSuccess || occ < 1) occ = 1;
-    const int cap_env = knobs().wave_mlp_grid;
-    const int64_t cap = cap_env > 0 ? cap_env : (int64_t)occ * cus;
-    const unsigned grid = (unsigned)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
-    hipLaunchKernelGGL((mlp_wave<PRE>), dim3(grid), dim3(256), sm, st, a, M);
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+// multi-layer chains run fused iff their shape has a compiled per-wave instance (callers fall back to one Linear per layer)
+static bool chain_compiled(const ChainArgs& a) {
+    if (a.m_total <= 0 || !knobs().mlp_shaped) return false;
+    return mlp_shape_matches<ShapeDecFc1>(a) || mlp_shape_matches<ShapeFc1>(a) || mlp_shape_matches<ShapeEnc64>(a) ||
+           mlp_shape_matches<ShapeEnc16>(a);
 }
 
-// multi-layer chains: the barrier-free per-wave kernel when the layers are narrow, the tile kernel otherwise
 static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
-    const bool on = knobs().wave_mlp;
-    const bool shaped = knobs().mlp_shaped;
-    if (a.m_total > 0 && on && shaped) {
-        if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
-        if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
-        if (mlp_shape_matches<ShapeEnc64>(a)) return launch_mlp_wave_s<ShapeEnc64, 4>(a, st);
-        if (mlp_shape_matches<ShapeEnc16>(a)) return launch_mlp_wave_s<ShapeEnc16, 8>(a, st);
-    }
-    WaveMlpMeta M;
-    int pre = 0;
-    if (a.m_total > 0 && on && wave_mlp_supported(a, &M, &pre)) {
-        if (pre == 2) return launch_wave_mlp_t<2>(a, M, st);
-        if (pre == 4) return launch_wave_mlp_t<4>(a, M, st);
-        if (pre == 8) return launch_wave_mlp_t<8>(a, M, st);
-        return launch_wave_mlp_t<12>(a, M, st);
-    }
-    return launch_chain(a, st);
+    if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
+    if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
+    if (mlp_shape_matches<ShapeEnc64>(a)) return launch_mlp_wave_s<ShapeEnc64, 4>(a, st);
+    if (mlp_shape_matches<ShapeEnc16>(a)) return launch_mlp_wave_s<ShapeEnc16, 8>(a, st);
+    return ML3D_E_UNSUPPORTED;
 }
 
-// one Linear described by LinArgs: MFMA chain kernel when the shapes allow, VALU kernel otherwise
+// one Linear described by LinArgs: a shape-compiled per-wave kernel or the tile GEMM; the VALU kernel for K < 8
 static int launch_linear_auto(const LinArgs& a, hipStream_t st);
 
 template <int D, int STAGE>
@@ -2157,9 +1663,8 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 }
 
 static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
-    // default: the register-prefetching tile GEMM of gemm.hip; A/B knobs: "chain" = single-layer launch of
-    // mlp_chain_mfma (no prefetch), "valu" = the scalar kernel
-    const int lin_mode = knobs().linear;                  // 0 default, 1 "chain", 2 "valu"
+    // default: the register-prefetching tile GEMM of gemm.hip; ML3D_RANDLA_LINEAR=valu forces the scalar kernel
+    const int lin_mode = knobs().linear;                  // 0 default, 2 "valu"
     const bool shaped = knobs().mlp_shaped;
     if (lin_mode == 0 && shaped && !a.a1 && a.m_total >= knobs().fuse_rows) {     // (tests lower the row threshold)
         // narrow Linears over many rows: the barrier-free per-wave kernel with a compiled shape
@@ -2174,7 +1679,7 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         if (a.cout == 32 && mlp_shape_matches<ShapeLin32x32>(c)) return launch_mlp_wave_s<ShapeLin32x32, 8>(c, st);
         if (a.cout == 64 && mlp_shape_matches<ShapeLin32x64>(c)) return launch_mlp_wave_s<ShapeLin32x64, 8>(c, st);
     }
-    if (lin_mode != 1 && lin_mode != 2 && a.c0 + a.c1 >= 8) {
+    if (lin_mode != 2 && a.c0 + a.c1 >= 8) {
         RowsA A;
         A.a = a.a0; A.lda = a.c0; A.k1 = a.c0;
         A.gather = a.a1 ? a.gather : nullptr; A.gather_stride = 1; A.a_rows = a.a1_rows_per_item;
@@ -2182,16 +1687,6 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         A.gather_on_a2 = 1; A.g_rows_per_item = a.rows_per_item; A.g_src_rows_per_item = a.a1_rows_per_item;
         Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0, a.bias2};
         return gemm_rows(A, a.wt, a.m_total, a.cout, a.c0 + A.k2, ep, a.out, a.cout, nullptr, 0, st);
-    }
-    if (lin_mode != 2 && a.c0 + a.c1 >= 8) {
-        ChainArgs c = {};
-        c.a0 = a.a0; c.c0 = a.c0; c.a1 = a.a1; c.c1 = a.a1 ? a.c1 : 0; c.gather = a.gather;
-        c.rows_per_item = a.rows_per_item; c.a1_rows_per_item = a.a1_rows_per_item;
-        c.n_layers = 1;
-        c.L[0].wt = a.wt; c.L[0].bias = a.bias; c.L[0].bias2 = a.bias2; c.L[0].cin = a.c0 + c.c1; c.L[0].cout = a.cout;
-        c.L[0].act = a.act; c.L[0].slope = a.slope;
-        c.out = a.out; c.m_total = a.m_total;
-        if (chain_supported(c)) return launch_chain(c, st);
     }
     return launch_linear(a, st);
 }
@@ -2377,8 +1872,9 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         s2.feat_in = feat; s2.out = enc;
         int rc = 0;
         // (the MFMA kernels keep point indices in 32 bits; a > 2^30-point batch level takes the generic VALU kernel)
-        const bool mfma_ok = (dd == 16 || dd == 32 || dd == 64 || dd == 128 || dd == 256) && !force_valu &&
-                             (dd != 16 || (M < ((int64_t)1 << 30) && s1.n0 < ((int64_t)1 << 30)));
+        const bool mfma_ok = !force_valu && (dd == 16 ? attn_mfma_fits<16>(s1) : dd == 32 ? attn_mfma_fits<32>(s1) :
+                                             dd == 64 ? attn_mfma_fits<64>(s1) : dd == 128 ? attn_mfma_fits<128>(s1) :
+                                             dd == 256 ? attn_mfma_fits<256>(s1) : false);
         if (mfma_ok) {
             float* agg = take(M * dd);
             float* p2 = take(M * dd);
@@ -2438,12 +1934,9 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             ch.L[1].wt = P(sb + 14); ch.L[1].bias = P(sb + 16); ch.L[1].bias2 = P(sb + 17);
             ch.L[1].cin = dd + d_in; ch.L[1].cout = 2 * dd; ch.L[1].act = 1; ch.L[1].slope = 0.01f;
             ch.out = enc; ch.m_total = M;
-            // (wide layers -- weights beyond the LDS image of mlp_wave -- run faster as two tile GEMMs than through the
-            //  barrier-per-layer chain kernel: 0.69 -> 0.35 ms at 128 channels; ML3D_RANDLA_CHAIN_WIDE=1 restores the chain)
-            const bool chain_wide = knobs().chain_wide;
-            WaveMlpMeta wm_probe;
-            int pre_probe = 0;
-            if (!no_fuse && M >= fuse_rows && chain_supported(ch) && (chain_wide || wave_mlp_supported(ch, &wm_probe, &pre_probe))) {
+            // (fused when the shape has a compiled per-wave instance: the first two encoder layers of every reference
+            //  config; wide layers run faster as two tile GEMMs than through any chain kernel: 0.69 -> 0.35 ms at 128 channels)
+            if (!no_fuse && M >= fuse_rows && chain_compiled(ch)) {
                 T.begin(8 * l + 5); rc = launch_chain_auto(ch, st); T.end(8 * l + 5); if (rc) return rc;
             } else {
                 {
@@ -2532,7 +2025,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             ch.L[3].wt = P(slot + 6); ch.L[3].bias = P(slot + 7); ch.L[3].cin = 32; ch.L[3].cout = d->num_classes; ch.L[3].act = 0;
             ch.out = out_scores; ch.m_total = a.m_total;
             const bool dec_fuse = knobs().dec_fc1;
-            if (dec_fuse && mlp_shape_matches<ShapeDecFc1>(ch)) {
+            if (dec_fuse && knobs().mlp_shaped && mlp_shape_matches<ShapeDecFc1>(ch)) {
                 T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200);
                 return rc;
             }
@@ -2574,7 +2067,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         ch.L[1].wt = P(slot + 2); ch.L[1].bias = P(slot + 3); ch.L[1].cin = 64; ch.L[1].cout = 32; ch.L[1].act = 1; ch.L[1].slope = 0.2f;
         ch.L[2].wt = P(slot + 4); ch.L[2].bias = P(slot + 5); ch.L[2].cin = 32; ch.L[2].cout = d->num_classes; ch.L[2].act = 0;
         ch.out = out_scores; ch.m_total = B * n[0];
-        if (!no_fuse && !force_valu && chain_supported(ch)) {
+        if (!no_fuse && !force_valu && chain_compiled(ch)) {
             // fc1.0 -> fc1.1 -> fc1.3 back to back: the 64- and 32-wide activations never leave LDS
             T.begin(1200); int rc = launch_chain_auto(ch, st); T.end(1200); if (rc) return rc;
         } else {

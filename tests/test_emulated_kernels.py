@@ -148,12 +148,10 @@ def test_randla_forward_fused_and_unfused_linear_chains_agree(ci, B, N):
 
 @pytest.mark.parametrize("knobs", [
     {"ML3D_ATTN_SPLIT": "0"},                                    # score Linear un-split (gathered features through the MFMAs)
-    {"ML3D_ATTN_WAVE": "0"},                                     # D <= 64 on the workgroup-tile prefetching kernel
-    {"ML3D_ATTN_WAVE": "0", "ML3D_ATTN_PF": "0"},                # the round's first attention kernel (reference path)
-    {"ML3D_ATTN_WAVE": "0", "ML3D_ATTN_SPLIT": "0"},
     {"ML3D_DEC_SPLIT": "0", "ML3D_RANDLA_DEC_FC1": "0"},         # decoder as one gather+concat GEMM per stage, separate fc1
-    {"ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # runtime-shaped per-wave MLP kernel
-    {"ML3D_RANDLA_WAVE_MLP": "0", "ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # barrier-per-layer chain kernel
+    {"ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # no fused chains: one Linear per layer
+    {"ML3D_RANDLA_PATH": "valu"},                                # the generic VALU kernels (the fallback for odd widths)
+    {"ML3D_RANDLA_LINEAR": "valu"},                              # scalar Linear kernel
     {"ML3D_ATTN_XCD": "0"},                                      # plain tile order
 ])
 def test_randla_forward_kernel_variants_agree_with_oracle(knobs):
