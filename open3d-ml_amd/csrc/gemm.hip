@@ -469,10 +469,23 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+// Split-K.  A workgroup walks its K chunks serially at ~2-4 us per chunk (global latency of one prefetch stage), so a deep-K
+// problem with about one workgroup per CU is latency-bound however few flops it has -- measured (KPConv, one MI355X): M = 4.6k,
+// K = 1920, N = 128 as 288 workgroups took 257 us = 9 TFLOP/s.  Problems with K >= 512 are split until ~4 workgroups per CU are
+// resident (partials summed by gemm_reduce).  ML3D_GEMM_SPLIT="tiles,aim" (read once) overrides the two numbers: split when
+// fewer than `tiles` workgroups, up to `aim` in total (round 1: "256,512").
 static int pick_splits(int64_t M, int N, int K) {
+    struct Rule { int64_t tiles, aim; };
+    static const Rule rule = [] {
+        Rule r = {1024, 1024};
+        const char* e = getenv("ML3D_GEMM_SPLIT");
+        long long a = 0, b = 0;
+        if (e && sscanf(e, "%lld,%lld", &a, &b) == 2 && a >= 0 && b >= 1) { r.tiles = a; r.aim = b; }
+        return r;
+    }();
     const int64_t tiles = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
-    if (tiles >= 256 || K < 512) return 1;
-    int64_t want = (512 + tiles - 1) / tiles;            // aim at ~2 workgroups per CU
+    if (tiles >= rule.tiles || K < 512) return 1;
+    int64_t want = (rule.aim + tiles - 1) / tiles;
     int64_t maxs = K / 128;                              // at least 4 chunks per split
     int64_t s = want < maxs ? want : maxs;
     if (s > 32) s = 32;

@@ -21,6 +21,7 @@
 //   Nq * (2*15*H*Cin + 2*15*Cin*Cout)   (SURVEY.md §8d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gemm.h"
 #include "grid.h"
@@ -188,6 +189,141 @@ __global__ void __launch_bounds__(256) kp_weighted_small(KpArgs A) {
         for (int c = 0; c < CIN; ++c) o[k * CIN + c] = acc[k][c];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// kp_small_fused — the whole KPConv of the FIRST layer (in_features_dim in {1 .. 5}, 64 output channels in the reference
+// configs) in one kernel: the [Nq, 15 * Cin] intermediate never exists in HBM and there is no K = 15 GEMM launch.
+// lane = (query of the wave's 8, PAIR of kernel points): per neighbour the lane computes the two influences of its pair
+// (packed f32) and multiplies them into Cin packed accumulators; neighbour index / position / feature loads are the same
+// address for the 8 lanes of a query (broadcast) and are requested U neighbours ahead of their use.  (The thread-per-query
+// kernel above walks 64 different index rows per instruction: 0.44 ms for 320 000 queries, bound by the address coalescer.)
+// Then the 15 * Cin weighted features of the wave's 8 queries go through LDS to the output layout -- lane = (query, 1/8 of
+// the output channels) -- for the [15 * Cin] x [Cout] product against the LDS-resident kernel weights, bias (folded BN) and
+// activation included.
+// ------------------------------------------------------------------------------------------------------------------
+struct KpOut {
+    const float* weights;         // [15 * cin][cout]
+    const float* bias;            // [cout] or null
+    int act; float slope; int cout;
+    float* out;                   // [nq, cout]
+};
+
+template <int CIN, int NV>       // NV = cout / 32 float4 column groups per lane
+__global__ void __launch_bounds__(256) kp_small_fused(KpArgs A, KpOut O) {
+    constexpr int KC = KP_K * CIN;                    // rows of the weight matrix
+    constexpr int WFP = KP_WP * CIN + 4;              // LDS pitch of a query's weighted features
+    constexpr int U = 4;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* WT = smem;                                 // [KC][cout]
+    float* WF = smem + KC * O.cout;                   // [4 waves][8 queries][WFP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < KC * O.cout; i += 256) WT[i] = O.weights[i];
+    __syncthreads();
+    const int qi = lane >> 3, kp = lane & 7;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * 8;
+    if (q0 >= A.nq) return;                           // wave-uniform, no block barrier below
+    const int64_t q = q0 + qi < A.nq ? q0 + qi : A.nq - 1;     // (the tail lanes redo the last query and do not store)
+    const bool q_ok = q0 + qi < A.nq;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // the lane's two kernel points (the sixteenth is padding: its accumulator is never read)
+    const int k0 = 2 * kp, k1 = 2 * kp + 1 < KP_K ? 2 * kp + 1 : 2 * kp;
+    const v2f kx = (v2f){A.kp[3 * k0], A.kp[3 * k1]}, ky = (v2f){A.kp[3 * k0 + 1], A.kp[3 * k1 + 1]},
+              kz = (v2f){A.kp[3 * k0 + 2], A.kp[3 * k1 + 2]};
+    const float qx = A.q_pts[3 * q], qy = A.q_pts[3 * q + 1], qz = A.q_pts[3 * q + 2];
+    v2f acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[c] = (v2f){0.f, 0.f};
+    const int32_t* irow = A.inds + q * A.h;
+    for (int h0 = 0; h0 < A.h; h0 += U) {
+        int idx[U];
+        float sx[U], sy[U], sz[U], xv[U][CIN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = h0 + u < A.h ? irow[h0 + u] : -1;
+            if (idx[u] < 0 || idx[u] >= A.ns) idx[u] = -1;       // shadow neighbour (kpconv.py:1048-1051)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = idx[u] < 0 ? 0 : idx[u];
+            const bool ok = idx[u] >= 0;
+            sx[u] = ok ? A.s_pts[3 * r] : 0.f; sy[u] = ok ? A.s_pts[3 * r + 1] : 0.f; sz[u] = ok ? A.s_pts[3 * r + 2] : 0.f;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xv[u][c] = ok ? A.x[r * CIN + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float nx = sx[u] - qx, ny = sy[u] - qy, nz = sz[u] - qz;
+            const v2f w = kp_influence2((v2f){nx, nx} - kx, (v2f){ny, ny} - ky, (v2f){nz, nz} - kz, A);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) acc[c] = __builtin_elementwise_fma(w, (v2f){xv[u][c], xv[u][c]}, acc[c]);
+        }
+    }
+    // weighted features -> LDS in [k][c] order (row index of the weight matrix = k * CIN + c)
+    float* wf = WF + (wave * 8 + qi) * WFP;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        wf[k0 * CIN + c] = acc[c].x;
+        if (2 * kp + 1 < KP_K) wf[(2 * kp + 1) * CIN + c] = acc[c].y;
+    }
+    wave_sync();
+    // out[q][co] = act(bias[co] + sum_kk wf[kk] * WT[kk][co]); lane = (query, column group kp): float4 v covers
+    // channels (v * 8 + kp) * 4 .. + 3, so the 8 lanes of a query write 128 contiguous bytes per v
+    float4 o[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int co = (v * 8 + kp) * 4;
+        o[v] = O.bias ? *reinterpret_cast<const float4*>(O.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll 5
+    for (int kk = 0; kk < KC; ++kk) {
+        const float f = wf[kk];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 w4 = *reinterpret_cast<const float4*>(WT + kk * O.cout + (v * 8 + kp) * 4);
+            o[v].x = fmaf(f, w4.x, o[v].x); o[v].y = fmaf(f, w4.y, o[v].y);
+            o[v].z = fmaf(f, w4.z, o[v].z); o[v].w = fmaf(f, w4.w, o[v].w);
+        }
+    }
+    if (q_ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 r = o[v];
+            if (O.act == 1) {
+                r.x = r.x > 0.f ? r.x : r.x * O.slope; r.y = r.y > 0.f ? r.y : r.y * O.slope;
+                r.z = r.z > 0.f ? r.z : r.z * O.slope; r.w = r.w > 0.f ? r.w : r.w * O.slope;
+            } else if (O.act == 2) {
+                r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(O.out + q * (int64_t)O.cout + (v * 8 + kp) * 4) = r;
+        }
+    }
+}
+
+template <int CIN>
+static bool launch_small_fused(const KpArgs& a, const KpOut& o, hipStream_t st) {
+    const int nv = o.cout / 32;
+    const size_t sm = sizeof(float) * ((size_t)KP_K * CIN * o.cout + 4 * 8 * (KP_WP * CIN + 4));
+    const unsigned nb = (unsigned)((a.nq + 31) / 32);
+    auto go = [&](auto kern) {
+        if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), sm, st, a, o);
+    };
+    switch (nv) {
+        case 1: go(kp_small_fused<CIN, 1>); break;
+        case 2: go(kp_small_fused<CIN, 2>); break;
+        case 3: go(kp_small_fused<CIN, 3>); break;
+        default: go(kp_small_fused<CIN, 4>); break;
+    }
+    return true;
+}
+
+// the fused first-layer kernel takes cin <= 5 with 32 | cout <= 128 and 16-byte aligned weights / bias / out
+static bool small_fused_ok(const KpArgs& a, const KpOut& o) {
+    // ML3D_KP_SMALL_FUSED=0 (read once): the two-kernel path (kp_weighted_small + K = 15 * cin GEMM) for A/B runs
+    static const bool on = [] { const char* e = getenv("ML3D_KP_SMALL_FUSED"); return !(e && e[0] == '0'); }();
+    return on && a.cin <= 5 && o.cout % 32 == 0 && o.cout <= 128 &&
+           ((((uintptr_t)o.weights) | ((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 15) == 0;
+}
+
 // max over the listed neighbours (shadow rows are zeros) / feature of the first listed neighbour
 __global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, const int32_t* __restrict__ inds,
                               int64_t nq, int h, int mode, float* __restrict__ out) {
@@ -300,6 +436,17 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
     const float sigma = kp_extent * 0.3f;                       // kpconv.py:1122-1125 + radius_gaussian eps
     a.gauss_den = 2.0f * sigma * sigma + 1e-9f;
     a.wf = wf;
+    const KpOut ko = {weights, bias, act, slope, cout, out};
+    if (max_neighbors > 0 && small_fused_ok(a, ko)) {
+        switch (cin) {
+            case 1: launch_small_fused<1>(a, ko, st); break;
+            case 2: launch_small_fused<2>(a, ko, st); break;
+            case 3: launch_small_fused<3>(a, ko, st); break;
+            case 4: launch_small_fused<4>(a, ko, st); break;
+            default: launch_small_fused<5>(a, ko, st); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
     int rc = launch_weighted(a, st);
     if (rc) return rc;
     RowsA A;

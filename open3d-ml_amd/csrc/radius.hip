@@ -69,6 +69,59 @@ __device__ __forceinline__ void rad_box(RadQuery& Q, const GridSeg& g, float r) 
     Q.zb = cell_coord(Q.qz + pad, g.lo[2], g.inv_c, g.dims[2]);
 }
 
+// ---- the candidate scan shared by both phases ------------------------------------------------------
+// The query's box is at most 4 x 4 rows of cells (cell >= r), each row one contiguous run [p0, p1) of the cell-sorted points.
+// Walking the rows one by one costs two DEPENDENT round trips per row (cell_start -> sorted) with the wave mostly idle (a row
+// holds ~10-60 points): 18-32 serial L2 latencies per query.  Here lanes 0 .. 2*rows-1 fetch all row bounds in ONE load, the
+// runs are concatenated by a prefix sum in scalar registers, and the 64 lanes stream the concatenation: two round trips and
+// ceil(T / 64) full-width steps per query.  body(active, candidate) is called in wave-uniform control flow.
+constexpr int RAD_ROWS = 16;
+
+template <class F>
+__device__ __forceinline__ void rad_scan(const RadArgs& A, const RadQuery& Q, const GridSeg& g, int lane, F&& body) {
+    if (!Q.any) return;
+    const int ny = Q.yb - Q.ya + 1, nz = Q.zb - Q.za + 1, nrows = ny * nz;
+    if (nrows <= RAD_ROWS) {
+        int b = 0;
+        if (lane < 2 * nrows) {
+            const int r = lane >> 1;
+            const int row = g.cell_base + g.dims[0] * ((Q.ya + r % ny) + g.dims[1] * (Q.za + r / ny));
+            b = A.G.cell_start[row + ((lane & 1) ? Q.xb + 1 : Q.xa)];
+        }
+        int pre[RAD_ROWS + 1], D[RAD_ROWS];
+        pre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < RAD_ROWS; ++r) {
+            const int p0 = __builtin_amdgcn_readlane(b, 2 * r), p1 = __builtin_amdgcn_readlane(b, 2 * r + 1);
+            D[r] = p0 - pre[r];                      // candidate f of row r is sorted[f + D[r]]
+            pre[r + 1] = pre[r] + (p1 - p0);         // (lanes >= 2 * nrows hold 0: empty rows)
+        }
+        const int T = pre[RAD_ROWS];
+        for (int f0 = 0; f0 < T; f0 += 64) {
+            const int f = f0 + lane;
+            int off = D[0];
+#pragma unroll
+            for (int j = 1; j < RAD_ROWS; ++j) off = f >= pre[j] ? D[j] : off;
+            const bool act = f < T;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) c = A.G.sorted[f + off];
+            body(act, c);
+        }
+        return;
+    }
+    for (int z = Q.za; z <= Q.zb; ++z)               // (unreachable with cell >= r; kept for any other grid)
+        for (int y = Q.ya; y <= Q.yb; ++y) {
+            const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+            const int p0 = A.G.cell_start[row + Q.xa], p1 = A.G.cell_start[row + Q.xb + 1];
+            for (int pb = p0; pb < p1; pb += 64) {
+                const int p = pb + lane;
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < p1) c = A.G.sorted[p];
+                body(p < p1, c);
+            }
+        }
+}
+
 // ---- phase 1: neighbours per query ---------------------------------------------------------------
 __global__ void __launch_bounds__(256) radius_count(RadArgs A, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
@@ -78,22 +131,10 @@ __global__ void __launch_bounds__(256) radius_count(RadArgs A, int* __restrict__
     const GridSeg g = A.G.segs[Q.s];
     rad_box(Q, g, A.r);
     int total = 0;
-    if (Q.any) {
-        for (int z = Q.za; z <= Q.zb; ++z)
-            for (int y = Q.ya; y <= Q.yb; ++y) {
-                const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                const int p0 = A.G.cell_start[row + Q.xa], p1 = A.G.cell_start[row + Q.xb + 1];
-                for (int pb = p0; pb < p1; pb += 64) {
-                    const int p = pb + lane;
-                    bool hit = false;
-                    if (p < p1) {
-                        const float4 c = A.G.sorted[p];
-                        hit = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z) <= A.r2;
-                    }
-                    total += __popcll(__ballot(hit));
-                }
-            }
-    }
+    rad_scan(A, Q, g, lane, [&](bool act, const float4& c) {
+        const bool hit = act && dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z) <= A.r2;
+        total += __popcll(__ballot(hit));
+    });
     if (lane == 0) counts[t] = total;
 }
 
@@ -126,7 +167,7 @@ __global__ void radius_splits(const int* __restrict__ c, int64_t nq, int64_t* __
 __global__ void __launch_bounds__(256)
 radius_fill(RadArgs A, const int64_t* __restrict__ row_splits, int index_local, int64_t dense_cols,
             int32_t pad_value, int32_t* __restrict__ out_index, float* __restrict__ out_d2, u64* spill) {
-    __shared__ u64 rows[4][RAD_LDS_ROW];
+    __shared__ __attribute__((aligned(16))) u64 rows[4][RAD_LDS_ROW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t t = (int64_t)blockIdx.x * 4 + w;
     if (t >= A.nq) return;                       // wave-uniform; no block barrier below
@@ -138,30 +179,17 @@ radius_fill(RadArgs A, const int64_t* __restrict__ row_splits, int index_local, 
     const bool in_lds = L <= RAD_LDS_ROW;
     u64* buf = in_lds ? rows[w] : (spill + rs);
     int total = 0;
-    if (Q.any) {
-        for (int z = Q.za; z <= Q.zb; ++z)
-            for (int y = Q.ya; y <= Q.yb; ++y) {
-                const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                const int p0 = A.G.cell_start[row + Q.xa], p1 = A.G.cell_start[row + Q.xb + 1];
-                for (int pb = p0; pb < p1; pb += 64) {
-                    const int p = pb + lane;
-                    bool hit = false;
-                    u64 key = 0ull;
-                    if (p < p1) {
-                        const float4 c = A.G.sorted[p];
-                        const float d2 = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z);
-                        hit = d2 <= A.r2;
-                        key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
-                    }
-                    const u64 m = __ballot(hit);
-                    if (hit) {
-                        const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-                        if (pos < L) buf[pos] = key;
-                    }
-                    total += __popcll(m);
-                }
-            }
-    }
+    rad_scan(A, Q, g, lane, [&](bool act, const float4& c) {
+        const float d2 = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z);
+        const bool hit = act && d2 <= A.r2;
+        const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
+        const u64 m = __ballot(hit);
+        if (hit) {
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < L) buf[pos] = key;
+        }
+        total += __popcll(m);
+    });
     if (!in_lds) __threadfence();
     wave_sync();   // every lane's keys are in `buf` before any lane ranks
     // rank sort: keys are distinct (distinct indices), rank = number of smaller keys
@@ -169,14 +197,36 @@ radius_fill(RadArgs A, const int64_t* __restrict__ row_splits, int index_local, 
     const int n_out = dense_cols > 0 ? (int)(L < dense_cols ? L : dense_cols) : L;
     int32_t* orow = dense_cols > 0 ? out_index + t * dense_cols : out_index + rs;
     float* drow = out_d2 ? (dense_cols > 0 ? out_d2 + t * dense_cols : out_d2 + rs) : nullptr;
-    const volatile u64* vb = buf;
-    for (int e = lane; e < L; e += 64) {
-        const u64 key = vb[e];
-        int rank = 0;
-        for (int j = 0; j < L; ++j) rank += (vb[j] < key) ? 1 : 0;
-        if (rank < n_out) {
-            orow[rank] = (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base);
-            if (drow) drow[rank] = __uint_as_float((unsigned)(key >> 32));
+    if (in_lds) {
+        // the keys are bit patterns of non-negative finite doubles (d2 <= r2 is a finite f32 in the high word), so their order
+        // as doubles is their order as integers: v_cmp_lt_f64 issues at full rate where the 64-bit integer compare does not
+        // (tools/micro/valu_rates.hip), and two keys arrive per ds_read_b128
+        const double* db = reinterpret_cast<const double*>(rows[w]);
+        for (int e = lane; e < L; e += 64) {
+            const double key = db[e];
+            int rank = 0;
+            int j = 0;
+            for (; j + 2 <= L; j += 2) {
+                const double k0 = db[j], k1 = db[j + 1];
+                rank += (k0 < key ? 1 : 0) + (k1 < key ? 1 : 0);
+            }
+            if (j < L) rank += db[j] < key ? 1 : 0;
+            if (rank < n_out) {
+                const u64 kb = (u64)__double_as_longlong(key);
+                orow[rank] = (int32_t)((int64_t)(unsigned)(kb & 0xffffffffull) + base);
+                if (drow) drow[rank] = __uint_as_float((unsigned)(kb >> 32));
+            }
+        }
+    } else {
+        const volatile u64* vb = buf;
+        for (int e = lane; e < L; e += 64) {
+            const u64 key = vb[e];
+            int rank = 0;
+            for (int j = 0; j < L; ++j) rank += (vb[j] < key) ? 1 : 0;
+            if (rank < n_out) {
+                orow[rank] = (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base);
+                if (drow) drow[rank] = __uint_as_float((unsigned)(key >> 32));
+            }
         }
     }
     if (dense_cols > 0)

@@ -18,7 +18,8 @@ def _layer(seed, n, r):
     return p, inds
 
 
-@pytest.mark.parametrize("cin,cout,n", [(1, 64, 700), (5, 16, 300), (32, 32, 600), (24, 40, 260), (64, 64, 300),
+@pytest.mark.parametrize("cin,cout,n", [(1, 64, 700), (5, 16, 300), (2, 32, 333), (4, 128, 300), (5, 96, 301), (3, 160, 200),
+                                        (32, 32, 600), (24, 40, 260), (64, 64, 300),
                                         (128, 128, 130), (256, 64, 70)])
 def test_kpconv_rigid_matches_reference_ops(cin, cout, n):
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -48,6 +49,27 @@ def test_kpconv_strided_queries_and_shadow_only_rows():
     ref = K.kpconv_rigid(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(inds).long(), torch.from_numpy(x),
                          torch.from_numpy(kp), torch.from_numpy(w), 0.08).numpy()
     assert rc == 0 and np.abs(out - ref).max() <= TOL and (out[-1] == 0).all()
+
+
+@pytest.mark.parametrize("cin,act", [(1, 0), (4, 2)])
+def test_kpconv_first_layer_fused_kernel_strided_shadow_rows_no_bias(cin, act):
+    """cin <= 5 with 32 | cout <= 128 runs as ONE kernel (kp_small_fused: influences + weighted sum + the [15 cin] x [cout]
+    product + activation); queries != supports, a query with only shadow neighbours, a ragged last wave (nq % 8 != 0)."""
+    rng = np.random.default_rng(30 + cin)
+    s = synth_data.toronto3d_sphere(23, 800)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.16)[0], [[50, 50, 50]]]).astype(np.float32)
+    if len(q) % 8 == 0:
+        q = q[1:]
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], 0.2)
+    x = rng.standard_normal((len(s), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, cin, 64)) * 0.3).astype(np.float32)
+    rc, out = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08, act=act, slope=0.1)
+    ref = K.kpconv_rigid(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08)
+    if act == 2:
+        ref = torch.relu(ref)
+    assert rc == 0 and np.abs(out - ref.numpy()).max() <= TOL * max(1.0, float(ref.abs().max())) and (out[-1] == 0).all()
 
 
 @pytest.mark.parametrize("m,k,n", [(300, 64, 128), (70, 1536, 96), (129, 15, 64), (64, 36, 8), (5, 3072, 512)])
