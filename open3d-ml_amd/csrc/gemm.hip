@@ -484,8 +484,11 @@ static int pick_splits(int64_t M, int N, int K) {
         return r;
     }();
     const int64_t tiles = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
-    if (tiles >= rule.tiles || K < 512) return 1;
-    int64_t want = (rule.aim + tiles - 1) / tiles;
+    // (K in [512, 768) -- RandLA's decoder and 512-wide Linears -- keeps round 1's numbers: measured 0.4 % faster there)
+    const int64_t thr = K >= 768 ? rule.tiles : (rule.tiles < 256 ? rule.tiles : 256);
+    const int64_t aim = K >= 768 ? rule.aim : (rule.aim < 512 ? rule.aim : 512);
+    if (tiles >= thr || K < 512) return 1;
+    int64_t want = (aim + tiles - 1) / tiles;
     int64_t maxs = K / 128;                              // at least 4 chunks per split
     int64_t s = want < maxs ? want : maxs;
     if (s > 32) s = 32;

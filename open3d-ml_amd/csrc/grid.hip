@@ -507,6 +507,35 @@ __global__ void __launch_bounds__(256) scan_final(int* a, int64_t n, const int* 
     }
 }
 
+// short arrays (<= SCAN_ONE_MAX elements: the histograms of a small radix sort, the counts / cells of the coarse KPConv levels)
+// in ONE launch of ONE 1024-thread workgroup: wave w owns a contiguous slice (rows of 64), sums it, the 16 slice sums meet in
+// LDS, then the wave scans its slice with the carry of the slices before it.  The three-launch form costs ~15 us of launch
+// latency per call however small n is, and a KPConv batch build issues ~60 scans per step.
+constexpr int SCAN_ONE_MAX = 32768;
+
+__global__ void __launch_bounds__(1024) scan_one(int* a, int n) {
+    __shared__ int ws[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rows = (n + 1023) / 1024;                 // rows of 64 per wave
+    const int base = wv * rows * 64;
+    int tot = 0;
+    for (int r = 0; r < rows; ++r) {
+        const int i = base + r * 64 + lane;
+        if (i < n) tot += a[i];
+    }
+    tot = wave_sum(tot);
+    if (lane == 0) ws[wv] = tot;
+    __syncthreads();
+    int carry = 0;
+    for (int w = 0; w < wv; ++w) carry += ws[w];
+    for (int r = 0; r < rows; ++r) {
+        const int i = base + r * 64 + lane;
+        const int incl = wave_inclusive_scan(i < n ? a[i] : 0) + carry;
+        if (i < n) a[i] = incl;
+        carry = __shfl(incl, 63);
+    }
+}
+
 // ---- K7: scatter into the cell-sorted float4 array ---------------------------------------------
 __global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_total,
                              const GridSeg* __restrict__ segs, int* cells, float4* sorted) {
@@ -528,6 +557,11 @@ __global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_to
 
 int scan_inclusive_i32(int* a, int64_t n, int* block_sums, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (n <= SCAN_ONE_MAX) {
+        hipLaunchKernelGGL(scan_one, dim3(1), dim3(1024), 0, stream, a, (int)n);
+        ML3D_LAUNCH_CHECK();
+        return 0;
+    }
     int sbk = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(scan_block_sums, dim3(sbk), dim3(256), 0, stream, a, n, block_sums);
     ML3D_LAUNCH_CHECK();

@@ -220,3 +220,76 @@ def make_trace(tag, ev_start, ev_stop):
     t.ev_start = C.c_void_p(ev_start.cuda_event)
     t.ev_stop = C.c_void_p(ev_stop.cuda_event)
     return t
+
+
+class KPConvPipeline:
+    """Batch build of step i + 1 under the forward of step i (KPConv segmentation inference, frame-parallel rows a10-a14).
+
+    The batch build of ``KPConvBatch`` (13 radius searches + 4 grid subsamplings per 5-layer batch) needs ~9 host read-backs of
+    result sizes; run back to back with the forward on one stream, every read-back drains the GPU.  Here the build runs on its
+    own HIP stream and the forward of the PREVIOUS batch is enqueued on a second stream first, so the read-backs of the build
+    only stall the host while the forward keeps the GPU busy.  ``submit`` returns the result of the previous batch (or None);
+    ``flush`` runs the forward of the last one.  Results are bit-identical to ``model(KPConvBatch(...))`` run in sequence."""
+
+    class Result:
+        def __init__(self, logits, done, batch):
+            self.logits, self.done, self.batch = logits, done, batch
+
+        def wait(self, stream=None):
+            """make ``stream`` (default: the caller's current stream) wait for the logits; returns them"""
+            s = stream or torch.cuda.current_stream(self.logits.device)
+            s.wait_event(self.done)
+            self.logits.record_stream(s)
+            return self.logits
+
+    def __init__(self, model, cfg, device):
+        self.model, self.cfg = model, cfg
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("KPConvPipeline needs an MI355X device; there is no CPU fallback")
+        with torch.cuda.device(self.device):
+            self.build = torch.cuda.Stream()
+            self.compute = torch.cuda.Stream()
+        self.pending = None          # (batch, built event)
+        self.alive = []              # results whose forward may still be reading the batch tensors (allocated on `build`)
+
+    def _forward_pending(self):
+        if self.pending is None:
+            return None
+        batch, built = self.pending
+        self.pending = None
+        with torch.cuda.device(self.device), torch.cuda.stream(self.compute):
+            self.compute.wait_event(built)
+            logits = self.model(batch)
+            done = torch.cuda.Event()
+            done.record(self.compute)
+        res = KPConvPipeline.Result(logits, done, batch)
+        # the batch's tensors live in the build stream's allocator pool: they must not be handed out again (to the NEXT build)
+        # before this forward has finished -- keep the batch referenced until its event has completed
+        self.alive = [r for r in self.alive if not r.done.query()]
+        self.alive.append(res)
+        while len(self.alive) > 2:
+            self.alive.pop(0).done.synchronize()
+        return res
+
+    def submit(self, points, lengths, features=None, rotations="random"):
+        from .torch.models.kpconv import KPConvBatch
+        prev = self._forward_pending()              # enqueued first: it runs while the host waits on the build's read-backs
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            self.build.wait_stream(cur)             # the caller's inputs
+            with torch.cuda.stream(self.build):
+                batch = KPConvBatch(points, lengths, self.cfg, features=features, rotations=rotations, device=self.device)
+                built = torch.cuda.Event()
+                built.record(self.build)
+            if torch.is_tensor(points) and points.is_cuda:
+                points.record_stream(self.build)
+        self.pending = (batch, built)
+        return prev
+
+    def flush(self):
+        return self._forward_pending()
+
+    def synchronize(self):
+        self.build.synchronize()
+        self.compute.synchronize()

@@ -106,3 +106,32 @@ def test_other_config_shapes_in_features_5_no_reduce_fc_gaussian():
     m.load_state_dict(sd)
     out = m(batch).cpu().numpy()
     assert np.abs(out - ref).max() <= TOL
+
+
+def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
+    """ml3d.engine.KPConvPipeline (what bench.py --workload kpconv times): the batch build of step i + 1 on one HIP stream under
+    the forward of step i on another.  Five different batches, twice through the pipeline (buffers of the caching allocator get
+    reused across streams) -- logits identical to model(KPConvBatch(..)) run one after the other."""
+    from ml3d.engine import KPConvPipeline
+    from ml3d.torch.models.kpconv import KPConvBatch
+    sd = K.make_state_dict(CFG, 77)
+    m = _model(sd)
+    batches = [[synth_data.toronto3d_sphere(40 + 3 * i + j, 2500 + 400 * j + 150 * i) for j in range(3)] for i in range(5)]
+    dev = torch.device("cuda:0")
+    inputs = [(torch.from_numpy(np.concatenate(b)).to(dev), [len(s) for s in b]) for b in batches]
+    np.random.seed(5)
+    seq = [m(KPConvBatch(p, l, CFG, device=dev)).cpu().numpy() for p, l in inputs for _ in (0,)]
+    for rep in range(2):
+        np.random.seed(5)
+        pipe = KPConvPipeline(m, CFG, dev)
+        got = []
+        for p, l in inputs:
+            r = pipe.submit(p, l)
+            if r is not None:
+                got.append(r)
+        got.append(pipe.flush())
+        assert pipe.flush() is None
+        outs = [r.wait().cpu().numpy() for r in got]
+        assert len(outs) == len(seq)
+        for a, b in zip(outs, seq):
+            assert a.shape == b.shape and np.array_equal(a, b)
