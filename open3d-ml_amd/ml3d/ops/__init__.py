@@ -7,6 +7,8 @@ CPU path (the CPU oracle lives under /oracle and is test infrastructure only).
 All kernels are enqueued on torch's CURRENT stream.
 """
 import ctypes as C
+
+import numpy as np
 from collections import namedtuple
 
 import torch
@@ -181,6 +183,28 @@ VoxelizeResult = namedtuple("VoxelizeResult", ["voxel_coords", "voxel_point_indi
                                                "voxel_batch_splits"])
 
 
+# row splits of a list of per-item lengths on the device.  A KPConv batch build asks for the same few lists ~6 times each
+# (conv / pool / upsample searches, subsampling and the two rotations of a layer): a small cache keyed by (lengths, device,
+# stream) turns ~40 tiny host-to-device copies per batch into ~6.  (The stream is part of the key: a cached tensor is only
+# handed to work enqueued on the stream its upload was ordered on.)
+_SPLITS_CACHE = {}
+
+
+def _splits_of_lengths(lengths, dev):
+    if torch.is_tensor(lengths):
+        lengths = lengths.tolist()
+    key = (tuple(int(v) for v in lengths), str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    hit = _SPLITS_CACHE.get(key)
+    if hit is None:
+        host = np.zeros(len(key[0]) + 1, np.int64)
+        np.cumsum(np.asarray(key[0], np.int64), out=host[1:])
+        hit = (torch.from_numpy(host).to(dev), int(host[-1]))
+        if len(_SPLITS_CACHE) >= 64:
+            _SPLITS_CACHE.clear()
+        _SPLITS_CACHE[key] = hit
+    return hit
+
+
 def _splits(rs, n, dev):
     if rs is None:
         return torch.tensor([0, int(n)], dtype=torch.int64, device=dev)
@@ -270,11 +294,8 @@ def fixed_radius_search(points, queries, radius, points_row_splits=None, queries
 def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius):
     """Deferred first half of ``radius_neighbors_dense``: grid + counts enqueued, sizes not read yet."""
     dev = supports.device
-    qs = torch.zeros(len(q_lengths) + 1, dtype=torch.int64)
-    ss = torch.zeros(len(s_lengths) + 1, dtype=torch.int64)
-    qs[1:] = torch.cumsum(torch.as_tensor(q_lengths, dtype=torch.int64).cpu(), 0)
-    ss[1:] = torch.cumsum(torch.as_tensor(s_lengths, dtype=torch.int64).cpu(), 0)
-    return _RadiusPlan(supports, queries, radius, ss.to(dev), qs.to(dev), defer=True)
+    return _RadiusPlan(supports, queries, radius, _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0],
+                       defer=True)
 
 
 def radius_fill_dense(plan, n_supports, max_cols=None):
@@ -292,11 +313,7 @@ def radius_neighbors_dense(queries, supports, q_lengths, s_lengths, radius, max_
     """``batch_neighbors`` (ml3d/torch/models/kpconv.py:2002-2034) on the GPU: dense int32 [Nq, max_nbrs]
     neighbour matrix padded with the shadow index Ns; search + ragged_to_dense fused in one fill kernel."""
     dev = supports.device
-    qs = torch.zeros(len(q_lengths) + 1, dtype=torch.int64)
-    ss = torch.zeros(len(s_lengths) + 1, dtype=torch.int64)
-    qs[1:] = torch.cumsum(torch.as_tensor(q_lengths, dtype=torch.int64).cpu(), 0)
-    ss[1:] = torch.cumsum(torch.as_tensor(s_lengths, dtype=torch.int64).cpu(), 0)
-    plan = _RadiusPlan(supports, queries, radius, ss.to(dev), qs.to(dev))
+    plan = _RadiusPlan(supports, queries, radius, _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0])
     cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
     if plan.nq == 0 or cols == 0:
         return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
@@ -378,13 +395,10 @@ def subsample_batch(points, batches_len, features=None, classes=None, sampleDl=0
     points = points.contiguous().float()
     dev = points.device
     n = points.shape[0]
-    lens = torch.as_tensor(batches_len, dtype=torch.int64).cpu()
-    rs = torch.zeros(lens.numel() + 1, dtype=torch.int64)
-    rs[1:] = torch.cumsum(lens, 0)
-    if int(rs[-1]) != n:
+    rs, total = _splits_of_lengths(batches_len, dev)
+    if total != n:
         raise RuntimeError("subsample_batch: batches_len does not sum to the number of points")
-    rs = rs.to(dev)
-    B = lens.numel()
+    B = rs.numel() - 1
     feats = None if features is None else features.contiguous().float()
     labs = None if classes is None else classes.contiguous().to(torch.int32).reshape(-1)
     wsb = lib.ml3d_subsample_workspace_bytes(n, B)
@@ -446,10 +460,7 @@ def rotate_points(points, lengths_or_splits, rotations, transpose=False, is_spli
     if is_splits:
         rs = lengths_or_splits.to(device=dev, dtype=torch.int64).contiguous()
     else:
-        ln = torch.as_tensor(lengths_or_splits, dtype=torch.int64).cpu()
-        rs = torch.zeros(ln.numel() + 1, dtype=torch.int64)
-        rs[1:] = torch.cumsum(ln, 0)
-        rs = rs.to(dev)
+        rs = _splits_of_lengths(lengths_or_splits, dev)[0]
     R = rotations.to(device=dev, dtype=torch.float32).contiguous()
     out = torch.empty_like(points)
     with torch.cuda.device(dev):
@@ -459,15 +470,67 @@ def rotate_points(points, lengths_or_splits, rotations, transpose=False, is_spli
     return out
 
 
+class _SubsamplePlan:
+    """``batch_grid_subsampling`` (points only) in two halves, so that its one host read-back (the number of pooled points, needed
+    to allocate them) can be shared with other pending sizes: ``stats`` int64 [2] = (pooled points, overflow flag) and
+    ``out_len`` int64 [B] stay on the device until ``resolve``; ``fill`` writes the pooled points."""
+
+    def __init__(self, points, batches_len, sampleDl, rotations=None):
+        lib = _abi.get()
+        _need_gpu(points)
+        self.rotations = rotations
+        pts = points.contiguous().float()
+        self.src = pts if rotations is None else rotate_points(pts, batches_len, rotations)
+        dev = self.src.device
+        self.n = self.src.shape[0]
+        self.rs, total = _splits_of_lengths(batches_len, dev)
+        if total != self.n:
+            raise RuntimeError("subsample_batch: batches_len does not sum to the number of points")
+        self.B = self.rs.numel() - 1
+        self.wsb = lib.ml3d_subsample_workspace_bytes(self.n, self.B)
+        self.ws = _ws(self.wsb, dev)
+        self.out_len = torch.empty(self.B, dtype=torch.int64, device=dev)
+        self.stats = torch.empty(2, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_subsample_count(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, float(sampleDl),
+                                          self.out_len.data_ptr(), self.stats.data_ptr(), self.ws.data_ptr(), self.wsb, _stream())
+        _abi.check(rc, "ml3d_subsample_count")
+        self.M = None
+
+    def resolve(self, values=None):
+        if self.M is None:
+            self.M, err = (int(x) for x in (self.stats.tolist() if values is None else values))
+            if err:
+                raise RuntimeError("subsample: a batch item spans >= 2^48 voxels at this sampleDl (unsupported)")
+        return self
+
+    def fill(self):
+        """-> (pooled points [M, 3], pooled lengths int32 [B] on the device)"""
+        lib = _abi.get()
+        self.resolve()
+        dev = self.src.device
+        op = torch.empty((self.M, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_subsample_fill(self.src.data_ptr(), None, 0, None, self.B, self.n, op.data_ptr(), None, None,
+                                         self.ws.data_ptr(), self.wsb, _stream())
+        _abi.check(rc, "ml3d_subsample_fill")
+        if self.rotations is not None:
+            # the pooled lengths stay on the device: their row splits are built there (no read-back for the rotation back)
+            rs = torch.zeros(self.B + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(self.out_len, 0, out=rs[1:])
+            op = rotate_points(op, rs, self.rotations, transpose=True, is_splits=True)
+        return op, self.out_len.to(torch.int32)
+
+
+def grid_subsampling_plan(points, batches_len, sampleDl=0.1, rotations=None):
+    """Deferred ``batch_grid_subsampling``: counting enqueued, sizes not read yet (``_SubsamplePlan``)."""
+    return _SubsamplePlan(points, batches_len, sampleDl, rotations)
+
+
 def batch_grid_subsampling(points, batches_len, sampleDl=0.1, rotations=None):
     """``batch_grid_subsampling`` (ml3d/torch/models/kpconv.py:2037-2111, points only) on the GPU.
     ``rotations`` = float32 [B,3,3] grid orientations (what ``random_grid_orient`` draws) or None."""
-    if rotations is None:
-        r = subsample_batch(points, batches_len, sampleDl=sampleDl)
-        return r[0], r[1]
-    rot = rotate_points(points, batches_len, rotations)
-    sp, sl = subsample_batch(rot, batches_len, sampleDl=sampleDl)[:2]
-    return rotate_points(sp, sl, rotations, transpose=True), sl
+    return _SubsamplePlan(points, batches_len, sampleDl, rotations).fill()
 
 
 def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias, extent, act=1, slope=0.1,

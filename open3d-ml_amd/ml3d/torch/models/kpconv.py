@@ -547,8 +547,8 @@ class KPConvBatch:
             if not ('pool' in block or 'strided' in block or 'global' in block or 'upsample' in block):
                 layer_blocks.append(block)
                 continue
-            # the conv search's sizes are read together with the subsample's (one host sync instead of two), the pool and
-            # upsample searches' together as well: 2 read-backs per layer
+            # the conv search's sizes are read together with the subsampling's, the pool and upsample searches' together as
+            # well: 2 host read-backs per pooling layer, 9 per 5-layer batch
             conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_normal) if layer_blocks else None
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / cfg['conv_radius']
@@ -560,14 +560,17 @@ class KPConvBatch:
                 else:
                     R = rotations[li]
                 Rt = None if R is None else torch.as_tensor(R, dtype=torch.float32).to(dev)
-                pool_p, pool_b = ops.batch_grid_subsampling(pts, lens, dl, Rt)
-                if conv_plan is not None:          # pooled lengths + the conv search's two sizes in one read-back
-                    vals = torch.cat([pool_b.to(torch.int64), conv_plan.stats]).tolist()
-                    pool_lens = [int(v) for v in vals[:len(lens)]]
-                    conv_plan.resolve(vals[len(lens):])
+                # ONE read-back for the subsampling's sizes (pooled points, per-item lengths) and the conv search's two
+                sub = ops.grid_subsampling_plan(pts, lens, dl, Rt)
+                parts = [sub.stats, sub.out_len] + ([conv_plan.stats] if conv_plan is not None else [])
+                vals = torch.cat(parts).tolist()
+                sub.resolve(vals[:2])
+                pool_lens = [int(v) for v in vals[2:2 + len(lens)]]
+                pool_p, _ = sub.fill()
+                if conv_plan is not None:
+                    conv_plan.resolve(vals[2 + len(lens):])
                     conv_i = ops.radius_fill_dense(conv_plan, pts.shape[0])
                 else:
-                    pool_lens = [int(v) for v in pool_b.tolist()]
                     conv_i = e_i
                 pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_normal)
                 up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_normal)
