@@ -135,9 +135,9 @@ def run_kpconv(args, rank, world, dev, dist):
     from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
     import synth_weights as W
     cfg = dict(W.TORONTO3D_CFG)
-    # spheres per step: the batch build is launch/latency-bound (≈430 small launches + 17 host read-backs per batch whatever
-    # its size), so throughput follows the batch: 8 -> 1231, 16 -> 1972, 32 -> 2586, 63 -> 3190 spheres/s
-    B = args.frames_per_step if args.frames_per_step != 64 else 32
+    # spheres per step: the batch build is launch/latency-bound (~550 small launches + 9 host read-backs per batch whatever
+    # its size), so throughput follows the batch (round 2, pipelined: 16 -> 3219, 32 -> 4400, 48 -> 4748, 63 -> 5002 spheres/s)
+    B = args.frames_per_step                               # 64 spheres per step by default, like the RandLA line
     sd = W.kpconv_state_dict(cfg, 2024)
     m = KPFCNN(**cfg, device=dev)
     m.load_state_dict(sd)

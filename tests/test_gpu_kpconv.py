@@ -121,9 +121,9 @@ def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
     inputs = [(torch.from_numpy(np.concatenate(b)).to(dev), [len(s) for s in b]) for b in batches]
     np.random.seed(5)
     seq = [m(KPConvBatch(p, l, CFG, device=dev)).cpu().numpy() for p, l in inputs for _ in (0,)]
-    for rep in range(2):
+    for rep in range(4):
         np.random.seed(5)
-        pipe = KPConvPipeline(m, CFG, dev)
+        pipe = KPConvPipeline(m, CFG, dev, threaded=rep >= 2)     # forward enqueued by the caller / by the worker thread
         got = []
         for p, l in inputs:
             r = pipe.submit(p, l)
