@@ -3,6 +3,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "grid.h"
 #include "ml3d_hip.h"
 
@@ -22,6 +24,56 @@ __device__ __forceinline__ float gm_act(float v, int act, float slope) {
     if (act == 1) return v > 0.f ? v : v * slope;
     if (act == 2) return v > 0.f ? v : 0.f;
     return v;
+}
+
+// ---- epilogue fast path -------------------------------------------------------------------------------------------------
+// The plain epilogue (bias [+ bias2] [+ residual] + activation, row-major C) is the whole kernel for shallow K: RandLA's and
+// KPConv's Linears have K = 32 .. 128 (1-4 chunks), and the generic store -- a 64-bit m * ldc + col, a bounds test and the
+// activation switch per element -- spent ~15 VALU instructions per output, which the f32 MFMAs cannot overlap.  When the output
+// is addressable with 32-bit offsets the row base is a SCALAR pointer (tile row origin + r-dependent row, uniform) and the
+// lane's contribution (its column + its half's 4 rows) one 32-bit offset computed once: a store is the bias add, the
+// activation and a global_store with scalar base.  ACT is resolved outside the element loops.
+template <int ACT>
+__device__ __forceinline__ float gm_act_t(float v, float slope) {
+    if (ACT == 1) return v > 0.f ? v : v * slope;
+    if (ACT == 2) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// one 32 x 32 accumulator block whose first row is `mrow0` (uniform): rows mrow0 + mfma32_row(r, hi), column `col`
+template <int ACT, bool FULL, bool RES>
+__device__ __forceinline__ void store_block32(const f32x16& acc, float b, float slope, float* __restrict__ C, int64_t ldc,
+                                              const float* __restrict__ R, int64_t ldr, int64_t mrow0, int64_t M, int col,
+                                              int hi) {
+    // the lane's pointer to (row mrow0 + 4 hi, column col), once; every store adds a UNIFORM row offset (scalar multiply)
+    float* cp = C + (mrow0 + 4 * hi) * ldc + col;
+    const float* rp = RES ? R + (mrow0 + 4 * hi) * ldr + col : nullptr;
+    const int rows_left = (int)(M - mrow0 < 32 ? M - mrow0 : 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ur = (r & 3) + 8 * (r >> 2);                // uniform part of the row; the lane's half adds 4 * hi
+        if (!FULL && ur + 4 * hi >= rows_left) continue;
+        const int so_c = __builtin_amdgcn_readfirstlane(ur * (int)ldc);
+        float v = acc[r] + b;
+        if (RES) v += rp[__builtin_amdgcn_readfirstlane(ur * (int)ldr)];
+        cp[so_c] = gm_act_t<ACT>(v, slope);
+    }
+}
+
+// ACT and FULL are resolved ONCE per kernel, outside the block loops (the loops stay small enough to unroll: the accumulators
+// must never be indexed dynamically)
+template <class F>
+__device__ __forceinline__ void dispatch_act_full(int act, bool full, F&& f) {
+    using T = std::integral_constant<bool, true>;
+    using N = std::integral_constant<bool, false>;
+    if (act == 1) { if (full) f(std::integral_constant<int, 1>{}, T{}); else f(std::integral_constant<int, 1>{}, N{}); }
+    else if (act == 2) { if (full) f(std::integral_constant<int, 2>{}, T{}); else f(std::integral_constant<int, 2>{}, N{}); }
+    else { if (full) f(std::integral_constant<int, 0>{}, T{}); else f(std::integral_constant<int, 0>{}, N{}); }
+}
+
+// 32-bit offsets inside a 36-row window of C / the residual (a block's rows + the lane's 4 * hi)
+__device__ __forceinline__ bool fast_store_ok(const Epilogue& ep, int64_t ldc, int N) {
+    return ep.ps == 0 && !ep.residual && 36 * ldc + N < 0x7fffffffll;
 }
 
 // ---- A loaders ---------------------------------------------------------------------------------------
@@ -77,10 +129,18 @@ struct ConvLoader {
     __device__ __forceinline__ Ctx prepare(int64_t m) const {
         Ctx c; c.img = nullptr; c.iy0 = 0; c.ix0 = 0;
         if (m < M) {
-            int ox = (int)(m % A.OW);
-            int64_t t = m / A.OW;
-            int oy = (int)(t % A.OH);
-            int b = (int)(t / A.OH);
+            int ox, oy, b;
+            if (M <= 0x7fffffffll) {        // (uniform) 32-bit divisions: ~20 instructions each instead of ~100 for int64
+                const unsigned mu = (unsigned)m, t = mu / (unsigned)A.OW;
+                ox = (int)(mu - t * (unsigned)A.OW);
+                b = (int)(t / (unsigned)A.OH);
+                oy = (int)(t - (unsigned)b * (unsigned)A.OH);
+            } else {
+                ox = (int)(m % A.OW);
+                const int64_t t = m / A.OW;
+                oy = (int)(t % A.OH);
+                b = (int)(t / A.OH);
+            }
             c.img = A.in + (int64_t)b * A.H * A.W * A.C;
             c.iy0 = oy * A.stride - A.pad;
             c.ix0 = ox * A.stride - A.pad;
@@ -107,7 +167,11 @@ struct ConvLoader {
 };
 
 // ---- tile kernel -------------------------------------------------------------------------------------
-template <class Loader>
+// PLAIN (RowsLoader only): one dense float4-addressable A block, K a multiple of the chunk, float4-addressable B -- the staging
+// loads are four running pointers (no per-chunk predicates, no loader branches).  The generic fetch below is ~170 VALU / 365
+// SALU instructions of control flow per chunk of 16 MFMAs in the listing; the Linears of RandLA-Net and KPConv (K = 32 .. 1024,
+// almost all plain) spent more time in it than in the matrix unit.
+template <class Loader, bool PLAIN = false>
 __global__ void __launch_bounds__(256)
 gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, float* __restrict__ C, int64_t ldc,
           int k_per_split, float* __restrict__ partial) {
@@ -128,6 +192,16 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     const typename Loader::Ctx c0 = L.prepare(m0 + ar), c1 = L.prepare(m0 + 32 + ar);
 
     float4 ra0, ra1, rb0, rb1;
+    // PLAIN: rows past M re-read row M - 1 and columns past N re-read column 0 (their products are never stored)
+    const float* pa0 = nullptr; const float* pa1 = nullptr; const float* pb0 = nullptr; const float* pb1 = nullptr;
+    if constexpr (PLAIN) {
+        const int64_t r0 = m0 + ar < L.M ? m0 + ar : L.M - 1, r1 = m0 + 32 + ar < L.M ? m0 + 32 + ar : L.M - 1;
+        pa0 = L.A.a + r0 * L.A.lda + kb + aq;
+        pa1 = L.A.a + r1 * L.A.lda + kb + aq;
+        const int colb = n0 + bq + 3 < N ? n0 + bq : 0;
+        pb0 = Bm + (int64_t)(kb + br) * N + colb;
+        pb1 = pb0 + (int64_t)16 * N;
+    }
     auto load_b = [&](int k) -> float4 {
         const int col = n0 + bq;
         if (k >= ke) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,6 +215,15 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
         return v;
     };
     auto fetch = [&](int k0) {
+        if constexpr (PLAIN) {
+            ra0 = *reinterpret_cast<const float4*>(pa0);
+            ra1 = *reinterpret_cast<const float4*>(pa1);
+            rb0 = *reinterpret_cast<const float4*>(pb0);
+            rb1 = *reinterpret_cast<const float4*>(pb1);
+            pa0 += GM_KC; pa1 += GM_KC;
+            pb0 += (int64_t)GM_KC * N; pb1 += (int64_t)GM_KC * N;
+            return;
+        }
         const int ka = k0 + aq;
         ra0 = ka < ke ? L.load4(c0, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
         ra1 = ka < ke ? L.load4(c1, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,6 +298,14 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     }
     float b = ep.bias ? ep.bias[col] : 0.f;
     if (ep.bias2) b += ep.bias2[col];
+    if (fast_store_ok(ep, ldc, N)) {
+        const int64_t mrow0 = m0 + __builtin_amdgcn_readfirstlane(rt) * 32;      // (scalar: uniform row offsets below)
+        dispatch_act_full(ep.act, mrow0 + 32 <= L.M, [&](auto act_c, auto full_c) {
+            store_block32<decltype(act_c)::value, decltype(full_c)::value, false>(acc, b, ep.slope, C, ldc, nullptr, 0, mrow0, L.M,
+                                                                                  col, hi);
+        });
+        return;
+    }
     // gathered residual: the tile's first row fixes the item (scalar division); a 64-row tile crosses items at most once
     int64_t rg_base = 0, rg_l0 = 0;
     if (ep.res_gather) {
@@ -258,10 +349,12 @@ struct ConvLoader2 {
     __device__ __forceinline__ Ctx prepare(int64_t m) const {
         Ctx c; c.off = 0; c.taps = 0u;
         if (m < M) {
-            const int ox = (int)(m % A.OW);
-            const int64_t t = m / A.OW;
-            const int oy = (int)(t % A.OH);
-            const int b = (int)(t / A.OH);
+            // (M = B * OH * OW < 2^31 is a precondition of this loader: 32-bit divisions, ~20 instructions each instead of ~100)
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)A.OW;
+            const int ox = (int)(mu - t * (unsigned)A.OW);
+            const int b = (int)(t / (unsigned)A.OH);
+            const int oy = (int)(t - (unsigned)b * (unsigned)A.OH);
             const int iy0 = oy * A.stride - A.pad, ix0 = ox * A.stride - A.pad;
             c.off = ((b * A.H + iy0) * A.W + ix0) * A.C;
             for (int ky = 0; ky < A.KH; ++ky)
@@ -398,6 +491,24 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
         }
     }
     // ---- epilogue (bias + residual + activation, or the pixel-shuffle store) ---------------------------------------
+    if (fast_store_ok(ep, ldc, N)) {
+        const int64_t mw0 = m0 + __builtin_amdgcn_readfirstlane(wr) * 64;        // (scalar: uniform row offsets below)
+        dispatch_act_full(ep.act, m0 + G2_BM <= L.M, [&](auto act_c, auto full_c) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = n0 + wc * (32 * CT) + 32 * j + cl;
+                if (col < N) {
+                    float b = ep.bias ? ep.bias[col] : 0.f;
+                    if (ep.bias2) b += ep.bias2[col];
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+                        store_block32<decltype(act_c)::value, decltype(full_c)::value, false>(acc[i][j], b, ep.slope, C, ldc, nullptr,
+                                                                                              0, mw0 + i * 32, L.M, col, hi);
+                }
+            }
+        });
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         const int col = n0 + wc * (32 * CT) + 32 * j + cl;
@@ -570,6 +681,20 @@ static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const E
     return true;
 }
 
+// the streamlined K loop of gemm_tile takes: one dense float4-addressable row block, whole chunks, float4-addressable B
+static bool plain_rows(const RowsLoader& L, int kper, int bvec) {
+    // ML3D_GEMM_PLAIN=0 (read once): the generic loader for every problem (A/B runs)
+    static const bool on = [] { const char* e = getenv("ML3D_GEMM_PLAIN"); return !(e && e[0] == '0'); }();
+    return on && L.vec && bvec && !L.A.gather && L.A.k2 == 0 && !L.A.a2 && (L.K % GM_KC) == 0 && (kper % GM_KC) == 0 && L.M > 0;
+}
+static bool plain_rows(const ConvLoader&, int, int) { return false; }
+static void launch_plain(const RowsLoader& L, dim3 grid, const float* Bm, int N, int bvec, const Epilogue& ep, float* C,
+                         int64_t ldc, int kper, float* partial, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_tile<RowsLoader, true>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+}
+static void launch_plain(const ConvLoader&, dim3, const float*, int, int, const Epilogue&, float*, int64_t, int, float*,
+                         hipStream_t) {}
+
 template <class Loader>
 static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
                        void* partial_ws, size_t partial_bytes, hipStream_t st) {
@@ -586,7 +711,8 @@ static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& 
     const int bvec = ((N & 3) == 0 && (((uintptr_t)Bm) & 15) == 0) ? 1 : 0;
     dim3 grid((unsigned)((M + GM_BM - 1) / GM_BM), (unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)splits);
     float* partial = splits > 1 ? (float*)partial_ws : nullptr;
-    hipLaunchKernelGGL((gemm_tile<Loader>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    if (plain_rows(L, kper, bvec)) launch_plain(L, grid, Bm, N, bvec, ep, C, ldc, kper, partial, st);
+    else hipLaunchKernelGGL((gemm_tile<Loader>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (splits > 1) {
         int64_t total = M * N;

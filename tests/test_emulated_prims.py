@@ -196,3 +196,49 @@ def test_vote_update_follows_numpy_float16_promotion():
     assert d.max() <= 2 ** -10 and (d == 0).mean() > 0.99          # at most one float16 ulp, almost always none
     untouched = np.setdiff1d(np.arange(300), inds)
     assert np.array_equal(out[untouched], probs[untouched])
+
+
+# ---- edge cases (empty / degenerate inputs) ---------------------------------------------------------------------------
+def test_radius_empty_queries_zero_radius_and_coincident_points():
+    p = _cloud(8, 300).astype(np.float32)
+    idx, rs = emu.radius(p, [0, 300], np.zeros((0, 3), np.float32), [0, 0], 0.5)
+    assert idx.shape == (0,) and rs.tolist() == [0]
+    # radius 0: a point finds exactly the points at its own position (d2 == 0 <= 0), duplicates in index order
+    q = np.concatenate([p[:50], p[:50]])                      # every position twice
+    idx, rs = emu.radius(q, [0, 100], q, [0, 100], 0.0)
+    ref = oops.fixed_radius_search(q, q, 0.0)
+    assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
+    assert (np.diff(rs) == 2).all() and (idx.reshape(100, 2)[:, 0] < idx.reshape(100, 2)[:, 1]).all()
+
+
+def test_radius_dense_with_no_neighbours_at_all_has_zero_columns():
+    p = _cloud(9, 40).astype(np.float32)
+    q = (p + 100.0).astype(np.float32)
+    dense = emu.radius(p, [0, 40], q, [0, 40], 0.1, dense=True)
+    assert dense.shape == (40, 0)
+
+
+def test_ragged_to_dense_empty_rows_and_zero_columns():
+    vals = np.arange(5, dtype=np.float32)
+    rs = np.array([0, 0, 2, 2, 5], np.int64)
+    out = emu.ragged_to_dense(vals, rs, 3, np.float32(-1))
+    assert out.tolist() == [[-1, -1, -1], [0, 1, -1], [-1, -1, -1], [2, 3, 4]]
+    assert emu.ragged_to_dense(vals, rs, 0, np.float32(-1)).shape == (4, 0)
+
+
+def test_subsample_empty_input_and_all_points_in_one_voxel():
+    out = emu.subsample_batch(np.zeros((0, 3), np.float32), [0], 0.1)
+    assert out[0].shape == (0, 3) and np.asarray(out[1]).tolist() == [0]
+    p = (np.random.default_rng(3).random((77, 3)) * 0.01 + 5.0).astype(np.float32)
+    out = emu.subsample_batch(p, [77], 1.0)
+    ref = oops.subsample_batch(p, [77], sampleDl=1.0)
+    assert out[0].shape == (1, 3) and np.array_equal(out[0], ref[0]) and np.asarray(out[1]).tolist() == [1]
+
+
+def test_nms_no_boxes_one_box_and_identical_boxes():
+    assert emu.nms(np.zeros((0, 5), np.float32), np.zeros(0, np.float32), 0.5).tolist() == []
+    b = np.array([[0, 0, 2, 1, 0.3]], np.float32)
+    assert emu.nms(b, np.array([0.7], np.float32), 0.5).tolist() == [0]
+    b3 = np.repeat(b, 3, 0)
+    keep = emu.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5)
+    assert keep.tolist() == oops.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5).tolist() == [1]

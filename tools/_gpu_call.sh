@@ -1,10 +1,19 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-mkdir -p gpurun_out/r3e
-timeout 200 python -m pytest tests/test_gpu_kpconv.py -x -q > gpurun_out/r3e/pytest.log 2>&1; tail -3 gpurun_out/r3e/pytest.log
-for f in "--frames-per-step 32" "" "--frames-per-step 32" ""; do timeout 100 python bench.py --workload kpconv --steps 20 --warmup 3 --no-cpu-baseline $f 2>gpurun_out/r3e/err.log < /dev/null | tail -1 | python -c "
+mkdir -p gpurun_out/r3h
+timeout 250 python -m pytest tests/test_gpu_kpconv.py tests/test_gpu_randlanet.py tests/test_gpu_pointpillars.py -x -q > gpurun_out/r3h/pytest.log 2>&1; tail -3 gpurun_out/r3h/pytest.log
+for e in "ML3D_GEMM_PLAIN=1" "ML3D_GEMM_PLAIN=0" "ML3D_GEMM_PLAIN=1" "ML3D_GEMM_PLAIN=0"; do
+env $e timeout 100 python bench.py --workload kpconv --steps 20 --warmup 3 --no-cpu-baseline 2>gpurun_out/r3h/err.log < /dev/null | tail -1 | python -c "
 import json,sys
 try:
-    d=json.loads(sys.stdin.readline()); print('kpconv $f %.0f /s  step %.3f ms block %.3f' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))
-except Exception as e: print('FAILED', e)"; done
-tail -3 gpurun_out/r3e/err.log
+    d=json.loads(sys.stdin.readline()); print('$e kpconv %.0f /s  step %.3f ms' % (d['value'], d['ms_per_step']))
+except Exception as e: print('FAILED', e)"
+env $e timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-workloads 2>>gpurun_out/r3h/err.log < /dev/null | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.readline()); print('$e randla %.0f /s median %.3f' % (d['value'], d['step_ms_median']))
+except Exception as e: print('randla FAILED', e)"
+done
+env ML3D_GEMM_PLAIN=1 timeout 100 python bench.py --workload pointpillars --steps 15 --warmup 3 --no-cpu-baseline 2>>gpurun_out/r3h/err.log < /dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('pointpillars %.0f /s' % d['value'])"
