@@ -41,8 +41,12 @@ class _CallTimer:
         self.count += 1
         return r
 
+    def samples_ms(self):
+        return [float(a.elapsed_time(b)) for a, b in self.events]
+
     def mean_ms(self):
-        return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else None
+        """median of the timed calls (a cold allocator block inside one call would dominate a mean of three)"""
+        return float(np.median(self.samples_ms())) if self.events else None
 
     def restore(self):
         setattr(self.ops, self.name, self.orig)
@@ -170,14 +174,14 @@ def run_kpconv(args, rank, world, dev, dist):
     finish(pipe.flush())
     torch.cuda.synchronize()
     # the block roofline: the first resnet block's KPConv (32 -> 32 on the full-resolution layer), timed with HIP events on its
-    # launch stream in three SEQUENTIAL steps after the timed region (inside the pipeline it shares the GPU with the next build)
+    # launch stream in five SEQUENTIAL steps after the timed region (inside the pipeline it shares the GPU with the next build)
     m(KPConvBatch(pts, lens, cfg, device=dev))           # (untimed: the caller-stream allocator pool is cold after a pipelined run)
     torch.cuda.synchronize()
     timer = _CallTimer(ops, "kpconv_rigid", 1)
-    for _ in range(3):
+    for _ in range(5):
         timer.new_step()
         m(KPConvBatch(pts, lens, cfg, device=dev))
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     timer.restore()
     if rank != 0:
         return None
@@ -195,7 +199,7 @@ def run_kpconv(args, rank, world, dev, dist):
            "roofline": {"bound": "mfma", "kernel": "kp_weighted<32,1> + gemm_tile (KPConv %d->%d, %d queries x %d neighbours)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-                        "flops_per_launch": flops}}
+                        "launch_ms_samples": timer.samples_ms(), "flops_per_launch": flops}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline
         sp = spheres[0]
