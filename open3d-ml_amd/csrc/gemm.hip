@@ -167,8 +167,8 @@ struct ConvLoader {
 };
 
 // ---- tile kernel -------------------------------------------------------------------------------------
-// PLAIN (RowsLoader only): one dense float4-addressable A block, K a multiple of the chunk, float4-addressable B -- the staging
-// loads are four running pointers (no per-chunk predicates, no loader branches).  The generic fetch below is ~170 VALU / 365
+// PLAIN (RowsLoader only): one or two dense float4-addressable column blocks of A with chunk-aligned widths, float4-addressable B --
+// the staging loads are running pointers (no per-chunk predicates, no loader branches).  The generic fetch below is ~170 VALU / 365
 // SALU instructions of control flow per chunk of 16 MFMAs in the listing; the Linears of RandLA-Net and KPConv (K = 32 .. 1024,
 // almost all plain) spent more time in it than in the matrix unit.
 template <class Loader, bool PLAIN = false>
@@ -194,10 +194,16 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     float4 ra0, ra1, rb0, rb1;
     // PLAIN: rows past M re-read row M - 1 and columns past N re-read column 0 (their products are never stored)
     const float* pa0 = nullptr; const float* pa1 = nullptr; const float* pb0 = nullptr; const float* pb1 = nullptr;
+    const float* qa0 = nullptr; const float* qa1 = nullptr;      // the second column block ([a | a2] concatenated, chunk-aligned)
     if constexpr (PLAIN) {
         const int64_t r0 = m0 + ar < L.M ? m0 + ar : L.M - 1, r1 = m0 + 32 + ar < L.M ? m0 + 32 + ar : L.M - 1;
         pa0 = L.A.a + r0 * L.A.lda + kb + aq;
         pa1 = L.A.a + r1 * L.A.lda + kb + aq;
+        if (L.A.k2 > 0) {
+            const int k2b = kb > L.A.k1 ? kb - L.A.k1 : 0;
+            qa0 = L.A.a2 + r0 * L.A.lda2 + k2b + aq;
+            qa1 = L.A.a2 + r1 * L.A.lda2 + k2b + aq;
+        }
         const int colb = n0 + bq + 3 < N ? n0 + bq : 0;
         pb0 = Bm + (int64_t)(kb + br) * N + colb;
         pb1 = pb0 + (int64_t)16 * N;
@@ -216,11 +222,17 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     };
     auto fetch = [&](int k0) {
         if constexpr (PLAIN) {
-            ra0 = *reinterpret_cast<const float4*>(pa0);
-            ra1 = *reinterpret_cast<const float4*>(pa1);
+            if (k0 < L.A.k1) {                                   // (uniform: block boundaries are chunk-aligned)
+                ra0 = *reinterpret_cast<const float4*>(pa0);
+                ra1 = *reinterpret_cast<const float4*>(pa1);
+                pa0 += GM_KC; pa1 += GM_KC;
+            } else {
+                ra0 = *reinterpret_cast<const float4*>(qa0);
+                ra1 = *reinterpret_cast<const float4*>(qa1);
+                qa0 += GM_KC; qa1 += GM_KC;
+            }
             rb0 = *reinterpret_cast<const float4*>(pb0);
             rb1 = *reinterpret_cast<const float4*>(pb1);
-            pa0 += GM_KC; pa1 += GM_KC;
             pb0 += (int64_t)GM_KC * N; pb1 += (int64_t)GM_KC * N;
             return;
         }
@@ -685,7 +697,9 @@ static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const E
 static bool plain_rows(const RowsLoader& L, int kper, int bvec) {
     // ML3D_GEMM_PLAIN=0 (read once): the generic loader for every problem (A/B runs)
     static const bool on = [] { const char* e = getenv("ML3D_GEMM_PLAIN"); return !(e && e[0] == '0'); }();
-    return on && L.vec && bvec && !L.A.gather && L.A.k2 == 0 && !L.A.a2 && (L.K % GM_KC) == 0 && (kper % GM_KC) == 0 && L.M > 0;
+    const bool one = L.A.k2 == 0 && L.A.k1 == L.K;
+    const bool two = L.A.k2 > 0 && L.A.a2 && (L.A.k1 % GM_KC) == 0 && L.A.k1 + L.A.k2 == L.K;
+    return on && L.vec && bvec && !L.A.gather && (one || two) && (L.K % GM_KC) == 0 && (kper % GM_KC) == 0 && L.M > 0;
 }
 static bool plain_rows(const ConvLoader&, int, int) { return false; }
 static void launch_plain(const RowsLoader& L, dim3 grid, const float* Bm, int N, int bvec, const Epilogue& ep, float* C,

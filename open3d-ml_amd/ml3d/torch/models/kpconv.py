@@ -595,7 +595,9 @@ class KPConvBatch:
 
 
 def random_grid_rotations(B):
-    """The np.random draws of ``batch_grid_subsampling`` (kpconv.py:2059-2080), same order and arithmetic."""
+    """The np.random draws of ``batch_grid_subsampling`` (kpconv.py:2059-2080) followed by the closed-form axis-angle
+    rotation of ``create_3D_rotations`` (ml3d/datasets/utils/operations.py:21-40): same draw order and the same float64
+    operation order (temporaries t1 .. t24 as there), because the bit-exact batch golden depends on every rounding."""
     theta = np.random.rand(B) * 2 * np.pi
     phi = (np.random.rand(B) - 0.5) * np.pi
     u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)]).T

@@ -1,11 +1,16 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-mkdir -p gpurun_out/r3i
-timeout 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r3i/bench.json 2> gpurun_out/r3i/err.log
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r3i/bench.json').read().strip().split('\n')[-1])
-print(round(d['value']))
-for w,v in d['workloads'].items():
-    print(w, round(v['value']), v['roofline'].get('avg_launch_ms'), v['roofline'].get('launch_ms_samples'))
-PY
+mkdir -p gpurun_out/r3k
+timeout 250 python -m pytest tests/test_gpu_kpconv.py tests/test_gpu_randlanet.py tests/test_gpu_pointpillars.py -x -q > gpurun_out/r3k/pytest.log 2>&1; tail -2 gpurun_out/r3k/pytest.log
+for i in 1 2; do
+timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-workloads 2>gpurun_out/r3k/err.log < /dev/null | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.readline()); print('randla %.0f /s median %.3f' % (d['value'], d['step_ms_median']))
+except Exception as e: print('randla FAILED', e)"
+timeout 100 python bench.py --workload kpconv --steps 20 --warmup 3 --no-cpu-baseline 2>>gpurun_out/r3k/err.log < /dev/null | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.readline()); print('kpconv %.0f /s  step %.3f ms' % (d['value'], d['ms_per_step']))
+except Exception as e: print('FAILED', e)"
+done
