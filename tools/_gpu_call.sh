@@ -1,16 +1,13 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-mkdir -p gpurun_out/r3k
-timeout 250 python -m pytest tests/test_gpu_kpconv.py tests/test_gpu_randlanet.py tests/test_gpu_pointpillars.py -x -q > gpurun_out/r3k/pytest.log 2>&1; tail -2 gpurun_out/r3k/pytest.log
-for i in 1 2; do
-timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-workloads 2>gpurun_out/r3k/err.log < /dev/null | tail -1 | python -c "
-import json,sys
-try:
-    d=json.loads(sys.stdin.readline()); print('randla %.0f /s median %.3f' % (d['value'], d['step_ms_median']))
-except Exception as e: print('randla FAILED', e)"
-timeout 100 python bench.py --workload kpconv --steps 20 --warmup 3 --no-cpu-baseline 2>>gpurun_out/r3k/err.log < /dev/null | tail -1 | python -c "
-import json,sys
-try:
-    d=json.loads(sys.stdin.readline()); print('kpconv %.0f /s  step %.3f ms' % (d['value'], d['ms_per_step']))
-except Exception as e: print('FAILED', e)"
-done
+O=gpurun_out/r2final2; mkdir -p $O
+export TMPDIR=/tmp
+timeout 400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" > $O/smoke.log 2>&1 < /dev/null; tail -1 $O/smoke.log
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null; tail -c 300 $O/bench.json
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/rl -o rl -- python bench.py --no-cpu-baseline --no-workloads > $O/rl_bench.json 2> $O/rl.err < /dev/null
+timeout 150 rocprofv3 --kernel-trace --stats -d $O/kp -o kp -- python bench.py --workload kpconv --steps 10 --warmup 3 --no-cpu-baseline > $O/kp_bench.json 2> $O/kp.err < /dev/null
+timeout 150 rocprofv3 --kernel-trace --stats -d $O/pp -o pp -- python bench.py --workload pointpillars --steps 10 --warmup 3 --no-cpu-baseline > $O/pp_bench.json 2> $O/pp.err < /dev/null
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o pf -- python bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-workloads > $O/pf.json 2> $O/pf.err < /dev/null
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o pw -- python bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-workloads > $O/pw.json 2> $O/pw.err < /dev/null
+ls $O
