@@ -1,3 +1,7 @@
+# The round's final validation call (gpurun --timeout 900 -- 'bash tools/_gpu_call.sh'): GPU tests, smoke, the default bench line and
+# the rocprofv3 passes behind profiles/r02_* (summarised afterwards with profiles/summarize_rocpd.py / summarize_pmc.py and
+# tools/make_traffic.py).  Every command reads /dev/null and has its own timeout: a command that waits on stdin once cost 30
+# GPU-minutes this round.
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 O=gpurun_out/r2final2; mkdir -p $O
