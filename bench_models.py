@@ -148,16 +148,14 @@ def run_kpconv(args, rank, world, dev, dist):
     spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
     lens = [len(s) for s in spheres]
     pts = torch.from_numpy(np.concatenate(spheres)).to(dev)
-    labels = torch.zeros((1, sum(lens)), dtype=torch.int32, device=dev)
     np.random.seed(0)
     overlap = not getattr(args, "no_overlap", False)
     from ml3d.engine import KPConvPipeline
     pipe = KPConvPipeline(m, cfg, dev)
 
     def finish(res):
-        if res is not None and world > 1:
-            labels.copy_(torch.argmax(res.wait(), 1).view(1, -1))
-            mdist.gather_predictions(labels, dst=0)
+        if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)
+            mdist.gather_ragged(torch.argmax(res.wait(), 1).to(torch.uint8), dst=0)
 
     def step():
         if overlap:
@@ -168,8 +166,7 @@ def run_kpconv(args, rank, world, dev, dist):
             batch = KPConvBatch(pts, lens, cfg, device=dev)
             logits = m(batch)
             if world > 1:
-                labels.copy_(torch.argmax(logits, 1).view(1, -1))
-                mdist.gather_predictions(labels, dst=0)
+                mdist.gather_ragged(torch.argmax(logits, 1).to(torch.uint8), dst=0)
     dt = _timed(step, args.steps, args.warmup, world, dist, dev)
     finish(pipe.flush())
     torch.cuda.synchronize()

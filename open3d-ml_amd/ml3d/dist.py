@@ -51,6 +51,28 @@ def gather_predictions(labels, dst=0, out=None, async_op=False):
     return (res, work) if async_op else res
 
 
+def gather_ragged(values, dst=0):
+    """The ragged case of the prediction gather (KPConv batches hold a different number of points on every
+    rank, PointPillars a different number of boxes): ``values`` is this rank's 1-D tensor of ANY length.  Sizes first (one tiny
+    all_gather), then a gather of the tensors padded to the longest; ``dst`` gets the list of every rank's tensor trimmed back
+    to its own length, the other ranks None.  The reference does the same for detection boxes with ``gather_object``
+    (ml3d/torch/pipelines/object_detection.py:222-233); tensors avoid the pickling."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [values]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = torch.tensor([values.numel()], dtype=torch.int64, device=values.device)
+    sizes = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(t.item()) for t in sizes]
+    longest = max(sizes)
+    padded = values.reshape(-1)
+    if padded.numel() < longest:
+        padded = torch.cat([padded, padded.new_zeros(longest - padded.numel())])
+    out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded.contiguous(), out, dst=dst)
+    return [t[:k] for t, k in zip(out, sizes)] if rank == dst else None
+
+
 def compact_labels(scores):
     """argmax over classes as the smallest integer type that holds it (uint8 for <= 256 classes): what travels."""
     lab = torch.argmax(scores, dim=-1)

@@ -119,3 +119,40 @@ def test_prediction_gather_single_process():
     slot = g.push(s)
     g.drain()
     assert g.gathered(slot)[0].dtype == torch.int32 and torch.equal(g.gathered(slot)[0].long(), s.argmax(2))
+
+
+def _ragged_worker(rank, world, port, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ml3d import dist as mdist
+    mdist.init("gloo")
+    for step in range(3):
+        n = 1000 + 37 * rank + 5 * step + (0 if rank else 400)        # a different length on every rank and step
+        vals = ((torch.arange(n) * (rank + 2) + step) % 8).to(torch.uint8)
+        got = mdist.gather_ragged(vals, dst=0)
+        if rank == 0:
+            assert len(got) == world
+            for r, t in enumerate(got):
+                m = 1000 + 37 * r + 5 * step + (0 if r else 400)
+                assert t.shape == (m,) and torch.equal(t, ((torch.arange(m) * (r + 2) + step) % 8).to(torch.uint8))
+        else:
+            assert got is None
+    if rank == 0:
+        np.save(out_path, np.array([1]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_ragged_gather_of_per_rank_label_vectors(tmp_path):
+    """KPConv / PointPillars at N > 1: every rank's batch has its own number of points / boxes (the ragged
+    case): sizes, then a padded gather, trimmed on rank 0."""
+    world = 2
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_ragged_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert os.path.exists(out)
+
+
+def test_ragged_gather_single_process_is_identity():
+    from ml3d.dist import gather_ragged
+    x = torch.arange(7)
+    assert gather_ragged(x)[0] is x
