@@ -139,13 +139,31 @@ def radius(points, psplits, queries, qsplits, r, dense=False, local=False, with_
     cols = longest if dense else 0
     idx = np.full((nq, cols) if dense else (total,), -5, np.int32)
     d2 = np.zeros(idx.shape, np.float32) if with_d2 else None
-    # the workspace of the count phase (it carries the grid) goes back in untouched; long rows sort in a separate spill buffer
-    spill = np.zeros(total + 2, np.uint64)
-    rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
-                            rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
-                            None if d2 is None else d2.ctypes.data, ws.ctypes.data, wsb, spill.ctypes.data + spill_phase,
-                            8 * total + 8, None)
-    assert rc == 0, rc
+    if spill_phase is None:
+        # spill == NULL: long rows sort at the tail of ONE workspace sized for the result; the count phase is repeated into it
+        wsb2 = L.ml3d_radius_workspace_bytes(ns, nq, B, total)
+        ws2 = _ws(wsb2)
+        rc = L.ml3d_radius_count(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                                 rs.ctypes.data, stats.ctypes.data, ws2.ctypes.data, wsb2, None)
+        assert rc == 0, rc
+        rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                                rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
+                                None if d2 is None else d2.ctypes.data, ws2.ctypes.data, wsb2, None, 0, None)
+        assert rc == 0, rc
+        # ... and a workspace WITHOUT room for the rows is refused instead of overrun
+        if total > 0:
+            rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                                    rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
+                                    None if d2 is None else d2.ctypes.data, ws.ctypes.data, wsb, None, 0, None)
+            assert rc != 0
+    else:
+        # the workspace of the count phase (it carries the grid) goes back in untouched; long rows sort in a separate spill buffer
+        spill = np.zeros(total + 2, np.uint64)
+        rc = L.ml3d_radius_fill(points.ctypes.data, ps.ctypes.data, queries.ctypes.data, qs.ctypes.data, B, ns, nq, r,
+                                rs.ctypes.data, total, 1 if local else 0, cols, ns, idx.ctypes.data,
+                                None if d2 is None else d2.ctypes.data, ws.ctypes.data, wsb, spill.ctypes.data + spill_phase,
+                                8 * total + 8, None)
+        assert rc == 0, rc
     if dense:
         return idx
     return (idx, rs, d2) if with_d2 else (idx, rs)

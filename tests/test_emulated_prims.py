@@ -52,7 +52,7 @@ def test_radius_spill_buffer_is_separate_from_the_grid_workspace():
     at an arbitrary 8-byte phase: no relocation of the grid, whatever the result size (ml3d_hip.h, ml3d_radius_fill)"""
     p = (_cloud(4, 700) * 0.1).astype(np.float32)
     ref = oops.fixed_radius_search(p, p[:30], 1.0)
-    for phase in (0, 8):
+    for phase in (0, 8, None):         # None: no spill buffer, ONE workspace sized for the result (and a too-small one refused)
         idx, rs = emu.radius(p, [0, 700], p[:30], [0, 30], 1.0, spill_phase=phase)
         assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
 
