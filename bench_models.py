@@ -81,7 +81,7 @@ def run_pointpillars(args, rank, world, dev, dist):
     from ml3d.torch.models.point_pillars import PointPillars
     import synth_weights as W
     cfg = W.POINTPILLARS_KITTI_CFG
-    B = args.frames_per_step if args.frames_per_step != 64 else 8     # sweeps per step (4: 955, 8: 1092, 16: 1134 frames/s)
+    B = args.frames_per_step if args.frames_per_step != 64 else 16    # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
     sd = W.pointpillars_state_dict(cfg, 2024)
     m = PointPillars(device=dev, **cfg)
     m.load_state_dict(sd)
