@@ -208,12 +208,22 @@ def main():
     host = torch.from_numpy(frames).pin_memory()          # what a data loader hands over: host xyz (in_channels = 3)
     gather = mdist.PredictionGather(B, N, CFG["num_classes"], dev)
 
+    # N > 1: argmax + label gather of a step run on their OWN stream behind that step's forward.  (Making the caller's stream wait
+    # for the compute stream instead would also hold back the NEXT step's upload and neighbour search, which are ordered after
+    # the caller's stream: the search-under-forward overlap would be lost exactly when scaling is measured.)
+    post = torch.cuda.Stream(device=dev) if (world > 1 and overlap) else None
+
     def one_step(knn_trace=None, fwd_trace=None, done=None):
         scores = stream.submit(host, None, knn_trace, fwd_trace, done)
         if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
-            if overlap:
-                torch.cuda.current_stream().wait_stream(stream.compute_stream)
-            gather.push(scores)
+            if post is not None:
+                with torch.cuda.stream(post):
+                    post.wait_stream(stream.compute_stream)          # this step's forward
+                    gather.push(scores)
+                # the forward that overwrites this `scores` slot (two steps on) must come after the argmax that reads it
+                stream.compute_stream.wait_stream(post)
+            else:
+                gather.push(scores)
 
     def drain():
         stream.synchronize()
