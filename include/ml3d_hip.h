@@ -36,6 +36,9 @@ extern "C" {
 #define ML3D_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess        */
 #define ML3D_E_UNSUPPORTED (-4)
 
+/* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
+/* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
+#define ML3D_ABI_VERSION 2
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */

@@ -276,7 +276,7 @@ static float tuning_occ() {
 
 using namespace ml3d;
 
-extern "C" int ml3d_abi_version(void) { return 1; }
+extern "C" int ml3d_abi_version(void) { return ML3D_ABI_VERSION; }
 
 extern "C" size_t ml3d_knn_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch) {
     (void)n_queries;

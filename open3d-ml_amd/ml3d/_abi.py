@@ -15,6 +15,8 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
+ABI_VERSION = 2          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "ml3d_abi_version",
@@ -178,7 +180,12 @@ def get():
             raise RuntimeError(
                 "ml3d: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-        _lib = bind(C.CDLL(LIB_PATH))
+        lib = bind(C.CDLL(LIB_PATH))
+        got = int(lib.ml3d_abi_version())
+        if got != ABI_VERSION:
+            raise RuntimeError("ml3d: %s has ABI version %d, this binding was written against %d (include/ml3d_hip.h) — rebuild "
+                               "it with `python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, got, ABI_VERSION))
+        _lib = lib
     return _lib
 
 

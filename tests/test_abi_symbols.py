@@ -33,7 +33,9 @@ def test_header_symbols_exported(built):
 
 
 def test_abi_version_and_sizes(built):
-    assert built.ml3d_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "ml3d_hip.h")).read()
+    ver = int(re.search(r"#define\s+ML3D_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert built.ml3d_abi_version() == ver == _abi.ABI_VERSION
     assert built.ml3d_knn_workspace_bytes(1000, 1000, 1) > 1000 * 16
     desc = _abi.make_desc(dict(num_layers=4, in_channels=3, dim_features=8, num_classes=19, num_neighbors=16,
                                dim_output=[16, 64, 128, 256], sub_sampling_ratio=[4, 4, 4, 4]), 2, 45056)
@@ -61,3 +63,13 @@ def test_product_ops_refuse_cpu_tensors(built):
     m = RandLANet(device="cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"coords": [torch.zeros(1, 64, 3)], "features": torch.zeros(1, 64, 3)})
+
+
+def test_stale_library_is_refused(built, monkeypatch):
+    """a library built from another revision of the header must not be called (its arguments would be misread)"""
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "ABI_VERSION", _abi.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _abi.get()
+    monkeypatch.setattr(_abi, "ABI_VERSION", _abi.ABI_VERSION - 1)
+    assert _abi.get() is not None
