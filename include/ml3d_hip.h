@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 2
+#define ML3D_ABI_VERSION 3
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -319,11 +319,18 @@ int ml3d_iou_3d(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m
 
 /* ------------------------------------------------------------------------- */
 /* patch sampler / vote accumulation                         */
-/* ml3d_nearest_to_center: the k points nearest to a centre, ascending         */
-/*   (d2, index) — replaces search_tree.query(center_point, k=num_points) of   */
+/* ml3d_nearest_to_center: the k points nearest to a centre — replaces         */
+/*   search_tree.query(center_point, k=num_points) of                          */
 /*   SemSegSpatiallyRegularSampler (ml3d/datasets/samplers/                    */
 /*   semseg_spatially_regular.py:90-91); k may be as large as n_points.        */
-/*   center_host: HOST float[3].  out_dist2 may be NULL.                       */
+/*   The reference's tree there is sklearn.neighbors.KDTree (randlanet.py:142, */
+/*   kpconv.py:384): float64 copies of the float32 points, neighbours ordered  */
+/*   by the float64 reduced distance (dx*dx + dy*dy) + dz*dz.  The ORDER is    */
+/*   observable (random.shuffle of the patch, then prefix subsampling), so     */
+/*   this entry orders by exactly that float64 value, ties by ascending index; */
+/*   pinned against scikit-learn in tests/test_emulated_prims.py.              */
+/*   center_host: HOST float[3].  out_dist2: DOUBLE [k] reduced distances      */
+/*   (sklearn's distance = sqrt of it), may be NULL.                           */
 /* ml3d_vote_update: probs[inds[i]] = smooth*probs[inds[i]] + (1-smooth)*      */
 /*   softmax(logits[i]) on a float16 accumulator [n_cloud, classes] with the   */
 /*   numpy promotion of ml3d/torch/models/randlanet.py:420-421, 457-462        */
@@ -332,7 +339,7 @@ int ml3d_iou_3d(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m
 size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points);
 
 int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host,
-                           int64_t k, int32_t* out_index, float* out_dist2,
+                           int64_t k, int32_t* out_index, double* out_dist2,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, int num_classes,

@@ -430,21 +430,27 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
 
 namespace ml3d {
 
-__global__ void center_keys(const float* __restrict__ pts, int64_t n, float cx, float cy, float cz, u64* __restrict__ keys,
+// sampler query (semseg_spatially_regular.py:90-91): the reference's search tree is sklearn's KDTree, which converts
+// the float32 sub-cloud to float64 and orders neighbours by the float64 reduced distance ((dx*dx + dy*dy) + dz*dz,
+// sklearn/metrics/_dist_metrics: sequential accumulation, no FMA).  The patch ORDER feeds random.shuffle and, through the
+// prefix subsampling of RandLANet.transform, every coarser level -- so the key is that float64 value, bit for bit
+// (positive doubles order like their bit patterns); ties keep ascending index (stable sort, values start as 0..n-1).
+__global__ void center_keys(const float* __restrict__ pts, int64_t n, double cx, double cy, double cz, u64* __restrict__ keys,
                             uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float d2 = dist2_canon(cx, cy, cz, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    keys[i] = ((u64)__float_as_uint(d2) << 32) | (u64)(uint32_t)i;
+    const double dx = (double)pts[3 * i] - cx, dy = (double)pts[3 * i + 1] - cy, dz = (double)pts[3 * i + 2] - cz;
+    const double d2 = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: three products, two sums, no FMA
+    keys[i] = (u64)__double_as_longlong(d2);
     vals[i] = (uint32_t)i;
 }
 
-__global__ void center_take(const u64* __restrict__ keys, int64_t k, int32_t* __restrict__ out_idx, float* __restrict__ out_d2) {
+__global__ void center_take(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t k,
+                            int32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    const u64 key = keys[i];
-    out_idx[i] = (int32_t)(key & 0xffffffffull);
-    if (out_d2) out_d2[i] = __uint_as_float((unsigned)(key >> 32));
+    out_idx[i] = (int32_t)vals[i];
+    if (out_d2) out_d2[i] = __longlong_as_double((long long)keys[i]);
 }
 
 // one wave per patch point: softmax over the C classes (lanes stride the classes), then the float16 vote update
@@ -485,7 +491,7 @@ extern "C" size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points) {
 }
 
 extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host, int64_t k,
-                                      int32_t* out_index, float* out_dist2, void* workspace, size_t workspace_bytes,
+                                      int32_t* out_index, double* out_dist2, void* workspace, size_t workspace_bytes,
                                       void* stream) {
     if (n_points < 0 || k < 0 || k > n_points || !center_host || n_points > 0x7ffffff0ll) return ML3D_E_INVALID;
     if (k == 0) return 0;
@@ -498,10 +504,10 @@ extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, con
     SortWs sw;
     if (!sort_ws_carve(p, sort_ws_bytes(n_points), n_points, &sw)) return ML3D_E_WORKSPACE;
     hipLaunchKernelGGL(center_keys, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, points, n_points,
-                       center_host[0], center_host[1], center_host[2], keys, vals);
+                       (double)center_host[0], (double)center_host[1], (double)center_host[2], keys, vals);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (sort_pairs_u64(keys, vals, n_points, 64, sw, st)) return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL(center_take, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, keys, k, out_index, out_dist2);
+    hipLaunchKernelGGL(center_take, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, keys, vals, k, out_index, out_dist2);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

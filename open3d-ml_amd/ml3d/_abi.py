@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 2          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 3          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -187,6 +187,16 @@ def get():
                                "it with `python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, got, ABI_VERSION))
         _lib = lib
     return _lib
+
+
+def require_gpu(device, what):
+    """The package's one device gate: every model / batch class calls it before touching the library.  There is no CPU
+    execution path behind any of them."""
+    import torch
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type != "cuda":
+        raise RuntimeError("%s needs an MI355X device (got '%s'); there is no CPU fallback" % (what, dev))
+    return dev
 
 
 def check(rc, what):

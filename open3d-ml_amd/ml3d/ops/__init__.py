@@ -746,9 +746,10 @@ def iou_3d(boxes_a, boxes_b):
 
 
 def nearest_to_center(points, center, k, return_distances=False):
-    """The ``k`` points nearest to ``center`` in ascending (d2, index) order — the
-    ``search_tree.query(center_point, k=num_points)`` of SemSegSpatiallyRegularSampler
-    (ml3d/datasets/samplers/semseg_spatially_regular.py:90-91).  int32 indices [k]."""
+    """The ``k`` points nearest to ``center`` — the ``search_tree.query(center_point, k=num_points)`` of
+    SemSegSpatiallyRegularSampler (ml3d/datasets/samplers/semseg_spatially_regular.py:90-91) in the order of the
+    reference's sklearn ``KDTree``: ascending FLOAT64 reduced distance (ties: ascending index).  int32 indices [k]
+    and, on request, the float64 reduced distances."""
     lib = _abi.get()
     _need_gpu(points)
     points = points.contiguous().float()
@@ -758,7 +759,7 @@ def nearest_to_center(points, center, k, return_distances=False):
     if c.numel() != 3 or not (0 <= int(k) <= n):
         raise RuntimeError("nearest_to_center: center must have 3 elements and 0 <= k <= n_points")
     idx = torch.empty(int(k), dtype=torch.int32, device=dev)
-    d2 = torch.empty(int(k), dtype=torch.float32, device=dev) if return_distances else None
+    d2 = torch.empty(int(k), dtype=torch.float64, device=dev) if return_distances else None
     wsb = lib.ml3d_nearest_to_center_workspace_bytes(n)
     ws = _ws(wsb, dev)
     with torch.cuda.device(dev):

@@ -4,21 +4,34 @@ MI355X ops."""
 import numpy as np
 import torch
 
+from ... import _abi
 from ... import ops
 
 
 class GpuSearchTree:
     """What ``preprocess`` stores as ``data['search_tree']`` (the reference builds an sklearn ``KDTree`` there,
-    randlanet.py:142).  The pipeline's samplers only use ``.data`` and ``.query(X, k)``
-    (ml3d/datasets/samplers/semseg_spatially_regular.py:90-91; randlanet.py:147-150, 389); both are served by the GPU
-    ops: the num_points-nearest patch query by a keyed radix sort of the whole cloud (``ops.nearest_to_center``), small k
-    by the grid k-NN.  Results come in the canonical ascending (distance, index) order; distances are Euclidean
-    (sqrt of the float32 squared distance), float64 like sklearn's."""
+    randlanet.py:142).  The pipeline's samplers only use ``.data``, ``.query(X, k)`` and ``.query_radius(X, r)``
+    (ml3d/datasets/samplers/semseg_spatially_regular.py:86-91; randlanet.py:147-150, 389); all are served by the GPU ops:
 
-    def __init__(self, points, device):
+    * the num_points-nearest patch query (ONE centre, k up to the whole cloud) by a keyed radix sort of the cloud
+      (``ops.nearest_to_center``) in sklearn's own order -- ascending float64 reduced distance -- because the patch order is
+      observable downstream (``random.shuffle``, then the prefix subsampling of ``RandLANet.transform``);
+    * small k / many queries by the grid k-NN (float32 squared distances, ascending (d2, index));
+    * ``query_radius`` by the fixed-radius search.  sklearn documents that result as UNSORTED: its order is the traversal
+      order of the tree's internal index array, which only sklearn's own build reproduces.  The radius sampler shuffles the
+      list and then cuts it by position (kpconv.py:480-489), so bit-identical spheres need that very order:
+      ``host_index=True`` (model kwarg ``sampler_index='sklearn'``) builds the reference's ``KDTree`` for this ONE
+      single-centre query per sphere -- the sampler's index only, never a neighbour search of the hot path.  The default
+      answers from the GPU in ascending (d2, index) order: the same SET, a different (equally arbitrary) order."""
+
+    def __init__(self, points, device, host_index=False):
         self.data = np.ascontiguousarray(points, dtype=np.float32)
         self.device = torch.device(device)
         self._dev = None
+        self._host = None
+        if host_index:
+            from sklearn.neighbors import KDTree      # the reference's own dependency (randlanet.py:8, kpconv.py:9)
+            self._host = KDTree(self.data)
 
     def _pts(self):
         if self._dev is None:
@@ -30,18 +43,18 @@ class GpuSearchTree:
         k = int(k)
         if X.shape[0] == 1 and k > 16:
             idx, d2 = ops.nearest_to_center(self._pts(), X[0], k, return_distances=True)
-            idx, d2 = idx.reshape(1, -1), d2.reshape(1, -1)
+            idx, dist = idx.reshape(1, -1), np.sqrt(d2.cpu().numpy()).reshape(1, -1)
         else:
             r = ops.knn_search(self._pts(), torch.from_numpy(X).to(self.device), k, return_distances=True)
-            idx, d2 = r.neighbors_index, r.neighbors_distance
+            idx, dist = r.neighbors_index, np.sqrt(r.neighbors_distance.cpu().numpy().astype(np.float64))
         idx = idx.cpu().numpy().astype(np.int64)
-        if not return_distance:
-            return idx
-        return np.sqrt(d2.cpu().numpy().astype(np.float64)), idx
+        return (dist, idx) if return_distance else idx
 
     def query_radius(self, X, r, **unused):
         """-> object array with one int64 index array per query row (sklearn's ``KDTree.query_radius``; used by the
         radius-based point sampler of KPConv, semseg_spatially_regular.py:86-87)."""
+        if self._host is not None:
+            return self._host.query_radius(X, r=r)
         X = np.ascontiguousarray(np.asarray(X, dtype=np.float32).reshape(-1, 3))
         res = ops.fixed_radius_search(self._pts(), torch.from_numpy(X).to(self.device), float(r))
         idx = res.neighbors_index.cpu().numpy().astype(np.int64)
@@ -52,11 +65,10 @@ class GpuSearchTree:
         return out
 
 
-def preprocess_segmentation(data, attr, grid_size, device, proj_splits=("test", "testing")):
+def preprocess_segmentation(data, attr, grid_size, device, proj_splits=("test", "testing"), host_index=False):
     """raw cloud dict -> {'point', 'feat', 'label', 'search_tree'[, 'proj_inds']} like the reference's ``preprocess``."""
     dev = torch.device(device)
-    if dev.type != 'cuda':
-        raise RuntimeError("preprocess runs on the MI355X ops; there is no CPU fallback")
+    _abi.require_gpu(dev, "preprocess (grid subsample / projection on the HIP ops)")
     points = np.array(data['point'][:, 0:3], dtype=np.float32)
     if 'label' not in data or data['label'] is None:
         labels = np.zeros((points.shape[0],), dtype=np.int32)
@@ -75,7 +87,7 @@ def preprocess_segmentation(data, attr, grid_size, device, proj_splits=("test", 
     out['point'] = sub_points.cpu().numpy()
     out['feat'] = None if sub_feat is None else sub_feat.cpu().numpy()
     out['label'] = sub_labels.cpu().numpy().astype(np.int32)
-    tree = GpuSearchTree(out['point'], dev)
+    tree = GpuSearchTree(out['point'], dev, host_index=host_index)
     tree._dev = sub_points
     out['search_tree'] = tree
     if attr['split'] in proj_splits:

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import _abi
 from ... import ops
 
 
@@ -274,8 +275,7 @@ class KPFCNN(nn.Module):
         if self.training:
             raise RuntimeError("KPFCNN (MI355X build) implements the inference forward only; call .eval()")
         dev = self.device
-        if dev.type != 'cuda':
-            raise RuntimeError("KPFCNN.forward needs an MI355X device; there is no CPU fallback")
+        _abi.require_gpu(dev, "KPFCNN.forward")
         P = self.packed_params(dev)
         lr = self.cfg.get('l_relu', 0.1)
         infl = _INFLUENCE[self.cfg.KP_influence]
@@ -330,96 +330,98 @@ class KPFCNN(nn.Module):
         """kpconv.py:353-396: grid subsample at ``first_subsampling_dl``, search structure, raw -> sub projection."""
         from ._datapath import preprocess_segmentation
         return preprocess_segmentation(data, attr, self.cfg.first_subsampling_dl, self.device,
-                                       proj_splits=("test", "testing", "validation", "valid"))
+                                       proj_splits=("test", "testing", "validation", "valid"),
+                                       host_index=self.cfg.get('sampler_index', 'gpu') == 'sklearn')
+
+    def _draw_augmentation(self, n, dim):
+        """The np.random draws of the reference's augmentation (kpconv.py:647-712), in its order -- rotation angle(s), scale,
+        symmetry flips, per-point noise -- so that a seeded run consumes the generator exactly like the reference does.
+        Returns (R [dim, dim] f32, scale [dim] f32, noise [n, dim] f32)."""
+        cfg, two_pi = self.cfg, 2 * np.pi
+        R = np.eye(dim)
+        if dim == 3 and cfg.augment_rotation == 'vertical':
+            a = np.random.rand() * two_pi
+            R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+        elif dim == 3 and cfg.augment_rotation == 'all':
+            from ._datapath import create_3D_rotations
+            a = np.random.rand() * two_pi
+            b = (np.random.rand() - 0.5) * np.pi
+            axis = np.array([np.cos(a) * np.cos(b), np.sin(a) * np.cos(b), np.sin(b)])
+            R = create_3D_rotations(axis.reshape(1, -1), (np.random.rand() * two_pi).reshape(1, -1))[0]
+        lo, hi = cfg.augment_scale_min, cfg.augment_scale_max
+        if cfg.augment_scale_anisotropic:
+            scale = np.random.rand(dim) * (hi - lo) + lo
+        else:
+            scale = np.random.rand() * (hi - lo) - lo          # sic: the reference subtracts min (kpconv.py:701)
+        flips = np.array(cfg.augment_symmetries).astype(np.int32) * np.random.randint(2, size=dim)
+        scale = (scale * (1 - flips * 2)).astype(np.float32)
+        noise = (np.random.randn(n, dim) * cfg.augment_noise).astype(np.float32)
+        return R.astype(np.float32), scale, noise
 
     def augmentation_transform(self, points, normals=None, verbose=False, is_test=False):
-        """kpconv.py:647-744 with the same ``np.random`` draw sequence; at test time the points come back untouched
-        (the draws still advance the generator, like the reference)."""
-        from ._datapath import create_3D_rotations
-        R = np.eye(points.shape[1])
-        if points.shape[1] == 3:
-            if self.cfg.augment_rotation == 'vertical':
-                theta = np.random.rand() * 2 * np.pi
-                c, s = np.cos(theta), np.sin(theta)
-                R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
-            elif self.cfg.augment_rotation == 'all':
-                theta = np.random.rand() * 2 * np.pi
-                phi = (np.random.rand() - 0.5) * np.pi
-                u = np.array([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
-                alpha = np.random.rand() * 2 * np.pi
-                R = create_3D_rotations(np.reshape(u, (1, -1)), np.reshape(alpha, (1, -1)))[0]
-        R = R.astype(np.float32)
-        min_s, max_s = self.cfg.augment_scale_min, self.cfg.augment_scale_max
-        if self.cfg.augment_scale_anisotropic:
-            scale = np.random.rand(points.shape[1]) * (max_s - min_s) + min_s
-        else:
-            scale = np.random.rand() * (max_s - min_s) - min_s
-        symmetries = np.array(self.cfg.augment_symmetries).astype(np.int32)
-        symmetries *= np.random.randint(2, size=points.shape[1])
-        scale = (scale * (1 - symmetries * 2)).astype(np.float32)
-        noise = (np.random.randn(points.shape[0], points.shape[1]) * self.cfg.augment_noise).astype(np.float32)
+        """kpconv.py:647-744: random rotation / scale / flips / noise of one input sphere -> (points, scale, R).  With
+        ``is_test`` the points come back untouched (the draws still advance ``np.random``).  NOTE the reference's pipelines
+        call ``transform`` WITHOUT ``is_test`` also at inference (torch_dataloader.py:85), i.e. the augmentation is live in
+        ``run_inference`` / ``run_test``; only the legacy ``inference_preprocess`` passes ``is_test=True``."""
+        if normals is not None:
+            raise NotImplementedError("KPFCNN (MI355X build): normals are not part of the segmentation path")
+        R, scale, noise = self._draw_augmentation(points.shape[0], points.shape[1])
         if is_test:
             return points, scale, R
-        raise NotImplementedError("KPFCNN (MI355X build): inference only; training augmentation stays on the reference")
+        return np.sum(points[:, :, None] * R, axis=1) * scale + noise, scale, R
+
+    def _crop_sphere(self, data, budget, min_pts, split, is_test):
+        """ONE input sphere around the sampler's next centre (the body of the loop of kpconv.py:446-531): recentred on the
+        centre, normalised (``trans_normalize``, ml3d/datasets/utils/transforms.py:7-26, in place on the cached features like
+        the reference), cut down to ``budget`` points at random, augmented."""
+        cloud, labels, colours = data['point'], data['label'], data['feat']
+        sphere, picked, centre = self.trans_point_sampler(pc=cloud.copy(), feat=colours, label=labels,
+                                                          search_tree=data['search_tree'], num_points=min_pts,
+                                                          radius=self.cfg.in_radius)
+        sphere = sphere - centre
+        norm = self.cfg.get('t_normalize', {})
+        axes = norm.get('recentering', [0, 1, 2])
+        sphere[:, axes] = sphere[:, axes] - sphere.mean(0)[axes]
+        method = norm.get('method', None)
+        if method == 'linear':
+            if norm.get('normalize_points', False):
+                sphere -= sphere.mean()
+                sphere /= (sphere.max(0) - sphere.min(0)).max()
+            if colours is not None:
+                colours -= norm.get('feat_bias', 0)
+                colours /= norm.get('feat_scale', 1)
+        elif method == 'coords_only':
+            colours = None
+        columns = sphere.copy() if colours is None else np.hstack((sphere, colours[picked, :]))
+        sphere_labels = labels[picked]
+        if sphere.shape[0] > budget:
+            keep = np.random.choice(sphere.shape[0], size=budget, replace=False)
+            sphere, columns, sphere_labels, picked = sphere[keep, :], columns[keep, :], sphere_labels[keep], picked[keep]
+        out_pts, scale, R = self.augmentation_transform(sphere, is_test=is_test)
+        if np.random.rand() > self.cfg.augment_color:
+            columns[:, 3:] *= 0
+        return dict(p_list=out_pts, f_list=columns, l_list=np.squeeze(sphere_labels), p0_list=centre, s_list=scale, R_list=R,
+                    r_inds_list=data['proj_inds'] if split in ['test'] else np.zeros((0,)), r_mask_list=picked,
+                    val_labels_list=labels.astype(np.int32))
 
     def transform(self, data, attr, is_test=False):
-        """kpconv.py:398-533: crop input spheres around the sampler's centres until ``min_in_points`` are collected,
-        recentre / normalise, assemble [xyz | features]; returns the reference's dict of lists (numpy).  The lists are what
-        ``KPConvBatch`` (this module: GPU neighbour / pooling build) or the reference's ``ConcatBatcher`` consume."""
-        points, sem_labels, feat, search_tree = data['point'], data['label'], data['feat'], data['search_tree']
-        result = {k_: [] for k_ in ('p_list', 'f_list', 'l_list', 'p0_list', 's_list', 'R_list', 'r_inds_list', 'r_mask_list',
-                                    'val_labels_list')}
-        result['cfg'] = self.cfg
-        curr_num_points = 0
-        max_num_points = min(self.cfg.batch_limit, self.cfg.max_in_points)
-        min_in_points = min(self.cfg.get('min_in_points', 3), self.cfg.max_in_points)
-        sampler = getattr(self, 'trans_point_sampler', None)
-        if sampler is None:
+        """kpconv.py:398-533: input spheres around the sampler's centres until ``min_in_points`` points are collected (at most
+        ``min(batch_limit, max_in_points)``); returns the reference's dict of per-sphere lists (numpy) + ``cfg``, which is
+        what ``KPConvBatch`` (this module: GPU neighbour / pooling build) or the reference's ``ConcatBatcher`` consume."""
+        if getattr(self, 'trans_point_sampler', None) is None:
             raise RuntimeError("KPFCNN.transform: set model.trans_point_sampler (the pipeline takes it from the dataset "
                                "split's sampler) or use inference_begin()")
-        while curr_num_points < min_in_points:
-            new_points = points.copy()
-            curr_new_points, mask_inds, p0 = sampler(pc=new_points, feat=feat, label=sem_labels, search_tree=search_tree,
-                                                     num_points=min_in_points, radius=self.cfg.in_radius)
-            curr_sem_labels = sem_labels[mask_inds]
-            o_labels = sem_labels.astype(np.int32)
-            curr_new_points = curr_new_points - p0
-            t_normalize = self.cfg.get('t_normalize', {})
-            dim = t_normalize.get('recentering', [0, 1, 2])          # trans_normalize (ml3d/datasets/utils/transforms.py:7-26)
-            curr_new_points[:, dim] = curr_new_points[:, dim] - curr_new_points.mean(0)[dim]
-            curr_feat = feat
-            if t_normalize.get('method', None) == 'linear':
-                if t_normalize.get('normalize_points', False):
-                    curr_new_points -= curr_new_points.mean()
-                    curr_new_points /= (curr_new_points.max(0) - curr_new_points.min(0)).max()
-                if curr_feat is not None:
-                    curr_feat -= t_normalize.get('feat_bias', 0)
-                    curr_feat /= t_normalize.get('feat_scale', 1)
-            elif t_normalize.get('method', None) == 'coords_only':
-                curr_feat = None
-            in_fts = curr_new_points.copy() if curr_feat is None else np.hstack((curr_new_points, curr_feat[mask_inds, :]))
-            in_pts, in_lbls = curr_new_points, curr_sem_labels
-            n = in_pts.shape[0]
-            residual = max_num_points - curr_num_points
-            if n > residual:
-                input_inds = np.random.choice(n, size=residual, replace=False)
-                in_pts, in_fts, in_lbls = in_pts[input_inds, :], in_fts[input_inds, :], in_lbls[input_inds]
-                mask_inds = mask_inds[input_inds]
-                n = input_inds.shape[0]
-            curr_num_points += n
-            proj_inds = data['proj_inds'] if attr['split'] in ['test'] else np.zeros((0,))
-            in_pts, scale, R = self.augmentation_transform(in_pts, is_test=is_test)
-            if np.random.rand() > self.cfg.augment_color:
-                in_fts[:, 3:] *= 0
-            result['p_list'] += [in_pts]
-            result['f_list'] += [in_fts]
-            result['l_list'] += [np.squeeze(in_lbls)]
-            result['p0_list'] += [p0]
-            result['s_list'] += [scale]
-            result['R_list'] += [R]
-            result['r_inds_list'] += [proj_inds]
-            result['r_mask_list'] += [mask_inds]
-            result['val_labels_list'] += [o_labels]
+        keys = ('p_list', 'f_list', 'l_list', 'p0_list', 's_list', 'R_list', 'r_inds_list', 'r_mask_list', 'val_labels_list')
+        result = {k_: [] for k_ in keys}
+        result['cfg'] = self.cfg
+        cap = min(self.cfg.batch_limit, self.cfg.max_in_points)
+        want = min(self.cfg.get('min_in_points', 3), self.cfg.max_in_points)
+        have = 0
+        while have < want:
+            sphere = self._crop_sphere(data, cap - have, want, attr['split'], is_test)
+            have += sphere['p_list'].shape[0]
+            for k_ in keys:
+                result[k_].append(sphere[k_])
         return result
 
     def make_batch(self, transformed):
@@ -529,8 +531,7 @@ class KPConvBatch:
 
     def __init__(self, points, lengths, cfg, features=None, rotations="random", device='cuda'):
         dev = torch.device(device)
-        if dev.type != 'cuda':
-            raise RuntimeError("KPConvBatch needs an MI355X device; there is no CPU fallback")
+        _abi.require_gpu(dev, "KPConvBatch")
         self.cfg = cfg
         pts = torch.as_tensor(points, dtype=torch.float32).to(dev).contiguous()
         lens = [int(v) for v in lengths]

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import _abi
 from ... import ops
 
 
@@ -344,8 +345,7 @@ class PointPillars(nn.Module):
         dir_cls_preds) as NCHW tensors like ``Anchor3DHead.forward``."""
         if self.training:
             raise RuntimeError("PointPillars (MI355X build) implements the inference forward only; call .eval()")
-        if self.device.type != 'cuda':
-            raise RuntimeError("PointPillars.forward needs an MI355X device; there is no CPU fallback")
+        _abi.require_gpu(self.device, "PointPillars.forward")
         points = inputs.point if hasattr(inputs, 'point') else inputs
         neck = self.extract_feats(points)
         P = self.packed_params(self.device)

@@ -133,8 +133,7 @@ class RandLANet(nn.Module):
         if self.training:
             raise RuntimeError("RandLANet (MI355X build) implements the inference forward only; call .eval()")
         dev = self.device
-        if dev.type != 'cuda':
-            raise RuntimeError("RandLANet.forward needs an MI355X device; there is no CPU fallback")
+        _abi.require_gpu(dev, "RandLANet.forward")
         coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
         pts = coords.to(dev, torch.float32).contiguous()
         feat = inputs['features'].to(dev, torch.float32).contiguous()

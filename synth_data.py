@@ -90,13 +90,9 @@ def kitti_sweep(frame_id):
     return lidar_sweep(3000 + int(frame_id), with_intensity=True)
 
 
-def toronto3d_sphere(frame_id, max_points=10000, radius=4.0, grid=0.08):
-    """KPConv / Toronto3D-shaped input sphere (SURVEY.md §8d frame 2): an urban mobile-laser-scan scene
-    (ground plane, two facades, poles, car-sized boxes; ~1000 pts/m^2 before subsampling) grid-subsampled
-    at ``grid`` and cropped to the ``max_points`` points nearest to the sphere centre within ``radius``.
-    Returns [n, 3] f32 centred on the sphere centre.  seed = 2000 + frame_id."""
-    rng = np.random.default_rng(2000 + int(frame_id))
-    R = radius * 1.05
+def _urban_scene(rng, R):
+    """Raw mobile-laser-scan scene on the square [-R, R]^2: ground plane, two facades, poles, car-sized boxes
+    (~1000 pts/m^2), float32 [n, 3] with N(0, 5 mm) noise.  Draw order is part of the golden files' seeds."""
 
     def plane(n, origin, u, v):
         a = rng.random((n, 2))
@@ -117,6 +113,29 @@ def toronto3d_sphere(frame_id, max_points=10000, radius=4.0, grid=0.08):
         parts.append(plane(5000, c + [0, s[1], 0], [s[0], 0, 0], [0, 0, s[2]]))
     pts = np.concatenate(parts).astype(np.float32)
     pts += rng.normal(0, 0.005, pts.shape).astype(np.float32)
+    return pts
+
+
+def toronto3d_tile(seed, half=6.0, density=0.25):
+    """A raw Toronto3D-shaped cloud for the segmentation PIPELINES (``run_inference`` of a whole cloud, not one sphere):
+    the urban scene on a ``2 half`` x ``2 half`` m tile, thinned to ``density`` of its ~1000 pts/m^2, with RGB features
+    in [0, 255] and labels 1..8 by height band.  Returns dict(point [n,3] f32, feat [n,3] f32, label [n] int32)."""
+    rng = np.random.default_rng(2500 + int(seed))
+    pts = _urban_scene(rng, half)
+    keep = rng.random(pts.shape[0]) < density
+    pts = np.ascontiguousarray(pts[keep], np.float32)
+    feat = rng.uniform(0, 255, (pts.shape[0], 3)).astype(np.float32)
+    label = (1 + np.clip((pts[:, 2] * 1.6).astype(np.int32), 0, 7)).astype(np.int32)
+    return dict(point=pts, feat=feat, label=label)
+
+
+def toronto3d_sphere(frame_id, max_points=10000, radius=4.0, grid=0.08):
+    """KPConv / Toronto3D-shaped input sphere (SURVEY.md §8d frame 2): an urban mobile-laser-scan scene
+    (ground plane, two facades, poles, car-sized boxes; ~1000 pts/m^2 before subsampling) grid-subsampled
+    at ``grid`` and cropped to the ``max_points`` points nearest to the sphere centre within ``radius``.
+    Returns [n, 3] f32 centred on the sphere centre.  seed = 2000 + frame_id."""
+    rng = np.random.default_rng(2000 + int(frame_id))
+    pts = _urban_scene(rng, radius * 1.05)
     sub = _grid_barycentre(pts, grid)
     centre = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 1.0], np.float32)
     d2 = ((sub - centre) ** 2).sum(1)

@@ -373,7 +373,7 @@ def nearest_to_center(points, center, k):
     c = np.ascontiguousarray(center, np.float32)
     n = len(points)
     idx = np.full(k, -1, np.int32)
-    d2 = np.zeros(k, np.float32)
+    d2 = np.zeros(k, np.float64)
     wsb = L.ml3d_nearest_to_center_workspace_bytes(n)
     ws = _ws(wsb)
     rc = L.ml3d_nearest_to_center(points.ctypes.data, n, c.ctypes.data, k, idx.ctypes.data, d2.ctypes.data, ws.ctypes.data,

@@ -170,14 +170,23 @@ def test_rotated_nms_matches_oracle(n, spread, thr):
     assert np.array_equal(emu.nms(b, s, thr), oops.nms(b, s, thr))
 
 
-def test_nearest_to_center_is_the_sampler_query_in_canonical_order():
+def test_nearest_to_center_is_the_sampler_query_in_sklearn_order():
+    """PINNED against the reference's actual dependency: semseg_spatially_regular.py:90-91 calls ``KDTree.query(centre, k)`` of
+    scikit-learn (randlanet.py:142).  Same indices in the same order, same float64 distances -- the order feeds
+    random.shuffle and the prefix subsampling of RandLANet.transform."""
+    from sklearn.neighbors import KDTree
     pts = synth_data.semantickitti_patch(9, 5000)
-    c = pts[123]
-    idx, d2 = emu.nearest_to_center(pts, c, 2048)
-    ref, rd = oops.knn_search(pts, c[None], 2048, brute=True, return_distances=True)
-    assert np.array_equal(idx, ref[0]) and np.array_equal(d2, rd[0]) and idx[0] == 123
-    idx_all, _ = emu.nearest_to_center(pts, c, 5000)
-    assert np.array_equal(np.sort(idx_all), np.arange(5000))
+    for c in (pts[123], pts[7] + np.float32(0.013), np.array([30.5, -2.25, 1.0], np.float32)):
+        idx, d2 = emu.nearest_to_center(pts, c, 2048)
+        dist, ref = KDTree(pts).query(c.reshape(1, -1), k=2048)
+        assert np.array_equal(idx, ref[0])
+        assert np.array_equal(np.sqrt(d2), dist[0])
+    idx_all, _ = emu.nearest_to_center(pts, pts[123], 5000)
+    assert idx_all[0] == 123 and np.array_equal(np.sort(idx_all), np.arange(5000))
+    # exact float64 ties (duplicated points) come back in ascending index order
+    dup = np.concatenate([pts[:50], pts[:50]])
+    idx, d2 = emu.nearest_to_center(dup, dup[3], 100)
+    assert all(idx[i] < idx[i + 1] for i in range(0, 100, 2)) and np.array_equal(d2[0::2], d2[1::2])
 
 
 def test_vote_update_follows_numpy_float16_promotion():

@@ -189,8 +189,10 @@ def test_sampler_patch_query_and_projection_and_votes():
     sub = oops.subsample(sweep, sampleDl=0.06)
     c = sub[4321]
     idx, d2 = ops.nearest_to_center(_t(sub), c, 45056, return_distances=True)
-    ref, rd = oops.knn_search(sub, c[None], 45056, brute=True, return_distances=True)
-    assert np.array_equal(idx.cpu().numpy(), ref[0]) and np.array_equal(d2.cpu().numpy(), rd[0])
+    # the reference's own search structure (randlanet.py:142): scikit-learn's KDTree, float64 order
+    from sklearn.neighbors import KDTree
+    rdist, ref = KDTree(sub).query(c.reshape(1, -1), k=45056)
+    assert np.array_equal(idx.cpu().numpy(), ref[0]) and np.array_equal(np.sqrt(d2.cpu().numpy()), rdist[0])
     # proj_inds = search_tree.query(points) (randlanet.py:147-150): 1-NN of every raw point in the sub-cloud
     proj = ops.knn_search(_t(sub), _t(sweep), 1).neighbors_index[:, 0].cpu().numpy()
     assert np.array_equal(proj, oops.knn_search(sub, sweep, 1)[:, 0])

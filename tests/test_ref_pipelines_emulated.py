@@ -1,0 +1,52 @@
+"""CPU, with the reference checkout: the REFERENCE's own ``run_inference`` pipelines (semantic_segmentation.py:122-187,
+object_detection.py:46-75), dataloader, samplers and batchers drive this repository's three model classes — resolved through
+the reference's registry from the unchanged YAML configs — with every primitive executed by the HOST EMULATION of the HIP
+library (tests/emu_runtime.py: the same .hip sources, test infrastructure), and the results are compared with the reference's
+own PyTorch-CPU models on the oracle ops for the same seeds / cloud / weights.  Row b2 ("configs and pipelines unchanged").
+The same driver runs on a GPU box at the YAML sizes (tools/gpu_ref_pipelines.sh -> profiles/r03_pipeline_*.log)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("ML3D_REFERENCE_ROOT", "/root/reference")
+DRIVER = os.path.join(ROOT, "tools", "ref_pipelines.py")
+
+pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ml3d")), reason="needs the reference checkout"),
+              pytest.mark.skipif(not emu.available(), reason="clang++ for the host emulator not found")]
+
+
+def _run(args, out):
+    env = dict(os.environ)
+    env.pop("OPEN3D_ML_ROOT", None)
+    r = subprocess.run([sys.executable, DRIVER, "--ref", REF, "--small", "--out", out] + args, cwd="/tmp", env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    return r.stdout
+
+
+def test_reference_pipelines_drive_the_native_models_and_match_the_reference_cpu_path(tmp_path):
+    out = str(tmp_path)
+    emu.lib()                                              # build the emulated library once, outside the timed subprocesses
+    ref_log = _run(["--side", "reference"], out)
+    nat_log = _run(["--side", "native", "--emu"], out)
+    for name in ("randlanet", "kpconv", "pointpillars"):
+        assert "[%s/native] model class ml3d_amd.torch.models" % name in nat_log        # the MI355X-native class ...
+        assert "pipeline class ml3d.torch.pipelines" in nat_log                         # ... under the reference's pipeline
+        assert "[%s/reference] model class ml3d.torch.models" % name in ref_log
+    for name in ("randlanet", "kpconv"):
+        a = np.load(os.path.join(out, "%s_native_small.npz" % name))
+        b = np.load(os.path.join(out, "%s_reference_small.npz" % name))
+        assert a["predict_labels"].shape == b["predict_labels"].shape and a["predict_labels"].size > 5000
+        assert (a["predict_labels"] == b["predict_labels"]).mean() >= 0.9999
+        assert np.abs(a["predict_scores"] - b["predict_scores"]).max() <= 2.0 ** -9      # float16 vote accumulator
+    a = np.load(os.path.join(out, "pointpillars_native_small.npz"))
+    b = np.load(os.path.join(out, "pointpillars_reference_small.npz"))
+    assert a["boxes"].shape == b["boxes"].shape and a["boxes"].shape[0] > 10
+    assert np.array_equal(a["labels"], b["labels"])
+    assert np.abs(a["boxes"] - b["boxes"]).max() <= 1e-3 and np.abs(a["scores"] - b["scores"]).max() <= 1e-4
