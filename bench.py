@@ -4,8 +4,9 @@
 A step = one pass of the hot path over one batch of synthetic SemanticKITTI-shaped frames: upload of the batch's xyz
 from pinned host memory (inside the timed region, on a copy stream), GPU neighbour pyramid (4x 16-NN +
 4x 1-NN, replaces the CPU knn_search calls of RandLANet.transform) and the fused RandLA-Net forward -> logits
-[B, 45056, 19].  N > 1: one process per GPU (torchrun), frames sharded across ranks (weak scaling); the only collective
-is an RCCL gather of the predicted labels to rank 0 inside the timed region (ml3d.dist.PredictionGather).
+[B, 45056, 19] -> argmax -> uint8 labels (ml3d.dist.PredictionGather, on its own stream; the same step at every N).  N > 1:
+one process per GPU (torchrun), frames sharded across ranks (weak scaling); the only collective is the RCCL gather of those
+labels to rank 0 inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline        the kernel with the longest average launch among the traced ones (the neighbour-search launch, layer-0 and layer-1
@@ -13,6 +14,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   launch stream; `roofline_other` carries the rest.  MFMA kernels: `frac` prices the flops the kernel
                   EXECUTES, `frac_reference_formulation` the flops of the reference's formulation of the same result.
   cpu_baseline    the CPU oracle (port of the reference path) on this box's host cores, best of a thread sweep.
+  latency         the model-class API (transform -> batcher -> forward -> update_probs) at the YAMLs' batch sizes 1 and 4:
+                  per-frame median / p95 over >= 200 frames (N = 1).
   workloads       BASELINE.json configs[2] / [3] (KPConv Toronto3D, PointPillars KITTI) measured in the same run (N = 1).
 """
 import argparse
@@ -137,6 +140,48 @@ def cpu_baseline(frames, sd, budget_s=24.0, max_frames=6, gpu_labels=None):
     return out
 
 
+def latency(dev, sd, frames_timed=200, frames_warm=20):
+    """Per-frame latency of the MODEL-CLASS API at the YAMLs' small batch sizes (randlanet_semantickitti.yml:38-45:
+    ``test_batch_size: 1``, ``batch_size: 4`` -- what ``run_inference`` / ``run_test`` of the reference's pipeline issue):
+    ``RandLANet.transform`` (patch sampler query + crop + recentre + GPU neighbour pyramid) -> ``DefaultBatcher`` ->
+    ``forward`` -> ``update_probs`` (softmax + float16 vote update), one synthetic SemanticKITTI sweep, host-timed with a
+    device synchronisation per step (>= 20 warm-up and >= 200 timed frames, median and p95)."""
+    import synth_data
+    from ml3d.torch.dataloaders import DefaultBatcher
+    from ml3d.torch.models import RandLANet
+    cfg = dict(CFG, grid_size=0.06, augment={"recenter": {"dim": [0, 1]}})
+    model = RandLANet(**cfg, device=dev, seed=5)
+    model.load_state_dict(sd)
+    sweep = synth_data.lidar_sweep(5000)
+    t0 = time.perf_counter()
+    model.inference_begin(dict(point=sweep, feat=None, label=np.zeros(sweep.shape[0], np.int32)))
+    torch.cuda.synchronize()
+    pre_ms = (time.perf_counter() - t0) * 1e3
+    attr = {"split": "test"}
+    collate = DefaultBatcher().collate_fn
+    out = {"api": "RandLANet.transform -> DefaultBatcher -> forward -> update_probs (float16 votes on the device)",
+           "cloud_points_raw": int(sweep.shape[0]), "cloud_points_sub": int(model.inference_data["point"].shape[0]),
+           "preprocess_ms_once_per_cloud": pre_ms, "frames_timed": frames_timed, "frames_warmup": frames_warm}
+    for B in (1, 4):
+        def step():
+            items = [{"data": model.transform(model.inference_data, attr), "attr": attr} for _ in range(B)]
+            inputs = collate(items)
+            scores = model(inputs["data"])
+            model.update_probs(inputs, scores, model.test_probs)
+            torch.cuda.synchronize()
+        for _ in range(max(1, frames_warm // B)):
+            step()
+        ts = []
+        for _ in range(max(1, frames_timed // B)):
+            t0 = time.perf_counter()
+            step()
+            ts.append((time.perf_counter() - t0) * 1e3 / B)
+        ts = np.asarray(ts)
+        out["batch_%d" % B] = {"ms_per_frame_median": float(np.median(ts)), "ms_per_frame_p95": float(np.percentile(ts, 95)),
+                               "frames_per_s": float(1e3 / np.median(ts)), "steps": int(ts.size)}
+    return out
+
+
 def synthetic_batch(rank, B, N, nd):
     """Distinct synthetic sweeps per rank, tiled by seeded z-rotations + re-shuffles to fill the batch."""
     import synth_data
@@ -169,6 +214,7 @@ def main():
                          "three-stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the KPConv / PointPillars side measurements")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (B = 1 / 4) model-API latency measurement")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
     args = ap.parse_args()
 
@@ -205,28 +251,36 @@ def main():
     sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
     overlap = not args.no_overlap
     stream = RandLAFrameStream(CFG, sd, B, N, dev, overlap=overlap)
-    host = torch.from_numpy(frames).pin_memory()          # what a data loader hands over: host xyz (in_channels = 3)
+    # what a data loader hands over: pinned host xyz (in_channels = 3).  Two DIFFERENT batches alternate (the second holds the
+    # frames in reverse order), so consecutive steps never upload / search / classify the same bytes.
+    hosts = [torch.from_numpy(frames).pin_memory(), torch.from_numpy(np.ascontiguousarray(frames[::-1])).pin_memory()]
+    step_no = [0]
     gather = mdist.PredictionGather(B, N, CFG["num_classes"], dev)
 
-    # N > 1: argmax + label gather of a step run on their OWN stream behind that step's forward.  (Making the caller's stream wait
-    # for the compute stream instead would also hold back the NEXT step's upload and neighbour search, which are ordered after
-    # the caller's stream: the search-under-forward overlap would be lost exactly when scaling is measured.)
-    post = torch.cuda.Stream(device=dev) if (world > 1 and overlap) else None
+    # Every step ends with the argmax of its scores ("forward + softmax/argmax" per frame) into a uint8 label
+    # buffer and -- the only data-path collective -- the gather of those labels to rank 0.  At N = 1 the gather degenerates to
+    # nothing, the argmax and the stream choreography are the SAME code, so N = 1 and N > 1 time the same step.  Both run on
+    # their OWN stream behind that step's forward.  (Making the caller's stream wait for the compute stream instead would
+    # also hold back the NEXT step's upload and neighbour search, which are ordered after the caller's stream: the
+    # search-under-forward overlap would be lost exactly when scaling is measured.)
+    post = torch.cuda.Stream(device=dev) if overlap else None
 
     def one_step(knn_trace=None, fwd_trace=None, done=None):
-        scores = stream.submit(host, None, knn_trace, fwd_trace, done)
-        if world > 1:      # the only data-path collective: predicted labels of every rank's frames -> rank 0
-            if post is not None:
-                with torch.cuda.stream(post):
-                    post.wait_stream(stream.compute_stream)          # this step's forward
-                    gather.push(scores)
-                # the forward that overwrites this `scores` slot (two steps on) must come after the argmax that reads it
-                stream.compute_stream.wait_stream(post)
-            else:
+        scores = stream.submit(hosts[step_no[0] & 1], None, knn_trace, fwd_trace, done)
+        step_no[0] += 1
+        if post is not None:
+            with torch.cuda.stream(post):
+                post.wait_stream(stream.compute_stream)          # this step's forward
                 gather.push(scores)
+            # the forward that overwrites this `scores` slot (two steps on) must come after the argmax that reads it
+            stream.compute_stream.wait_stream(post)
+        else:
+            gather.push(scores)
 
     def drain():
         stream.synchronize()
+        if post is not None:
+            post.synchronize()
         gather.drain()
 
     for _ in range(args.warmup):
@@ -299,7 +353,7 @@ def main():
             "config": {"workload": "RandLA-Net SemanticKITTI inference, %d synthetic 45056-point frames per step per GPU "
                                    "(randlanet_semantickitti.yml): host->device upload of xyz + GPU kNN pyramid + fused forward" % B,
                        "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world,
-                       "h2d_in_timed_region": True, "streams": 3 if overlap else 1},
+                       "h2d_in_timed_region": True, "argmax_in_timed_region": True, "streams": 4 if overlap else 1},
             "roofline": cands[0], "roofline_other": cands[1:],
         }
         if args.breakdown:
@@ -325,12 +379,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, sd, gpu_labels=gpu_labels)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_latency:
+            try:
+                out["latency"] = latency(dev, sd)
+            except Exception as e:          # a side measurement must never take the headline line down
+                out["latency"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_workloads:
             import bench_models
             wl = {}
             del stream
             torch.cuda.empty_cache()
-            sub = argparse.Namespace(steps=8, warmup=2, frames_per_step=64, no_cpu_baseline=args.no_cpu_baseline)
+            sub = argparse.Namespace(steps=20, warmup=3, frames_per_step=64, no_cpu_baseline=args.no_cpu_baseline)
             for name, fn in (("kpconv", bench_models.run_kpconv), ("pointpillars", bench_models.run_pointpillars)):
                 try:
                     wl[name] = fn(sub, 0, 1, dev, None)

@@ -14,6 +14,18 @@ import torch
 PEAK_F32_TFLOPS = 157.3
 
 
+def _traffic(key, units):
+    """HBM-side bytes per launch of the roofline op from the committed PMC passes (profiles/traffic.json: per-unit figures
+    = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / units, collected as MI355X_MICROARCH.md prescribes); None if not collected."""
+    import json
+    import os
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+        return float(tj["kernels"][key]["bytes_per_launch_per_frame"]) * units
+    except Exception:
+        return None
+
+
 class _CallTimer:
     """Wraps one function of ml3d.ops and brackets its `which`-th call of every step with HIP events."""
 
@@ -52,17 +64,25 @@ class _CallTimer:
         setattr(self.ops, self.name, self.orig)
 
 
-def _timed(step, K, W, world, dist, dev):
+def _timed(step, K, W, world, dist, dev, ev_stream=None, intervals=None):
+    """``intervals`` (list): filled with the K completion-to-completion times (ms) of the steps on ``ev_stream``."""
     for _ in range(W):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if intervals is not None else None
+    if evs:
+        evs[0].record(ev_stream() if callable(ev_stream) else ev_stream)
     t0 = time.perf_counter()
-    for _ in range(K):
+    for i in range(K):
         step()
+        if evs:
+            evs[i + 1].record(ev_stream() if callable(ev_stream) else ev_stream)
     torch.cuda.synchronize()
+    if evs:
+        intervals.extend(float(evs[i].elapsed_time(evs[i + 1])) for i in range(K))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -86,17 +106,24 @@ def run_pointpillars(args, rank, world, dev, dist):
     m = PointPillars(device=dev, **cfg)
     m.load_state_dict(sd)
     clouds_np = [W.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
-    clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]
+    # what a data loader hands over: pinned HOST sweeps; their upload is part of every timed step
+    hosts = [torch.from_numpy(c).pin_memory() for c in clouds_np]
     timer = _CallTimer(ops, "conv2d_nhwc", 1)       # 2nd conv of a step: 3x3 64->64 stride 1 on the 248 x 216 map
-    nbox = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+    n_boxes = [0]
 
     def step():
         timer.new_step()
+        clouds = [h.to(dev, non_blocking=True) for h in hosts]
         outs = m(clouds)
-        if world > 1:       # predictions only: per-sweep count of confident anchors stands in for the box list
-            nbox.copy_((outs[0].flatten(1) > 0).sum(1, keepdim=True))
-            mdist.gather_predictions(nbox, dst=0)
-    dt = _timed(step, args.steps, args.warmup, world, dist, dev)
+        # box decode + per-class rotated NMS of every sweep (Anchor3DHead.get_bboxes, point_pillars.py:945-1025): the step ends
+        # with the detections, not with the head maps
+        boxes, scores, labels = m.bbox_head.get_bboxes(*outs)
+        n_boxes[0] = sum(int(b.shape[0]) for b in boxes)
+        if world > 1:       # predictions only: every rank's [n_i, 9] rows (box, score, label) -> rank 0 (ragged gather)
+            rows = torch.cat([torch.cat([b, s[:, None], l[:, None].to(b.dtype)], 1) for b, s, l in zip(boxes, scores, labels)])
+            mdist.gather_ragged(rows.reshape(-1), dst=0)
+    iv = []
+    dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=lambda: torch.cuda.current_stream(dev), intervals=iv)
     timer.restore()
     if rank != 0:
         return None
@@ -106,15 +133,18 @@ def run_pointpillars(args, rank, world, dev, dist):
     ms = timer.mean_ms()
     out = {"metric": "point-cloud frames/sec (PointPillars KITTI inference: voxelize + pillar features + BEV backbone + heads)",
            "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_median": float(np.median(iv)),
+           "step_ms_p95": float(np.percentile(iv, 95)), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "PointPillars KITTI detection, %d synthetic KITTI-shaped sweeps per step per GPU "
-                                  "(pointpillars_kitti.yml)" % B, "frames_per_step_per_gpu": B,
+                                  "(pointpillars_kitti.yml): host->device upload + voxelize + pillar features + BEV backbone + "
+                                  "heads + box decode + rotated NMS" % B, "frames_per_step_per_gpu": B,
+                      "h2d_in_timed_region": True, "decode_nms_in_timed_region": True, "boxes_last_step": n_boxes[0],
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
            "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-                        "flops_per_launch": flops}}
+                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import pointpillars_ref as P          # the checker, used here only as the timed CPU baseline
         pts = [torch.from_numpy(c) for c in clouds_np[:1]]
@@ -147,7 +177,8 @@ def run_kpconv(args, rank, world, dev, dist):
     m.load_state_dict(sd)
     spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
     lens = [len(s) for s in spheres]
-    pts = torch.from_numpy(np.concatenate(spheres)).to(dev)
+    host_pts = torch.from_numpy(np.concatenate(spheres)).pin_memory()     # the stacked spheres of a step arrive from the HOST
+    pts = host_pts.to(dev)
     np.random.seed(0)
     overlap = not getattr(args, "no_overlap", False)
     from ml3d.engine import KPConvPipeline
@@ -158,6 +189,7 @@ def run_kpconv(args, rank, world, dev, dist):
             mdist.gather_ragged(torch.argmax(res.wait(), 1).to(torch.uint8), dst=0)
 
     def step():
+        pts = host_pts.to(dev, non_blocking=True)              # H2D inside the timed step
         if overlap:
             # the batch build of this step (9 host read-backs) on one stream under the forward of the previous step on another:
             # every timed step = one build + one forward, as in the sequential loop
@@ -167,7 +199,9 @@ def run_kpconv(args, rank, world, dev, dist):
             logits = m(batch)
             if world > 1:
                 mdist.gather_ragged(torch.argmax(logits, 1).to(torch.uint8), dst=0)
-    dt = _timed(step, args.steps, args.warmup, world, dist, dev)
+    iv = []
+    dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
+                (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     finish(pipe.flush())
     torch.cuda.synchronize()
     # the block roofline: the first resnet block's KPConv (32 -> 32 on the full-resolution layer), timed with HIP events on its
@@ -188,14 +222,17 @@ def run_kpconv(args, rank, world, dev, dist):
     ms = timer.mean_ms()
     out = {"metric": "point-cloud spheres/sec (KPConv rigid Toronto3D inference: GPU batch build + forward)",
            "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_median": float(np.median(iv)),
+           "step_ms_p95": float(np.percentile(iv, 95)), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "KPConv (rigid) Toronto3D inference, %d synthetic 10000-point input spheres per step per "
                                   "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, " (build of step i+1 overlapped with the forward of step i on two HIP streams)" if overlap else ""),
-                      "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "parallelism": "frame-parallel x%d" % world},
+                      "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
+                      "parallelism": "frame-parallel x%d" % world},
            "roofline": {"bound": "mfma", "kernel": "kp_weighted<32,1> + gemm_tile (KPConv %d->%d, %d queries x %d neighbours)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        "traffic": _traffic("kpconv_block_32_32", B), "avg_launch_ms": ms,
                         "launch_ms_samples": timer.samples_ms(), "flops_per_launch": flops}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline

@@ -334,7 +334,8 @@ int ml3d_iou_3d(const float* boxes_a, const float* boxes_b, int64_t n, int64_t m
 /* ml3d_vote_update: probs[inds[i]] = smooth*probs[inds[i]] + (1-smooth)*      */
 /*   softmax(logits[i]) on a float16 accumulator [n_cloud, classes] with the   */
 /*   numpy promotion of ml3d/torch/models/randlanet.py:420-421, 457-462        */
-/*   (float16 product, float32 sum, float16 store).  inds must be distinct.    */
+/*   (float16 product, float32 sum, float16 store).  inds must be distinct    */
+/*   (the caller keeps the last occurrence of a repeated point).               */
 /* ------------------------------------------------------------------------- */
 size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points);
 
@@ -356,7 +357,9 @@ int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, 
 /* sub_idx[l] is the prefix neighbor_idx[l][:, :n_{l+1}] — not materialised.   */
 /* All indices are item-local, as RandLANet.forward consumes them.             */
 /* The pointer tables neighbor_idx_host / interp_idx_host are HOST arrays of   */
-/* device pointers, length num_layers.                                         */
+/* device pointers, length num_layers.  1 <= num_layers <= 8                   */
+/* (ML3D_RANDLA_MAX_LAYERS; the reference's configs use 4 or 5): more is       */
+/* ML3D_E_INVALID / 0 workspace bytes.                                         */
 /* ------------------------------------------------------------------------- */
 size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0, int num_layers,
                                            const int32_t* ratios_host);

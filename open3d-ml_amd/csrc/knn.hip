@@ -154,7 +154,7 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
             }
             if (kth != KEY_EMPTY && gd > 0.f) {
                 float dk = __uint_as_float((unsigned)(kth >> 32));
-                if (SUB) {
+                if (SUB && n_sub > 0) {       // (n_sub == 0: no coarser level, the interpolation index is -1 whatever is scanned)
                     // both answers must be final: the nearest prefix point may lie beyond the k-th neighbour
                     const u64 k1 = (u64)__double_as_longlong(best1);
                     if (k1 != KEY_EMPTY) dk = fmaxf(dk, __uint_as_float((unsigned)(k1 >> 32))); else dk = 3.0e38f;
@@ -322,7 +322,7 @@ static int pyramid_sizes(int64_t n0, int num_layers, const int32_t* ratios, int6
 
 extern "C" size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0, int num_layers,
                                                       const int32_t* ratios_host) {
-    if (num_layers <= 0 || num_layers > 15 || !ratios_host) return 0;
+    if (num_layers <= 0 || num_layers > KNN_MAX_JOBS || !ratios_host) return 0;
     int64_t n[17];
     if (pyramid_sizes(n0, num_layers, ratios_host, n)) return 0;
     size_t b = 0;
@@ -354,7 +354,7 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
                                                size_t workspace_bytes, void* stream, const ml3d_trace* tr) {
     auto tb = [&](int tag) { if (tr && tr->tag == tag && tr->ev_start) (void)hipEventRecord((hipEvent_t)tr->ev_start, (hipStream_t)stream); };
     auto te = [&](int tag) { if (tr && tr->tag == tag && tr->ev_stop) (void)hipEventRecord((hipEvent_t)tr->ev_stop, (hipStream_t)stream); };
-    if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > 15 || !ratios_host || k <= 0 ||
+    if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > KNN_MAX_JOBS || !ratios_host || k <= 0 ||
         !neighbor_idx_host || !interp_idx_host)
         return ML3D_E_INVALID;
     if (k > 64) return ML3D_E_UNSUPPORTED;
@@ -392,7 +392,6 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
     // 1-NN of level l in level l + 1 (randlanet.py:224).  Level l + 1 is the prefix [:n_{l+1}] of level l, so the
     // interpolation target is simply the nearest scanned candidate with index < n_{l+1}: it rides along in the k-NN scan
     // (one extra key per lane) instead of eight searches on five grids.
-    if (num_layers > KNN_MAX_JOBS) return ML3D_E_UNSUPPORTED;
     KnnJobs Jk;
     Jk.n = 0;
     for (int l = 0; l < num_layers; ++l) {

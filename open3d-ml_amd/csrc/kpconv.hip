@@ -52,7 +52,12 @@ __device__ __forceinline__ float kp_influence(float d2, const KpArgs& A) {
 typedef float kp_v2f __attribute__((ext_vector_type(2)));
 
 // the influences of TWO kernel points at once on packed f32 (v_pk_add / v_pk_mul / v_pk_fma): the 15 x (3 sub, 3 mul, 2 add,
-// sqrt, fma, max) per (query, neighbour) pair are 40 % of the gather kernel's instructions
+// sqrt, fma, max) per (query, neighbour) pair are 40 % of the gather kernel's instructions.
+// NOTE: d2 and 1 - d / extent are FUSED here (explicit fma, unaffected by -ffp-contract=off) while the scalar
+// kp_influence above rounds every product: the two differ in the last ulp, so which kernel a layer takes (kp_small_fused /
+// kp_weighted on this form, kp_weighted_small on the scalar one) shows in the last bit of the influence weights.  KPConv
+// features are a FLOAT row of SURVEY.md §8 (tolerance 1e-4 on the logits, tests/test_gpu_kpconv.py), never a bit-exact one
+// -- unlike the index ops, whose d2 must stay unfused -- and ML3D_KP_SMALL_FUSED=0 is an A/B of speed, not of bits.
 __device__ __forceinline__ kp_v2f kp_influence2(kp_v2f dx, kp_v2f dy, kp_v2f dz, const KpArgs& A) {
     const kp_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
     if (A.influence == 0) return (kp_v2f){1.0f, 1.0f};

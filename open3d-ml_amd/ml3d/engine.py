@@ -23,12 +23,12 @@ class RandLAInferenceEngine:
         scores bit for bit, better locality of the neighbour gathers).  False / 0 = off, True = every level, an int n =
         the n finest levels only.  Default: the two finest levels (measured at 64 frames of 45 056 points, two runs each:
         5290 / 5273 frames/s off, 5483 / 5483 every level, 5563 / 5555 two levels -- the gather sets of the coarse levels
-        fit the L2 anyway and their kernels lose 7 % to the indirection); ``ML3D_TILE_ORDER`` = 0 / 1 (all) / n overrides."""
+        fit the L2 anyway and their kernels lose 7 % to the indirection).  ``ML3D_TILE_ORDER`` overrides with the SAME meaning
+        as the argument: 0 = off, n = the n finest levels, ``all`` = every level."""
         self.lib = _abi.get()
         if tile_order is None:
-            tile_order = int(os.environ.get("ML3D_TILE_ORDER", "2") or 0)
-            if tile_order == 1:
-                tile_order = True
+            env = (os.environ.get("ML3D_TILE_ORDER", "2") or "0").strip().lower()
+            tile_order = True if env == "all" else int(env)
         self.tile_levels = (int(cfg["num_layers"]) if tile_order is True else int(tile_order or 0))
         self.tile_order = self.tile_levels > 0
         self.cfg = cfg

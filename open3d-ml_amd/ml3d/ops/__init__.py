@@ -107,10 +107,12 @@ def randla_knn_pyramid(points, ratios, k, out=None, workspace=None, tile_order=N
     t_i = _abi.ptr_table([t.data_ptr() for t in itp])
     with torch.cuda.device(dev):
         if tile_order is not None:
-            if len(tile_order) != L or any(t.dtype != torch.int32 or t.numel() != B * n[l] or not t.is_contiguous()
-                                           for l, t in enumerate(tile_order)):
-                raise RuntimeError("randla_knn_pyramid: tile_order must be one contiguous int32 [B * n_l] tensor per level")
-            t_o = _abi.ptr_table([t.data_ptr() for t in tile_order])
+            # one entry per level; None = no order wanted for that level (the engine orders only the finest levels)
+            if len(tile_order) != L or any(t is not None and (t.dtype != torch.int32 or t.numel() != B * n[l] or
+                                                              not t.is_contiguous()) for l, t in enumerate(tile_order)):
+                raise RuntimeError("randla_knn_pyramid: tile_order must be one contiguous int32 [B * n_l] tensor (or None) "
+                                   "per level")
+            t_o = _abi.ptr_table([0 if t is None else t.data_ptr() for t in tile_order])
             rc = lib.ml3d_randla_knn_pyramid_ordered(points.data_ptr(), B, n0, L, r, int(k), t_n, t_i, t_o, ws.data_ptr(),
                                                      ws.numel(), _stream(), None)
         else:
@@ -150,8 +152,9 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
         if tuple(interp_idx[l].shape) not in ((B, sizes[l], 1), (B, sizes[l])):
             raise RuntimeError("randla_forward: interp_idx[%d] must be [%d, %d, 1], got %s"
                                % (l, B, sizes[l], tuple(interp_idx[l].shape)))
-        if tile_order is not None and (l >= len(tile_order) or tile_order[l].numel() != B * sizes[l]):
-            raise RuntimeError("randla_forward: tile_order[%d] must hold %d rows" % (l, B * sizes[l]))
+        if tile_order is not None and (l >= len(tile_order) or
+                                       (tile_order[l] is not None and tile_order[l].numel() != B * sizes[l])):
+            raise RuntimeError("randla_forward: tile_order[%d] must hold %d rows (or be None)" % (l, B * sizes[l]))
     if out is None:
         out = torch.empty((B, n0, desc.num_classes), dtype=torch.float32, device=dev)
     wsb = lib.ml3d_randla_forward_workspace_bytes(C.byref(desc))
@@ -163,9 +166,9 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
     with torch.cuda.device(dev):
         if tile_order is not None:
             for t in tile_order:
-                if t.dtype != torch.int32 or not t.is_contiguous() or t.device != dev:
+                if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or t.device != dev):
                     raise RuntimeError("randla_forward: tile_order tensors must be contiguous int32 on the same device")
-            t_o = _abi.ptr_table([t.data_ptr() for t in tile_order])
+            t_o = _abi.ptr_table([0 if t is None else t.data_ptr() for t in tile_order])
             rc = lib.ml3d_randla_forward_ordered(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
                                                  t_n, t_i, t_o, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), None)
         else:
@@ -773,7 +776,9 @@ def vote_update(test_probs, point_inds, logits, smooth=0.95):
     """In place: ``test_probs[inds] = smooth * test_probs[inds] + (1 - smooth) * softmax(logits)`` on the float16
     vote accumulator [N_cloud, classes] (ml3d/torch/models/randlanet.py:420-421, 457-462).
     ONE batch item per call: every wave does an unsynchronised read-modify-write of its point's row, so the indices of a
-    call must be unique (a patch never lists a point twice).  Patches of a batch that share points are applied by calling
+    call MUST be unique.  A patch padded with repeated points (cloud smaller than num_points) is de-duplicated by the caller,
+    keeping each point's last occurrence = numpy's fancy-assignment result (``RandLANet.update_probs``).  Patches of a batch
+    that share points are applied by calling
     this once per item, in order, on one stream -- what ``RandLANet.update_probs`` / ``KPFCNN.update_probs`` do and what
     the reference's sequential loop (randlanet.py:455-463) means."""
     lib = _abi.get()

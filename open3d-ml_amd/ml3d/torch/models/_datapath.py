@@ -33,6 +33,14 @@ class GpuSearchTree:
             from sklearn.neighbors import KDTree      # the reference's own dependency (randlanet.py:8, kpconv.py:9)
             self._host = KDTree(self.data)
 
+    def __getstate__(self):
+        """The reference's dataloader caches ``preprocess`` results with ``np.save`` (pickle; ml3d/utils/dataset_helper.py:
+        65-69) and re-reads the file for every patch: only host state is stored, the device copy is rebuilt on first use."""
+        return dict(data=self.data, device=str(self.device), host=self._host)
+
+    def __setstate__(self, st):
+        self.data, self.device, self._host, self._dev = st['data'], torch.device(st['device']), st['host'], None
+
     def _pts(self):
         if self._dev is None:
             self._dev = torch.from_numpy(self.data).to(self.device)

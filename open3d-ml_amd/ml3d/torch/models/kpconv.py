@@ -113,7 +113,9 @@ def default_kernel_points(radius, K=15):
 def _block_decider(block_name, radius, in_dim, out_dim, layer_ind, cfg):
     """kpconv.py:1171-1210, rigid subset."""
     if 'deformable' in block_name or 'equivariant' in block_name or 'invariant' in block_name:
-        raise NotImplementedError("KPFCNN (MI355X build): block '%s' is outside the rigid-KPConv scope" % block_name)
+        raise NotImplementedError("KPFCNN (MI355X build): block '%s' is outside the rigid-KPConv scope.  With an Open3D-ML "
+                                  "checkout (OPEN3D_ML_ROOT) the `open3d.ml.torch` registry falls back to the checkout's "
+                                  "PyTorch KPFCNN for such configs; standalone there is no implementation" % block_name)
     if block_name == 'unary':
         return UnaryBlock(in_dim, out_dim, cfg.use_batch_norm, cfg.batch_norm_momentum, l_relu=cfg.get('l_relu', 0.1))
     if block_name in ('simple', 'simple_strided'):
@@ -425,32 +427,9 @@ class KPFCNN(nn.Module):
         return result
 
     def make_batch(self, transformed):
-        """``ConcatBatcher.collate_fn`` for ONE transformed cloud (concat_batcher.py:120-184 feature selection +
-        ``segmentation_inputs``), with the neighbour / pooling matrices built on the GPU (``KPConvBatch``)."""
-        pts = np.concatenate(transformed['p_list'], 0).astype(np.float32)
-        fts = np.concatenate(transformed['f_list'], 0).astype(np.float32)
-        lens = [int(p.shape[0]) for p in transformed['p_list']]
-        ones = np.ones_like(pts[:, :1], dtype=np.float32)
-        d = self.cfg.in_features_dim
-        if d == 1:
-            feats = ones
-        elif d == 2:
-            feats = np.hstack((ones, fts[:, 2:3]))
-        elif d == 3:
-            feats = fts[:, 3:6]
-        elif d == 4:
-            feats = np.hstack((ones, fts[:, 3:6]))
-        elif d == 5:
-            feats = np.hstack((ones, fts[:, 2:3], fts[:, 3:6]))
-        elif d >= 6:
-            feats = np.hstack((ones, fts))
-        else:
-            raise ValueError("in_features_dim must be >= 1")
-        b = KPConvBatch(pts, lens, self.cfg, features=feats, device=self.device)
-        b.labels = torch.from_numpy(np.concatenate([np.atleast_1d(l) for l in transformed['l_list']]).astype(np.int64))
-        b.reproj_inds, b.reproj_masks = transformed['r_inds_list'], transformed['r_mask_list']
-        b.val_labels = transformed['val_labels_list']
-        return b
+        """``ConcatBatcher.collate_fn`` for ONE transformed cloud -> the GPU ``KPConvBatch`` (``ml3d.torch.dataloaders``)."""
+        from ..dataloaders import ConcatBatcher
+        return ConcatBatcher(self.device, 'KPFCNN').collate_fn([{'data': transformed, 'attr': {}}])['data']
 
     def update_probs(self, inputs, results, test_probs):
         """kpconv.py:560-587: per input sphere, smooth the votes of the points it covers (float16 accumulator)."""
@@ -593,6 +572,21 @@ class KPConvBatch:
             layer_blocks = []
             if 'global' in block or 'upsample' in block:
                 break
+
+
+def _kpconv_batch_to(self, device):
+    """``KPConvBatch.to`` of the reference (concat_batcher.py:327-341; the pipelines call it, semantic_segmentation.py:236):
+    the matrices are built on the device already -- only a different device would mean a copy."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and self.points and self.points[0].device != dev and dev.index is not None:
+        for name in ('points', 'neighbors', 'pools', 'upsamples'):
+            setattr(self, name, [t.to(dev) for t in getattr(self, name)])
+        self.features = self.features.to(dev)
+    return self
+
+
+KPConvBatch.to = _kpconv_batch_to
+KPConvBatch.pin_memory = lambda self: self
 
 
 def random_grid_rotations(B):

@@ -235,9 +235,17 @@ class RandLANet(nn.Module):
         inds_all = inputs['data']['point_inds']
         for b in range(results.size()[0]):
             logits = torch.reshape(results[b], (-1, self.cfg.num_classes)).to(dev, torch.float32).contiguous()
-            inds = torch.as_tensor(np.asarray(inds_all[b].cpu() if isinstance(inds_all[b], torch.Tensor) else inds_all[b]),
-                                   dtype=torch.int32).to(dev)
-            ops.vote_update(tp, inds, logits, self.test_smooth)
+            inds = np.asarray(inds_all[b].cpu() if isinstance(inds_all[b], torch.Tensor) else inds_all[b]).reshape(-1)
+            if inds.size > tp.shape[0] or (inds.size and np.bincount(inds).max() > 1):
+                # a cloud smaller than num_points: the sampler pads the patch with REPEATED points
+                # (semseg_spatially_regular.py:80-84).  numpy's ``test_probs[inds] = f(test_probs[inds])`` reads every row's
+                # OLD value first and the LAST occurrence's write wins; the kernel updates rows in place, one wave per listed
+                # row, so it gets each point once -- its last occurrence.
+                _, first_in_reversed = np.unique(inds[::-1], return_index=True)
+                keep = np.sort(inds.size - 1 - first_in_reversed)
+                inds = inds[keep]
+                logits = logits[torch.from_numpy(keep).to(dev)].contiguous()
+            ops.vote_update(tp, torch.as_tensor(inds, dtype=torch.int32).to(dev), logits, self.test_smooth)
         return tp.cpu().numpy() if on_host else tp
 
     # ---- legacy single-cloud API (randlanet.py:382-439): the pipeline does not use it, but it is part of BaseModel ----
@@ -268,8 +276,7 @@ class RandLANet(nn.Module):
         pc = pc[idxs]
         dists = np.sum(np.square((pc - center_point).astype(np.float32)), axis=1)
         delta = np.square(1 - dists / np.max(dists))
-        np.add.at(self.possibility, idxs, delta) if pc.shape[0] > search_tree.data.shape[0] else \
-            self.possibility.__setitem__(idxs, self.possibility[idxs] + delta)
+        self.possibility[idxs] += delta       # plain fancy +=, like the reference: a padded (repeated) point is bumped ONCE
         return pc, idxs, center_point
 
     def inference_preprocess(self):

@@ -17,12 +17,35 @@ if _checkout():
     from ml3d.utils import Config, get_module   # noqa: F401
 
     def _register_native_models():
-        from ml3d.utils import MODEL
-        from ... import _product
         import importlib
+        import logging
+        from ml3d.utils import MODEL
+        from ml3d.torch.models.kpconv import KPFCNN as _ReferenceKPFCNN
+        from ... import _product
         _product.product()
         native = importlib.import_module("ml3d_amd.torch.models")
-        for cls in (native.RandLANet, native.KPFCNN, native.PointPillars):
+
+        class KPFCNN(native.KPFCNN):
+            """The registry entry for ``KPFCNN``: the MI355X-native class for rigid architectures; configs with
+            ``*_deformable*`` blocks (only ml3d/configs/kpconv_parislille3d.yml:28-32) are outside the rigid scope and FALL
+            BACK to the checkout's own PyTorch ``KPFCNN`` (kpconv.py:1011-1041, 1071-1103), which then runs on PyTorch-ROCm
+            with its neighbour searches / subsampling served by the native ops of this shim."""
+            _warned = False
+
+            def __new__(cls, *args, **kwargs):
+                arch = kwargs.get("architecture", None)
+                if arch is not None and any("deformable" in str(b) for b in arch):
+                    if not KPFCNN._warned:
+                        logging.getLogger(__name__).warning(
+                            "KPFCNN: deformable KPConv blocks are outside the MI355X-native (rigid) scope; using the "
+                            "Open3D-ML checkout's PyTorch KPFCNN on the native ops instead")
+                        KPFCNN._warned = True
+                    return _ReferenceKPFCNN(*args, **kwargs)
+                return super().__new__(cls)
+
+        KPFCNN.__module__ = native.KPFCNN.__module__
+        KPFCNN.__qualname__ = "KPFCNN"
+        for cls in (native.RandLANet, KPFCNN, native.PointPillars):
             MODEL._register_module(cls, "torch")
             setattr(models, cls.__name__, cls)
 

@@ -13,20 +13,16 @@ from oracle import randlanet_ref as R
 
 pytestmark = pytest.mark.gpu
 
-CFG = dict(num_neighbors=16, num_layers=4, num_points=4096, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
-           dim_features=8, dim_output=[16, 64, 128, 256], grid_size=0.3, augment={'recenter': {'dim': [0, 1]}})
+# the model section of randlanet_semantickitti.yml: 45 056-point patches, 0.06 m grid
+CFG = dict(num_neighbors=16, num_layers=4, num_points=45056, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+           dim_features=8, dim_output=[16, 64, 128, 256], grid_size=0.06, augment={'recenter': {'dim': [0, 1]}})
 
 
-class _OracleTree:
-    """CPU stand-in with the sklearn ``KDTree`` calls the samplers make, on the oracle's exact (d2, index) order."""
-
-    def __init__(self, pts):
-        self.data = pts
-
-    def query(self, X, k=1, return_distance=True):
-        idx, d2 = oops.knn_search(self.data, np.asarray(X, np.float32).reshape(-1, 3), k, brute=k > 64, return_distances=True)
-        idx = idx.astype(np.int64)
-        return (np.sqrt(d2.astype(np.float64)), idx) if return_distance else idx
+def _OracleTree(pts):
+    """The reference's own search structure (randlanet.py:142): scikit-learn's KDTree.  The patch query must come back in
+    ITS order (float64 distances) -- the order feeds the shuffle and the prefix subsampling."""
+    from sklearn.neighbors import KDTree
+    return KDTree(pts)
 
 
 def _make_sampler(possibility, seed):
@@ -71,7 +67,7 @@ def test_randlanet_cloud_to_labels_matches_the_oracle_path():
     assert np.array_equal(got['point'], ref['point']) and np.array_equal(got['label'], ref['label'])
     assert np.array_equal(got['proj_inds'], ref['proj_inds'])
     n = got['point'].shape[0]
-    assert n > 2 * CFG['num_points']
+    assert n > 1.5 * CFG['num_points']
 
     # ---- sampler loop: transform -> forward -> update_probs, 6 patches, both paths from identical sampler state -------------
     poss_g = np.random.default_rng(9).random(n) * 1e-3
@@ -80,7 +76,7 @@ def test_randlanet_cloud_to_labels_matches_the_oracle_path():
     samp_o = _make_sampler(poss_o, 123)
     probs_g = np.zeros((n, CFG['num_classes']), np.float16)
     probs_o = np.zeros((n, CFG['num_classes']), np.float16)
-    for step in range(6):
+    for step in range(3):
         inp = model.transform(got, attr)
         # oracle path: same crop, recentre, pyramid on the CPU oracle
         pc, idxs, _ = samp_o(ref['point'].copy(), None, ref['label'], ref['search_tree'], CFG['num_points'])
@@ -104,7 +100,7 @@ def test_randlanet_cloud_to_labels_matches_the_oracle_path():
         probs_o[idxs] = 0.95 * probs_o[idxs] + (1 - 0.95) * p
     assert np.array_equal(poss_g, poss_o)
     d = np.abs(probs_g.astype(np.float32) - probs_o.astype(np.float32))
-    assert d.max() <= 2 ** -9            # float16 accumulator: at most an ulp or two apart after six updates
+    assert d.max() <= 2 ** -9            # float16 accumulator: at most an ulp or two apart after three updates
     seen = probs_o.sum(1) > 0
     lab_g = np.argmax(probs_g, 1)[got['proj_inds']]
     lab_o = np.argmax(probs_o, 1)[ref['proj_inds']]

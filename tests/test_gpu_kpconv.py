@@ -135,3 +135,52 @@ def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
         assert len(outs) == len(seq)
         for a, b in zip(outs, seq):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_per_sphere():
+    """The configuration bench.py --workload kpconv times: 64 input spheres (~640 000 points) per batch through
+    ``KPConvPipeline``.  Only at this size are the register-blocked GEMM (>= 256 workgroups), deep split-K, the 32-bit offset
+    epilogue (wf is 1.2 GB) and the three-launch scans selected.  Batch items are independent (per-item grid rotations), so
+    spheres {0, 31, 63} are checked one by one against the oracle run on that sphere alone with the same rotation: every
+    points / neighbours / pools / upsamples matrix exact (after removing the item's row offset; the batch's extra columns
+    must be shadow entries), logits <= 1e-4."""
+    from ml3d.engine import KPConvPipeline
+    B = 64
+    spheres = [synth_data.toronto3d_sphere(i) for i in range(B)]          # the bench's spheres (rank 0)
+    lens = [len(s) for s in spheres]
+    dev = torch.device("cuda:0")
+    pts = torch.from_numpy(np.concatenate(spheres)).to(dev)
+    sd = K.make_state_dict(CFG, 2024)
+    m = _model(sd)
+    np.random.seed(0)
+    pipe = KPConvPipeline(m, CFG, dev)
+    assert pipe.submit(pts, lens) is None
+    res = pipe.flush()
+    logits = res.wait().cpu().numpy()
+    torch.cuda.synchronize()
+    batch = res.batch
+    L = CFG["num_layers"]
+    blens = [batch.lengths[l].numpy().astype(np.int64) for l in range(L)]
+    offs = [np.concatenate([[0], np.cumsum(x)]) for x in blens]
+    assert logits.shape == (sum(lens), CFG["num_classes"]) and np.isfinite(logits).all()
+    for i in (0, 31, 63):
+        rots = [None if R is None else R[i:i + 1] for R in batch.rotations]      # this item's grid orientations
+        seg = K.segmentation_inputs(spheres[i], [lens[i]], CFG, rotations=rots)
+        for l in range(L):
+            a, b = offs[l][i], offs[l][i + 1]
+            assert np.array_equal(batch.points[l][a:b].cpu().numpy(), seg["points"][l]), (i, l)
+
+            def same(mat, ref, q_off, s_off, s_tot, s_len):
+                """item rows of a batch matrix vs the single-sphere matrix: global -> local indices, shadow -> local shadow"""
+                got = mat[q_off[0]:q_off[1]].cpu().numpy().astype(np.int64)
+                loc = np.where(got == s_tot, s_len, got - s_off)
+                w = ref.shape[1]
+                assert loc.shape[1] >= w and np.array_equal(loc[:, :w], ref) and (loc[:, w:] == s_len).all(), (i, l)
+            same(batch.neighbors[l], seg["neighbors"][l], (a, b), a, offs[l][-1], b - a)
+            if l + 1 < L:
+                c, d = offs[l + 1][i], offs[l + 1][i + 1]
+                same(batch.pools[l], seg["pools"][l], (c, d), a, offs[l][-1], b - a)
+                same(batch.upsamples[l], seg["upsamples"][l], (a, b), c, offs[l + 1][-1], d - c)
+        ref = K.forward(sd, CFG, K.to_torch_batch(seg), torch.ones((lens[i], 1))).numpy()
+        a, b = offs[0][i], offs[0][i + 1]
+        assert np.abs(logits[a:b] - ref).max() <= TOL, (i, float(np.abs(logits[a:b] - ref).max()))

@@ -94,3 +94,32 @@ def test_get_bboxes_decode_and_hip_nms_match_reference_golden(golden_dir):
         assert np.array_equal(labels[i].cpu().numpy(), g["labels%d" % i])
         assert np.abs(scores[i].cpu().numpy() - g["scores%d" % i]).max() <= 1e-6
         assert np.abs(boxes[i].cpu().numpy() - g["boxes%d" % i]).max() <= 1e-4
+
+
+def test_bench_configuration_16_sweeps_matches_the_oracle_on_sweeps_0_and_15():
+    """The configuration bench.py --workload pointpillars times: 16 KITTI-shaped sweeps per forward.  Only at this size do the
+    SECOND convolutions take the 128 x 128 register-blocked tiles everywhere (>= 256 workgroups on the 62 x 54 and 31 x 27
+    maps) and the canvas / neck offsets pass 2^31 bytes.  The head maps of the first and the last sweep of the batch against
+    the oracle's forward of those two sweeps (<= 1e-4), and their detections (decode + rotated NMS) against the oracle's
+    ``get_bboxes`` on the oracle's maps."""
+    cfg = P.KITTI_CFG
+    sd = P.make_state_dict(cfg, 2024)
+    clouds = _clouds(cfg, range(16))                                   # the bench's sweeps (rank 0)
+    m = _model(cfg, sd)
+    outs = m([torch.from_numpy(c).cuda() for c in clouds])
+    torch.cuda.synchronize()
+    pick = [0, 15]
+    ref, _ = P.forward(sd, cfg, [torch.from_numpy(clouds[i]) for i in pick])
+    for a, b in zip(outs, ref):
+        assert a.shape[0] == 16 and a.shape[1:] == b.shape[1:]
+        assert (a[pick].cpu() - b).abs().max().item() <= TOL
+    boxes, scores, labels = m.bbox_head.get_bboxes(*outs)          # the whole batch decodes (what the bench step ends with)
+    assert len(boxes) == 16 and all(b.shape[1] == 7 and b.shape[0] == s.shape[0] == l.shape[0]
+                                    for b, s, l in zip(boxes, scores, labels))
+    # decode + NMS on IDENTICAL inputs (the oracle's maps: a 1e-4 difference of the maps may swap the 100th / 101st candidate)
+    gb, gs, gl = m.bbox_head.get_bboxes(*[t.cuda() for t in ref])
+    for j in range(len(pick)):
+        rb, rs, rl = P.get_bboxes_single(cfg, ref[0][j], ref[1][j], ref[2][j])
+        assert np.array_equal(gl[j].cpu().numpy(), rl.numpy()), j
+        assert np.abs(gs[j].cpu().numpy() - rs.numpy()).max() <= 1e-5
+        assert np.abs(gb[j].cpu().numpy() - rb.numpy()).max() <= 1e-3

@@ -95,3 +95,41 @@ def test_reference_configs_and_registry_resolve_against_the_shim():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RESOLVED" in r.stdout
+
+
+_DEFORMABLE = r'''
+import os, sys, types
+import torch.utils as _tu
+_tb = types.ModuleType("torch.utils.tensorboard")
+_tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
+sys.modules["torch.utils.tensorboard"] = _tb
+_tu.tensorboard = _tb
+import open3d.ml as _ml3d
+import open3d.ml.torch as ml3d
+os.chdir(%(tmp)r)                      # the reference KPFCNN caches its kernel dispositions in the working directory
+cfg = _ml3d.utils.Config.load_from_file(os.path.join(%(ref)r, "ml3d", "configs", "kpconv_parislille3d.yml"))
+assert any("deformable" in b for b in cfg.model.architecture)
+Model = _ml3d.utils.get_module("model", cfg.model.name, "torch")
+assert Model.__module__.startswith("ml3d_amd.torch.models")            # the registry entry is this repository's ...
+m = Model(**cfg.model, device="cpu")
+assert type(m).__module__ == "ml3d.torch.models.kpconv", type(m)        # ... and hands deformable configs to the checkout's class
+assert any("Deformable" in type(b).__name__ or getattr(getattr(b, "KPConv", None), "deformable", False) for b in m.encoder_blocks)
+cfg2 = _ml3d.utils.Config.load_from_file(os.path.join(%(ref)r, "ml3d", "configs", "kpconv_toronto3d.yml"))
+m2 = Model(**cfg2.model, device="cpu")
+assert type(m2).__module__.startswith("ml3d_amd.torch.models"), type(m2)   # rigid configs stay native
+print("FALLBACK-OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ml3d")), reason="needs the reference checkout (absent on the GPU box)")
+def test_deformable_kpconv_config_falls_back_to_the_checkouts_model(tmp_path):
+    """SURVEY.md §8: kpconv_parislille3d.yml (the only config with *_deformable* blocks) must fall back to the PyTorch path
+    rather than fail; standalone (no checkout) the native class refuses with that instruction."""
+    env = dict(os.environ, OPEN3D_ML_ROOT=REF, PYTHONPATH=os.pathsep.join([PKG, os.path.join(ROOT, "tests", "stubs")]))
+    r = subprocess.run([sys.executable, "-c", _DEFORMABLE % {"ref": os.path.abspath(REF), "tmp": str(tmp_path)}], env=env,
+                       cwd="/tmp", capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "FALLBACK-OK" in r.stdout
+    from ml3d.torch.models import KPFCNN
+    with pytest.raises(NotImplementedError, match="OPEN3D_ML_ROOT"):
+        KPFCNN(architecture=["simple", "resnetb_deformable", "nearest_upsample", "unary"], device="cpu")

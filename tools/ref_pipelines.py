@@ -179,11 +179,11 @@ def run_one(name, side, utils, dev, ref, small, out_dir, sampler_index="sklearn"
         out["boxes"] = np.array([b.to_xyzwhlr() for b in boxes], np.float32).reshape(-1, 7)
         out["scores"] = np.array([b.confidence for b in boxes], np.float32)
         out["labels"] = np.array([model.name2lbl.get(b.label_class, -1) for b in boxes], np.int64)
-        print("[%s/%s] %d boxes in %.2f s" % (name, side, len(boxes), dt), flush=True)
+        print("\n[%s/%s] %d boxes in %.2f s" % (name, side, len(boxes), dt), flush=True)
     else:
         out["predict_labels"] = np.asarray(res["predict_labels"]).astype(np.int64)
         out["predict_scores"] = np.asarray(res["predict_scores"]).astype(np.float32)
-        print("[%s/%s] %d points labelled in %.2f s; label histogram %s" % (
+        print("\n[%s/%s] %d points labelled in %.2f s; label histogram %s" % (
             name, side, out["predict_labels"].shape[0], dt, np.bincount(out["predict_labels"]).tolist()), flush=True)
     os.makedirs(out_dir, exist_ok=True)
     np.savez_compressed(os.path.join(out_dir, "%s_%s%s.npz" % (name, side, "_small" if small else "")), **out)
