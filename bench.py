@@ -105,7 +105,8 @@ def cpu_baseline(frames, sd, budget_s=24.0, max_frames=6, gpu_labels=None):
 
     sweep = {}
     t_sweep0 = time.perf_counter()
-    for nt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+    # (capped at 64 threads: on the 256-thread GPU box one frame at 256 threads took 44 s in round 2 -- pure oversubscription)
+    for nt in sorted({t for t in (8, 16, 32, 64, min(ncpu, 64)) if t <= ncpu}):
         torch.set_num_threads(nt)
         sweep[nt] = one(0)[0]
         if time.perf_counter() - t_sweep0 > budget_s * 0.5:
@@ -171,11 +172,21 @@ def latency(dev, sd, frames_timed=200, frames_warm=20):
             torch.cuda.synchronize()
         for _ in range(max(1, frames_warm // B)):
             step()
+        prof = None
+        if os.environ.get("ML3D_BENCH_PROFILE"):        # debugging aid: where the host time of a step goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         ts = []
         for _ in range(max(1, frames_timed // B)):
             t0 = time.perf_counter()
             step()
             ts.append((time.perf_counter() - t0) * 1e3 / B)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            print("---- latency profile, batch %d ----" % B, file=sys.stderr)
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(22)
         ts = np.asarray(ts)
         out["batch_%d" % B] = {"ms_per_frame_median": float(np.median(ts)), "ms_per_frame_p95": float(np.percentile(ts, 95)),
                                "frames_per_s": float(1e3 / np.median(ts)), "steps": int(ts.size)}
@@ -200,6 +211,9 @@ def synthetic_batch(rank, B, N, nd):
 
 
 def main():
+    if os.environ.get("ML3D_BENCH_WATCHDOG"):          # debugging aid: python tracebacks of every thread after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ML3D_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -218,6 +232,10 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
     args = ap.parse_args()
 
+    # host-side glue (collate, small CPU tensor ops) must not fan out over every core of a 256-thread host: an OpenMP
+    # fork-join across 256 threads costs milliseconds per tiny op, and 8 ranks share the node (cpu_baseline runs its own sweep)
+    HOST_THREADS = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)))))
+    torch.set_num_threads(HOST_THREADS)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -377,6 +395,7 @@ def main():
             torch.cuda.synchronize()
             gpu_labels = torch.argmax(sc[:6], dim=2).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(frames, sd, gpu_labels=gpu_labels)
+            torch.set_num_threads(HOST_THREADS)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_latency:

@@ -303,6 +303,34 @@ int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_thres
              void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Anchor3DHead.get_bboxes for a whole batch — replaces the */
+/* per-sample, per-class loop of ml3d/torch/models/point_pillars.py:945-1025   */
+/* (sigmoid / top nms_pre / BBoxCoder.decode, objdet_helper.py:286-313 /       */
+/* multiclass_nms, objdet_helper.py:316-350 / direction fix) without a host    */
+/* read-back per class.  Head maps in the reference's NCHW layout:             */
+/*   cls [B, A*C, H, W], reg [B, A*7, H, W], dir [B, A*2, H, W]; anchors       */
+/*   [H*W*A, 7] in (h, w, a) order (Anchor3DRangeGenerator.grid_anchors).      */
+/* ml3d_pp_anchor_scores: out_scores [B, H*W*A] = max_c sigmoid(cls) — the key */
+/*   of the nms_pre top-k (point_pillars.py:985-992), which the caller takes.  */
+/* ml3d_pp_boxes: candidates [B, k] int64 anchor indices (k <= 4096) ->        */
+/*   out_rows [B, C*k, 9] f32 = (x, y, z, w, l, h, yaw, score, label) of the   */
+/*   kept boxes, class-major and in NMS order like the reference's torch.cat,  */
+/*   out_total [B] int32 = rows used per sample.  A candidate takes part in    */
+/*   class c iff score_c > score_threshold; rotated-BEV IoU > iou_threshold    */
+/*   suppresses (greedy, descending score, ties by candidate index).           */
+/* ------------------------------------------------------------------------- */
+int ml3d_pp_anchor_scores(const float* cls_nchw, int64_t batch, int num_anchors, int num_classes,
+                          int64_t hw, float* out_scores, void* stream);
+
+size_t ml3d_pp_boxes_workspace_bytes(int64_t batch, int64_t k, int num_classes);
+
+int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const float* dir_nchw,
+                  const float* anchors, const int64_t* candidates, int64_t batch, int64_t k,
+                  int num_anchors, int num_classes, int64_t hw, float score_threshold,
+                  float iou_threshold, float dir_offset, float* out_rows, int32_t* out_total,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* pairwise rotated box IoU for the detection metric —       */
 /* replaces open3d.ml.contrib.iou_bev_{cpu,cuda} / iou_3d_{cpu,cuda}           */
 /*   ml3d/metrics/mAP.py:85-88, ml3d/metrics/__init__.py:3-9,                  */

@@ -90,20 +90,26 @@ template <int K, bool SUB>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
                                         float* __restrict__ out_d2, int64_t t, int n_sub = 0,
-                                        int32_t* __restrict__ out_sub = nullptr) {
-    if (t >= Q.n_total) return;
-    int s; int64_t local;
-    float qx, qy, qz;
-    seg_locate(Q.segs, t, s, local);
-    if (Q.sorted_q) {
-        float4 q = Q.sorted_q[t];
-        qx = q.x; qy = q.y; qz = q.z;
-        local = __float_as_int(q.w);
-    } else {
-        const float* p = Q.raw + 3 * (seg_begin_global(Q.segs, s) + local);
-        qx = p[0]; qy = p[1]; qz = p[2];
+                                        int32_t* __restrict__ out_sub = nullptr, int* __restrict__ stage = nullptr) {
+    // stage: LDS, 64 * 17 + 128 ints per wave of the workgroup, for the transposed store of 16 indices per query (below)
+    const bool transposed = K == 16 && k == 16 && !out_d2 && stage;
+    const bool active = t < Q.n_total;
+    if (!active && !transposed) return;           // (with the transposed store an idle lane of a ragged last wave still
+    int s = 0; int64_t local = 0;                 //  helps to write the rows of the others)
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int64_t out_row = -1;
+    if (active) {
+        seg_locate(Q.segs, t, s, local);
+        if (Q.sorted_q) {
+            float4 q = Q.sorted_q[t];
+            qx = q.x; qy = q.y; qz = q.z;
+            local = __float_as_int(q.w);
+        } else {
+            const float* p = Q.raw + 3 * (seg_begin_global(Q.segs, s) + local);
+            qx = p[0]; qy = p[1]; qz = p[2];
+        }
+        out_row = seg_begin_packed(Q.segs, s) + local;
     }
-    int64_t out_row = seg_begin_packed(Q.segs, s) + local;
 
     const GridSeg g = G.segs[s];
     double best[K];
@@ -111,7 +117,7 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
     for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
     double best1 = __longlong_as_double((long long)KEY_EMPTY);
 
-    if (g.n > 0) {
+    if (active && g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
         int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
         int cz = cell_coord(qz, g.lo[2], g.inv_c, g.dims[2]);
@@ -164,9 +170,33 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
         }
     }
     int64_t base = index_local ? 0 : seg_begin_global(support_segs, s);
-    if (SUB) {
+    if (SUB && active) {
         const u64 k1 = (u64)__double_as_longlong(best1);
         out_sub[out_row] = k1 != KEY_EMPTY ? (int32_t)(unsigned)(k1 & 0xffffffffull) : -1;
+    }
+    if (transposed) {
+        // The queries of a wave sit in cell-sorted order, their result rows anywhere: 16 stores of 4 bytes per lane at a
+        // 64-byte stride are 64 partial-line writes per instruction (WRITE_SIZE 2x the index bytes, profiles/r02_pmc_write).
+        // Transposed through a wave-private LDS patch [64 rows][16 + 1] instead, every store instruction writes four WHOLE
+        // 64-byte rows (16 lanes x 4 bytes each).
+        const int lane = threadIdx.x & 63;
+        int* patch = stage + (threadIdx.x >> 6) * (64 * 17 + 64 * 2);
+        long long* rows = (long long*)(patch + 64 * 17);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u64 key = (u64)__double_as_longlong(best[j]);
+            patch[lane * 17 + j] = key != KEY_EMPTY ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
+        }
+        rows[lane] = out_row;
+        wave_lds_sync();
+        const int col = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = i * 4 + (lane >> 4);
+            const long long row = rows[r];
+            if (row >= 0) out_idx[row * 16 + col] = patch[r * 17 + col];
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -204,6 +234,9 @@ struct KnnJobs {
     int n;
 };
 
+#ifndef ML3D_KNN_TRANSPOSED_STORE
+#define ML3D_KNN_TRANSPOSED_STORE 1      // A/B switch of the build (tools/build_variant.sh): 0 = per-lane stores of round 2
+#endif
 #ifndef KNN_WAVES
 #define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
 #endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
@@ -213,13 +246,15 @@ __global__ void __launch_bounds__(256)
 ML3D_WAVES_PER_SIMD(KNN_WAVES)
 #endif
 knn_query_multi(KnnJobs J, int k, int index_local) {
+    __shared__ int stage[K == 16 ? 4 * (64 * 17 + 64 * 2) : 1];
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
     knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
-                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub);
+                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub,
+                    K == 16 && ML3D_KNN_TRANSPOSED_STORE ? stage : nullptr);
 }
 
 template <bool SUB>

@@ -187,6 +187,180 @@ nms_reduce(const u64* __restrict__ mask, const uint32_t* __restrict__ order, int
     if (lane == 0) *count = m;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Anchor3DHead.get_bboxes for a WHOLE BATCH without host read-backs (ml3d/torch/models/point_pillars.py:945-1025;
+// BBoxCoder.decode, ml3d/torch/utils/objdet_helper.py:286-313; multiclass_nms, :316-350).  The per-sample, per-class loop of
+// the reference (B x C calls of nms, each behind a nonzero() that synchronises) becomes four launches:
+//   pp_anchor_scores   max over the classes of sigmoid(cls) per anchor            -> the key of the nms_pre top-k (caller)
+//   pp_decode          the selected candidates: anchor + deltas -> boxes, class scores, direction bit, BEV corners form
+//   nmsb_order / nmsb_mask / nmsb_reduce   P = B x C independent NMS problems over the k candidates of a sample: a candidate
+//                      takes part in class c iff its score_c > score_thr (point_pillars.py:1001); greedy order = descending
+//                      score, ties by ascending candidate index -- the order of ml3d_nms on the compacted list
+//   pp_collect         kept candidates, class-major like the reference's torch.cat, yaw corrected by the direction classifier
+// Head maps are read in the reference's NCHW layout (channel = a * C + c, a * 7 + t, a * 2 + d; anchors ordered (h, w, a)).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+__global__ void __launch_bounds__(256)
+pp_anchor_scores(const float* __restrict__ cls, int64_t B, int A, int C, int64_t HW, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * HW) return;
+    const int64_t b = t / HW, hw = t - b * HW;
+    const float* base = cls + b * (int64_t)A * C * HW + hw;
+    for (int a = 0; a < A; ++a) {
+        float m = -1.0f;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, sigmoid_f32(base[(int64_t)(a * C + c) * HW]));
+        out[(b * HW + hw) * A + a] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pp_decode(const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ dir,
+          const float* __restrict__ anchors, const int64_t* __restrict__ cand, int64_t B, int64_t k, int A, int C, int64_t HW,
+          float* __restrict__ box, float* __restrict__ bev, float* __restrict__ score, int32_t* __restrict__ dirbit) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * k) return;
+    const int64_t b = t / k, j = t - b * k;
+    const int64_t ai = cand[t];
+    const int64_t hw = ai / A;
+    const int a = (int)(ai - hw * A);
+    const float* an = anchors + 7 * ai;
+    float d[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) d[q] = reg[(b * A * 7 + (int64_t)(a * 7 + q)) * HW + hw];
+    const float xa = an[0], ya = an[1], wa = an[3], la = an[4], ha = an[5], ra = an[6];
+    const float za = __fadd_rn(an[2], __fdiv_rn(ha, 2.0f));
+    const float diag = sqrtf(__fadd_rn(__fmul_rn(la, la), __fmul_rn(wa, wa)));
+    const float hg = __fmul_rn(expf(d[5]), ha);
+    float o[7];
+    o[0] = __fadd_rn(__fmul_rn(d[0], diag), xa);
+    o[1] = __fadd_rn(__fmul_rn(d[1], diag), ya);
+    o[2] = __fsub_rn(__fadd_rn(__fmul_rn(d[2], ha), za), __fdiv_rn(hg, 2.0f));
+    o[3] = __fmul_rn(expf(d[3]), wa);
+    o[4] = __fmul_rn(expf(d[4]), la);
+    o[5] = hg;
+    o[6] = __fadd_rn(d[6], ra);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) box[7 * t + q] = o[q];
+    // xywhr_to_xyxyr(box3d_to_bev(.)) (objdet_helper.py:69-100): (x, y, w, l, r) -> corners form
+    const float hwid = __fdiv_rn(o[3], 2.0f), hlen = __fdiv_rn(o[4], 2.0f);
+    bev[5 * t + 0] = __fsub_rn(o[0], hwid); bev[5 * t + 1] = __fsub_rn(o[1], hlen);
+    bev[5 * t + 2] = __fadd_rn(o[0], hwid); bev[5 * t + 3] = __fadd_rn(o[1], hlen); bev[5 * t + 4] = o[6];
+    for (int c = 0; c < C; ++c) score[(b * C + c) * k + j] = sigmoid_f32(cls[(b * A * C + (int64_t)(a * C + c)) * HW + hw]);
+    const float d0 = dir[(b * A * 2 + (int64_t)(a * 2)) * HW + hw], d1 = dir[(b * A * 2 + (int64_t)(a * 2 + 1)) * HW + hw];
+    dirbit[t] = d1 > d0 ? 1 : 0;                 // torch.max(dim=-1)[1]: the first maximum
+}
+
+constexpr int NMSB_MAX = 4096;                   // candidates per problem (nms_pre of the reference's configs: 100 .. 4096)
+
+// one workgroup per problem: rank of every participating candidate among the participating ones
+__global__ void __launch_bounds__(256)
+nmsb_order(const float* __restrict__ scores, int64_t n, float score_thr, uint32_t* __restrict__ order, int32_t* __restrict__ nvalid) {
+    __shared__ u64 keys[NMSB_MAX];
+    __shared__ int cnt;
+    const int64_t p = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float sc = scores[p * n + i];
+        keys[i] = sc > score_thr ? (((u64)(~f2ord(sc)) << 32) | (u64)(uint32_t)i) : ~0ull;
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 me = keys[i];
+        if (me == ~0ull) continue;
+        int r = 0;
+        for (int64_t q = 0; q < n; ++q) r += keys[q] < me ? 1 : 0;
+        order[p * n + r] = (uint32_t)i;
+        atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) nvalid[p] = cnt;
+}
+
+__global__ void __launch_bounds__(64)
+nmsb_mask(const float* __restrict__ bev, const uint32_t* __restrict__ order, const int32_t* __restrict__ nvalid, int64_t n,
+          int C, float thr, int words, u64* __restrict__ mask) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    const int64_t p = blockIdx.z;
+    const int64_t nv = nvalid[p];
+    if (cb < rb || (int64_t)rb * 64 >= nv) return;
+    const float* boxes = bev + (p / C) * n * 5;
+    const uint32_t* ord = order + p * n;
+    __shared__ float bb[64][5];
+    const int t = threadIdx.x;
+    const int64_t bj = (int64_t)cb * 64 + t;
+    if (bj < nv) {
+        const float* s = boxes + 5 * (int64_t)ord[bj];
+        for (int q = 0; q < 5; ++q) bb[t][q] = s[q];
+    }
+    __syncthreads();
+    const int64_t a = (int64_t)rb * 64 + t;
+    if (a >= nv) return;
+    float ba[5];
+    const float* s = boxes + 5 * (int64_t)ord[a];
+    for (int q = 0; q < 5; ++q) ba[q] = s[q];
+    P2 ca[4];
+    box_corners(ba, ca);
+    u64 bits = 0ull;
+    const int64_t left = nv - (int64_t)cb * 64;
+    const int cols = (int)(left < 0 ? 0 : (left < 64 ? left : 64));
+    for (int j = (rb == cb ? t + 1 : 0); j < cols; ++j)
+        if (iou_bev(ba, ca, bb[j]) > thr) bits |= 1ull << j;
+    mask[(p * n + a) * words + cb] = bits;
+}
+
+__global__ void __launch_bounds__(64)
+nmsb_reduce(const u64* __restrict__ mask, const uint32_t* __restrict__ order, const int32_t* __restrict__ nvalid, int64_t n,
+            int words, int32_t* __restrict__ keep, int32_t* __restrict__ count) {
+    const int64_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t nv = nvalid[p];
+    const u64* mk = mask + p * n * words;
+    const uint32_t* ord = order + p * n;
+    u64 removed = 0ull;                           // lane l owns word l: 64 words = 4096 candidates (NMSB_MAX)
+    int m = 0;
+    for (int64_t a = 0; a < nv; ++a) {
+        const int w = (int)(a >> 6);
+        const u64 word = __shfl(removed, w);
+        if ((word >> (a & 63)) & 1ull) continue;  // wave-uniform
+        if (lane == 0) keep[p * n + m] = (int32_t)ord[a];
+        ++m;
+        if (lane < words && lane >= w) removed |= mk[a * words + lane];
+    }
+    if (lane == 0) count[p] = m;
+}
+
+// rows [B, C * k, 9] = (box7 with the yaw of the direction classifier, score, label), class-major; total [B]
+__global__ void __launch_bounds__(256)
+pp_collect(const float* __restrict__ box, const float* __restrict__ score, const int32_t* __restrict__ dirbit,
+           const int32_t* __restrict__ keep, const int32_t* __restrict__ count, int64_t B, int64_t k, int C, float dir_offset,
+           float* __restrict__ rows, int32_t* __restrict__ total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C * k) return;
+    const int64_t p = t / k, j = t - p * k;
+    const int64_t b = p / C;
+    const int c = (int)(p - b * C);
+    int off = 0, tot = 0;
+    for (int q = 0; q < C; ++q) {
+        const int n_q = count[b * C + q];
+        if (q < c) off += n_q;
+        tot += n_q;
+    }
+    if (c == 0 && j == 0) total[b] = tot;
+    if (j >= count[p]) return;
+    const int64_t ci = keep[p * k + j];
+    const float* src = box + 7 * (b * k + ci);
+    float* dst = rows + 9 * (b * C * k + off + j);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst[q] = src[q];
+    const float PI = 3.14159274101257324f;       // float32(np.pi): torch scales an f32 tensor by the python float in f32
+    const float val = __fsub_rn(src[6], dir_offset);
+    const float rot = __fsub_rn(val, __fmul_rn(floorf(__fadd_rn(__fdiv_rn(val, PI), 1.0f)), PI));
+    dst[6] = __fadd_rn(__fadd_rn(rot, dir_offset), __fmul_rn(PI, (float)dirbit[b * k + ci]));
+    dst[7] = score[p * k + ci];
+    dst[8] = (float)c;
+}
+
 static inline size_t nms_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace ml3d
@@ -224,6 +398,60 @@ extern "C" int ml3d_nms(const float* boxes, const float* scores, int64_t n, floa
                        words, mask);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64), 0, st, mask, order, n, words, out_keep, out_count);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_pp_anchor_scores(const float* cls_nchw, int64_t batch, int num_anchors, int num_classes, int64_t hw,
+                                     float* out_scores, void* stream) {
+    if (batch < 0 || num_anchors <= 0 || num_classes <= 0 || hw < 0) return ML3D_E_INVALID;
+    if (batch * hw == 0) return 0;
+    if (!cls_nchw || !out_scores) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(ml3d::pp_anchor_scores, dim3((unsigned)((batch * hw + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cls_nchw, batch, num_anchors, num_classes, hw, out_scores);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" size_t ml3d_pp_boxes_workspace_bytes(int64_t batch, int64_t k, int num_classes) {
+    if (batch < 0 || k < 0 || num_classes <= 0 || k > NMSB_MAX) return 0;
+    const size_t P = (size_t)(batch > 0 ? batch : 1) * (size_t)num_classes, n = (size_t)(k > 0 ? k : 1);
+    const size_t words = (n + 63) / 64;
+    return nms_align(4 * P * n) /* order */ + nms_align(4 * P) /* nvalid */ + nms_align(8 * P * n * words) /* mask */ +
+           nms_align(4 * P * n) /* keep */ + nms_align(4 * P) /* count */ + nms_align(4 * 7 * (P / num_classes) * n) /* box */ +
+           nms_align(4 * 5 * (P / num_classes) * n) /* bev */ + nms_align(4 * P * n) /* score */ +
+           nms_align(4 * (P / num_classes) * n) /* dir */ + 512;
+}
+
+extern "C" int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const float* dir_nchw, const float* anchors,
+                             const int64_t* candidates, int64_t batch, int64_t k, int num_anchors, int num_classes, int64_t hw,
+                             float score_threshold, float iou_threshold, float dir_offset, float* out_rows,
+                             int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch < 0 || k < 0 || num_anchors <= 0 || num_classes <= 0 || hw < 0 || !out_total) return ML3D_E_INVALID;
+    if (k > NMSB_MAX) return ML3D_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0) return 0;
+    if (k == 0) { (void)hipMemsetAsync(out_total, 0, sizeof(int32_t) * (size_t)batch, st); return 0; }
+    if (!cls_nchw || !reg_nchw || !dir_nchw || !anchors || !candidates || !out_rows) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_pp_boxes_workspace_bytes(batch, k, num_classes)) return ML3D_E_WORKSPACE;
+    const int64_t P = batch * num_classes;
+    const int words = (int)((k + 63) / 64);
+    char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint32_t* order = (uint32_t*)p;  p += nms_align(4 * (size_t)(P * k));
+    int32_t* nvalid = (int32_t*)p;   p += nms_align(4 * (size_t)P);
+    u64* mask = (u64*)p;             p += nms_align(8 * (size_t)(P * k * words));
+    int32_t* keep = (int32_t*)p;     p += nms_align(4 * (size_t)(P * k));
+    int32_t* count = (int32_t*)p;    p += nms_align(4 * (size_t)P);
+    float* box = (float*)p;          p += nms_align(4 * 7 * (size_t)(batch * k));
+    float* bev = (float*)p;          p += nms_align(4 * 5 * (size_t)(batch * k));
+    float* score = (float*)p;        p += nms_align(4 * (size_t)(P * k));
+    int32_t* dirbit = (int32_t*)p;
+    hipLaunchKernelGGL(ml3d::pp_decode, dim3((unsigned)((batch * k + 255) / 256)), dim3(256), 0, st, cls_nchw, reg_nchw, dir_nchw,
+                       anchors, candidates, batch, k, num_anchors, num_classes, hw, box, bev, score, dirbit);
+    hipLaunchKernelGGL(ml3d::nmsb_order, dim3((unsigned)P), dim3(256), 0, st, score, k, score_threshold, order, nvalid);
+    hipLaunchKernelGGL(ml3d::nmsb_mask, dim3((unsigned)words, (unsigned)words, (unsigned)P), dim3(64), 0, st, bev, order, nvalid,
+                       k, num_classes, iou_threshold, words, mask);
+    hipLaunchKernelGGL(ml3d::nmsb_reduce, dim3((unsigned)P), dim3(64), 0, st, mask, order, nvalid, k, words, keep, count);
+    hipLaunchKernelGGL(ml3d::pp_collect, dim3((unsigned)((P * k + 255) / 256)), dim3(256), 0, st, box, score, dirbit, keep, count,
+                       batch, k, num_classes, dir_offset, out_rows, out_total);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

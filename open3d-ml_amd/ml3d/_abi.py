@@ -46,6 +46,9 @@ SYMBOLS = [
     "ml3d_nhwc_to_nchw",
     "ml3d_nms_workspace_bytes",
     "ml3d_nms",
+    "ml3d_pp_anchor_scores",
+    "ml3d_pp_boxes_workspace_bytes",
+    "ml3d_pp_boxes",
     "ml3d_iou_bev",
     "ml3d_iou_3d",
     "ml3d_nearest_to_center_workspace_bytes",
@@ -141,6 +144,12 @@ def bind(lib):
     lib.ml3d_nms_workspace_bytes.argtypes = [i64]
     lib.ml3d_nms.restype = C.c_int
     lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_pp_anchor_scores.restype = C.c_int
+    lib.ml3d_pp_anchor_scores.argtypes = [vp, i64, i32, i32, i64, vp, vp]
+    lib.ml3d_pp_boxes_workspace_bytes.restype = sz
+    lib.ml3d_pp_boxes_workspace_bytes.argtypes = [i64, i64, i32]
+    lib.ml3d_pp_boxes.restype = C.c_int
+    lib.ml3d_pp_boxes.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i64, f32, f32, f32, vp, vp, vp, sz, vp]
     lib.ml3d_iou_bev.restype = C.c_int
     lib.ml3d_iou_bev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.ml3d_iou_3d.restype = C.c_int

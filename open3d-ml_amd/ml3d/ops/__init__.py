@@ -719,6 +719,43 @@ def nms(boxes, scores, nms_overlap_thresh):
     return keep[:int(count.item())]
 
 
+def pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, nms_pre, score_thr, iou_thr, dir_offset=0.0):
+    """``Anchor3DHead.get_bboxes`` for the whole batch with no host read-back inside (point_pillars.py:945-1025): head maps
+    [B, A*C | A*7 | A*2, H, W] (NCHW, like the reference's), ``anchors`` [H*W*A, 7] -> (rows [B, C*k, 9], total [B] int32):
+    ``rows[b, :total[b]]`` = (x, y, z, w, l, h, yaw, score, label) of sample b's detections, class-major in NMS order."""
+    lib = _abi.get()
+    _need_gpu(cls_scores, bbox_preds, dir_preds, anchors)
+    cls_scores, bbox_preds, dir_preds = (t.detach().contiguous().float() for t in (cls_scores, bbox_preds, dir_preds))
+    anchors = anchors.contiguous().float()
+    B, AC, H, W = cls_scores.shape
+    A = dir_preds.shape[1] // 2
+    C_ = AC // A
+    if bbox_preds.shape[1] != A * 7 or anchors.shape[0] != H * W * A or anchors.shape[1] != 7:
+        raise RuntimeError("pointpillars_boxes: head maps / anchors do not agree on the anchor count")
+    dev = cls_scores.device
+    n_anchor = H * W * A
+    with torch.cuda.device(dev):
+        if n_anchor > int(nms_pre):
+            smax = torch.empty((B, n_anchor), dtype=torch.float32, device=dev)
+            rc = lib.ml3d_pp_anchor_scores(cls_scores.data_ptr(), B, A, C_, H * W, smax.data_ptr(), _stream())
+            _abi.check(rc, "ml3d_pp_anchor_scores")
+            cand = torch.topk(smax, int(nms_pre), dim=1)[1].contiguous()
+        else:
+            cand = torch.arange(n_anchor, dtype=torch.int64, device=dev).repeat(B, 1).contiguous()
+        k = cand.shape[1]
+        rows = torch.empty((B, C_ * k, 9), dtype=torch.float32, device=dev)
+        total = torch.empty(B, dtype=torch.int32, device=dev)
+        wsb = lib.ml3d_pp_boxes_workspace_bytes(B, k, C_)
+        if wsb == 0:
+            raise RuntimeError("pointpillars_boxes: nms_pre = %d candidates per sample is beyond the batched kernel (4096)" % k)
+        ws = _ws(wsb, dev)
+        rc = lib.ml3d_pp_boxes(cls_scores.data_ptr(), bbox_preds.data_ptr(), dir_preds.data_ptr(), anchors.data_ptr(),
+                               cand.data_ptr(), B, k, A, C_, H * W, float(score_thr), float(iou_thr), float(dir_offset),
+                               rows.data_ptr(), total.data_ptr(), ws.data_ptr(), wsb, _stream())
+    _abi.check(rc, "ml3d_pp_boxes")
+    return rows, total
+
+
 # ---------------------------------------------------------------------------------------------------
 # patch sampler / vote accumulation (SURVEY.md §8 f1)
 # ---------------------------------------------------------------------------------------------------

@@ -215,9 +215,35 @@ class Anchor3DHead(nn.Module):
             bboxes[..., 6] = dir_rot + self.dir_offset + np.pi * dir_scores.to(bboxes.dtype)
         return bboxes, sc, labels
 
+    def _anchors_for(self, featmap_size, device):
+        key = (tuple(int(v) for v in featmap_size), str(device))
+        cache = self.__dict__.setdefault('_anchor_cache', {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = self.grid_anchors(featmap_size, device).contiguous()
+        return cache[key]
+
+    @torch.no_grad()
     def get_bboxes(self, cls_scores, bbox_preds, dir_preds):
-        out = [self.get_bboxes_single(c, b, d) for c, b, d in zip(cls_scores, bbox_preds, dir_preds)]
-        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+        """point_pillars.py:945-963 for the whole batch: ONE pass of the batched HIP kernels (``ops.pointpillars_boxes``:
+        anchor scores -> top nms_pre -> decode -> B x C rotated NMS problems -> class-major rows) and ONE host read-back (the
+        per-sample box counts) instead of the reference's per-sample, per-class loop.  Same lists of (bboxes [M, 7],
+        scores [M], labels [M]) as the reference; ``get_bboxes_single`` keeps the loop formulation (one nms call per class)."""
+        if not torch.is_tensor(cls_scores):
+            cls_scores, bbox_preds, dir_preds = (torch.stack(list(t)) for t in (cls_scores, bbox_preds, dir_preds))
+        if self.nms_pre > 4096:                      # beyond the batched kernel's per-problem capacity: the loop formulation
+            out = [self.get_bboxes_single(c, b, d) for c, b, d in zip(cls_scores, bbox_preds, dir_preds)]
+            return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+        anchors = self._anchors_for(cls_scores.shape[-2:], cls_scores.device)
+        rows, total = ops.pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, self.nms_pre, self.score_thr, 0.01,
+                                             self.dir_offset)
+        boxes, scores, labels = [], [], []
+        for b, n in enumerate(total.tolist()):
+            r = rows[b, :n]
+            boxes.append(r[:, :7])
+            scores.append(r[:, 7])
+            labels.append(r[:, 8].long())
+        return boxes, scores, labels
 
 
 def _bn_affine(bn):

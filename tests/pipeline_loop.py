@@ -100,3 +100,27 @@ def run_detection(model, data, device, batcher):
     with torch.no_grad():
         results = model(batch)
         return model.inference_end(results, batch)
+
+
+def box_lists_agree(boxes_a, labels_a, boxes_b, labels_b, rel=1e-4):
+    """Two detection lists describe the same boxes: per class a one-to-one matching with every coordinate within ``rel`` *
+    max(1, |value|).  (Row-by-row comparison is too strict: the lists are in NMS = descending-score order, and two candidates
+    whose scores differ by less than the 1e-4 float tolerance of the head maps may swap places.)  -> worst relative error."""
+    import numpy as np
+    boxes_a, boxes_b = np.asarray(boxes_a, np.float64).reshape(-1, 7), np.asarray(boxes_b, np.float64).reshape(-1, 7)
+    labels_a, labels_b = np.asarray(labels_a).reshape(-1), np.asarray(labels_b).reshape(-1)
+    if boxes_a.shape != boxes_b.shape or not np.array_equal(np.sort(labels_a), np.sort(labels_b)):
+        return float("inf")
+    worst = 0.0
+    for c in np.unique(labels_b):
+        A, B = boxes_a[labels_a == c], boxes_b[labels_b == c]
+        free = np.ones(len(B), bool)
+        for row in A:
+            err = (np.abs(B - row) / np.maximum(1.0, np.abs(B))).max(1)
+            err[~free] = np.inf
+            j = int(np.argmin(err))
+            if not np.isfinite(err[j]) or err[j] > rel:
+                return float(err[j])
+            free[j] = False
+            worst = max(worst, float(err[j]))
+    return worst

@@ -88,3 +88,49 @@ assert np.array_equal(t0.query_radius(c, r=1.0)[0], t1.query_radius(c, r=1.0)[0]
 assert np.array_equal(pre['proj_inds'], back['proj_inds']) and t1.data.dtype == np.float32
 print("ok")
 ''')
+
+
+def test_batched_get_bboxes_matches_the_oracle_loop_formulation():
+    """``Anchor3DHead.get_bboxes`` (batched HIP decode + B x C NMS problems, one read-back) vs the oracle's restatement of the
+    reference's per-sample / per-class loop (oracle/pointpillars_ref.get_bboxes_single, pinned to the real reference by
+    tests/golden/pointpillars_small.npz): the golden's own head maps, then random maps with nms_pre = 300 candidates (five mask
+    words per problem), a sample where nothing passes the score threshold, and a map smaller than nms_pre (no top-k)."""
+    _run(r'''
+from oracle import pointpillars_ref as P
+from ml3d.torch.models.point_pillars import PointPillars
+import copy
+g = np.load(os.path.join(ROOT, "tests", "golden", "pointpillars_small.npz"))
+cfg = P.SMALL_CFG
+m = PointPillars(device="cpu", **cfg)
+cls, reg, dr = (torch.from_numpy(g[k]) for k in ("cls", "reg", "dir"))
+boxes, scores, labels = m.bbox_head.get_bboxes(cls, reg, dr)
+for i in range(cls.shape[0]):
+    assert np.array_equal(labels[i].numpy(), g["labels%d" % i]), i
+    assert np.abs(scores[i].numpy() - g["scores%d" % i]).max() <= 1e-6
+    assert np.abs(boxes[i].numpy() - g["boxes%d" % i]).max() <= 1e-4
+    rb, rs, rl = P.get_bboxes_single(cfg, cls[i], reg[i], dr[i])
+    assert np.array_equal(labels[i].numpy(), rl.numpy()) and np.abs(boxes[i].numpy() - rb.numpy()).max() <= 1e-4
+# random maps, many survivors
+for nms_pre, H, W, thr, bias in ((300, 12, 16, 0.3, 0.0), (64, 4, 4, 0.1, 0.0), (100, 10, 10, 0.5, -9.0)):
+    c2 = copy.deepcopy(cfg)
+    c2["head"] = dict(c2["head"], nms_pre=nms_pre, score_thr=thr)
+    m2 = PointPillars(device="cpu", **c2)
+    A, C = m2.bbox_head.num_anchors, len(c2["classes"])
+    rng = np.random.default_rng(nms_pre)
+    cls = torch.from_numpy((rng.standard_normal((3, A * C, H, W)) * 2 + bias).astype(np.float32))
+    cls[2] -= 30.0 if bias == 0.0 else 0.0                     # sample 2: nothing above the threshold
+    reg = torch.from_numpy((rng.standard_normal((3, A * 7, H, W)) * 0.3).astype(np.float32))
+    dr = torch.from_numpy(rng.standard_normal((3, A * 2, H, W)).astype(np.float32))
+    boxes, scores, labels = m2.bbox_head.get_bboxes(cls, reg, dr)
+    for i in range(3):
+        rb, rs, rl = P.get_bboxes_single(c2, cls[i], reg[i], dr[i])
+        assert np.array_equal(labels[i].numpy(), rl.numpy()), (nms_pre, i, len(rl), len(labels[i]))
+        if len(rl):
+            assert np.abs(scores[i].numpy() - rs.numpy()).max() <= 1e-6
+            assert np.abs(boxes[i].numpy() - rb.numpy()).max() <= 1e-4
+    assert len(labels[2]) == 0 or bias != 0.0
+    # the loop formulation of the product (one ml3d_nms call per class) agrees as well
+    sb, ss, sl = m2.bbox_head.get_bboxes_single(cls[0], reg[0], dr[0])
+    assert np.array_equal(sl.numpy(), labels[0].numpy()) and (len(sl) == 0 or np.abs(sb.numpy() - boxes[0].numpy()).max() <= 1e-6)
+print("ok")
+''')

@@ -139,11 +139,15 @@ def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
 
 def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_per_sphere():
     """The configuration bench.py --workload kpconv times: 64 input spheres (~640 000 points) per batch through
-    ``KPConvPipeline``.  Only at this size are the register-blocked GEMM (>= 256 workgroups), deep split-K, the 32-bit offset
-    epilogue (wf is 1.2 GB) and the three-launch scans selected.  Batch items are independent (per-item grid rotations), so
-    spheres {0, 31, 63} are checked one by one against the oracle run on that sphere alone with the same rotation: every
-    points / neighbours / pools / upsamples matrix exact (after removing the item's row offset; the batch's extra columns
-    must be shadow entries), logits <= 1e-4."""
+    ``KPConvPipeline``.  Only at this size are deep split-K, the 32-bit offset epilogue (wf is 1.2 GB) and the three-launch
+    scans selected.  Spheres {0, 31, 63} are checked one by one against the oracle run on that sphere alone with the same grid
+    rotation: every points / neighbours / pools / upsamples matrix exact (after removing the item's row offset; the batch's
+    extra columns must be shadow entries), logits <= 1e-4.
+
+    The oracle forward gets the item's matrices AT THE BATCH'S WIDTH: ``max_pool`` (kpconv.py:821-839) takes the maximum over
+    all columns, shadow entries (zero features) included, so in the reference itself a row's pooled value depends on how many
+    padding columns the longest row of the batch adds (max(negatives) vs max(negatives, 0)) -- batch items are independent
+    only up to that padding."""
     from ml3d.engine import KPConvPipeline
     B = 64
     spheres = [synth_data.toronto3d_sphere(i) for i in range(B)]          # the bench's spheres (rank 0)
@@ -163,24 +167,31 @@ def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_
     blens = [batch.lengths[l].numpy().astype(np.int64) for l in range(L)]
     offs = [np.concatenate([[0], np.cumsum(x)]) for x in blens]
     assert logits.shape == (sum(lens), CFG["num_classes"]) and np.isfinite(logits).all()
+
+    def item_rows(mat, ref, rows, s_off, s_tot, s_len, where):
+        """item rows of a batch matrix, global -> local indices (shadow -> local shadow); must extend ``ref`` by shadows only"""
+        got = mat[rows[0]:rows[1]].cpu().numpy().astype(np.int64)
+        loc = np.where(got == s_tot, s_len, got - s_off)
+        w = ref.shape[1]
+        assert loc.shape[1] >= w and np.array_equal(loc[:, :w], ref) and (loc[:, w:] == s_len).all(), where
+        return loc
+
     for i in (0, 31, 63):
         rots = [None if R is None else R[i:i + 1] for R in batch.rotations]      # this item's grid orientations
         seg = K.segmentation_inputs(spheres[i], [lens[i]], CFG, rotations=rots)
+        wide = dict(seg, neighbors=[], pools=[], upsamples=[])
         for l in range(L):
             a, b = offs[l][i], offs[l][i + 1]
             assert np.array_equal(batch.points[l][a:b].cpu().numpy(), seg["points"][l]), (i, l)
-
-            def same(mat, ref, q_off, s_off, s_tot, s_len):
-                """item rows of a batch matrix vs the single-sphere matrix: global -> local indices, shadow -> local shadow"""
-                got = mat[q_off[0]:q_off[1]].cpu().numpy().astype(np.int64)
-                loc = np.where(got == s_tot, s_len, got - s_off)
-                w = ref.shape[1]
-                assert loc.shape[1] >= w and np.array_equal(loc[:, :w], ref) and (loc[:, w:] == s_len).all(), (i, l)
-            same(batch.neighbors[l], seg["neighbors"][l], (a, b), a, offs[l][-1], b - a)
+            wide["neighbors"].append(item_rows(batch.neighbors[l], seg["neighbors"][l], (a, b), a, offs[l][-1], b - a, (i, l, "n")))
             if l + 1 < L:
                 c, d = offs[l + 1][i], offs[l + 1][i + 1]
-                same(batch.pools[l], seg["pools"][l], (c, d), a, offs[l][-1], b - a)
-                same(batch.upsamples[l], seg["upsamples"][l], (a, b), c, offs[l + 1][-1], d - c)
-        ref = K.forward(sd, CFG, K.to_torch_batch(seg), torch.ones((lens[i], 1))).numpy()
+                wide["pools"].append(item_rows(batch.pools[l], seg["pools"][l], (c, d), a, offs[l][-1], b - a, (i, l, "p")))
+                wide["upsamples"].append(item_rows(batch.upsamples[l], seg["upsamples"][l], (a, b), c, offs[l + 1][-1], d - c,
+                                                   (i, l, "u")))
+            else:
+                wide["pools"].append(seg["pools"][l])
+                wide["upsamples"].append(seg["upsamples"][l])
+        ref = K.forward(sd, CFG, K.to_torch_batch(wide), torch.ones((lens[i], 1))).numpy()
         a, b = offs[0][i], offs[0][i + 1]
         assert np.abs(logits[a:b] - ref).max() <= TOL, (i, float(np.abs(logits[a:b] - ref).max()))
