@@ -111,6 +111,30 @@ int ml3d_radius_fill(const float* points, const int64_t* points_row_splits,
 /* out [rows, out_cols, elem_bytes]; row r = values[rs[r] : rs[r] + out_cols]  */
 /* padded with default_value (device, elem_bytes).                             */
 /* ------------------------------------------------------------------------- */
+/* batch_neighbors (ml3d/torch/models/kpconv.py:2002-2034) in ONE traversal:   */
+/* the dense [n_queries, longest] int32 matrix of the KPConv batcher, padded   */
+/* with the shadow index.  ml3d_radius_dense_gather searches once and parks    */
+/* every row -- canonical (d2, index) order, GLOBAL indices -- in a stash of   */
+/* `cap` (<= 256) entries per query inside the workspace; out_stats [2] int64  */
+/* = {overflow flag, longest row}.  The caller reads them (its one host sync   */
+/* per search, the reference's .item() at kpconv.py:2028), allocates           */
+/* [n_queries, dense_cols <= cap] and calls ml3d_radius_dense_expand (a copy + */
+/* pad stream).  overflow != 0 (a row longer than cap): use ml3d_radius_count  */
+/* + ml3d_radius_fill for that search.                                         */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_radius_dense_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch, int cap);
+
+int ml3d_radius_dense_gather(const float* points, const int64_t* points_row_splits,
+                             const float* queries, const int64_t* queries_row_splits,
+                             int64_t batch, int64_t n_points, int64_t n_queries, float radius,
+                             int cap, int64_t* out_stats, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+int ml3d_radius_dense_expand(int64_t n_points, int64_t n_queries, int64_t batch, int cap,
+                             int64_t dense_cols, int32_t pad_value, int32_t* out_index,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 int ml3d_ragged_to_dense(const void* values, const int64_t* row_splits, int64_t rows,
                          int64_t out_cols, int64_t elem_bytes, const void* default_value,
                          void* out, void* stream);
@@ -208,13 +232,20 @@ int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* nei
 /* (kpconv.py:283-286, 821-838, 1468-1481).  a [*, lda] uses k1 columns, row m of the        */
 /* product reads a[a_gather[m*a_gather_stride]] (rows >= a_rows are zeros) or a[m] when      */
 /* a_gather is NULL; a2 [m, lda2] contributes k2 more columns; weights_t [k1+k2, n].         */
+/* residual [*, ldr] is added before the activation: row m, or -- residual_gather != NULL -- */
+/* row residual_gather[m * residual_gather_stride] when that lies in [0, residual_rows), else*/
+/* nothing.  The latter is the decoder step split by linearity:                              */
+/*   W . [x[up[m,0]] ; skip[m]] = (x W_x)[up[m,0]] + skip[m] W_skip                          */
+/* -- the upsampled half is multiplied on the COARSE level (a quarter of the rows) and comes */
+/* back through the upsampling index (shadow index = no coarse neighbour = zero features).   */
 size_t ml3d_linear_workspace_bytes(int64_t m, int n, int k);
 
 int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a_gather,
                 int64_t a_gather_stride, int64_t a_rows, const float* a2, int64_t lda2, int k2,
                 const float* weights_t, const float* bias, const float* residual, int64_t ldr,
-                int act, float slope, float* out, int64_t ldc, int64_t m, int n,
-                void* workspace, size_t workspace_bytes, void* stream);
+                const int32_t* residual_gather, int64_t residual_gather_stride,
+                int64_t residual_rows, int act, float slope, float* out, int64_t ldc, int64_t m,
+                int n, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ml3d_gather_pool: mode 0 = max_pool (kpconv.py:841-858, shadow rows count as zeros),     */
 /* mode 1 = closest_pool (kpconv.py:821-838, feature of the FIRST listed neighbour).         */
@@ -307,9 +338,13 @@ int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_thres
 /* per-sample, per-class loop of ml3d/torch/models/point_pillars.py:945-1025   */
 /* (sigmoid / top nms_pre / BBoxCoder.decode, objdet_helper.py:286-313 /       */
 /* multiclass_nms, objdet_helper.py:316-350 / direction fix) without a host    */
-/* read-back per class.  Head maps in the reference's NCHW layout:             */
-/*   cls [B, A*C, H, W], reg [B, A*7, H, W], dir [B, A*2, H, W]; anchors       */
-/*   [H*W*A, 7] in (h, w, a) order (Anchor3DRangeGenerator.grid_anchors).      */
+/* read-back per class.  Head maps: cls [B, A*C, H, W], reg [B, A*7, H, W],    */
+/*   dir [B, A*2, H, W] in ANY strided layout -- each map comes with three     */
+/*   ELEMENT strides (batch, channel, pixel): the reference's NCHW tensors     */
+/*   (C*H*W, H*W, 1) or channel slices of a fused NHWC head tensor             */
+/*   (H*W*Ctot, 1, Ctot); HOST arrays cls_strides[3] / strides9[9] = cls, reg, */
+/*   dir.  anchors [H*W*A, 7] in (h, w, a) order                               */
+/*   (Anchor3DRangeGenerator.grid_anchors).                                    */
 /* ml3d_pp_anchor_scores: out_scores [B, H*W*A] = max_c sigmoid(cls) — the key */
 /*   of the nms_pre top-k (point_pillars.py:985-992), which the caller takes.  */
 /* ml3d_pp_boxes: candidates [B, k] int64 anchor indices (k <= 4096) ->        */
@@ -319,12 +354,13 @@ int ml3d_nms(const float* boxes, const float* scores, int64_t n, float iou_thres
 /*   class c iff score_c > score_threshold; rotated-BEV IoU > iou_threshold    */
 /*   suppresses (greedy, descending score, ties by candidate index).           */
 /* ------------------------------------------------------------------------- */
-int ml3d_pp_anchor_scores(const float* cls_nchw, int64_t batch, int num_anchors, int num_classes,
-                          int64_t hw, float* out_scores, void* stream);
+int ml3d_pp_anchor_scores(const float* cls, const int64_t* cls_strides, int64_t batch,
+                          int num_anchors, int num_classes, int64_t hw, float* out_scores,
+                          void* stream);
 
 size_t ml3d_pp_boxes_workspace_bytes(int64_t batch, int64_t k, int num_classes);
 
-int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const float* dir_nchw,
+int ml3d_pp_boxes(const float* cls, const float* reg, const float* dir, const int64_t* strides9,
                   const float* anchors, const int64_t* candidates, int64_t batch, int64_t k,
                   int num_anchors, int num_classes, int64_t hw, float score_threshold,
                   float iou_threshold, float dir_offset, float* out_rows, int32_t* out_total,

@@ -36,6 +36,10 @@ struct Epilogue {
     // -- the per-COARSE-point half of "nearest upsample + concat + Linear" added back through the upsampling index
     const int32_t* res_gather;
     int64_t rg_rows_per_item, rg_src_rows_per_item;
+    // rg_stride: element stride of res_gather (0 = 1; KPConv: the first column of an [M, H] neighbour matrix);
+    // rg_limit: gathered rows outside [0, rg_limit) contribute nothing (the shadow neighbour of a point with no coarse point
+    // in reach); must be set whenever res_gather is
+    int64_t rg_stride, rg_limit;
 };
 
 // dense / gathered / concatenated rows

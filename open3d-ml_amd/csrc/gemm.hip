@@ -333,9 +333,13 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
             float v = acc[r] + b;
             if (ep.residual) {
                 int64_t rr = m;
-                if (ep.res_gather)
-                    rr = rg_base + (rg_l0 + lr >= ep.rg_rows_per_item ? ep.rg_src_rows_per_item : 0) + ep.res_gather[m];
-                v += ep.residual[rr * ep.ldr + col];
+                bool take = true;
+                if (ep.res_gather) {
+                    const int64_t g = ep.res_gather[ep.rg_stride ? m * ep.rg_stride : m];
+                    take = g >= 0 && g < ep.rg_limit;
+                    rr = rg_base + (rg_l0 + lr >= ep.rg_rows_per_item ? ep.rg_src_rows_per_item : 0) + g;
+                }
+                if (take) v += ep.residual[rr * ep.ldr + col];
             }
             C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
         }
@@ -584,8 +588,13 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
         if (ep.bias) v += ep.bias2 ? ep.bias[col] + ep.bias2[col] : ep.bias[col];
         if (ep.residual) {
             int64_t rr = m;
-            if (ep.res_gather) rr = (m / ep.rg_rows_per_item) * ep.rg_src_rows_per_item + ep.res_gather[m];
-            v += ep.residual[rr * ep.ldr + col];
+            bool take = true;
+            if (ep.res_gather) {
+                const int64_t g = ep.res_gather[ep.rg_stride ? m * ep.rg_stride : m];
+                take = g >= 0 && g < ep.rg_limit;
+                rr = (m / ep.rg_rows_per_item) * ep.rg_src_rows_per_item + g;
+            }
+            if (take) v += ep.residual[rr * ep.ldr + col];
         }
         C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
     }

@@ -471,12 +471,13 @@ extern "C" size_t ml3d_linear_workspace_bytes(int64_t m, int n, int k) {
 
 extern "C" int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a_gather, int64_t a_gather_stride,
                            int64_t a_rows, const float* a2, int64_t lda2, int k2, const float* weights_t,
-                           const float* bias, const float* residual, int64_t ldr, int act, float slope, float* out,
+                           const float* bias, const float* residual, int64_t ldr, const int32_t* residual_gather,
+                           int64_t residual_gather_stride, int64_t residual_rows, int act, float slope, float* out,
                            int64_t ldc, int64_t m, int n, void* workspace, size_t workspace_bytes, void* stream) {
     if (m < 0 || n <= 0 || k1 < 0 || k2 < 0 || k1 + k2 <= 0 || act < 0 || act > 2) return ML3D_E_INVALID;
     if (m == 0) return 0;
     if (!weights_t || !out || (k1 > 0 && !a) || (k2 > 0 && !a2) || lda < k1 || (k2 > 0 && lda2 < k2) || ldc < n ||
-        (residual && ldr < n))
+        (residual && ldr < n) || (residual_gather && (!residual || residual_gather_stride < 1 || residual_rows < 0)))
         return ML3D_E_INVALID;
     RowsA A;
     A.a = a; A.lda = lda; A.k1 = k1;
@@ -484,6 +485,10 @@ extern "C" int ml3d_linear(const float* a, int64_t lda, int k1, const int32_t* a
     A.a2 = a2; A.lda2 = lda2; A.k2 = k2;
     A.gather_on_a2 = 0; A.g_rows_per_item = 0; A.g_src_rows_per_item = 0;
     Epilogue ep = {bias, residual, ldr, act, slope, 0, 0, 0, 0};
+    if (residual_gather) {      // global row indices: one "item" spanning every row
+        ep.res_gather = residual_gather; ep.rg_rows_per_item = (int64_t)1 << 62; ep.rg_src_rows_per_item = 0;
+        ep.rg_stride = residual_gather_stride; ep.rg_limit = residual_rows;
+    }
     char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
     size_t avail = workspace ? (workspace_bytes > 256 ? workspace_bytes - 256 : 0) : 0;
     return gemm_rows(A, weights_t, m, n, k1 + k2, ep, out, ldc, p, avail, (hipStream_t)stream);

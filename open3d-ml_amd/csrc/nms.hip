@@ -201,22 +201,27 @@ nms_reduce(const u64* __restrict__ mask, const uint32_t* __restrict__ order, int
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
+// A head map is addressed as base[b * sb + channel * sc + pixel * sp]: NCHW (sb = channels * HW, sc = HW, sp = 1, the
+// reference's layout) or a channel slice of the fused NHWC head tensor (sb = HW * Ctot, sc = 1, sp = Ctot).
+struct HeadMap { const float* base; int64_t sb, sc, sp; };
+__device__ __forceinline__ float head_at(const HeadMap& m, int64_t b, int ch, int64_t hw) {
+    return m.base[b * m.sb + (int64_t)ch * m.sc + hw * m.sp];
+}
+
 __global__ void __launch_bounds__(256)
-pp_anchor_scores(const float* __restrict__ cls, int64_t B, int A, int C, int64_t HW, float* __restrict__ out) {
+pp_anchor_scores(HeadMap cls, int64_t B, int A, int C, int64_t HW, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * HW) return;
     const int64_t b = t / HW, hw = t - b * HW;
-    const float* base = cls + b * (int64_t)A * C * HW + hw;
     for (int a = 0; a < A; ++a) {
         float m = -1.0f;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, sigmoid_f32(base[(int64_t)(a * C + c) * HW]));
+        for (int c = 0; c < C; ++c) m = fmaxf(m, sigmoid_f32(head_at(cls, b, a * C + c, hw)));
         out[(b * HW + hw) * A + a] = m;
     }
 }
 
 __global__ void __launch_bounds__(256)
-pp_decode(const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ dir,
-          const float* __restrict__ anchors, const int64_t* __restrict__ cand, int64_t B, int64_t k, int A, int C, int64_t HW,
+pp_decode(HeadMap cls, HeadMap reg, HeadMap dir, const float* __restrict__ anchors, const int64_t* __restrict__ cand, int64_t B, int64_t k, int A, int C, int64_t HW,
           float* __restrict__ box, float* __restrict__ bev, float* __restrict__ score, int32_t* __restrict__ dirbit) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * k) return;
@@ -227,7 +232,7 @@ pp_decode(const float* __restrict__ cls, const float* __restrict__ reg, const fl
     const float* an = anchors + 7 * ai;
     float d[7];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) d[q] = reg[(b * A * 7 + (int64_t)(a * 7 + q)) * HW + hw];
+    for (int q = 0; q < 7; ++q) d[q] = head_at(reg, b, a * 7 + q, hw);
     const float xa = an[0], ya = an[1], wa = an[3], la = an[4], ha = an[5], ra = an[6];
     const float za = __fadd_rn(an[2], __fdiv_rn(ha, 2.0f));
     const float diag = sqrtf(__fadd_rn(__fmul_rn(la, la), __fmul_rn(wa, wa)));
@@ -246,8 +251,8 @@ pp_decode(const float* __restrict__ cls, const float* __restrict__ reg, const fl
     const float hwid = __fdiv_rn(o[3], 2.0f), hlen = __fdiv_rn(o[4], 2.0f);
     bev[5 * t + 0] = __fsub_rn(o[0], hwid); bev[5 * t + 1] = __fsub_rn(o[1], hlen);
     bev[5 * t + 2] = __fadd_rn(o[0], hwid); bev[5 * t + 3] = __fadd_rn(o[1], hlen); bev[5 * t + 4] = o[6];
-    for (int c = 0; c < C; ++c) score[(b * C + c) * k + j] = sigmoid_f32(cls[(b * A * C + (int64_t)(a * C + c)) * HW + hw]);
-    const float d0 = dir[(b * A * 2 + (int64_t)(a * 2)) * HW + hw], d1 = dir[(b * A * 2 + (int64_t)(a * 2 + 1)) * HW + hw];
+    for (int c = 0; c < C; ++c) score[(b * C + c) * k + j] = sigmoid_f32(head_at(cls, b, a * C + c, hw));
+    const float d0 = head_at(dir, b, a * 2, hw), d1 = head_at(dir, b, a * 2 + 1, hw);
     dirbit[t] = d1 > d0 ? 1 : 0;                 // torch.max(dim=-1)[1]: the first maximum
 }
 
@@ -277,36 +282,40 @@ nmsb_order(const float* __restrict__ scores, int64_t n, float score_thr, uint32_
     if (threadIdx.x == 0) nvalid[p] = cnt;
 }
 
+// one wave per (sorted candidate a, 64-candidate word cb >= word of a): lane j tests the pair (a, 64 cb + j) and the ballot IS
+// the mask word -- every rotated IoU of a problem in parallel (a first version gave a thread 64 pairs in a row: 0.72 ms per
+// 16-sweep step for 48 problems of 100 candidates, latency-bound with the clipping arrays in scratch).  Two boxes whose
+// circumscribed circles are disjoint cannot intersect: their IoU is exactly 0 and the clipping is skipped (most pairs).
 __global__ void __launch_bounds__(64)
 nmsb_mask(const float* __restrict__ bev, const uint32_t* __restrict__ order, const int32_t* __restrict__ nvalid, int64_t n,
           int C, float thr, int words, u64* __restrict__ mask) {
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    const int64_t p = blockIdx.z;
+    const int64_t p = blockIdx.z, a = blockIdx.y;
+    const int cb = blockIdx.x, lane = threadIdx.x;
     const int64_t nv = nvalid[p];
-    if (cb < rb || (int64_t)rb * 64 >= nv) return;
+    if (a >= nv || cb < (int)(a >> 6)) return;
     const float* boxes = bev + (p / C) * n * 5;
     const uint32_t* ord = order + p * n;
-    __shared__ float bb[64][5];
-    const int t = threadIdx.x;
-    const int64_t bj = (int64_t)cb * 64 + t;
-    if (bj < nv) {
-        const float* s = boxes + 5 * (int64_t)ord[bj];
-        for (int q = 0; q < 5; ++q) bb[t][q] = s[q];
+    const int64_t j = (int64_t)cb * 64 + lane;
+    bool sup = false;
+    if (j > a && j < nv) {
+        float ba[5], bj[5];
+        const float* sa = boxes + 5 * (int64_t)ord[a];
+        const float* sj = boxes + 5 * (int64_t)ord[j];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { ba[q] = sa[q]; bj[q] = sj[q]; }
+        // circumscribed circles (rotation about the box centre): disjoint circles -> disjoint boxes -> IoU 0, never > thr >= 0
+        const float dx = 0.5f * ((ba[0] + ba[2]) - (bj[0] + bj[2])), dy = 0.5f * ((ba[1] + ba[3]) - (bj[1] + bj[3]));
+        const float ra = 0.5f * sqrtf((ba[2] - ba[0]) * (ba[2] - ba[0]) + (ba[3] - ba[1]) * (ba[3] - ba[1]));
+        const float rj = 0.5f * sqrtf((bj[2] - bj[0]) * (bj[2] - bj[0]) + (bj[3] - bj[1]) * (bj[3] - bj[1]));
+        const float reach = (ra + rj) * 1.0001f + 1e-6f;
+        if (!(dx * dx + dy * dy > reach * reach)) {        // (NaN / inf boxes take the full test, like ml3d_nms)
+            P2 ca[4];
+            box_corners(ba, ca);
+            sup = iou_bev(ba, ca, bj) > thr;
+        }
     }
-    __syncthreads();
-    const int64_t a = (int64_t)rb * 64 + t;
-    if (a >= nv) return;
-    float ba[5];
-    const float* s = boxes + 5 * (int64_t)ord[a];
-    for (int q = 0; q < 5; ++q) ba[q] = s[q];
-    P2 ca[4];
-    box_corners(ba, ca);
-    u64 bits = 0ull;
-    const int64_t left = nv - (int64_t)cb * 64;
-    const int cols = (int)(left < 0 ? 0 : (left < 64 ? left : 64));
-    for (int j = (rb == cb ? t + 1 : 0); j < cols; ++j)
-        if (iou_bev(ba, ca, bb[j]) > thr) bits |= 1ull << j;
-    mask[(p * n + a) * words + cb] = bits;
+    const u64 bits = __ballot(sup);
+    if (lane == 0) mask[(p * n + a) * words + cb] = bits;
 }
 
 __global__ void __launch_bounds__(64)
@@ -401,13 +410,14 @@ extern "C" int ml3d_nms(const float* boxes, const float* scores, int64_t n, floa
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
-extern "C" int ml3d_pp_anchor_scores(const float* cls_nchw, int64_t batch, int num_anchors, int num_classes, int64_t hw,
-                                     float* out_scores, void* stream) {
+extern "C" int ml3d_pp_anchor_scores(const float* cls, const int64_t* cls_strides, int64_t batch, int num_anchors,
+                                     int num_classes, int64_t hw, float* out_scores, void* stream) {
     if (batch < 0 || num_anchors <= 0 || num_classes <= 0 || hw < 0) return ML3D_E_INVALID;
     if (batch * hw == 0) return 0;
-    if (!cls_nchw || !out_scores) return ML3D_E_INVALID;
+    if (!cls || !cls_strides || !out_scores) return ML3D_E_INVALID;
+    const ml3d::HeadMap mc = {cls, cls_strides[0], cls_strides[1], cls_strides[2]};
     hipLaunchKernelGGL(ml3d::pp_anchor_scores, dim3((unsigned)((batch * hw + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       cls_nchw, batch, num_anchors, num_classes, hw, out_scores);
+                       mc, batch, num_anchors, num_classes, hw, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
@@ -421,8 +431,8 @@ extern "C" size_t ml3d_pp_boxes_workspace_bytes(int64_t batch, int64_t k, int nu
            nms_align(4 * (P / num_classes) * n) /* dir */ + 512;
 }
 
-extern "C" int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const float* dir_nchw, const float* anchors,
-                             const int64_t* candidates, int64_t batch, int64_t k, int num_anchors, int num_classes, int64_t hw,
+extern "C" int ml3d_pp_boxes(const float* cls, const float* reg, const float* dir, const int64_t* strides9,
+                             const float* anchors, const int64_t* candidates, int64_t batch, int64_t k, int num_anchors, int num_classes, int64_t hw,
                              float score_threshold, float iou_threshold, float dir_offset, float* out_rows,
                              int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
     if (batch < 0 || k < 0 || num_anchors <= 0 || num_classes <= 0 || hw < 0 || !out_total) return ML3D_E_INVALID;
@@ -430,7 +440,9 @@ extern "C" int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const
     hipStream_t st = (hipStream_t)stream;
     if (batch == 0) return 0;
     if (k == 0) { (void)hipMemsetAsync(out_total, 0, sizeof(int32_t) * (size_t)batch, st); return 0; }
-    if (!cls_nchw || !reg_nchw || !dir_nchw || !anchors || !candidates || !out_rows) return ML3D_E_INVALID;
+    if (!cls || !reg || !dir || !strides9 || !anchors || !candidates || !out_rows) return ML3D_E_INVALID;
+    const ml3d::HeadMap mc = {cls, strides9[0], strides9[1], strides9[2]}, mr = {reg, strides9[3], strides9[4], strides9[5]},
+                        md = {dir, strides9[6], strides9[7], strides9[8]};
     if (workspace_bytes < ml3d_pp_boxes_workspace_bytes(batch, k, num_classes)) return ML3D_E_WORKSPACE;
     const int64_t P = batch * num_classes;
     const int words = (int)((k + 63) / 64);
@@ -444,10 +456,10 @@ extern "C" int ml3d_pp_boxes(const float* cls_nchw, const float* reg_nchw, const
     float* bev = (float*)p;          p += nms_align(4 * 5 * (size_t)(batch * k));
     float* score = (float*)p;        p += nms_align(4 * (size_t)(P * k));
     int32_t* dirbit = (int32_t*)p;
-    hipLaunchKernelGGL(ml3d::pp_decode, dim3((unsigned)((batch * k + 255) / 256)), dim3(256), 0, st, cls_nchw, reg_nchw, dir_nchw,
+    hipLaunchKernelGGL(ml3d::pp_decode, dim3((unsigned)((batch * k + 255) / 256)), dim3(256), 0, st, mc, mr, md,
                        anchors, candidates, batch, k, num_anchors, num_classes, hw, box, bev, score, dirbit);
     hipLaunchKernelGGL(ml3d::nmsb_order, dim3((unsigned)P), dim3(256), 0, st, score, k, score_threshold, order, nvalid);
-    hipLaunchKernelGGL(ml3d::nmsb_mask, dim3((unsigned)words, (unsigned)words, (unsigned)P), dim3(64), 0, st, bev, order, nvalid,
+    hipLaunchKernelGGL(ml3d::nmsb_mask, dim3((unsigned)words, (unsigned)k, (unsigned)P), dim3(64), 0, st, bev, order, nvalid,
                        k, num_classes, iou_threshold, words, mask);
     hipLaunchKernelGGL(ml3d::nmsb_reduce, dim3((unsigned)P), dim3(64), 0, st, mask, order, nvalid, k, words, keep, count);
     hipLaunchKernelGGL(ml3d::pp_collect, dim3((unsigned)((P * k + 255) / 256)), dim3(256), 0, st, box, score, dirbit, keep, count,

@@ -236,6 +236,71 @@ radius_fill(RadArgs A, const int64_t* __restrict__ row_splits, int index_local, 
         }
 }
 
+// ---- one traversal for the DENSE result (batch_neighbors of the KPConv batcher) ---------------------------------------
+// The two-phase form walks the grid twice (count -> host reads the sizes -> fill): 1.4 + 1.9 ms of a 12 ms 64-sphere step
+// (profiles/r03_kp_kernel_stats.csv).  For the dense [Nq, longest] matrix the only thing the host must know before it can
+// allocate is the LONGEST row.  radius_gather does the whole search once -- scan, compaction, rank sort -- and parks every
+// row, already in canonical order and with global indices, in a stash of `cap` entries per query next to its length;
+// radius_expand then only copies rows into the [Nq, cols] matrix and pads (a coalesced stream).  A row longer than `cap`
+// (or than the LDS staging row) raises a flag and the caller falls back to the two-phase entries for that search.
+__global__ void __launch_bounds__(256)
+radius_gather(RadArgs A, int cap, int32_t* __restrict__ stash, int* __restrict__ counts, unsigned long long* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) u64 rows[4][RAD_LDS_ROW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + w;
+    if (t >= A.nq) return;                       // wave-uniform; no block barrier below
+    RadQuery Q = rad_setup(A, t);
+    const GridSeg g = A.G.segs[Q.s];
+    rad_box(Q, g, A.r);
+    int total = 0;
+    rad_scan(A, Q, g, lane, [&](bool act, const float4& c) {
+        const float d2 = dist2_canon(Q.qx, Q.qy, Q.qz, c.x, c.y, c.z);
+        const bool hit = act && d2 <= A.r2;
+        const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c.w);
+        const u64 m = __ballot(hit);
+        if (hit) {
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < RAD_LDS_ROW) rows[w][pos] = key;
+        }
+        total += __popcll(m);
+    });
+    if (lane == 0) {
+        counts[t] = total;
+        // longest row / overflow flag: a plain read first -- after the first few waves the maximum stands and almost no
+        // wave issues the atomic (one atomic per wave on one address would serialise 160 000 of them per 640 000 queries)
+        if ((unsigned long long)total > *(volatile unsigned long long*)&stats[1]) atomicMax(&stats[1], (unsigned long long)total);
+        if (total > cap || total > RAD_LDS_ROW) stats[0] = 1ull;
+    }
+    if (total > cap || total > RAD_LDS_ROW) return;
+    wave_sync();
+    const int64_t base = seg_begin_global(A.psegs, Q.s);
+    const double* db = reinterpret_cast<const double*>(rows[w]);
+    int32_t* orow = stash + t * cap;
+    for (int e = lane; e < total; e += 64) {
+        const double key = db[e];
+        int rank = 0;
+        int j = 0;
+        for (; j + 2 <= total; j += 2) {
+            const double k0 = db[j], k1 = db[j + 1];
+            rank += (k0 < key ? 1 : 0) + (k1 < key ? 1 : 0);
+        }
+        if (j < total) rank += db[j] < key ? 1 : 0;
+        const u64 kb = (u64)__double_as_longlong(key);
+        orow[rank] = (int32_t)((int64_t)(unsigned)(kb & 0xffffffffull) + base);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+radius_expand(const int32_t* __restrict__ stash, const int* __restrict__ counts, int64_t nq, int cap, int64_t cols,
+              int32_t pad_value, int32_t* __restrict__ out) {
+    const int64_t total = nq * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / cols;
+        const int j = (int)(i - t * cols);
+        out[i] = j < counts[t] ? stash[t * cap + j] : pad_value;
+    }
+}
+
 // ---- ragged_to_dense -----------------------------------------------------------------------------
 // element = `elem` 4-byte words; out[r][c] = values[rs[r] + c] for c < min(len, cols), else default
 __global__ void ragged_to_dense_k(const uint32_t* __restrict__ values, const int64_t* __restrict__ rs, int64_t rows,
@@ -357,6 +422,68 @@ extern "C" int ml3d_radius_fill(const float* points, const int64_t* points_row_s
     A.r = radius; A.r2 = radius * radius;
     hipLaunchKernelGGL(radius_fill, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, A, row_splits, index_local,
                        dense_cols, pad_value, out_index, out_dist2, W.spill);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+static size_t rad_dense_fixed_bytes(int64_t n_points, int64_t n_queries, int64_t batch) {
+    return rad_align(grid_ws_bytes(n_points, batch)) + rad_align(sizeof(int) * (size_t)(n_queries + 2)) + rad_align(16) + 256;
+}
+
+extern "C" size_t ml3d_radius_dense_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch, int cap) {
+    if (n_points < 0 || n_queries < 0 || batch <= 0 || cap <= 0 || cap > RAD_LDS_ROW) return 0;
+    return rad_dense_fixed_bytes(n_points, n_queries, batch) + rad_align(sizeof(int32_t) * (size_t)n_queries * (size_t)cap) + 256;
+}
+
+struct RadDenseWs { GridWs grid; int* counts; unsigned long long* stats; int32_t* stash; };
+
+static bool rad_dense_carve(void* ws, size_t bytes, int64_t n_points, int64_t n_queries, int64_t batch, int cap, RadDenseWs* out) {
+    if (bytes < ml3d_radius_dense_workspace_bytes(n_points, n_queries, batch, cap)) return false;
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const size_t gb = grid_ws_bytes(n_points, batch);
+    if (!grid_ws_carve(p, gb, n_points, batch, &out->grid)) return false;
+    p += rad_align(gb);
+    out->counts = (int*)p;                  p += rad_align(sizeof(int) * (size_t)(n_queries + 2));
+    out->stats = (unsigned long long*)p;    p += rad_align(16);
+    out->stash = (int32_t*)p;
+    return true;
+}
+
+extern "C" int ml3d_radius_dense_gather(const float* points, const int64_t* points_row_splits, const float* queries,
+                                        const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
+                                        int64_t n_queries, float radius, int cap, int64_t* out_stats, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    int rc = rad_args(points, points_row_splits, queries, queries_row_splits, batch, n_points, n_queries, radius);
+    if (rc) return rc;
+    if (!out_stats || cap <= 0 || cap > RAD_LDS_ROW) return ML3D_E_INVALID;
+    RadDenseWs W;
+    if (!rad_dense_carve(workspace, workspace_bytes, n_points, n_queries, batch, cap, &W)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Segs ps = {points_row_splits, 0, 0, (int)batch};
+    Segs qs = {queries_row_splits, 0, 0, (int)batch};
+    if (grid_build_fixed(points, ps, W.grid, radius, st)) return ML3D_E_LAUNCH;
+    (void)hipMemsetAsync(out_stats, 0, 16, st);
+    if (n_queries == 0) return 0;
+    RadArgs A;
+    A.G = grid_view(W.grid);
+    A.queries = queries; A.qsegs = qs; A.psegs = ps; A.nq = n_queries;
+    A.r = radius; A.r2 = radius * radius;
+    hipLaunchKernelGGL(radius_gather, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, A, cap, W.stash, W.counts,
+                       (unsigned long long*)out_stats);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_radius_dense_expand(int64_t n_points, int64_t n_queries, int64_t batch, int cap, int64_t dense_cols,
+                                        int32_t pad_value, int32_t* out_index, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    if (n_points < 0 || n_queries < 0 || batch <= 0 || dense_cols < 0 || dense_cols > cap) return ML3D_E_INVALID;
+    if (n_queries == 0 || dense_cols == 0) return 0;
+    if (!out_index) return ML3D_E_INVALID;
+    RadDenseWs W;
+    if (!rad_dense_carve(workspace, workspace_bytes, n_points, n_queries, batch, cap, &W)) return ML3D_E_WORKSPACE;
+    const int64_t total = n_queries * dense_cols;
+    const unsigned nb = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+    hipLaunchKernelGGL(radius_expand, dim3(nb), dim3(256), 0, (hipStream_t)stream, W.stash, W.counts, n_queries, cap, dense_cols,
+                       pad_value, out_index);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

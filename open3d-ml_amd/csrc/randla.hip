@@ -2044,7 +2044,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             if (rc) return rc;
             RowsA As = {};
             As.a = a.a0; As.lda = skip_c; As.k1 = skip_c;
-            Epilogue e1 = {a.bias, up, skip_c, 1, 0.2f, 0, 0, 0, 0, nullptr, a.gather, n[lev], n[lev + 1]};
+            Epilogue e1 = {a.bias, up, skip_c, 1, 0.2f, 0, 0, 0, 0, nullptr, a.gather, n[lev], n[lev + 1], 0, n[lev + 1]};
             rc = gemm_rows(As, a.wt, a.m_total, skip_c, skip_c, e1, outp, skip_c, nullptr, 0, st);
             T.end(1100 + i);
             if (rc) return rc;

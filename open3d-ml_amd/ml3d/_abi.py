@@ -25,6 +25,9 @@ SYMBOLS = [
     "ml3d_radius_workspace_bytes",
     "ml3d_radius_count",
     "ml3d_radius_fill",
+    "ml3d_radius_dense_workspace_bytes",
+    "ml3d_radius_dense_gather",
+    "ml3d_radius_dense_expand",
     "ml3d_ragged_to_dense",
     "ml3d_voxelize_workspace_bytes",
     "ml3d_voxelize_count",
@@ -99,6 +102,12 @@ def bind(lib):
     lib.ml3d_radius_count.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_radius_fill.restype = C.c_int
     lib.ml3d_radius_fill.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, vp, i64, i32, i64, C.c_int32, vp, vp, vp, sz, vp, sz, vp]
+    lib.ml3d_radius_dense_workspace_bytes.restype = sz
+    lib.ml3d_radius_dense_workspace_bytes.argtypes = [i64, i64, i64, i32]
+    lib.ml3d_radius_dense_gather.restype = C.c_int
+    lib.ml3d_radius_dense_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, i32, vp, vp, sz, vp]
+    lib.ml3d_radius_dense_expand.restype = C.c_int
+    lib.ml3d_radius_dense_expand.argtypes = [i64, i64, i64, i32, i64, C.c_int32, vp, vp, sz, vp]
     lib.ml3d_ragged_to_dense.restype = C.c_int
     lib.ml3d_ragged_to_dense.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
     lib.ml3d_voxelize_workspace_bytes.restype = sz
@@ -123,8 +132,8 @@ def bind(lib):
     lib.ml3d_linear_workspace_bytes.restype = sz
     lib.ml3d_linear_workspace_bytes.argtypes = [i64, i32, i32]
     lib.ml3d_linear.restype = C.c_int
-    lib.ml3d_linear.argtypes = [vp, i64, i32, vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i32, f32, vp, i64, i64, i32,
-                                vp, sz, vp]
+    lib.ml3d_linear.argtypes = [vp, i64, i32, vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, vp, i64, i64, i32, f32, vp, i64,
+                                i64, i32, vp, sz, vp]
     lib.ml3d_gather_pool.restype = C.c_int
     lib.ml3d_gather_pool.argtypes = [vp, i64, i32, vp, i64, i64, i32, vp, vp]
     lib.ml3d_pillar_features_workspace_bytes.restype = sz
@@ -145,11 +154,11 @@ def bind(lib):
     lib.ml3d_nms.restype = C.c_int
     lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_pp_anchor_scores.restype = C.c_int
-    lib.ml3d_pp_anchor_scores.argtypes = [vp, i64, i32, i32, i64, vp, vp]
+    lib.ml3d_pp_anchor_scores.argtypes = [vp, vp, i64, i32, i32, i64, vp, vp]
     lib.ml3d_pp_boxes_workspace_bytes.restype = sz
     lib.ml3d_pp_boxes_workspace_bytes.argtypes = [i64, i64, i32]
     lib.ml3d_pp_boxes.restype = C.c_int
-    lib.ml3d_pp_boxes.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i64, f32, f32, f32, vp, vp, vp, sz, vp]
+    lib.ml3d_pp_boxes.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i64, f32, f32, f32, vp, vp, vp, sz, vp]
     lib.ml3d_iou_bev.restype = C.c_int
     lib.ml3d_iou_bev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.ml3d_iou_3d.restype = C.c_int

@@ -312,3 +312,67 @@ class KPConvPipeline:
     def synchronize(self):
         self.build.synchronize()
         self.compute.synchronize()
+
+
+class PointPillarsStream:
+    """Host sweeps in, detections out (PointPillars detection, frame-parallel rows a15-a19): what ``bench.py --workload
+    pointpillars`` times.  Three HIP streams: the pinned host sweeps of step i + 1 are uploaded on the copy stream while step i
+    runs voxelize -> pillar features -> backbone -> heads -> batched box decode + NMS on the compute stream, and the few
+    hundred KB of detections (rows + per-sample counts) travel back into pinned host buffers asynchronously; ``submit``
+    returns the detections of the PREVIOUS step (three lists like ``Anchor3DHead.get_bboxes``; None on the first call) after
+    waiting only for that step's copy event -- no device-wide synchronisation anywhere, the host runs one step ahead.
+    ``flush`` returns the last step's detections."""
+
+    def __init__(self, model, device):
+        self.model = model
+        self.device = _abi.require_gpu(device, "PointPillarsStream")
+        with torch.cuda.device(self.device):
+            self.h2d = torch.cuda.Stream()
+            self.compute = torch.cuda.Stream()
+            self.uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.host = [None, None]       # (rows pinned, total pinned)
+        self.keep = [None, None]       # device tensors of a slot's step, referenced until its results have been fetched
+        self.k = 0
+        self.pending = None
+
+    def _fetch(self, slot):
+        self.done[slot].synchronize()
+        rows, total = self.host[slot]
+        out = self.model.bbox_head.split_rows(rows, total)
+        self.keep[slot] = None
+        return [b.clone() for b in out[0]], [s.clone() for s in out[1]], out[2]
+
+    @torch.no_grad()
+    def submit(self, host_clouds):
+        slot = self.k & 1
+        self.k += 1
+        prev, self.pending = self.pending, slot
+        with torch.cuda.device(self.device):
+            with torch.cuda.stream(self.h2d):
+                clouds = [h.to(self.device, non_blocking=True) for h in host_clouds]
+                self.uploaded[slot].record(self.h2d)
+            with torch.cuda.stream(self.compute):
+                self.compute.wait_event(self.uploaded[slot])
+                for c in clouds:
+                    c.record_stream(self.compute)
+                rows, total = self.model.detect(clouds)
+                res = None
+                if prev is not None:
+                    res = self._fetch(prev)          # (its pinned buffers are free again before this step's copies are enqueued)
+                if self.host[slot] is None or self.host[slot][0].shape != rows.shape:
+                    self.host[slot] = (torch.empty(rows.shape, dtype=rows.dtype).pin_memory(),
+                                       torch.empty(total.shape, dtype=total.dtype).pin_memory())
+                self.host[slot][0].copy_(rows, non_blocking=True)
+                self.host[slot][1].copy_(total, non_blocking=True)
+                self.done[slot].record(self.compute)
+                self.keep[slot] = (clouds, rows, total)
+        return res
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        return None if prev is None else self._fetch(prev)
+
+    def synchronize(self):
+        self.h2d.synchronize()
+        self.compute.synchronize()

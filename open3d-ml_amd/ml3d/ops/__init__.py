@@ -278,7 +278,7 @@ class _RadiusPlan:
 
 def resolve_plans(*plans):
     """One read-back for the sizes of several deferred plans (anything with ``.stats`` [2] int64 and ``.resolve``)."""
-    todo = [p for p in plans if p is not None and p.total is None]
+    todo = [p for p in plans if p is not None and p.longest is None]
     if todo:
         vals = torch.cat([p.stats for p in todo]).tolist()
         for i, p in enumerate(todo):
@@ -294,11 +294,77 @@ def fixed_radius_search(points, queries, radius, points_row_splits=None, queries
     return RadiusResult(idx, plan.row_splits, d2 if d2 is not None else torch.empty(0, device=idx.device))
 
 
+class _DenseRadiusPlan:
+    """``batch_neighbors`` in ONE traversal (``ml3d_radius_dense_gather`` / ``_expand``): the search runs once and parks every
+    row, sorted and with global indices, in a per-query stash of ``CAP`` entries inside the workspace; what the host must read
+    before it can allocate the dense matrix is just ``stats`` = (overflow flag, longest row).  A row longer than ``CAP`` sends
+    this one search through the two-phase ``_RadiusPlan`` instead (count -> read -> fill)."""
+    CAP = 128
+
+    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits):
+        lib = _abi.get()
+        _need_gpu(points, queries)
+        self.points = points.contiguous().float()
+        self.queries = self.points if queries is points else queries.contiguous().float()
+        dev = self.points.device
+        self.ns, self.nq = self.points.shape[0], self.queries.shape[0]
+        self.prs = _splits(points_row_splits, self.ns, dev)
+        self.qrs = _splits(queries_row_splits, self.nq, dev)
+        if self.prs.numel() != self.qrs.numel():
+            raise RuntimeError("fixed_radius_search: points and queries must have the same batch size")
+        self.batch = self.prs.numel() - 1
+        self.radius = float(radius)
+        self.stats = torch.empty(2, dtype=torch.int64, device=dev)
+        self.wsb = lib.ml3d_radius_dense_workspace_bytes(self.ns, self.nq, self.batch, self.CAP)
+        self.ws = _ws(self.wsb, dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_radius_dense_gather(self.points.data_ptr(), self.prs.data_ptr(), self.queries.data_ptr(),
+                                              self.qrs.data_ptr(), self.batch, self.ns, self.nq, self.radius, self.CAP,
+                                              self.stats.data_ptr(), self.ws.data_ptr(), self.wsb, _stream())
+        _abi.check(rc, "ml3d_radius_dense_gather")
+        self.total = self.longest = None          # (``total`` stays unknown: the dense result never needs it)
+        self.fallback = None
+
+    def resolve(self, values=None):
+        if self.longest is None:
+            overflow, longest = (int(x) for x in (self.stats.tolist() if values is None else values))
+            if overflow:                          # some row is longer than the stash: the two-phase search for this one
+                self.fallback = _RadiusPlan(self.points, self.queries, self.radius, self.prs, self.qrs)
+                longest = self.fallback.longest
+            self.longest, self.total = longest, -1
+        return self
+
+    def fill_dense(self, cols, pad_value):
+        if self.fallback is not None:
+            return self.fallback.fill(dense_cols=cols, pad_value=pad_value)[0]
+        lib = _abi.get()
+        dev = self.points.device
+        idx = torch.empty((self.nq, int(cols)), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_radius_dense_expand(self.ns, self.nq, self.batch, self.CAP, int(cols), int(pad_value), idx.data_ptr(),
+                                              self.ws.data_ptr(), self.wsb, _stream())
+        _abi.check(rc, "ml3d_radius_dense_expand")
+        return idx
+
+
+def _one_pass_radius():
+    # ML3D_RADIUS_ONE_PASS=0 (read once): the two-phase search for the dense result as well (A/B runs)
+    global _ONE_PASS
+    try:
+        return _ONE_PASS
+    except NameError:
+        import os
+        _ONE_PASS = os.environ.get("ML3D_RADIUS_ONE_PASS", "1") != "0"
+        return _ONE_PASS
+
+
 def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius):
-    """Deferred first half of ``radius_neighbors_dense``: grid + counts enqueued, sizes not read yet."""
+    """Deferred first half of ``radius_neighbors_dense``: the search is enqueued, its sizes not read yet."""
     dev = supports.device
-    return _RadiusPlan(supports, queries, radius, _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0],
-                       defer=True)
+    prs, qrs = _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0]
+    if _one_pass_radius():
+        return _DenseRadiusPlan(supports, queries, radius, prs, qrs)
+    return _RadiusPlan(supports, queries, radius, prs, qrs, defer=True)
 
 
 def radius_fill_dense(plan, n_supports, max_cols=None):
@@ -308,6 +374,8 @@ def radius_fill_dense(plan, n_supports, max_cols=None):
     cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
     if plan.nq == 0 or cols == 0:
         return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
+    if isinstance(plan, _DenseRadiusPlan):
+        return plan.fill_dense(cols, n_supports)
     idx, _ = plan.fill(dense_cols=cols, pad_value=n_supports)
     return idx
 
@@ -315,13 +383,7 @@ def radius_fill_dense(plan, n_supports, max_cols=None):
 def radius_neighbors_dense(queries, supports, q_lengths, s_lengths, radius, max_cols=None):
     """``batch_neighbors`` (ml3d/torch/models/kpconv.py:2002-2034) on the GPU: dense int32 [Nq, max_nbrs]
     neighbour matrix padded with the shadow index Ns; search + ragged_to_dense fused in one fill kernel."""
-    dev = supports.device
-    plan = _RadiusPlan(supports, queries, radius, _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0])
-    cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
-    if plan.nq == 0 or cols == 0:
-        return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
-    idx, _ = plan.fill(dense_cols=cols, pad_value=supports.shape[0])
-    return idx
+    return radius_fill_dense(radius_plan_dense(queries, supports, q_lengths, s_lengths, radius), supports.shape[0], max_cols)
 
 
 def ragged_to_dense(values, row_splits, out_col_size, default_value):
@@ -569,9 +631,11 @@ def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias
     return out
 
 
-def linear(a, weights_t, bias=None, a2=None, gather=None, residual=None, act=0, slope=0.0):
+def linear(a, weights_t, bias=None, a2=None, gather=None, residual=None, act=0, slope=0.0, residual_gather=None):
     """act([gather(a) | a2] @ weights_t + bias + residual) — UnaryBlock / decoder step (kpconv.py:1288-1293,
-    283-286).  gather: int32 [M, H] neighbour matrix whose FIRST column selects the row of ``a`` (closest_pool)."""
+    283-286).  gather: int32 [M, H] neighbour matrix whose FIRST column selects the row of ``a`` (closest_pool).
+    residual_gather: int32 [M, H] neighbour matrix whose first column selects the ROW OF ``residual`` added to output row m
+    (rows >= residual.shape[0], the shadow index, add nothing)."""
     lib = _abi.get()
     _need_gpu(a, weights_t, bias, a2, gather, residual)
     dev = a.device
@@ -589,6 +653,12 @@ def linear(a, weights_t, bias=None, a2=None, gather=None, residual=None, act=0, 
     for t in (a, weights_t, bias, a2, residual):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise RuntimeError("linear: float32 contiguous tensors required")
+    rg_stride = 0
+    if residual_gather is not None:
+        if residual is None or residual_gather.dtype != torch.int32 or not residual_gather.is_contiguous() or \
+                residual_gather.shape[0] != m:
+            raise RuntimeError("linear: residual_gather must be a contiguous int32 [M, H] matrix next to a residual")
+        rg_stride = residual_gather.shape[1] if residual_gather.dim() == 2 else 1
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
     wsb = lib.ml3d_linear_workspace_bytes(m, n, k1 + k2)
     ws = _ws(wsb, dev)
@@ -596,7 +666,9 @@ def linear(a, weights_t, bias=None, a2=None, gather=None, residual=None, act=0, 
         rc = lib.ml3d_linear(a.data_ptr(), k1, k1, None if gather is None else gather.data_ptr(), gstride, a.shape[0],
                              None if a2 is None else a2.data_ptr(), k2, k2, weights_t.data_ptr(),
                              None if bias is None else bias.data_ptr(),
-                             None if residual is None else residual.data_ptr(), n, int(act), float(slope),
+                             None if residual is None else residual.data_ptr(), n,
+                             None if residual_gather is None else residual_gather.data_ptr(), rg_stride,
+                             0 if residual is None else residual.shape[0], int(act), float(slope),
                              out.data_ptr(), n, m, n, ws.data_ptr(), wsb, _stream())
     _abi.check(rc, "ml3d_linear")
     return out
@@ -719,13 +791,27 @@ def nms(boxes, scores, nms_overlap_thresh):
     return keep[:int(count.item())]
 
 
+def _head_map(t):
+    """[B, ch, H, W] float32 head map in any layout whose (H, W) plane has ONE pixel stride (NCHW tensors, channel slices of
+    an NHWC tensor viewed as NCHW) -> (tensor, (batch, channel, pixel) element strides); anything else is made contiguous."""
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 4:
+        raise RuntimeError("pointpillars_boxes: head maps must be [B, channels, H, W]")
+    if t.shape[2] > 1 and t.stride(2) != t.shape[3] * t.stride(3):
+        t = t.contiguous()
+    return t, (t.stride(0), t.stride(1), t.stride(3))
+
+
 def pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, nms_pre, score_thr, iou_thr, dir_offset=0.0):
     """``Anchor3DHead.get_bboxes`` for the whole batch with no host read-back inside (point_pillars.py:945-1025): head maps
-    [B, A*C | A*7 | A*2, H, W] (NCHW, like the reference's), ``anchors`` [H*W*A, 7] -> (rows [B, C*k, 9], total [B] int32):
-    ``rows[b, :total[b]]`` = (x, y, z, w, l, h, yaw, score, label) of sample b's detections, class-major in NMS order."""
+    [B, A*C | A*7 | A*2, H, W] (the reference's NCHW tensors, or NCHW VIEWS of a fused NHWC head tensor -- no copy either
+    way), ``anchors`` [H*W*A, 7] -> (rows [B, C*k, 9], total [B] int32): ``rows[b, :total[b]]`` = (x, y, z, w, l, h, yaw,
+    score, label) of sample b's detections, class-major in NMS order."""
     lib = _abi.get()
     _need_gpu(cls_scores, bbox_preds, dir_preds, anchors)
-    cls_scores, bbox_preds, dir_preds = (t.detach().contiguous().float() for t in (cls_scores, bbox_preds, dir_preds))
+    (cls_scores, s_cls), (bbox_preds, s_reg), (dir_preds, s_dir) = (_head_map(t) for t in (cls_scores, bbox_preds, dir_preds))
     anchors = anchors.contiguous().float()
     B, AC, H, W = cls_scores.shape
     A = dir_preds.shape[1] // 2
@@ -734,10 +820,11 @@ def pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, nms_pre, scor
         raise RuntimeError("pointpillars_boxes: head maps / anchors do not agree on the anchor count")
     dev = cls_scores.device
     n_anchor = H * W * A
+    strides = (C.c_int64 * 9)(*[int(v) for v in s_cls + s_reg + s_dir])
     with torch.cuda.device(dev):
         if n_anchor > int(nms_pre):
             smax = torch.empty((B, n_anchor), dtype=torch.float32, device=dev)
-            rc = lib.ml3d_pp_anchor_scores(cls_scores.data_ptr(), B, A, C_, H * W, smax.data_ptr(), _stream())
+            rc = lib.ml3d_pp_anchor_scores(cls_scores.data_ptr(), strides, B, A, C_, H * W, smax.data_ptr(), _stream())
             _abi.check(rc, "ml3d_pp_anchor_scores")
             cand = torch.topk(smax, int(nms_pre), dim=1)[1].contiguous()
         else:
@@ -749,7 +836,7 @@ def pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, nms_pre, scor
         if wsb == 0:
             raise RuntimeError("pointpillars_boxes: nms_pre = %d candidates per sample is beyond the batched kernel (4096)" % k)
         ws = _ws(wsb, dev)
-        rc = lib.ml3d_pp_boxes(cls_scores.data_ptr(), bbox_preds.data_ptr(), dir_preds.data_ptr(), anchors.data_ptr(),
+        rc = lib.ml3d_pp_boxes(cls_scores.data_ptr(), bbox_preds.data_ptr(), dir_preds.data_ptr(), strides, anchors.data_ptr(),
                                cand.data_ptr(), B, k, A, C_, H * W, float(score_thr), float(iou_thr), float(dir_offset),
                                rows.data_ptr(), total.data_ptr(), ws.data_ptr(), wsb, _stream())
     _abi.check(rc, "ml3d_pp_boxes")

@@ -10,6 +10,8 @@ points / neighbour / pool / upsample matrices of ``KPConvBatch.segmentation_inpu
 Deformable blocks (only kpconv_parislille3d.yml) are outside the rigid scope and raise.
 There is no CPU execution path.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -269,6 +271,20 @@ class KPFCNN(nn.Module):
         return ops.linear(x, p['wt'], p['b'], a2=a2, gather=gather, residual=residual,
                           act=p['act'] if act is None else act, slope=p['slope'] if slope is None else slope)
 
+    _SPLIT_DECODER = os.environ.get("ML3D_KP_DECODER_SPLIT", "1") != "0"     # A/B knob (speed only), read once
+
+    def _upsample_concat_unary(self, p, x, skip, up):
+        """NearestUpsampleBlock + torch.cat + UnaryBlock of the decoder (kpconv.py:283-286, 821-838, 1468-1481):
+        ``act(W . [x[up[:, 0]] ; skip] + b)``.  The Linear is split by linearity, ``(x W_x)[up[:, 0]] + skip W_skip``: the
+        upsampled half is multiplied on the COARSE level (a quarter of the rows) and added back through the upsampling index
+        in the fine GEMM's epilogue, whose A operand is then one dense row block (the streamlined K loop) instead of a
+        gathered + concatenated one.  Same result up to summation order (tolerance 1e-4 on the logits)."""
+        if not self._SPLIT_DECODER:
+            return self._unary(p, x, a2=skip, gather=up)
+        k1 = x.shape[1]
+        coarse = ops.linear(x, p['wt'][:k1], None)
+        return ops.linear(skip, p['wt'][k1:], p['b'], residual=coarse, residual_gather=up, act=p['act'], slope=p['slope'])
+
     def forward(self, batch):
         """``batch``: object with ``points``, ``neighbors``, ``pools``, ``upsamples`` (lists per layer) and
         ``features`` — the reference's ``KPConvBatch`` (int64 CPU tensors are moved / narrowed to int32) or this
@@ -312,7 +328,7 @@ class KPFCNN(nn.Module):
             if bi in self.decoder_concats:
                 skip = skip_x.pop()
                 if pending_up is not None:
-                    x = self._unary(p, x, a2=skip, gather=pending_up)
+                    x = self._upsample_concat_unary(p, x, skip, pending_up)
                     pending_up = None
                 else:
                     x = self._unary(p, x, a2=skip)

@@ -224,19 +224,16 @@ class Anchor3DHead(nn.Module):
         return cache[key]
 
     @torch.no_grad()
-    def get_bboxes(self, cls_scores, bbox_preds, dir_preds):
-        """point_pillars.py:945-963 for the whole batch: ONE pass of the batched HIP kernels (``ops.pointpillars_boxes``:
-        anchor scores -> top nms_pre -> decode -> B x C rotated NMS problems -> class-major rows) and ONE host read-back (the
-        per-sample box counts) instead of the reference's per-sample, per-class loop.  Same lists of (bboxes [M, 7],
-        scores [M], labels [M]) as the reference; ``get_bboxes_single`` keeps the loop formulation (one nms call per class)."""
-        if not torch.is_tensor(cls_scores):
-            cls_scores, bbox_preds, dir_preds = (torch.stack(list(t)) for t in (cls_scores, bbox_preds, dir_preds))
-        if self.nms_pre > 4096:                      # beyond the batched kernel's per-problem capacity: the loop formulation
-            out = [self.get_bboxes_single(c, b, d) for c, b, d in zip(cls_scores, bbox_preds, dir_preds)]
-            return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
-        anchors = self._anchors_for(cls_scores.shape[-2:], cls_scores.device)
-        rows, total = ops.pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, self.nms_pre, self.score_thr, 0.01,
-                                             self.dir_offset)
+    def boxes_device(self, cls_scores, bbox_preds, dir_preds):
+        """The batched HIP decode + NMS (``ops.pointpillars_boxes``) with nothing read back: rows [B, C * k, 9] =
+        (box7, score, label), class-major in NMS order, and total [B] int32 = rows used per sample -- both on the device."""
+        anchors = self._anchors_for(tuple(cls_scores.shape[-2:]), cls_scores.device)
+        return ops.pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, self.nms_pre, self.score_thr, 0.01,
+                                      self.dir_offset)
+
+    @staticmethod
+    def split_rows(rows, total):
+        """(rows, total) of ``boxes_device`` (device or host tensors) -> the reference's three lists."""
         boxes, scores, labels = [], [], []
         for b, n in enumerate(total.tolist()):
             r = rows[b, :n]
@@ -244,6 +241,19 @@ class Anchor3DHead(nn.Module):
             scores.append(r[:, 7])
             labels.append(r[:, 8].long())
         return boxes, scores, labels
+
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, dir_preds):
+        """point_pillars.py:945-963 for the whole batch: ONE pass of the batched HIP kernels (anchor scores -> top nms_pre ->
+        decode -> B x C rotated NMS problems -> class-major rows) and ONE host read-back (the per-sample box counts) instead of
+        the reference's per-sample, per-class loop.  Same lists of (bboxes [M, 7], scores [M], labels [M]) as the reference;
+        ``get_bboxes_single`` keeps the loop formulation (one nms call per class)."""
+        if not torch.is_tensor(cls_scores):
+            cls_scores, bbox_preds, dir_preds = (torch.stack(list(t)) for t in (cls_scores, bbox_preds, dir_preds))
+        if self.nms_pre > 4096:                      # beyond the batched kernel's per-problem capacity: the loop formulation
+            out = [self.get_bboxes_single(c, b, d) for c, b, d in zip(cls_scores, bbox_preds, dir_preds)]
+            return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+        return self.split_rows(*self.boxes_device(cls_scores, bbox_preds, dir_preds))
 
 
 def _bn_affine(bn):
@@ -366,9 +376,9 @@ class PointPillars(nn.Module):
             off += d['cout']
         return neck
 
-    def forward(self, inputs):
-        """``inputs.point``: list of [N_i, 3+C] clouds (point_pillars.py:133-138).  Returns (cls_score, bbox_pred,
-        dir_cls_preds) as NCHW tensors like ``Anchor3DHead.forward``."""
+    def head_maps_nhwc(self, inputs):
+        """The three head maps as ONE NHWC tensor [B, H, W, A*C + A*7 + A*2] (what the fused head GEMM writes) + the
+        channel split."""
         if self.training:
             raise RuntimeError("PointPillars (MI355X build) implements the inference forward only; call .eval()")
         _abi.require_gpu(self.device, "PointPillars.forward")
@@ -376,9 +386,27 @@ class PointPillars(nn.Module):
         neck = self.extract_feats(points)
         P = self.packed_params(self.device)
         B, H, W, Cn = neck.shape
-        heads = ops.linear(neck.view(B * H * W, Cn), P['head_w'], P['head_b']).view(B, H, W, -1)
+        return ops.linear(neck.view(B * H * W, Cn), P['head_w'], P['head_b']).view(B, H, W, -1), P['head_split']
+
+    @torch.no_grad()
+    def detect(self, inputs):
+        """Clouds -> detections on the device, (rows [B, C * k, 9], total [B]) of ``Anchor3DHead.boxes_device``: ``forward`` +
+        ``get_bboxes`` without the three NHWC -> NCHW transposes in between (the decode kernels read channel-slice views of
+        the fused head tensor) and without a host read-back.  Same numbers as ``get_bboxes(*forward(inputs))``."""
+        heads, split = self.head_maps_nhwc(inputs)
+        nchw = heads.permute(0, 3, 1, 2)
+        views, off = [], 0
+        for c in split:
+            views.append(nchw[:, off:off + c])
+            off += c
+        return self.bbox_head.boxes_device(*views)
+
+    def forward(self, inputs):
+        """``inputs.point``: list of [N_i, 3+C] clouds (point_pillars.py:133-138).  Returns (cls_score, bbox_pred,
+        dir_cls_preds) as NCHW tensors like ``Anchor3DHead.forward``."""
+        heads, split = self.head_maps_nhwc(inputs)
         outs, off = [], 0
-        for c in P['head_split']:
+        for c in split:
             outs.append(ops.nhwc_to_nchw(heads, off, c))
             off += c
         return tuple(outs)

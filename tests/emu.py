@@ -255,7 +255,8 @@ def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, s
     return rc, out
 
 
-def linear(a, wt, bias=None, a2=None, gather=None, gather_stride=1, residual=None, act=0, slope=0.0, m=None):
+def linear(a, wt, bias=None, a2=None, gather=None, gather_stride=1, residual=None, act=0, slope=0.0, m=None,
+           residual_gather=None):
     L = lib()
     a = np.ascontiguousarray(a, np.float32)
     wt = np.ascontiguousarray(wt, np.float32)
@@ -268,13 +269,15 @@ def linear(a, wt, bias=None, a2=None, gather=None, gather_stride=1, residual=Non
         m = a.shape[0] if g is None else (g.size // gather_stride)
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     r = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    rg = None if residual_gather is None else np.ascontiguousarray(residual_gather, np.int32)
     out = np.zeros((m, n), np.float32)
     wsb = L.ml3d_linear_workspace_bytes(m, n, k1 + k2)
     ws = _ws(wsb)
     rc = L.ml3d_linear(a.ctypes.data, k1, k1, None if g is None else g.ctypes.data, gather_stride, a.shape[0],
                        None if a2c is None else a2c.ctypes.data, k2, k2, wt.ctypes.data,
-                       None if b is None else b.ctypes.data, None if r is None else r.ctypes.data, n, act, slope,
-                       out.ctypes.data, n, m, n, ws.ctypes.data, wsb, None)
+                       None if b is None else b.ctypes.data, None if r is None else r.ctypes.data, n,
+                       None if rg is None else rg.ctypes.data, 0 if rg is None else (rg.shape[1] if rg.ndim == 2 else 1),
+                       0 if r is None else r.shape[0], act, slope, out.ctypes.data, n, m, n, ws.ctypes.data, wsb, None)
     return rc, out
 
 

@@ -134,3 +134,58 @@ for nms_pre, H, W, thr, bias in ((300, 12, 16, 0.3, 0.0), (64, 4, 4, 0.1, 0.0), 
     assert np.array_equal(sl.numpy(), labels[0].numpy()) and (len(sl) == 0 or np.abs(sb.numpy() - boxes[0].numpy()).max() <= 1e-6)
 print("ok")
 ''')
+
+
+def test_pointpillars_stream_returns_each_steps_detections_one_step_later():
+    """``ml3d.engine.PointPillarsStream`` (what bench.py --workload pointpillars times): upload -> forward -> batched decode +
+    NMS -> asynchronous copy back; ``submit`` hands out the previous step's lists, identical to ``get_bboxes`` of a plain
+    forward of the same sweeps."""
+    _run(r'''
+import synth_data, synth_weights as W
+from ml3d.engine import PointPillarsStream
+from ml3d.torch.models.point_pillars import PointPillars
+cfg = W.POINTPILLARS_SMALL_CFG
+m = PointPillars(device="cpu", **cfg)
+m.load_state_dict(W.pointpillars_state_dict(cfg, 4))
+steps = [[torch.from_numpy(W.crop_for_cfg(synth_data.kitti_sweep(10 * s + i), cfg)) for i in range(2)] for s in range(3)]
+want = [m.bbox_head.get_bboxes(*m(c)) for c in steps]          # the reference API path: NCHW head maps, then get_bboxes
+pipe = PointPillarsStream(m, "cpu")
+got = [pipe.submit(c) for c in steps] + [pipe.flush()]
+assert got[0] is None and pipe.flush() is None
+for (wb, ws, wl), (gb, gs, gl) in zip(want, got[1:]):
+    assert len(gb) == 2
+    for i in range(2):
+        assert torch.equal(wl[i], gl[i]) and torch.equal(wb[i], gb[i]) and torch.equal(ws[i], gs[i]) and len(gl[i]) > 0
+print("ok")
+''')
+
+
+def test_one_pass_dense_radius_search_equals_the_two_phase_search_and_the_oracle():
+    """``ops.radius_neighbors_dense`` = batch_neighbors (kpconv.py:2002-2034).  The one-traversal form (gather into a per-query
+    stash, then expand) against the oracle and the two-phase form: batched supports != queries, an empty item, a query without
+    neighbours, and a cluster of 200 coincident-ish points whose rows overflow the 128-entry stash (falls back, same matrix)."""
+    _run(r'''
+import synth_data
+from oracle import kpconv_ref as K
+from ml3d import ops
+rng = np.random.default_rng(0)
+a, b = synth_data.toronto3d_sphere(5, 1500), synth_data.toronto3d_sphere(6, 900)
+sup = np.concatenate([a, b]).astype(np.float32)
+qa = np.concatenate([K.batch_grid_subsampling(a, [len(a)], 0.3)[0], [[40, 40, 40]]]).astype(np.float32)     # last: no neighbours
+qb = K.batch_grid_subsampling(b, [len(b)], 0.3)[0].astype(np.float32)
+qry = np.concatenate([qa, qb])
+for r in (0.25, 0.6):
+    ref = K.batch_neighbors(qry, sup, [len(qa), 0, len(qb)], [len(a), 0, len(b)], r)
+    got = ops.radius_neighbors_dense(torch.from_numpy(qry), torch.from_numpy(sup), [len(qa), 0, len(qb)], [len(a), 0, len(b)], r)
+    assert got.dtype == torch.int32 and np.array_equal(got.numpy(), ref), r
+    assert (got[len(qa) - 1] == len(sup)).all()
+plan = ops.radius_plan_dense(torch.from_numpy(qry), torch.from_numpy(sup), [len(qa), 0, len(qb)], [len(a), 0, len(b)], 0.25)
+assert type(plan).__name__ == "_DenseRadiusPlan" and plan.resolve().fallback is None
+# overflow: 200 points within 1 cm -> rows of >= 200 neighbours
+dense = np.concatenate([a[:300], a[7] + rng.normal(0, 0.003, (200, 3)).astype(np.float32)]).astype(np.float32)
+ref = K.batch_neighbors(dense, dense, [len(dense)], [len(dense)], 0.25)
+plan = ops.radius_plan_dense(torch.from_numpy(dense), torch.from_numpy(dense), [len(dense)], [len(dense)], 0.25)
+got = ops.radius_fill_dense(plan, len(dense))
+assert plan.fallback is not None and ref.shape[1] >= 200 and np.array_equal(got.numpy(), ref)
+print("ok")
+''')

@@ -99,6 +99,28 @@ def test_linear_fused_upsample_concat_is_decoder_step():
     assert rc == 0 and np.abs(out - ref).max() <= TOL
 
 
+@pytest.mark.parametrize("m,kc,ks,n", [(200, 64, 32, 48), (1000, 128, 64, 64), (77, 256, 128, 128)])
+def test_linear_split_decoder_step_gathered_residual(m, kc, ks, n):
+    """The decoder step split by linearity (KPFCNN._upsample_concat_unary): (x W_x)[up[:, 0]] + skip W_skip + b, the coarse
+    product entering the fine GEMM's epilogue through the upsampling index; shadow index (= number of coarse rows) adds zeros."""
+    rng = np.random.default_rng(m)
+    nc = max(3, m // 4)
+    xc = rng.standard_normal((nc, kc)).astype(np.float32)
+    skip = rng.standard_normal((m, ks)).astype(np.float32)
+    up = rng.integers(0, nc + 1, (m, 5)).astype(np.int32)           # nc == shadow
+    up[3, 0] = nc
+    wt = (rng.standard_normal((kc + ks, n)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    rc0, coarse = emu.linear(xc, wt[:kc])
+    rc1, out = emu.linear(skip, wt[kc:], bias=b, residual=coarse, residual_gather=up, act=1, slope=0.2)
+    xs = K.closest_pool(torch.from_numpy(xc), torch.from_numpy(up).long())
+    y = torch.cat([xs, torch.from_numpy(skip)], 1) @ torch.from_numpy(wt) + torch.from_numpy(b)
+    ref = torch.nn.functional.leaky_relu(y, 0.2).numpy()
+    assert rc0 == 0 and rc1 == 0 and np.abs(out - ref).max() <= TOL
+    rc2, fused = emu.linear(xc, wt, bias=b, a2=skip, gather=up, gather_stride=5, act=1, slope=0.2)
+    assert rc2 == 0 and np.abs(out - fused).max() <= TOL
+
+
 def test_gather_pools_match_reference_ops():
     rng = np.random.default_rng(2)
     x = rng.standard_normal((500, 24)).astype(np.float32)

@@ -20,7 +20,33 @@ def table(path):
     return out
 
 
+OPS = {   # bench_models.py's roofline key -> (kernel-name substrings that make up the op, units per launch); tables from
+          # `rocprofv3 --pmc ... -- python tools/roofline_ops.py kp|pp` (only that op runs there)
+    "kpconv_block_32_32": (("kp_weighted", "gemm_tile", "splitk", "reduce"), 64),
+    "pp_conv3x3_64": (("gemm_tile",), 16),
+}
+
+
+def add_op(key, fetch_csv, write_csv):
+    """python tools/make_traffic.py --op <key> <fetch.csv> <write.csv>: add one op's entry to profiles/traffic.json"""
+    f, w = table(fetch_csv), table(write_csv)
+    subs, units = OPS[key]
+    fetch_kib = sum(v for (k, c), v in f.items() if c == "FETCH_SIZE" and any(s_ in k for s_ in subs))
+    write_kib = sum(v for (k, c), v in w.items() if c == "WRITE_SIZE" and any(s_ in k for s_ in subs))
+    names = sorted({k for (k, c) in f if c == "FETCH_SIZE" and any(s_ in k for s_ in subs)})
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    out = json.load(open(path))
+    out["kernels"][key] = {"rocprof_names": names, "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib,
+                           "bytes_per_launch_per_frame": (2.0 * fetch_kib + write_kib) * 1024.0 / units,
+                           "source": "%s + %s (tools/roofline_ops.py: the op alone, %d units per launch; sum over its kernels)"
+                                     % (os.path.basename(fetch_csv), os.path.basename(write_csv), units)}
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out["kernels"][key], indent=1))
+
+
 def main():
+    if sys.argv[1] == "--op":
+        return add_op(sys.argv[2], sys.argv[3], sys.argv[4])
     f, w, frames = table(sys.argv[1]), table(sys.argv[2]), int(sys.argv[3])
     kernels = {}
     for key, sub in KEYS.items():
