@@ -120,14 +120,17 @@ int ml3d_radius_fill(const float* points, const int64_t* points_row_splits,
 /* per search, the reference's .item() at kpconv.py:2028), allocates           */
 /* [n_queries, dense_cols <= cap] and calls ml3d_radius_dense_expand (a copy + */
 /* pad stream).  overflow != 0 (a row longer than cap): use ml3d_radius_count  */
-/* + ml3d_radius_fill for that search.                                         */
+/* + ml3d_radius_fill for that search.  reuse_grid != 0: `workspace` is the    */
+/* one an earlier gather over the SAME points / row splits / radius used and   */
+/* whose expand has been enqueued -- its grid is searched again with other     */
+/* queries (the conv and the pool search of a KPConv layer).                   */
 /* ------------------------------------------------------------------------- */
 size_t ml3d_radius_dense_workspace_bytes(int64_t n_points, int64_t n_queries, int64_t batch, int cap);
 
 int ml3d_radius_dense_gather(const float* points, const int64_t* points_row_splits,
                              const float* queries, const int64_t* queries_row_splits,
                              int64_t batch, int64_t n_points, int64_t n_queries, float radius,
-                             int cap, int64_t* out_stats, void* workspace,
+                             int cap, int reuse_grid, int64_t* out_stats, void* workspace,
                              size_t workspace_bytes, void* stream);
 
 int ml3d_radius_dense_expand(int64_t n_points, int64_t n_queries, int64_t batch, int cap,
@@ -409,6 +412,12 @@ int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* c
 
 int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, int num_classes,
                      float smooth, void* probs_f16, int64_t n_cloud, void* stream);
+
+/* ml3d_argmax_labels: out_labels[i] = argmax_c scores[i, c] as uint8 (num_classes <= 256; first  */
+/*   maximum, NaN = maximum, like torch.argmax) -- the predicted labels that leave the GPU          */
+/*   (SURVEY.md §8d "forward + softmax/argmax", §8e gather of predictions): 1 byte per point.       */
+int ml3d_argmax_labels(const float* scores, int64_t n, int num_classes, uint8_t* out_labels,
+                       void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* RandLA-Net neighbour pyramid: the whole loop of                             */

@@ -90,7 +90,8 @@ template <int K, bool SUB>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
                                         float* __restrict__ out_d2, int64_t t, int n_sub = 0,
-                                        int32_t* __restrict__ out_sub = nullptr, int* __restrict__ stage = nullptr) {
+                                        int32_t* __restrict__ out_sub = nullptr, int* __restrict__ stage = nullptr,
+                                        bool vec_store = false) {
     // stage: LDS, 64 * 17 + 128 ints per wave of the workgroup, for the transposed store of 16 indices per query (below)
     const bool transposed = K == 16 && k == 16 && !out_d2 && stage;
     const bool active = t < Q.n_total;
@@ -174,11 +175,30 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
         const u64 k1 = (u64)__double_as_longlong(best1);
         out_sub[out_row] = k1 != KEY_EMPTY ? (int32_t)(unsigned)(k1 & 0xffffffffull) : -1;
     }
-    if (transposed) {
+    if (K == 16 && k == 16 && !out_d2 && vec_store && !stage) {
         // The queries of a wave sit in cell-sorted order, their result rows anywhere: 16 stores of 4 bytes per lane at a
         // 64-byte stride are 64 partial-line writes per instruction (WRITE_SIZE 2x the index bytes, profiles/r02_pmc_write).
-        // Transposed through a wave-private LDS patch [64 rows][16 + 1] instead, every store instruction writes four WHOLE
-        // 64-byte rows (16 lanes x 4 bytes each).
+        // Four 16-byte stores per lane instead: a lane's 64-byte row (64-byte aligned: row * 16 ints) is complete after four
+        // consecutive instructions, a quarter of the write requests, no LDS.
+        if (!active) return;
+        struct alignas(16) I4 { int32_t v[4]; };
+        I4* dst = reinterpret_cast<I4*>(out_idx + out_row * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            I4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u64 key = (u64)__double_as_longlong(best[4 * q + e]);
+                o.v[e] = key != KEY_EMPTY ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
+            }
+            dst[q] = o;
+        }
+        return;
+    }
+    if (transposed) {
+        // ... or transposed through a wave-private LDS patch [64 rows][16 + 1]: every store instruction then writes four WHOLE
+        // 64-byte rows (16 lanes x 4 bytes each).  (Measured slower overall than the vector stores: the 19 KB of LDS per
+        // workgroup keep the forward's LDS-heavy kernels off the CUs the search occupies -- ML3D_KNN_STORE=1 for A/B runs.)
         const int lane = threadIdx.x & 63;
         int* patch = stage + (threadIdx.x >> 6) * (64 * 17 + 64 * 2);
         long long* rows = (long long*)(patch + 64 * 17);
@@ -234,19 +254,22 @@ struct KnnJobs {
     int n;
 };
 
-#ifndef ML3D_KNN_TRANSPOSED_STORE
-#define ML3D_KNN_TRANSPOSED_STORE 1      // A/B switch of the build (tools/build_variant.sh): 0 = per-lane stores of round 2
-#endif
+// how the 16 indices of a query are stored: 0 = sixteen 4-byte stores per lane (round 2), 1 = transposed through LDS (whole
+// 64-byte rows per instruction), 2 = four 16-byte stores per lane (default).  ML3D_KNN_STORE, read once; speed only.
+static int knn_store_mode() {
+    static const int v = [] { const char* e = getenv("ML3D_KNN_STORE"); return e ? atoi(e) : 2; }();
+    return v;
+}
 #ifndef KNN_WAVES
 #define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
 #endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
-template <int K, bool SUB>
+template <int K, bool SUB, bool STAGE = false>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0
 ML3D_WAVES_PER_SIMD(KNN_WAVES)
 #endif
-knn_query_multi(KnnJobs J, int k, int index_local) {
-    __shared__ int stage[K == 16 ? 4 * (64 * 17 + 64 * 2) : 1];
+knn_query_multi(KnnJobs J, int k, int index_local, int store_mode) {
+    __shared__ int stage[STAGE ? 4 * (64 * 17 + 64 * 2) : 1];      // (store mode 1 only)
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
@@ -254,7 +277,7 @@ knn_query_multi(KnnJobs J, int k, int index_local) {
     const KnnJob& jb = J.j[ji];
     knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
                     (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub,
-                    K == 16 && ML3D_KNN_TRANSPOSED_STORE ? stage : nullptr);
+                    STAGE ? stage : nullptr, store_mode == 2);
 }
 
 template <bool SUB>
@@ -265,11 +288,15 @@ static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t st
         blocks += (unsigned)((J.j[i].Q.n_total + 255) / 256);
     }
     if (blocks == 0) return 0;
-    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 16) hipLaunchKernelGGL((knn_query_multi<16, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
-    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local);
+    const int mode = knn_store_mode();
+    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+    else if (k <= 16) {
+        if (mode == 1) hipLaunchKernelGGL((knn_query_multi<16, SUB, true>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+        else hipLaunchKernelGGL((knn_query_multi<16, SUB, false>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+    }
+    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
     else return ML3D_E_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
@@ -515,7 +542,31 @@ vote_update(const float* __restrict__ logits, const int32_t* __restrict__ inds, 
     }
 }
 
+// labels = argmax over the classes (first maximum, NaN counts as the maximum -- torch.argmax), one thread per point
+__global__ void __launch_bounds__(256)
+argmax_rows(const float* __restrict__ scores, int64_t n, int C, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* row = scores + i * C;
+    float best = row[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = row[c];
+        if ((v > best || v != v) && !(best != best)) { best = v; arg = c; }
+    }
+    out[i] = (uint8_t)arg;
+}
+
 }  // namespace ml3d
+
+extern "C" int ml3d_argmax_labels(const float* scores, int64_t n, int num_classes, uint8_t* out_labels, void* stream) {
+    if (n < 0 || num_classes <= 0 || num_classes > 256) return ML3D_E_INVALID;
+    if (n == 0) return 0;
+    if (!scores || !out_labels) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(argmax_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, n, num_classes,
+                       out_labels);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
 
 extern "C" size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points) {
     if (n_points < 0) return 0;

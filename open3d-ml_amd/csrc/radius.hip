@@ -450,8 +450,8 @@ static bool rad_dense_carve(void* ws, size_t bytes, int64_t n_points, int64_t n_
 
 extern "C" int ml3d_radius_dense_gather(const float* points, const int64_t* points_row_splits, const float* queries,
                                         const int64_t* queries_row_splits, int64_t batch, int64_t n_points,
-                                        int64_t n_queries, float radius, int cap, int64_t* out_stats, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+                                        int64_t n_queries, float radius, int cap, int reuse_grid, int64_t* out_stats,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
     int rc = rad_args(points, points_row_splits, queries, queries_row_splits, batch, n_points, n_queries, radius);
     if (rc) return rc;
     if (!out_stats || cap <= 0 || cap > RAD_LDS_ROW) return ML3D_E_INVALID;
@@ -460,7 +460,9 @@ extern "C" int ml3d_radius_dense_gather(const float* points, const int64_t* poin
     hipStream_t st = (hipStream_t)stream;
     Segs ps = {points_row_splits, 0, 0, (int)batch};
     Segs qs = {queries_row_splits, 0, 0, (int)batch};
-    if (grid_build_fixed(points, ps, W.grid, radius, st)) return ML3D_E_LAUNCH;
+    // reuse_grid: the workspace already holds the grid of THESE points at THIS radius (built by an earlier gather whose expand
+    // has been enqueued): the conv and the pool search of a KPConv layer share supports and radius (concat_batcher.py:234-262)
+    if (!reuse_grid && grid_build_fixed(points, ps, W.grid, radius, st)) return ML3D_E_LAUNCH;
     (void)hipMemsetAsync(out_stats, 0, 16, st);
     if (n_queries == 0) return 0;
     RadArgs A;

@@ -57,6 +57,7 @@ SYMBOLS = [
     "ml3d_nearest_to_center_workspace_bytes",
     "ml3d_nearest_to_center",
     "ml3d_vote_update",
+    "ml3d_argmax_labels",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
     "ml3d_randla_param_layout",
@@ -105,7 +106,7 @@ def bind(lib):
     lib.ml3d_radius_dense_workspace_bytes.restype = sz
     lib.ml3d_radius_dense_workspace_bytes.argtypes = [i64, i64, i64, i32]
     lib.ml3d_radius_dense_gather.restype = C.c_int
-    lib.ml3d_radius_dense_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, i32, vp, vp, sz, vp]
+    lib.ml3d_radius_dense_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, i32, i32, vp, vp, sz, vp]
     lib.ml3d_radius_dense_expand.restype = C.c_int
     lib.ml3d_radius_dense_expand.argtypes = [i64, i64, i64, i32, i64, C.c_int32, vp, vp, sz, vp]
     lib.ml3d_ragged_to_dense.restype = C.c_int
@@ -169,6 +170,8 @@ def bind(lib):
     lib.ml3d_nearest_to_center.argtypes = [vp, i64, vp, i64, vp, vp, vp, sz, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
+    lib.ml3d_argmax_labels.restype = C.c_int
+    lib.ml3d_argmax_labels.argtypes = [vp, i64, i32, vp, vp]
     lib.ml3d_randla_pyramid_workspace_bytes.restype = sz
     lib.ml3d_randla_pyramid_workspace_bytes.argtypes = [i64, i64, i32, vp]
     lib.ml3d_randla_knn_pyramid.restype = C.c_int

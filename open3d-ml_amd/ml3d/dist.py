@@ -75,6 +75,9 @@ def gather_ragged(values, dst=0):
 
 def compact_labels(scores):
     """argmax over classes as the smallest integer type that holds it (uint8 for <= 256 classes): what travels."""
+    if scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous() and scores.shape[-1] <= 256:
+        from . import ops
+        return ops.argmax_labels(scores)
     lab = torch.argmax(scores, dim=-1)
     return lab.to(torch.uint8 if scores.shape[-1] <= 256 else torch.int32)
 
@@ -105,7 +108,11 @@ class PredictionGather:
         if self.pending[i] is not None:
             self.pending[i].wait()
             self.pending[i] = None
-        self.labels[i].copy_(torch.argmax(scores, dim=2))
+        if scores.is_cuda and self.labels[i].dtype == torch.uint8 and scores.dtype == torch.float32 and scores.is_contiguous():
+            from . import ops
+            ops.argmax_labels(scores, out=self.labels[i])       # one HIP kernel: 19 floats in, 1 byte out per point
+        else:
+            self.labels[i].copy_(torch.argmax(scores, dim=2))
         if self.world > 1:
             _, self.pending[i] = gather_predictions(self.labels[i], dst=self.dst, out=self.recv[i], async_op=True)
         return i

@@ -301,7 +301,10 @@ class _DenseRadiusPlan:
     this one search through the two-phase ``_RadiusPlan`` instead (count -> read -> fill)."""
     CAP = 128
 
-    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits):
+    def __init__(self, points, queries, radius, points_row_splits, queries_row_splits, grid_from=None):
+        """``grid_from``: an earlier plan over the SAME support tensor, row splits and radius whose result has been taken
+        (``fill_dense`` enqueued): its workspace -- grid included -- is searched again with these queries instead of building
+        the grid a second time (the conv and the pool search of a KPConv layer, concat_batcher.py:234-262)."""
         lib = _abi.get()
         _need_gpu(points, queries)
         self.points = points.contiguous().float()
@@ -316,11 +319,17 @@ class _DenseRadiusPlan:
         self.radius = float(radius)
         self.stats = torch.empty(2, dtype=torch.int64, device=dev)
         self.wsb = lib.ml3d_radius_dense_workspace_bytes(self.ns, self.nq, self.batch, self.CAP)
-        self.ws = _ws(self.wsb, dev)
+        reuse = isinstance(grid_from, _DenseRadiusPlan) and grid_from.filled and grid_from.points is self.points and \
+            grid_from.prs is self.prs and grid_from.radius == self.radius and grid_from.wsb >= self.wsb
+        if reuse:
+            self.ws, self.wsb = grid_from.ws, grid_from.wsb
+        else:
+            self.ws = _ws(self.wsb, dev)
+        self.filled = False
         with torch.cuda.device(dev):
             rc = lib.ml3d_radius_dense_gather(self.points.data_ptr(), self.prs.data_ptr(), self.queries.data_ptr(),
                                               self.qrs.data_ptr(), self.batch, self.ns, self.nq, self.radius, self.CAP,
-                                              self.stats.data_ptr(), self.ws.data_ptr(), self.wsb, _stream())
+                                              1 if reuse else 0, self.stats.data_ptr(), self.ws.data_ptr(), self.wsb, _stream())
         _abi.check(rc, "ml3d_radius_dense_gather")
         self.total = self.longest = None          # (``total`` stays unknown: the dense result never needs it)
         self.fallback = None
@@ -335,6 +344,7 @@ class _DenseRadiusPlan:
         return self
 
     def fill_dense(self, cols, pad_value):
+        self.filled = True
         if self.fallback is not None:
             return self.fallback.fill(dense_cols=cols, pad_value=pad_value)[0]
         lib = _abi.get()
@@ -358,12 +368,13 @@ def _one_pass_radius():
         return _ONE_PASS
 
 
-def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius):
-    """Deferred first half of ``radius_neighbors_dense``: the search is enqueued, its sizes not read yet."""
+def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius, grid_from=None):
+    """Deferred first half of ``radius_neighbors_dense``: the search is enqueued, its sizes not read yet.  ``grid_from``: an
+    already filled plan over the same supports and radius whose grid is reused."""
     dev = supports.device
     prs, qrs = _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0]
     if _one_pass_radius():
-        return _DenseRadiusPlan(supports, queries, radius, prs, qrs)
+        return _DenseRadiusPlan(supports, queries, radius, prs, qrs, grid_from=grid_from)
     return _RadiusPlan(supports, queries, radius, prs, qrs, defer=True)
 
 
@@ -373,6 +384,8 @@ def radius_fill_dense(plan, n_supports, max_cols=None):
     dev = plan.points.device
     cols = plan.longest if max_cols is None else min(plan.longest, int(max_cols))
     if plan.nq == 0 or cols == 0:
+        if isinstance(plan, _DenseRadiusPlan):
+            plan.filled = True
         return torch.empty((plan.nq, cols), dtype=torch.int32, device=dev)
     if isinstance(plan, _DenseRadiusPlan):
         return plan.fill_dense(cols, n_supports)
@@ -894,6 +907,24 @@ def nearest_to_center(points, center, k, return_distances=False):
                                         None if d2 is None else d2.data_ptr(), ws.data_ptr(), wsb, _stream())
     _abi.check(rc, "ml3d_nearest_to_center")
     return (idx, d2) if return_distances else idx
+
+
+def argmax_labels(scores, out=None):
+    """uint8 labels [...] = argmax over the last axis of float32 ``scores`` [..., C <= 256] (first maximum, like
+    torch.argmax) -- one pass over the scores instead of torch's generic reduction + dtype cast."""
+    lib = _abi.get()
+    _need_gpu(scores)
+    if scores.dtype != torch.float32 or not scores.is_contiguous() or scores.shape[-1] > 256:
+        raise RuntimeError("argmax_labels: contiguous float32 scores with at most 256 classes")
+    n = scores.numel() // scores.shape[-1]
+    if out is None:
+        out = torch.empty(scores.shape[:-1], dtype=torch.uint8, device=scores.device)
+    elif out.dtype != torch.uint8 or out.numel() != n or not out.is_contiguous():
+        raise RuntimeError("argmax_labels: out must be a contiguous uint8 tensor with one entry per point")
+    with torch.cuda.device(scores.device):
+        rc = lib.ml3d_argmax_labels(scores.data_ptr(), n, int(scores.shape[-1]), out.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_argmax_labels")
+    return out
 
 
 def vote_update(test_probs, point_inds, logits, smooth=0.95):

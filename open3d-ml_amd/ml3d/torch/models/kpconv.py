@@ -568,7 +568,8 @@ class KPConvBatch:
                     conv_i = ops.radius_fill_dense(conv_plan, pts.shape[0])
                 else:
                     conv_i = e_i
-                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_normal)
+                # (same supports, same radius as the conv search: its grid is searched again)
+                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_normal, grid_from=conv_plan)
                 up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_normal)
                 ops.resolve_plans(pool_plan, up_plan)
                 pool_i = ops.radius_fill_dense(pool_plan, pts.shape[0])

@@ -394,3 +394,13 @@ def vote_update(probs16, inds, logits, smooth):
                             probs16.shape[0], None)
     assert rc == 0, rc
     return probs16
+
+
+def argmax_labels(scores):
+    L = lib()
+    scores = np.ascontiguousarray(scores, np.float32)
+    n = scores.size // scores.shape[-1]
+    out = np.full(n, 255, np.uint8)
+    rc = L.ml3d_argmax_labels(scores.ctypes.data, n, scores.shape[-1], out.ctypes.data, None)
+    assert rc == 0, rc
+    return out.reshape(scores.shape[:-1])

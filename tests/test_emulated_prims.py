@@ -251,3 +251,15 @@ def test_nms_no_boxes_one_box_and_identical_boxes():
     b3 = np.repeat(b, 3, 0)
     keep = emu.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5)
     assert keep.tolist() == oops.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5).tolist() == [1]
+
+
+def test_argmax_labels_is_torch_argmax_first_maximum_and_nan():
+    import torch
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((7, 301, 19)).astype(np.float32)
+    s[0, :50] = np.round(s[0, :50])                     # ties: the first maximum wins
+    s[1, 3, 5] = np.nan
+    s[1, 4, 0] = np.nan
+    s[2, 9, :] = -np.inf
+    assert np.array_equal(emu.argmax_labels(s), torch.argmax(torch.from_numpy(s), -1).numpy().astype(np.uint8))
+    assert np.array_equal(emu.argmax_labels(s[:, :, :1]), np.zeros((7, 301), np.uint8))

@@ -205,3 +205,14 @@ def test_sampler_patch_query_and_projection_and_votes():
     ref_p[ii] = 0.95 * ref_p[ii] + (1 - 0.95) * torch.softmax(torch.from_numpy(logits), -1).numpy()
     d = np.abs(out.astype(np.float32) - ref_p.astype(np.float32))
     assert d.max() <= 2 ** -10 and (d == 0).mean() > 0.99
+
+
+def test_argmax_labels_matches_torch_argmax():
+    from ml3d import ops
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((4, 45056, 19)).astype(np.float32)
+    s[0, :500] = np.round(s[0, :500])
+    s[1, 3, 5] = np.nan
+    t = _t(s)
+    got = ops.argmax_labels(t)
+    assert got.dtype == torch.uint8 and torch.equal(got.long(), torch.argmax(t, -1))
