@@ -25,6 +25,12 @@ import re
 import sys
 import time
 
+# The step runs on five HIP streams (caller, upload, neighbour search, forward, label post-processing).  ROCm multiplexes
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in first-use order, and two streams that share a queue run
+# back to back: with five streams on four queues whether the search overlaps the forward (+9 % frames/s) was decided by
+# which stream happened to be touched first (measured: profiles/r03_search_gate_ab.log).  Eight queues: one per stream.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
     if p not in sys.path:

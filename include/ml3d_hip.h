@@ -504,10 +504,15 @@ int ml3d_randla_forward(const ml3d_randla_desc* desc_host, const float* params,
 /* harness can time a single kernel inside a full forward without a profiler.            */
 /* tag = 8*layer + {0 mlp1, 1 lfa_stage1, 2 lfa_stage2, 3 gather_max};                   */
 /*       1000 fc0, 1001 mlp, 1100+i decoder stage i, 1200/1201/1202 fc1 layers.          */
+/* `next` chains further records (NULL ends the list): every record whose tag matches is */
+/* served.  Besides timing, a recorded event is how another stream synchronises with a   */
+/* POINT INSIDE the forward (ml3d.engine.PipelinedRandLAEngine starts the next batch's   */
+/* neighbour search once the bandwidth-bound first layer of the running forward is done).*/
 typedef struct ml3d_trace {
     int32_t tag;
     void* ev_start;
     void* ev_stop;
+    const struct ml3d_trace* next;
 } ml3d_trace;
 
 int ml3d_randla_forward_traced(const ml3d_randla_desc* desc_host, const float* params,

@@ -414,8 +414,8 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
                                                int32_t* const* neighbor_idx_host, int32_t* const* interp_idx_host,
                                                int32_t* const* tile_order_host, void* workspace,
                                                size_t workspace_bytes, void* stream, const ml3d_trace* tr) {
-    auto tb = [&](int tag) { if (tr && tr->tag == tag && tr->ev_start) (void)hipEventRecord((hipEvent_t)tr->ev_start, (hipStream_t)stream); };
-    auto te = [&](int tag) { if (tr && tr->tag == tag && tr->ev_stop) (void)hipEventRecord((hipEvent_t)tr->ev_stop, (hipStream_t)stream); };
+    auto tb = [&](int tag) { for (const ml3d_trace* r = tr; r; r = r->next) if (r->tag == tag && r->ev_start) (void)hipEventRecord((hipEvent_t)r->ev_start, (hipStream_t)stream); };
+    auto te = [&](int tag) { for (const ml3d_trace* r = tr; r; r = r->next) if (r->tag == tag && r->ev_stop) (void)hipEventRecord((hipEvent_t)r->ev_stop, (hipStream_t)stream); };
     if (!points || batch <= 0 || n0 <= 0 || num_layers <= 0 || num_layers > KNN_MAX_JOBS || !ratios_host || k <= 0 ||
         !neighbor_idx_host || !interp_idx_host)
         return ML3D_E_INVALID;

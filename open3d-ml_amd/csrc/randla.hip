@@ -1651,8 +1651,14 @@ gather_max4(const float* __restrict__ feat, const int32_t* __restrict__ nidx, fl
 struct Tracer {
     const ml3d_trace* t;
     hipStream_t st;
-    void begin(int tag) const { if (t && t->tag == tag && t->ev_start) (void)hipEventRecord((hipEvent_t)t->ev_start, st); }
-    void end(int tag) const { if (t && t->tag == tag && t->ev_stop) (void)hipEventRecord((hipEvent_t)t->ev_stop, st); }
+    void begin(int tag) const {
+        for (const ml3d_trace* r = t; r; r = r->next)
+            if (r->tag == tag && r->ev_start) (void)hipEventRecord((hipEvent_t)r->ev_start, st);
+    }
+    void end(int tag) const {
+        for (const ml3d_trace* r = t; r; r = r->next)
+            if (r->tag == tag && r->ev_stop) (void)hipEventRecord((hipEvent_t)r->ev_stop, st);
+    }
 };
 
 static int launch_linear(const LinArgs& a, hipStream_t st) {

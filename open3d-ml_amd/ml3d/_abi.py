@@ -85,7 +85,10 @@ class RandlaDesc(C.Structure):
 
 
 class Trace(C.Structure):
-    _fields_ = [("tag", C.c_int32), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+    pass
+
+
+Trace._fields_ = [("tag", C.c_int32), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("next", C.POINTER(Trace))]
 
 
 def bind(lib):

@@ -109,6 +109,18 @@ class PipelinedRandLAEngine:
             self.compute = torch.cuda.Stream(priority=pc)
             self.knn_done = [torch.cuda.Event(), torch.cuda.Event()]
             self.fwd_done = [torch.cuda.Event(), torch.cuda.Event()]
+            # WHEN the next batch's search may start, relative to the running forward.  The search launch is VALU-bound
+            # (profiles/r03_pmc_knn_sq.csv: 0.7-0.8 of the VALU issue cycles): whatever shares its SIMDs gets the leftover
+            # issue slots.  Left to itself it lands on the forward's first layer, whose per-point chain is a short,
+            # bandwidth-bound persistent kernel that then runs 6x longer (0.16 -> 1.0 ms, r03 kernel tables).  The gate is an
+            # event the LIBRARY records inside the forward at the start of the kernel with this trace tag (8 * layer + stage,
+            # ml3d_hip.h); the search stream waits for the previous forward's gate.  ML3D_SEARCH_GATE: tag, -1 = no gate.
+            self.gate_tag = int(os.environ.get("ML3D_SEARCH_GATE", "9"))
+            self.gate = [torch.cuda.Event(), torch.cuda.Event()]
+            for g in self.gate:
+                g.record()                        # materialise the hipEvent_t -- on the CALLER's stream: the first use of a
+                                                  # stream decides its hardware queue (see bench.py, GPU_MAX_HW_QUEUES)
+        self.gate_rec = [None, None]
         self.i = 0
         self.n = self.eng[0].n
 
@@ -133,11 +145,21 @@ class PipelinedRandLAEngine:
             features.record_stream(self.compute)
             with torch.cuda.stream(self.search):
                 self.search.wait_event(self.fwd_done[slot])      # the forward that last read these index buffers
+                if self.gate_tag >= 0 and self.i > 1:
+                    self.search.wait_event(self.gate[slot ^ 1])  # ... and the gate inside the forward enqueued just before
                 e.neighbors(points, knn_trace)
                 self.knn_done[slot].record(self.search)
             with torch.cuda.stream(self.compute):
                 self.compute.wait_event(self.knn_done[slot])
-                out = e.forward(points, features, fwd_trace)
+                tr = fwd_trace
+                if self.gate_tag >= 0:
+                    g = _abi.Trace()
+                    g.tag, g.ev_start, g.ev_stop = self.gate_tag, C.c_void_p(self.gate[slot].cuda_event), None
+                    if fwd_trace is not None:
+                        g.next = C.pointer(fwd_trace)
+                    self.gate_rec[slot] = (g, fwd_trace)         # (keep the host records alive through the call)
+                    tr = g
+                out = e.forward(points, features, tr)
                 self.fwd_done[slot].record(self.compute)
         return out
 
