@@ -204,7 +204,8 @@ def run_kpconv(args, rank, world, dev, dist):
     np.random.seed(0)
     overlap = not getattr(args, "no_overlap", False)
     from ml3d.engine import KPConvPipeline
-    pipe = KPConvPipeline(m, cfg, dev)
+    import os
+    pipe = KPConvPipeline(m, cfg, dev, threaded=os.environ.get("ML3D_KP_THREADED", "0") == "1")      # (A/B knob)
 
     def finish(res):
         if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)

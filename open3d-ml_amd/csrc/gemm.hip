@@ -171,7 +171,7 @@ struct ConvLoader {
 // the staging loads are running pointers (no per-chunk predicates, no loader branches).  The generic fetch below is ~170 VALU / 365
 // SALU instructions of control flow per chunk of 16 MFMAs in the listing; the Linears of RandLA-Net and KPConv (K = 32 .. 1024,
 // almost all plain) spent more time in it than in the matrix unit.
-template <class Loader, bool PLAIN = false>
+template <class Loader, bool PLAIN = false, int DEPTH = 2>
 __global__ void __launch_bounds__(256)
 gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, float* __restrict__ C, int64_t ldc,
           int k_per_split, float* __restrict__ partial) {
@@ -191,7 +191,12 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     const int br = tid >> 4, bq = (tid & 15) * 4;
     const typename Loader::Ctx c0 = L.prepare(m0 + ar), c1 = L.prepare(m0 + 32 + ar);
 
-    float4 ra0, ra1, rb0, rb1;
+    // TWO register sets: the global loads of chunks k + 1 and k + 2 are in flight while chunk k is multiplied.  A workgroup walks
+    // its chunks serially and one chunk's loads take 1-2.5 us against 0.43 us of MFMAs: with one chunk in flight (rounds 1-2) every
+    // iteration waited for memory, and the small-M / deep-K GEMMs of KPConv's coarse layers (one round of workgroups: the
+    // kernel takes as long as ONE workgroup) ran at ~2.6 us per chunk (profiles/r03_kp_kernel_stats.csv: 34 launches of 70-120 us).
+    float4 ra0, ra1, rb0, rb1;       // set 0
+    float4 sa0, sa1, sb0, sb1;       // set 1
     // PLAIN: rows past M re-read row M - 1 and columns past N re-read column 0 (their products are never stored)
     const float* pa0 = nullptr; const float* pa1 = nullptr; const float* pb0 = nullptr; const float* pb1 = nullptr;
     const float* qa0 = nullptr; const float* qa1 = nullptr;      // the second column block ([a | a2] concatenated, chunk-aligned)
@@ -220,60 +225,90 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
         v.w = col + 3 < N ? p[3] : 0.f;
         return v;
     };
-    auto fetch = [&](int k0) {
-        if constexpr (PLAIN) {
-            if (k0 < L.A.k1) {                                   // (uniform: block boundaries are chunk-aligned)
-                ra0 = *reinterpret_cast<const float4*>(pa0);
-                ra1 = *reinterpret_cast<const float4*>(pa1);
-                pa0 += GM_KC; pa1 += GM_KC;
-            } else {
-                ra0 = *reinterpret_cast<const float4*>(qa0);
-                ra1 = *reinterpret_cast<const float4*>(qa1);
-                qa0 += GM_KC; qa1 += GM_KC;
-            }
-            rb0 = *reinterpret_cast<const float4*>(pb0);
-            rb1 = *reinterpret_cast<const float4*>(pb1);
-            pb0 += (int64_t)GM_KC * N; pb1 += (int64_t)GM_KC * N;
-            return;
-        }
-        const int ka = k0 + aq;
-        ra0 = ka < ke ? L.load4(c0, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ra1 = ka < ke ? L.load4(c1, k0, aq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rb0 = load_b(k0 + br);
-        rb1 = load_b(k0 + 16 + br);
-    };
-    auto stash = [&]() {
-        *reinterpret_cast<float4*>(As + ar * GM_AP + aq) = ra0;
-        *reinterpret_cast<float4*>(As + (32 + ar) * GM_AP + aq) = ra1;
-        *reinterpret_cast<float4*>(Bs + br * GM_BP + bq) = rb0;
-        *reinterpret_cast<float4*>(Bs + (16 + br) * GM_BP + bq) = rb1;
-    };
-
+    // (plain lambdas over named registers: passing a register struct by reference left it in scratch memory)
+#define ML3D_GM_FETCH(A0, A1, B0, B1, K0)                                                            \
+    do {                                                                                             \
+        const int k0_ = (K0);                                                                        \
+        if constexpr (PLAIN) {                                                                       \
+            if (k0_ < L.A.k1) { /* (uniform: block boundaries are chunk-aligned) */                  \
+                A0 = *reinterpret_cast<const float4*>(pa0);                                          \
+                A1 = *reinterpret_cast<const float4*>(pa1);                                          \
+                pa0 += GM_KC; pa1 += GM_KC;                                                          \
+            } else {                                                                                 \
+                A0 = *reinterpret_cast<const float4*>(qa0);                                          \
+                A1 = *reinterpret_cast<const float4*>(qa1);                                          \
+                qa0 += GM_KC; qa1 += GM_KC;                                                          \
+            }                                                                                        \
+            B0 = *reinterpret_cast<const float4*>(pb0);                                              \
+            B1 = *reinterpret_cast<const float4*>(pb1);                                              \
+            pb0 += (int64_t)GM_KC * N; pb1 += (int64_t)GM_KC * N;                                    \
+        } else {                                                                                     \
+            const int ka_ = k0_ + aq;                                                                \
+            A0 = ka_ < ke ? L.load4(c0, k0_, aq) : make_float4(0.f, 0.f, 0.f, 0.f);                   \
+            A1 = ka_ < ke ? L.load4(c1, k0_, aq) : make_float4(0.f, 0.f, 0.f, 0.f);                   \
+            B0 = load_b(k0_ + br);                                                                   \
+            B1 = load_b(k0_ + 16 + br);                                                              \
+        }                                                                                            \
+    } while (0)
+#define ML3D_GM_STASH(A0, A1, B0, B1)                                                                \
+    do {                                                                                             \
+        *reinterpret_cast<float4*>(As + ar * GM_AP + aq) = A0;                                       \
+        *reinterpret_cast<float4*>(As + (32 + ar) * GM_AP + aq) = A1;                                \
+        *reinterpret_cast<float4*>(Bs + br * GM_BP + bq) = B0;                                       \
+        *reinterpret_cast<float4*>(Bs + (16 + br) * GM_BP + bq) = B1;                                \
+    } while (0)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    if (kb < ke) {
-        fetch(kb);
-        stash();
-        block_sync_lds();
-        for (int k0 = kb; k0 < ke; k0 += GM_KC) {
-            const bool more = k0 + GM_KC < ke;
-            if (more) fetch(k0 + GM_KC);       // global loads in flight under the MFMAs
-            const float* arow = As + (rt * 32 + cl) * GM_AP + hi * (GM_KC / 2);
-            const float* brow = Bs + (hi * (GM_KC / 2)) * GM_BP + ctw * 32 + cl;
+    auto multiply = [&]() {
+        const float* arow = As + (rt * 32 + cl) * GM_AP + hi * (GM_KC / 2);
+        const float* brow = Bs + (hi * (GM_KC / 2)) * GM_BP + ctw * 32 + cl;
 #pragma unroll
-            for (int s4 = 0; s4 < GM_KC / 8; ++s4) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 4 * s4);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, brow[(4 * s4 + 0) * GM_BP], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, brow[(4 * s4 + 1) * GM_BP], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, brow[(4 * s4 + 2) * GM_BP], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, brow[(4 * s4 + 3) * GM_BP], acc, 0, 0, 0);
-            }
-            // (LDS-only barriers: the next chunk's global loads stay in flight across them)
+        for (int s4 = 0; s4 < GM_KC / 8; ++s4) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 4 * s4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, brow[(4 * s4 + 0) * GM_BP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, brow[(4 * s4 + 1) * GM_BP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, brow[(4 * s4 + 2) * GM_BP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, brow[(4 * s4 + 3) * GM_BP], acc, 0, 0, 0);
+        }
+    };
+
+
+    if constexpr (DEPTH == 1) {              // one chunk in flight (rounds 1-2): 36 registers, eight waves per SIMD
+        if (kb < ke) {
+            ML3D_GM_FETCH(ra0, ra1, rb0, rb1, kb);
+            ML3D_GM_STASH(ra0, ra1, rb0, rb1);
             block_sync_lds();
-            if (more) {
-                stash();
+            for (int k0 = kb; k0 < ke; k0 += GM_KC) {
+                const bool more = k0 + GM_KC < ke;
+                if (more) ML3D_GM_FETCH(ra0, ra1, rb0, rb1, k0 + GM_KC);
+                multiply();
+                block_sync_lds();
+                if (more) {
+                    ML3D_GM_STASH(ra0, ra1, rb0, rb1);
+                    block_sync_lds();
+                }
+            }
+        }
+    } else if (kb < ke) {
+        ML3D_GM_FETCH(ra0, ra1, rb0, rb1, kb);
+        if (kb + GM_KC < ke) ML3D_GM_FETCH(sa0, sa1, sb0, sb1, kb + GM_KC);
+        ML3D_GM_STASH(ra0, ra1, rb0, rb1);
+        block_sync_lds();
+        // LDS holds chunk k0; the loop body is unrolled by two so that the register sets alternate statically
+        for (int k0 = kb; k0 < ke; k0 += 2 * GM_KC) {
+            if (k0 + 2 * GM_KC < ke) ML3D_GM_FETCH(ra0, ra1, rb0, rb1, k0 + 2 * GM_KC);      // set 1 (chunk k0 + 1) is in flight or landed
+            multiply();
+            // (LDS-only barriers: the outstanding global loads stay in flight across them)
+            block_sync_lds();
+            if (!(k0 + GM_KC < ke)) break;
+            ML3D_GM_STASH(sa0, sa1, sb0, sb1);
+            block_sync_lds();
+            if (k0 + 3 * GM_KC < ke) ML3D_GM_FETCH(sa0, sa1, sb0, sb1, k0 + 3 * GM_KC);
+            multiply();
+            block_sync_lds();
+            if (k0 + 2 * GM_KC < ke) {
+                ML3D_GM_STASH(ra0, ra1, rb0, rb1);
                 block_sync_lds();
             }
         }
@@ -702,6 +737,18 @@ static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const E
     return true;
 }
 
+// Chunks in flight per workgroup of gemm_tile.  Two chunks cost 32 more registers (66 -> 98: four waves per SIMD instead of
+// seven): they pay where the kernel lasts as long as ONE workgroup's serial walk over K -- the small-M / deep-K problems that
+// fit the chip in a round or two (KPConv's coarse layers: +2.5 % spheres/s) -- and lose where many rounds of workgroups hide
+// each other's latency anyway (RandLA's and PointPillars' 10^5 .. 10^6-row Linears: -1 %), measured in one call on one box
+// (gpurun_out/r3k).  Rule: two chunks up to ML3D_GEMM_DEPTH2_MAX_WGS workgroups (default 4096); ML3D_GEMM_DEPTH=1|2 pins it.
+static int gemm_depth(const dim3& grid) {
+    static const int pin = [] { const char* e = getenv("ML3D_GEMM_DEPTH"); return e ? atoi(e) : 0; }();
+    static const long long max_wgs = [] { const char* e = getenv("ML3D_GEMM_DEPTH2_MAX_WGS"); return e ? atoll(e) : 4096ll; }();
+    if (pin == 1 || pin == 2) return pin;
+    return (long long)grid.x * grid.y * grid.z <= max_wgs ? 2 : 1;
+}
+
 // the streamlined K loop of gemm_tile takes: one dense float4-addressable row block, whole chunks, float4-addressable B
 static bool plain_rows(const RowsLoader& L, int kper, int bvec) {
     // ML3D_GEMM_PLAIN=0 (read once): the generic loader for every problem (A/B runs)
@@ -713,7 +760,8 @@ static bool plain_rows(const RowsLoader& L, int kper, int bvec) {
 static bool plain_rows(const ConvLoader&, int, int) { return false; }
 static void launch_plain(const RowsLoader& L, dim3 grid, const float* Bm, int N, int bvec, const Epilogue& ep, float* C,
                          int64_t ldc, int kper, float* partial, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_tile<RowsLoader, true>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    if (gemm_depth(grid) == 1) hipLaunchKernelGGL((gemm_tile<RowsLoader, true, 1>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    else hipLaunchKernelGGL((gemm_tile<RowsLoader, true, 2>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
 }
 static void launch_plain(const ConvLoader&, dim3, const float*, int, int, const Epilogue&, float*, int64_t, int, float*,
                          hipStream_t) {}
@@ -735,7 +783,8 @@ static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& 
     dim3 grid((unsigned)((M + GM_BM - 1) / GM_BM), (unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)splits);
     float* partial = splits > 1 ? (float*)partial_ws : nullptr;
     if (plain_rows(L, kper, bvec)) launch_plain(L, grid, Bm, N, bvec, ep, C, ldc, kper, partial, st);
-    else hipLaunchKernelGGL((gemm_tile<Loader>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    else if (gemm_depth(grid) == 1) hipLaunchKernelGGL((gemm_tile<Loader, false, 1>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
+    else hipLaunchKernelGGL((gemm_tile<Loader, false, 2>), grid, dim3(256), 0, st, L, Bm, N, bvec, ep, C, ldc, kper, partial);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (splits > 1) {
         int64_t total = M * N;
