@@ -741,10 +741,11 @@ static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const E
 // seven): they pay where the kernel lasts as long as ONE workgroup's serial walk over K -- the small-M / deep-K problems that
 // fit the chip in a round or two (KPConv's coarse layers: +2.5 % spheres/s) -- and lose where many rounds of workgroups hide
 // each other's latency anyway (RandLA's and PointPillars' 10^5 .. 10^6-row Linears: -1 %), measured in one call on one box
-// (gpurun_out/r3k).  Rule: two chunks up to ML3D_GEMM_DEPTH2_MAX_WGS workgroups (default 4096); ML3D_GEMM_DEPTH=1|2 pins it.
+// (gpurun_out/r3k).  Rule: two chunks up to ML3D_GEMM_DEPTH2_MAX_WGS workgroups (default 12288:
+// KPConv's 2 200-row-tile layer included, RandLA's / PointPillars' 13 000+-tile Linears not); ML3D_GEMM_DEPTH=1|2 pins it.
 static int gemm_depth(const dim3& grid) {
     static const int pin = [] { const char* e = getenv("ML3D_GEMM_DEPTH"); return e ? atoi(e) : 0; }();
-    static const long long max_wgs = [] { const char* e = getenv("ML3D_GEMM_DEPTH2_MAX_WGS"); return e ? atoll(e) : 4096ll; }();
+    static const long long max_wgs = [] { const char* e = getenv("ML3D_GEMM_DEPTH2_MAX_WGS"); return e ? atoll(e) : 12288ll; }();
     if (pin == 1 || pin == 2) return pin;
     return (long long)grid.x * grid.y * grid.z <= max_wgs ? 2 : 1;
 }

@@ -47,13 +47,27 @@ struct QuerySrc {
 // and four selects.  d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on
 // gfx950).  Measured (tools/micro/valu_rates.hip, profiles/r02_micro_valu_rates.log): v_min_f64 / v_max_f64 issue at the
 // rate of v_min_u32; the integer form (v_cmp_lt_u64 + 4 v_cndmask) is 7.6x slower.
+// The `if` costs 16 v_mov_b64 of phi copies at its join on top of the 31 min / max of an insertion (ISA listing).  Round 3 tried
+// the BRANCHLESS form (KNN_BRANCHLESS=1: an EMPTY key leaves the list as it is, slots past a run carry EMPTY): 146 instead of
+// ~190 VALU instructions per group of three candidates -- and the launch got SLOWER, 1.97 ms against 1.62 ms alone, 5657
+// against 5808 frames/s (gpurun_out/r3m, same box, two runs each): waves DO skip the chain often enough (once the list is
+// tight most candidates of all 64 lanes fail the test), and an unconditional chain pays 32 f64 operations for every one of them.
+#ifndef KNN_BRANCHLESS
+#define KNN_BRANCHLESS 0        // build-time A/B switch (tools/build_variant.sh)
+#endif
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
+#if KNN_BRANCHLESS
+    best[K - 1] = key_min(best[K - 1], key);
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
+#else
     if (key < best[K - 1]) {
         best[K - 1] = key;
 #pragma unroll
         for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
     }
+#endif
 }
 
 #ifndef KNN_GROUP
@@ -73,15 +87,19 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
         float4 c[KNN_GROUP];
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
+        // straight-line: a slot past the run (its load was clamped) carries the EMPTY key, which the insertion ignores -- no
+        // branch, hence no phi copies of the 16-entry list at a join (they were a third of the instructions of an insertion)
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) {
-            if (p + j < p1) {
-                float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
-                u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
-                const double kd = __longlong_as_double((long long)key);
-                if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
-                topk_insert<K>(best, kd);
-            }
+#if !KNN_BRANCHLESS
+            if (!(p + j < p1)) continue;
+#endif
+            const float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
+            const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
+            const double empty = __longlong_as_double((long long)KEY_EMPTY);
+            const double kd = (p + j < p1) ? __longlong_as_double((long long)key) : empty;
+            if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : empty);
+            topk_insert<K>(best, kd);
         }
     }
 }

@@ -1277,7 +1277,9 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
             const uint32_t mi = m_base + 4 * wave + pp;                       // position of the point in the walk
             // ORD: the point's row is held by the lanes that built its X rows (lanes 16 pp .. 16 pp + 15 of this wave)
             const uint32_t m = ORD ? (uint32_t)__builtin_amdgcn_readlane((int)mrow_cur, 16 * pp) : mi;
-            if (g == 0 && mi < m_tot) A.out[(int64_t)m * D + col] = ag / sum;
+            // (v_rcp_f32 + multiply: 2 instructions against ~10 for the IEEE division, 1 ulp -- this kernel is VALU-issue bound,
+            //  profiles/r03_pmc_forward.md; the 1e-4 parity gate has five orders of magnitude of room)
+            if (g == 0 && mi < m_tot) A.out[(int64_t)m * D + col] = ag * __builtin_amdgcn_rcpf(sum);
         }
         wave_lds_sync();
         cur = nxt;
