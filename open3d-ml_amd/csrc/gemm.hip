@@ -769,14 +769,14 @@ static void launch_plain(const ConvLoader&, dim3, const float*, int, int, const 
 
 template <class Loader>
 static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
-                       void* partial_ws, size_t partial_bytes, hipStream_t st) {
+                       void* partial_ws, size_t partial_bytes, hipStream_t st, bool allow_big = true) {
     const int64_t M = L.M;
     const int K = L.K;
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || !Bm || !C) return ML3D_E_INVALID;
     int splits = pick_splits(M, N, K);
     if (splits > 1 && (!partial_ws || partial_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N)) splits = 1;
-    if (splits == 1 && gemm_launch_big(L, Bm, N, ep, C, ldc, st)) return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    if (splits == 1 && allow_big && gemm_launch_big(L, Bm, N, ep, C, ldc, st)) return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     // split boundaries are multiples of the K chunk (so also of 4: float4 loads never straddle one)
     int kper = ((K + splits - 1) / splits + GM_KC - 1) / GM_KC * GM_KC;
     splits = (K + kper - 1) / kper;
@@ -807,15 +807,69 @@ int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Ep
     return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
 }
 
+// Tail of the register-blocked convolution.  A launch of T tiles on S resident workgroups takes ceil(T / S) rounds, and the
+// SECOND maps give few of them: 16 sweeps of 248 x 216 x 64 are 6696 tiles on 1536 slots = 4.36 rounds (the fifth round is a
+// third full), 124 x 108 x 128: 1674 tiles on 512 slots = 3.27, 62 x 54 x 256: 837 on 512 = 1.63.  The images of a batch are
+// independent, so the batch is cut where the full rounds end: the first B1 images on the 128-row tiles, the remaining few on the
+// 64 x 64 tiles of gemm_tile (2048 slots, a fraction of ONE short round).  MEASURED (round 3, gpurun_out/r3n, one box, two runs
+// each): SLOWER -- SECOND 3x3 64 -> 64 at 16 sweeps 0.672 / 0.639 ms cut 14 + 2 against 0.628 / 0.623 ms uncut, PointPillars
+// 1223 / 1228 against 1251 / 1249 frames/s: the two images on the small tiles cost more than the third-full last round they
+// replace (the launch boundary and the 64 x 64 kernel's lower efficiency eat it).  OFF by default; ML3D_GEMM_TAIL_SPLIT=1
+// (read once) switches it on for further experiments.
+static int conv_tail_split(const ConvA& A, int N, int K, const float* Bm, const Epilogue& ep) {
+    static const bool on = [] { const char* e = getenv("ML3D_GEMM_TAIL_SPLIT"); return e && e[0] == '1'; }();
+    if (!on || A.B < 2 || ep.ps > 0) return 0;
+    const int64_t rows = (int64_t)A.OH * A.OW, M = rows * A.B;
+    const int bn = big_bn(M, N, K, Bm, ep);
+    if (!bn || (A.C % GM_KC) != 0) return 0;
+    const int kc = big_kc(K, A.C, bn);
+    const size_t lds = sizeof(float) * ((size_t)G2_BM * (kc + 4) + (size_t)kc * (bn + 4));
+    int wg_cu = (int)(163840 / lds);
+    wg_cu = wg_cu > 8 ? 8 : (wg_cu < 1 ? 1 : wg_cu);
+    if (bn == 128 && wg_cu > 5) wg_cu = 5;                       // (96 registers: five waves per SIMD)
+    // (ML3D_GEMM_TAIL_SLOTS, read once: the resident-workgroup count assumed -- the emulator tests set a tiny one so that
+    //  small maps exercise the cut)
+    static const int64_t slots_env = [] { const char* e = getenv("ML3D_GEMM_TAIL_SLOTS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t slots = slots_env > 0 ? slots_env : 256ll * wg_cu, ct = (N + bn - 1) / bn;
+    auto tiles = [&](int64_t b) { return (b * rows + G2_BM - 1) / G2_BM * ct; };
+    const int64_t total = tiles(A.B), full = total / slots;
+    const double frac = (double)total / (double)slots - (double)full;
+    if (full < 1 || full > 10 || frac < 0.04 || frac > 0.62) return 0;
+    int b1 = (int)(full * slots * G2_BM / (ct * rows));
+    while (b1 > 0 && tiles(b1) > full * slots) --b1;
+    if (b1 < 1 || b1 >= A.B) return 0;
+    if (big_bn(rows * b1, N, K, Bm, ep) == 0) return 0;           // the head must still qualify for the 128-row tiles
+    static const bool dbg = getenv("ML3D_GEMM_TAIL_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[ml3d] conv tail split: %d + %d images (%lld tiles, %lld slots)\n", b1, A.B - b1, (long long)total, (long long)slots);
+    return b1;
+}
+
 int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws,
               size_t partial_bytes, hipStream_t stream) {
     if (!A.in || (A.C & 3) || A.KH <= 0 || A.KW <= 0 || A.stride <= 0) return ML3D_E_INVALID;
-    ConvLoader L;
-    L.A = A;
-    L.M = (int64_t)A.B * A.OH * A.OW;
-    L.K = A.KH * A.KW * A.C;
-    L.chunk_uniform = (A.C % GM_KC) == 0 ? 1 : 0;
-    return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
+    const int K = A.KH * A.KW * A.C;
+    const int b1 = conv_tail_split(A, N, K, Bm, ep);
+    for (int part = 0; part < (b1 > 0 ? 2 : 1); ++part) {
+        ConvA P = A;
+        Epilogue e = ep;
+        float* Cp = C;
+        if (b1 > 0) {
+            const int64_t rows = (int64_t)A.OH * A.OW;
+            const int b0 = part == 0 ? 0 : b1;
+            P.B = part == 0 ? b1 : A.B - b1;
+            P.in = A.in + (int64_t)b0 * A.H * A.W * A.C;
+            Cp = C + (int64_t)b0 * rows * ldc;
+            if (e.residual) e.residual = ep.residual + (int64_t)b0 * rows * ep.ldr;
+        }
+        ConvLoader L;
+        L.A = P;
+        L.M = (int64_t)P.B * P.OH * P.OW;
+        L.K = K;
+        L.chunk_uniform = (A.C % GM_KC) == 0 ? 1 : 0;
+        const int rc = gemm_launch(L, Bm, N, e, Cp, ldc, partial_ws, partial_bytes, stream, !(b1 > 0 && part == 1));
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // namespace ml3d

@@ -1,15 +1,10 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3m; mkdir -p $O
+O=gpurun_out/r3n; mkdir -p $O
 export TMPDIR=/tmp
-LIB=open3d-ml_amd/ml3d/lib
-cp $LIB/libml3d_hip.so /tmp/base.so
-timeout 200 python -m pytest tests/test_gpu_knn.py tests/test_gpu_randlanet.py tests/test_gpu_kpconv.py -m gpu -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log
-for v in base knn_branchy base knn_branchy; do
-  if [ "$v" = base ]; then cp /tmp/base.so $LIB/libml3d_hip.so; else cp $LIB/ab/$v.so $LIB/libml3d_hip.so; fi
-  timeout 120 python bench.py --no-workloads --no-cpu-baseline --no-latency > $O/rl_$v.json 2> $O/rl_$v.err
-  echo "randla $v: $(python -c "import json; d=json.load(open('$O/rl_$v.json')); print(round(d['value'],1), round(d['step_ms_median'],3), [ (r['kernel'][:18], round(r['avg_launch_ms'],3)) for r in [d['roofline']]+d['roofline_other']])" 2>&1 | tail -1)"
-  timeout 60 python tools/knn_only.py 5 2>/dev/null | tail -2
+timeout 200 python -m pytest tests/test_gpu_pointpillars.py tests/test_gpu_pipelines.py -m gpu -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log
+ML3D_GEMM_TAIL_DEBUG=1 timeout 60 python tools/roofline_ops.py pp 3 2>&1 | tail -3
+for t in 1 0 1 0; do
+  ML3D_GEMM_TAIL_SPLIT=$t timeout 120 python bench.py --workload pointpillars --no-cpu-baseline > $O/pp_$t.json 2> $O/pp_$t.err
+  echo "pointpillars tail_split=$t: $(python -c "import json; d=json.load(open('$O/pp_$t.json')); print(round(d['value'],1), round(d['step_ms_median'],3), round(d['roofline']['avg_launch_ms'],4), round(d['roofline']['frac'],3))" 2>&1 | tail -1)"
 done
-cp /tmp/base.so $LIB/libml3d_hip.so
-timeout 120 python bench.py --workload kpconv --no-cpu-baseline > $O/kp.json 2> $O/kp.err; echo "kpconv: $(python -c "import json; d=json.load(open('$O/kp.json')); print(round(d['value'],1), round(d['step_ms_median'],3))" 2>&1 | tail -1)"
