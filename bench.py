@@ -339,6 +339,24 @@ def main():
     out = None
     if rank == 0:
         n_lv = stream.n
+        # the same three kernels with NOTHING else on the GPU (after the timed region): what the overlap with the other stream
+        # costs each of them -- the neighbour-search launch runs under the forward on purpose and takes ~1.5x its solo time there
+        alone = {}
+        try:
+            e1 = stream.single_engine()
+            a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_ev.record(); b_ev.record()
+            torch.cuda.synchronize()
+            for kind, tag in TRACED:
+                ts = []
+                for _ in range(3):
+                    tr = make_trace(tag, a_ev, b_ev)
+                    e1.step(stream.pts[0], stream.pts[0], tr if kind == "knn" else None, tr if kind == "fwd" else None)
+                    torch.cuda.synchronize()
+                    ts.append(a_ev.elapsed_time(b_ev))
+                alone[(kind, tag)] = float(np.median(ts))
+        except Exception:
+            alone = {}
         # per-step intervals on the compute stream (completion of step i-1 -> completion of step i)
         iv = np.array([done_ev[i].elapsed_time(done_ev[i + 1]) for i in range(K)])
         per_tag = {}
@@ -352,7 +370,8 @@ def main():
                 cands.append({"bound": "hbm", "kernel": "knn_query_multi<16, true> (16-NN + prefix 1-NN of all pyramid levels, one launch)",
                               "achieved": kb / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_query_multi<16, true>", B),
-                              "avg_launch_ms": ms, "bytes_per_launch": kb,
+                              "avg_launch_ms": ms, "bytes_per_launch": kb, "avg_launch_ms_alone": alone.get((kind, tag)),
+                              "frac_alone": (kb / (alone[(kind, tag)] * 1e-3) / 1e9 / PEAK_HBM_GBS) if alone.get((kind, tag)) else None,
                               "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU / latency-bound "
                                       "(~150 candidates x ~45 instructions per query), not HBM-bound: DESIGN.md §3.2"})
             else:
@@ -365,7 +384,8 @@ def main():
                               "achieved": fl_ex / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                               "frac": fl_ex / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                               "frac_reference_formulation": fl_ref / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                              "traffic": _traffic(name, B), "avg_launch_ms": ms, "executed_flops_per_launch": fl_ex,
+                              "traffic": _traffic(name, B), "avg_launch_ms": ms, "avg_launch_ms_alone": alone.get((kind, tag)),
+                              "executed_flops_per_launch": fl_ex,
                               "reference_flops_per_launch": fl_ref})
         cands.sort(key=lambda c: -c["avg_launch_ms"])
         out = {

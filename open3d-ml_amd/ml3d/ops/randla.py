@@ -1,0 +1,79 @@
+"""The fused RandLA-Net forward."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _abi
+from . import _gates
+from ._gates import KnnResult, RadiusResult, VoxelizeResult, _splits, _splits_of_lengths
+
+
+def _stream():
+    return _gates._stream()
+
+
+def _need_gpu(*tensors):
+    return _gates._need_gpu(*tensors)
+
+
+def _ws(nbytes, device):
+    return _gates._ws(nbytes, device)
+
+from .search import pyramid_sizes
+
+
+def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out=None, workspace=None, tile_order=None):
+    """Fused RandLA-Net forward (ml3d/torch/models/randlanet.py:241-298) -> scores [B, N, classes].
+    ``tile_order`` (optional, from ``randla_knn_pyramid``): walk each level's attention tiles in that point order
+    (same result, better cache locality of the neighbour gathers)."""
+    lib = _abi.get()
+    _need_gpu(params, features, points, *neighbor_idx, *interp_idx)
+    dev = points.device
+    B, n0 = int(desc.batch), int(desc.num_points)
+    if tuple(points.shape) != (B, n0, 3) or tuple(features.shape) != (B, n0, desc.in_channels):
+        raise RuntimeError("randla_forward: points/features shape does not match the descriptor")
+    for t in (points, features):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("randla_forward: points/features must be contiguous float32")
+    for t in list(neighbor_idx) + list(interp_idx):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("randla_forward: index tensors must be contiguous int32")
+    # the C ABI receives bare pointers and derives every extent from the descriptor: the list lengths and the shape of
+    # every level are checked HERE (a short list or a wrong K would be an out-of-bounds device read, not an error)
+    L, K = int(desc.num_layers), int(desc.num_neighbors)
+    sizes = pyramid_sizes(n0, [int(desc.sub_sampling_ratio[i]) for i in range(L)])
+    if len(neighbor_idx) != L or len(interp_idx) != L:
+        raise RuntimeError("randla_forward: need %d neighbour and %d interpolation index tensors (got %d / %d)"
+                           % (L, L, len(neighbor_idx), len(interp_idx)))
+    for l in range(L):
+        if tuple(neighbor_idx[l].shape) != (B, sizes[l], K):
+            raise RuntimeError("randla_forward: neighbor_idx[%d] must be [%d, %d, %d], got %s"
+                               % (l, B, sizes[l], K, tuple(neighbor_idx[l].shape)))
+        if tuple(interp_idx[l].shape) not in ((B, sizes[l], 1), (B, sizes[l])):
+            raise RuntimeError("randla_forward: interp_idx[%d] must be [%d, %d, 1], got %s"
+                               % (l, B, sizes[l], tuple(interp_idx[l].shape)))
+        if tile_order is not None and (l >= len(tile_order) or
+                                       (tile_order[l] is not None and tile_order[l].numel() != B * sizes[l])):
+            raise RuntimeError("randla_forward: tile_order[%d] must hold %d rows (or be None)" % (l, B * sizes[l]))
+    if out is None:
+        out = torch.empty((B, n0, desc.num_classes), dtype=torch.float32, device=dev)
+    wsb = lib.ml3d_randla_forward_workspace_bytes(C.byref(desc))
+    ws = workspace if workspace is not None else _ws(wsb, dev)
+    if ws.numel() < wsb:
+        raise RuntimeError("randla_forward: workspace too small")
+    t_n = _abi.ptr_table([t.data_ptr() for t in neighbor_idx])
+    t_i = _abi.ptr_table([t.data_ptr() for t in interp_idx])
+    with torch.cuda.device(dev):
+        if tile_order is not None:
+            for t in tile_order:
+                if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or t.device != dev):
+                    raise RuntimeError("randla_forward: tile_order tensors must be contiguous int32 on the same device")
+            t_o = _abi.ptr_table([0 if t is None else t.data_ptr() for t in tile_order])
+            rc = lib.ml3d_randla_forward_ordered(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
+                                                 t_n, t_i, t_o, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), None)
+        else:
+            rc = lib.ml3d_randla_forward(C.byref(desc), params.data_ptr(), features.data_ptr(), points.data_ptr(),
+                                         t_n, t_i, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _abi.check(rc, "ml3d_randla_forward")
+    return out

@@ -3,7 +3,7 @@ CPU tensors against the HOST EMULATION of ``libml3d_hip.so`` (tests/hipemu — t
 host), so that host glue (the reference's pipelines driving the native model classes, batchers, vote updates) can be
 exercised in this GPU-less container.
 
-The product has no such mode: every op insists on HIP tensors (``ops._need_gpu``), every model on a HIP device
+The product has no such mode: every op insists on HIP tensors (``ops._gates._need_gpu``), every model on a HIP device
 (``_abi.require_gpu``) and ``_abi.get()`` on the hipcc-built library.  ``install()`` monkeypatches exactly those three gates
 (plus the handful of ``torch.cuda`` stream / device context calls the host side makes) INSIDE THE TEST PROCESS.  Nothing
 under ``open3d-ml_amd/`` imports this module, and it is useless on a GPU box (the -m gpu tests run the real library).
@@ -92,8 +92,9 @@ def install(product="ml3d"):
     ops = importlib.import_module(product + ".ops")
     _abi._lib = _abi.bind(C.CDLL(emu_library_path()))
     _abi.require_gpu = lambda device, what: (torch.device(device) if not isinstance(device, torch.device) else device)
-    ops._need_gpu = lambda *t: None
-    ops._stream = lambda: None
+    gates = importlib.import_module(product + ".ops._gates")      # the one place every op checks / takes its stream from
+    gates._need_gpu = lambda *t: None
+    gates._stream = lambda: None
     torch.cuda.device = _null
     torch.cuda.stream = _null
     torch.cuda.current_stream = lambda *a, **k: _Stream()
