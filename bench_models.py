@@ -111,7 +111,11 @@ def run_pointpillars(args, rank, world, dev, dist):
     n_boxes = [0]
     overlap = not getattr(args, "no_overlap", False)
     from ml3d.engine import PointPillarsStream
-    pipe = PointPillarsStream(m, dev)
+    import os
+    # ML3D_PP_LANES (A/B knob, default 2): the step's sweeps are dealt to this many independent pipelines (own HIP streams) --
+    # while one lane's convolution drains its last, partly filled round of tiles the other lane's kernels fill the idle CUs
+    lanes = max(1, min(B, int(os.environ.get("ML3D_PP_LANES", "2"))))
+    pipe = PointPillarsStream(m, dev, lanes=lanes)
 
     def deliver(res):
         """a step's detections (host tensors): counted; N > 1: every rank's [n_i, 9] rows -> rank 0 (the ragged gather)"""
@@ -161,7 +165,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                                   "(pointpillars_kitti.yml): host->device upload + voxelize + pillar features + BEV backbone + "
                                   "heads + box decode + rotated NMS" % B, "frames_per_step_per_gpu": B,
                       "h2d_in_timed_region": True, "decode_nms_in_timed_region": True, "d2h_of_detections_in_timed_region": True,
-                      "boxes_last_step": n_boxes[0], "streams": 2 if overlap else 1,
+                      "boxes_last_step": n_boxes[0], "streams": 2 * lanes if overlap else 1, "lanes": lanes if overlap else 1,
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
            "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

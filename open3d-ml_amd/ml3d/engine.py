@@ -336,9 +336,9 @@ class KPConvPipeline:
         self.compute.synchronize()
 
 
-class PointPillarsStream:
-    """Host sweeps in, detections out (PointPillars detection, frame-parallel rows a15-a19): what ``bench.py --workload
-    pointpillars`` times.  Three HIP streams: the pinned host sweeps of step i + 1 are uploaded on the copy stream while step i
+class _PointPillarsLane:
+    """One lane of ``PointPillarsStream``.  Host sweeps in, detections out (PointPillars detection, frame-parallel rows a15-a19).
+    Two HIP streams: the pinned host sweeps of step i + 1 are uploaded on the copy stream while step i
     runs voxelize -> pillar features -> backbone -> heads -> batched box decode + NMS on the compute stream, and the few
     hundred KB of detections (rows + per-sample counts) travel back into pinned host buffers asynchronously; ``submit``
     returns the detections of the PREVIOUS step (three lists like ``Anchor3DHead.get_bboxes``; None on the first call) after
@@ -398,3 +398,38 @@ class PointPillarsStream:
     def synchronize(self):
         self.h2d.synchronize()
         self.compute.synchronize()
+
+
+class PointPillarsStream:
+    """Host sweeps in, detections out: what ``bench.py --workload pointpillars`` times.  The sweeps of a step are dealt to
+    ``lanes`` independent pipelines (``_PointPillarsLane``: upload on a copy stream, voxelize -> pillar features -> backbone ->
+    heads -> batched box decode + NMS on a compute stream, detections copied back to pinned host memory asynchronously, results
+    handed out one step later after waiting only for that step's copy event).  Why lanes: a BEV convolution of 16 sweeps is 4.4
+    rounds of tiles on the resident workgroups, a deeper one 3.3 or 1.6 -- the last, partly filled round of every launch leaves
+    CUs idle, and nothing else is queued behind it on ONE stream.  With two lanes the other half-batch's kernels fill them:
+    1244 -> 1404 frames/s at 16 sweeps per step (four lanes: 1060 -- the kernels get too small; ``gpurun_out/r3p``).
+    ``submit`` returns the detections of the PREVIOUS step (three lists in the order of that step's sweeps; None on the first
+    call), ``flush`` the last step's."""
+
+    def __init__(self, model, device, lanes=2):
+        self.lanes = [_PointPillarsLane(model, device) for _ in range(max(1, int(lanes)))]
+        self.compute = self.lanes[-1].compute          # (the stream whose completion events pace a step in the bench)
+
+    @staticmethod
+    def _merge(parts):
+        parts = [p for p in parts if p is not None]
+        if not parts:
+            return None
+        return tuple(sum((list(p[i]) for p in parts), []) for i in range(3))
+
+    def submit(self, host_clouds):
+        n, k = len(host_clouds), len(self.lanes)
+        k = max(1, min(k, n))
+        return self._merge([self.lanes[i].submit(host_clouds[i * n // k:(i + 1) * n // k]) for i in range(k)])
+
+    def flush(self):
+        return self._merge([lane.flush() for lane in self.lanes])
+
+    def synchronize(self):
+        for lane in self.lanes:
+            lane.synchronize()

@@ -149,13 +149,14 @@ m = PointPillars(device="cpu", **cfg)
 m.load_state_dict(W.pointpillars_state_dict(cfg, 4))
 steps = [[torch.from_numpy(W.crop_for_cfg(synth_data.kitti_sweep(10 * s + i), cfg)) for i in range(2)] for s in range(3)]
 want = [m.bbox_head.get_bboxes(*m(c)) for c in steps]          # the reference API path: NCHW head maps, then get_bboxes
-pipe = PointPillarsStream(m, "cpu")
-got = [pipe.submit(c) for c in steps] + [pipe.flush()]
-assert got[0] is None and pipe.flush() is None
-for (wb, ws, wl), (gb, gs, gl) in zip(want, got[1:]):
-    assert len(gb) == 2
-    for i in range(2):
-        assert torch.equal(wl[i], gl[i]) and torch.equal(wb[i], gb[i]) and torch.equal(ws[i], gs[i]) and len(gl[i]) > 0
+for lanes in (1, 2, 3):                 # the step's sweeps dealt to 1 / 2 pipelines (3 lanes: clipped to the 2 sweeps of a step)
+    pipe = PointPillarsStream(m, "cpu", lanes=lanes)
+    got = [pipe.submit(c) for c in steps] + [pipe.flush()]
+    assert got[0] is None and pipe.flush() is None
+    for (wb, ws, wl), (gb, gs, gl) in zip(want, got[1:]):
+        assert len(gb) == 2
+        for i in range(2):
+            assert torch.equal(wl[i], gl[i]) and torch.equal(wb[i], gb[i]) and torch.equal(ws[i], gs[i]) and len(gl[i]) > 0
 print("ok")
 ''')
 

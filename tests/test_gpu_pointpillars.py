@@ -123,3 +123,26 @@ def test_bench_configuration_16_sweeps_matches_the_oracle_on_sweeps_0_and_15():
         assert np.array_equal(gl[j].cpu().numpy(), rl.numpy()), j
         assert np.abs(gs[j].cpu().numpy() - rs.numpy()).max() <= 1e-5
         assert (np.abs(gb[j].cpu().numpy() - rb.numpy()) / np.maximum(1.0, np.abs(rb.numpy()))).max() <= 1e-4
+
+
+def test_two_lane_stream_returns_the_single_lane_detections():
+    """``ml3d.engine.PointPillarsStream`` as bench.py runs it (2 lanes: the 16 sweeps of a step dealt to two independent
+    pipelines whose kernels overlap on the GPU) against one lane: every sweep's labels identical, scores and boxes to 1e-5
+    (the forward of a sweep does not depend on which other sweeps share its launch), in the order the sweeps were submitted."""
+    from ml3d.engine import PointPillarsStream
+    cfg = P.KITTI_CFG
+    m = _model(cfg, P.make_state_dict(cfg, 2024))
+    steps = [_clouds(cfg, range(16 * s, 16 * s + 16)) for s in range(3)]
+    hosts = [[torch.from_numpy(c).pin_memory() for c in st] for st in steps]
+    runs = []
+    for lanes in (1, 2):
+        pipe = PointPillarsStream(m, "cuda", lanes=lanes)
+        got = [pipe.submit(h) for h in hosts] + [pipe.flush()]
+        assert got[0] is None and pipe.flush() is None
+        runs.append(got[1:])
+    for one, two in zip(*runs):
+        assert len(one[0]) == len(two[0]) == 16
+        for i in range(16):
+            assert torch.equal(one[2][i], two[2][i]) and len(one[2][i]) > 0, i
+            assert (one[1][i] - two[1][i]).abs().max().item() <= 1e-5
+            assert (one[0][i] - two[0][i]).abs().max().item() <= 1e-4
