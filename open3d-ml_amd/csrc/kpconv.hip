@@ -157,6 +157,138 @@ __global__ void __launch_bounds__(256) kp_weighted(KpArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// kp_agg_mfma<NT> -- the same weighted sum (Cin = 16 NT) on v_mfma_f32_16x16x4_f32, one WAVE per query:
+//   wf[k][c] = sum_h w[k][h] * x[idx_h][c]   =   A [16 kernel-point slots x 4 neighbours]  x  B [4 neighbours x 16 channels]
+// per group of four neighbours and per 16-channel tile.  Lane (k = lane & 15, j = lane >> 4) owns neighbour j of the group:
+// it computes the ONE influence w[k][j] the A operand wants from it (its kernel point k in three registers, the neighbour's
+// position one broadcast load per 16 lanes) and loads the NT channels k NT .. k NT + NT - 1 of that neighbour's feature row (the
+// 16 lanes of a neighbour read one contiguous row) as its B values -- tile nt holds channels {k NT + nt}.  No LDS at all.
+// kp_weighted above gives every lane of a query ALL sixteen weights of every neighbour through LDS: four ds_read_b128 per
+// neighbour and wave, 32 cycles of the CU's one LDS return path against 32 cycles of packed FMAs on each of FOUR SIMDs -- the
+// Cin = 32 block ran LDS-bound at 1.1 ms for 640 000 queries (profiles/r03_pmc_kp_fetch.csv).  Here the weights never leave
+// the lane that computes them, and the product runs on the matrix unit at the same f32 rate.
+// The row's indices are read once (lane = column, two registers for widths up to 128); the walk ends at the row's last real
+// neighbour (dense rows list the real ones first: ~30 of 73 columns at the Toronto3D bench size, the rest is padding that the
+// lockstep loops of kp_weighted iterate over), wherever the shadows sit.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE>       // 0 constant, 1 linear, 2 gaussian: compile-time here (no branch per group of four neighbours)
+__device__ __forceinline__ float kp_influence1(float dx, float dy, float dz, const KpArgs& A) {
+    // (the arithmetic of kp_influence2, one kernel point: fused d2, fused 1 - d / extent; v_sqrt_f32 itself -- 1 ulp -- instead
+    //  of sqrtf()'s 20-instruction correctly rounded sequence: the kernel is issue-bound and the weights are a float row)
+    if constexpr (MODE == 0) return 1.0f;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if constexpr (MODE == 1) { const float w = fmaf(__builtin_amdgcn_sqrtf(d2), -A.inv_extent, 1.0f); return w > 0.f ? w : 0.f; }
+    return expf(-d2 / A.gauss_den);
+}
+
+template <int NT>
+struct KpRow {                       // one neighbour as lane (k, j) sees it: position + its NT channels
+    float sx, sy, sz;
+    float xv[NT];
+    int idx;
+};
+
+template <int NT>
+__device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int idx, int k) {
+    // UNCONDITIONAL loads (a shadow lane reads row 0 and is zeroed when consumed): loads inside an `if (idx >= 0)` leave the
+    // number of outstanding requests unknown, and the compiler then waits for ALL of them before the previous group's use
+    r.idx = idx;
+    const int64_t i = idx < 0 ? 0 : idx;
+    const float* sp = A.s_pts + 3 * i;
+    r.sx = sp[0]; r.sy = sp[1]; r.sz = sp[2];
+    const float* xr = A.x + i * (16 * NT) + k * NT;
+    if constexpr (NT == 1) r.xv[0] = xr[0];
+    else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(xr); r.xv[0] = v.x; r.xv[1] = v.y; }
+    else {
+#pragma unroll
+        for (int t = 0; t < NT / 4; ++t) {
+            const float4 v = reinterpret_cast<const float4*>(xr)[t];
+            r.xv[4 * t] = v.x; r.xv[4 * t + 1] = v.y; r.xv[4 * t + 2] = v.z; r.xv[4 * t + 3] = v.w;
+        }
+    }
+}
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
+    constexpr int CIN = 16 * NT;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane & 15, j = lane >> 4;
+    const bool kreal = k < KP_K;                                  // slot 15 is padding: weight 0, never stored
+    const float kx = kreal ? A.kp[3 * k] : 0.f, ky = kreal ? A.kp[3 * k + 1] : 0.f, kz = kreal ? A.kp[3 * k + 2] : 0.f;
+    // XCD-contiguous walk (workgroup b runs on XCD b & 7): each XCD takes one contiguous eighth of the queries, so the feature
+    // rows that neighbouring queries share stay in that XCD's L2
+    const int64_t per_xcd = (A.nq + 7) / 8;
+    const int64_t qbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t stride = (int64_t)(gridDim.x >> 3) * 4;
+    for (int64_t t = (int64_t)(blockIdx.x >> 3) * 4 + wave; t < per_xcd; t += stride) {
+        const int64_t q = qbase + t;
+        if (q >= A.nq) break;
+        const int32_t* row = A.inds + q * A.h;
+        int ia = lane < A.h ? row[lane] : -1, ib = 64 + lane < A.h ? row[64 + lane] : -1;
+        if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
+        if (ib < 0 || ib >= A.ns) ib = -1;
+        const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
+        const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
+        const int groups = (count + 3) >> 2;
+        const float* qp = A.q_pts + 3 * q;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // this lane's column of group g (wave-uniform choice of the index register: g is uniform); -1 past the last group
+        auto column = [&](int g) -> int {
+            const int c = 4 * g + j;
+            const int v = __shfl(c < 64 ? ia : ib, c & 63);
+            return g < groups ? v : -1;
+        };
+        auto consume = [&](const KpRow<NT>& r) {
+            const float nx = r.sx - qx, ny = r.sy - qy, nz = r.sz - qz;
+            float w = kp_influence1<MODE>(nx - kx, ny - ky, nz - kz, A);
+            const bool real = r.idx >= 0;
+            w = (kreal && real) ? w : 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
+        };
+        // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is consumed (a
+        // rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
+        KpRow<NT> ra, rb;
+        kp_row_load<NT>(ra, A, column(0), k);
+        for (int g = 0; g < groups; g += 2) {
+            // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for all four before the first
+            //  MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the younger is in flight)
+            kp_row_load<NT>(rb, A, column(g + 1), k);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            kp_row_load<NT>(ra, A, column(g + 2), k);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(rb);                  // (unconditional: past the last group the column is -1, a zero MFMA -- under an `if` the
+                                          //  compiler sinks rb's loads into the branch, right in front of their use)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // D: lane (column k, j) holds kernel points 4 j .. 4 j + 3 of channels k NT .. k NT + NT - 1
+        float* o = A.wf + q * (int64_t)(KP_K * CIN) + k * NT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 4 * j + r;
+            if (kk < KP_K) {
+                float* dst = o + kk * CIN;
+                if constexpr (NT == 1) dst[0] = acc[0][r];
+                else if constexpr (NT == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0][r], acc[1][r]);
+                else {
+#pragma unroll
+                    for (int t4 = 0; t4 < NT / 4; ++t4)
+                        reinterpret_cast<float4*>(dst)[t4] = make_float4(acc[4 * t4][r], acc[4 * t4 + 1][r], acc[4 * t4 + 2][r],
+                                                                         acc[4 * t4 + 3][r]);
+                }
+            }
+        }
+    }
+}
+
 // tiny Cin (the first layer, in_features_dim in {1, 2, 4, 5}): one thread per query, weights on the fly
 template <int CIN>
 __global__ void __launch_bounds__(256) kp_weighted_small(KpArgs A) {
@@ -329,6 +461,194 @@ static bool small_fused_ok(const KpArgs& a, const KpOut& o) {
            ((((uintptr_t)o.weights) | ((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 15) == 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// kp_fused32 -- the Cin = 32 -> Cout = 32 block (the KPConv inside the two full-resolution resnet bottlenecks of every
+// first_features_dim = 128 config: 640 000 queries x 73 neighbours at the Toronto3D bench size) as ONE kernel.
+// The two-kernel form writes wf [Nq, 480] (1.2 GB) and reads it back in a K = 480, N = 32 GEMM that HBM bounds at a sixth of
+// the matrix peak: 0.68 + 0.75 ms.  Here a persistent workgroup owns a tile of 16 queries:
+//   aggregation (as kp_weighted<32, 1>: 32 lanes per query = one channel each, 8 packed accumulators = 16 kernel-point slots,
+//     wave w takes queries 4w .. 4w+3 two at a time; the feature rows of U neighbours are requested before the first is used --
+//     the kernel runs at 3 waves per SIMD, the two-kernel form hid that latency with 8)
+//   -> wf tile [16][512] in LDS (slot 15 of the 16 kernel points is padding, its rows of the weight matrix are zeros)
+//   -> v_mfma_f32_16x16x4_f32: wave w multiplies the tile's columns [128 w, 128 w + 128) with ITS rows of the kernel weights,
+//     held in 64 registers for the whole launch (lane (col, g) of block s, step j: W[128 w + 16 s + 4 g + j][16 nt + col]);
+//     A = one ds_read_b128 per lane and block (row = lane & 15, the lane's four k)
+//   -> the four waves' partial [16 x 32] sums through LDS, bias (folded BN) + activation, 128-byte output rows.
+// The f32 MFMA and the packed FMAs of the aggregation share the issue slots of a SIMD (tools/micro), so the product costs its
+// 64 MFMAs per wave and tile (~2 k cycles on ~10 k of aggregation) -- and the 2.4 GB round trip of wf is gone.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int KF_TQ = 16;                 // queries per tile
+constexpr int KF_K = KP_WP * 32;          // padded K: 16 kernel-point slots x 32 channels
+constexpr int KF_WFP = KF_K + 4;          // LDS pitch of a query's weighted features
+constexpr int KF_HC = 16;                 // neighbours per influence chunk
+constexpr int KF_U = 4;                   // feature rows in flight per lane
+
+#ifndef KF_MIN_WGS
+#define KF_MIN_WGS 3            // workgroups per CU the register allocation aims at (build-time A/B: tools/build_variant.sh)
+#endif
+__global__ void __launch_bounds__(256, KF_MIN_WGS) kp_fused32(KpArgs A, KpOut O) {
+    constexpr int CIN = 32, COUT = 32;
+    __shared__ __attribute__((aligned(16))) float WF[KF_TQ * KF_WFP];
+    __shared__ __attribute__((aligned(16))) float W[4][2][KF_HC][KP_WP];
+    __shared__ int NI[4][2][KF_HC];
+    __shared__ __attribute__((aligned(16))) float RED[4][KF_TQ][COUT];
+    __shared__ float KPs[KP_WP * 3];                 // x[16] | y[16] | z[16]; the sixteenth point is padding
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < KP_WP * 3) KPs[tid] = (tid % KP_WP) < KP_K ? A.kp[3 * (tid % KP_WP) + tid / KP_WP] : 0.f;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // this wave's rows of the kernel weights, in MFMA B layout
+    const int col = lane & 15, g = lane >> 4;
+    float bw[8][4][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = 128 * wave + 16 * s + 4 * g + j;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float v = O.weights[(kk < KP_K * CIN ? kk : 0) * COUT + 16 * nt + col];
+                bw[s][j][nt] = kk < KP_K * CIN ? v : 0.f;
+            }
+        }
+    __syncthreads();
+    const int64_t tiles = (A.nq + KF_TQ - 1) / KF_TQ;
+    // XCD-contiguous walk: workgroup b runs on XCD b & 7 (round-robin dispatch); each XCD takes one contiguous eighth of the
+    // tiles, so the neighbour rows a tile's queries share with the next tile stay in that XCD's L2
+    const int64_t per_xcd = (tiles + 7) / 8;
+    const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
+    const int qi = lane >> 5, c = lane & 31;
+    for (int64_t it = blockIdx.x >> 3; it < per_xcd; it += slots) {
+        const int64_t tile = (int64_t)xcd * per_xcd + it;
+        if (tile >= tiles) break;
+        const int64_t tq0 = tile * KF_TQ;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int row0 = 4 * wave + 2 * sub;                     // tile rows of this pass: row0, row0 + 1
+            const int64_t q0 = tq0 + row0;
+            v2f acc[KP_WP / 2];
+#pragma unroll
+            for (int k = 0; k < KP_WP / 2; ++k) acc[k] = (v2f){0.f, 0.f};
+            for (int h0 = 0; h0 < A.h; h0 += KF_HC) {
+                // ---- influence weights of the chunk's 2 x 16 (query, neighbour) pairs: lane = (pair, half of the 8 kernel-point
+                //      pairs) -> LDS; shadow pairs get zero weights and index -1 --------------------------------------------
+                const int pr = lane >> 1, half = lane & 1;
+                const int pq = pr / KF_HC, ph = pr % KF_HC;
+                const int64_t qq = q0 + pq;
+                const int hh = h0 + ph;
+                int idx = -1;
+                if (qq < A.nq && hh < A.h) {
+                    idx = A.inds[qq * A.h + hh];
+                    if (idx < 0 || idx >= A.ns) idx = -1;            // shadow neighbour (kpconv.py:1048-1051)
+                }
+                if (half == 0) NI[wave][pq][ph] = idx;
+                kp_v2f* wrow = reinterpret_cast<kp_v2f*>(&W[wave][pq][ph][8 * half]);
+                if (idx >= 0) {
+                    const float* sp = A.s_pts + 3 * (int64_t)idx;
+                    const float* qp = A.q_pts + 3 * qq;
+                    const float nx = sp[0] - qp[0], ny = sp[1] - qp[1], nz = sp[2] - qp[2];
+                    const kp_v2f* kx = reinterpret_cast<const kp_v2f*>(KPs) + 4 * half;
+                    const kp_v2f* ky = reinterpret_cast<const kp_v2f*>(KPs + KP_WP) + 4 * half;
+                    const kp_v2f* kz = reinterpret_cast<const kp_v2f*>(KPs + 2 * KP_WP) + 4 * half;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        wrow[k] = kp_influence2((kp_v2f){nx, nx} - kx[k], (kp_v2f){ny, ny} - ky[k], (kp_v2f){nz, nz} - kz[k], A);
+                    if (half == 1) W[wave][pq][ph][KP_K] = 0.f;      // the padding slot of the last pair
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wrow[k] = (kp_v2f){0.f, 0.f};
+                }
+                // entries of the chunk in use: up to the last real neighbour of either query (rows list them first)
+                const unsigned long long real = __ballot(idx >= 0);
+                int hn = 0;
+                if (real) {
+                    const unsigned lo = (unsigned)real, hi = (unsigned)(real >> 32);         // pairs of query 0 / query 1
+                    const int t0 = lo ? (31 - __builtin_clz(lo)) / 2 + 1 : 0, t1 = hi ? (31 - __builtin_clz(hi)) / 2 + 1 : 0;
+                    hn = t0 > t1 ? t0 : t1;
+                }
+                wave_lds_sync();
+                // ---- stream the neighbours' feature rows, KF_U rows in flight ---------------------------------------------
+                for (int p0 = 0; p0 < hn; p0 += KF_U) {
+                    float xv[KF_U];
+#pragma unroll
+                    for (int u = 0; u < KF_U; ++u) {
+                        const int id = p0 + u < KF_HC ? NI[wave][qi][p0 + u] : -1;
+                        xv[u] = id >= 0 ? A.x[(int64_t)id * CIN + c] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < KF_U; ++u) {
+                        if (p0 + u < KF_HC) {
+                            const float4* wp = reinterpret_cast<const float4*>(&W[wave][qi][p0 + u][0]);
+                            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                            const v2f wk[8] = {(v2f){w0.x, w0.y}, (v2f){w0.z, w0.w}, (v2f){w1.x, w1.y}, (v2f){w1.z, w1.w},
+                                               (v2f){w2.x, w2.y}, (v2f){w2.z, w2.w}, (v2f){w3.x, w3.y}, (v2f){w3.z, w3.w}};
+#pragma unroll
+                            for (int k = 0; k < KP_WP / 2; ++k) acc[k] = __builtin_elementwise_fma(wk[k], (v2f){xv[u], xv[u]}, acc[k]);
+                        }
+                        // (keeps the next neighbour's 16 weights out of registers until this one's FMAs are issued: with all four
+                        //  hoisted the kernel needs 192 VGPRs = 2 waves per SIMD instead of 3)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                wave_lds_sync();
+            }
+            // weighted features of the pass's two queries -> the tile (row index of the weight matrix = k * 32 + c)
+            float* wf = WF + (row0 + qi) * KF_WFP + c;
+#pragma unroll
+            for (int k = 0; k < KP_WP / 2; ++k) { wf[(2 * k) * CIN] = acc[k].x; wf[(2 * k + 1) * CIN] = acc[k].y; }
+        }
+        block_sync_lds();
+        // ---- [16 x 512] x [512 x 32]: this wave's 128 columns of the tile against its rows of the weights -----------------
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = WF + col * KF_WFP + 128 * wave + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[s][0][0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[s][0][1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[s][1][0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[s][1][1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[s][2][0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[s][2][1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[s][3][0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[s][3][1], d1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                 // lane holds rows 4g .. 4g+3 of column col
+            RED[wave][4 * g + r][col] = d0[r];
+            RED[wave][4 * g + r][16 + col] = d1[r];
+        }
+        block_sync_lds();
+        {   // ---- sum of the four partials + bias + activation: thread = (row, pair of output channels) --------------------
+            const int row = tid >> 4, co = 2 * (tid & 15);
+            float2 r = O.bias ? *reinterpret_cast<const float2*>(O.bias + co) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float2 p = *reinterpret_cast<const float2*>(&RED[w][row][co]);
+                r.x += p.x; r.y += p.y;
+            }
+            if (O.act == 1) { r.x = r.x > 0.f ? r.x : r.x * O.slope; r.y = r.y > 0.f ? r.y : r.y * O.slope; }
+            else if (O.act == 2) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; }
+            if (tq0 + row < A.nq) *reinterpret_cast<float2*>(O.out + (tq0 + row) * (int64_t)COUT + co) = r;
+        }
+        // (the next tile's WF rows are written after its aggregation, its RED after its first barrier: no third barrier)
+    }
+}
+
+// the fused block takes cin = cout = 32 with 8-byte aligned bias / out (ML3D_KP_FUSED32=0, read once: the two-kernel path)
+static bool fused32_ok(const KpArgs& a, const KpOut& o) {
+    static const bool on = [] { const char* e = getenv("ML3D_KP_FUSED32"); return e && e[0] == '1'; }();
+    return on && a.cin == 32 && o.cout == 32 && a.h > 0 && ((((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 7) == 0;
+}
+
+static void launch_fused32(const KpArgs& a, const KpOut& o, hipStream_t st) {
+    const int64_t tiles = (a.nq + KF_TQ - 1) / KF_TQ;
+    static const int per_cu = [] { const char* e = getenv("ML3D_KP_FUSED32_WGS"); int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
+    int64_t nb = (tiles + 7) / 8 * 8;                             // a multiple of 8: one slot row per XCD
+    const int64_t cap = (int64_t)per_cu * 256;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(kp_fused32, dim3((unsigned)nb), dim3(256), 0, st, a, o);
+}
+
 // max over the listed neighbours (shadow rows are zeros) / feature of the first listed neighbour
 __global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, const int32_t* __restrict__ inds,
                               int64_t nq, int h, int mode, float* __restrict__ out) {
@@ -386,8 +706,36 @@ static void launch_kpw(const KpArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((kp_weighted<G, J>), dim3(nb), dim3(256), 0, st, a);
 }
 
+template <int NT>
+static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
+    int64_t nb = ((a.nq + 3) / 4 + 7) / 8 * 8;                    // four queries (waves) per workgroup, a multiple of 8 workgroups
+    if (nb > 256 * 8) nb = 256 * 8;
+    if (a.influence == 0) hipLaunchKernelGGL((kp_agg_mfma<NT, 0>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else if (a.influence == 1) hipLaunchKernelGGL((kp_agg_mfma<NT, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((kp_agg_mfma<NT, 2>), dim3((unsigned)nb), dim3(256), 0, st, a);
+}
+
+// the MFMA aggregation takes cin in {16, 32, 64, 128, 256}, rows of up to 128 columns, 16-byte aligned features / wf
+// (ML3D_KP_AGG_MFMA=0, read once: the packed-FMA kernels for A/B runs)
+static bool agg_mfma_ok(const KpArgs& a) {
+    static const bool on = [] { const char* e = getenv("ML3D_KP_AGG_MFMA"); return !(e && e[0] == '0'); }();
+    const int c = a.cin;
+    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h <= 128 && a.ns > 0 &&
+           ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
+}
+
 static int launch_weighted(const KpArgs& a, hipStream_t st) {
     const int c = a.cin;
+    if (agg_mfma_ok(a)) {
+        switch (c) {
+            case 16: launch_agg_mfma<1>(a, st); break;
+            case 32: launch_agg_mfma<2>(a, st); break;
+            case 64: launch_agg_mfma<4>(a, st); break;
+            case 128: launch_agg_mfma<8>(a, st); break;
+            default: launch_agg_mfma<16>(a, st); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
     const unsigned nbs = (unsigned)((a.nq + 255) / 256);
     if (c == 1) hipLaunchKernelGGL(kp_weighted_small<1>, dim3(nbs), dim3(256), 0, st, a);
     else if (c == 2) hipLaunchKernelGGL(kp_weighted_small<2>, dim3(nbs), dim3(256), 0, st, a);
@@ -450,6 +798,10 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
             case 4: launch_small_fused<4>(a, ko, st); break;
             default: launch_small_fused<5>(a, ko, st); break;
         }
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
+    if (fused32_ok(a, ko)) {
+        launch_fused32(a, ko, st);
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
     int rc = launch_weighted(a, st);

@@ -346,6 +346,7 @@ static inline float __fsqrt_rn(float a) { return sqrtf(a); }
 #define __expf(a) expf(a)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
     return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
 }

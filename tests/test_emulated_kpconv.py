@@ -51,6 +51,79 @@ def test_kpconv_strided_queries_and_shadow_only_rows():
     assert rc == 0 and np.abs(out - ref).max() <= TOL and (out[-1] == 0).all()
 
 
+@pytest.mark.parametrize("cin,n,r", [(16, 700, 0.3), (32, 1500, 0.3), (64, 800, 0.35), (128, 500, 0.3), (256, 300, 0.25)])
+def test_kpconv_mfma_aggregation_rows_wider_than_64_shadows_anywhere(cin, n, r):
+    """cin in {16, 32, 64, 128, 256} aggregates on the matrix unit (kp_agg_mfma: one wave per query, lane = (kernel point,
+    neighbour of a group of four)).  Rows of 65 .. 128 columns (second index register), the columns of every row shuffled so that
+    shadow entries sit ANYWHERE (the walk ends at the last real column, not at the first shadow), strided queries, a query with
+    only shadow neighbours."""
+    rng = np.random.default_rng(cin)
+    s = synth_data.toronto3d_sphere(22, n)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.1)[0], [[50, 50, 50]]]).astype(np.float32)
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], r)
+    assert 40 < inds.shape[1] <= 128
+    inds = np.take_along_axis(inds, np.argsort(rng.random(inds.shape), axis=1), 1)
+    x = rng.standard_normal((len(s), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, cin, 32)) * (0.5 / np.sqrt(cin))).astype(np.float32)
+    rc, out = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08)
+    ref = K.kpconv_rigid(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08).numpy()
+    assert rc == 0 and np.abs(out - ref).max() <= TOL * max(1.0, np.abs(ref).max()) and (out[-1] == 0).all()
+
+
+_FUSED32_CASE = r"""
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import emu, synth_data
+from oracle import kpconv_ref as K
+rng = np.random.default_rng(3)
+s = synth_data.toronto3d_sphere(22, 4300)
+q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.05)[0], [[50, 50, 50]]]).astype(np.float32)   # last: no neighbours
+if len(q) %% 16 == 0:
+    q = q[1:]
+inds = K.batch_neighbors(q, s, [len(q)], [len(s)], 0.12)
+assert (inds[-1] == len(s)).all() and len(q) > 16 * 256                 # more tiles than the 256 workgroups of the launch
+x = rng.standard_normal((len(s), 32)).astype(np.float32)
+kp = K.synthetic_kernel_points(0.2)
+w = (rng.standard_normal((15, 32, 32)) * 0.1).astype(np.float32)
+for infl, name in ((1, "linear"), (2, "gaussian")):
+    rc, out = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08, act=2, influence=infl)
+    tq, ts, ti, tx, tk, tw = (torch.from_numpy(a) for a in (q, s, inds.astype(np.int64), x, kp, w))
+    if infl == 1:
+        ref = K.kpconv_rigid(tq, ts, ti, tx, tk, tw, 0.08)
+    else:                           # radius_gaussian (kpconv.py:1119-1125): exp(-d2 / (2 sigma^2 + eps)), sigma = 0.3 extent
+        nb = torch.cat((ts, torch.zeros_like(ts[:1]) + 1e6), 0)[ti] - tq.unsqueeze(1)
+        sq = ((nb.unsqueeze(2) - tk) ** 2).sum(3)
+        wgt = torch.exp(-sq / (2 * (0.3 * 0.08) ** 2 + 1e-9)).transpose(1, 2)
+        wf = torch.matmul(wgt, torch.cat((tx, torch.zeros_like(tx[:1])), 0)[ti]).permute(1, 0, 2)
+        ref = torch.matmul(wf, tw).sum(0)
+    ref = torch.relu(ref).numpy()
+    assert rc == 0 and np.abs(out - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())) and (out[-1] == 0).all(), name
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("fused,wgs", [("1", "1"), ("0", "3")])        # (the fused block is opt-in: measured slower)
+def test_kpconv_32_to_32_fused_block_walks_several_tiles_per_workgroup(fused, wgs):
+    """cin = cout = 32 runs as ONE kernel (kp_fused32: aggregation -> wf tile in LDS -> MFMA against register-resident kernel
+    weights -> cross-wave sum, bias, activation).  4 000+ strided queries = more 16-query tiles than the launch has workgroups
+    (ML3D_KP_FUSED32_WGS=1: 256), so a workgroup walks several tiles of its XCD's share; a query with only shadow neighbours, a
+    ragged last tile, no bias, ReLU, linear and gaussian influence.  ML3D_KP_FUSED32=0: the two-kernel path, same gate."""
+    import os
+    import subprocess
+    import sys
+    emu.lib()
+    env = dict(os.environ, ML3D_KP_FUSED32=fused, ML3D_KP_FUSED32_WGS=wgs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FUSED32_CASE % {"root": root}], capture_output=True, text=True, timeout=900,
+                       cwd="/tmp", env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("cin,act", [(1, 0), (4, 2)])
 def test_kpconv_first_layer_fused_kernel_strided_shadow_rows_no_bias(cin, act):
     """cin <= 5 with 32 | cout <= 128 runs as ONE kernel (kp_small_fused: influences + weighted sum + the [15 cin] x [cout]
