@@ -222,18 +222,33 @@ __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
     const int64_t per_xcd = (A.nq + 7) / 8;
     const int64_t qbase = (int64_t)(blockIdx.x & 7) * per_xcd;
     const int64_t stride = (int64_t)(gridDim.x >> 3) * 4;
-    for (int64_t t = (int64_t)(blockIdx.x >> 3) * 4 + wave; t < per_xcd; t += stride) {
+    // the NEXT query's index row and position are requested while this one is aggregated (a wave walks its queries serially:
+    // without this every query starts with two dependent round trips -- row, then first neighbours -- that nothing covers);
+    // unconditional, clamped loads again: a wave past its last query re-reads query 0 and drops it
+    int ia_n, ib_n;
+    float qx_n, qy_n, qz_n;
+    auto request = [&](int64_t tt) {
+        const int64_t qq = qbase + tt;
+        const int64_t qc = (tt < per_xcd && qq < A.nq) ? qq : 0;
+        const int32_t* row = A.inds + qc * A.h;
+        ia_n = row[lane < A.h ? lane : A.h - 1];
+        ib_n = row[64 + lane < A.h ? 64 + lane : A.h - 1];
+        const float* qp = A.q_pts + 3 * qc;
+        qx_n = qp[0]; qy_n = qp[1]; qz_n = qp[2];
+    };
+    int64_t t = (int64_t)(blockIdx.x >> 3) * 4 + wave;
+    request(t);
+    for (; t < per_xcd; t += stride) {
         const int64_t q = qbase + t;
         if (q >= A.nq) break;
-        const int32_t* row = A.inds + q * A.h;
-        int ia = lane < A.h ? row[lane] : -1, ib = 64 + lane < A.h ? row[64 + lane] : -1;
+        int ia = lane < A.h ? ia_n : -1, ib = 64 + lane < A.h ? ib_n : -1;
+        const float qx = qx_n, qy = qy_n, qz = qz_n;
+        request(t + stride);
         if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
         if (ib < 0 || ib >= A.ns) ib = -1;
         const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
         const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
         const int groups = (count + 3) >> 2;
-        const float* qp = A.q_pts + 3 * q;
-        const float qx = qp[0], qy = qp[1], qz = qp[2];
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -370,7 +385,18 @@ __global__ void __launch_bounds__(256) kp_small_fused(KpArgs A, KpOut O) {
 #pragma unroll
     for (int c = 0; c < CIN; ++c) acc[c] = (v2f){0.f, 0.f};
     const int32_t* irow = A.inds + q * A.h;
-    for (int h0 = 0; h0 < A.h; h0 += U) {
+    // columns in use: up to the last real neighbour of any of the wave's 8 queries.  Dense rows list the real neighbours first
+    // and pad to the widest row of the BATCH (73 columns at the Toronto3D bench size, ~30 real on average): the lockstep walk
+    // below paid full price for every shadow column.  The 8 lanes of a query scan its row once (column = lane & 7 + 8 i; the
+    // same lines the walk reads next), then a wave-wide max -- exact wherever the shadows sit.
+    int hend = 0;
+    for (int c0 = kp; c0 < A.h; c0 += 8) {
+        const int v = irow[c0];
+        if (v >= 0 && v < A.ns && q_ok) hend = c0 + 1;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(hend, m); hend = o > hend ? o : hend; }
+    for (int h0 = 0; h0 < hend; h0 += U) {
         int idx[U];
         float sx[U], sy[U], sz[U], xv[U][CIN];
 #pragma unroll
@@ -720,7 +746,7 @@ static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
 static bool agg_mfma_ok(const KpArgs& a) {
     static const bool on = [] { const char* e = getenv("ML3D_KP_AGG_MFMA"); return !(e && e[0] == '0'); }();
     const int c = a.cin;
-    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h <= 128 && a.ns > 0 &&
+    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h > 0 && a.h <= 128 && a.ns > 0 && a.nq > 0 &&
            ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
 }
 

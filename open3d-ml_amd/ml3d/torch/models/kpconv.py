@@ -258,6 +258,13 @@ class KPFCNN(nn.Module):
                     d['u1'] = None if isinstance(blk.unary1, nn.Identity) else self._pack_unary(blk.unary1, dev)
                     d['sc'] = None if isinstance(blk.unary_shortcut, nn.Identity) else \
                         self._pack_unary(blk.unary_shortcut, dev)
+                    # unary2 and the shortcut Linear are both activation-free and meet in one sum (kpconv.py:1451-1461):
+                    # [y | shortcut_in] . [W_u2 ; W_sc] + (b_u2 + b_sc) is ONE GEMM over the concatenated K -- the shortcut's
+                    # [N, out] output is neither written nor read back as a residual (656 MB per block on the full-resolution layer)
+                    d['u2sc'] = None
+                    if d['sc'] is not None and self._FUSE_SHORTCUT and d['sc']['act'] == 0 and d['u2']['act'] == 0:
+                        d['u2sc'] = dict(wt=torch.cat([d['u2']['wt'], d['sc']['wt']], 0).contiguous(),
+                                         b=(d['u2']['b'] + d['sc']['b']).contiguous(), act=0, slope=0.0)
                     P['enc'].append(d)
             for blk in self.decoder_blocks:
                 P['dec'].append(self._pack_unary(blk, dev) if isinstance(blk, UnaryBlock) else None)
@@ -272,6 +279,7 @@ class KPFCNN(nn.Module):
                           act=p['act'] if act is None else act, slope=p['slope'] if slope is None else slope)
 
     _SPLIT_DECODER = os.environ.get("ML3D_KP_DECODER_SPLIT", "1") != "0"     # A/B knob (speed only), read once
+    _FUSE_SHORTCUT = os.environ.get("ML3D_KP_FUSE_SHORTCUT", "1") != "0"     # A/B knob: unary2 + shortcut Linear as one GEMM
 
     def _upsample_concat_unary(self, p, x, skip, up):
         """NearestUpsampleBlock + torch.cat + UnaryBlock of the decoder (kpconv.py:283-286, 821-838, 1468-1481):
@@ -316,6 +324,9 @@ class KPFCNN(nn.Module):
                 y = x if p['u1'] is None else self._unary(p['u1'], x)
                 y = ops.kpconv_rigid(q_pts, pts[L], inds, y, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)
                 sc = ops.gather_pool(x, inds, 'max') if strided else x
+                if p['u2sc'] is not None:
+                    x = self._unary(p['u2sc'], y, a2=sc, act=1, slope=lr)
+                    continue
                 if p['sc'] is not None:
                     sc = self._unary(p['sc'], sc)
                 # unary2 (no relu) + shortcut, then LeakyReLU (kpconv.py:1451-1461): one GEMM epilogue
