@@ -21,4 +21,10 @@ __device__ __forceinline__ double key_min(double a, double b) {
     return lo;
 }
 
+// "does any ACTIVE lane of this wave see pred" in DIVERGENT control flow (lanes whose loops have different trip counts): a ballot
+// over the current exec mask.  The host emulator runs every lane as its own fiber and cannot rendezvous lanes that sit at
+// different iterations, so its stand-in answers with the lane's own predicate -- callers must stay correct when the answer is
+// `true` more often than that (k-NN pending queue: an early flush is always exact).
+__device__ __forceinline__ bool wave_any_active(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+
 }  // namespace ml3d

@@ -70,15 +70,76 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
 #endif
 }
 
+// ---- pending queue (K = 16, round 3; measured, OFF by default) ---------------------------------------------------------------
+// An insertion chain is 31 f64 operations (+16 moves) and the wave runs it whenever ANY of its 64 lanes accepts the candidate.
+// Instead a lane PARKS an accepted key (key < its current 16th) in a lane-private LDS column of KNN_QD slots -- one predicated
+// ds_write_b64 -- and the wave merges all queues into the lists only when some lane's queue is nearly full: sort the 8 pending
+// keys (19 compare-exchanges), half-cleaner against the upper half of the list, two bitonic merges = 63 compare-exchanges + 8
+// minima = 134 f64 operations for up to 8 keys per lane instead of 8 x 47.  The 16th is stale between flushes (too large), so a
+// key the exact search needs is never rejected; the queues are flushed before every stop test.  Bit-exact on the emulator and
+// on the MI355X (tests/test_emulated_prims.py builds this variant; tests/test_gpu_knn.py passed with it).
+// Measured (profiles/r03_pmc_knn_queue.csv, gpurun_out/r3z, r3aa): 597 M instead of 729 M VALU wave-instructions per launch --
+// only -18 %: the chain ran in ~30 % of the wave's candidate steps, not in all of them (the lanes' runs differ in length: a
+// wave makes ~410 candidate steps for ~150 candidates per lane, and most steps serve few lanes) -- 1.60 ms against 1.76 ms
+// alone at five waves per SIMD (the flush needs 96 registers; at six it spills: 2.5 ms), 2.0-2.3 against 2.55 ms under the
+// forward, but 5777 / 5787 against 5812 frames/s and 5844 against 5893 in a second call: the 16 KB of LDS per workgroup and the
+// lower occupancy cost the forward what the search gains.  KNN_QUEUE=1 builds it (tools/build_variant.sh).
+#ifndef KNN_QUEUE
+#define KNN_QUEUE 0            // build-time A/B switch: 1 = pending queue, 0 = insertion chain per candidate (default)
+#endif
+constexpr int KNN_QD = 8;      // pending keys per lane; slot s of thread t lives at q[s * 256 + t] (conflict-free columns)
+
+#define ML3D_CE(a, b) key_minmax(a, b, a, b)
+__device__ __forceinline__ void sort8_keys(double (&v)[8]) {      // Batcher's odd-even merge sort, 19 compare-exchanges
+    ML3D_CE(v[0], v[1]); ML3D_CE(v[2], v[3]); ML3D_CE(v[4], v[5]); ML3D_CE(v[6], v[7]);
+    ML3D_CE(v[0], v[2]); ML3D_CE(v[1], v[3]); ML3D_CE(v[4], v[6]); ML3D_CE(v[5], v[7]);
+    ML3D_CE(v[1], v[2]); ML3D_CE(v[5], v[6]);
+    ML3D_CE(v[0], v[4]); ML3D_CE(v[1], v[5]); ML3D_CE(v[2], v[6]); ML3D_CE(v[3], v[7]);
+    ML3D_CE(v[2], v[4]); ML3D_CE(v[3], v[5]);
+    ML3D_CE(v[1], v[2]); ML3D_CE(v[3], v[4]); ML3D_CE(v[5], v[6]);
+}
+// b[o .. o + 7] bitonic -> ascending (12 compare-exchanges)
+template <int O>
+__device__ __forceinline__ void bitonic8_keys(double (&b)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ML3D_CE(b[O + i], b[O + i + 4]);
+#pragma unroll
+    for (int s = 0; s < 8; s += 4) { ML3D_CE(b[O + s], b[O + s + 2]); ML3D_CE(b[O + s + 1], b[O + s + 3]); }
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) ML3D_CE(b[O + s], b[O + s + 1]);
+}
+// merge the lane's pending keys into its sorted list; the queue comes back empty (every slot EMPTY)
+__device__ __forceinline__ void topk_flush(double (&best)[16], double* __restrict__ q, int& cnt) {
+    const double empty = __longlong_as_double((long long)KEY_EMPTY);
+    double v[KNN_QD];
+#pragma unroll
+    for (int s = 0; s < KNN_QD; ++s) v[s] = q[s * 256];
+#pragma unroll
+    for (int s = 0; s < KNN_QD; ++s) q[s * 256] = empty;
+    cnt = 0;
+    sort8_keys(v);
+    // the 16 smallest of list + pending = list[0..7] and the 8 smallest of list[8..15] + pending (half-cleaner: ascending
+    // against descending is bitonic, the element-wise minima are its lower half)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) best[8 + i] = key_min(best[8 + i], v[7 - i]);
+    bitonic8_keys<8>(best);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ML3D_CE(best[i], best[15 - i]);
+    bitonic8_keys<0>(best);
+    bitonic8_keys<8>(best);
+}
+#undef ML3D_CE
+
 #ifndef KNN_GROUP
 #define KNN_GROUP 3
 #endif
 
 // SUB: also track the nearest candidate whose index is below n_sub -- the RandLA pyramid's 1-NN interpolation target
 // (level l + 1 is the prefix [:n_sub] of level l, randlanet.py:222-224), found in the same scan as the k-NN
-template <int K, bool SUB>
+template <int K, bool SUB, bool QUEUED>
 __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
-                                         float qz, double (&best)[K], int n_sub, double& best1) {
+                                         float qz, double (&best)[K], int n_sub, double& best1,
+                                         double* __restrict__ queue, int& pending) {
     int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
     // per group instead of one per candidate -- the loop is latency-bound: lane-per-query gathers, ~5 waves per SIMD);
@@ -87,6 +148,10 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
         float4 c[KNN_GROUP];
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
+        if constexpr (QUEUED) {
+            // room for a whole group in every active lane's queue (one check and ONE flush site per group, under the loads)
+            if (wave_any_active(pending > KNN_QD - KNN_GROUP)) topk_flush(best, queue, pending);
+        }
         // straight-line: a slot past the run (its load was clamped) carries the EMPTY key, which the insertion ignores -- no
         // branch, hence no phi copies of the 16-entry list at a join (they were a third of the instructions of an insertion)
 #pragma unroll
@@ -99,17 +164,21 @@ __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell
             const double empty = __longlong_as_double((long long)KEY_EMPTY);
             const double kd = (p + j < p1) ? __longlong_as_double((long long)key) : empty;
             if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : empty);
-            topk_insert<K>(best, kd);
+            if constexpr (QUEUED) {
+                if (kd < best[K - 1]) { queue[pending * 256] = kd; ++pending; }
+            } else {
+                topk_insert<K>(best, kd);
+            }
         }
     }
 }
 
-template <int K, bool SUB>
+template <int K, bool SUB, bool QUEUED = false>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
                                         float* __restrict__ out_d2, int64_t t, int n_sub = 0,
                                         int32_t* __restrict__ out_sub = nullptr, int* __restrict__ stage = nullptr,
-                                        bool vec_store = false) {
+                                        bool vec_store = false, double* __restrict__ queue = nullptr) {
     // stage: LDS, 64 * 17 + 128 ints per wave of the workgroup, for the transposed store of 16 indices per query (below)
     const bool transposed = K == 16 && k == 16 && !out_d2 && stage;
     const bool active = t < Q.n_total;
@@ -135,6 +204,11 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
     double best1 = __longlong_as_double((long long)KEY_EMPTY);
+    int pending = 0;
+    if constexpr (QUEUED) {
+#pragma unroll
+        for (int s_ = 0; s_ < KNN_QD; ++s_) queue[s_ * 256] = __longlong_as_double((long long)KEY_EMPTY);
+    }
 
     if (active && g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
@@ -150,13 +224,20 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
                 for (int y = ya; y <= yb; ++y) {
                     int ay = y > cy ? y - cy : cy - y;
                     int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                    if (r == 1 || az == r || ay == r) {
-                        scan_run<K, SUB>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1);
-                    } else {
-                        if (cx - r >= 0) scan_run<K, SUB>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1);
-                        if (cx + r <= dxm) scan_run<K, SUB>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1);
+                    // a face row of the shell is one run of cells, an inner row its two end cells: ONE inlined copy of the scan
+                    // (three copies -- each with its flush -- did not fit the register budget)
+                    const bool face = r == 1 || az == r || ay == r;
+                    for (int part = 0; part < (face ? 1 : 2); ++part) {
+                        int ca, cb;
+                        if (face) { ca = row + xa; cb = row + xb; }
+                        else if (part == 0) { if (cx - r < 0) continue; ca = cb = row + cx - r; }
+                        else { if (cx + r > dxm) continue; ca = cb = row + cx + r; }
+                        scan_run<K, SUB, QUEUED>(G, ca, cb, qx, qy, qz, best, n_sub, best1, queue, pending);
                     }
                 }
+            }
+            if constexpr (QUEUED) {          // the stop test reads the EXACT list: merge what is still parked
+                if (wave_any_active(pending > 0)) topk_flush(best, queue, pending);
             }
             // every point outside the scanned box is at least `gd` away (inf when the box face is
             // past the grid).  Stop once the k-th best is strictly inside that radius.
@@ -279,8 +360,12 @@ static int knn_store_mode() {
     return v;
 }
 #ifndef KNN_WAVES
+#if KNN_QUEUE
+#define KNN_WAVES 5        // (the queue merge needs 96 registers)
+#else
 #define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
 #endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
+#endif
 template <int K, bool SUB, bool STAGE = false>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0
@@ -288,14 +373,15 @@ ML3D_WAVES_PER_SIMD(KNN_WAVES)
 #endif
 knn_query_multi(KnnJobs J, int k, int index_local, int store_mode) {
     __shared__ int stage[STAGE ? 4 * (64 * 17 + 64 * 2) : 1];      // (store mode 1 only)
+    __shared__ double pend[(K == 16 && KNN_QUEUE) ? KNN_QD * 256 : 1];   // the lanes' pending keys (16 KB)
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
-    knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+    knn_one<K, SUB, K == 16 && KNN_QUEUE>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
                     (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub,
-                    STAGE ? stage : nullptr, store_mode == 2);
+                    STAGE ? stage : nullptr, store_mode == 2, (K == 16 && KNN_QUEUE) ? pend + threadIdx.x : nullptr);
 }
 
 template <bool SUB>
