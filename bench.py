@@ -16,7 +16,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline    the CPU oracle (port of the reference path) on this box's host cores, best of a thread sweep.
   latency         the model-class API (transform -> batcher -> forward -> update_probs) at the YAMLs' batch sizes 1 and 4:
                   per-frame median / p95 over >= 200 frames (N = 1).
-  workloads       BASELINE.json configs[2] / [3] (KPConv Toronto3D, PointPillars KITTI) measured in the same run (N = 1).
+  workloads       BASELINE.json configs[2] / [3] (KPConv Toronto3D, PointPillars KITTI): `bench.py --workload ...` run as a child
+                  process each, after the headline measurement (N = 1).
 """
 import argparse
 import json
@@ -372,8 +373,9 @@ def main():
                               "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_query_multi<16, true>", B),
                               "avg_launch_ms": ms, "bytes_per_launch": kb, "avg_launch_ms_alone": alone.get((kind, tag)),
                               "frac_alone": (kb / (alone[(kind, tag)] * 1e-3) / 1e9 / PEAK_HBM_GBS) if alone.get((kind, tag)) else None,
-                              "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU / latency-bound "
-                                      "(~150 candidates x ~45 instructions per query), not HBM-bound: DESIGN.md §3.2"})
+                              "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU-issue bound "
+                                      "(714 M wave-instructions per launch, ~410 candidate steps per wave for ~150 candidates "
+                                      "per lane: profiles/r03_pmc_knn_sq.csv), not HBM-bound: DESIGN.md §3.2"})
             else:
                 layer, stage = tag // 8, tag % 8
                 d = CFG["dim_output"][layer]
@@ -430,14 +432,24 @@ def main():
             except Exception as e:          # a side measurement must never take the headline line down
                 out["latency"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_workloads:
-            import bench_models
-            wl = {}
+            # each side workload in its OWN process (`bench.py --workload ...`, what a deployment runs: one process per GPU and
+            # model).  In-process after the headline they inherit its five HIP streams' hardware-queue assignments -- ROCm maps
+            # streams to queues in first-use order -- and PointPillars' two lanes then share a queue: 1156 instead of 1390-1406
+            # frames/s (gpurun_out/r3fin2 against r3p / r3q).
+            import subprocess
             del stream
             torch.cuda.empty_cache()
-            sub = argparse.Namespace(steps=20, warmup=3, frames_per_step=64, no_cpu_baseline=args.no_cpu_baseline)
-            for name, fn in (("kpconv", bench_models.run_kpconv), ("pointpillars", bench_models.run_pointpillars)):
+            wl = {}
+            for name in ("kpconv", "pointpillars"):
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "30", "--warmup", "8"]       # (a fresh process: the
+                # first steps still grow the allocator pools of both streams -- with 3 warm-up steps a cold box showed 13 ms outliers
+                # among 8.8 ms steps)
+                if args.no_cpu_baseline:
+                    cmd.append("--no-cpu-baseline")
                 try:
-                    wl[name] = fn(sub, 0, 1, dev, None)
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    wl[name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
                 except Exception as e:      # a side measurement must never take the headline line down
                     wl[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["workloads"] = wl

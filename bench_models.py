@@ -256,7 +256,7 @@ def run_kpconv(args, rank, world, dev, dist):
                                   "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, " (build of step i+1 overlapped with the forward of step i on two HIP streams)" if overlap else ""),
                       "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
                       "parallelism": "frame-parallel x%d" % world},
-           "roofline": {"bound": "mfma", "kernel": "kp_weighted<32,1> + gemm_tile (KPConv %d->%d, %d queries x %d neighbours)" % (cin, cout, nq, H),
+           "roofline": {"bound": "mfma", "kernel": "kp_agg_mfma<2> + gemm_tile (KPConv %d->%d, %d queries x %d neighbour columns)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "traffic": _traffic("kpconv_block_32_32", B), "avg_launch_ms": ms,

@@ -1,13 +1,9 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3aa; mkdir -p $O
+O=gpurun_out/r3fin3; mkdir -p $O
 export TMPDIR=/tmp
-LIB=open3d-ml_amd/ml3d/lib
-cp $LIB/libml3d_hip.so /tmp/base.so
-for v in base q_w5 q_w4 noq q_w5; do
-  if [ "$v" = base ]; then cp /tmp/base.so $LIB/libml3d_hip.so; else cp $LIB/ab/$v.so $LIB/libml3d_hip.so; fi
-  echo "$v: $(timeout 120 python tools/knn_only.py 7 2>&1 | tail -1)"
-  timeout 200 python bench.py --no-cpu-baseline --no-workloads --no-latency > $O/rl_$v.json 2> $O/rl_$v.err
-  echo "$v: $(python -c "import json; d=json.load(open('$O/rl_$v.json')); r=d['roofline']; print(round(d['value'],1), round(d['ms_per_step'],3), r['kernel'][:20], round(r['avg_launch_ms'],3), r.get('avg_launch_ms_alone'))" 2>&1 | tail -1)"
-done
-cp /tmp/base.so $LIB/libml3d_hip.so
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; python -c "
+import json; d=json.load(open('$O/bench.json'))
+print('randla', round(d['value'],1), d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('avg_launch_ms'), d['latency']['batch_1']['ms_per_frame_median'], d['latency']['batch_4']['ms_per_frame_median'])
+for k,w in d['workloads'].items(): print(k, round(w.get('value',0),1), w.get('roofline',{}).get('frac'), w.get('config',{}).get('lanes'), w.get('error'))
+"
