@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3fin3; mkdir -p $O
+O=gpurun_out/r3ac; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; python -c "
-import json; d=json.load(open('$O/bench.json'))
-print('randla', round(d['value'],1), d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('avg_launch_ms'), d['latency']['batch_1']['ms_per_frame_median'], d['latency']['batch_4']['ms_per_frame_median'])
-for k,w in d['workloads'].items(): print(k, round(w.get('value',0),1), w.get('roofline',{}).get('frac'), w.get('config',{}).get('lanes'), w.get('error'))
-"
+
+for i in 1 2 3; do for s in 2 3 1; do
+  ML3D_PP_STAGGER=$s timeout 150 python bench.py --workload pointpillars --no-cpu-baseline --steps 30 --warmup 8 > $O/pp_${s}_$i.json 2> $O/pp_${s}_$i.err
+  echo "stagger=$s run $i: $(python -c "import json; d=json.load(open('$O/pp_${s}_$i.json')); print(round(d['value'],1), round(d['step_ms_median'],3), round(d['step_ms_p95'],3))" 2>&1 | tail -1)"
+done; done
