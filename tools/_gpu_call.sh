@@ -1,9 +1,14 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3ac; mkdir -p $O
+O=gpurun_out/r3ad; mkdir -p $O
 export TMPDIR=/tmp
-
-for i in 1 2 3; do for s in 2 3 1; do
-  ML3D_PP_STAGGER=$s timeout 150 python bench.py --workload pointpillars --no-cpu-baseline --steps 30 --warmup 8 > $O/pp_${s}_$i.json 2> $O/pp_${s}_$i.err
-  echo "stagger=$s run $i: $(python -c "import json; d=json.load(open('$O/pp_${s}_$i.json')); print(round(d['value'],1), round(d['step_ms_median'],3), round(d['step_ms_p95'],3))" 2>&1 | tail -1)"
-done; done
+timeout 600 python -m pytest tests/test_gpu_kpconv.py -x -q 2>&1 | tail -2
+run() { # name, env...
+  name=$1; shift
+  env "$@" timeout 200 python bench.py --workload kpconv --no-cpu-baseline --steps 30 --warmup 8 > $O/kp_$name.json 2> $O/kp_$name.err
+  echo "kpconv $name: $(python -c "import json; d=json.load(open('$O/kp_$name.json')); r=d['roofline']; print(round(d['value'],1), round(d['step_ms_median'],3), 'block ms', round(r['avg_launch_ms'],3), 'frac', round(r['frac'],3))" 2>&1 | tail -1)"
+}
+run pair ML3D_KP_AGG_PAIR=1
+run single ML3D_KP_AGG_PAIR=0
+run pair_b ML3D_KP_AGG_PAIR=1
+run single_b ML3D_KP_AGG_PAIR=0
