@@ -1,14 +1,6 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3ad; mkdir -p $O
+O=gpurun_out/r3ae; mkdir -p $O
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_kpconv.py -x -q 2>&1 | tail -2
-run() { # name, env...
-  name=$1; shift
-  env "$@" timeout 200 python bench.py --workload kpconv --no-cpu-baseline --steps 30 --warmup 8 > $O/kp_$name.json 2> $O/kp_$name.err
-  echo "kpconv $name: $(python -c "import json; d=json.load(open('$O/kp_$name.json')); r=d['roofline']; print(round(d['value'],1), round(d['step_ms_median'],3), 'block ms', round(r['avg_launch_ms'],3), 'frac', round(r['frac'],3))" 2>&1 | tail -1)"
-}
-run pair ML3D_KP_AGG_PAIR=1
-run single ML3D_KP_AGG_PAIR=0
-run pair_b ML3D_KP_AGG_PAIR=1
-run single_b ML3D_KP_AGG_PAIR=0
+ML3D_BENCH_PROFILE=1 timeout 600 python bench.py --no-workloads --no-cpu-baseline --steps 5 --warmup 2 > $O/b.json 2> $O/prof.txt
+grep -A45 "latency profile, batch 1" $O/prof.txt | cut -c1-180 | head -60
