@@ -224,15 +224,24 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
                 for (int y = ya; y <= yb; ++y) {
                     int ay = y > cy ? y - cy : cy - y;
                     int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                    // a face row of the shell is one run of cells, an inner row its two end cells: ONE inlined copy of the scan
-                    // (three copies -- each with its flush -- did not fit the register budget)
-                    const bool face = r == 1 || az == r || ay == r;
-                    for (int part = 0; part < (face ? 1 : 2); ++part) {
-                        int ca, cb;
-                        if (face) { ca = row + xa; cb = row + xb; }
-                        else if (part == 0) { if (cx - r < 0) continue; ca = cb = row + cx - r; }
-                        else { if (cx + r > dxm) continue; ca = cb = row + cx + r; }
-                        scan_run<K, SUB, QUEUED>(G, ca, cb, qx, qy, qz, best, n_sub, best1, queue, pending);
+                    if constexpr (QUEUED) {
+                        // a face row of the shell is one run of cells, an inner row its two end cells: ONE inlined copy of the
+                        // scan (three copies -- each with its flush -- did not fit the register budget)
+                        const bool face = r == 1 || az == r || ay == r;
+                        for (int part = 0; part < (face ? 1 : 2); ++part) {
+                            int ca, cb;
+                            if (face) { ca = row + xa; cb = row + xb; }
+                            else if (part == 0) { if (cx - r < 0) continue; ca = cb = row + cx - r; }
+                            else { if (cx + r > dxm) continue; ca = cb = row + cx + r; }
+                            scan_run<K, SUB, QUEUED>(G, ca, cb, qx, qy, qz, best, n_sub, best1, queue, pending);
+                        }
+                    } else if (r == 1 || az == r || ay == r) {
+                        scan_run<K, SUB, QUEUED>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1, queue, pending);
+                    } else {
+                        // (three inlined copies of the scan: the one-copy loop above costs the insertion form 9 % -- 1.73 against
+                        //  1.59 ms alone, gpurun_out/r3af)
+                        if (cx - r >= 0) scan_run<K, SUB, QUEUED>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1, queue, pending);
+                        if (cx + r <= dxm) scan_run<K, SUB, QUEUED>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1, queue, pending);
                     }
                 }
             }

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3ae; mkdir -p $O
+O=gpurun_out/r3ag; mkdir -p $O
 export TMPDIR=/tmp
-ML3D_BENCH_PROFILE=1 timeout 600 python bench.py --no-workloads --no-cpu-baseline --steps 5 --warmup 2 > $O/b.json 2> $O/prof.txt
-grep -A45 "latency profile, batch 1" $O/prof.txt | cut -c1-180 | head -60
+R=$GRAFT_REPO_ROOT
+cd /tmp && ML3D_KNN_PHASES=1 rocprofv3 --kernel-trace --stats -d $R/$O/pf -o k -- python $R/tools/knn_only.py 3 > /dev/null 2>&1
+cd $R; python profiles/summarize_rocpd.py $O/pf/k_results.db 2>/dev/null | grep -E "knn_query|Name" | cut -c1-200
