@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3ag; mkdir -p $O
+O=gpurun_out/r3ah; mkdir -p $O
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd /tmp && ML3D_KNN_PHASES=1 rocprofv3 --kernel-trace --stats -d $R/$O/pf -o k -- python $R/tools/knn_only.py 3 > /dev/null 2>&1
-cd $R; python profiles/summarize_rocpd.py $O/pf/k_results.db 2>/dev/null | grep -E "knn_query|Name" | cut -c1-200
+for i in 1 2 3; do for d in 0 1 2 3; do
+  ML3D_PP_DUMMY_STREAMS=$d timeout 150 python bench.py --workload pointpillars --no-cpu-baseline --steps 30 --warmup 8 > $O/pp_${d}_$i.json 2> $O/pp_${d}_$i.err
+  echo "dummy=$d run $i: $(python -c "import json; d=json.load(open('$O/pp_${d}_$i.json')); print(round(d['value'],1), round(d['step_ms_median'],3))" 2>&1 | tail -1)"
+done; done
