@@ -195,3 +195,34 @@ def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_
         ref = K.forward(sd, CFG, K.to_torch_batch(wide), torch.ones((lens[i], 1))).numpy()
         a, b = offs[0][i], offs[0][i + 1]
         assert np.abs(logits[a:b] - ref).max() <= TOL, (i, float(np.abs(logits[a:b] - ref).max()))
+
+
+@pytest.mark.parametrize("cin,n,r", [(16, 2000, 0.3), (32, 4000, 0.3), (64, 2500, 0.35), (128, 1500, 0.3), (256, 900, 0.25),
+                                     (24, 1200, 0.3)])
+def test_kpconv_op_rows_wider_than_64_with_shadows_anywhere(cin, n, r):
+    """``ops.kpconv_rigid`` on the hardware for every aggregation kernel: the MFMA form (cin in {16, 32, 64, 128, 256}: one wave
+    per query, two index registers for rows of 65 .. 128 columns, ballot for the last real column, ds_bpermute for a group's
+    column) and the packed-FMA form (cin = 24).  The columns of every row are shuffled so that shadow entries sit ANYWHERE;
+    strided queries; a query with only shadow neighbours; bias + LeakyReLU.  <= 1e-4 against the oracle's restatement."""
+    from ml3d import ops
+    rng = np.random.default_rng(cin)
+    s = synth_data.toronto3d_sphere(22, n)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.1)[0], [[50, 50, 50]]]).astype(np.float32)
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], r)
+    assert 40 < inds.shape[1] <= 128 and (inds[-1] == len(s)).all()
+    inds = np.take_along_axis(inds, np.argsort(rng.random(inds.shape), axis=1), 1)
+    x = rng.standard_normal((len(s), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, cin, 32)) * (0.5 / np.sqrt(cin))).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    d = "cuda:0"
+    out = ops.kpconv_rigid(torch.from_numpy(q).to(d), torch.from_numpy(s).to(d), torch.from_numpy(inds).to(d),
+                           torch.from_numpy(x).to(d), torch.from_numpy(kp).to(d),
+                           torch.from_numpy(w.reshape(15 * cin, 32)).to(d), torch.from_numpy(b).to(d), 0.08, 1, 0.2, 1)
+    torch.cuda.synchronize()
+    ref = K.kpconv_rigid(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08)
+    ref = torch.nn.functional.leaky_relu(ref + torch.from_numpy(b), 0.2).numpy()
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    assert np.abs(got[-1] - np.where(b > 0, b, 0.2 * b)).max() <= 1e-6          # only shadows: act(bias)
