@@ -289,16 +289,22 @@ def main():
     # also hold back the NEXT step's upload and neighbour search, which are ordered after the caller's stream: the
     # search-under-forward overlap would be lost exactly when scaling is measured.)
     post = torch.cuda.Stream(device=dev) if overlap else None
+    labelled = [torch.cuda.Event(), torch.cuda.Event()] if overlap else None
 
     def one_step(knn_trace=None, fwd_trace=None, done=None):
-        scores = stream.submit(hosts[step_no[0] & 1], None, knn_trace, fwd_trace, done)
+        slot = step_no[0] & 1
+        if post is not None and step_no[0] >= 2:
+            # the pipelined engine has two score buffers in ping-pong: this step's forward overwrites the one whose argmax was
+            # enqueued TWO steps ago -- wait for that one only (waiting for the previous step's argmax, as until round 3, put
+            # 0.15 ms of label post-processing between consecutive forwards)
+            stream.compute_stream.wait_event(labelled[slot])
+        scores = stream.submit(hosts[slot], None, knn_trace, fwd_trace, done)
         step_no[0] += 1
         if post is not None:
             with torch.cuda.stream(post):
                 post.wait_stream(stream.compute_stream)          # this step's forward
                 gather.push(scores)
-            # the forward that overwrites this `scores` slot (two steps on) must come after the argmax that reads it
-            stream.compute_stream.wait_stream(post)
+                labelled[slot].record(post)
         else:
             gather.push(scores)
 
