@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops as oops
-from synth_weights import (TORONTO3D_CFG, arch_plan, synthetic_kernel_points,  # noqa: F401  (input generation)
+from synth_weights import (TORONTO3D_CFG, KPCONV_DEFORM_SMALL_CFG, arch_plan, synthetic_kernel_points,  # noqa: F401  (input generation)
                            kpconv_state_dict as make_state_dict)
 
 
@@ -90,21 +90,22 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius):
 
 
 def segmentation_inputs(stacked_points, stack_lengths, cfg, rotations="random"):
-    """concat_batcher.py:186-305 for rigid architectures.  ``rotations``: "random" (draw from np.random like
+    """concat_batcher.py:186-305.  Layers with a deformable block search with ``deform_radius`` instead of ``conv_radius``
+    (:219-252).  ``rotations``: "random" (draw from np.random like
     the reference), None (axis-aligned pooling grids) or a list with one [B,3,3] array per pooling layer.
     Returns dict(points, neighbors, pools, upsamples, lengths, rotations)."""
     r_normal = cfg["first_subsampling_dl"] * cfg["conv_radius"]
     layer_blocks = []
     out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], rotations=[])
     stack_lengths = np.asarray(stack_lengths, np.int32)
+    r_deform = lambda: r_normal * cfg.get("deform_radius", 6.0) / cfg["conv_radius"]
     for block in cfg["architecture"]:
-        if "deformable" in block:
-            raise NotImplementedError("deformable KPConv is out of scope")
         if not ("pool" in block or "strided" in block or "global" in block or "upsample" in block):
             layer_blocks.append(block)
             continue
         if layer_blocks:
-            conv_i = batch_neighbors(stacked_points, stacked_points, stack_lengths, stack_lengths, r_normal)
+            r = r_deform() if any("deformable" in b for b in layer_blocks) else r_normal
+            conv_i = batch_neighbors(stacked_points, stacked_points, stack_lengths, stack_lengths, r)
         else:
             conv_i = np.zeros((0, 1), np.int32)
         if "pool" in block or "strided" in block:
@@ -117,8 +118,11 @@ def segmentation_inputs(stacked_points, stack_lengths, cfg, rotations="random"):
             else:
                 R = rotations[li]
             pool_p, pool_b = batch_grid_subsampling(stacked_points, stack_lengths, dl, R)
-            pool_i = batch_neighbors(pool_p, stacked_points, pool_b, stack_lengths, r_normal)
-            up_i = batch_neighbors(stacked_points, pool_p, stack_lengths, pool_b, 2 * r_normal)
+            r_pool = r_deform() if "deformable" in block else r_normal
+            pool_i = batch_neighbors(pool_p, stacked_points, pool_b, stack_lengths, r_pool)
+            # (concat_batcher.py:262-263: `2 * r` with r as the pooling branch left it -- the deform radius after a deformable
+            #  strided block)
+            up_i = batch_neighbors(stacked_points, pool_p, stack_lengths, pool_b, 2 * r_pool)
             out["rotations"].append(R)
         else:
             pool_i = np.zeros((0, 1), np.int32)
@@ -169,6 +173,46 @@ def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
     return torch.sum(torch.matmul(wf, weights), dim=0)
 
 
+def kpconv_deformable(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, offset_weights, offset_bias,
+                      modulated=False):
+    """KPConv.forward, deformable branch, KP_influence='linear', aggregation 'sum' (kpconv.py:1011-1159): offsets from the
+    inner rigid convolution, deformed kernel points per query, the in-range pruning of the neighbour lists (:1071-1103;
+    it only drops neighbours whose influence is 0), weighted sum, optional modulations, kernel weights."""
+    K = kernel_points.shape[0]
+    off = kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, offset_weights, extent) + offset_bias
+    if modulated:
+        unscaled = off[:, :3 * K].view(-1, K, 3)
+        modulations = 2 * torch.sigmoid(off[:, 3 * K:])
+    else:
+        unscaled, modulations = off.view(-1, K, 3), None
+    offsets = unscaled * extent
+    s_pad = torch.cat((s_pts, torch.zeros_like(s_pts[:1, :]) + 1e6), 0)
+    neighbors = s_pad[neighb_inds, :] - q_pts.unsqueeze(1)
+    deformed = (offsets + kernel_points).unsqueeze(1)                       # [n, 1, K, 3]
+    sq = torch.sum((neighbors.unsqueeze(2) - deformed) ** 2, dim=3)         # [n, H, K]
+    in_range = torch.any(sq < extent ** 2, dim=2).type(torch.int32)
+    new_max = int(torch.max(torch.sum(in_range, dim=1)))
+    row_bool, row_inds = torch.topk(in_range, new_max, dim=1)
+    new_inds = neighb_inds.gather(1, row_inds)
+    sq = sq.gather(1, row_inds.unsqueeze(2).expand(-1, -1, K))
+    new_inds = new_inds * row_bool
+    new_inds = new_inds - (row_bool.type(torch.int64) - 1) * int(s_pad.shape[0] - 1)
+    w = torch.clamp(1 - torch.sqrt(sq) / extent, min=0.0).transpose(1, 2)
+    xp = torch.cat((x, torch.zeros_like(x[:1, :])), 0)
+    wf = torch.matmul(w, xp[new_inds])
+    if modulations is not None:
+        wf = wf * modulations.unsqueeze(2)
+    return torch.sum(torch.matmul(wf.permute(1, 0, 2), weights), dim=0)
+
+
+def _conv(sd, p, b, q_pts, s_pts, inds, x, cfg):
+    """The block's KPConv (rigid or deformable by the block name, kpconv.py:1321-1332)."""
+    if "deform" in b["name"]:
+        return kpconv_deformable(q_pts, s_pts, inds, x, sd[p + ".kernel_points"], sd[p + ".weights"], b["extent"],
+                                 sd[p + ".offset_conv.weights"], sd[p + ".offset_bias"], cfg.get("modulated", False))
+    return kpconv_rigid(q_pts, s_pts, inds, x, sd[p + ".kernel_points"], sd[p + ".weights"], b["extent"])
+
+
 def max_pool(x, inds):
     """kpconv.py:841-858."""
     xp = torch.cat((x, torch.zeros_like(x[:1, :])), 0)
@@ -199,12 +243,12 @@ def forward(sd, cfg, batch, features):
         s_pts = batch["points"][L]
         inds = batch["pools"][L] if strided else batch["neighbors"][L]
         if "simple" in b["name"]:
-            y = kpconv_rigid(q_pts, s_pts, inds, x, sd[p + ".KPConv.kernel_points"], sd[p + ".KPConv.weights"], b["extent"])
+            y = _conv(sd, p + ".KPConv", b, q_pts, s_pts, inds, x, cfg)
             x = F.leaky_relu(_bn_block(sd, p + ".batch_norm", y, ubn), lr)
         else:
             mid = b["out_dim"] // 4
             y = _unary(sd, p + ".unary1", x, cfg) if b["in_dim"] != mid else x
-            y = kpconv_rigid(q_pts, s_pts, inds, y, sd[p + ".KPConv.kernel_points"], sd[p + ".KPConv.weights"], b["extent"])
+            y = _conv(sd, p + ".KPConv", b, q_pts, s_pts, inds, y, cfg)
             y = F.leaky_relu(_bn_block(sd, p + ".batch_norm_conv", y, ubn), lr)
             y = _unary(sd, p + ".unary2", y, cfg, relu=False)
             sc = max_pool(x, inds) if strided else x

@@ -121,6 +121,18 @@ TORONTO3D_CFG = dict(   # ml3d/configs/kpconv_toronto3d.yml:23-82 (inference-rel
     num_classes=8, num_kernel_points=15, num_layers=5, use_batch_norm=True, reduce_fc=True, l_relu=0.2)
 
 
+# a three-layer architecture with the deformable blocks of kpconv_parislille3d.yml:28-32 (deformable KPConv 32 -> 32 at a
+# full and a strided block, 64 -> 64 on the coarsest layer); deform_radius below the YAML's 6.0 keeps the test batches small
+KPCONV_DEFORM_SMALL_CFG = dict(
+    KP_extent=1.2, KP_influence="linear", aggregation_mode="sum",
+    architecture=["simple", "resnetb", "resnetb_strided", "resnetb_deformable", "resnetb_deformable_strided",
+                  "resnetb_deformable", "nearest_upsample", "unary", "nearest_upsample", "unary"],
+    batch_limit=10000, batch_norm_momentum=0.98, conv_radius=2.5, deform_radius=5.0, first_features_dim=64,
+    first_subsampling_dl=0.08, fixed_kernel_points="center", in_features_dim=1, in_points_dim=3, in_radius=2.0,
+    lbl_values=[0, 1, 2, 3, 4, 5], ignored_label_inds=[0], max_in_points=10000, modulated=False,
+    num_classes=5, num_kernel_points=15, num_layers=3, use_batch_norm=True, reduce_fc=False, l_relu=0.1)
+
+
 # ---------------------------------------------------------------------------------------------------
 # architecture walk (kpconv.py:131-236) -> flat list of block descriptors
 # ---------------------------------------------------------------------------------------------------
@@ -209,20 +221,27 @@ def kpconv_state_dict(cfg, seed):
         else:
             sd[prefix + ".batch_norm.bias"] = rnd(cout, scale=0.3)
 
-    def kpconv(prefix, cin, cout, radius):
+    def kpconv(prefix, cin, cout, radius, deformable=False):
         sd[prefix + ".weights"] = rnd(K, cin, cout, scale=(3.0 / (cin * 4.0)) ** 0.5)
         sd[prefix + ".kernel_points"] = torch.from_numpy(synthetic_kernel_points(radius, K))
+        if deformable:
+            # kpconv.py:948-965: an inner rigid KPConv cin -> 3 K (+ K modulations) and a bias; `kernel_points` IS the inner
+            # convolution's parameter (kpconv.py:977-978: both names in the state dict).  Offsets of a few tenths of the extent.
+            od = (4 if cfg.get("modulated", False) else 3) * K
+            sd[prefix + ".offset_conv.weights"] = rnd(K, cin, od, scale=0.35 * (3.0 / (cin * 4.0)) ** 0.5)
+            sd[prefix + ".offset_conv.kernel_points"] = sd[prefix + ".kernel_points"].clone()
+            sd[prefix + ".offset_bias"] = rnd(od, scale=0.1)
 
     for i, b in enumerate(plan["encoder"]):
         p = "encoder_blocks.%d" % i
         if "simple" in b["name"]:
-            kpconv(p + ".KPConv", b["in_dim"], b["out_dim"] // 2, b["radius"])
+            kpconv(p + ".KPConv", b["in_dim"], b["out_dim"] // 2, b["radius"], "deform" in b["name"])
             bn(p + ".batch_norm", b["out_dim"] // 2)
         elif "resnetb" in b["name"]:
             mid = b["out_dim"] // 4
             if b["in_dim"] != mid:
                 unary(p + ".unary1", b["in_dim"], mid)
-            kpconv(p + ".KPConv", mid, mid, b["radius"])
+            kpconv(p + ".KPConv", mid, mid, b["radius"], "deform" in b["name"])
             bn(p + ".batch_norm_conv", mid)
             unary(p + ".unary2", mid, b["out_dim"])
             if b["in_dim"] != b["out_dim"]:
