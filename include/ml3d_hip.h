@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 3
+#define ML3D_ABI_VERSION 4
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -227,6 +227,23 @@ int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* nei
                       int num_kernel_points, float kp_extent, int kp_influence_mode,
                       const float* weights, const float* bias, int act, float slope, int cout,
                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ml3d_kpconv_deformable replaces the deformable branch of KPConv.forward                      */
+/*   (kpconv.py:1011-1066, 1139-1159) once the inner convolution has run: offset_features        */
+/*   [Nq, offset_dim] = offset_conv(q, s, idx, x) + offset_bias (one ml3d_kpconv_rigid call with */
+/*   the inner weights, act 0); offset_dim = 45 (3 per kernel point, in units of KP_extent) or   */
+/*   60 (+ 15 modulation logits, modulations = 2 sigmoid).  Kernel point k of query q sits at    */
+/*   kernel_points[k] + offsets[q, k] * kp_extent; everything else as ml3d_kpconv_rigid, same    */
+/*   workspace.  The neighbour pruning of kpconv.py:1071-1103 only removes neighbours whose      */
+/*   LINEAR influence is zero, so it is not performed; kp_influence_mode != 1 (linear) and cin   */
+/*   outside {16, 32, 64, 128, 256} return ML3D_E_UNSUPPORTED.                                   */
+int ml3d_kpconv_deformable(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                           int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                           const float* features, int cin, const float* kernel_points,
+                           int num_kernel_points, float kp_extent, int kp_influence_mode,
+                           const float* offset_features, int offset_dim, const float* weights,
+                           const float* bias, int act, float slope, int cout, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ml3d_linear: out = act([gather(a) | a2] @ weights_t + bias + residual) on f32 MFMA.       */
 /* Replaces UnaryBlock (Linear + BatchNormBlock + LeakyReLU, kpconv.py:1288-1293), the       */

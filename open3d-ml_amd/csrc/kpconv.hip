@@ -41,6 +41,9 @@ struct KpArgs {
     float inv_extent; int influence;   // 0 constant, 1 linear, 2 gaussian (sigma = 0.3 * extent)
     float gauss_den;              // 2 * sigma^2 + eps
     float* wf;                    // [nq, 15 * cin]
+    // deformable KPConv (kpconv.py:1011-1066): the inner convolution's output per query, [nq, off_dim]: 15 x 3 offsets in
+    // units of the extent (+ 15 modulation logits when off_dim = 60); null = rigid
+    const float* off; int off_dim; float extent;
 };
 
 __device__ __forceinline__ float kp_influence(float d2, const KpArgs& A) {
@@ -209,7 +212,7 @@ __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int i
     }
 }
 
-template <int NT, int MODE>
+template <int NT, int MODE, bool DEF = false>
 __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
     constexpr int CIN = 16 * NT;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -243,46 +246,77 @@ __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
         if (q >= A.nq) break;
         int ia = lane < A.h ? ia_n : -1, ib = 64 + lane < A.h ? ib_n : -1;
         const float qx = qx_n, qy = qy_n, qz = qz_n;
+        const int32_t* row_cur = A.inds + q * A.h;
         request(t + stride);
-        if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
-        if (ib < 0 || ib >= A.ns) ib = -1;
-        const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
-        const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
-        const int groups = (count + 3) >> 2;
+        // DEF: this query's kernel points = the layer's + its offsets (lane k owns point k; the 16 lanes j of a point agree)
+        float kxq = kx, kyq = ky, kzq = kz, modq = 1.0f;
+        if constexpr (DEF) {
+            if (kreal) {
+                const float* o = A.off + q * (int64_t)A.off_dim;
+                kxq = fmaf(o[3 * k], A.extent, kx); kyq = fmaf(o[3 * k + 1], A.extent, ky); kzq = fmaf(o[3 * k + 2], A.extent, kz);
+                if (A.off_dim > 3 * KP_K) modq = 2.0f / (1.0f + expf(-o[3 * KP_K + k]));      // 2 sigmoid (kpconv.py:1023-1024)
+            }
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // this lane's column of group g (wave-uniform choice of the index register: g is uniform); -1 past the last group
-        auto column = [&](int g) -> int {
-            const int c = 4 * g + j;
-            const int v = __shfl(c < 64 ? ia : ib, c & 63);
-            return g < groups ? v : -1;
-        };
-        auto consume = [&](const KpRow<NT>& r) {
-            const float nx = r.sx - qx, ny = r.sy - qy, nz = r.sz - qz;
-            float w = kp_influence1<MODE>(nx - kx, ny - ky, nz - kz, A);
-            const bool real = r.idx >= 0;
-            w = (kreal && real) ? w : 0.f;
+        // rows wider than 128 columns (the deformable layers search with deform_radius) are walked 128 columns at a time; the
+        // first block's indices were requested under the previous query, later blocks are read here
+        for (int cb = 0; cb < A.h; cb += 128) {
+            if (cb > 0) {
+                ia = cb + lane < A.h ? row_cur[cb + lane] : -1;
+                ib = cb + 64 + lane < A.h ? row_cur[cb + 64 + lane] : -1;
+            }
+            if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
+            if (ib < 0 || ib >= A.ns) ib = -1;
+            const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
+            const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
+            const int groups = (count + 3) >> 2;
+            // this lane's column of group g (wave-uniform choice of the index register: g is uniform); -1 past the last group
+            auto column = [&](int g) -> int {
+                const int c = 4 * g + j;
+                const int v = __shfl(c < 64 ? ia : ib, c & 63);
+                return g < groups ? v : -1;
+            };
+            auto consume = [&](const KpRow<NT>& r) {
+                const float nx = r.sx - qx, ny = r.sy - qy, nz = r.sz - qz;
+                float w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
+                const bool real = r.idx >= 0;
+                w = (kreal && real) ? w : 0.f;
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
-        };
-        // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is consumed (a
-        // rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
-        KpRow<NT> ra, rb;
-        kp_row_load<NT>(ra, A, column(0), k);
-        for (int g = 0; g < groups; g += 2) {
-            // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for all four before the first
-            //  MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the younger is in flight)
-            kp_row_load<NT>(rb, A, column(g + 1), k);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(ra);
-            __builtin_amdgcn_sched_barrier(0);
-            kp_row_load<NT>(ra, A, column(g + 2), k);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(rb);                  // (unconditional: past the last group the column is -1, a zero MFMA -- under an `if` the
-                                          //  compiler sinks rb's loads into the branch, right in front of their use)
-            __builtin_amdgcn_sched_barrier(0);
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
+            };
+            // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is
+            // consumed (a rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
+            KpRow<NT> ra, rb;
+            kp_row_load<NT>(ra, A, column(0), k);
+            for (int g = 0; g < groups; g += 2) {
+                // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for all four before the
+                //  first MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the
+                //  younger is in flight)
+                kp_row_load<NT>(rb, A, column(g + 1), k);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(ra);
+                __builtin_amdgcn_sched_barrier(0);
+                kp_row_load<NT>(ra, A, column(g + 2), k);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(rb);              // (unconditional: past the last group the column is -1, a zero MFMA -- under an `if`
+                                          //  the compiler sinks rb's loads into the branch, right in front of their use)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (DEF) {
+            // modulations scale kernel point kk's row of the weighted features (kpconv.py:1147-1149); this lane stores rows
+            // 4 j .. 4 j + 3, lane kk holds modulation kk
+            if (A.off_dim > 3 * KP_K) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = __shfl(modq, 4 * j + r);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n][r] *= m;
+                }
+            }
         }
         // D: lane (column k, j) holds kernel points 4 j .. 4 j + 3 of channels k NT .. k NT + NT - 1
         float* o = A.wf + q * (int64_t)(KP_K * CIN) + k * NT;
@@ -752,17 +786,18 @@ template <int NT>
 static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
     int64_t nb = ((a.nq + 3) / 4 + 7) / 8 * 8;                    // four queries (waves) per workgroup, a multiple of 8 workgroups
     if (nb > 256 * 8) nb = 256 * 8;
+    if (a.off) { hipLaunchKernelGGL((kp_agg_mfma<NT, 1, true>), dim3((unsigned)nb), dim3(256), 0, st, a); return; }   // (linear only)
     if (a.influence == 0) hipLaunchKernelGGL((kp_agg_mfma<NT, 0>), dim3((unsigned)nb), dim3(256), 0, st, a);
     else if (a.influence == 1) hipLaunchKernelGGL((kp_agg_mfma<NT, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((kp_agg_mfma<NT, 2>), dim3((unsigned)nb), dim3(256), 0, st, a);
 }
 
-// the MFMA aggregation takes cin in {16, 32, 64, 128, 256}, rows of up to 128 columns, 16-byte aligned features / wf
+// the MFMA aggregation takes cin in {16, 32, 64, 128, 256} and 16-byte aligned features / wf
 // (ML3D_KP_AGG_MFMA=0, read once: the packed-FMA kernels for A/B runs)
 static bool agg_mfma_ok(const KpArgs& a) {
     static const bool on = [] { const char* e = getenv("ML3D_KP_AGG_MFMA"); return !(e && e[0] == '0'); }();
     const int c = a.cin;
-    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h > 0 && a.h <= 128 && a.ns > 0 && a.nq > 0 &&
+    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h > 0 && a.ns > 0 && a.nq > 0 &&
            ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
 }
 
@@ -807,11 +842,11 @@ extern "C" size_t ml3d_kpconv_workspace_bytes(int64_t n_queries, int cin, int co
     return b + 512;
 }
 
-extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
-                                 int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
-                                 const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
-                                 const float* weights, const float* bias, int act, float slope, int cout, float* out,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                      int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                      const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
+                      const float* offset_features, int offset_dim, const float* weights, const float* bias, int act,
+                      float slope, int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (n_queries < 0 || n_supports < 0 || max_neighbors < 0 || cin <= 0 || cout <= 0 || !(kp_extent > 0.f) ||
         kp_influence_mode < 0 || kp_influence_mode > 2 || max_neighbors > 0x7fffffff)
         return ML3D_E_INVALID;
@@ -831,8 +866,13 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
     const float sigma = kp_extent * 0.3f;                       // kpconv.py:1122-1125 + radius_gaussian eps
     a.gauss_den = 2.0f * sigma * sigma + 1e-9f;
     a.wf = wf;
+    a.off = offset_features; a.off_dim = offset_dim; a.extent = kp_extent;
     const KpOut ko = {weights, bias, act, slope, cout, out};
-    if (max_neighbors > 0 && small_fused_ok(a, ko)) {
+    if (offset_features) {
+        // the deformed kernel points live in the MFMA aggregation only; the neighbour pruning of kpconv.py:1071-1103 drops
+        // neighbours whose LINEAR influence is zero anyway -- with another influence function it would change the sum
+        if (kp_influence_mode != 1 || !agg_mfma_ok(a)) return ML3D_E_UNSUPPORTED;
+    } else if (max_neighbors > 0 && small_fused_ok(a, ko)) {
         switch (cin) {
             case 1: launch_small_fused<1>(a, ko, st); break;
             case 2: launch_small_fused<2>(a, ko, st); break;
@@ -841,8 +881,7 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
             default: launch_small_fused<5>(a, ko, st); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-    }
-    if (fused32_ok(a, ko)) {
+    } else if (fused32_ok(a, ko)) {
         launch_fused32(a, ko, st);
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
@@ -856,6 +895,29 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
     Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
     return gemm_rows(A, weights, n_queries, cout, KP_K * cin, ep, out, cout, p,
                      gemm_partial_bytes(n_queries, cout, KP_K * cin), st);
+}
+
+extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                 int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                 const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
+                                 const float* weights, const float* bias, int act, float slope, int cout, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    return kpconv_run(q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, kernel_points,
+                      num_kernel_points, kp_extent, kp_influence_mode, nullptr, 0, weights, bias, act, slope, cout, out,
+                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int ml3d_kpconv_deformable(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                                      int64_t n_queries, int64_t n_supports, int64_t max_neighbors, const float* features,
+                                      int cin, const float* kernel_points, int num_kernel_points, float kp_extent,
+                                      int kp_influence_mode, const float* offset_features, int offset_dim,
+                                      const float* weights, const float* bias, int act, float slope, int cout, float* out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!offset_features || (offset_dim != 3 * KP_K && offset_dim != 4 * KP_K)) return ML3D_E_INVALID;
+    if (max_neighbors <= 0) return ML3D_E_INVALID;
+    return kpconv_run(q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, kernel_points,
+                      num_kernel_points, kp_extent, kp_influence_mode, offset_features, offset_dim, weights, bias, act, slope,
+                      cout, out, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t ml3d_linear_workspace_bytes(int64_t m, int n, int k) {

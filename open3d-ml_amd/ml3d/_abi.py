@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 3          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 4          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -37,7 +37,7 @@ SYMBOLS = [
     "ml3d_subsample_fill",
     "ml3d_rotate_points",
     "ml3d_kpconv_workspace_bytes",
-    "ml3d_kpconv_rigid",
+    "ml3d_kpconv_rigid", "ml3d_kpconv_deformable",
     "ml3d_linear_workspace_bytes",
     "ml3d_linear",
     "ml3d_gather_pool",
@@ -133,6 +133,9 @@ def bind(lib):
     lib.ml3d_kpconv_rigid.restype = C.c_int
     lib.ml3d_kpconv_rigid.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, vp, i32, f32, i32, vp,
                                       vp, sz, vp]
+    lib.ml3d_kpconv_deformable.restype = C.c_int
+    lib.ml3d_kpconv_deformable.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, i32, vp, vp, i32, f32,
+                                           i32, vp, vp, sz, vp]
     lib.ml3d_linear_workspace_bytes.restype = sz
     lib.ml3d_linear_workspace_bytes.argtypes = [i64, i32, i32]
     lib.ml3d_linear.restype = C.c_int

@@ -21,9 +21,11 @@ def _ws(nbytes, device):
     return _gates._ws(nbytes, device)
 
 def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias, extent, act=1, slope=0.1,
-                 influence=1):
+                 influence=1, offset_features=None):
     """KPConv rigid aggregation + folded BN + activation (kpconv.py:1048-1159, 1357-1358).
-    weights_kc_o: [15 * cin, cout] (BN-folded), neighb_inds int32 [Nq, H] with shadow index Ns."""
+    weights_kc_o: [15 * cin, cout] (BN-folded), neighb_inds int32 [Nq, H] with shadow index Ns.
+    ``offset_features`` [Nq, 45 | 60]: the DEFORMABLE convolution (kpconv.py:1011-1066) -- kernel point k of query q at
+    ``kernel_points[k] + offset_features[q, 3k:3k+3] * extent``, columns 45.. = modulation logits (see ``kpconv_deformable``)."""
     lib = _abi.get()
     _need_gpu(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o)
     dev = x.device
@@ -44,6 +46,19 @@ def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias
     if wsb == 0:
         raise RuntimeError("kpconv_rigid: unsupported configuration (15 kernel points, cin <= 512)")
     ws = _ws(wsb, dev)
+    if offset_features is not None:
+        _need_gpu(offset_features)
+        if offset_features.dtype != torch.float32 or not offset_features.is_contiguous() or offset_features.dim() != 2 or \
+                offset_features.shape[0] != nq or offset_features.shape[1] not in (3 * K, 4 * K):
+            raise RuntimeError("kpconv_deformable: offset_features must be contiguous float32 [Nq, 3K] or [Nq, 4K]")
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_kpconv_deformable(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H,
+                                            x.data_ptr(), cin, kernel_points.data_ptr(), K, float(extent), int(influence),
+                                            offset_features.data_ptr(), int(offset_features.shape[1]),
+                                            weights_kc_o.data_ptr(), None if bias is None else bias.data_ptr(), int(act),
+                                            float(slope), cout, out.data_ptr(), ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_kpconv_deformable")
+        return out
     with torch.cuda.device(dev):
         rc = lib.ml3d_kpconv_rigid(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, x.data_ptr(),
                                    cin, kernel_points.data_ptr(), K, float(extent), int(influence),
@@ -51,6 +66,17 @@ def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias
                                    float(slope), cout, out.data_ptr(), ws.data_ptr(), wsb, _stream())
     _abi.check(rc, "ml3d_kpconv_rigid")
     return out
+
+
+def kpconv_deformable(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias, extent, offset_weights_kc_o,
+                      offset_bias, act=1, slope=0.1, influence=1):
+    """The deformable KPConv of ``resnetb_deformable`` / ``simple_deformable`` blocks (kpconv.py:1011-1159): the inner rigid
+    convolution cin -> 3K (+K modulated) gives each query its kernel-point offsets (``offset_weights_kc_o`` [15 * cin, 45 | 60],
+    ``offset_bias``), then the convolution itself runs with the query's own kernel points.  ``KP_influence: linear`` only."""
+    off = kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, offset_weights_kc_o, offset_bias, extent, act=0,
+                       influence=influence)
+    return kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias, extent, act=act, slope=slope,
+                        influence=influence, offset_features=off)
 
 
 def linear(a, weights_t, bias=None, a2=None, gather=None, residual=None, act=0, slope=0.0, residual_gather=None):

@@ -236,7 +236,7 @@ def subsample_batch(points, lengths, dl, features=None, labels=None):
     return op, lens, of, ol
 
 
-def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1):
+def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1, offset_features=None):
     L = lib()
     q_pts, s_pts, x = (np.ascontiguousarray(a, np.float32) for a in (q_pts, s_pts, x))
     inds = np.ascontiguousarray(inds, np.int32)
@@ -248,6 +248,13 @@ def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, s
     out = np.zeros((nq, cout), np.float32)
     wsb = L.ml3d_kpconv_workspace_bytes(nq, cin, cout, K)
     ws = _ws(wsb)
+    if offset_features is not None:
+        off = np.ascontiguousarray(offset_features, np.float32)
+        rc = L.ml3d_kpconv_deformable(q_pts.ctypes.data, s_pts.ctypes.data, inds.ctypes.data, nq, len(s_pts), H,
+                                      x.ctypes.data, cin, kp.ctypes.data, K, extent, influence, off.ctypes.data,
+                                      off.shape[1], w.ctypes.data, None if b is None else b.ctypes.data, act, slope, cout,
+                                      out.ctypes.data, ws.ctypes.data, wsb, None)
+        return rc, out
     rc = L.ml3d_kpconv_rigid(q_pts.ctypes.data, s_pts.ctypes.data, inds.ctypes.data, nq, len(s_pts), H, x.ctypes.data,
                              cin, kp.ctypes.data, K, extent, influence, w.ctypes.data,
                              None if b is None else b.ctypes.data, act, slope, cout, out.ctypes.data, ws.ctypes.data, wsb,

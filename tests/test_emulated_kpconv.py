@@ -72,6 +72,41 @@ def test_kpconv_mfma_aggregation_rows_wider_than_64_shadows_anywhere(cin, n, r):
     assert rc == 0 and np.abs(out - ref).max() <= TOL * max(1.0, np.abs(ref).max()) and (out[-1] == 0).all()
 
 
+@pytest.mark.parametrize("cin,n,r,modulated", [(32, 1500, 0.3, False), (64, 900, 0.55, False), (16, 700, 0.3, True),
+                                                 (128, 500, 0.3, True)])
+def test_kpconv_deformable_matches_the_reference_formulation(cin, n, r, modulated):
+    """``ml3d_kpconv_deformable`` (kpconv.py:1011-1159): the inner rigid convolution's output moves each query's kernel points,
+    optional modulations scale the weighted features.  Against the oracle's restatement of the reference branch INCLUDING its
+    in-range pruning and top-k reordering of the neighbour lists (which only drops zero-influence neighbours).  The 0.55 m case
+    has rows wider than 128 columns (walked 128 at a time); strided queries, a query with only shadow neighbours."""
+    rng = np.random.default_rng(cin + 7)
+    s = synth_data.toronto3d_sphere(22, n)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.1)[0], [[50, 50, 50]]]).astype(np.float32)
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], r)
+    assert (inds.shape[1] > 128) == (r > 0.5)
+    x = rng.standard_normal((len(s), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    od = 60 if modulated else 45
+    w = (rng.standard_normal((15, cin, 32)) * (0.5 / np.sqrt(cin))).astype(np.float32)
+    ow = (rng.standard_normal((15, cin, od)) * (0.12 / np.sqrt(cin))).astype(np.float32)
+    ob = (rng.standard_normal(od) * 0.1).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    rc, off = emu.kpconv_rigid(q, s, inds, x, kp, ow, 0.08, bias=ob)                     # the inner convolution
+    assert rc == 0
+    rc, out = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08, bias=b, act=1, slope=0.1, offset_features=off)
+    assert rc == 0
+    t = torch.from_numpy
+    ref = K.kpconv_deformable(t(q), t(s), t(inds).long(), t(x), t(kp), t(w), 0.08, t(ow), t(ob), modulated)
+    ref = torch.nn.functional.leaky_relu(ref + t(b), 0.1).numpy()
+    assert np.abs(out - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    # the offsets really move the result (a rigid run differs)
+    rc, rigid = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08, bias=b, act=1, slope=0.1)
+    assert np.abs(rigid - ref).max() > 100 * TOL
+    # unsupported corners say so
+    rc, _ = emu.kpconv_rigid(q, s, inds, x, kp, w, 0.08, influence=2, offset_features=off)
+    assert rc == emu._abi.E_UNSUPPORTED if hasattr(emu._abi, "E_UNSUPPORTED") else rc != 0
+
+
 _FUSED32_CASE = r"""
 import os, sys
 ROOT = %(root)r
