@@ -236,7 +236,7 @@ int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* nei
 /*   kernel_points[k] + offsets[q, k] * kp_extent; everything else as ml3d_kpconv_rigid, same    */
 /*   workspace.  The neighbour pruning of kpconv.py:1071-1103 only removes neighbours whose      */
 /*   LINEAR influence is zero, so it is not performed; kp_influence_mode != 1 (linear) and cin   */
-/*   outside {16, 32, 64, 128, 256} return ML3D_E_UNSUPPORTED.                                   */
+/*   outside {16, 32, 64, 128, 256, 512} return ML3D_E_UNSUPPORTED.                              */
 int ml3d_kpconv_deformable(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
                            int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
                            const float* features, int cin, const float* kernel_points,

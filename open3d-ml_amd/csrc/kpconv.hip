@@ -44,6 +44,9 @@ struct KpArgs {
     // deformable KPConv (kpconv.py:1011-1066): the inner convolution's output per query, [nq, off_dim]: 15 x 3 offsets in
     // units of the extent (+ 15 modulation logits when off_dim = 60); null = rigid
     const float* off; int off_dim; float extent;
+    // kp_agg_mfma works on a SLICE of 16 NT channels starting at c_off of rows that are c_total floats wide (cin = 512 runs
+    // as two slices of 256); c_total = cin, c_off = 0 otherwise
+    int c_total, c_off;
 };
 
 __device__ __forceinline__ float kp_influence(float d2, const KpArgs& A) {
@@ -200,7 +203,7 @@ __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int i
     const int64_t i = idx < 0 ? 0 : idx;
     const float* sp = A.s_pts + 3 * i;
     r.sx = sp[0]; r.sy = sp[1]; r.sz = sp[2];
-    const float* xr = A.x + i * (16 * NT) + k * NT;
+    const float* xr = A.x + i * A.c_total + A.c_off + k * NT;
     if constexpr (NT == 1) r.xv[0] = xr[0];
     else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(xr); r.xv[0] = v.x; r.xv[1] = v.y; }
     else {
@@ -214,7 +217,6 @@ __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int i
 
 template <int NT, int MODE, bool DEF = false>
 __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
-    constexpr int CIN = 16 * NT;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane & 15, j = lane >> 4;
@@ -319,12 +321,12 @@ __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
             }
         }
         // D: lane (column k, j) holds kernel points 4 j .. 4 j + 3 of channels k NT .. k NT + NT - 1
-        float* o = A.wf + q * (int64_t)(KP_K * CIN) + k * NT;
+        float* o = A.wf + q * (int64_t)(KP_K * A.c_total) + A.c_off + k * NT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kk = 4 * j + r;
             if (kk < KP_K) {
-                float* dst = o + kk * CIN;
+                float* dst = o + kk * A.c_total;
                 if constexpr (NT == 1) dst[0] = acc[0][r];
                 else if constexpr (NT == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0][r], acc[1][r]);
                 else {
@@ -797,7 +799,8 @@ static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
 static bool agg_mfma_ok(const KpArgs& a) {
     static const bool on = [] { const char* e = getenv("ML3D_KP_AGG_MFMA"); return !(e && e[0] == '0'); }();
     const int c = a.cin;
-    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256) && a.h > 0 && a.ns > 0 && a.nq > 0 &&
+    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256 || (c == 512 && a.off)) && a.h > 0 && a.ns > 0 &&
+           a.nq > 0 &&
            ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
 }
 
@@ -809,7 +812,14 @@ static int launch_weighted(const KpArgs& a, hipStream_t st) {
             case 32: launch_agg_mfma<2>(a, st); break;
             case 64: launch_agg_mfma<4>(a, st); break;
             case 128: launch_agg_mfma<8>(a, st); break;
-            default: launch_agg_mfma<16>(a, st); break;
+            case 256: launch_agg_mfma<16>(a, st); break;
+            default: {                      // 512 (deformable only: the rigid form has kp_weighted<64, 8>): two slices of 256
+                KpArgs h = a;
+                launch_agg_mfma<16>(h, st);
+                h.c_off = 256;
+                launch_agg_mfma<16>(h, st);
+                break;
+            }
         }
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
@@ -867,6 +877,7 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
     a.gauss_den = 2.0f * sigma * sigma + 1e-9f;
     a.wf = wf;
     a.off = offset_features; a.off_dim = offset_dim; a.extent = kp_extent;
+    a.c_total = cin; a.c_off = 0;
     const KpOut ko = {weights, bias, act, slope, cout, out};
     if (offset_features) {
         // the deformed kernel points live in the MFMA aggregation only; the neighbour pruning of kpconv.py:1071-1103 drops

@@ -29,14 +29,24 @@ class _Cfg(dict):
 
 # ---- parameter holders (names follow the reference classes) -----------------------------------------
 class KPConv(nn.Module):
-    """kpconv.py:891-1003: ``weights`` [K, cin, cout], ``kernel_points`` [K, 3] (not trained)."""
+    """kpconv.py:891-1003: ``weights`` [K, cin, cout], ``kernel_points`` [K, 3] (not trained).  ``deformable``: the inner rigid
+    convolution ``offset_conv`` (cin -> 3 K, + K when ``modulated``) and ``offset_bias``; ``kernel_points`` IS the inner
+    convolution's parameter (kpconv.py:948-978: both names appear in the state dict)."""
 
-    def __init__(self, kernel_size, in_channels, out_channels, KP_extent, radius):
+    def __init__(self, kernel_size, in_channels, out_channels, KP_extent, radius, deformable=False, modulated=False):
         super().__init__()
         self.K, self.in_channels, self.out_channels = kernel_size, in_channels, out_channels
         self.KP_extent, self.radius = KP_extent, radius
+        self.deformable, self.modulated = bool(deformable), bool(modulated)
         self.weights = nn.Parameter(torch.zeros((kernel_size, in_channels, out_channels), dtype=torch.float32))
-        self.kernel_points = nn.Parameter(default_kernel_points(radius, kernel_size), requires_grad=False)
+        if self.deformable:
+            self.offset_dim = (4 if self.modulated else 3) * kernel_size
+            self.offset_conv = KPConv(kernel_size, in_channels, self.offset_dim, KP_extent, radius)
+            self.offset_bias = nn.Parameter(torch.zeros(self.offset_dim, dtype=torch.float32))
+            self.kernel_points = self.offset_conv.kernel_points
+        else:
+            self.offset_dim, self.offset_conv, self.offset_bias = None, None, None
+            self.kernel_points = nn.Parameter(default_kernel_points(radius, kernel_size), requires_grad=False)
         nn.init.kaiming_uniform_(self.weights, a=5 ** 0.5)
 
 
@@ -69,7 +79,8 @@ class SimpleBlock(nn.Module):
         super().__init__()
         self.block_name, self.layer_ind = block_name, layer_ind
         extent = radius * cfg.KP_extent / cfg.conv_radius
-        self.KPConv = KPConv(cfg.num_kernel_points, in_dim, out_dim // 2, extent, radius)
+        self.KPConv = KPConv(cfg.num_kernel_points, in_dim, out_dim // 2, extent, radius,
+                             deformable='deform' in block_name, modulated=cfg.get('modulated', False))
         self.batch_norm = BatchNormBlock(out_dim // 2, cfg.use_batch_norm, cfg.batch_norm_momentum)
 
 
@@ -83,7 +94,8 @@ class ResnetBottleneckBlock(nn.Module):
         bn, mom, lr = cfg.use_batch_norm, cfg.batch_norm_momentum, cfg.get('l_relu', 0.1)
         mid = out_dim // 4
         self.unary1 = UnaryBlock(in_dim, mid, bn, mom, l_relu=lr) if in_dim != mid else nn.Identity()
-        self.KPConv = KPConv(cfg.num_kernel_points, mid, mid, extent, radius)
+        self.KPConv = KPConv(cfg.num_kernel_points, mid, mid, extent, radius,
+                             deformable='deform' in block_name, modulated=cfg.get('modulated', False))
         self.batch_norm_conv = BatchNormBlock(mid, bn, mom)
         self.unary2 = UnaryBlock(mid, out_dim, bn, mom, no_relu=True, l_relu=lr)
         self.unary_shortcut = UnaryBlock(in_dim, out_dim, bn, mom, no_relu=True, l_relu=lr) \
@@ -112,17 +124,26 @@ def default_kernel_points(radius, K=15):
     return torch.from_numpy((np.asarray(pts) * radius).astype(np.float32))
 
 
+_DEFORMABLE_CIN = (16, 32, 64, 128, 256, 512)     # input widths ml3d_kpconv_deformable takes (the MFMA aggregation)
+
+
 def _block_decider(block_name, radius, in_dim, out_dim, layer_ind, cfg):
-    """kpconv.py:1171-1210, rigid subset."""
-    if 'deformable' in block_name or 'equivariant' in block_name or 'invariant' in block_name:
-        raise NotImplementedError("KPFCNN (MI355X build): block '%s' is outside the rigid-KPConv scope.  With an Open3D-ML "
-                                  "checkout (OPEN3D_ML_ROOT) the `open3d.ml.torch` registry falls back to the checkout's "
-                                  "PyTorch KPFCNN for such configs; standalone there is no implementation" % block_name)
+    """kpconv.py:1171-1210: rigid and deformable blocks (the equivariant / invariant names of the reference's decider have
+    no implementation there either)."""
+    if 'equivariant' in block_name or 'invariant' in block_name:
+        raise NotImplementedError("KPFCNN (MI355X build): block '%s' has no implementation" % block_name)
+    if 'deformable' in block_name:
+        cin = in_dim if 'simple' in block_name else out_dim // 4
+        if cfg.KP_influence != 'linear' or cin not in _DEFORMABLE_CIN:
+            raise NotImplementedError("KPFCNN (MI355X build): deformable block '%s' needs KP_influence='linear' and a KPConv "
+                                      "input width in %s (got %s, %d).  With an Open3D-ML checkout (OPEN3D_ML_ROOT) the "
+                                      "`open3d.ml.torch` registry falls back to the checkout's PyTorch KPFCNN for such "
+                                      "configs" % (block_name, list(_DEFORMABLE_CIN), cfg.KP_influence, cin))
     if block_name == 'unary':
         return UnaryBlock(in_dim, out_dim, cfg.use_batch_norm, cfg.batch_norm_momentum, l_relu=cfg.get('l_relu', 0.1))
-    if block_name in ('simple', 'simple_strided'):
+    if block_name in ('simple', 'simple_strided', 'simple_deformable', 'simple_deformable_strided'):
         return SimpleBlock(block_name, in_dim, out_dim, radius, layer_ind, cfg)
-    if block_name in ('resnetb', 'resnetb_strided'):
+    if block_name in ('resnetb', 'resnetb_strided', 'resnetb_deformable', 'resnetb_deformable_strided'):
         return ResnetBottleneckBlock(block_name, in_dim, out_dim, radius, layer_ind, cfg)
     if block_name == 'nearest_upsample':
         return NearestUpsampleBlock(layer_ind)
@@ -243,9 +264,14 @@ class KPFCNN(nn.Module):
     def _pack_conv(self, conv, bnb, dev):
         s, t = self._bn_affine(bnb, conv.out_channels)
         w = conv.weights.detach().double().cpu() * s[None, None, :]
-        return dict(w=w.reshape(conv.K * conv.in_channels, conv.out_channels).float().contiguous().to(dev),
-                    b=t.float().to(dev), kp=conv.kernel_points.detach().float().contiguous().to(dev),
-                    extent=float(conv.KP_extent))
+        d = dict(w=w.reshape(conv.K * conv.in_channels, conv.out_channels).float().contiguous().to(dev),
+                 b=t.float().to(dev), kp=conv.kernel_points.detach().float().contiguous().to(dev),
+                 extent=float(conv.KP_extent), ow=None, ob=None)
+        if conv.deformable:        # the inner convolution: no batch norm, its bias is offset_bias (kpconv.py:1014-1016)
+            d['ow'] = conv.offset_conv.weights.detach().float().reshape(conv.K * conv.in_channels, conv.offset_dim) \
+                .contiguous().to(dev)
+            d['ob'] = conv.offset_bias.detach().float().contiguous().to(dev)
+        return d
 
     def packed_params(self, dev):
         if self._packed is None or self._packed[0] != dev:
@@ -318,11 +344,15 @@ class KPFCNN(nn.Module):
             q_pts = pts[L + 1] if strided else pts[L]
             inds = pools[L] if strided else nbrs[L]
             c = p['conv']
+            conv = (lambda xin: ops.kpconv_rigid(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)) \
+                if c['ow'] is None else \
+                (lambda xin: ops.kpconv_deformable(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], c['ow'],
+                                                   c['ob'], 1, lr, infl))
             if isinstance(blk, SimpleBlock):
-                x = ops.kpconv_rigid(q_pts, pts[L], inds, x, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)
+                x = conv(x)
             else:
                 y = x if p['u1'] is None else self._unary(p['u1'], x)
-                y = ops.kpconv_rigid(q_pts, pts[L], inds, y, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)
+                y = conv(y)
                 sc = ops.gather_pool(x, inds, 'max') if strided else x
                 if p['u2sc'] is not None:
                     x = self._unary(p['u2sc'], y, a2=sc, act=1, slope=lr)
@@ -548,15 +578,17 @@ class KPConvBatch:
         r_normal = cfg['first_subsampling_dl'] * cfg['conv_radius']
         layer_blocks = []
         e_i = torch.empty((0, 1), dtype=torch.int32, device=dev)
+        deform = cfg.get('deform_radius', 6.0) / cfg['conv_radius']
         for block in cfg['architecture']:
-            if 'deformable' in block:
-                raise NotImplementedError("KPConvBatch (MI355X build): deformable layers are outside the rigid scope")
             if not ('pool' in block or 'strided' in block or 'global' in block or 'upsample' in block):
                 layer_blocks.append(block)
                 continue
+            # layers with a deformable block search with deform_radius instead of conv_radius (concat_batcher.py:219-252)
+            r_conv = r_normal * deform if any('deformable' in b for b in layer_blocks) else r_normal
+            r_pool = r_normal * deform if 'deformable' in block else r_normal
             # the conv search's sizes are read together with the subsampling's, the pool and upsample searches' together as
             # well: 2 host read-backs per pooling layer, 9 per 5-layer batch
-            conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_normal) if layer_blocks else None
+            conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_conv) if layer_blocks else None
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / cfg['conv_radius']
                 li = len(self.points)
@@ -579,9 +611,11 @@ class KPConvBatch:
                     conv_i = ops.radius_fill_dense(conv_plan, pts.shape[0])
                 else:
                     conv_i = e_i
-                # (same supports, same radius as the conv search: its grid is searched again)
-                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_normal, grid_from=conv_plan)
-                up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_normal)
+                # (same supports and, unless only one of the two is deformable, the same radius as the conv search: its grid is
+                #  searched again; the upsample radius is twice the POOL radius, concat_batcher.py:262-263)
+                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_pool,
+                                                  grid_from=conv_plan if r_pool == r_conv else None)
+                up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_pool)
                 ops.resolve_plans(pool_plan, up_plan)
                 pool_i = ops.radius_fill_dense(pool_plan, pts.shape[0])
                 up_i = ops.radius_fill_dense(up_plan, pool_p.shape[0])

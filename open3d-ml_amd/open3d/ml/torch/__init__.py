@@ -26,8 +26,9 @@ if _checkout():
         native = importlib.import_module("ml3d_amd.torch.models")
 
         class KPFCNN(native.KPFCNN):
-            """The registry entry for ``KPFCNN``: the MI355X-native class for rigid architectures; configs with
-            ``*_deformable*`` blocks (only ml3d/configs/kpconv_parislille3d.yml:28-32) are outside the rigid scope and FALL
+            """The registry entry for ``KPFCNN``: the MI355X-native class -- rigid blocks and, since round 3, the deformable ones
+            of ml3d/configs/kpconv_parislille3d.yml:28-32 (``KP_influence: linear``).  A config the native class refuses at
+            construction (NotImplementedError: a deformable block with another influence function or an unusual width) FALLS
             BACK to the checkout's own PyTorch ``KPFCNN`` (kpconv.py:1011-1041, 1071-1103), which then runs on PyTorch-ROCm
             with its neighbour searches / subsampling served by the native ops of this shim."""
             _warned = False
@@ -35,12 +36,14 @@ if _checkout():
             def __new__(cls, *args, **kwargs):
                 arch = kwargs.get("architecture", None)
                 if arch is not None and any("deformable" in str(b) for b in arch):
-                    if not KPFCNN._warned:
-                        logging.getLogger(__name__).warning(
-                            "KPFCNN: deformable KPConv blocks are outside the MI355X-native (rigid) scope; using the "
-                            "Open3D-ML checkout's PyTorch KPFCNN on the native ops instead")
-                        KPFCNN._warned = True
-                    return _ReferenceKPFCNN(*args, **kwargs)
+                    try:
+                        native.KPFCNN(*args, **dict(kwargs, device="cpu"))        # (a dry construction: parameters only)
+                    except NotImplementedError as e:
+                        if not KPFCNN._warned:
+                            logging.getLogger(__name__).warning(
+                                "KPFCNN: %s; using the Open3D-ML checkout's PyTorch KPFCNN on the native ops instead", e)
+                            KPFCNN._warned = True
+                        return _ReferenceKPFCNN(*args, **kwargs)
                 return super().__new__(cls)
 
         KPFCNN.__module__ = native.KPFCNN.__module__

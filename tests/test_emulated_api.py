@@ -190,3 +190,37 @@ got = ops.radius_fill_dense(plan, len(dense))
 assert plan.fallback is not None and ref.shape[1] >= 200 and np.array_equal(got.numpy(), ref)
 print("ok")
 ''')
+
+
+def test_kpfcnn_with_deformable_blocks_matches_the_real_reference_golden():
+    """``KPFCNN`` with ``resnetb_deformable`` / ``resnetb_deformable_strided`` blocks (kpconv_parislille3d.yml:28-32; here the
+    three-layer KPCONV_DEFORM_SMALL_CFG): GPU-side batch build (deform radius on the deformable layers) and forward through the
+    emulated library against the logits of the REAL reference's KPFCNN (tests/golden/kpconv_deform_small.npz), <= 1e-4; the
+    state dict carries ``offset_conv.weights``, ``offset_conv.kernel_points`` and ``offset_bias`` like the reference's."""
+    _run(r'''
+import synth_data
+from oracle import kpconv_ref as K
+from ml3d.torch.models.kpconv import KPConvBatch, KPFCNN
+cfg = dict(K.KPCONV_DEFORM_SMALL_CFG)
+g = np.load(os.path.join(ROOT, "tests", "golden", "kpconv_deform_small.npz"))
+spheres = [synth_data.toronto3d_sphere(int(f), int(g["max_points"])) for f in g["frame_ids"]]
+np.random.seed(int(g["np_seed"]))
+batch = KPConvBatch(np.concatenate(spheres), [len(s) for s in spheres], cfg, device="cpu")
+for l in range(cfg["num_layers"]):
+    nb = batch.neighbors[l].numpy().astype(np.int64)
+    assert list(nb.shape) == list(g["nbr_shape%d" % l]) and np.int64((nb * (np.arange(nb.shape[1]) + 1)).sum()) == g["nbr_checksum%d" % l], l
+m = KPFCNN(**cfg, device="cpu")
+sd = K.make_state_dict(cfg, int(g["weights_seed"]))
+assert set(m.state_dict().keys()) == set(sd.keys())
+m.load_state_dict(sd)
+out = m.eval()(batch).numpy()
+assert out.shape == g["logits"].shape and np.abs(out - g["logits"]).max() <= 1e-4, np.abs(out - g["logits"]).max()
+# a deformable block the kernels do not take is refused at construction (the open3d shim then falls back to the checkout)
+bad = dict(cfg, KP_influence="gaussian")
+try:
+    KPFCNN(**bad, device="cpu")
+    raise SystemExit("expected NotImplementedError")
+except NotImplementedError:
+    pass
+print("ok")
+''')

@@ -73,7 +73,7 @@ def test_kpconv_mfma_aggregation_rows_wider_than_64_shadows_anywhere(cin, n, r):
 
 
 @pytest.mark.parametrize("cin,n,r,modulated", [(32, 1500, 0.3, False), (64, 900, 0.55, False), (16, 700, 0.3, True),
-                                                 (128, 500, 0.3, True)])
+                                                 (128, 500, 0.3, True), (512, 260, 0.3, False)])
 def test_kpconv_deformable_matches_the_reference_formulation(cin, n, r, modulated):
     """``ml3d_kpconv_deformable`` (kpconv.py:1011-1159): the inner rigid convolution's output moves each query's kernel points,
     optional modulations scale the weighted features.  Against the oracle's restatement of the reference branch INCLUDING its

@@ -226,3 +226,65 @@ def test_kpconv_op_rows_wider_than_64_with_shadows_anywhere(cin, n, r):
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
     assert np.abs(got[-1] - np.where(b > 0, b, 0.2 * b)).max() <= 1e-6          # only shadows: act(bias)
+
+
+def test_deformable_architecture_batch_and_forward_match_the_reference_golden(golden_dir):
+    """The deformable blocks of kpconv_parislille3d.yml:28-32 on a three-layer architecture (synth_weights.
+    KPCONV_DEFORM_SMALL_CFG): deformable KPConv 32 -> 32 at a full and a strided block, 64 -> 64 on the coarsest layer.  The
+    batch (deform radius on the deformable layers' conv / pool searches, twice the POOL radius for the upsampling) against the
+    REAL reference's KPConvBatch, the logits against the REAL reference's KPFCNN.forward (oracle/gen_golden.py), <= 1e-4."""
+    from ml3d.torch.models.kpconv import KPConvBatch, KPFCNN
+    cfg = dict(K.KPCONV_DEFORM_SMALL_CFG)
+    g = np.load(os.path.join(golden_dir, "kpconv_deform_small.npz"))
+    spheres = [synth_data.toronto3d_sphere(int(f), int(g["max_points"])) for f in g["frame_ids"]]
+    np.random.seed(int(g["np_seed"]))
+    batch = KPConvBatch(np.concatenate(spheres), [len(s) for s in spheres], cfg, device="cuda:0")
+    assert np.array_equal(batch.rotations[0], g["rot0"])
+    for l in range(cfg["num_layers"]):
+        nb = batch.neighbors[l].cpu().numpy().astype(np.int64)
+        assert list(nb.shape) == list(g["nbr_shape%d" % l]), l
+        assert np.int64((nb * (np.arange(nb.shape[1]) + 1)).sum()) == g["nbr_checksum%d" % l], l
+        assert np.array_equal(batch.lengths[l].numpy(), g["lengths"][l])
+    assert np.array_equal(batch.upsamples[0][:64].cpu().numpy(), g["up0_head"])
+    # every matrix against the oracle's restatement of the batcher
+    np.random.seed(int(g["np_seed"]))
+    seg = K.segmentation_inputs(np.concatenate(spheres), [len(s) for s in spheres], cfg)
+    for l in range(cfg["num_layers"]):
+        for name in ("neighbors", "pools", "upsamples"):
+            assert np.array_equal(getattr(batch, name)[l].cpu().numpy(), seg[name][l]), (name, l)
+    m = KPFCNN(**cfg, device="cuda:0")
+    m.load_state_dict(K.make_state_dict(cfg, int(g["weights_seed"])))
+    out = m.eval()(batch)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert out.shape == g["logits"].shape and np.abs(out - g["logits"]).max() <= TOL
+    assert (out.argmax(1) == g["logits"].argmax(1)).mean() >= 0.999
+
+
+@pytest.mark.parametrize("cin,n,r,modulated", [(32, 4000, 0.3, False), (64, 2500, 0.55, False), (128, 1500, 0.3, True),
+                                               (512, 700, 0.3, False)])
+def test_kpconv_deformable_op_matches_the_reference_formulation(cin, n, r, modulated):
+    """``ops.kpconv_deformable`` on the hardware (kpconv.py:1011-1159): inner convolution -> per-query kernel points (and
+    modulations) in the MFMA aggregation; rows wider than 128 columns (0.55 m); cin = 512 as two channel slices.  Against the
+    oracle's restatement of the reference branch INCLUDING its in-range pruning of the neighbour lists."""
+    from ml3d import ops
+    rng = np.random.default_rng(cin + 7)
+    s = synth_data.toronto3d_sphere(22, n)
+    q = np.concatenate([K.batch_grid_subsampling(s, [len(s)], 0.1)[0], [[50, 50, 50]]]).astype(np.float32)
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], r)
+    assert (inds.shape[1] > 128) == (r > 0.5)
+    x = rng.standard_normal((len(s), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    od = 60 if modulated else 45
+    w = (rng.standard_normal((15, cin, 32)) * (0.5 / np.sqrt(cin))).astype(np.float32)
+    ow = (rng.standard_normal((15, cin, od)) * (0.12 / np.sqrt(cin))).astype(np.float32)
+    ob = (rng.standard_normal(od) * 0.1).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    out = ops.kpconv_deformable(g(q), g(s), g(inds), g(x), g(kp), g(w.reshape(15 * cin, 32)), g(b), 0.08,
+                                g(ow.reshape(15 * cin, od)), g(ob), 1, 0.1, 1)
+    torch.cuda.synchronize()
+    t = torch.from_numpy
+    ref = K.kpconv_deformable(t(q), t(s), t(inds).long(), t(x), t(kp), t(w), 0.08, t(ow), t(ob), modulated)
+    ref = torch.nn.functional.leaky_relu(ref + t(b), 0.1).numpy()
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())

@@ -112,8 +112,17 @@ assert any("deformable" in b for b in cfg.model.architecture)
 Model = _ml3d.utils.get_module("model", cfg.model.name, "torch")
 assert Model.__module__.startswith("ml3d_amd.torch.models")            # the registry entry is this repository's ...
 m = Model(**cfg.model, device="cpu")
-assert type(m).__module__ == "ml3d.torch.models.kpconv", type(m)        # ... and hands deformable configs to the checkout's class
-assert any("Deformable" in type(b).__name__ or getattr(getattr(b, "KPConv", None), "deformable", False) for b in m.encoder_blocks)
+# round 3: the YAML's deformable blocks (KP_influence linear, KPConv widths 128 / 256 / 512) run on the native class ...
+assert type(m).__module__.startswith("ml3d_amd.torch.models"), type(m)
+assert sum(getattr(getattr(b, "KPConv", None), "deformable", False) for b in m.encoder_blocks) == 5
+import ml3d.torch.models.kpconv as _refkp
+ref_keys = set(_refkp.KPFCNN(**cfg.model).state_dict().keys())
+assert set(m.state_dict().keys()) == ref_keys                              # ... with the reference's state-dict layout
+# ... and a deformable config the kernels do not take is handed to the checkout's class instead of failing
+bad = dict(cfg.model, KP_influence="gaussian")
+m3 = Model(**bad, device="cpu")
+assert type(m3).__module__ == "ml3d.torch.models.kpconv", type(m3)
+assert any(getattr(getattr(b, "KPConv", None), "deformable", False) for b in m3.encoder_blocks)
 cfg2 = _ml3d.utils.Config.load_from_file(os.path.join(%(ref)r, "ml3d", "configs", "kpconv_toronto3d.yml"))
 m2 = Model(**cfg2.model, device="cpu")
 assert type(m2).__module__.startswith("ml3d_amd.torch.models"), type(m2)   # rigid configs stay native
@@ -123,8 +132,10 @@ print("FALLBACK-OK")
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ml3d")), reason="needs the reference checkout (absent on the GPU box)")
 def test_deformable_kpconv_config_falls_back_to_the_checkouts_model(tmp_path):
-    """kpconv_parislille3d.yml (the only config with *_deformable* blocks) must fall back to the PyTorch path
-    rather than fail; standalone (no checkout) the native class refuses with that instruction."""
+    """kpconv_parislille3d.yml (the only config with *_deformable* blocks) must not fail.  Since round 3 its blocks
+    run on the native class (same state-dict keys as the reference's); a deformable config outside what the kernels take
+    (another influence function) falls back to the checkout's PyTorch model; standalone the native class refuses it with that
+    instruction."""
     env = dict(os.environ, OPEN3D_ML_ROOT=REF, PYTHONPATH=os.pathsep.join([PKG, os.path.join(ROOT, "tests", "stubs")]))
     r = subprocess.run([sys.executable, "-c", _DEFORMABLE % {"ref": os.path.abspath(REF), "tmp": str(tmp_path)}], env=env,
                        cwd="/tmp", capture_output=True, text=True, timeout=900)
@@ -132,4 +143,4 @@ def test_deformable_kpconv_config_falls_back_to_the_checkouts_model(tmp_path):
     assert "FALLBACK-OK" in r.stdout
     from ml3d.torch.models import KPFCNN
     with pytest.raises(NotImplementedError, match="OPEN3D_ML_ROOT"):
-        KPFCNN(architecture=["simple", "resnetb_deformable", "nearest_upsample", "unary"], device="cpu")
+        KPFCNN(architecture=["simple", "resnetb_deformable", "nearest_upsample", "unary"], KP_influence="gaussian", device="cpu")
