@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops as oops
-from synth_weights import (TORONTO3D_CFG, KPCONV_DEFORM_SMALL_CFG, arch_plan, synthetic_kernel_points,  # noqa: F401  (input generation)
+from synth_weights import (TORONTO3D_CFG, KPCONV_DEFORM_SMALL_CFG, PARISLILLE3D_CFG, arch_plan, synthetic_kernel_points,  # noqa: F401  (input generation)
                            kpconv_state_dict as make_state_dict)
 
 

@@ -121,6 +121,17 @@ TORONTO3D_CFG = dict(   # ml3d/configs/kpconv_toronto3d.yml:23-82 (inference-rel
     num_classes=8, num_kernel_points=15, num_layers=5, use_batch_norm=True, reduce_fc=True, l_relu=0.2)
 
 
+PARISLILLE3D_CFG = dict(   # ml3d/configs/kpconv_parislille3d.yml:17-82 (inference-relevant keys): five deformable blocks
+    KP_extent=1.0, KP_influence="linear", aggregation_mode="sum",
+    architecture=["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb_strided", "resnetb_deformable",
+                  "resnetb_deformable_strided", "resnetb_deformable", "resnetb_deformable_strided", "resnetb_deformable",
+                  "nearest_upsample", "unary", "nearest_upsample", "unary", "nearest_upsample", "unary", "nearest_upsample",
+                  "unary"],
+    batch_limit=20000, batch_norm_momentum=0.98, conv_radius=2.5, deform_radius=6.0, first_features_dim=128,
+    first_subsampling_dl=0.08, fixed_kernel_points="center", in_features_dim=1, in_points_dim=3, in_radius=4.0,
+    lbl_values=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9], ignored_label_inds=[0], max_in_points=17000, modulated=False,
+    num_classes=9, num_kernel_points=15, num_layers=5, use_batch_norm=True, reduce_fc=True, l_relu=0.2)
+
 # a three-layer architecture with the deformable blocks of kpconv_parislille3d.yml:28-32 (deformable KPConv 32 -> 32 at a
 # full and a strided block, 64 -> 64 on the coarsest layer); deform_radius below the YAML's 6.0 keeps the test batches small
 KPCONV_DEFORM_SMALL_CFG = dict(

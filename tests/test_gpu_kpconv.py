@@ -288,3 +288,30 @@ def test_kpconv_deformable_op_matches_the_reference_formulation(cin, n, r, modul
     ref = K.kpconv_deformable(t(q), t(s), t(inds).long(), t(x), t(kp), t(w), 0.08, t(ow), t(ob), modulated)
     ref = torch.nn.functional.leaky_relu(ref + t(b), 0.1).numpy()
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_parislille3d_architecture_runs_natively_and_matches_the_oracle():
+    """kpconv_parislille3d.yml's model section (five deformable blocks, KPConv widths 128 / 128 / 256 / 256 / 512,
+    deform_radius 6.0): GPU batch build against the oracle's restatement of the batcher (rows of 300+ columns on the deformable
+    layers: the dense search's 128-entry stash overflows and falls back, the aggregation walks the rows 128 columns at a time)
+    and the forward against the oracle's (pinned to the real reference on the small deformable architecture), <= 1e-4."""
+    from ml3d.torch.models.kpconv import KPConvBatch, KPFCNN
+    cfg = dict(K.PARISLILLE3D_CFG)
+    spheres = [synth_data.toronto3d_sphere(8, 6000), synth_data.toronto3d_sphere(9, 2500)]
+    pts, lens = np.concatenate(spheres), [len(s) for s in spheres]
+    np.random.seed(3)
+    seg = K.segmentation_inputs(pts, lens, cfg)
+    np.random.seed(3)
+    batch = KPConvBatch(pts, lens, cfg, device="cuda:0")
+    assert max(seg["neighbors"][l].shape[1] for l in range(5)) > 128
+    for l in range(cfg["num_layers"]):
+        for name in ("neighbors", "pools", "upsamples"):
+            assert np.array_equal(getattr(batch, name)[l].cpu().numpy(), seg[name][l]), (name, l)
+    sd = K.make_state_dict(cfg, 21)
+    m = KPFCNN(**cfg, device="cuda:0")
+    m.load_state_dict(sd)
+    out = m.eval()(batch)
+    torch.cuda.synchronize()
+    ref = K.forward(sd, cfg, K.to_torch_batch(seg), torch.ones((len(pts), 1))).numpy()
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    assert (out.cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.999
