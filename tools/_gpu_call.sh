@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_kpconv.py -x -q -k "parislille or deformable" 2>&1 | tail -8
+mkdir -p gpurun_out/r3an
+for b in 16 32; do timeout 600 python tools/bench_deformable.py $b 20 2>&1 | tail -1 | tee -a gpurun_out/r3an/deformable.log; done
