@@ -32,7 +32,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "open3d-ml_amd")
 
-MODELS = {"randlanet": "randlanet_semantickitti.yml", "kpconv": "kpconv_toronto3d.yml", "pointpillars": "pointpillars_kitti.yml"}
+MODELS = {"randlanet": "randlanet_semantickitti.yml", "kpconv": "kpconv_toronto3d.yml", "pointpillars": "pointpillars_kitti.yml",
+          "kpconv_deform": "kpconv_parislille3d.yml"}        # (five deformable blocks, kpconv_parislille3d.yml:28-32)
 
 
 def _stub_tensorboard():
@@ -97,7 +98,7 @@ def small_overrides(name, cfg):
     if name == "randlanet":
         m["num_points"] = 1024
         m["dim_output"] = [16, 32, 64, 64]
-    elif name == "kpconv":
+    elif name.startswith("kpconv"):
         m["first_subsampling_dl"] = 0.3
         m["in_radius"] = 2.5
         m["min_in_points"] = 120
@@ -120,7 +121,7 @@ def make_data(name, small):
             pts = pts[np.linalg.norm(pts[:, :2], axis=1) < 4.2]
         return dict(point=np.ascontiguousarray(pts, np.float32), feat=None,
                     label=(1 + (np.arange(pts.shape[0]) % 19)).astype(np.int32))
-    if name == "kpconv":
+    if name.startswith("kpconv"):
         return synth_data.toronto3d_tile(7, half=2.0 if small else 6.0, density=0.1 if small else 0.25)
     sweep = synth_data.kitti_sweep(11)
     return dict(point=np.ascontiguousarray(sweep, np.float32), calib=None, bounding_boxes=[])
@@ -131,7 +132,7 @@ def state_dict_for(name, model_cfg):
     cfg = {k: (v.to_dict() if hasattr(v, "to_dict") else v) for k, v in dict(model_cfg).items()}
     if name == "randlanet":
         return synth_weights.randlanet_state_dict(cfg, 31)
-    if name == "kpconv":
+    if name.startswith("kpconv"):
         return synth_weights.kpconv_state_dict(cfg, 32)
     return synth_weights.pointpillars_state_dict(cfg, 33)
 
@@ -141,7 +142,7 @@ def run_one(name, side, utils, dev, ref, small, out_dir, sampler_index="sklearn"
     cfg = utils.Config.load_from_file(os.path.join(ref, "ml3d", "configs", MODELS[name]))
     if small:
         small_overrides(name, cfg)
-    if side == "native" and name == "kpconv" and sampler_index != "gpu":
+    if side == "native" and name.startswith("kpconv") and sampler_index != "gpu":
         # the radius sampler's sphere order is sklearn's tree-traversal order (unsorted by contract); the native class reproduces
         # it only with the reference's own index structure for that ONE query per sphere (ml3d/torch/models/_datapath.py)
         cfg.model["sampler_index"] = sampler_index
