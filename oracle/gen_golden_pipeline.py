@@ -1,8 +1,8 @@
-"""Generate tests/golden/pipeline_{randlanet,kpconv,pointpillars}.npz from the REAL reference pipelines, in this container:
+"""Generate tests/golden/pipeline_{randlanet,kpconv,pointpillars,kpconv_deform}.npz from the REAL reference pipelines, in this container:
 
     python -m oracle.gen_golden_pipeline            (needs /root/reference; ~1 min of CPU)
 
-For each of the three unchanged YAML configs (randlanet_semantickitti / kpconv_toronto3d / pointpillars_kitti) the
+For each of the four unchanged YAML configs (randlanet_semantickitti / kpconv_toronto3d / pointpillars_kitti / kpconv_parislille3d) the
 reference's OWN pipeline class runs ``run_inference`` on a seeded synthetic cloud with the reference's OWN PyTorch-CPU model
 (the oracle's C ops stand in for the un-installable open3d wheel, oracle/ref_shim.py) — tools/ref_pipelines.py, side
 "reference".  The same models then go through tests/pipeline_loop.py (the checkout-free restatement of that loop which the

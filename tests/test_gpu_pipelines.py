@@ -83,6 +83,16 @@ def test_kpfcnn_toronto3d_cloud_through_transform_make_batch_forward_update_prob
     check_segmentation(res, g, 0.9995)
 
 
+def test_kpfcnn_parislille3d_deformable_cloud_matches_the_reference_pipeline():
+    """kpconv_parislille3d.yml unchanged (five ``resnetb_deformable*`` blocks, deform_radius 6.0): the native class through the
+    pipeline loop against what the REAL reference pipeline + the reference's PyTorch-CPU KPFCNN produced."""
+    g, cfg = _golden("kpconv_deform")
+    assert sum("deformable" in b for b in cfg["architecture"]) == 5 and cfg["deform_radius"] == 6.0
+    data = synth_data.toronto3d_tile(7, half=6.0, density=0.25)
+    res = native_segmentation("kpconv_deform", cfg, data, int(g["batch_size"]), "cuda:0")
+    check_segmentation(res, g, 0.9995)
+
+
 def test_pointpillars_kitti_sweep_through_forward_and_inference_end_matches_the_reference_pipeline():
     from ml3d.torch.models import PointPillars
     g, cfg = _golden("pointpillars")

@@ -35,11 +35,11 @@ def test_reference_pipelines_drive_the_native_models_and_match_the_reference_cpu
     emu.lib()                                              # build the emulated library once, outside the timed subprocesses
     ref_log = _run(["--side", "reference"], out)
     nat_log = _run(["--side", "native", "--emu"], out)
-    for name in ("randlanet", "kpconv", "pointpillars"):
+    for name in ("randlanet", "kpconv", "pointpillars", "kpconv_deform"):
         assert "[%s/native] model class ml3d_amd.torch.models" % name in nat_log        # the MI355X-native class ...
         assert "pipeline class ml3d.torch.pipelines" in nat_log                         # ... under the reference's pipeline
         assert "[%s/reference] model class ml3d.torch.models" % name in ref_log
-    for name in ("randlanet", "kpconv"):
+    for name in ("randlanet", "kpconv", "kpconv_deform"):       # (kpconv_deform: kpconv_parislille3d.yml, five deformable blocks)
         a = np.load(os.path.join(out, "%s_native_small.npz" % name))
         b = np.load(os.path.join(out, "%s_reference_small.npz" % name))
         assert a["predict_labels"].shape == b["predict_labels"].shape and a["predict_labels"].size > 5000
