@@ -224,3 +224,34 @@ except NotImplementedError:
     pass
 print("ok")
 ''')
+
+
+def test_kpfcnn_modulated_deformable_and_simple_deformable_blocks_match_the_oracle():
+    """``modulated: true`` (offset_dim 60: 2 sigmoid modulations on the weighted features, kpconv.py:1017-1024, 1147-1149) and a
+    ``simple_deformable`` block (kpconv.py:1321-1332) -- no reference config uses either, the reference code has both: native
+    batch + forward on the emulated library against the oracle's restatement."""
+    _run(r'''
+import synth_data
+from oracle import kpconv_ref as K
+from ml3d.torch.models.kpconv import KPConvBatch, KPFCNN
+cfg = dict(K.KPCONV_DEFORM_SMALL_CFG, modulated=True, num_layers=2,
+           architecture=["simple", "resnetb_strided", "simple_deformable", "resnetb_deformable", "nearest_upsample", "unary"])
+spheres = [synth_data.toronto3d_sphere(5, 1300), synth_data.toronto3d_sphere(6, 900)]
+pts, lens = np.concatenate(spheres), [len(s) for s in spheres]
+np.random.seed(4)
+seg = K.segmentation_inputs(pts, lens, cfg)
+np.random.seed(4)
+batch = KPConvBatch(pts, lens, cfg, device="cpu")
+for l in range(2):
+    for name in ("neighbors", "pools", "upsamples"):
+        assert np.array_equal(getattr(batch, name)[l].numpy(), seg[name][l]), (name, l)
+sd = K.make_state_dict(cfg, 9)
+assert sd["encoder_blocks.2.KPConv.offset_conv.weights"].shape[2] == 60 and sd["encoder_blocks.2.KPConv.offset_bias"].shape[0] == 60
+m = KPFCNN(**cfg, device="cpu")
+assert set(m.state_dict().keys()) == set(sd.keys())
+m.load_state_dict(sd)
+out = m.eval()(batch).numpy()
+ref = K.forward(sd, cfg, K.to_torch_batch(seg), torch.ones((len(pts), 1))).numpy()
+assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+print("ok")
+''')
