@@ -1,13 +1,14 @@
-"""KPFCNN / KPConv (rigid, inference) on MI355X — host-side mirror of the reference model.
+"""KPFCNN / KPConv (rigid and deformable blocks, inference) on MI355X — host-side mirror of the reference model.
 
 Same constructor arguments, module/parameter names and state_dict layout as the reference
 ``ml3d/torch/models/kpconv.py:33-291``, so ``ml3d/configs/kpconv_*.yml`` and
 published checkpoints load unchanged.  The module tree only OWNS parameters: ``forward`` folds eval-mode
 BatchNorm into the weights once and runs the hand-written HIP kernels through the C ABI
-(``ml3d.ops.kpconv_rigid`` / ``linear`` / ``gather_pool``).  ``KPConvBatch`` builds the per-layer
+(``ml3d.ops.kpconv_rigid`` / ``kpconv_deformable`` / ``linear`` / ``gather_pool``).  ``KPConvBatch`` builds the per-layer
 points / neighbour / pool / upsample matrices of ``KPConvBatch.segmentation_inputs``
 (ml3d/torch/dataloaders/concat_batcher.py:186-305) on the GPU (fixed-radius search + grid subsample).
-Deformable blocks (only kpconv_parislille3d.yml) are outside the rigid scope and raise.
+Deformable blocks (kpconv_parislille3d.yml:28-32) run natively for ``KP_influence: linear`` (kpconv.py:1011-1159: inner
+offset convolution, per-query kernel points, optional modulations); other deformable variants raise at construction.
 There is no CPU execution path.
 """
 import os
