@@ -261,12 +261,14 @@ def _one_pass_radius():
         return _ONE_PASS
 
 
-def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius, grid_from=None):
+def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius, grid_from=None, long_rows=False):
     """Deferred first half of ``radius_neighbors_dense``: the search is enqueued, its sizes not read yet.  ``grid_from``: an
-    already filled plan over the same supports and radius whose grid is reused."""
+    already filled plan over the same supports and radius whose grid is reused.  ``long_rows``: the caller expects rows beyond
+    the one-traversal form's 128-entry stash (KPConv's deformable layers: deform_radius 6.0, hundreds of neighbours) -- go
+    straight to the two-phase search instead of gathering once, overflowing and searching again."""
     dev = supports.device
     prs, qrs = _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0]
-    if _one_pass_radius():
+    if _one_pass_radius() and not long_rows:
         return _DenseRadiusPlan(supports, queries, radius, prs, qrs, grid_from=grid_from)
     return _RadiusPlan(supports, queries, radius, prs, qrs, defer=True)
 

@@ -589,7 +589,7 @@ class KPConvBatch:
             r_pool = r_normal * deform if 'deformable' in block else r_normal
             # the conv search's sizes are read together with the subsampling's, the pool and upsample searches' together as
             # well: 2 host read-backs per pooling layer, 9 per 5-layer batch
-            conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_conv) if layer_blocks else None
+            conv_plan = ops.radius_plan_dense(pts, pts, lens, lens, r_conv, long_rows=r_conv > r_normal) if layer_blocks else None
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / cfg['conv_radius']
                 li = len(self.points)
@@ -614,8 +614,8 @@ class KPConvBatch:
                     conv_i = e_i
                 # (same supports and, unless only one of the two is deformable, the same radius as the conv search: its grid is
                 #  searched again; the upsample radius is twice the POOL radius, concat_batcher.py:262-263)
-                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_pool,
-                                                  grid_from=conv_plan if r_pool == r_conv else None)
+                pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_pool, long_rows=r_pool > r_normal,
+                                                  grid_from=conv_plan if (r_pool == r_conv and r_pool == r_normal) else None)
                 up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_pool)
                 ops.resolve_plans(pool_plan, up_plan)
                 pool_i = ops.radius_fill_dense(pool_plan, pts.shape[0])
