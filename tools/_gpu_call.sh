@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
-O=gpurun_out/r3fin7; mkdir -p $O
+O=gpurun_out/r3fin8; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tee $O/gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
-import json; d=json.load(open('$O/bench.json'))
-print('randla', round(d['value'],1), d['step_ms_median'], d['roofline']['frac'], d['roofline'].get('avg_launch_ms'), d['roofline'].get('avg_launch_ms_alone'))
-for k,w in d['workloads'].items(): print(k, round(w.get('value',0),1), w.get('step_ms_median'), w.get('roofline',{}).get('frac'), w.get('error'))
-"
+R=$GRAFT_REPO_ROOT
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/$O/pf -o kp -- python $R/bench.py --workload kpconv --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $R/$O/pf -o pp -- python $R/bench.py --workload pointpillars --no-cpu-baseline > /dev/null 2>&1
+cd $R
+for w in kp pp; do python profiles/summarize_rocpd.py $O/pf/${w}_results.db > $O/${w}_kernel_stats.csv 2>/dev/null; done
+rm -rf $O/pf; head -5 $O/kp_kernel_stats.csv | cut -c1-120; head -4 $O/pp_kernel_stats.csv | cut -c1-120
