@@ -444,29 +444,23 @@ class PointPillars(nn.Module):
         """point_pillars.py:269-297: decode + rotated NMS on the GPU (``Anchor3DHead.get_bboxes``), then one box object per
         detection.  With an Open3D-ML checkout on the path the objects are its ``BEVBox3D`` (what the pipeline's metrics
         and ``save_test_result`` expect); standalone they are ``DetectedBox`` records with the same fields."""
-        bboxes_b, scores_b, labels_b = self.bbox_head.get_bboxes(*results)
         try:
             from ml3d.datasets.utils import BEVBox3D as Box       # the reference's class when a checkout is importable
         except Exception:
             Box = DetectedBox
-        calibs = getattr(inputs, 'calib', None) or [None] * len(bboxes_b)
-        inference_result = []
-        for _calib, _bboxes, _scores, _labels in zip(calibs, bboxes_b, scores_b, labels_b):
-            bboxes = _bboxes.cpu().detach().numpy()
-            scores = _scores.cpu().detach().numpy()
-            labels = _labels.cpu().detach().numpy()
-            inference_result.append([])
-            world_cam, cam_img = None, None
-            if _calib is not None:
-                world_cam = _calib.get('world_cam', None)
-                cam_img = _calib.get('cam_img', None)
-            for bbox, score, label in zip(bboxes, scores, labels):
-                dim = bbox[[3, 5, 4]]
-                pos = bbox[:3] + [0, 0, dim[1] / 2]
-                yaw = bbox[-1]
-                name = self.lbl2name.get(int(label), "ignore")
-                inference_result[-1].append(Box(pos, dim, yaw, name, score, world_cam, cam_img))
-        return inference_result
+        calibs = list(getattr(inputs, 'calib', None) or [])
+        detections = []
+        for i, (boxes, scores, labels) in enumerate(zip(*self.bbox_head.get_bboxes(*results))):
+            calib = (calibs[i] if i < len(calibs) else None) or {}
+            b = boxes.detach().cpu().numpy()                                   # rows [x, y, z(bottom), w, l, h, yaw]
+            size = b[:, [3, 5, 4]]                                             # (w, h, l), the box object's order
+            centre = b[:, :3].astype(np.float64)
+            centre[:, 2] += size[:, 1].astype(np.float64) / 2                  # bottom face -> box centre
+            names = [self.lbl2name.get(int(l), "ignore") for l in labels.detach().cpu().numpy()]
+            conf = scores.detach().cpu().numpy()
+            detections.append([Box(centre[j], size[j], b[j, 6], names[j], conf[j], calib.get('world_cam'), calib.get('cam_img'))
+                               for j in range(b.shape[0])])
+        return detections
 
     def inference_begin(self, data):
         raise NotImplementedError("PointPillars: the reference drives detection through its pipeline (run_inference), "
