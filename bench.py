@@ -8,7 +8,12 @@ from pinned host memory (inside the timed region, on a copy stream, SURVEY.md §
 one process per GPU (torchrun), frames sharded across ranks (weak scaling); the only collective is the RCCL gather of those
 labels to rank 0 inside the timed region.
 
+``python bench.py --gpus N`` WITHOUT torchrun launches its own N ranks (``launch_ranks``: one child process per GPU with the
+torchrun environment, rendezvous on 127.0.0.1 -- what the reference's scripts/run_pipeline.py:195-206 does with mp.spawn);
+under torchrun (RANK / WORLD_SIZE set) it is one rank.  N ranks on fewer than N devices is an error, never a silent N = 1.
+
 Prints ONE JSON line (rank 0).  Extra objects:
+  ranks_seen      world size as torch.distributed reports it + the all-gathered device identities of the ranks.
   roofline        the kernel with the longest average launch among the traced ones (the neighbour-search launch, layer-0 and layer-1
                   attention kernels), timed live with HIP events recorded by the library around that kernel's launch on the
                   launch stream; `roofline_other` carries the rest.  MFMA kernels: `frac` prices the flops the kernel
@@ -217,6 +222,119 @@ def synthetic_batch(rank, B, N, nd):
     return frames
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, stub=False):
+    """``python bench.py --gpus N`` without torchrun: start N ranks of this script (one process per GPU, torchrun's
+    environment, rendezvous on 127.0.0.1), wait for all of them, return the worst exit code.  Rank 0's stdout is ours, so
+    the ONE JSON line still is.  The reference launches its ranks the same way (scripts/run_pipeline.py:195-206)."""
+    import subprocess
+    if not stub:
+        nd = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if nd < n:
+            raise SystemExit("bench.py --gpus %d: %d ranks, %d device%s visible -- refusing to run fewer ranks than asked for"
+                             % (n, n, nd, "" if nd == 1 else "s"))
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, ML3D_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stdin=subprocess.DEVNULL))
+    rc = 0
+    try:
+        # a rank that dies leaves the others in a collective: poll, and take the rest down (by PID) when one has failed
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def device_identity(dev):
+    """What tells two ranks' GPUs apart (the UUID where this torch exposes it, the PCI address otherwise)."""
+    if dev.type != "cuda":
+        return "cpu-stub:pid%d" % os.getpid()
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = getattr(pr, "uuid", None)
+    if uuid is not None:
+        return "%s uuid=%s" % (pr.name, uuid)
+    return "%s pci=%04x:%02x:%02x" % (pr.name, getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                      getattr(pr, "pci_device_id", 0))
+
+
+def ranks_seen(dev, world, dist, stub=False):
+    """{"world_size", "devices"}: the process group's own view of the job (every rank's device identity, all-gathered).
+    Two ranks on one GPU would share its HBM and CUs and still print n_gpus = N: that is an error here."""
+    me = device_identity(dev)
+    if world > 1:
+        ids = [None] * world
+        dist.all_gather_object(ids, me)
+        ws = dist.get_world_size()
+    else:
+        ids, ws = [me], 1
+    if not stub and len(set(ids)) != len(ids):
+        raise SystemExit("bench.py: %d ranks share devices %s -- one process per GPU" % (ws, ids))
+    return {"world_size": int(ws), "devices": ids}
+
+
+class _HostEvent:
+    """--stub stand-in for torch.cuda.Event (the stub runs the step logic on CPU tensors over gloo)."""
+
+    def __init__(self, enable_timing=False):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _StubFrameStream:
+    """--stub stand-in for ml3d.engine.RandLAFrameStream: scores are a pure function of (rank, step) on the CPU, so rank 0
+    can rebuild what every rank must have sent.  Everything around it -- launcher, process group, PredictionGather, the
+    barriers and the max-over-ranks clock -- is the code the GPU run executes."""
+    compute_stream = None
+
+    def __init__(self, rank, B, N, C):
+        self.rank, self.B, self.N, self.C, self.k = rank, B, N, C, 0
+        self.n = [N]
+
+    @staticmethod
+    def scores_of(rank, step, B, N, C):
+        return torch.rand((B, N, C), generator=torch.Generator().manual_seed(7919 * rank + step))
+
+    def submit(self, host, feats=None, knn_trace=None, fwd_trace=None, done=None):
+        sc = self.scores_of(self.rank, self.k, self.B, self.N, self.C)
+        self.k += 1
+        if done is not None:
+            done.record()
+        return sc
+
+    def synchronize(self):
+        pass
+
+
 def main():
     if os.environ.get("ML3D_BENCH_WATCHDOG"):          # debugging aid: python tracebacks of every thread after N seconds
         import faulthandler
@@ -237,7 +355,14 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the KPConv / PointPillars side measurements")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (B = 1 / 4) model-API latency measurement")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU / gloo dry run of the launcher and of every N > 1 branch with a stand-in for the GPU step "
+                         "(tests/test_bench_launcher.py); prints a line marked \"stub\": true that is NOT a measurement")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no torchrun around us: be the launcher (N ranks, one per GPU), never a silent single rank
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], stub=args.stub))
 
     # host-side glue (collate, small CPU tensor ops) must not fan out over every core of a 256-thread host: an OpenMP
     # fork-join across 256 threads costs milliseconds per tiny op, and 8 ranks share the node (cpu_baseline runs its own sweep)
@@ -246,23 +371,32 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE under torchrun")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    stub = args.stub
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        if local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: local rank %d of %d ranks, %d device(s) visible -- one process per GPU"
+                             % (local, world, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     from ml3d import dist as mdist
     if world > 1:
         import torch.distributed as dist
-        mdist.init("nccl", dev)
+        mdist.init("gloo" if stub else "nccl", dev)
+    seen = ranks_seen(dev, world, dist, stub)
 
     if args.workload != "randlanet":
         import bench_models
         fn = bench_models.run_kpconv if args.workload == "kpconv" else bench_models.run_pointpillars
         out = fn(args, rank, world, dev, dist)
         if rank == 0:
+            out["ranks_seen"] = seen
             print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
@@ -272,13 +406,19 @@ def main():
     from ml3d.engine import RandLAFrameStream, make_trace
 
     B, N = args.frames_per_step, CFG["num_points"]
-    frames = synthetic_batch(rank, B, N, args.distinct_frames)
-    sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
-    overlap = not args.no_overlap
-    stream = RandLAFrameStream(CFG, sd, B, N, dev, overlap=overlap)
-    # what a data loader hands over: pinned host xyz (in_channels = 3).  Two DIFFERENT batches alternate (the second holds the
-    # frames in reverse order), so consecutive steps never upload / search / classify the same bytes.
-    hosts = [torch.from_numpy(frames).pin_memory(), torch.from_numpy(np.ascontiguousarray(frames[::-1])).pin_memory()]
+    overlap = not args.no_overlap and not stub
+    if stub:
+        N = 257
+        stream, hosts = _StubFrameStream(rank, B, N, CFG["num_classes"]), [None, None]
+        Event, sync = _HostEvent, (lambda: None)
+    else:
+        Event, sync = torch.cuda.Event, torch.cuda.synchronize
+        frames = synthetic_batch(rank, B, N, args.distinct_frames)
+        sd = synth_weights.randlanet_state_dict(CFG, 2024)   # deterministic pseudo-trained weights (no checkpoints offline)
+        stream = RandLAFrameStream(CFG, sd, B, N, dev, overlap=overlap)
+        # what a data loader hands over: pinned host xyz (in_channels = 3).  Two DIFFERENT batches alternate (the second holds
+        # the frames in reverse order), so consecutive steps never upload / search / classify the same bytes.
+        hosts = [torch.from_numpy(frames).pin_memory(), torch.from_numpy(np.ascontiguousarray(frames[::-1])).pin_memory()]
     step_no = [0]
     gather = mdist.PredictionGather(B, N, CFG["num_classes"], dev)
 
@@ -318,25 +458,25 @@ def main():
         one_step()
     drain()
     K = args.steps
-    tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    done_ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    tev = [(Event(enable_timing=True), Event(enable_timing=True)) for _ in range(K)]
+    done_ev = [Event(enable_timing=True) for _ in range(K + 1)]
     for a, b in tev:
         a.record(); b.record()           # materialise the hipEvent_t handles
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     done_ev[0].record(stream.compute_stream)
     t0 = time.perf_counter()
     for i in range(K):
         kind, tag = TRACED[i % len(TRACED)]
-        tr = make_trace(tag, *tev[i])
+        tr = None if stub else make_trace(tag, *tev[i])
         one_step(tr if kind == "knn" else None, tr if kind == "fwd" else None, done_ev[i + 1])
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -344,7 +484,22 @@ def main():
         dt = float(t.item())
 
     out = None
-    if rank == 0:
+    if stub:
+        # the dry run's check: rank 0 must hold every rank's labels of the LAST step (the async gather's second buffer)
+        if rank == 0:
+            last = args.warmup + K - 1
+            got = gather.gathered(last % gather.depth)
+            assert len(got) == world, (len(got), world)
+            for r in range(world):
+                want = _StubFrameStream.scores_of(r, last, B, N, CFG["num_classes"]).argmax(2).to(torch.uint8)
+                assert torch.equal(got[r], want), "rank %d's labels did not arrive on rank 0" % r
+            out = {"stub": True, "metric": "NOT A MEASUREMENT: bench.py --stub (launcher + N > 1 step logic on CPU tensors over gloo)",
+                   "value": B * K * world / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+                   "ms_per_step": dt / K * 1e3, "scaling": "weak", "ranks_seen": seen,
+                   "self_launched": bool(os.environ.get("ML3D_BENCH_SELF_LAUNCHED")),
+                   "gathered_ranks_checked": world}
+            print(json.dumps(out), flush=True)
+    elif rank == 0:
         n_lv = stream.n
         # the same three kernels with NOTHING else on the GPU (after the timed region): what the overlap with the other stream
         # costs each of them -- the neighbour-search launch runs under the forward on purpose and takes ~1.5x its solo time there
@@ -401,7 +556,7 @@ def main():
             "value": B * K * world / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "step_ms_median": float(np.median(iv)), "step_ms_p95": float(np.percentile(iv, 95)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "ranks_seen": seen,
             "config": {"workload": "RandLA-Net SemanticKITTI inference, %d synthetic 45056-point frames per step per GPU "
                                    "(randlanet_semantickitti.yml): host->device upload of xyz + GPU kNN pyramid + fused forward" % B,
                        "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world,

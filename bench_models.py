@@ -65,13 +65,17 @@ class _CallTimer:
 
 
 def _timed(step, K, W, world, dist, dev, ev_stream=None, intervals=None):
-    """``intervals`` (list): filled with the K completion-to-completion times (ms) of the steps on ``ev_stream``."""
+    """``intervals`` (list): filled with the K completion-to-completion times (ms) of the steps on ``ev_stream``.
+    (``dev`` = cpu only in bench.py --stub, the CPU / gloo dry run of the N > 1 branches: no events, no device syncs.)"""
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    if dev.type != "cuda":
+        intervals = None
     for _ in range(W):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if intervals is not None else None
     if evs:
         evs[0].record(ev_stream() if callable(ev_stream) else ev_stream)
@@ -80,12 +84,12 @@ def _timed(step, K, W, world, dist, dev, ev_stream=None, intervals=None):
         step()
         if evs:
             evs[i + 1].record(ev_stream() if callable(ev_stream) else ev_stream)
-    torch.cuda.synchronize()
+    sync()
     if evs:
         intervals.extend(float(evs[i].elapsed_time(evs[i + 1])) for i in range(K))
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -94,28 +98,93 @@ def _timed(step, K, W, world, dist, dev, ev_stream=None, intervals=None):
     return dt
 
 
+class _StubDetections:
+    """bench.py --stub: stand-in for ml3d.engine.PointPillarsStream -- a step's detections are a pure function of (rank, step)
+    with a DIFFERENT number of boxes on every rank and step, handed over one step late like the real stream."""
+    compute = None
+
+    def __init__(self, rank, sweeps):
+        self.rank, self.sweeps, self.k, self.prev = rank, sweeps, 0, None
+
+    @staticmethod
+    def result_of(rank, step, sweeps):
+        g = torch.Generator().manual_seed(104729 * rank + step)
+        n = [3 + (5 * rank + 2 * step + i) % 7 for i in range(sweeps)]
+        return ([torch.rand((k, 7), generator=g) for k in n], [torch.rand((k,), generator=g) for k in n],
+                [torch.randint(0, 3, (k,), generator=g) for k in n])
+
+    def submit(self, hosts):
+        out, self.prev = self.prev, self.result_of(self.rank, self.k, self.sweeps)
+        self.k += 1
+        return out
+
+    def flush(self):
+        out, self.prev = self.prev, None
+        return out
+
+
+class _StubLogits:
+    """bench.py --stub: stand-in for ml3d.engine.KPConvPipeline -- logits [n, 8] with a rank- and step-dependent n."""
+    compute = None
+
+    class _Res:
+        def __init__(self, t):
+            self.t = t
+
+        def wait(self):
+            return self.t
+
+    def __init__(self, rank):
+        self.rank, self.k, self.prev = rank, 0, None
+
+    @staticmethod
+    def logits_of(rank, step):
+        g = torch.Generator().manual_seed(1299709 * rank + step)
+        return torch.rand((500 + 41 * rank + 13 * step, 8), generator=g)
+
+    def submit(self, pts, lens):
+        out, self.prev = self.prev, self._Res(self.logits_of(self.rank, self.k))
+        self.k += 1
+        return out
+
+    def flush(self):
+        out, self.prev = self.prev, None
+        return out
+
+
+def _stub_line(name, units, args, world, dt, checked):
+    return {"stub": True, "metric": "NOT A MEASUREMENT: bench.py --stub --workload %s (N > 1 step logic on CPU tensors over gloo)" % name,
+            "value": units * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "scaling": "weak", "gathered_ranks_checked": checked}
+
+
 def run_pointpillars(args, rank, world, dev, dist):
-    import synth_data
-    from ml3d import ops
     from ml3d import dist as mdist
-    from ml3d.torch.models.point_pillars import PointPillars
-    import synth_weights as W
-    cfg = W.POINTPILLARS_KITTI_CFG
-    B = args.frames_per_step if args.frames_per_step != 64 else 16    # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
-    sd = W.pointpillars_state_dict(cfg, 2024)
-    m = PointPillars(device=dev, **cfg)
-    m.load_state_dict(sd)
-    clouds_np = [W.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
-    # what a data loader hands over: pinned HOST sweeps; their upload is part of every timed step
-    hosts = [torch.from_numpy(c).pin_memory() for c in clouds_np]
-    n_boxes = [0]
-    overlap = not getattr(args, "no_overlap", False)
-    from ml3d.engine import PointPillarsStream
     import os
-    # ML3D_PP_LANES (A/B knob, default 2): the step's sweeps are dealt to this many independent pipelines (own HIP streams) --
-    # while one lane's convolution drains its last, partly filled round of tiles the other lane's kernels fill the idle CUs
-    lanes = max(1, min(B, int(os.environ.get("ML3D_PP_LANES", "2"))))
-    pipe = PointPillarsStream(m, dev, lanes=lanes)
+    stub = bool(getattr(args, "stub", False))
+    B = args.frames_per_step if args.frames_per_step != 64 else 16    # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
+    n_boxes = [0]
+    last = [None, 0]            # (what rank 0 received for the last delivered step, number of delivered steps)
+    overlap = not getattr(args, "no_overlap", False)
+    if stub:
+        hosts, pipe = None, _StubDetections(rank, B)
+    else:
+        import synth_data
+        from ml3d import ops
+        from ml3d.torch.models.point_pillars import PointPillars
+        import synth_weights as W
+        cfg = W.POINTPILLARS_KITTI_CFG
+        sd = W.pointpillars_state_dict(cfg, 2024)
+        m = PointPillars(device=dev, **cfg)
+        m.load_state_dict(sd)
+        clouds_np = [W.crop_for_cfg(synth_data.kitti_sweep(rank * 100 + i), cfg) for i in range(B)]
+        # what a data loader hands over: pinned HOST sweeps; their upload is part of every timed step (SURVEY.md §8d)
+        hosts = [torch.from_numpy(c).pin_memory() for c in clouds_np]
+        from ml3d.engine import PointPillarsStream
+        # ML3D_PP_LANES (A/B knob, default 2): the step's sweeps are dealt to this many independent pipelines (own HIP streams)
+        # -- while one lane's convolution drains its last, partly filled round of tiles the other lane's kernels fill the idle CUs
+        lanes = max(1, min(B, int(os.environ.get("ML3D_PP_LANES", "2"))))
+        pipe = PointPillarsStream(m, dev, lanes=lanes)
 
     def deliver(res):
         """a step's detections (host tensors): counted; N > 1: every rank's [n_i, 9] rows -> rank 0 (the ragged gather)"""
@@ -125,7 +194,8 @@ def run_pointpillars(args, rank, world, dev, dist):
         n_boxes[0] = sum(int(b.shape[0]) for b in boxes)
         if world > 1:
             rows = torch.cat([torch.cat([b, s[:, None], l[:, None].to(b.dtype)], 1) for b, s, l in zip(boxes, scores, labels)])
-            mdist.gather_ragged(rows.reshape(-1).to(dev), dst=0)
+            last[0] = mdist.gather_ragged(rows.reshape(-1).to(dev), dst=0)
+        last[1] += 1
 
     def step():
         # upload (copy stream) -> voxelize / pillar features / backbone / heads -> batched box decode + rotated NMS
@@ -140,6 +210,16 @@ def run_pointpillars(args, rank, world, dev, dist):
     dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     deliver(pipe.flush())
+    if stub:
+        if rank == 0 and world > 1:
+            # rank 0 must hold every rank's rows of the last delivered step, each at that rank's own length
+            k = last[1] - 1
+            assert len(last[0]) == world
+            for r in range(world):
+                b, sc, lb = _StubDetections.result_of(r, k, B)
+                want = torch.cat([torch.cat([x, y[:, None], z[:, None].to(x.dtype)], 1) for x, y, z in zip(b, sc, lb)]).reshape(-1)
+                assert torch.equal(last[0][r], want), "rank %d's detections did not arrive intact" % r
+        return _stub_line("pointpillars", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
     # the conv roofline: SECOND's second convolution (3x3 64 -> 64, stride 1, 248 x 216), timed with HIP events on its launch
     # stream in five forwards after the timed region
@@ -189,31 +269,38 @@ def run_pointpillars(args, rank, world, dev, dist):
 
 
 def run_kpconv(args, rank, world, dev, dist):
-    import synth_data
-    from ml3d import ops
     from ml3d import dist as mdist
-    from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
-    import synth_weights as W
-    cfg = dict(W.TORONTO3D_CFG)
+    import os
+    stub = bool(getattr(args, "stub", False))
     # spheres per step: the batch build is launch/latency-bound (~550 small launches + 9 host read-backs per batch whatever
     # its size), so throughput follows the batch (round 2, pipelined: 16 -> 3219, 32 -> 4400, 48 -> 4748, 63 -> 5002 spheres/s)
     B = args.frames_per_step                               # 64 spheres per step by default, like the RandLA line
-    sd = W.kpconv_state_dict(cfg, 2024)
-    m = KPFCNN(**cfg, device=dev)
-    m.load_state_dict(sd)
-    spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
-    lens = [len(s) for s in spheres]
-    host_pts = torch.from_numpy(np.concatenate(spheres)).pin_memory()     # the stacked spheres of a step arrive from the HOST
-    pts = host_pts.to(dev)
-    np.random.seed(0)
     overlap = not getattr(args, "no_overlap", False)
-    from ml3d.engine import KPConvPipeline
-    import os
-    pipe = KPConvPipeline(m, cfg, dev, threaded=os.environ.get("ML3D_KP_THREADED", "0") == "1")      # (A/B knob)
+    last = [None, 0]
+    if stub:
+        host_pts, lens, pipe = torch.zeros((4, 3)), [4], _StubLogits(rank)
+    else:
+        import synth_data
+        from ml3d import ops
+        from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+        import synth_weights as W
+        cfg = dict(W.TORONTO3D_CFG)
+        sd = W.kpconv_state_dict(cfg, 2024)
+        m = KPFCNN(**cfg, device=dev)
+        m.load_state_dict(sd)
+        spheres = [synth_data.toronto3d_sphere(rank * 100 + i) for i in range(B)]
+        lens = [len(s) for s in spheres]
+        host_pts = torch.from_numpy(np.concatenate(spheres)).pin_memory()     # the stacked spheres of a step arrive from the HOST
+        pts = host_pts.to(dev)
+        np.random.seed(0)
+        from ml3d.engine import KPConvPipeline
+        pipe = KPConvPipeline(m, cfg, dev)
 
     def finish(res):
         if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)
-            mdist.gather_ragged(torch.argmax(res.wait(), 1).to(torch.uint8), dst=0)
+            last[0] = mdist.gather_ragged(torch.argmax(res.wait(), 1).to(torch.uint8), dst=0)
+        if res is not None:
+            last[1] += 1
 
     def step():
         pts = host_pts.to(dev, non_blocking=True)              # H2D inside the timed step
@@ -230,6 +317,14 @@ def run_kpconv(args, rank, world, dev, dist):
     dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     finish(pipe.flush())
+    if stub:
+        if rank == 0 and world > 1:
+            k = last[1] - 1
+            assert len(last[0]) == world
+            for r in range(world):
+                want = torch.argmax(_StubLogits.logits_of(r, k), 1).to(torch.uint8)
+                assert torch.equal(last[0][r], want), "rank %d's labels did not arrive intact" % r
+        return _stub_line("kpconv", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
     # the block roofline: the first resnet block's KPConv (32 -> 32 on the full-resolution layer), timed with HIP events on its
     # launch stream in five SEQUENTIAL steps after the timed region (inside the pipeline it shares the GPU with the next build)
