@@ -550,10 +550,26 @@ class KPFCNN(nn.Module):
         return False
 
     def get_optimizer(self, cfg_pipeline):
-        raise NotImplementedError("KPFCNN (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """kpconv.py:293-313: SGD with a separate learning rate for the deformable offsets' parameters."""
+        deform = [v for k, v in self.named_parameters() if 'offset' in k]
+        other = [v for k, v in self.named_parameters() if 'offset' not in k]
+        optimizer = torch.optim.SGD([{'params': other}, {'params': deform, 'lr': cfg_pipeline.learning_rate * cfg_pipeline.deform_lr_factor}],
+                                    lr=cfg_pipeline.learning_rate, momentum=cfg_pipeline.momentum, weight_decay=cfg_pipeline.weight_decay)
+        return optimizer, torch.optim.lr_scheduler.ExponentialLR(optimizer, cfg_pipeline.scheduler_gamma)
 
     def get_loss(self, Loss, results, inputs, device):
-        raise NotImplementedError("KPFCNN (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """kpconv.py:315-351 for rigid architectures: class-weighted cross entropy over the non-ignored points; the
+        regulariser of the deformable offsets (kpconv.py:2167-2206) needs the per-layer ``min_d2`` / deformed kernel points of
+        a training forward, which the fused inference kernels do not materialise -> refused for deformable configs."""
+        from ..modules import valid_scores_and_labels
+        cfg = self.cfg
+        if any('deformable' in b for b in cfg.architecture):
+            raise NotImplementedError("KPFCNN (MI355X build): the offset regulariser of deformable blocks is training-side "
+                                      "state the inference kernels do not produce (SURVEY.md §8 f4)")
+        scores, labels = valid_scores_and_labels(results, inputs['data'].labels, cfg.num_classes, cfg.ignored_label_inds, device)
+        self.output_loss = Loss.weighted_CrossEntropyLoss(scores, labels)
+        self.reg_loss = torch.zeros((), device=scores.device)
+        return self.output_loss + self.reg_loss, labels, scores
 
 
 class KPConvBatch:

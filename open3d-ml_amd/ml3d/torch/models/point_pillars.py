@@ -279,6 +279,10 @@ class PointPillars(nn.Module):
         self.backbone = SECOND(**backbone)
         self.neck = SECONDFPN(**neck)
         self.bbox_head = Anchor3DHead(num_classes=len(self.classes), **head)
+        from ..modules import CrossEntropyLoss, FocalLoss, SmoothL1Loss          # (parameter-free: the state dict is unchanged)
+        self.loss_cls = FocalLoss(**loss.get("focal", {}))
+        self.loss_bbox = SmoothL1Loss(**loss.get("smooth_l1", {}))
+        self.loss_dir = CrossEntropyLoss(**loss.get("cross_entropy", {}))
         self.device = torch.device(device) if isinstance(device, str) else device
         self._packed = None
         self.eval()
@@ -469,10 +473,47 @@ class PointPillars(nn.Module):
     inference_preprocess = inference_begin
 
     def get_optimizer(self, cfg):
-        raise NotImplementedError("PointPillars (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """point_pillars.py:135-137."""
+        return torch.optim.AdamW(self.parameters(), **cfg), None
 
     def get_loss(self, results, inputs):
-        raise NotImplementedError("PointPillars (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """point_pillars.py:140-205: focal classification loss over the positive + negative anchors, smooth-L1 box loss with the
+        sine-difference yaw term and the two-bin direction loss over the positives, each averaged by the number of positives.
+        ``results`` = the three head maps of ``forward``; ``inputs.labels`` / ``inputs.bboxes`` = per-sample ground truth
+        (``ObjectDetectBatch``).  Runs on the maps' device; the validation pass of the reference's ``ObjectDetection.run_valid``
+        calls it under ``no_grad`` (object_detection.py:190-193).  Gradients flow into the head maps only as far as the forward
+        that produced them is differentiable -- the fused HIP forward is inference-only."""
+        from ..modules import assign_anchor_targets
+        scores, bboxes, dirs = results
+        head = self.bbox_head
+        nc, R = head.num_classes, len(head.rotations)
+        dev = scores.device
+        gt_boxes = [b.to(dev) for b in inputs.bboxes]
+        gt_labels = torch.cat([l.to(dev) for l in inputs.labels], 0)
+        anchors = head._anchors_for(tuple(bboxes.shape[-2:]), dev)
+        target_deltas, target_idx, pos_idx, neg_idx = assign_anchor_targets(anchors, nc, R, head.iou_thr, gt_boxes)
+        avg_factor = pos_idx.size(0)
+        scores = scores.permute(0, 2, 3, 1).reshape(-1, nc)
+        target_labels = torch.full((scores.size(0),), nc, device=dev, dtype=gt_labels.dtype)
+        target_labels[pos_idx] = gt_labels[target_idx]
+        used = torch.cat([pos_idx, neg_idx], 0)
+        loss_cls = self.loss_cls(scores[used], target_labels[used], avg_factor=avg_factor)
+        ok = (target_labels[pos_idx] >= 0) & (target_labels[pos_idx] < nc)          # ground truth of classes the head does not model
+        pos_idx, target_idx, target_deltas = pos_idx[ok], target_idx[ok], target_deltas[ok]
+        bboxes = bboxes.permute(0, 2, 3, 1).reshape(-1, head.box_code_size)[pos_idx]
+        dirs = dirs.permute(0, 2, 3, 1).reshape(-1, 2)[pos_idx]
+        if len(pos_idx) > 0:
+            yaw = torch.cat(gt_boxes, 0)[target_idx][:, -1]
+            yaw = yaw - torch.floor(yaw / (2 * np.pi)) * (2 * np.pi)                  # into [0, 2 pi)
+            loss_dir = self.loss_dir(dirs, (yaw / np.pi).long() % 2, avg_factor=avg_factor)
+            # sin(a - b) = sin a cos b - cos a sin b, split over prediction and target
+            r_pred = torch.sin(bboxes[:, -1:]) * torch.cos(target_deltas[:, -1:])
+            r_tgt = torch.cos(bboxes[:, -1:]) * torch.sin(target_deltas[:, -1:])
+            loss_bbox = self.loss_bbox(torch.cat([bboxes[:, :-1], r_pred], -1), torch.cat([target_deltas[:, :-1], r_tgt], -1),
+                                       avg_factor=avg_factor)
+        else:
+            loss_cls, loss_bbox, loss_dir = loss_cls.sum(), bboxes.sum(), dirs.sum()
+        return {'loss_cls': loss_cls, 'loss_bbox': loss_bbox, 'loss_dir': loss_dir}
 
 
 class DetectedBox:

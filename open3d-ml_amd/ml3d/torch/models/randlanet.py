@@ -297,7 +297,14 @@ class RandLANet(nn.Module):
         return False
 
     def get_optimizer(self, cfg_pipeline):
-        raise NotImplementedError("RandLANet (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """randlanet.py:352-357."""
+        optimizer = torch.optim.Adam(self.parameters(), **cfg_pipeline.optimizer)
+        return optimizer, torch.optim.lr_scheduler.ExponentialLR(optimizer, cfg_pipeline.scheduler_gamma)
 
     def get_loss(self, Loss, results, inputs, device):
-        raise NotImplementedError("RandLANet (MI355X build): inference only; training stays on the reference (SURVEY.md §8 f4)")
+        """randlanet.py:359-380: class-weighted cross entropy (``Loss`` = the pipeline's ``SemSegLoss``) over the points whose
+        label is not ignored.  Returns (loss, labels, scores)."""
+        from ..modules import valid_scores_and_labels
+        cfg = self.cfg
+        scores, labels = valid_scores_and_labels(results, inputs['data']['labels'], cfg.num_classes, cfg.ignored_label_inds, device)
+        return Loss.weighted_CrossEntropyLoss(scores, labels), labels, scores

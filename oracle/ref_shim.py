@@ -131,8 +131,8 @@ def install():
     o3d.core = core
     ml = mod("open3d.ml")
     ml.contrib = mod("open3d.ml.contrib", subsample=oops.subsample, subsample_batch=oops.subsample_batch,
-                     iou_bev_cpu=_unsupported, iou_3d_cpu=_unsupported, iou_bev_cuda=_unsupported,
-                     iou_3d_cuda=_unsupported)
+                     iou_bev_cpu=oops.iou_bev, iou_3d_cpu=oops.iou_3d, iou_bev_cuda=oops.iou_bev,
+                     iou_3d_cuda=oops.iou_3d)
     mlt = mod("open3d.ml.torch")
     mlt.ops = mod("open3d.ml.torch.ops", voxelize=t_voxelize, ragged_to_dense=t_ragged_to_dense, nms=t_nms,
                   knn_search=_unsupported, reduce_subarrays_sum=_unsupported, roi_pool=_unsupported,

@@ -157,3 +157,98 @@ def test_nms_rotated():
     assert ops.nms(boxes, scores, 0.3).tolist() == [0, 2]
     assert ops.nms(boxes, scores, 0.99).tolist() == [0, 1, 2]   # box 3 == box 0 rotated by 90 deg: IoU 1
     assert ops.nms(boxes[:0], scores[:0], 0.5).tolist() == []
+
+
+# ---- rotated IoU / NMS pinned to an INDEPENDENT float64 construction ---------------------------------------
+# The oracle clips polygons (Sutherland-Hodgman, float32); here the intersection of two rotated rectangles is the polytope of
+# their eight half-planes: Chebyshev centre by linear programming (scipy.optimize.linprog) -> scipy.spatial.HalfspaceIntersection
+# (Qhull's dual construction) -> ConvexHull.volume (= area in 2-D).  Nothing is shared with the oracle but the box convention
+# (x0, y0, x1, y1, yaw about the centre: objdet_helper.py:316-350 hands ``bev[:, [0, 1, 2, 3, 4]]`` to open3d's nms).
+def _halfplanes(box):
+    x0, y0, x1, y1, r = [float(v) for v in box]
+    c = np.array([(x0 + x1) / 2, (y0 + y1) / 2])
+    hw, hh = (x1 - x0) / 2, (y1 - y0) / 2
+    u, v = np.array([np.cos(r), np.sin(r)]), np.array([-np.sin(r), np.cos(r)])
+    # n . p <= n . c + half extent, for the four outward normals
+    return np.array([[u[0], u[1], -(u @ c) - hw], [-u[0], -u[1], (u @ c) - hw],
+                     [v[0], v[1], -(v @ c) - hh], [-v[0], -v[1], (v @ c) - hh]])
+
+
+def _iou_f64(a, b):
+    from scipy.optimize import linprog
+    from scipy.spatial import ConvexHull, HalfspaceIntersection
+    hs = np.concatenate([_halfplanes(a), _halfplanes(b)])
+    # Chebyshev centre: maximise t s.t. n . p + t <= -offset (unit normals)
+    res = linprog([0, 0, -1], A_ub=np.c_[hs[:, :2], np.ones(8)], b_ub=-hs[:, 2], bounds=[(None, None), (None, None), (0, None)])
+    inter = 0.0
+    if res.status == 0 and res.x[2] > 1e-9:
+        inter = ConvexHull(HalfspaceIntersection(hs, res.x[:2]).intersections).volume
+    area = lambda q: (float(q[2]) - float(q[0])) * (float(q[3]) - float(q[1]))
+    return inter / (area(a) + area(b) - inter), inter
+
+
+def _random_boxes(rng, n, spread):
+    c = rng.uniform(-spread, spread, (n, 2))
+    wh = rng.uniform(0.4, 4.5, (n, 2))
+    return np.concatenate([c - wh / 2, c + wh / 2, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)
+
+
+def test_rotated_iou_matches_an_independent_float64_halfspace_construction():
+    rng = np.random.default_rng(31)
+    a, b = _random_boxes(rng, 1000, 2.5), _random_boxes(rng, 1000, 2.5)
+    worst, overlapping = 0.0, 0
+    for i in range(1000):
+        got = float(ops.lib().ml3d_oracle_iou_bev(ops._p(np.ascontiguousarray(a[i])), ops._p(np.ascontiguousarray(b[i]))))
+        ref, inter = _iou_f64(a[i], b[i])
+        overlapping += inter > 1e-3
+        worst = max(worst, abs(got - ref))
+    assert overlapping > 400                       # the sample really exercises partial overlaps, not just disjoint pairs
+    assert worst <= 1e-5, worst
+
+
+def test_pairwise_iou_bev_and_iou_3d_match_the_float64_construction():
+    rng = np.random.default_rng(32)
+    n, m = 24, 30
+    # mAP.py:85-88 conventions: bev boxes (x, z, w, l, yaw); 3-D boxes (x, y, z, w, h, l, yaw), y = bottom face, y axis down
+    A = np.c_[rng.uniform(-4, 4, (n, 3)), rng.uniform(0.5, 4, (n, 3)), rng.uniform(-3, 3, n)].astype(np.float32)
+    B = np.c_[rng.uniform(-4, 4, (m, 3)), rng.uniform(0.5, 4, (m, 3)), rng.uniform(-3, 3, m)].astype(np.float32)
+    bev = ops.iou_bev(A[:, [0, 2, 3, 5, 6]], B[:, [0, 2, 3, 5, 6]])
+    vol = ops.iou_3d(A, B)
+
+    def corner(q):
+        return np.array([q[0] - q[3] / 2, q[2] - q[5] / 2, q[0] + q[3] / 2, q[2] + q[5] / 2, q[6]], np.float64)
+    for i in range(n):
+        for j in range(m):
+            iou2, inter = _iou_f64(corner(A[i]), corner(B[j]))
+            assert abs(float(bev[i, j]) - iou2) <= 1e-5
+            # heights: the box spans [y - h, y] (y = bottom, axis pointing down)
+            top = max(float(A[i, 1]) - float(A[i, 4]), float(B[j, 1]) - float(B[j, 4]))
+            bot = min(float(A[i, 1]), float(B[j, 1]))
+            iv = inter * max(0.0, bot - top)
+            va, vb = float(A[i, 3] * A[i, 4] * A[i, 5]), float(B[j, 3] * B[j, 4] * B[j, 5])
+            assert abs(float(vol[i, j]) - iv / (va + vb - iv)) <= 1e-5
+
+
+def test_nms_keep_lists_match_a_greedy_loop_over_the_float64_iou():
+    rng = np.random.default_rng(33)
+    for trial, (n, thr) in enumerate([(90, 0.01), (90, 0.3), (110, 0.5), (60, 0.7)]):
+        boxes = _random_boxes(rng, n, 6.0)
+        scores = rng.random(n).astype(np.float32)
+        iou = np.zeros((n, n))
+        for i in range(n):
+            for j in range(i + 1, n):
+                iou[i, j] = iou[j, i] = _iou_f64(boxes[i], boxes[j])[0]
+        # a pair within 1e-5 of the threshold can legitimately fall either way in float32: one box of each such pair leaves
+        amb = np.unique(np.nonzero(np.triu((np.abs(iou - thr) < 1e-5) & (iou > 0)))[0])
+        if amb.size:
+            sel = np.setdiff1d(np.arange(n), amb)
+            boxes, scores, iou, n = boxes[sel], scores[sel], iou[np.ix_(sel, sel)], sel.size
+        assert n >= 50
+        order = np.argsort(-scores, kind="stable")
+        keep, dead = [], np.zeros(n, bool)
+        for i in order:
+            if dead[i]:
+                continue
+            keep.append(int(i))
+            dead |= iou[i] > thr
+        assert ops.nms(boxes, scores, thr).tolist() == keep, trial
