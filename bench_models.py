@@ -207,7 +207,16 @@ def run_pointpillars(args, rank, world, dev, dist):
             outs = m([h.to(dev, non_blocking=True) for h in hosts])
             deliver(tuple([t.cpu() for t in lst] for lst in m.bbox_head.get_bboxes(*outs)))
     iv = []
-    dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
+    # the roofline kernel, timed IN the timed region: SECOND's second convolution (3x3 64 -> 64, stride 1, 248 x 216) of the
+    # first lane's forward of every step -- the launch shape the timed path issues (B / lanes sweeps), with the other lane
+    # co-running, bracketed by HIP events on the lane's own compute stream (the stream the kernel is launched on)
+    timer = None if stub else _CallTimer(ops, "conv2d_nhwc", 1)
+    timed_step = step
+    if timer is not None:
+        def timed_step():
+            timer.new_step()
+            step()
+    dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     deliver(pipe.flush())
     if stub:
@@ -221,21 +230,28 @@ def run_pointpillars(args, rank, world, dev, dist):
                 assert torch.equal(last[0][r], want), "rank %d's detections did not arrive intact" % r
         return _stub_line("pointpillars", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
-    # the conv roofline: SECOND's second convolution (3x3 64 -> 64, stride 1, 248 x 216), timed with HIP events on its launch
-    # stream in five forwards after the timed region
-    clouds = [h.to(dev) for h in hosts]
-    timer = _CallTimer(ops, "conv2d_nhwc", 1)
-    for _ in range(5):
-        timer.new_step()
-        m(clouds)
-        torch.cuda.synchronize()
     timer.restore()
+    in_region = timer.samples_ms()[args.warmup:]            # (the warm-up steps' launches are not part of the figure)
+    shapes = timer.shapes
+    # the same convolution ALONE on the GPU, as a whole-batch launch and as a lane-shaped one: what the co-running lane costs it
+    clouds = [h.to(dev) for h in hosts]
+    alone = {}
+    for tag, sub in (("lane", clouds[:max(1, B // lanes)] if overlap else clouds), ("batch", clouds)):
+        t2 = _CallTimer(ops, "conv2d_nhwc", 1)
+        for _ in range(5):
+            t2.new_step()
+            m(sub)
+            torch.cuda.synchronize()
+        t2.restore()
+        alone[tag] = t2.mean_ms()
     if rank != 0:
         return None
-    (x, w, *_), y = timer.shapes
+    (x, w, *_), y = shapes
     Bm, OH, OW, Co = y.shape
     flops = 2.0 * Bm * OH * OW * Co * w.shape[0]
-    ms = timer.mean_ms()
+    ms = float(np.mean(in_region))
+    # the whole forward's algorithmic flops (68.3 GFLOP per KITTI frame through backbone + neck + heads)
+    e2e_tflops = 68.3e9 * (B * args.steps * world / dt) / world / 1e12
     out = {"metric": "point-cloud frames/sec (PointPillars KITTI inference: voxelize + pillar features + BEV backbone + heads)",
            "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_median": float(np.median(iv)),
@@ -250,7 +266,14 @@ def run_pointpillars(args, rank, world, dev, dist):
            "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                        "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops}}
+                        "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops,
+                        "sweeps_per_launch": int(Bm), "launches_timed": len(in_region),
+                        "timed": "inside the timed region, on the lane's compute stream, the other lane co-running",
+                        "avg_launch_ms_alone_lane_shape": alone["lane"], "avg_launch_ms_alone_whole_batch": alone["batch"],
+                        "frac_alone_whole_batch": 2.0 * B * OH * OW * Co * w.shape[0] / (alone["batch"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        "end_to_end_tflops": e2e_tflops, "end_to_end_frac": e2e_tflops / PEAK_F32_TFLOPS,
+                        "end_to_end_note": "68.3 GFLOP per frame (SURVEY.md §8d) x frames/s per GPU: every kernel of the step, "
+                                           "H2D, voxelize, decode and NMS included"}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import pointpillars_ref as P          # the checker, used here only as the timed CPU baseline
         pts = [torch.from_numpy(c) for c in clouds_np[:1]]
@@ -314,7 +337,16 @@ def run_kpconv(args, rank, world, dev, dist):
             if world > 1:
                 mdist.gather_ragged(torch.argmax(logits, 1).to(torch.uint8), dst=0)
     iv = []
-    dt = _timed(step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
+    # the roofline op, timed IN the timed region: the first resnet block's KPConv (32 -> 32 on the full-resolution layer) of every
+    # step's forward, bracketed by HIP events on the stream it is launched on (the pipeline's compute stream), the next batch's
+    # build co-running on the other stream
+    timer = None if stub else _CallTimer(ops, "kpconv_rigid", 1)
+    timed_step = step
+    if timer is not None:
+        def timed_step():
+            timer.new_step()
+            step()
+    dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     finish(pipe.flush())
     if stub:
@@ -326,22 +358,30 @@ def run_kpconv(args, rank, world, dev, dist):
                 assert torch.equal(last[0][r], want), "rank %d's labels did not arrive intact" % r
         return _stub_line("kpconv", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
-    # the block roofline: the first resnet block's KPConv (32 -> 32 on the full-resolution layer), timed with HIP events on its
-    # launch stream in five SEQUENTIAL steps after the timed region (inside the pipeline it shares the GPU with the next build)
+    timer.restore()
+    in_region = timer.samples_ms()[max(0, args.warmup - 1):]     # (the pipeline runs a step's forward one submit later)
+    shapes = timer.shapes
+    # the same op with nothing else on the GPU: five SEQUENTIAL steps after the timed region
     m(KPConvBatch(pts, lens, cfg, device=dev))           # (untimed: the caller-stream allocator pool is cold after a pipelined run)
     torch.cuda.synchronize()
-    timer = _CallTimer(ops, "kpconv_rigid", 1)
+    t2 = _CallTimer(ops, "kpconv_rigid", 1)
     for _ in range(5):
-        timer.new_step()
+        t2.new_step()
         m(KPConvBatch(pts, lens, cfg, device=dev))
         torch.cuda.synchronize()
-    timer.restore()
+    t2.restore()
     if rank != 0:
         return None
-    (q, s, inds, x, kp, w, *_), y = timer.shapes
+    (q, s, inds, x, kp, w, *_), y = shapes
     nq, H, cin, cout = q.shape[0], inds.shape[1], x.shape[1], y.shape[1]
-    flops = nq * (2.0 * 15 * H * cin + 2.0 * 15 * cin * cout)
-    ms = timer.mean_ms()
+    # EXECUTED flops: the dense index matrix is padded with shadow entries up to the longest row of the batch (H columns);
+    # the aggregation kernel stops at a row's last real neighbour, so a row costs its REAL length (sum over the rows below),
+    # not H.  `frac` prices that; `frac_reference_formulation` the reference's dense [N, H] formulation (kpconv.py:1105-1118).
+    real = int((inds < s.shape[0]).sum().item())
+    flops_exec = 2.0 * 15 * real * cin + nq * 2.0 * 15 * cin * cout
+    flops_dense = nq * (2.0 * 15 * H * cin + 2.0 * 15 * cin * cout)
+    ms = float(np.mean(in_region))
+    flops = flops_exec
     out = {"metric": "point-cloud spheres/sec (KPConv rigid Toronto3D inference: GPU batch build + forward)",
            "value": B * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_median": float(np.median(iv)),
@@ -354,8 +394,15 @@ def run_kpconv(args, rank, world, dev, dist):
            "roofline": {"bound": "mfma", "kernel": "kp_agg_mfma<2> + gemm_tile (KPConv %d->%d, %d queries x %d neighbour columns)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        "frac_reference_formulation": flops_dense / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "traffic": _traffic("kpconv_block_32_32", B), "avg_launch_ms": ms,
-                        "launch_ms_samples": timer.samples_ms(), "flops_per_launch": flops}}
+                        "executed_flops_per_launch": flops_exec, "reference_flops_per_launch": flops_dense,
+                        "real_neighbours_per_query": real / float(nq), "launches_timed": len(in_region),
+                        "timed": "inside the timed region, on the pipeline's compute stream, the next batch's build co-running",
+                        "avg_launch_ms_alone": t2.mean_ms(),
+                        "frac_alone": flops_exec / (t2.mean_ms() * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        # the op's ALGORITHMIC HBM bytes: index matrix + positions + feature rows in, output rows out
+                        "algorithmic_bytes_per_launch": 4.0 * nq * H + 12.0 * (nq + s.shape[0]) + 4.0 * cin * s.shape[0] + 4.0 * cout * nq}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline
         sp = spheres[0]
