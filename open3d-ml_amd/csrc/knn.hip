@@ -47,220 +47,119 @@ struct QuerySrc {
 // and four selects.  d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on
 // gfx950).  Measured (tools/micro/valu_rates.hip, profiles/r02_micro_valu_rates.log): v_min_f64 / v_max_f64 issue at the
 // rate of v_min_u32; the integer form (v_cmp_lt_u64 + 4 v_cndmask) is 7.6x slower.
-// The `if` costs 16 v_mov_b64 of phi copies at its join on top of the 31 min / max of an insertion (ISA listing).  Round 3 tried
-// the BRANCHLESS form (KNN_BRANCHLESS=1: an EMPTY key leaves the list as it is, slots past a run carry EMPTY): 146 instead of
-// ~190 VALU instructions per group of three candidates -- and the launch got SLOWER, 1.97 ms against 1.62 ms alone, 5657
-// against 5808 frames/s (gpurun_out/r3m, same box, two runs each): waves DO skip the chain often enough (once the list is
-// tight most candidates of all 64 lanes fail the test), and an unconditional chain pays 32 f64 operations for every one of them.
-#ifndef KNN_BRANCHLESS
-#define KNN_BRANCHLESS 0        // build-time A/B switch (tools/build_variant.sh)
-#endif
+// (Measured and removed, numbers in DESIGN.md §3.2: a branchless insertion, a pending queue merged by sorting networks, an
+// LDS-transposed index store.)
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
-#if KNN_BRANCHLESS
-    best[K - 1] = key_min(best[K - 1], key);
-#pragma unroll
-    for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
-#else
     if (key < best[K - 1]) {
         best[K - 1] = key;
 #pragma unroll
         for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
     }
-#endif
 }
 
-// ---- pending queue (K = 16, round 3; measured, OFF by default) ---------------------------------------------------------------
-// An insertion chain is 31 f64 operations (+16 moves) and the wave runs it whenever ANY of its 64 lanes accepts the candidate.
-// Instead a lane PARKS an accepted key (key < its current 16th) in a lane-private LDS column of KNN_QD slots -- one predicated
-// ds_write_b64 -- and the wave merges all queues into the lists only when some lane's queue is nearly full: sort the 8 pending
-// keys (19 compare-exchanges), half-cleaner against the upper half of the list, two bitonic merges = 63 compare-exchanges + 8
-// minima = 134 f64 operations for up to 8 keys per lane instead of 8 x 47.  The 16th is stale between flushes (too large), so a
-// key the exact search needs is never rejected; the queues are flushed before every stop test.  Bit-exact on the emulator and
-// on the MI355X (tests/test_emulated_prims.py builds this variant; tests/test_gpu_knn.py passed with it).
-// Measured (profiles/r03_pmc_knn_queue.csv, gpurun_out/r3z, r3aa): 597 M instead of 729 M VALU wave-instructions per launch --
-// only -18 %: the chain ran in ~30 % of the wave's candidate steps, not in all of them (the lanes' runs differ in length: a
-// wave makes ~410 candidate steps for ~150 candidates per lane, and most steps serve few lanes) -- 1.60 ms against 1.76 ms
-// alone at five waves per SIMD (the flush needs 96 registers; at six it spills: 2.5 ms), 2.0-2.3 against 2.55 ms under the
-// forward, but 5777 / 5787 against 5812 frames/s and 5844 against 5893 in a second call: the 16 KB of LDS per workgroup and the
-// lower occupancy cost the forward what the search gains.  KNN_QUEUE=1 builds it (tools/build_variant.sh).
-#ifndef KNN_QUEUE
-#define KNN_QUEUE 0            // build-time A/B switch: 1 = pending queue, 0 = insertion chain per candidate (default)
-#endif
-constexpr int KNN_QD = 8;      // pending keys per lane; slot s of thread t lives at q[s * 256 + t] (conflict-free columns)
-
-#define ML3D_CE(a, b) key_minmax(a, b, a, b)
-__device__ __forceinline__ void sort8_keys(double (&v)[8]) {      // Batcher's odd-even merge sort, 19 compare-exchanges
-    ML3D_CE(v[0], v[1]); ML3D_CE(v[2], v[3]); ML3D_CE(v[4], v[5]); ML3D_CE(v[6], v[7]);
-    ML3D_CE(v[0], v[2]); ML3D_CE(v[1], v[3]); ML3D_CE(v[4], v[6]); ML3D_CE(v[5], v[7]);
-    ML3D_CE(v[1], v[2]); ML3D_CE(v[5], v[6]);
-    ML3D_CE(v[0], v[4]); ML3D_CE(v[1], v[5]); ML3D_CE(v[2], v[6]); ML3D_CE(v[3], v[7]);
-    ML3D_CE(v[2], v[4]); ML3D_CE(v[3], v[5]);
-    ML3D_CE(v[1], v[2]); ML3D_CE(v[3], v[4]); ML3D_CE(v[5], v[6]);
-}
-// b[o .. o + 7] bitonic -> ascending (12 compare-exchanges)
-template <int O>
-__device__ __forceinline__ void bitonic8_keys(double (&b)[16]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ML3D_CE(b[O + i], b[O + i + 4]);
-#pragma unroll
-    for (int s = 0; s < 8; s += 4) { ML3D_CE(b[O + s], b[O + s + 2]); ML3D_CE(b[O + s + 1], b[O + s + 3]); }
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) ML3D_CE(b[O + s], b[O + s + 1]);
-}
-// merge the lane's pending keys into its sorted list; the queue comes back empty (every slot EMPTY)
-__device__ __forceinline__ void topk_flush(double (&best)[16], double* __restrict__ q, int& cnt) {
-    const double empty = __longlong_as_double((long long)KEY_EMPTY);
-    double v[KNN_QD];
-#pragma unroll
-    for (int s = 0; s < KNN_QD; ++s) v[s] = q[s * 256];
-#pragma unroll
-    for (int s = 0; s < KNN_QD; ++s) q[s * 256] = empty;
-    cnt = 0;
-    sort8_keys(v);
-    // the 16 smallest of list + pending = list[0..7] and the 8 smallest of list[8..15] + pending (half-cleaner: ascending
-    // against descending is bitonic, the element-wise minima are its lower half)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) best[8 + i] = key_min(best[8 + i], v[7 - i]);
-    bitonic8_keys<8>(best);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ML3D_CE(best[i], best[15 - i]);
-    bitonic8_keys<0>(best);
-    bitonic8_keys<8>(best);
-}
-#undef ML3D_CE
-
-#ifndef KNN_GROUP
-#define KNN_GROUP 3
-#endif
+constexpr int KNN_GROUP = 3;
 
 // SUB: also track the nearest candidate whose index is below n_sub -- the RandLA pyramid's 1-NN interpolation target
 // (level l + 1 is the prefix [:n_sub] of level l, randlanet.py:222-224), found in the same scan as the k-NN
-template <int K, bool SUB, bool QUEUED>
+template <int K, bool SUB>
 __device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
-                                         float qz, double (&best)[K], int n_sub, double& best1,
-                                         double* __restrict__ queue, int& pending) {
+                                         float qz, double (&best)[K], int n_sub, double& best1) {
     int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
-    // per group instead of one per candidate -- the loop is latency-bound: lane-per-query gathers, ~5 waves per SIMD);
-    // indices past the run are clamped to its last point and skipped
+    // per group instead of one per candidate); indices past the run are clamped to its last point and skipped
     for (int p = p0; p < p1; p += KNN_GROUP) {
         float4 c[KNN_GROUP];
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
-        if constexpr (QUEUED) {
-            // room for a whole group in every active lane's queue (one check and ONE flush site per group, under the loads)
-            if (wave_any_active(pending > KNN_QD - KNN_GROUP)) topk_flush(best, queue, pending);
-        }
-        // straight-line: a slot past the run (its load was clamped) carries the EMPTY key, which the insertion ignores -- no
-        // branch, hence no phi copies of the 16-entry list at a join (they were a third of the instructions of an insertion)
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) {
-#if !KNN_BRANCHLESS
             if (!(p + j < p1)) continue;
-#endif
             const float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
             const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
-            const double empty = __longlong_as_double((long long)KEY_EMPTY);
-            const double kd = (p + j < p1) ? __longlong_as_double((long long)key) : empty;
-            if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : empty);
-            if constexpr (QUEUED) {
-                if (kd < best[K - 1]) { queue[pending * 256] = kd; ++pending; }
+            const double kd = __longlong_as_double((long long)key);
+            if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
+            topk_insert<K>(best, kd);
+        }
+    }
+}
+
+// every point outside the box of shell r around cell (cx, cy, cz) is at least this far from the query (inf when the box
+// reaches past the grid on every side: `all`)
+__device__ __forceinline__ float shell_guard(const GridSeg& g, float qx, float qy, float qz, int cx, int cy, int cz, int r,
+                                             bool& all) {
+    const int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
+    all = (cx - r <= 0) && (cx + r >= dxm) && (cy - r <= 0) && (cy + r >= dym) && (cz - r <= 0) && (cz + r >= dzm);
+    float gd = 3.0e38f;
+    if (cx - r > 0) gd = fminf(gd, qx - (g.lo[0] + (float)(cx - r) * g.c));
+    if (cx + r < dxm) gd = fminf(gd, (g.lo[0] + (float)(cx + r + 1) * g.c) - qx);
+    if (cy - r > 0) gd = fminf(gd, qy - (g.lo[1] + (float)(cy - r) * g.c));
+    if (cy + r < dym) gd = fminf(gd, (g.lo[1] + (float)(cy + r + 1) * g.c) - qy);
+    if (cz - r > 0) gd = fminf(gd, qz - (g.lo[2] + (float)(cz - r) * g.c));
+    if (cz + r < dzm) gd = fminf(gd, (g.lo[2] + (float)(cz + r + 1) * g.c) - qz);
+    return gd - g.margin;
+}
+
+// all rows of shell r, one run at a time (the general scan: any K, and the cursor kernel's overflow path)
+template <int K, bool SUB>
+__device__ __forceinline__ void scan_shell(const GridView& G, const GridSeg& g, float qx, float qy, float qz, int cx, int cy,
+                                           int cz, int r, double (&best)[K], int n_sub, double& best1) {
+    const int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
+    const int xa = max(cx - r, 0), xb = min(cx + r, dxm);
+    const int ya = max(cy - r, 0), yb = min(cy + r, dym);
+    const int za = max(cz - r, 0), zb = min(cz + r, dzm);
+    for (int z = za; z <= zb; ++z) {
+        const int az = z > cz ? z - cz : cz - z;
+        for (int y = ya; y <= yb; ++y) {
+            const int ay = y > cy ? y - cy : cy - y;
+            const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+            if (r == 1 || az == r || ay == r) {
+                scan_run<K, SUB>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1);
             } else {
-                topk_insert<K>(best, kd);
+                // (inlined copies of the scan: a one-copy loop over the two end cells costs 9 % -- 1.73 against 1.59 ms alone)
+                if (cx - r >= 0) scan_run<K, SUB>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1);
+                if (cx + r <= dxm) scan_run<K, SUB>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1);
             }
         }
     }
 }
 
-template <int K, bool SUB, bool QUEUED = false>
+template <int K, bool SUB>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
                                         float* __restrict__ out_d2, int64_t t, int n_sub = 0,
-                                        int32_t* __restrict__ out_sub = nullptr, int* __restrict__ stage = nullptr,
-                                        bool vec_store = false, double* __restrict__ queue = nullptr) {
-    // stage: LDS, 64 * 17 + 128 ints per wave of the workgroup, for the transposed store of 16 indices per query (below)
-    const bool transposed = K == 16 && k == 16 && !out_d2 && stage;
-    const bool active = t < Q.n_total;
-    if (!active && !transposed) return;           // (with the transposed store an idle lane of a ragged last wave still
-    int s = 0; int64_t local = 0;                 //  helps to write the rows of the others)
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    int64_t out_row = -1;
-    if (active) {
-        seg_locate(Q.segs, t, s, local);
-        if (Q.sorted_q) {
-            float4 q = Q.sorted_q[t];
-            qx = q.x; qy = q.y; qz = q.z;
-            local = __float_as_int(q.w);
-        } else {
-            const float* p = Q.raw + 3 * (seg_begin_global(Q.segs, s) + local);
-            qx = p[0]; qy = p[1]; qz = p[2];
-        }
-        out_row = seg_begin_packed(Q.segs, s) + local;
+                                        int32_t* __restrict__ out_sub = nullptr, bool vec_store = false) {
+    if (t >= Q.n_total) return;
+    int s = 0; int64_t local = 0;
+    float qx, qy, qz;
+    seg_locate(Q.segs, t, s, local);
+    if (Q.sorted_q) {
+        float4 q = Q.sorted_q[t];
+        qx = q.x; qy = q.y; qz = q.z;
+        local = __float_as_int(q.w);
+    } else {
+        const float* p = Q.raw + 3 * (seg_begin_global(Q.segs, s) + local);
+        qx = p[0]; qy = p[1]; qz = p[2];
     }
+    const int64_t out_row = seg_begin_packed(Q.segs, s) + local;
 
     const GridSeg g = G.segs[s];
     double best[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = __longlong_as_double((long long)KEY_EMPTY);
     double best1 = __longlong_as_double((long long)KEY_EMPTY);
-    int pending = 0;
-    if constexpr (QUEUED) {
-#pragma unroll
-        for (int s_ = 0; s_ < KNN_QD; ++s_) queue[s_ * 256] = __longlong_as_double((long long)KEY_EMPTY);
-    }
 
-    if (active && g.n > 0) {
+    if (g.n > 0) {
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
         int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
         int cz = cell_coord(qz, g.lo[2], g.inv_c, g.dims[2]);
-        int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
         for (int r = 1;; ++r) {
-            int xa = max(cx - r, 0), xb = min(cx + r, dxm);
-            int ya = max(cy - r, 0), yb = min(cy + r, dym);
-            int za = max(cz - r, 0), zb = min(cz + r, dzm);
-            for (int z = za; z <= zb; ++z) {
-                int az = z > cz ? z - cz : cz - z;
-                for (int y = ya; y <= yb; ++y) {
-                    int ay = y > cy ? y - cy : cy - y;
-                    int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-                    if constexpr (QUEUED) {
-                        // a face row of the shell is one run of cells, an inner row its two end cells: ONE inlined copy of the
-                        // scan (three copies -- each with its flush -- did not fit the register budget)
-                        const bool face = r == 1 || az == r || ay == r;
-                        for (int part = 0; part < (face ? 1 : 2); ++part) {
-                            int ca, cb;
-                            if (face) { ca = row + xa; cb = row + xb; }
-                            else if (part == 0) { if (cx - r < 0) continue; ca = cb = row + cx - r; }
-                            else { if (cx + r > dxm) continue; ca = cb = row + cx + r; }
-                            scan_run<K, SUB, QUEUED>(G, ca, cb, qx, qy, qz, best, n_sub, best1, queue, pending);
-                        }
-                    } else if (r == 1 || az == r || ay == r) {
-                        scan_run<K, SUB, QUEUED>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1, queue, pending);
-                    } else {
-                        // (three inlined copies of the scan: the one-copy loop above costs the insertion form 9 % -- 1.73 against
-                        //  1.59 ms alone, gpurun_out/r3af)
-                        if (cx - r >= 0) scan_run<K, SUB, QUEUED>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1, queue, pending);
-                        if (cx + r <= dxm) scan_run<K, SUB, QUEUED>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1, queue, pending);
-                    }
-                }
-            }
-            if constexpr (QUEUED) {          // the stop test reads the EXACT list: merge what is still parked
-                if (wave_any_active(pending > 0)) topk_flush(best, queue, pending);
-            }
+            scan_shell<K, SUB>(G, g, qx, qy, qz, cx, cy, cz, r, best, n_sub, best1);
             // every point outside the scanned box is at least `gd` away (inf when the box face is
             // past the grid).  Stop once the k-th best is strictly inside that radius.
-            bool all = (cx - r <= 0) && (cx + r >= dxm) && (cy - r <= 0) && (cy + r >= dym) &&
-                       (cz - r <= 0) && (cz + r >= dzm);
+            bool all;
+            const float gd = shell_guard(g, qx, qy, qz, cx, cy, cz, r, all);
             if (all) break;
-            float gd = 3.0e38f;
-            if (cx - r > 0) gd = fminf(gd, qx - (g.lo[0] + (float)(cx - r) * g.c));
-            if (cx + r < dxm) gd = fminf(gd, (g.lo[0] + (float)(cx + r + 1) * g.c) - qx);
-            if (cy - r > 0) gd = fminf(gd, qy - (g.lo[1] + (float)(cy - r) * g.c));
-            if (cy + r < dym) gd = fminf(gd, (g.lo[1] + (float)(cy + r + 1) * g.c) - qy);
-            if (cz - r > 0) gd = fminf(gd, qz - (g.lo[2] + (float)(cz - r) * g.c));
-            if (cz + r < dzm) gd = fminf(gd, (g.lo[2] + (float)(cz + r + 1) * g.c) - qz);
-            gd -= g.margin;
             u64 kth = (u64)__double_as_longlong(best[K - 1]);
             if (k < K) {
                 // fewer than K requested: the k-th entry decides
@@ -279,50 +178,26 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
         }
     }
     int64_t base = index_local ? 0 : seg_begin_global(support_segs, s);
-    if (SUB && active) {
+    if (SUB) {
         const u64 k1 = (u64)__double_as_longlong(best1);
         out_sub[out_row] = k1 != KEY_EMPTY ? (int32_t)(unsigned)(k1 & 0xffffffffull) : -1;
     }
-    if (K == 16 && k == 16 && !out_d2 && vec_store && !stage) {
+    if (K == 16 && k == 16 && !out_d2 && vec_store) {
         // The queries of a wave sit in cell-sorted order, their result rows anywhere: 16 stores of 4 bytes per lane at a
         // 64-byte stride are 64 partial-line writes per instruction (WRITE_SIZE 2x the index bytes, profiles/r02_pmc_write).
-        // Four 16-byte stores per lane instead: a lane's 64-byte row (64-byte aligned: row * 16 ints) is complete after four
-        // consecutive instructions, a quarter of the write requests, no LDS.
-        if (!active) return;
+        // Four 16-byte stores per lane instead: a lane's 64-byte row (the caller checked the base's 16-byte alignment) is
+        // complete after four consecutive instructions, a quarter of the write requests.
         struct alignas(16) I4 { int32_t v[4]; };
         I4* dst = reinterpret_cast<I4*>(out_idx + out_row * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int qd = 0; qd < 4; ++qd) {
             I4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const u64 key = (u64)__double_as_longlong(best[4 * q + e]);
+                const u64 key = (u64)__double_as_longlong(best[4 * qd + e]);
                 o.v[e] = key != KEY_EMPTY ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
             }
-            dst[q] = o;
-        }
-        return;
-    }
-    if (transposed) {
-        // ... or transposed through a wave-private LDS patch [64 rows][16 + 1]: every store instruction then writes four WHOLE
-        // 64-byte rows (16 lanes x 4 bytes each).  (Measured slower overall than the vector stores: the 19 KB of LDS per
-        // workgroup keep the forward's LDS-heavy kernels off the CUs the search occupies -- ML3D_KNN_STORE=1 for A/B runs.)
-        const int lane = threadIdx.x & 63;
-        int* patch = stage + (threadIdx.x >> 6) * (64 * 17 + 64 * 2);
-        long long* rows = (long long*)(patch + 64 * 17);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u64 key = (u64)__double_as_longlong(best[j]);
-            patch[lane * 17 + j] = key != KEY_EMPTY ? (int32_t)((int64_t)(unsigned)(key & 0xffffffffull) + base) : -1;
-        }
-        rows[lane] = out_row;
-        wave_lds_sync();
-        const int col = lane & 15;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = i * 4 + (lane >> 4);
-            const long long row = rows[r];
-            if (row >= 0) out_idx[row * 16 + col] = patch[r * 17 + col];
+            dst[qd] = o;
         }
         return;
     }
@@ -362,54 +237,44 @@ struct KnnJobs {
     int n;
 };
 
-// how the 16 indices of a query are stored: 0 = sixteen 4-byte stores per lane (round 2), 1 = transposed through LDS (whole
-// 64-byte rows per instruction), 2 = four 16-byte stores per lane (default).  ML3D_KNN_STORE, read once; speed only.
-static int knn_store_mode() {
-    static const int v = [] { const char* e = getenv("ML3D_KNN_STORE"); return e ? atoi(e) : 2; }();
-    return v;
-}
 #ifndef KNN_WAVES
-#if KNN_QUEUE
-#define KNN_WAVES 5        // (the queue merge needs 96 registers)
-#else
 #define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
 #endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
-#endif
-template <int K, bool SUB, bool STAGE = false>
+template <int K, bool SUB>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0
 ML3D_WAVES_PER_SIMD(KNN_WAVES)
 #endif
-knn_query_multi(KnnJobs J, int k, int index_local, int store_mode) {
-    __shared__ int stage[STAGE ? 4 * (64 * 17 + 64 * 2) : 1];      // (store mode 1 only)
-    __shared__ double pend[(K == 16 && KNN_QUEUE) ? KNN_QD * 256 : 1];   // the lanes' pending keys (16 KB)
+knn_query_multi(KnnJobs J, int k, int index_local, int vec_store) {
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
-    knn_one<K, SUB, K == 16 && KNN_QUEUE>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
-                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub,
-                    STAGE ? stage : nullptr, store_mode == 2, (K == 16 && KNN_QUEUE) ? pend + threadIdx.x : nullptr);
+    knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub, vec_store != 0);
 }
+
+// threads per workgroup of the multi-job launch.  No LDS, no barriers: ONE wave per workgroup, so a wave slot is refilled as soon
+// as its wave retires instead of when four have (1.65 against 1.71 ms per 64-frame launch, +0.5-1 % frames/s: gpurun r4e).
+static int knn_block() { return 64; }
 
 template <bool SUB>
 static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
+    const int T = knn_block();
     unsigned blocks = 0;
+    int vec = 1;            // 16-byte index stores need every job's rows at a 16-byte aligned base (a view or a carved slab may not be)
     for (int i = 0; i < J.n; ++i) {
         J.j[i].block_begin = blocks;
-        blocks += (unsigned)((J.j[i].Q.n_total + 255) / 256);
+        blocks += (unsigned)((J.j[i].Q.n_total + T - 1) / T);
+        if ((uintptr_t)J.j[i].out_idx & 15) vec = 0;
     }
     if (blocks == 0) return 0;
-    const int mode = knn_store_mode();
-    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
-    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
-    else if (k <= 16) {
-        if (mode == 1) hipLaunchKernelGGL((knn_query_multi<16, SUB, true>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
-        else hipLaunchKernelGGL((knn_query_multi<16, SUB, false>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
-    }
-    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
-    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(256), 0, stream, J, k, index_local, mode);
+    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
+    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
+    else if (k <= 16) hipLaunchKernelGGL((knn_query_multi<16, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
+    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
+    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
     else return ML3D_E_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }

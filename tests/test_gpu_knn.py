@@ -82,8 +82,7 @@ def test_full_size_properties_batch():
     n0 = nbr[0].cpu().numpy()
     assert np.array_equal(n0[:, :, 0], np.broadcast_to(np.arange(N), (B, N)))          # self first
     assert np.array_equal(n0[0], n0[2]) and np.array_equal(n0[1], n0[3])               # deterministic / batch-independent
-    g = np.take_along_axis(pts[0][None].repeat(16, 0).transpose(1, 0, 2), n0[0][:, :, None].repeat(3, 2), 0) \
-        if False else pts[0][n0[0]]
+    g = pts[0][n0[0]]
     d2 = ((pts[0][:, None, :] - g) ** 2).sum(-1)
     assert (np.diff(d2, axis=1) >= -1e-6).all()                                        # ascending distance
     assert all(len(set(r)) == 16 for r in n0[0][::997])                                # no duplicates

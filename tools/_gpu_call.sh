@@ -1,9 +1,12 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r4a
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/r4a/pytest.log; tail -4 gpurun_out/r4a/pytest.log
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/r4a/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-workloads > $GRAFT_REPO_ROOT/gpurun_out/r4a/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/r4a/prof.err
-cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/r4a/prof -name "*kernel_stats.csv" | head -1); head -12 "$f" | cut -c1-200
-find gpurun_out/r4a/prof -name "*.csv" ! -name "*kernel_stats.csv" -delete; find gpurun_out/r4a/prof -name "*.db" -delete
+for b in 256 128 64; do
+  echo "== general kernel block=$b: $(ML3D_KNN_PYRAMID=0 ML3D_KNN_BLOCK=$b python tools/knn_only.py 7 2>&1 | tail -1)"
+done
+for b in 256 64 256 64; do
+  echo "== bench block=$b: $(ML3D_KNN_PYRAMID=0 ML3D_KNN_BLOCK=$b python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-workloads 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=[d['roofline']]+d['roofline_other']
+print('%.0f frames/s step %.2f ms' % (d['value'], d['ms_per_step']), ' | '.join('%s %.3f ms (alone %.3f)' % (x['kernel'][:18], x['avg_launch_ms'], x['avg_launch_ms_alone'] or 0) for x in r))")"
+done
