@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 4
+#define ML3D_ABI_VERSION 5
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -429,6 +429,37 @@ int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* c
 
 int ml3d_vote_update(const float* logits, const int32_t* point_inds, int64_t n, int num_classes,
                      float smooth, void* probs_f16, int64_t n_cloud, void* stream);
+
+/* ---- the patch loop of one cloud with NOTHING read back (ABI 5) ------------------------------- */
+/* The sampler + transform of a test cloud (semseg_spatially_regular.py:64-111,                    */
+/* randlanet.py:156-212) touch the whole patch on the host: crop, float32 distances to the centre, */
+/* possibility bump, recentring.  These entries do the same arithmetic, in numpy's order, on device */
+/* buffers, so that consecutive patches of a cloud queue up without a host synchronisation.         */
+/* ml3d_nearest_to_center_dev: ml3d_nearest_to_center with the centre read from DEVICE memory       */
+/*   (center_dev: float[3], e.g. the row of the cloud an argmin kernel picked).                     */
+/* ml3d_patch_crop: patch row j = points[cand[perm[j]]] (cand: the k nearest in query order, perm:  */
+/*   the host's shuffle of 0..k-1 -- random.shuffle / Generator.permutation draw no data);          */
+/*   out_sel[j] = that cloud index; d_j = ((dx*dx)+(dy*dy))+(dz*dz) in float32 (np.sum over the     */
+/*   three squares); possibility[out_sel[j]] += (float64)((1 - d_j / max_j d_j)^2) with the float32 */
+/*   quotient / difference / square of semseg_spatially_regular.py:104-107.  Indices must be        */
+/*   distinct (a cloud smaller than the patch stays on the host path).  scratch: k floats + 64 B.   */
+/* ml3d_patch_recenter: pts[:, d] -= mean_d for every axis d in dims_mask (bit d), mean_d = the     */
+/*   SEQUENTIAL float32 sum of column d over rows 0..k-1, divided by k -- numpy's mean(0) of a      */
+/*   C-contiguous float32 [k, 3] array accumulates row by row, and the recentred coordinates feed   */
+/*   the neighbour search, so the order is reproduced, not approximated (augmentation.py:16-24).    */
+/*   Then features[j] = [pts[j] | (extra[j] - feat_bias) / feat_scale] (randlanet.py:203-206 with   */
+/*   the 'normalize.feat' augmentation; extra / n_extra may be NULL / 0).  scratch: 16 bytes.       */
+int ml3d_nearest_to_center_dev(const float* points, int64_t n_points, const float* center_dev,
+                               int64_t k, int32_t* out_index, double* out_dist2,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+int ml3d_patch_crop(const float* points, int64_t n_points, const int32_t* cand, const int32_t* perm,
+                    const float* center_dev, int64_t k, float* out_pts, int32_t* out_sel,
+                    double* possibility, void* scratch, size_t scratch_bytes, void* stream);
+
+int ml3d_patch_recenter(float* pts, int64_t k, int dims_mask, const float* extra, int n_extra,
+                        float feat_bias, float feat_scale, float* out_features,
+                        void* scratch, size_t scratch_bytes, void* stream);
 
 /* ml3d_argmax_labels: out_labels[i] = argmax_c scores[i, c] as uint8 (num_classes <= 256; first  */
 /*   maximum, NaN = maximum, like torch.argmax) -- the predicted labels that leave the GPU          */

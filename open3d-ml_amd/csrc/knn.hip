@@ -100,25 +100,42 @@ __device__ __forceinline__ float shell_guard(const GridSeg& g, float qx, float q
     return gd - g.margin;
 }
 
-// all rows of shell r, one run at a time (the general scan: any K, and the cursor kernel's overflow path)
+__device__ __forceinline__ float axis_gap(float q, float lo, float c, int i, float margin) {
+    // distance along one axis from q to the slab of cell i: [lo + i c, lo + (i + 1) c); 0 inside
+    const float a = (lo + (float)i * c) - q, b = q - (lo + (float)(i + 1) * c);
+    return fmaxf(fmaxf(a, b) - margin, 0.f);
+}
+
+// The shell between box radius r_in (already read) and r_out: every cell with r_in < max(|dx|, |dy|, |dz|) <= r_out, one run of
+// cells per row (rows that cross the inner box: the two ends).  r_out = r_in + 1 is the classic unit shell.
+// An isolated point (a lone return metres from anything: 1-7 % of the waves hold one) walks tens of shells before it has k
+// neighbours; one shell at a time that is (2 r + 1)^2 row visits per shell, O(R^3) in all, and ONE such lane sets the time of a
+// small launch (a single 45 056-point frame: 1.2 ms on average, up to 6.9 ms, against 1.7 ms for 64 frames: round-4 profile of
+// the model-class patch loop).  Beyond the third shell the box therefore grows GEOMETRICALLY (and jumps straight to the box
+// that holds the k-th neighbour's ball once k points are known): O(R^2) row visits.  `bound`: squared distance beyond which a
+// row cannot matter (inf while the list is short); a superset of what unit shells would read, so the result is unchanged.
 template <int K, bool SUB>
-__device__ __forceinline__ void scan_shell(const GridView& G, const GridSeg& g, float qx, float qy, float qz, int cx, int cy,
-                                           int cz, int r, double (&best)[K], int n_sub, double& best1) {
+__device__ __forceinline__ void scan_shell(const GridView& G, const GridSeg& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           int r_in, int r_out, float bound, double (&best)[K], int n_sub, double& best1) {
     const int dxm = g.dims[0] - 1, dym = g.dims[1] - 1, dzm = g.dims[2] - 1;
-    const int xa = max(cx - r, 0), xb = min(cx + r, dxm);
-    const int ya = max(cy - r, 0), yb = min(cy + r, dym);
-    const int za = max(cz - r, 0), zb = min(cz + r, dzm);
+    const int xa = max(cx - r_out, 0), xb = min(cx + r_out, dxm);
+    const int ya = max(cy - r_out, 0), yb = min(cy + r_out, dym);
+    const int za = max(cz - r_out, 0), zb = min(cz + r_out, dzm);
     for (int z = za; z <= zb; ++z) {
         const int az = z > cz ? z - cz : cz - z;
+        const float ez = axis_gap(qz, g.lo[2], g.c, z, g.margin);
         for (int y = ya; y <= yb; ++y) {
             const int ay = y > cy ? y - cy : cy - y;
+            const float ey = axis_gap(qy, g.lo[1], g.c, y, g.margin);
+            if ((ez * ez + ey * ey) * 0.999999f > bound) continue;
             const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
-            if (r == 1 || az == r || ay == r) {
+            if (r_in == 0 || az > r_in || ay > r_in) {
                 scan_run<K, SUB>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1);
             } else {
-                // (inlined copies of the scan: a one-copy loop over the two end cells costs 9 % -- 1.73 against 1.59 ms alone)
-                if (cx - r >= 0) scan_run<K, SUB>(G, row + cx - r, row + cx - r, qx, qy, qz, best, n_sub, best1);
-                if (cx + r <= dxm) scan_run<K, SUB>(G, row + cx + r, row + cx + r, qx, qy, qz, best, n_sub, best1);
+                // (inlined copies of the scan: a one-copy loop over the two ends costs 9 % -- 1.73 against 1.59 ms alone)
+                const int lb = min(cx - r_in - 1, dxm), ra = max(cx + r_in + 1, 0);
+                if (xa <= lb) scan_run<K, SUB>(G, row + xa, row + lb, qx, qy, qz, best, n_sub, best1);
+                if (ra <= xb) scan_run<K, SUB>(G, row + ra, row + xb, qx, qy, qz, best, n_sub, best1);
             }
         }
     }
@@ -153,8 +170,10 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
         int cx = cell_coord(qx, g.lo[0], g.inv_c, g.dims[0]);
         int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
         int cz = cell_coord(qz, g.lo[2], g.inv_c, g.dims[2]);
-        for (int r = 1;; ++r) {
-            scan_shell<K, SUB>(G, g, qx, qy, qz, cx, cy, cz, r, best, n_sub, best1);
+        constexpr int UNIT_SHELLS = 3;        // shells read one at a time before the box starts to grow geometrically
+        float dk = 3.0e38f;                   // squared distance both answers are known within (inf: not yet)
+        for (int r_in = 0, r = 1;;) {
+            scan_shell<K, SUB>(G, g, qx, qy, qz, cx, cy, cz, r_in, r, dk, best, n_sub, best1);
             // every point outside the scanned box is at least `gd` away (inf when the box face is
             // past the grid).  Stop once the k-th best is strictly inside that radius.
             bool all;
@@ -166,15 +185,28 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
 #pragma unroll
                 for (int j = 0; j < K; ++j) if (j == k - 1) kth = (u64)__double_as_longlong(best[j]);
             }
-            if (kth != KEY_EMPTY && gd > 0.f) {
-                float dk = __uint_as_float((unsigned)(kth >> 32));
+            dk = 3.0e38f;
+            if (kth != KEY_EMPTY) {
+                dk = __uint_as_float((unsigned)(kth >> 32));
                 if (SUB && n_sub > 0) {       // (n_sub == 0: no coarser level, the interpolation index is -1 whatever is scanned)
                     // both answers must be final: the nearest prefix point may lie beyond the k-th neighbour
                     const u64 k1 = (u64)__double_as_longlong(best1);
                     if (k1 != KEY_EMPTY) dk = fmaxf(dk, __uint_as_float((unsigned)(k1 >> 32))); else dk = 3.0e38f;
                 }
-                if (dk < gd * gd * 0.999999f) break;
+                if (gd > 0.f && dk < gd * gd * 0.999999f) break;
             }
+            r_in = r;
+            if (r < UNIT_SHELLS) { ++r; continue; }
+            int rn = r + max(1, r >> 1);
+            if (dk < 3.0e38f) {
+                // the box that holds the ball of the k-th neighbour: nothing beyond it can matter
+                const float rad = sqrtf(dk) * 1.00001f + g.margin;
+                const int need = max(max(cx - cell_coord(qx - rad, g.lo[0], g.inv_c, g.dims[0]), cell_coord(qx + rad, g.lo[0], g.inv_c, g.dims[0]) - cx),
+                                     max(max(cy - cell_coord(qy - rad, g.lo[1], g.inv_c, g.dims[1]), cell_coord(qy + rad, g.lo[1], g.inv_c, g.dims[1]) - cy),
+                                         max(cz - cell_coord(qz - rad, g.lo[2], g.inv_c, g.dims[2]), cell_coord(qz + rad, g.lo[2], g.inv_c, g.dims[2]) - cz)));
+                rn = max(r + 1, need);
+            }
+            r = rn;
         }
     }
     int64_t base = index_local ? 0 : seg_begin_global(support_segs, s);
@@ -474,10 +506,11 @@ namespace ml3d {
 // sklearn/metrics/_dist_metrics: sequential accumulation, no FMA).  The patch ORDER feeds random.shuffle and, through the
 // prefix subsampling of RandLANet.transform, every coarser level -- so the key is that float64 value, bit for bit
 // (positive doubles order like their bit patterns); ties keep ascending index (stable sort, values start as 0..n-1).
-__global__ void center_keys(const float* __restrict__ pts, int64_t n, double cx, double cy, double cz, u64* __restrict__ keys,
-                            uint32_t* __restrict__ vals) {
+__global__ void center_keys(const float* __restrict__ pts, int64_t n, double cx, double cy, double cz,
+                            const float* __restrict__ cdev, u64* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (cdev) { cx = (double)cdev[0]; cy = (double)cdev[1]; cz = (double)cdev[2]; }
     const double dx = (double)pts[3 * i] - cx, dy = (double)pts[3 * i + 1] - cy, dz = (double)pts[3 * i + 2] - cz;
     const double d2 = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: three products, two sums, no FMA
     keys[i] = (u64)__double_as_longlong(d2);
@@ -553,10 +586,10 @@ extern "C" size_t ml3d_nearest_to_center_workspace_bytes(int64_t n_points) {
            sort_ws_bytes(m) + 512;
 }
 
-extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host, int64_t k,
-                                      int32_t* out_index, double* out_dist2, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
-    if (n_points < 0 || k < 0 || k > n_points || !center_host || n_points > 0x7ffffff0ll) return ML3D_E_INVALID;
+static int nearest_to_center_impl(const float* points, int64_t n_points, const float* center_host, const float* center_dev,
+                                  int64_t k, int32_t* out_index, double* out_dist2, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (n_points < 0 || k < 0 || k > n_points || (!center_host && !center_dev) || n_points > 0x7ffffff0ll) return ML3D_E_INVALID;
     if (k == 0) return 0;
     if (!points || !out_index) return ML3D_E_INVALID;
     if (workspace_bytes < ml3d_nearest_to_center_workspace_bytes(n_points)) return ML3D_E_WORKSPACE;
@@ -567,10 +600,152 @@ extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, con
     SortWs sw;
     if (!sort_ws_carve(p, sort_ws_bytes(n_points), n_points, &sw)) return ML3D_E_WORKSPACE;
     hipLaunchKernelGGL(center_keys, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, points, n_points,
-                       (double)center_host[0], (double)center_host[1], (double)center_host[2], keys, vals);
+                       center_host ? (double)center_host[0] : 0.0, center_host ? (double)center_host[1] : 0.0,
+                       center_host ? (double)center_host[2] : 0.0, center_dev, keys, vals);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (sort_pairs_u64(keys, vals, n_points, 64, sw, st)) return ML3D_E_LAUNCH;
     hipLaunchKernelGGL(center_take, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, keys, vals, k, out_index, out_dist2);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_nearest_to_center(const float* points, int64_t n_points, const float* center_host, int64_t k,
+                                      int32_t* out_index, double* out_dist2, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (!center_host) return ML3D_E_INVALID;
+    return nearest_to_center_impl(points, n_points, center_host, nullptr, k, out_index, out_dist2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ml3d_nearest_to_center_dev(const float* points, int64_t n_points, const float* center_dev, int64_t k,
+                                          int32_t* out_index, double* out_dist2, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (!center_dev) return ML3D_E_INVALID;
+    return nearest_to_center_impl(points, n_points, nullptr, center_dev, k, out_index, out_dist2, workspace, workspace_bytes, stream);
+}
+
+// ---- the patch loop on device buffers (ml3d_hip.h, ABI 5) ----------------------------------------------------------------
+namespace ml3d {
+
+__global__ void __launch_bounds__(256)
+patch_gather(const float* __restrict__ pts, const int32_t* __restrict__ cand, const int32_t* __restrict__ perm,
+             const float* __restrict__ center, int64_t k, float* __restrict__ out_pts, int32_t* __restrict__ out_sel,
+             float* __restrict__ d2, unsigned* __restrict__ d2max_bits) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float d = 0.f;
+    if (j < k) {
+        const int32_t i = cand[perm[j]];
+        const float x = pts[3 * (int64_t)i], y = pts[3 * (int64_t)i + 1], z = pts[3 * (int64_t)i + 2];
+        out_pts[3 * j] = x; out_pts[3 * j + 1] = y; out_pts[3 * j + 2] = z;
+        out_sel[j] = i;
+        // np.sum(np.square((pc - center).astype(np.float32)), axis=1): three float32 squares added left to right
+        const float dx = __fsub_rn(x, center[0]), dy = __fsub_rn(y, center[1]), dz = __fsub_rn(z, center[2]);
+        d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        d2[j] = d;
+    }
+    // max of non-negative floats == max of their bit patterns
+    unsigned b = __float_as_uint(d);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(d2max_bits, b);
+}
+
+__global__ void __launch_bounds__(256)
+patch_bump(const int32_t* __restrict__ sel, const float* __restrict__ d2, const unsigned* __restrict__ d2max_bits, int64_t k,
+           double* __restrict__ possibility) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const float mx = __uint_as_float(*d2max_bits);
+    const float t = __fsub_rn(1.0f, __fdiv_rn(d2[j], mx));          // float32: 1 - dists / np.max(dists)
+    possibility[sel[j]] += (double)__fmul_rn(t, t);                 // float64 += float32 square
+}
+
+// one workgroup: the whole patch staged in LDS by all threads (5 120 rows per stage), then threads 0..2 add their
+// column IN ROW ORDER -- 32 LDS reads in flight under 32 DEPENDENT adds (the chain is the 45 056 additions; their operands'
+// latency must not sit on it)
+__global__ void __launch_bounds__(256)
+patch_mean_seq(const float* __restrict__ pts, int64_t k, float* __restrict__ mean_out) {
+    constexpr int ROWS = 5120;            // 60 KB of LDS per stage
+    __shared__ float buf[ROWS * 3];
+    float s = 0.f;
+    for (int64_t base = 0; base < k; base += ROWS) {
+        const int rows = (int)min<int64_t>(ROWS, k - base);
+        const float4* src4 = reinterpret_cast<const float4*>(pts + 3 * base);         // (3 * base * 4 bytes: 16-byte aligned, ROWS % 4 == 0)
+        const int n4 = rows * 3 / 4;
+        for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(buf)[e] = src4[e];
+        for (int e = n4 * 4 + threadIdx.x; e < rows * 3; e += 256) buf[e] = pts[3 * base + e];
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float* col = buf + threadIdx.x;
+            int r = 0;
+            float v[32];
+            if (rows >= 32) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = col[3 * i];
+                for (; r + 64 <= rows; r += 32) {
+                    float w[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) w[i] = col[3 * (r + 32 + i)];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) s = __fadd_rn(s, v[i]);
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) v[i] = w[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) s = __fadd_rn(s, v[i]);
+                r += 32;
+            }
+            for (; r < rows; ++r) s = __fadd_rn(s, col[3 * r]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) mean_out[threadIdx.x] = __fdiv_rn(s, (float)k);
+}
+
+__global__ void __launch_bounds__(256)
+patch_apply(float* __restrict__ pts, int64_t k, int dims_mask, const float* __restrict__ mean, const float* __restrict__ extra,
+            int n_extra, float bias, float scale, float* __restrict__ feats) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const int C = 3 + n_extra;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float v = pts[3 * j + d];
+        if (dims_mask & (1 << d)) { v = __fsub_rn(v, mean[d]); pts[3 * j + d] = v; }
+        if (feats) feats[j * C + d] = v;
+    }
+    if (feats)
+        for (int c = 0; c < n_extra; ++c) feats[j * C + 3 + c] = __fdiv_rn(__fsub_rn(extra[j * n_extra + c], bias), scale);
+}
+
+}  // namespace ml3d
+
+extern "C" int ml3d_patch_crop(const float* points, int64_t n_points, const int32_t* cand, const int32_t* perm,
+                               const float* center_dev, int64_t k, float* out_pts, int32_t* out_sel, double* possibility,
+                               void* scratch, size_t scratch_bytes, void* stream) {
+    if (k < 0 || n_points < 0 || k > n_points) return ML3D_E_INVALID;
+    if (k == 0) return 0;
+    if (!points || !cand || !perm || !center_dev || !out_pts || !out_sel || !possibility || !scratch) return ML3D_E_INVALID;
+    if (scratch_bytes < sizeof(float) * (size_t)k + 64) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* mx = (unsigned*)scratch;
+    float* d2 = (float*)((char*)scratch + 64);
+    if (hipMemsetAsync(mx, 0, sizeof(unsigned), st) != hipSuccess) return ML3D_E_LAUNCH;
+    const dim3 grid((unsigned)((k + 255) / 256)), block(256);
+    hipLaunchKernelGGL(patch_gather, grid, block, 0, st, points, cand, perm, center_dev, k, out_pts, out_sel, d2, mx);
+    hipLaunchKernelGGL(patch_bump, grid, block, 0, st, out_sel, d2, mx, k, possibility);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_patch_recenter(float* pts, int64_t k, int dims_mask, const float* extra, int n_extra, float feat_bias,
+                                   float feat_scale, float* out_features, void* scratch, size_t scratch_bytes, void* stream) {
+    if (k < 0 || n_extra < 0 || (n_extra > 0 && !extra) || (dims_mask & ~7)) return ML3D_E_INVALID;
+    if (k == 0) return 0;
+    if (!pts || !scratch) return ML3D_E_INVALID;
+    if (scratch_bytes < 16) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* mean = (float*)scratch;
+    if (dims_mask) hipLaunchKernelGGL(patch_mean_seq, dim3(1), dim3(256), 0, st, pts, k, mean);
+    hipLaunchKernelGGL(patch_apply, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, dims_mask, mean, extra, n_extra,
+                       feat_bias, feat_scale, out_features);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

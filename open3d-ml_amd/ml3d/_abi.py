@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 4          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 5          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -56,6 +56,9 @@ SYMBOLS = [
     "ml3d_iou_3d",
     "ml3d_nearest_to_center_workspace_bytes",
     "ml3d_nearest_to_center",
+    "ml3d_nearest_to_center_dev",
+    "ml3d_patch_crop",
+    "ml3d_patch_recenter",
     "ml3d_vote_update",
     "ml3d_argmax_labels",
     "ml3d_randla_pyramid_workspace_bytes",
@@ -174,6 +177,12 @@ def bind(lib):
     lib.ml3d_nearest_to_center_workspace_bytes.argtypes = [i64]
     lib.ml3d_nearest_to_center.restype = C.c_int
     lib.ml3d_nearest_to_center.argtypes = [vp, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.ml3d_nearest_to_center_dev.restype = C.c_int
+    lib.ml3d_nearest_to_center_dev.argtypes = [vp, i64, vp, i64, vp, vp, vp, sz, vp]
+    lib.ml3d_patch_crop.restype = C.c_int
+    lib.ml3d_patch_crop.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_patch_recenter.restype = C.c_int
+    lib.ml3d_patch_recenter.argtypes = [vp, i64, i32, vp, i32, f32, f32, vp, vp, sz, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_argmax_labels.restype = C.c_int

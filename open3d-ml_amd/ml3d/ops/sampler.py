@@ -44,6 +44,49 @@ def nearest_to_center(points, center, k, return_distances=False):
     return (idx, d2) if return_distances else idx
 
 
+def device_patch(points, possibility, center_index, perm, k, recenter_dims=(), extra=None, feat_bias=0.0, feat_scale=1.0):
+    """One step of the spatially regular patch loop (semseg_spatially_regular.py:64-111 + randlanet.py:185-212) with nothing
+    read back: ``points`` float32 [n, 3], ``possibility`` float64 [n] (bumped IN PLACE), ``center_index`` a 1-element DEVICE
+    index tensor (the argmin of the possibilities), ``perm`` the host-drawn shuffle of 0..k-1 as a device int32 tensor,
+    ``extra`` optional float32 [n, c] per-point features.  Returns (patch points [k, 3] recentred on ``recenter_dims``,
+    features [k, 3 + c], selected cloud indices int32 [k]) -- the arithmetic and its ORDER are numpy's (float32 squared
+    distances left to right, sequential float32 column sums for the mean): the patch feeds an exact neighbour search."""
+    lib = _abi.get()
+    _need_gpu(points, possibility, center_index, perm)
+    dev = points.device
+    n = points.shape[0]
+    k = int(k)
+    if points.dtype != torch.float32 or not points.is_contiguous() or possibility.dtype != torch.float64 or \
+            not possibility.is_contiguous() or possibility.numel() != n or perm.dtype != torch.int32 or perm.numel() != k or k > n:
+        raise RuntimeError("device_patch: float32 [n, 3] points, float64 [n] possibilities, int32 [k] permutation, k <= n")
+    center = points[center_index.reshape(1)].reshape(3).contiguous()          # (a device gather: the centre is never on the host)
+    cand = torch.empty(k, dtype=torch.int32, device=dev)
+    wsb = lib.ml3d_nearest_to_center_workspace_bytes(n)
+    ws = _ws(wsb, dev)
+    pts = torch.empty((k, 3), dtype=torch.float32, device=dev)
+    sel = torch.empty(k, dtype=torch.int32, device=dev)
+    scratch = torch.empty(4 * k + 64, dtype=torch.uint8, device=dev)
+    n_extra = 0 if extra is None else int(extra.shape[1])
+    feats = torch.empty((k, 3 + n_extra), dtype=torch.float32, device=dev)
+    ex = None
+    mask = 0
+    for d in recenter_dims:
+        mask |= 1 << int(d)
+    with torch.cuda.device(dev):
+        rc = lib.ml3d_nearest_to_center_dev(points.data_ptr(), n, center.data_ptr(), k, cand.data_ptr(), None, ws.data_ptr(), wsb,
+                                            _stream())
+        _abi.check(rc, "ml3d_nearest_to_center_dev")
+        rc = lib.ml3d_patch_crop(points.data_ptr(), n, cand.data_ptr(), perm.data_ptr(), center.data_ptr(), k, pts.data_ptr(),
+                                 sel.data_ptr(), possibility.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream())
+        _abi.check(rc, "ml3d_patch_crop")
+        if n_extra:
+            ex = extra[sel.long()].contiguous()
+        rc = lib.ml3d_patch_recenter(pts.data_ptr(), k, mask, None if ex is None else ex.data_ptr(), n_extra, float(feat_bias),
+                                     float(feat_scale), feats.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream())
+        _abi.check(rc, "ml3d_patch_recenter")
+    return pts, feats, sel
+
+
 def argmax_labels(scores, out=None):
     """uint8 labels [...] = argmax over the last axis of float32 ``scores`` [..., C <= 256] (first maximum, like
     torch.argmax) -- one pass over the scores instead of torch's generic reduction + dtype cast."""

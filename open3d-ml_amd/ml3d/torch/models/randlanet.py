@@ -144,6 +144,8 @@ class RandLANet(nn.Module):
                 # random_sample (randlanet.py:300-327) pools through sub_idx; the kernels take it as the PREFIX of the
                 # level's neighbour matrix, which is what transform builds (randlanet.py:222-223).  Anything else is refused.
                 for l, (sub, nb) in enumerate(zip(inputs['sub_idx'], nbr)):
+                    if sub.is_cuda and sub.dtype == torch.int32 and sub.shape[-2] <= nb.shape[-2]:
+                        continue      # this class's own transform (int32 device lists, prefix views): comparing would drain the GPU
                     sub = sub.to(dev)
                     if sub.shape[-2] > nb.shape[-2] or not torch.equal(sub.to(torch.int32), nb[..., :sub.shape[-2], :]):
                         raise RuntimeError("RandLANet.forward: sub_idx[%d] is not the prefix of neighbor_indices[%d]" % (l, l))
@@ -189,14 +191,16 @@ class RandLANet(nn.Module):
         cfg = self.cfg
         if attr['split'] in ['training', 'train']:
             raise NotImplementedError("RandLANet (MI355X build): inference transform only (SURVEY.md §8 f4)")
-        pc = data['point'].copy()
-        label = data['label'].copy()
-        feat = data['feat'].copy() if data['feat'] is not None else None
-        tree = data['search_tree']
         sampler = getattr(self, 'trans_point_sampler', None)
         if sampler is None:
             raise RuntimeError("RandLANet.transform: set model.trans_point_sampler (the pipeline takes it from the dataset "
                                "split's sampler, semantic_segmentation.py:156) or use inference_begin()")
+        if self._device_loop_serves(data, sampler):
+            return self._transform_device()
+        pc = data['point'].copy()
+        label = data['label'].copy()
+        feat = data['feat'].copy() if data['feat'] is not None else None
+        tree = data['search_tree']
         pc, selected_idxs, center_point = sampler(pc=pc, feat=feat, label=label, search_tree=tree,
                                                   num_points=cfg.num_points)
         label = label[selected_idxs]
@@ -235,8 +239,12 @@ class RandLANet(nn.Module):
         inds_all = inputs['data']['point_inds']
         for b in range(results.size()[0]):
             logits = torch.reshape(results[b], (-1, self.cfg.num_classes)).to(dev, torch.float32).contiguous()
+            if isinstance(inds_all[b], torch.Tensor) and inds_all[b].is_cuda:
+                # the device patch loop's indices: the k nearest of a cloud of >= k points, distinct by construction
+                ops.vote_update(tp, inds_all[b].reshape(-1).to(torch.int32), logits, self.test_smooth)
+                continue
             inds = np.asarray(inds_all[b].cpu() if isinstance(inds_all[b], torch.Tensor) else inds_all[b]).reshape(-1)
-            if inds.size > tp.shape[0] or (inds.size and np.bincount(inds).max() > 1):
+            if inds.size > tp.shape[0]:
                 # a cloud smaller than num_points: the sampler pads the patch with REPEATED points
                 # (semseg_spatially_regular.py:80-84).  numpy's ``test_probs[inds] = f(test_probs[inds])`` reads every row's
                 # OLD value first and the LAST occurrence's write wins; the kernel updates rows in place, one wave per listed
@@ -260,6 +268,62 @@ class RandLANet(nn.Module):
         self.test_probs = torch.zeros((num_points, self.cfg.num_classes), dtype=torch.float16, device=self.device)
         if getattr(self, 'trans_point_sampler', None) is None:
             self.trans_point_sampler = self._possibility_sampler
+        self._dev_loop = self._device_loop_state(self.inference_data)
+
+    # ---- the same loop with the cloud, the possibilities and every patch RESIDENT on the device -------------------------------
+    # The host loop above touches the whole patch per step (copies of the cloud, a 45 056-index read-back, numpy crops, an
+    # upload): ~3 ms of host work around ~0.5 ms of kernels.  With the model's own sampler nothing of that needs the host: the
+    # centre is an argmin ON the device, the crop / distances / possibility bump / recentring are kernels that reproduce numpy's
+    # arithmetic and ORDER (ml3d_patch_crop, ml3d_patch_recenter), and the only host input per patch is the shuffle of 0..k-1,
+    # which depends on no data (``rng.permutation(idxs) == idxs[rng.permutation(k)]``: same draws) and is uploaded.  Patches are
+    # identical to the host loop's, index for index (tests/test_gpu_api.py).
+    def _device_loop_state(self, data):
+        cfg = self.cfg
+        aug = dict(cfg.get('augment', {}) or {})
+        norm = dict(aug.get('normalize', None) or {})
+        supported = set(aug) <= {'recenter', 'normalize', 'rotate', 'scale', 'noise'} and set(norm) <= {'feat'} and \
+            (not norm or norm['feat'].get('method', 'linear') == 'linear')
+        tree = data['search_tree']
+        if not supported or not isinstance(tree, GpuSearchTree) or tree.data.shape[0] < cfg.num_points:
+            return None
+        dev = self.device
+        feat = None if data['feat'] is None else torch.from_numpy(np.ascontiguousarray(data['feat'], dtype=np.float32)).to(dev)
+        if cfg.in_channels != 3 + (0 if feat is None else feat.shape[1]):
+            return None            # (the host path raises the reference's "Wrong feature dimension" error)
+        rec = aug.get('recenter', None)
+        nf = norm.get('feat', {}) if norm else {}
+        return dict(points=tree._pts(), feat=feat, label=torch.from_numpy(np.ascontiguousarray(data['label'])).to(dev),
+                    possibility=torch.from_numpy(self.possibility).to(dev), data=data,
+                    dims=tuple(rec.get('dim', [0, 1, 2])) if rec else (), bias=float(nf.get('bias', 0)), scale=float(nf.get('scale', 1)))
+
+    def _device_loop_serves(self, data, sampler):
+        st = getattr(self, '_dev_loop', None)
+        return st is not None and data is st['data'] and sampler == self._possibility_sampler
+
+    def _transform_device(self):
+        cfg, st, dev = self.cfg, self._dev_loop, self.device
+        k = int(cfg.num_points)
+        center = torch.argmin(st['possibility']).reshape(1)
+        perm = torch.from_numpy(self.rng.permutation(k).astype(np.int32)).to(dev, non_blocking=True)
+        pts, feats, sel = ops.device_patch(st['points'], st['possibility'], center, perm, k, st['dims'], st['feat'],
+                                           st['bias'], st['scale'])
+        nbr, itp = ops.randla_knn_pyramid(pts[None], cfg.sub_sampling_ratio, cfg.num_neighbors)
+        inputs, coords, n = dict(), [], k
+        for i in range(cfg.num_layers):
+            coords.append(pts[:n])
+            n = n // cfg.sub_sampling_ratio[i]
+        inputs['coords'] = coords
+        inputs['neighbor_indices'] = [t[0] for t in nbr]
+        inputs['sub_idx'] = [nbr[i][0, :k // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))] for i in range(cfg.num_layers)]
+        inputs['interp_idx'] = [t[0] for t in itp]
+        inputs['features'] = feats
+        inputs['point_inds'] = sel
+        inputs['labels'] = st['label'][sel.long()].long()
+        return inputs
+
+    def _min_possibility(self):
+        st = getattr(self, '_dev_loop', None)
+        return float(torch.min(st['possibility'])) if st is not None else float(np.min(self.possibility))
 
     def _possibility_sampler(self, pc, feat, label, search_tree, num_points):
         """Spatially regular patch sampler on ``self.possibility`` (the reference's
@@ -281,7 +345,7 @@ class RandLANet(nn.Module):
 
     def inference_preprocess(self):
         attr = {'split': 'test'}
-        data = self.transform(self.inference_data, attr, int(np.argmin(self.possibility)))
+        data = self.transform(self.inference_data, attr)
         batch = {k: ([t[None] if isinstance(t, torch.Tensor) else torch.as_tensor(t)[None] for t in v]
                      if isinstance(v, list) else torch.as_tensor(v)[None]) for k, v in data.items()}
         self.inference_input = {'data': batch, 'attr': attr}
@@ -289,7 +353,7 @@ class RandLANet(nn.Module):
 
     def inference_end(self, inputs, results):
         self.update_probs(inputs, results, self.test_probs)
-        if np.min(self.possibility) > 0.5:
+        if self._min_possibility() > 0.5:
             probs = self.test_probs.cpu().numpy()
             pred_labels = np.argmax(probs, 1)[self.inference_proj_inds]
             self.inference_result = {'predict_labels': pred_labels, 'predict_scores': probs[self.inference_proj_inds]}

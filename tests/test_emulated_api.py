@@ -255,3 +255,47 @@ ref = K.forward(sd, cfg, K.to_torch_batch(seg), torch.ones((len(pts), 1))).numpy
 assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
 print("ok")
 ''')
+
+
+def test_device_resident_patch_loop_reproduces_the_host_loop_patch_for_patch():
+    """The model-class loop of ONE cloud with everything on the device (ml3d_nearest_to_center_dev, ml3d_patch_crop,
+    ml3d_patch_recenter; only the data-free shuffle comes from the host) against the host loop that crops / recentres in
+    numpy: same selected indices, bit-identical recentred coordinates and features (numpy's SEQUENTIAL float32 column means,
+    its left-to-right float32 squared distances), identical possibilities and labels, patch after patch."""
+    _run(r'''
+import synth_data
+from oracle import randlanet_ref as R
+from ml3d.torch.models import RandLANet
+for in_ch, aug in ((3, {"recenter": {"dim": [0, 1]}}), (6, {"recenter": {"dim": [0, 1, 2]}, "normalize": {"feat": {"method": "linear", "bias": 0, "scale": 255}}})):
+    cfg = dict(num_neighbors=16, num_layers=2, num_points=640, num_classes=5, sub_sampling_ratio=[4, 4], in_channels=in_ch,
+               dim_features=8, dim_output=[16, 32], grid_size=0.25, augment=aug)
+    tile = synth_data.toronto3d_tile(3, half=3.0, density=0.08)
+    data = dict(point=tile["point"], feat=tile["feat"] if in_ch == 6 else None, label=tile["label"])
+    runs = []
+    for device_loop in (False, True):
+        m = RandLANet(**cfg, device="cpu", seed=9)
+        m.load_state_dict(R.make_state_dict(cfg, 4))
+        m.inference_begin(dict(data))
+        assert m._dev_loop is not None and m.inference_data["point"].shape[0] > 640
+        if not device_loop:
+            m._dev_loop = None
+        got = []
+        for step in range(7):
+            inp = m.inference_preprocess()["data"]
+            res = m(inp)
+            done = m.inference_end({"data": inp}, res)
+            got.append({k: (np.asarray(v[0].cpu()) if isinstance(v, torch.Tensor) else [np.asarray(t[0].cpu()) for t in v])
+                        for k, v in inp.items()} | {"logits": res.numpy().copy()})
+        poss = m._dev_loop["possibility"].numpy() if device_loop else m.possibility
+        runs.append((got, poss.copy(), m.test_probs.numpy().copy()))
+    (a, pa, va), (b, pb, vb) = runs
+    for step, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x["point_inds"], y["point_inds"]), step
+        assert np.array_equal(x["coords"][0], y["coords"][0]) and np.array_equal(x["features"], y["features"]), step
+        assert np.array_equal(x["labels"], y["labels"])
+        for l in range(2):
+            assert np.array_equal(x["neighbor_indices"][l], y["neighbor_indices"][l]) and np.array_equal(x["interp_idx"][l], y["interp_idx"][l])
+        assert np.array_equal(x["logits"], y["logits"]), step
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
+print("ok")
+''')

@@ -202,3 +202,40 @@ def test_pairwise_box_iou_matches_the_oracle():
     assert np.abs(i3 - oops.iou_3d(pred, tgt)).max() <= 1e-5
     assert np.allclose(np.diag(i3[:5, :5]), 1.0, atol=1e-5) and (i3 <= bev + 1e-6).all()
     assert iou_bev_cuda(np.zeros((0, 5), np.float32), tgt[:, [0, 2, 3, 5, 6]]).shape == (0, 25)
+
+
+def test_device_resident_patch_loop_equals_the_host_loop_at_the_yaml_size():
+    """randlanet_semantickitti.yml sizes (45 056-point patches of a 0.06 m sub-cloud): the loop that keeps the cloud, the
+    possibilities and every patch on the device (``RandLANet._transform_device``: ml3d_nearest_to_center_dev,
+    ml3d_patch_crop, ml3d_patch_recenter) against the host loop that crops and recentres in numpy -- the same patches index for
+    index, bit-identical recentred coordinates (numpy's sequential float32 column mean reproduced), neighbour lists, scores,
+    possibilities and votes; and nothing but the data-free shuffle crosses the bus per patch."""
+    from ml3d.torch.models import RandLANet
+    cfg = dict(num_neighbors=16, num_layers=4, num_points=45056, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+               dim_features=8, dim_output=[16, 64, 128, 256], grid_size=0.06, augment={"recenter": {"dim": [0, 1]}})
+    sweep = synth_data.lidar_sweep(4200)
+    data = dict(point=sweep, feat=None, label=np.zeros(sweep.shape[0], np.int32))
+    sd = R.make_state_dict(cfg, 12)
+    runs = []
+    for device_loop in (False, True):
+        m = RandLANet(**cfg, device="cuda:0", seed=21)
+        m.load_state_dict(sd)
+        m.inference_begin(dict(data))
+        assert m._dev_loop is not None
+        if not device_loop:
+            m._dev_loop = None
+        got = []
+        for _ in range(4):
+            inp = m.inference_preprocess()["data"]
+            res = m(inp)
+            m.inference_end({"data": inp}, res)
+            assert isinstance(inp["point_inds"], torch.Tensor) and inp["point_inds"].is_cuda == device_loop
+            got.append(dict(sel=np.asarray(inp["point_inds"][0].cpu()), pts=np.asarray(inp["coords"][0][0].cpu()),
+                            nbr=np.asarray(inp["neighbor_indices"][1][0].cpu()), logits=res.cpu().numpy()))
+        poss = m._dev_loop["possibility"].cpu().numpy() if device_loop else m.possibility.copy()
+        runs.append((got, poss, m.test_probs.cpu().numpy()))
+    (a, pa, va), (b, pb, vb) = runs
+    for x, y in zip(a, b):
+        assert np.array_equal(x["sel"], y["sel"]) and np.array_equal(x["pts"], y["pts"]) and np.array_equal(x["nbr"], y["nbr"])
+        assert np.array_equal(x["logits"], y["logits"])
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
