@@ -639,21 +639,12 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
 // Split-K.  A workgroup walks its K chunks serially at ~2-4 us per chunk (global latency of one prefetch stage), so a deep-K
 // problem with about one workgroup per CU is latency-bound however few flops it has -- measured (KPConv, one MI355X): M = 4.6k,
 // K = 1920, N = 128 as 288 workgroups took 257 us = 9 TFLOP/s.  Problems with K >= 512 are split until ~4 workgroups per CU are
-// resident (partials summed by gemm_reduce).  ML3D_GEMM_SPLIT="tiles,aim" (read once) overrides the two numbers: split when
-// fewer than `tiles` workgroups, up to `aim` in total (round 1: "256,512").
+// resident (partials summed by gemm_reduce).
 static int pick_splits(int64_t M, int N, int K) {
-    struct Rule { int64_t tiles, aim; };
-    static const Rule rule = [] {
-        Rule r = {1024, 1024};
-        const char* e = getenv("ML3D_GEMM_SPLIT");
-        long long a = 0, b = 0;
-        if (e && sscanf(e, "%lld,%lld", &a, &b) == 2 && a >= 0 && b >= 1) { r.tiles = a; r.aim = b; }
-        return r;
-    }();
     const int64_t tiles = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
     // (K in [512, 768) -- RandLA's decoder and 512-wide Linears -- keeps round 1's numbers: measured 0.4 % faster there)
-    const int64_t thr = K >= 768 ? rule.tiles : (rule.tiles < 256 ? rule.tiles : 256);
-    const int64_t aim = K >= 768 ? rule.aim : (rule.aim < 512 ? rule.aim : 512);
+    const int64_t thr = K >= 768 ? 1024 : 256;
+    const int64_t aim = K >= 768 ? 1024 : 512;
     if (tiles >= thr || K < 512) return 1;
     int64_t want = (aim + tiles - 1) / tiles;
     int64_t maxs = K / 128;                              // at least 4 chunks per split
@@ -671,12 +662,11 @@ size_t gemm_partial_bytes(int64_t M, int N, int K) {
 // residual, and enough 128-row tiles to fill the 256 CUs -- medium problems (the 62 x 54 and 31 x 27 maps of SECOND's deeper
 // blocks at 8 sweeps) fill the chip better with the 64 x 64 tiles of gemm_tile.  Returns the column-tile width to use, 0 = no.
 static int big_bn(int64_t M, int N, int K, const float* Bm, const Epilogue& ep) {
-    // ML3D_GEMM_BIG_MIN_TILES (read once, at the first call): workgroups below which gemm_tile keeps the problem; the
-    // emulator tests set 1 to push small problems through this kernel, A/B runs a huge value to switch it off
+    // ML3D_GEMM_BIG_MIN_TILES (read once, at the first call): workgroups below which gemm_tile keeps the problem -- a TEST hook:
+    // the emulator tests set 1 to push small problems (of any depth) through this kernel.  Shallow K (RandLA's per-point
+    // Linears, K = 32 .. 128: one or two chunks, nothing to pipeline) stays on gemm_tile.
     static const int64_t min_tiles = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_TILES"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
-    // shallow K (RandLA's per-point Linears, K = 32 .. 128): one or two chunks -- nothing to pipeline, and the 64-register
-    // accumulator block makes prologue + epilogue the whole kernel; they stay on gemm_tile.  ML3D_GEMM_BIG_MIN_K (read once).
-    static const int min_k = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_K"); return e ? atoi(e) : 256; }();
+    const int min_k = min_tiles <= 1 ? 0 : 256;
     if ((N & 3) || (K % GM_KC) != 0 || K < min_k || (((uintptr_t)Bm) & 15) != 0 || ep.res_gather) return 0;
     const int64_t rows = (M + G2_BM - 1) / G2_BM;
     if (N > 64 && rows * ((N + 127) / 128) >= 2 * min_tiles) return 128;
@@ -701,13 +691,10 @@ static void launch_big(const L2& L, const float* Bm, int N, int bn, int kc, cons
 
 // K chunk: 64 for the 128-column tiles when the operands allow it (half the barriers per MFMA, twice the matrix time to
 // hide the next chunk's global loads under: SECOND's 128- and 256-channel convs), 32 for the 64-column tiles (measured:
-// 3x3 64 -> 64 conv 0.328 ms at 32 vs 0.362 ms at 64).  ML3D_GEMM_BIG_KC (read once) pins it for A/B runs.
+// 3x3 64 -> 64 conv 0.328 ms at 32 vs 0.362 ms at 64).
 static int big_kc(int K, int c_or_zero, int bn) {
-    static const int pin = [] { const char* e = getenv("ML3D_GEMM_BIG_KC"); return e ? atoi(e) : 0; }();
     const bool ok64 = (K % 64) == 0 && (c_or_zero == 0 || (c_or_zero % 64) == 0);
-    if (pin == 32 || !ok64) return 32;
-    if (pin == 64) return 64;
-    return bn == 128 ? 64 : 32;
+    return (ok64 && bn == 128) ? 64 : 32;
 }
 
 static bool gemm_launch_big(const ConvLoader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
@@ -723,40 +710,25 @@ static bool gemm_launch_big(const ConvLoader& L, const float* Bm, int N, const E
     return true;
 }
 
-static bool gemm_launch_big(const RowsLoader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
-                            hipStream_t st) {
-    // Row-major (Linear) problems stay on gemm_tile unless ML3D_GEMM_BIG_ROWS=1 (read once): measured on all three workloads
-    // (profiles/r02_gemm_ab.log) the 128-row kernel LOSES there -- RandLA 5657 vs 5787 frames/s, KPConv 2753 vs 2796 spheres/s,
-    // PointPillars 1137 vs 1165 frames/s: the Linears have K <= 1024 with an A operand that is read once (no 9-tap reuse out
-    // of L2 as in the convolutions), so the deeper register block buys nothing and its lower occupancy costs.
-    static const bool rows_on = [] { const char* e = getenv("ML3D_GEMM_BIG_ROWS"); return e ? atoi(e) != 0 : false; }();
-    const int bn = rows_on ? big_bn(L.M, N, L.K, Bm, ep) : 0;
-    if (!bn || !L.vec) return false;
-    // a chunk may straddle the boundary of the two concatenated operands only at a multiple of 4 (float4 loads): any KC works
-    launch_big(L, Bm, N, bn, big_kc(L.K, 0, bn), ep, C, ldc, st);
-    return true;
-}
+// Row-major (Linear) problems stay on gemm_tile: measured on all three workloads (profiles/r02_gemm_ab.log, again in round 3) the
+// 128-row kernel LOSES there -- RandLA 5657 vs 5787 frames/s, KPConv 2753 vs 2796 spheres/s, PointPillars 1137 vs 1165 frames/s:
+// the Linears have K <= 1024 with an A operand that is read once (no 9-tap reuse out of L2 as in the convolutions), so the deeper
+// register block buys nothing and its lower occupancy costs.
+static bool gemm_launch_big(const RowsLoader&, const float*, int, const Epilogue&, float*, int64_t, hipStream_t) { return false; }
 
 // Chunks in flight per workgroup of gemm_tile.  Two chunks cost 32 more registers (66 -> 98: four waves per SIMD instead of
 // seven): they pay where the kernel lasts as long as ONE workgroup's serial walk over K -- the small-M / deep-K problems that
 // fit the chip in a round or two (KPConv's coarse layers: +2.5 % spheres/s) -- and lose where many rounds of workgroups hide
 // each other's latency anyway (RandLA's and PointPillars' 10^5 .. 10^6-row Linears: -1 %), measured in one call on one box
-// (gpurun_out/r3k).  Rule: two chunks up to ML3D_GEMM_DEPTH2_MAX_WGS workgroups (default 12288:
-// KPConv's 2 200-row-tile layer included, RandLA's / PointPillars' 13 000+-tile Linears not); ML3D_GEMM_DEPTH=1|2 pins it.
-static int gemm_depth(const dim3& grid) {
-    static const int pin = [] { const char* e = getenv("ML3D_GEMM_DEPTH"); return e ? atoi(e) : 0; }();
-    static const long long max_wgs = [] { const char* e = getenv("ML3D_GEMM_DEPTH2_MAX_WGS"); return e ? atoll(e) : 12288ll; }();
-    if (pin == 1 || pin == 2) return pin;
-    return (long long)grid.x * grid.y * grid.z <= max_wgs ? 2 : 1;
-}
+// (gpurun_out/r3k).  Rule: two chunks up to 12 288 workgroups (KPConv's 2 200-row-tile layer included, RandLA's / PointPillars'
+// 13 000+-tile Linears not).
+static int gemm_depth(const dim3& grid) { return (long long)grid.x * grid.y * grid.z <= 12288ll ? 2 : 1; }
 
 // the streamlined K loop of gemm_tile takes: one dense float4-addressable row block, whole chunks, float4-addressable B
 static bool plain_rows(const RowsLoader& L, int kper, int bvec) {
-    // ML3D_GEMM_PLAIN=0 (read once): the generic loader for every problem (A/B runs)
-    static const bool on = [] { const char* e = getenv("ML3D_GEMM_PLAIN"); return !(e && e[0] == '0'); }();
     const bool one = L.A.k2 == 0 && L.A.k1 == L.K;
     const bool two = L.A.k2 > 0 && L.A.a2 && (L.A.k1 % GM_KC) == 0 && L.A.k1 + L.A.k2 == L.K;
-    return on && L.vec && bvec && !L.A.gather && (one || two) && (L.K % GM_KC) == 0 && (kper % GM_KC) == 0 && L.M > 0;
+    return L.vec && bvec && !L.A.gather && (one || two) && (L.K % GM_KC) == 0 && (kper % GM_KC) == 0 && L.M > 0;
 }
 static bool plain_rows(const ConvLoader&, int, int) { return false; }
 static void launch_plain(const RowsLoader& L, dim3 grid, const float* Bm, int N, int bvec, const Epilogue& ep, float* C,
@@ -769,14 +741,14 @@ static void launch_plain(const ConvLoader&, dim3, const float*, int, int, const 
 
 template <class Loader>
 static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc,
-                       void* partial_ws, size_t partial_bytes, hipStream_t st, bool allow_big = true) {
+                       void* partial_ws, size_t partial_bytes, hipStream_t st) {
     const int64_t M = L.M;
     const int K = L.K;
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || !Bm || !C) return ML3D_E_INVALID;
     int splits = pick_splits(M, N, K);
     if (splits > 1 && (!partial_ws || partial_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N)) splits = 1;
-    if (splits == 1 && allow_big && gemm_launch_big(L, Bm, N, ep, C, ldc, st)) return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    if (splits == 1 && gemm_launch_big(L, Bm, N, ep, C, ldc, st)) return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     // split boundaries are multiples of the K chunk (so also of 4: float4 loads never straddle one)
     int kper = ((K + splits - 1) / splits + GM_KC - 1) / GM_KC * GM_KC;
     splits = (K + kper - 1) / kper;
@@ -807,69 +779,18 @@ int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Ep
     return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
 }
 
-// Tail of the register-blocked convolution.  A launch of T tiles on S resident workgroups takes ceil(T / S) rounds, and the
-// SECOND maps give few of them: 16 sweeps of 248 x 216 x 64 are 6696 tiles on 1536 slots = 4.36 rounds (the fifth round is a
-// third full), 124 x 108 x 128: 1674 tiles on 512 slots = 3.27, 62 x 54 x 256: 837 on 512 = 1.63.  The images of a batch are
-// independent, so the batch is cut where the full rounds end: the first B1 images on the 128-row tiles, the remaining few on the
-// 64 x 64 tiles of gemm_tile (2048 slots, a fraction of ONE short round).  MEASURED (round 3, gpurun_out/r3n, one box, two runs
-// each): SLOWER -- SECOND 3x3 64 -> 64 at 16 sweeps 0.672 / 0.639 ms cut 14 + 2 against 0.628 / 0.623 ms uncut, PointPillars
-// 1223 / 1228 against 1251 / 1249 frames/s: the two images on the small tiles cost more than the third-full last round they
-// replace (the launch boundary and the 64 x 64 kernel's lower efficiency eat it).  OFF by default; ML3D_GEMM_TAIL_SPLIT=1
-// (read once) switches it on for further experiments.
-static int conv_tail_split(const ConvA& A, int N, int K, const float* Bm, const Epilogue& ep) {
-    static const bool on = [] { const char* e = getenv("ML3D_GEMM_TAIL_SPLIT"); return e && e[0] == '1'; }();
-    if (!on || A.B < 2 || ep.ps > 0) return 0;
-    const int64_t rows = (int64_t)A.OH * A.OW, M = rows * A.B;
-    const int bn = big_bn(M, N, K, Bm, ep);
-    if (!bn || (A.C % GM_KC) != 0) return 0;
-    const int kc = big_kc(K, A.C, bn);
-    const size_t lds = sizeof(float) * ((size_t)G2_BM * (kc + 4) + (size_t)kc * (bn + 4));
-    int wg_cu = (int)(163840 / lds);
-    wg_cu = wg_cu > 8 ? 8 : (wg_cu < 1 ? 1 : wg_cu);
-    if (bn == 128 && wg_cu > 5) wg_cu = 5;                       // (96 registers: five waves per SIMD)
-    // (ML3D_GEMM_TAIL_SLOTS, read once: the resident-workgroup count assumed -- the emulator tests set a tiny one so that
-    //  small maps exercise the cut)
-    static const int64_t slots_env = [] { const char* e = getenv("ML3D_GEMM_TAIL_SLOTS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-    const int64_t slots = slots_env > 0 ? slots_env : 256ll * wg_cu, ct = (N + bn - 1) / bn;
-    auto tiles = [&](int64_t b) { return (b * rows + G2_BM - 1) / G2_BM * ct; };
-    const int64_t total = tiles(A.B), full = total / slots;
-    const double frac = (double)total / (double)slots - (double)full;
-    if (full < 1 || full > 10 || frac < 0.04 || frac > 0.62) return 0;
-    int b1 = (int)(full * slots * G2_BM / (ct * rows));
-    while (b1 > 0 && tiles(b1) > full * slots) --b1;
-    if (b1 < 1 || b1 >= A.B) return 0;
-    if (big_bn(rows * b1, N, K, Bm, ep) == 0) return 0;           // the head must still qualify for the 128-row tiles
-    static const bool dbg = getenv("ML3D_GEMM_TAIL_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[ml3d] conv tail split: %d + %d images (%lld tiles, %lld slots)\n", b1, A.B - b1, (long long)total, (long long)slots);
-    return b1;
-}
-
+// (A cut of the batch at the last full round of tiles -- the tail images on the 64 x 64 kernel -- was measured in round 3 and
+//  was slower: 0.672 / 0.639 against 0.628 / 0.623 ms for SECOND's 3x3 64 -> 64 at 16 sweeps; PointPillars' two lanes fill the
+//  partly filled last rounds instead, ml3d/engine.py.)
 int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws,
               size_t partial_bytes, hipStream_t stream) {
     if (!A.in || (A.C & 3) || A.KH <= 0 || A.KW <= 0 || A.stride <= 0) return ML3D_E_INVALID;
-    const int K = A.KH * A.KW * A.C;
-    const int b1 = conv_tail_split(A, N, K, Bm, ep);
-    for (int part = 0; part < (b1 > 0 ? 2 : 1); ++part) {
-        ConvA P = A;
-        Epilogue e = ep;
-        float* Cp = C;
-        if (b1 > 0) {
-            const int64_t rows = (int64_t)A.OH * A.OW;
-            const int b0 = part == 0 ? 0 : b1;
-            P.B = part == 0 ? b1 : A.B - b1;
-            P.in = A.in + (int64_t)b0 * A.H * A.W * A.C;
-            Cp = C + (int64_t)b0 * rows * ldc;
-            if (e.residual) e.residual = ep.residual + (int64_t)b0 * rows * ep.ldr;
-        }
-        ConvLoader L;
-        L.A = P;
-        L.M = (int64_t)P.B * P.OH * P.OW;
-        L.K = K;
-        L.chunk_uniform = (A.C % GM_KC) == 0 ? 1 : 0;
-        const int rc = gemm_launch(L, Bm, N, e, Cp, ldc, partial_ws, partial_bytes, stream, !(b1 > 0 && part == 1));
-        if (rc) return rc;
-    }
-    return 0;
+    ConvLoader L;
+    L.A = A;
+    L.M = (int64_t)A.B * A.OH * A.OW;
+    L.K = A.KH * A.KW * A.C;
+    L.chunk_uniform = (A.C % GM_KC) == 0 ? 1 : 0;
+    return gemm_launch(L, Bm, N, ep, C, ldc, partial_ws, partial_bytes, stream);
 }
 
 }  // namespace ml3d

@@ -658,42 +658,44 @@ patch_bump(const int32_t* __restrict__ sel, const float* __restrict__ d2, const 
     possibility[sel[j]] += (double)__fmul_rn(t, t);                 // float64 += float32 square
 }
 
-// one workgroup: the whole patch staged in LDS by all threads (5 120 rows per stage), then threads 0..2 add their
-// column IN ROW ORDER -- 32 LDS reads in flight under 32 DEPENDENT adds (the chain is the 45 056 additions; their operands'
-// latency must not sit on it)
+// one workgroup: 5 120 rows per stage transposed into LDS (column-major) by all threads, then threads 0..2 add their column IN
+// ROW ORDER: the chain is the 45 056 dependent additions, so everything else is kept off it -- 16-byte LDS reads, eight of
+// them (32 values) in flight under the 32 adds of the previous block, two register blocks in ping-pong (no copies)
 __global__ void __launch_bounds__(256)
 patch_mean_seq(const float* __restrict__ pts, int64_t k, float* __restrict__ mean_out) {
     constexpr int ROWS = 5120;            // 60 KB of LDS per stage
-    __shared__ float buf[ROWS * 3];
+    __shared__ __attribute__((aligned(16))) float buf[3 * ROWS];
     float s = 0.f;
     for (int64_t base = 0; base < k; base += ROWS) {
         const int rows = (int)min<int64_t>(ROWS, k - base);
-        const float4* src4 = reinterpret_cast<const float4*>(pts + 3 * base);         // (3 * base * 4 bytes: 16-byte aligned, ROWS % 4 == 0)
-        const int n4 = rows * 3 / 4;
-        for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(buf)[e] = src4[e];
-        for (int e = n4 * 4 + threadIdx.x; e < rows * 3; e += 256) buf[e] = pts[3 * base + e];
+        for (int e = threadIdx.x; e < rows * 3; e += 256) {
+            const int r = e / 3, c = e - 3 * r;
+            buf[c * ROWS + r] = pts[3 * base + e];
+        }
         __syncthreads();
         if (threadIdx.x < 3) {
-            const float* col = buf + threadIdx.x;
+            const float* col = buf + threadIdx.x * ROWS;
+            const float4* col4 = reinterpret_cast<const float4*>(col);
             int r = 0;
-            float v[32];
-            if (rows >= 32) {
+            if (rows >= 64) {
+                float4 a[8], b[8];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = col[3 * i];
-                for (; r + 64 <= rows; r += 32) {
-                    float w[32];
+                for (int i = 0; i < 8; ++i) a[i] = col4[i];
+                for (; r + 96 <= rows; r += 64) {
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) w[i] = col[3 * (r + 32 + i)];
+                    for (int i = 0; i < 8; ++i) b[i] = col4[(r + 32) / 4 + i];
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) s = __fadd_rn(s, v[i]);
+                    for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, a[i].x); s = __fadd_rn(s, a[i].y); s = __fadd_rn(s, a[i].z); s = __fadd_rn(s, a[i].w); }
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) v[i] = w[i];
+                    for (int i = 0; i < 8; ++i) a[i] = col4[(r + 64) / 4 + i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, b[i].x); s = __fadd_rn(s, b[i].y); s = __fadd_rn(s, b[i].z); s = __fadd_rn(s, b[i].w); }
                 }
 #pragma unroll
-                for (int i = 0; i < 32; ++i) s = __fadd_rn(s, v[i]);
+                for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, a[i].x); s = __fadd_rn(s, a[i].y); s = __fadd_rn(s, a[i].z); s = __fadd_rn(s, a[i].w); }
                 r += 32;
             }
-            for (; r < rows; ++r) s = __fadd_rn(s, col[3 * r]);
+            for (; r < rows; ++r) s = __fadd_rn(s, col[r]);
         }
         __syncthreads();
     }

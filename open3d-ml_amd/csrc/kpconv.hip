@@ -517,199 +517,13 @@ static bool launch_small_fused(const KpArgs& a, const KpOut& o, hipStream_t st) 
 
 // the fused first-layer kernel takes cin <= 5 with 32 | cout <= 128 and 16-byte aligned weights / bias / out
 static bool small_fused_ok(const KpArgs& a, const KpOut& o) {
-    // ML3D_KP_SMALL_FUSED=0 (read once): the two-kernel path (kp_weighted_small + K = 15 * cin GEMM) for A/B runs
-    static const bool on = [] { const char* e = getenv("ML3D_KP_SMALL_FUSED"); return !(e && e[0] == '0'); }();
-    return on && a.cin <= 5 && o.cout % 32 == 0 && o.cout <= 128 &&
+    return a.cin <= 5 && o.cout % 32 == 0 && o.cout <= 128 &&
            ((((uintptr_t)o.weights) | ((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 15) == 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// kp_fused32 -- the Cin = 32 -> Cout = 32 block (the KPConv inside the two full-resolution resnet bottlenecks of every
-// first_features_dim = 128 config: 640 000 queries x 73 neighbours at the Toronto3D bench size) as ONE kernel.
-// The two-kernel form writes wf [Nq, 480] (1.2 GB) and reads it back in a K = 480, N = 32 GEMM that HBM bounds at a sixth of
-// the matrix peak: 0.68 + 0.75 ms.  Here a persistent workgroup owns a tile of 16 queries:
-//   aggregation (as kp_weighted<32, 1>: 32 lanes per query = one channel each, 8 packed accumulators = 16 kernel-point slots,
-//     wave w takes queries 4w .. 4w+3 two at a time; the feature rows of U neighbours are requested before the first is used --
-//     the kernel runs at 3 waves per SIMD, the two-kernel form hid that latency with 8)
-//   -> wf tile [16][512] in LDS (slot 15 of the 16 kernel points is padding, its rows of the weight matrix are zeros)
-//   -> v_mfma_f32_16x16x4_f32: wave w multiplies the tile's columns [128 w, 128 w + 128) with ITS rows of the kernel weights,
-//     held in 64 registers for the whole launch (lane (col, g) of block s, step j: W[128 w + 16 s + 4 g + j][16 nt + col]);
-//     A = one ds_read_b128 per lane and block (row = lane & 15, the lane's four k)
-//   -> the four waves' partial [16 x 32] sums through LDS, bias (folded BN) + activation, 128-byte output rows.
-// The f32 MFMA and the packed FMAs of the aggregation share the issue slots of a SIMD (tools/micro), so the product costs its
-// 64 MFMAs per wave and tile (~2 k cycles on ~10 k of aggregation) -- and the 2.4 GB round trip of wf is gone.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int KF_TQ = 16;                 // queries per tile
-constexpr int KF_K = KP_WP * 32;          // padded K: 16 kernel-point slots x 32 channels
-constexpr int KF_WFP = KF_K + 4;          // LDS pitch of a query's weighted features
-constexpr int KF_HC = 16;                 // neighbours per influence chunk
-constexpr int KF_U = 4;                   // feature rows in flight per lane
-
-#ifndef KF_MIN_WGS
-#define KF_MIN_WGS 3            // workgroups per CU the register allocation aims at (build-time A/B: tools/build_variant.sh)
-#endif
-__global__ void __launch_bounds__(256, KF_MIN_WGS) kp_fused32(KpArgs A, KpOut O) {
-    constexpr int CIN = 32, COUT = 32;
-    __shared__ __attribute__((aligned(16))) float WF[KF_TQ * KF_WFP];
-    __shared__ __attribute__((aligned(16))) float W[4][2][KF_HC][KP_WP];
-    __shared__ int NI[4][2][KF_HC];
-    __shared__ __attribute__((aligned(16))) float RED[4][KF_TQ][COUT];
-    __shared__ float KPs[KP_WP * 3];                 // x[16] | y[16] | z[16]; the sixteenth point is padding
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < KP_WP * 3) KPs[tid] = (tid % KP_WP) < KP_K ? A.kp[3 * (tid % KP_WP) + tid / KP_WP] : 0.f;
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    // this wave's rows of the kernel weights, in MFMA B layout
-    const int col = lane & 15, g = lane >> 4;
-    float bw[8][4][2];
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kk = 128 * wave + 16 * s + 4 * g + j;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float v = O.weights[(kk < KP_K * CIN ? kk : 0) * COUT + 16 * nt + col];
-                bw[s][j][nt] = kk < KP_K * CIN ? v : 0.f;
-            }
-        }
-    __syncthreads();
-    const int64_t tiles = (A.nq + KF_TQ - 1) / KF_TQ;
-    // XCD-contiguous walk: workgroup b runs on XCD b & 7 (round-robin dispatch); each XCD takes one contiguous eighth of the
-    // tiles, so the neighbour rows a tile's queries share with the next tile stay in that XCD's L2
-    const int64_t per_xcd = (tiles + 7) / 8;
-    const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
-    const int qi = lane >> 5, c = lane & 31;
-    for (int64_t it = blockIdx.x >> 3; it < per_xcd; it += slots) {
-        const int64_t tile = (int64_t)xcd * per_xcd + it;
-        if (tile >= tiles) break;
-        const int64_t tq0 = tile * KF_TQ;
-        for (int sub = 0; sub < 2; ++sub) {
-            const int row0 = 4 * wave + 2 * sub;                     // tile rows of this pass: row0, row0 + 1
-            const int64_t q0 = tq0 + row0;
-            v2f acc[KP_WP / 2];
-#pragma unroll
-            for (int k = 0; k < KP_WP / 2; ++k) acc[k] = (v2f){0.f, 0.f};
-            for (int h0 = 0; h0 < A.h; h0 += KF_HC) {
-                // ---- influence weights of the chunk's 2 x 16 (query, neighbour) pairs: lane = (pair, half of the 8 kernel-point
-                //      pairs) -> LDS; shadow pairs get zero weights and index -1 --------------------------------------------
-                const int pr = lane >> 1, half = lane & 1;
-                const int pq = pr / KF_HC, ph = pr % KF_HC;
-                const int64_t qq = q0 + pq;
-                const int hh = h0 + ph;
-                int idx = -1;
-                if (qq < A.nq && hh < A.h) {
-                    idx = A.inds[qq * A.h + hh];
-                    if (idx < 0 || idx >= A.ns) idx = -1;            // shadow neighbour (kpconv.py:1048-1051)
-                }
-                if (half == 0) NI[wave][pq][ph] = idx;
-                kp_v2f* wrow = reinterpret_cast<kp_v2f*>(&W[wave][pq][ph][8 * half]);
-                if (idx >= 0) {
-                    const float* sp = A.s_pts + 3 * (int64_t)idx;
-                    const float* qp = A.q_pts + 3 * qq;
-                    const float nx = sp[0] - qp[0], ny = sp[1] - qp[1], nz = sp[2] - qp[2];
-                    const kp_v2f* kx = reinterpret_cast<const kp_v2f*>(KPs) + 4 * half;
-                    const kp_v2f* ky = reinterpret_cast<const kp_v2f*>(KPs + KP_WP) + 4 * half;
-                    const kp_v2f* kz = reinterpret_cast<const kp_v2f*>(KPs + 2 * KP_WP) + 4 * half;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        wrow[k] = kp_influence2((kp_v2f){nx, nx} - kx[k], (kp_v2f){ny, ny} - ky[k], (kp_v2f){nz, nz} - kz[k], A);
-                    if (half == 1) W[wave][pq][ph][KP_K] = 0.f;      // the padding slot of the last pair
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) wrow[k] = (kp_v2f){0.f, 0.f};
-                }
-                // entries of the chunk in use: up to the last real neighbour of either query (rows list them first)
-                const unsigned long long real = __ballot(idx >= 0);
-                int hn = 0;
-                if (real) {
-                    const unsigned lo = (unsigned)real, hi = (unsigned)(real >> 32);         // pairs of query 0 / query 1
-                    const int t0 = lo ? (31 - __builtin_clz(lo)) / 2 + 1 : 0, t1 = hi ? (31 - __builtin_clz(hi)) / 2 + 1 : 0;
-                    hn = t0 > t1 ? t0 : t1;
-                }
-                wave_lds_sync();
-                // ---- stream the neighbours' feature rows, KF_U rows in flight ---------------------------------------------
-                for (int p0 = 0; p0 < hn; p0 += KF_U) {
-                    float xv[KF_U];
-#pragma unroll
-                    for (int u = 0; u < KF_U; ++u) {
-                        const int id = p0 + u < KF_HC ? NI[wave][qi][p0 + u] : -1;
-                        xv[u] = id >= 0 ? A.x[(int64_t)id * CIN + c] : 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < KF_U; ++u) {
-                        if (p0 + u < KF_HC) {
-                            const float4* wp = reinterpret_cast<const float4*>(&W[wave][qi][p0 + u][0]);
-                            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-                            const v2f wk[8] = {(v2f){w0.x, w0.y}, (v2f){w0.z, w0.w}, (v2f){w1.x, w1.y}, (v2f){w1.z, w1.w},
-                                               (v2f){w2.x, w2.y}, (v2f){w2.z, w2.w}, (v2f){w3.x, w3.y}, (v2f){w3.z, w3.w}};
-#pragma unroll
-                            for (int k = 0; k < KP_WP / 2; ++k) acc[k] = __builtin_elementwise_fma(wk[k], (v2f){xv[u], xv[u]}, acc[k]);
-                        }
-                        // (keeps the next neighbour's 16 weights out of registers until this one's FMAs are issued: with all four
-                        //  hoisted the kernel needs 192 VGPRs = 2 waves per SIMD instead of 3)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                wave_lds_sync();
-            }
-            // weighted features of the pass's two queries -> the tile (row index of the weight matrix = k * 32 + c)
-            float* wf = WF + (row0 + qi) * KF_WFP + c;
-#pragma unroll
-            for (int k = 0; k < KP_WP / 2; ++k) { wf[(2 * k) * CIN] = acc[k].x; wf[(2 * k + 1) * CIN] = acc[k].y; }
-        }
-        block_sync_lds();
-        // ---- [16 x 512] x [512 x 32]: this wave's 128 columns of the tile against its rows of the weights -----------------
-        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = WF + col * KF_WFP + 128 * wave + 4 * g;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[s][0][0], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[s][0][1], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[s][1][0], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[s][1][1], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[s][2][0], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[s][2][1], d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[s][3][0], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[s][3][1], d1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                                 // lane holds rows 4g .. 4g+3 of column col
-            RED[wave][4 * g + r][col] = d0[r];
-            RED[wave][4 * g + r][16 + col] = d1[r];
-        }
-        block_sync_lds();
-        {   // ---- sum of the four partials + bias + activation: thread = (row, pair of output channels) --------------------
-            const int row = tid >> 4, co = 2 * (tid & 15);
-            float2 r = O.bias ? *reinterpret_cast<const float2*>(O.bias + co) : make_float2(0.f, 0.f);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float2 p = *reinterpret_cast<const float2*>(&RED[w][row][co]);
-                r.x += p.x; r.y += p.y;
-            }
-            if (O.act == 1) { r.x = r.x > 0.f ? r.x : r.x * O.slope; r.y = r.y > 0.f ? r.y : r.y * O.slope; }
-            else if (O.act == 2) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; }
-            if (tq0 + row < A.nq) *reinterpret_cast<float2*>(O.out + (tq0 + row) * (int64_t)COUT + co) = r;
-        }
-        // (the next tile's WF rows are written after its aggregation, its RED after its first barrier: no third barrier)
-    }
-}
-
-// the fused block takes cin = cout = 32 with 8-byte aligned bias / out (ML3D_KP_FUSED32=0, read once: the two-kernel path)
-static bool fused32_ok(const KpArgs& a, const KpOut& o) {
-    static const bool on = [] { const char* e = getenv("ML3D_KP_FUSED32"); return e && e[0] == '1'; }();
-    return on && a.cin == 32 && o.cout == 32 && a.h > 0 && ((((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 7) == 0;
-}
-
-static void launch_fused32(const KpArgs& a, const KpOut& o, hipStream_t st) {
-    const int64_t tiles = (a.nq + KF_TQ - 1) / KF_TQ;
-    static const int per_cu = [] { const char* e = getenv("ML3D_KP_FUSED32_WGS"); int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
-    int64_t nb = (tiles + 7) / 8 * 8;                             // a multiple of 8: one slot row per XCD
-    const int64_t cap = (int64_t)per_cu * 256;
-    if (nb > cap) nb = cap;
-    hipLaunchKernelGGL(kp_fused32, dim3((unsigned)nb), dim3(256), 0, st, a, o);
-}
+// (A one-kernel Cin = 32 -> Cout = 32 block -- a persistent workgroup aggregating 16 queries into an LDS tile and multiplying it
+//  with register-resident kernel weights -- was built in round 3, parity-green and SLOWER than the two kernels: 1.69 against
+//  1.45 ms, 168 registers + 50 KB of LDS = 3 waves per SIMD; removed in round 4)
 
 // max over the listed neighbours (shadow rows are zeros) / feature of the first listed neighbour
 __global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, const int32_t* __restrict__ inds,
@@ -797,9 +611,8 @@ static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
 // the MFMA aggregation takes cin in {16, 32, 64, 128, 256} and 16-byte aligned features / wf
 // (ML3D_KP_AGG_MFMA=0, read once: the packed-FMA kernels for A/B runs)
 static bool agg_mfma_ok(const KpArgs& a) {
-    static const bool on = [] { const char* e = getenv("ML3D_KP_AGG_MFMA"); return !(e && e[0] == '0'); }();
     const int c = a.cin;
-    return on && (c == 16 || c == 32 || c == 64 || c == 128 || c == 256 || (c == 512 && a.off)) && a.h > 0 && a.ns > 0 &&
+    return (c == 16 || c == 32 || c == 64 || c == 128 || c == 256 || (c == 512 && a.off)) && a.h > 0 && a.ns > 0 &&
            a.nq > 0 &&
            ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
 }
@@ -891,9 +704,6 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
             case 4: launch_small_fused<4>(a, ko, st); break;
             default: launch_small_fused<5>(a, ko, st); break;
         }
-        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
-    } else if (fused32_ok(a, ko)) {
-        launch_fused32(a, ko, st);
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
     int rc = launch_weighted(a, st);

@@ -30,30 +30,25 @@ namespace ml3d {
 // of the process; the library keeps no other state.  (The variant tests run one process per setting.)
 struct Knobs {
     bool attn_xcd, attn_split, dec_split, dec_fc1, mlp_shaped;
-    bool force_valu, no_fuse;         // ML3D_RANDLA_PATH = valu | unfused
-    int linear;                       // ML3D_RANDLA_LINEAR: 0 default, 2 = valu
+    bool force_valu, no_fuse;
+    int linear;
     int attn_grid, attn16_grid;
     long long fuse_rows;
 };
-static bool knob_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
+// The A/B switches of rounds 1-3 are settled (numbers in DESIGN.md §3.3, §9): XCD-aware tile walk, split score Linear, split
+// decoder, decoder-last + fc1 chain and shaped MLP chains are ON wherever their shape conditions hold; the generic VALU kernels
+// and the per-layer launches remain as the fallback for widths / sizes the MFMA kernels do not cover.  One value is still read
+// from the environment, once: ML3D_RANDLA_FUSE_ROWS, the row count from which per-point chains fuse (the emulator tests lower
+// it so that small levels reach the fused kernels).
 static const Knobs& knobs() {
     static const Knobs k = [] {
         Knobs v;
-        v.attn_xcd = !knob_off("ML3D_ATTN_XCD");
-        v.attn_split = !knob_off("ML3D_ATTN_SPLIT");
-        v.dec_split = !knob_off("ML3D_DEC_SPLIT");
-        v.dec_fc1 = !knob_off("ML3D_RANDLA_DEC_FC1");
-        v.mlp_shaped = !knob_off("ML3D_RANDLA_MLP_SHAPED");
-        const char* e = getenv("ML3D_RANDLA_PATH");
-        v.force_valu = e && e[0] == 'v';
-        v.no_fuse = e && e[0] == 'u';
-        e = getenv("ML3D_RANDLA_LINEAR");
-        v.linear = (e && e[0] == 'v') ? 2 : 0;
-        e = getenv("ML3D_ATTN_GRID");
-        v.attn_grid = e ? atoi(e) : 2560;
-        e = getenv("ML3D_ATTN16_GRID");
-        v.attn16_grid = e ? atoi(e) : 4096;
-        e = getenv("ML3D_RANDLA_FUSE_ROWS");
+        v.attn_xcd = v.attn_split = v.dec_split = v.dec_fc1 = v.mlp_shaped = true;
+        v.force_valu = v.no_fuse = false;
+        v.linear = 0;
+        v.attn_grid = 2560;
+        v.attn16_grid = 4096;
+        const char* e = getenv("ML3D_RANDLA_FUSE_ROWS");
         v.fuse_rows = e ? atoll(e) : 64 * 1024;
         return v;
     }();

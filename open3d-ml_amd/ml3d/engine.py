@@ -104,9 +104,8 @@ class PipelinedRandLAEngine:
         self.eng[1].params = self.eng[0].params            # one weight replica
         self.device = self.eng[0].device
         with torch.cuda.device(self.device):
-            ps, pc = (int(v) for v in os.environ.get("ML3D_STREAM_PRIO", "0,0").split(","))     # A/B knob: HIP stream priorities
-            self.search = torch.cuda.Stream(priority=ps)
-            self.compute = torch.cuda.Stream(priority=pc)
+            self.search = torch.cuda.Stream()             # (HIP stream priorities were measured in round 3: no effect)
+            self.compute = torch.cuda.Stream()
             self.knn_done = [torch.cuda.Event(), torch.cuda.Event()]
             self.fwd_done = [torch.cuda.Event(), torch.cuda.Event()]
             # WHEN the next batch's search may start, relative to the running forward.  The search launch is VALU-bound
@@ -276,9 +275,8 @@ class KPConvPipeline:
             raise RuntimeError("KPConvPipeline needs an MI355X device; there is no CPU fallback")
         with torch.cuda.device(self.device):
             # (the build is the critical path of a step: its stream gets the higher HIP priority, +1 % measured)
-            pb, pc = (int(v) for v in os.environ.get("ML3D_KP_STREAM_PRIO", "-1,0").split(","))
-            self.build = torch.cuda.Stream(priority=pb)
-            self.compute = torch.cuda.Stream(priority=pc)
+            self.build = torch.cuda.Stream(priority=-1)
+            self.compute = torch.cuda.Stream(priority=0)
         self.pending = None          # (batch, built event)
         self.alive = []              # results whose forward may still be reading the batch tensors (allocated on `build`)
         self.pool = None
@@ -423,9 +421,13 @@ class PointPillarsStream:
         return tuple(sum((list(p[i]) for p in parts), []) for i in range(3))
 
     def submit(self, host_clouds):
+        """A step with fewer sweeps than lanes (a final short step) uses the first lanes only; the idle lanes still hand over
+        THEIR share of the previous step here, so the merged result always is exactly the previous step's detections, in order."""
         n, k = len(host_clouds), len(self.lanes)
-        k = max(1, min(k, n))
-        return self._merge([self.lanes[i].submit(host_clouds[i * n // k:(i + 1) * n // k]) for i in range(k)])
+        use = max(1, min(k, n))
+        parts = [self.lanes[i].submit(host_clouds[i * n // use:(i + 1) * n // use]) for i in range(use)]
+        parts += [self.lanes[i].flush() for i in range(use, k)]
+        return self._merge(parts)
 
     def flush(self):
         return self._merge([lane.flush() for lane in self.lanes])

@@ -250,17 +250,6 @@ class _DenseRadiusPlan:
         return idx
 
 
-def _one_pass_radius():
-    # ML3D_RADIUS_ONE_PASS=0 (read once): the two-phase search for the dense result as well (A/B runs)
-    global _ONE_PASS
-    try:
-        return _ONE_PASS
-    except NameError:
-        import os
-        _ONE_PASS = os.environ.get("ML3D_RADIUS_ONE_PASS", "1") != "0"
-        return _ONE_PASS
-
-
 def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius, grid_from=None, long_rows=False):
     """Deferred first half of ``radius_neighbors_dense``: the search is enqueued, its sizes not read yet.  ``grid_from``: an
     already filled plan over the same supports and radius whose grid is reused.  ``long_rows``: the caller expects rows beyond
@@ -268,7 +257,7 @@ def radius_plan_dense(queries, supports, q_lengths, s_lengths, radius, grid_from
     straight to the two-phase search instead of gathering once, overflowing and searching again."""
     dev = supports.device
     prs, qrs = _splits_of_lengths(s_lengths, dev)[0], _splits_of_lengths(q_lengths, dev)[0]
-    if _one_pass_radius() and not long_rows:
+    if not long_rows:
         return _DenseRadiusPlan(supports, queries, radius, prs, qrs, grid_from=grid_from)
     return _RadiusPlan(supports, queries, radius, prs, qrs, defer=True)
 

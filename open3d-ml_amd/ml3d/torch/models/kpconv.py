@@ -305,8 +305,8 @@ class KPFCNN(nn.Module):
         return ops.linear(x, p['wt'], p['b'], a2=a2, gather=gather, residual=residual,
                           act=p['act'] if act is None else act, slope=p['slope'] if slope is None else slope)
 
-    _SPLIT_DECODER = os.environ.get("ML3D_KP_DECODER_SPLIT", "1") != "0"     # A/B knob (speed only), read once
-    _FUSE_SHORTCUT = os.environ.get("ML3D_KP_FUSE_SHORTCUT", "1") != "0"     # A/B knob: unary2 + shortcut Linear as one GEMM
+    _SPLIT_DECODER = True        # decoder step split by linearity (+2 %); False = one gather + concat GEMM
+    _FUSE_SHORTCUT = True        # unary2 + shortcut Linear as ONE GEMM over the concatenated K
 
     def _upsample_concat_unary(self, p, x, skip, up):
         """NearestUpsampleBlock + torch.cat + UnaryBlock of the decoder (kpconv.py:283-286, 821-838, 1468-1481):

@@ -139,24 +139,12 @@ def _run_variant(knobs, ci, B, N, seed_pts, seed_w):
 
 
 @pytest.mark.parametrize("ci,B,N", [(0, 2, 1024), (2, 3, 1100)])
-def test_randla_forward_fused_and_unfused_linear_chains_agree(ci, B, N):
-    """pool2.mlp + (mlp2 | shortcut) as one 2-layer chain launch (large levels) vs one launch per Linear; with the row
-    threshold at 1 the shape-compiled per-wave kernels (incl. decoder-last + fc1) run at these small sizes too."""
+def test_randla_forward_fused_linear_chains(ci, B, N):
+    """pool2.mlp + (mlp2 | shortcut) as one 2-layer chain launch, decoder-last + fc1 as one 4-layer chain: these per-wave kernels
+    take levels of >= 64 k rows; ML3D_RANDLA_FUSE_ROWS=1 (the library's one test hook, read once per process) lets the small
+    levels the emulator can afford reach them.  The default (per-layer launches at this size) runs in every other test here; the
+    generic VALU kernels (lfa_stage, linear_act: the fallback for widths without an MFMA kernel) in the dim_output [8, 32] config."""
     _run_variant({"ML3D_RANDLA_FUSE_ROWS": "1"}, ci, B, N, 4, 12)
-    _run_variant({"ML3D_RANDLA_FUSE_ROWS": "1", "ML3D_RANDLA_PATH": "unfused"}, ci, B, N, 4, 12)
-
-
-@pytest.mark.parametrize("knobs", [
-    {"ML3D_ATTN_SPLIT": "0"},                                    # score Linear un-split (gathered features through the MFMAs)
-    {"ML3D_DEC_SPLIT": "0", "ML3D_RANDLA_DEC_FC1": "0"},         # decoder as one gather+concat GEMM per stage, separate fc1
-    {"ML3D_RANDLA_MLP_SHAPED": "0", "ML3D_RANDLA_FUSE_ROWS": "1"},   # no fused chains: one Linear per layer
-    {"ML3D_RANDLA_PATH": "valu"},                                # the generic VALU kernels (the fallback for odd widths)
-    {"ML3D_RANDLA_LINEAR": "valu"},                              # scalar Linear kernel
-    {"ML3D_ATTN_XCD": "0"},                                      # plain tile order
-])
-def test_randla_forward_kernel_variants_agree_with_oracle(knobs):
-    """Every A/B knob selects a different kernel for the same math: each variant must meet the same 1e-4 gate."""
-    _run_variant(knobs, 0, 2, 1024, 9, 13)
 
 
 def test_tile_order_is_a_cloud_major_spatial_permutation():

@@ -1,5 +1,7 @@
 """CPU: the KPConv building blocks (kpconv.hip + gemm.hip) through the host emulator vs the oracle's
 PyTorch restatement of the reference ops (oracle/kpconv_ref.py) — float tolerance 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -142,20 +144,15 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("fused,wgs", [("1", "1"), ("0", "3")])        # (the fused block is opt-in: measured slower)
-def test_kpconv_32_to_32_fused_block_walks_several_tiles_per_workgroup(fused, wgs):
-    """cin = cout = 32 runs as ONE kernel (kp_fused32: aggregation -> wf tile in LDS -> MFMA against register-resident kernel
-    weights -> cross-wave sum, bias, activation).  4 000+ strided queries = more 16-query tiles than the launch has workgroups
-    (ML3D_KP_FUSED32_WGS=1: 256), so a workgroup walks several tiles of its XCD's share; a query with only shadow neighbours, a
-    ragged last tile, no bias, ReLU, linear and gaussian influence.  ML3D_KP_FUSED32=0: the two-kernel path, same gate."""
-    import os
+def test_kpconv_32_to_32_block_strided_queries_shadow_rows():
+    """cin = cout = 32 (the KPConv of the full-resolution resnet blocks): MFMA aggregation + GEMM on 4 000+ strided queries, a
+    query with only shadow neighbours, a ragged last tile, no bias, ReLU, linear and gaussian influence."""
     import subprocess
     import sys
     emu.lib()
-    env = dict(os.environ, ML3D_KP_FUSED32=fused, ML3D_KP_FUSED32_WGS=wgs)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _FUSED32_CASE % {"root": root}], capture_output=True, text=True, timeout=900,
-                       cwd="/tmp", env=env)
+                       cwd="/tmp")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
