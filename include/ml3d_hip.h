@@ -245,6 +245,28 @@ int ml3d_kpconv_deformable(const float* q_pts, const float* s_pts, const int32_t
                            const float* bias, int act, float slope, int cout, float* out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training side of the rigid KPConv (ABI 5) ---------------------------------- */
+/* ml3d_kpconv_weighted: wf[q, k, c] = sum_h w[q, k, h] * features[inds[q, h], c] -- the first half of */
+/*   ml3d_kpconv_rigid (kpconv.py:1105-1137) into a caller buffer [n_queries, 15 * cin]; with it     */
+/*   KPConv.forward is `wf . weights` (kpconv.py:1139-1159) and its parameter gradient               */
+/*   `wf^T . grad_out`, both plain GEMMs of the caller.                                              */
+/* ml3d_kpconv_weighted_backward: the adjoint of that sum with respect to the features (the          */
+/*   influences depend on geometry only -- kernel points are buffers, kpconv.py:959-963):            */
+/*   grad_features[inds[q, h], c] += sum_k w[q, k, h] * grad_wf[q, k, c]; grad_features [n_supports, */
+/*   cin] is ZEROED here, then accumulated with float atomics (loss.backward() of                   */
+/*   semantic_segmentation.py:423 reaches it through ml3d.ops.KPConvFunction).                       */
+int ml3d_kpconv_weighted(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                         int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                         const float* features, int cin, const float* kernel_points,
+                         int num_kernel_points, float kp_extent, int kp_influence_mode,
+                         float* out_wf, void* stream);
+
+int ml3d_kpconv_weighted_backward(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                                  int64_t n_queries, int64_t n_supports, int64_t max_neighbors, int cin,
+                                  const float* kernel_points, int num_kernel_points, float kp_extent,
+                                  int kp_influence_mode, const float* grad_wf, float* grad_features,
+                                  void* stream);
+
 /* ml3d_linear: out = act([gather(a) | a2] @ weights_t + bias + residual) on f32 MFMA.       */
 /* Replaces UnaryBlock (Linear + BatchNormBlock + LeakyReLU, kpconv.py:1288-1293), the       */
 /* residual add of ResnetBottleneckBlock (kpconv.py:1461) and, with a_gather = upsamples[:,0]*/

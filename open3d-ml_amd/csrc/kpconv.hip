@@ -718,6 +718,102 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
                      gemm_partial_bytes(n_queries, cout, KP_K * cin), st);
 }
 
+// ---- training side of the rigid KPConv ---------------------------------------------------------------
+// out = wf . W with wf[q, k, c] = sum_h w[q, k, h] x[inds[q, h], c] (kpconv.py:1105-1159); the influences w depend on geometry
+// only (kernel points are not trained).  Forward for autograd = the aggregation kernels above writing wf for the caller;
+// backward: dW = wf^T . g and dwf = g . W^T are plain GEMMs (the caller's), the adjoint of the aggregation is a scatter:
+//   dx[inds[q, h], c] += sum_k w[q, k, h] dwf[q, k, c]
+// One wave per query, lane = channel (chunks of 64): the query's 15 x 64 slice of dwf sits in registers, lanes 0..14 compute the
+// influences of a neighbour once, every lane forms its channel's sum over the kernel points from 15 broadcasts and adds it
+// to the neighbour's row with one atomic.  (Summation order over the queries that share a neighbour is the hardware's:
+// gradients are a float row, tolerance 1e-4.)
+namespace ml3d {
+
+__global__ void __launch_bounds__(256) kp_weighted_adjoint(KpArgs A, const float* __restrict__ dwf, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= A.nq) return;
+    const float qx = A.q_pts[3 * q], qy = A.q_pts[3 * q + 1], qz = A.q_pts[3 * q + 2];
+    const int k = lane < KP_K ? lane : 0;
+    const float kx = A.kp[3 * k], ky = A.kp[3 * k + 1], kz = A.kp[3 * k + 2];
+    const int32_t* row = A.inds + q * A.h;
+    for (int c0 = 0; c0 < A.cin; c0 += 64) {
+        const int c = c0 + lane;
+        const bool live = c < A.cin;
+        float g[KP_K];
+#pragma unroll
+        for (int kk = 0; kk < KP_K; ++kk) g[kk] = live ? dwf[(q * KP_K + kk) * A.cin + c] : 0.f;
+        for (int h = 0; h < A.h; ++h) {
+            const int idx = row[h];
+            if (idx < 0 || idx >= A.ns) continue;               // shadow neighbour (wave-uniform: the row is the wave's)
+            const float* sp = A.s_pts + 3 * (int64_t)idx;
+            const float dxk = (sp[0] - qx) - kx, dyk = (sp[1] - qy) - ky, dzk = (sp[2] - qz) - kz;
+            float w = kp_influence(dxk * dxk + dyk * dyk + dzk * dzk, A);
+            if (lane >= KP_K) w = 0.f;
+            float v = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KP_K; ++kk) v = fmaf(__shfl(w, kk), g[kk], v);
+            if (live) atomicAdd(dx + (int64_t)idx * A.cin + c, v);
+        }
+    }
+}
+
+}  // namespace ml3d
+
+static int kp_geometry_args(KpArgs& a, const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                            int64_t n_supports, int64_t max_neighbors, int cin, const float* kernel_points, int num_kernel_points,
+                            float kp_extent, int kp_influence_mode) {
+    if (n_queries < 0 || n_supports < 0 || max_neighbors < 0 || cin <= 0 || !(kp_extent > 0.f) || kp_influence_mode < 0 ||
+        kp_influence_mode > 2 || max_neighbors > 0x7fffffff)
+        return ML3D_E_INVALID;
+    if (num_kernel_points != KP_K || cin > 512) return ML3D_E_UNSUPPORTED;
+    if (n_queries > 0 && (!q_pts || !kernel_points || (max_neighbors > 0 && (!neighb_inds || !s_pts)))) return ML3D_E_INVALID;
+    a.q_pts = q_pts; a.s_pts = s_pts; a.inds = neighb_inds; a.nq = n_queries; a.ns = n_supports; a.h = (int)max_neighbors;
+    a.x = nullptr; a.cin = cin; a.kp = kernel_points;
+    a.inv_extent = 1.0f / kp_extent; a.influence = kp_influence_mode;
+    const float sigma = kp_extent * 0.3f;
+    a.gauss_den = 2.0f * sigma * sigma + 1e-9f;
+    a.wf = nullptr;
+    a.off = nullptr; a.off_dim = 0; a.extent = kp_extent;
+    a.c_total = cin; a.c_off = 0;
+    return 0;
+}
+
+extern "C" int ml3d_kpconv_weighted(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                    int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                    const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
+                                    float* out_wf, void* stream) {
+    KpArgs a;
+    const int rc = kp_geometry_args(a, q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, cin, kernel_points,
+                                    num_kernel_points, kp_extent, kp_influence_mode);
+    if (rc) return rc;
+    if (n_queries == 0) return 0;
+    if (!out_wf || (max_neighbors > 0 && !features)) return ML3D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (max_neighbors == 0)
+        return hipMemsetAsync(out_wf, 0, sizeof(float) * (size_t)n_queries * KP_K * (size_t)cin, st) == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    a.x = features; a.wf = out_wf;
+    return launch_weighted(a, st);
+}
+
+extern "C" int ml3d_kpconv_weighted_backward(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                                             int64_t n_queries, int64_t n_supports, int64_t max_neighbors, int cin,
+                                             const float* kernel_points, int num_kernel_points, float kp_extent,
+                                             int kp_influence_mode, const float* grad_wf, float* grad_features, void* stream) {
+    KpArgs a;
+    const int rc = kp_geometry_args(a, q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, cin, kernel_points,
+                                    num_kernel_points, kp_extent, kp_influence_mode);
+    if (rc) return rc;
+    if (n_supports == 0) return 0;
+    if (!grad_features) return ML3D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)n_supports * (size_t)cin, st) != hipSuccess) return ML3D_E_LAUNCH;
+    if (n_queries == 0 || max_neighbors == 0) return 0;
+    if (!grad_wf) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(kp_weighted_adjoint, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, a, grad_wf, grad_features);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
 extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
                                  int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
                                  const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,

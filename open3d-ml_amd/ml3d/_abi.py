@@ -37,7 +37,7 @@ SYMBOLS = [
     "ml3d_subsample_fill",
     "ml3d_rotate_points",
     "ml3d_kpconv_workspace_bytes",
-    "ml3d_kpconv_rigid", "ml3d_kpconv_deformable",
+    "ml3d_kpconv_rigid", "ml3d_kpconv_deformable", "ml3d_kpconv_weighted", "ml3d_kpconv_weighted_backward",
     "ml3d_linear_workspace_bytes",
     "ml3d_linear",
     "ml3d_gather_pool",
@@ -136,6 +136,10 @@ def bind(lib):
     lib.ml3d_kpconv_rigid.restype = C.c_int
     lib.ml3d_kpconv_rigid.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, vp, i32, f32, i32, vp,
                                       vp, sz, vp]
+    lib.ml3d_kpconv_weighted.restype = C.c_int
+    lib.ml3d_kpconv_weighted.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, vp]
+    lib.ml3d_kpconv_weighted_backward.restype = C.c_int
+    lib.ml3d_kpconv_weighted_backward.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, i32, f32, i32, vp, vp, vp]
     lib.ml3d_kpconv_deformable.restype = C.c_int
     lib.ml3d_kpconv_deformable.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, i32, vp, i32, vp, vp, i32, f32,
                                            i32, vp, vp, sz, vp]

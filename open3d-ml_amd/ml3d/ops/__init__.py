@@ -13,7 +13,8 @@ from .search import (knn_search, pyramid_sizes, randla_knn_pyramid, resolve_plan
 from .randla import randla_forward   # noqa: F401
 from .voxel import (voxelize, subsample_batch, subsample, rotate_points, grid_subsampling_plan,   # noqa: F401
                     batch_grid_subsampling, _SubsamplePlan)
-from .kpconv import kpconv_rigid, kpconv_deformable, linear, gather_pool   # noqa: F401
+from .kpconv import (kpconv_rigid, kpconv_deformable, linear, gather_pool, kpconv_weighted, kpconv_weighted_backward,   # noqa: F401
+                     KPConvFunction)
 from .detection import (pillar_features, conv2d_nhwc, deconv2d_nhwc, nhwc_to_nchw, nms, pointpillars_boxes,   # noqa: F401
                         iou_bev, iou_3d)
 from .sampler import nearest_to_center, argmax_labels, vote_update, device_patch   # noqa: F401

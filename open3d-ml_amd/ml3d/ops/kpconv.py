@@ -134,3 +134,66 @@ def gather_pool(x, inds, mode):
                                   0 if mode == "max" else 1, out.data_ptr(), _stream())
     _abi.check(rc, "ml3d_gather_pool")
     return out
+
+
+# ---- training side: the rigid KPConv as a differentiable op --------------------------------------------------
+def kpconv_weighted(q_pts, s_pts, neighb_inds, x, kernel_points, extent, influence=1):
+    """wf [Nq, 15 * cin]: the kernel-point-weighted neighbour sums of ``KPConv.forward`` (kpconv.py:1105-1137) on the HIP
+    aggregation kernels."""
+    lib = _abi.get()
+    _need_gpu(q_pts, s_pts, neighb_inds, x, kernel_points)
+    nq, ns = q_pts.shape[0], s_pts.shape[0]
+    H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
+    cin, K = x.shape[1], kernel_points.shape[0]
+    wf = torch.empty((nq, K * cin), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ml3d_kpconv_weighted(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, x.data_ptr(), cin,
+                                      kernel_points.data_ptr(), K, float(extent), int(influence), wf.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_kpconv_weighted")
+    return wf
+
+
+def kpconv_weighted_backward(q_pts, s_pts, neighb_inds, grad_wf, cin, kernel_points, extent, influence=1):
+    """dx [Ns, cin]: the adjoint of ``kpconv_weighted`` with respect to the features (a scatter-add over the neighbour lists)."""
+    lib = _abi.get()
+    _need_gpu(q_pts, s_pts, neighb_inds, grad_wf, kernel_points)
+    nq, ns = q_pts.shape[0], s_pts.shape[0]
+    H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
+    K = kernel_points.shape[0]
+    dx = torch.empty((ns, int(cin)), dtype=torch.float32, device=grad_wf.device)
+    with torch.cuda.device(grad_wf.device):
+        rc = lib.ml3d_kpconv_weighted_backward(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, int(cin),
+                                               kernel_points.data_ptr(), K, float(extent), int(influence), grad_wf.data_ptr(),
+                                               dx.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_kpconv_weighted_backward")
+    return dx
+
+
+class KPConvFunction(torch.autograd.Function):
+    """``KPConv.forward`` of the rigid branch (kpconv.py:1005-1159, no bias / norm / activation: those are the caller's modules in
+    training) with hand-written forward AND backward: forward = HIP aggregation + ``wf @ W``; backward: ``dW = wf^T @ g``,
+    ``dwf = g @ W^T`` (library GEMMs) and the HIP scatter ``ml3d_kpconv_weighted_backward`` for the features.  Geometry (points,
+    neighbour lists, kernel points) gets no gradient -- the reference does not train it either (kpconv.py:959-963)."""
+
+    @staticmethod
+    def forward(ctx, x, weights, q_pts, s_pts, neighb_inds, kernel_points, extent, influence):
+        x = x.contiguous()
+        K, cin, cout = weights.shape
+        wf = kpconv_weighted(q_pts, s_pts, neighb_inds, x, kernel_points, extent, influence)
+        ctx.save_for_backward(wf, weights, q_pts, s_pts, neighb_inds, kernel_points)
+        ctx.geom = (float(extent), int(influence), int(cin))
+        return wf @ weights.reshape(K * cin, cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        wf, weights, q_pts, s_pts, neighb_inds, kernel_points = ctx.saved_tensors
+        extent, influence, cin = ctx.geom
+        K, _, cout = weights.shape
+        g = g.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = (wf.t() @ g).reshape(K, cin, cout)
+        if ctx.needs_input_grad[0]:
+            dwf = (g @ weights.reshape(K * cin, cout).t()).contiguous()
+            dx = kpconv_weighted_backward(q_pts, s_pts, neighb_inds, dwf, cin, kernel_points, extent, influence)
+        return dx, dw, None, None, None, None, None, None

@@ -244,6 +244,11 @@ class KPFCNN(nn.Module):
         self._packed = None
         return super().load_state_dict(*a, **k)
 
+    def train(self, mode=True):
+        """(the folded-BatchNorm parameter pack of the inference kernels is stale as soon as training touches the weights)"""
+        self._packed = None
+        return super().train(mode)
+
     def invalidate_packed(self):
         self._packed = None
 
@@ -326,7 +331,7 @@ class KPFCNN(nn.Module):
         module's GPU ``KPConvBatch``.  Returns logits [N0, num_classes - ignored] like ``KPFCNN.forward``
         (kpconv.py:270-291)."""
         if self.training:
-            raise RuntimeError("KPFCNN (MI355X build) implements the inference forward only; call .eval()")
+            return self._forward_train(batch)
         dev = self.device
         _abi.require_gpu(dev, "KPFCNN.forward")
         P = self.packed_params(dev)
@@ -384,6 +389,65 @@ class KPFCNN(nn.Module):
         x = self._unary(P['head'][0], x)
         return self._unary(P['head'][1], x)
 
+
+    # ---- training forward: rigid architectures, differentiable ------------------------------------
+    def _forward_train(self, batch):
+        """``KPFCNN.forward`` in TRAINING mode (kpconv.py:270-291 with the blocks of :1343-1461): every KPConv is
+        ``ops.KPConvFunction`` -- HIP aggregation forward, hand-written HIP scatter backward, GEMMs for the weight products --
+        around it the reference's own module arithmetic on torch's autograd: BatchNorm1d on the batch statistics (NOT folded:
+        the inference kernels fold the running statistics, which training must update), LeakyReLU, bias-free Linears, the
+        max / closest pools as indexed gathers.  Deformable blocks are refused (their offset regulariser is out of scope)."""
+        import torch.nn.functional as F
+        if any('deformable' in b for b in self.cfg.architecture):
+            raise NotImplementedError("KPFCNN (MI355X build): training of deformable blocks is out of scope (SURVEY.md §8 f4)")
+        dev = self.device
+        _abi.require_gpu(dev, "KPFCNN.forward (training)")
+        lr = self.cfg.get('l_relu', 0.1)
+        infl = _INFLUENCE[self.cfg.KP_influence]
+        pts = [t.to(dev, torch.float32).contiguous() for t in batch.points]
+        idx = lambda lst: [t.to(dev).to(torch.int32).contiguous() for t in lst]
+        nbrs, pools, ups = idx(batch.neighbors), idx(batch.pools), idx(batch.upsamples)
+
+        def bn(blk, x):             # BatchNormBlock.forward (kpconv.py:1238-1249): per-channel statistics over the N rows
+            return blk.batch_norm(x) if blk.use_bn else x + blk.bias
+
+        def unary(ub, x):           # UnaryBlock.forward (kpconv.py:1288-1293)
+            x = bn(ub.batch_norm, ub.mlp(x))
+            return x if ub.no_relu else F.leaky_relu(x, ub.l_relu)
+
+        def padded(x):              # the shadow neighbour's zero feature row (kpconv.py:809-811, 848-850)
+            return torch.cat([x, torch.zeros_like(x[:1])], 0)
+
+        x = batch.features.to(dev, torch.float32).contiguous()
+        skip_x = []
+        for bi, blk in enumerate(self.encoder_blocks):
+            if bi in self.encoder_skips:
+                skip_x.append(x)
+            L = blk.layer_ind
+            strided = 'strided' in blk.block_name
+            q_pts = pts[L + 1] if strided else pts[L]
+            inds = pools[L] if strided else nbrs[L]
+            conv = blk.KPConv
+            kp_apply = lambda xin: ops.KPConvFunction.apply(xin, conv.weights, q_pts, pts[L], inds, conv.kernel_points,
+                                                            conv.KP_extent, infl)
+            if isinstance(blk, SimpleBlock):
+                x = F.leaky_relu(bn(blk.batch_norm, kp_apply(x)), lr)
+                continue
+            y = x if isinstance(blk.unary1, nn.Identity) else unary(blk.unary1, x)
+            y = F.leaky_relu(bn(blk.batch_norm_conv, kp_apply(y)), lr)
+            y = unary(blk.unary2, y)
+            sc = padded(x)[inds.long()].max(1)[0] if strided else x                     # max_pool (kpconv.py:841-858)
+            if not isinstance(blk.unary_shortcut, nn.Identity):
+                sc = unary(blk.unary_shortcut, sc)
+            x = F.leaky_relu(y + sc, lr)
+        for bi, blk in enumerate(self.decoder_blocks):
+            if bi in self.decoder_concats:
+                x = torch.cat([x, skip_x.pop()], dim=1)
+            if isinstance(blk, NearestUpsampleBlock):
+                x = padded(x)[ups[blk.layer_ind - 1][:, 0].long()]                      # closest_pool (kpconv.py:821-838)
+            else:
+                x = unary(blk, x)
+        return unary(self.head_softmax, unary(self.head_mlp, x))
 
     # ---- the reference's data path around forward (kpconv.py:353-633), on the GPU ops ---------------------------------
     def preprocess(self, data, attr):

@@ -1,0 +1,70 @@
+"""tests/golden/train_kpconv.npz: ONE training step's forward + backward of the REAL reference KPFCNN (rigid, small architecture)
+on PyTorch-CPU -- model.train() (BatchNorm on batch statistics), cross entropy on seeded labels, loss.backward()
+(semantic_segmentation.py:412-437) -- for the native training forward + hand-written KPConv backward to be held against
+(tests/test_gpu_training.py).  Stored: logits, loss, the gradient of every KPConv weight tensor and of a few Linear / norm
+parameters, one updated running mean.  Run from the repo root:  python -m oracle.gen_golden_train"""
+import importlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+import synth_data  # noqa: E402
+import synth_weights  # noqa: E402
+
+TRAIN_CFG = dict(synth_weights.TORONTO3D_CFG, first_features_dim=64, num_layers=3, in_features_dim=4,
+                 architecture=["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb_strided", "resnetb",
+                               "nearest_upsample", "unary", "nearest_upsample", "unary"])
+
+
+def train_inputs(np_seed=31):
+    spheres = [synth_data.toronto3d_sphere(61, 1800), synth_data.toronto3d_sphere(62, 1400)]
+    rng = np.random.default_rng(5)
+    cols = [np.concatenate([s, rng.random((len(s), 3), dtype=np.float32)], 1) for s in spheres]
+    labels = [rng.integers(0, 9, len(s)).astype(np.int32) for s in spheres]
+    return spheres, cols, labels
+
+
+def main():
+    os.chdir(tempfile.mkdtemp())
+    ref_shim.reference_modules()
+    from oracle import kpconv_ref as K
+    kp = importlib.import_module("ml3d.torch.models.kpconv")
+    cb = importlib.import_module("ml3d.torch.dataloaders.concat_batcher")
+    sl = importlib.import_module("ml3d.torch.modules.losses.semseg_loss")
+    cfg = dict(TRAIN_CFG)
+    model = kp.KPFCNN(**cfg)
+    sd = K.make_state_dict(cfg, 77)
+    model.load_state_dict(sd)
+    model.train()
+    spheres, cols, labels = train_inputs()
+    data = dict(p_list=spheres, f_list=cols, l_list=labels, p0_list=[np.zeros(3) for _ in spheres],
+                s_list=[np.ones(3, np.float32) for _ in spheres], R_list=[np.eye(3, dtype=np.float32) for _ in spheres],
+                r_inds_list=[np.zeros(0) for _ in spheres], r_mask_list=[np.zeros(0) for _ in spheres],
+                val_labels_list=[np.zeros(0) for _ in spheres], cfg=model.cfg)
+    model.cfg.batch_limit = 10 ** 9
+    np.random.seed(31)
+    batch = cb.KPConvBatch([{"data": data}])
+    logits = model(batch)
+    scores, lab = sl.filter_valid_label(logits, batch.labels, cfg["num_classes"], cfg["ignored_label_inds"], "cpu")
+    loss = torch.nn.CrossEntropyLoss()(scores, lab)
+    loss.backward()
+    out = dict(logits=logits.detach().numpy(), loss=np.float64(loss.item()), n_valid=np.int64(len(lab)))
+    named = dict(model.named_parameters())
+    keep = [k for k in named if k.endswith("KPConv.weights")] + ["encoder_blocks.1.unary1.mlp.weight", "encoder_blocks.2.unary2.mlp.weight",
+                                                                 "encoder_blocks.0.batch_norm.batch_norm.weight", "decoder_blocks.1.mlp.weight",
+                                                                 "head_softmax.mlp.weight", "head_mlp.batch_norm.batch_norm.bias"]
+    for k in keep:
+        out["grad:" + k] = named[k].grad.numpy()
+    out["running_mean:encoder_blocks.0"] = dict(model.named_buffers())["encoder_blocks.0.batch_norm.batch_norm.running_mean"].numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_kpconv.npz"), **out)
+    print("loss", loss.item(), "logits", logits.shape, "grads", len(keep), {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
+
+
+if __name__ == "__main__":
+    main()

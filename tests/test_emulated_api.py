@@ -299,3 +299,41 @@ for in_ch, aug in ((3, {"recenter": {"dim": [0, 1]}}), (6, {"recenter": {"dim": 
     assert np.array_equal(pa, pb) and np.array_equal(va, vb)
 print("ok")
 ''')
+
+
+def test_kpconv_autograd_function_matches_torch_autograd_of_the_oracle():
+    """ops.KPConvFunction (HIP aggregation forward, hand-written HIP scatter backward + GEMMs) against torch's own autograd
+    through the oracle's pure-torch KPConv (oracle/kpconv_ref.kpconv_rigid = kpconv.py:1005-1159): output, d/dx and d/dW, for the
+    MFMA aggregation (cin 32), the generic one (cin 8), the first-layer one (cin 4), 96 channels (two lane chunks in the adjoint),
+    strided queries and shadow columns anywhere."""
+    _run(r'''
+import synth_data
+from oracle import kpconv_ref as K
+from ml3d import ops
+rng = np.random.default_rng(2)
+s = synth_data.toronto3d_sphere(23, 700)
+q = K.batch_grid_subsampling(s, [len(s)], 0.16)[0].astype(np.float32)
+kp = K.synthetic_kernel_points(0.2)
+for cin, cout, strided, infl in ((32, 16, False, 1), (8, 24, True, 1), (4, 32, False, 2), (96, 8, True, 1)):
+    qq = q if strided else s
+    inds = K.batch_neighbors(qq, s, [len(qq)], [len(s)], 0.2).astype(np.int32)
+    inds = np.take_along_axis(inds, np.argsort(rng.random(inds.shape), axis=1), 1)        # shadows anywhere in a row
+    x = torch.from_numpy(rng.standard_normal((len(s), cin)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((15, cin, cout)) * 0.2).astype(np.float32)).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((len(qq), cout)).astype(np.float32))
+    tq, ts, ti, tk = torch.from_numpy(qq), torch.from_numpy(s), torch.from_numpy(inds), torch.from_numpy(kp)
+    ref = K.kpconv_rigid(tq, ts, ti.long(), x, tk, w, 0.24, influence={1: "linear", 2: "gaussian"}[infl]) if "influence" in K.kpconv_rigid.__code__.co_varnames \
+        else K.kpconv_rigid(tq, ts, ti.long(), x, tk, w, 0.24)
+    if infl != 1 and "influence" not in K.kpconv_rigid.__code__.co_varnames:
+        continue
+    ref.backward(g)
+    gx_ref, gw_ref = x.grad.clone(), w.grad.clone()
+    x.grad = None; w.grad = None
+    out = ops.KPConvFunction.apply(x, w, tq, ts, ti, tk, 0.24, infl)
+    out.backward(g)
+    sc = lambda t: max(1.0, float(t.abs().max()))
+    assert (out - ref).abs().max() <= 1e-4 * sc(ref), (cin, float((out - ref).abs().max()))
+    assert (x.grad - gx_ref).abs().max() <= 1e-4 * sc(gx_ref), (cin, float((x.grad - gx_ref).abs().max()))
+    assert (w.grad - gw_ref).abs().max() <= 1e-4 * sc(gw_ref), (cin, float((w.grad - gw_ref).abs().max()))
+print("ok")
+''')

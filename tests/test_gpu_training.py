@@ -1,0 +1,78 @@
+"""GPU: the training side of the rigid KPConv (narrow): KPFCNN in train mode -- every KPConv through
+``ops.KPConvFunction`` (HIP aggregation forward, hand-written HIP scatter backward), BatchNorm on batch statistics -- against ONE
+forward + backward of the REAL reference KPFCNN on PyTorch-CPU (tests/golden/train_kpconv.npz, oracle/gen_golden_train.py:
+semantic_segmentation.py:412-437's loss.backward() on the reference's module)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kpconv_ref as K
+from oracle.gen_golden_train import TRAIN_CFG, train_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    from ml3d.torch.dataloaders import kpconv_input_features
+    from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+    cfg = dict(TRAIN_CFG)
+    m = KPFCNN(**cfg, device="cuda:0")
+    m.load_state_dict(K.make_state_dict(cfg, 77))
+    spheres, cols, labels = train_inputs()
+    pts, columns = np.concatenate(spheres), np.concatenate(cols)
+    np.random.seed(31)
+    batch = KPConvBatch(pts, [len(s) for s in spheres], cfg, features=kpconv_input_features(pts, columns, cfg["in_features_dim"]).astype(np.float32),
+                        device="cuda:0")
+    batch.labels = torch.from_numpy(np.concatenate(labels).astype(np.int64))
+    return cfg, m, batch
+
+
+def test_one_training_step_forward_and_gradients_match_the_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "train_kpconv.npz"))
+    cfg, m, batch = _setup()
+    m.train()
+    logits = m(batch)
+    assert logits.requires_grad and np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= 1e-4
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    loss, labels, scores = m.get_loss(loss_obj, logits, {"data": batch}, "cuda:0")
+    assert int(labels.numel()) == int(g["n_valid"]) and abs(float(loss) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if not key.startswith("grad:"):
+            continue
+        want = g[key]
+        got = named[key[5:]].grad.detach().cpu().numpy()
+        assert got.shape == want.shape
+        # gradients here are O(1e-2): 1e-4 of the largest entry of each tensor (atomics reorder the scatter sums)
+        assert np.abs(got - want).max() <= max(2e-6, 1e-3 * float(np.abs(want).max())), (key, float(np.abs(got - want).max()), float(np.abs(want).max()))
+        checked += 1
+    assert checked == 12
+    rm = dict(m.named_buffers())["encoder_blocks.0.batch_norm.batch_norm.running_mean"].cpu().numpy()
+    assert np.abs(rm - g["running_mean:encoder_blocks.0"]).max() <= 1e-5
+
+
+def test_an_optimisation_step_lowers_the_loss_and_inference_sees_the_new_weights():
+    cfg, m, batch = _setup()
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    cfgp = type("P", (), dict(learning_rate=0.05, deform_lr_factor=0.1, momentum=0.0, weight_decay=0.0, scheduler_gamma=1.0))()
+    m.eval()
+    with torch.no_grad():
+        before = m(batch).clone()
+    m.train()
+    opt, _ = m.get_optimizer(cfgp)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss, _, _ = m.get_loss(loss_obj, m(batch), {"data": batch}, "cuda:0")
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[2] < losses[0]
+    m.eval()
+    with torch.no_grad():
+        after = m(batch)
+    assert (after - before).abs().max() > 1e-3          # the fused inference kernels repacked the trained weights
