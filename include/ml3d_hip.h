@@ -483,6 +483,19 @@ int ml3d_patch_recenter(float* pts, int64_t k, int dims_mask, const float* extra
                         float feat_bias, float feat_scale, float* out_features,
                         void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- RandLA-Net random_sample as a differentiable op (training side, SURVEY.md §8 f4, ABI 5) ------------------ */
+/* ml3d_randla_gather_max: out[b, i, c] = max_k features[b, pool_idx[b, i, k], c], i < n_out (randlanet.py:300-327;   */
+/*   pool_idx = the first n_out rows of the level's [n_in, 16] neighbour matrix, batch-local indices).                  */
+/* ml3d_randla_gather_max_backward: grad_features [batch, n_in, c] (zeroed here) += grad_out at the FIRST maximal    */
+/*   neighbour of every (b, i, c), float atomics (loss.backward() of semantic_segmentation.py:423 through              */
+/*   ml3d.ops.GatherMaxFunction).                                                                                       */
+int ml3d_randla_gather_max(const float* features, const int32_t* pool_idx, int64_t batch, int64_t n_in,
+                           int64_t n_out, int channels, float* out, void* stream);
+
+int ml3d_randla_gather_max_backward(const float* features, const int32_t* pool_idx, const float* grad_out,
+                                    int64_t batch, int64_t n_in, int64_t n_out, int channels,
+                                    float* grad_features, void* stream);
+
 /* ml3d_argmax_labels: out_labels[i] = argmax_c scores[i, c] as uint8 (num_classes <= 256; first  */
 /*   maximum, NaN = maximum, like torch.argmax) -- the predicted labels that leave the GPU          */
 /*   (SURVEY.md §8d "forward + softmax/argmax", §8e gather of predictions): 1 byte per point.       */

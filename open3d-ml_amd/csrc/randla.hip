@@ -1645,6 +1645,28 @@ gather_max4(const float* __restrict__ feat, const int32_t* __restrict__ nidx, fl
     reinterpret_cast<float4*>(out + ((size_t)b * n_out + i) * (4 * cv))[q] = v;
 }
 
+// adjoint of random_sample for training: the gradient of an output element goes to the neighbour that held
+// the maximum -- the FIRST of equal maxima, like torch.max(dim) -- with one float atomic (several kept points may share it)
+__global__ void __launch_bounds__(256)
+gather_max_adjoint(const float* __restrict__ feat, const int32_t* __restrict__ nidx, const float* __restrict__ gout,
+                   float* __restrict__ gfeat, int64_t n_in, int64_t n_out, int64_t batch, int c) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= batch * n_out * c) return;
+    const int ch = (int)(e % c);
+    const int64_t r = e / c;
+    const int64_t b = r / n_out, i = r - b * n_out;
+    const int32_t* id = nidx + (b * n_in + i) * RK;
+    float v = -3.0e38f;
+    int64_t arg = 0;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const int64_t row = b * n_in + id[k];
+        const float x = feat[row * c + ch];
+        if (x > v) { v = x; arg = row; }
+    }
+    atomicAdd(gfeat + arg * c + ch, gout[r * c + ch]);
+}
+
 struct Tracer {
     const ml3d_trace* t;
     hipStream_t st;
@@ -2083,4 +2105,31 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         }
     }
     return 0;
+}
+
+// ---- random_sample as a stand-alone differentiable op (training side) ------------------------------------
+extern "C" int ml3d_randla_gather_max(const float* features, const int32_t* pool_idx, int64_t batch, int64_t n_in, int64_t n_out,
+                                      int channels, float* out, void* stream) {
+    if (batch < 0 || n_in < 0 || n_out < 0 || n_out > n_in || channels <= 0) return ML3D_E_INVALID;
+    if (batch * n_out == 0) return 0;
+    if (!features || !pool_idx || !out) return ML3D_E_INVALID;
+    const int64_t total = batch * n_out * channels;
+    hipLaunchKernelGGL(gather_max, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, features, pool_idx, out,
+                       n_in, n_out, batch, channels);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_randla_gather_max_backward(const float* features, const int32_t* pool_idx, const float* grad_out, int64_t batch,
+                                               int64_t n_in, int64_t n_out, int channels, float* grad_features, void* stream) {
+    if (batch < 0 || n_in < 0 || n_out < 0 || n_out > n_in || channels <= 0) return ML3D_E_INVALID;
+    if (batch * n_in == 0) return 0;
+    if (!grad_features) return ML3D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)(batch * n_in) * (size_t)channels, st) != hipSuccess) return ML3D_E_LAUNCH;
+    if (n_out == 0) return 0;
+    if (!features || !pool_idx || !grad_out) return ML3D_E_INVALID;
+    const int64_t total = batch * n_out * channels;
+    hipLaunchKernelGGL(gather_max_adjoint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, features, pool_idx, grad_out,
+                       grad_features, n_in, n_out, batch, channels);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }

@@ -60,6 +60,8 @@ SYMBOLS = [
     "ml3d_patch_crop",
     "ml3d_patch_recenter",
     "ml3d_vote_update",
+    "ml3d_randla_gather_max",
+    "ml3d_randla_gather_max_backward",
     "ml3d_argmax_labels",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
@@ -187,6 +189,10 @@ def bind(lib):
     lib.ml3d_patch_crop.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, sz, vp]
     lib.ml3d_patch_recenter.restype = C.c_int
     lib.ml3d_patch_recenter.argtypes = [vp, i64, i32, vp, i32, f32, f32, vp, vp, sz, vp]
+    lib.ml3d_randla_gather_max.restype = C.c_int
+    lib.ml3d_randla_gather_max.argtypes = [vp, vp, i64, i64, i64, i32, vp, vp]
+    lib.ml3d_randla_gather_max_backward.restype = C.c_int
+    lib.ml3d_randla_gather_max_backward.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_argmax_labels.restype = C.c_int

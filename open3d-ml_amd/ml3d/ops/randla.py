@@ -77,3 +77,38 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
                                          t_n, t_i, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _abi.check(rc, "ml3d_randla_forward")
     return out
+
+
+# ---- training side: random_sample as a differentiable op ------------------------------------------------------
+class GatherMaxFunction(torch.autograd.Function):
+    """``RandLANet.random_sample`` (randlanet.py:300-327): features [B, n_in, C] point-major, pool_idx int32 [B, n_out, 16] ->
+    [B, n_out, C], the max over the 16 listed neighbours; HIP forward, hand-written HIP backward (the gradient goes to the
+    first maximal neighbour, like ``torch.max``)."""
+
+    @staticmethod
+    def forward(ctx, features, pool_idx):
+        lib = _abi.get()
+        _need_gpu(features, pool_idx)
+        features = features.contiguous()
+        pool_idx = pool_idx.to(torch.int32).contiguous()
+        B, n_in, c = features.shape
+        n_out = pool_idx.shape[1]
+        out = torch.empty((B, n_out, c), dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            rc = lib.ml3d_randla_gather_max(features.data_ptr(), pool_idx.data_ptr(), B, n_in, n_out, c, out.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_gather_max")
+        ctx.save_for_backward(features, pool_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        features, pool_idx = ctx.saved_tensors
+        B, n_in, c = features.shape
+        g = g.contiguous()
+        gf = torch.empty_like(features)
+        with torch.cuda.device(features.device):
+            rc = lib.ml3d_randla_gather_max_backward(features.data_ptr(), pool_idx.data_ptr(), g.data_ptr(), B, n_in, pool_idx.shape[1],
+                                                     c, gf.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_gather_max_backward")
+        return gf, None

@@ -131,7 +131,7 @@ class RandLANet(nn.Module):
         when present (int64 from the reference's CPU transform is accepted), otherwise the pyramid is
         searched on the GPU.  Returns scores [B, N, num_classes] like the reference."""
         if self.training:
-            raise RuntimeError("RandLANet (MI355X build) implements the inference forward only; call .eval()")
+            return self._forward_train(inputs)
         dev = self.device
         _abi.require_gpu(dev, "RandLANet.forward")
         coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
@@ -154,6 +154,87 @@ class RandLANet(nn.Module):
         B, N, _ = pts.shape
         desc = _abi.make_desc(self.cfg, B, N)
         return ops.randla_forward(desc, self.packed_params(dev), feat, pts, nbr, itp)
+
+    # ---- training forward -----------------------------------------------------------------------------------
+    def train(self, mode=True):
+        """(the folded-BatchNorm parameter pack of the fused inference kernels is stale once training touches the weights)"""
+        self._packed = None
+        return super().train(mode)
+
+    def _forward_train(self, inputs):
+        """``RandLANet.forward`` in TRAINING mode (randlanet.py:241-298 with :533-692), differentiable: point-major
+        ``[B, N, C]`` tensors, every 1x1 (transposed) convolution as the Linear it is, BatchNorm2d(eps 1e-6) on the batch
+        statistics over all rows (NOT folded), the neighbour pyramid from the HIP search when the dict carries none,
+        ``random_sample`` through ``ops.GatherMaxFunction`` (HIP forward + hand-written HIP backward); the gathers of the
+        encodings and the attentive pooling run on torch's autograd (their fused inference kernels have no adjoint yet).
+        Dropout(0.5) of fc1 is live, like in the reference."""
+        import torch.nn.functional as F
+        cfg, dev = self.cfg, self.device
+        _abi.require_gpu(dev, "RandLANet.forward (training)")
+        coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
+        pts = coords.to(dev, torch.float32).contiguous()
+        feat = inputs['features'].to(dev, torch.float32)
+        if 'neighbor_indices' in inputs and 'interp_idx' in inputs:
+            nbr = [t.to(dev).long() for t in inputs['neighbor_indices']]
+            itp = [t.to(dev).long() for t in inputs['interp_idx']]
+        else:
+            a, b = self.neighbor_pyramid(pts)
+            nbr, itp = [t.long() for t in a], [t.long() for t in b]
+        B = pts.shape[0]
+
+        def shared(m, x):           # SharedMLP.forward (randlanet.py:503-518) on [..., Cin] rows
+            w = m.conv.weight[:, :, 0, 0]
+            w = w.t() if isinstance(m.conv, nn.ConvTranspose2d) else w           # ConvTranspose2d stores [Cin, Cout]
+            y = F.linear(x, w, m.conv.bias)
+            if m.batch_norm is not None:
+                bn = m.batch_norm
+                shp = y.shape
+                y = F.batch_norm(y.reshape(-1, shp[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
+                                 bn.eps).reshape(shp)
+            return m.activation_fn(y) if m.activation_fn is not None else y
+
+        def gather(x, idx):         # x [B, N, C], idx [B, M, K] -> [B, M, K, C]
+            return x[torch.arange(B, device=dev)[:, None, None], idx]
+
+        def lse(m, xyz, f, idx, rel=None):      # LocalSpatialEncoding.forward (randlanet.py:557-605)
+            if rel is None:
+                nb = gather(xyz, idx)
+                ctr = xyz[:, :, None, :].expand_as(nb)
+                d = ctr - nb
+                rel = torch.cat([torch.sqrt((d * d).sum(-1, keepdim=True)), d, ctr, nb], -1)
+            enc = shared(m.mlp, rel)
+            return torch.cat([gather(f, idx), enc], -1), enc
+
+        def att(m, x):              # AttentivePooling.forward (randlanet.py:622-639): softmax over the K neighbours
+            scores = torch.softmax(m.score_fn[0](x), dim=-2)
+            return shared(m.mlp, (scores * x).sum(-2))
+
+        y = F.linear(feat, self.fc0.weight, self.fc0.bias)
+        y = F.leaky_relu(F.batch_norm(y.reshape(-1, y.shape[-1]), self.bn0.running_mean, self.bn0.running_var, self.bn0.weight,
+                                      self.bn0.bias, True, self.bn0.momentum, self.bn0.eps).reshape(y.shape), 0.2)
+        skips, n = [], pts.shape[1]
+        for i, blk in enumerate(self.encoder):
+            xyz = pts[:, :n]
+            f1 = shared(blk.mlp1, y)
+            x1, enc = lse(blk.lse1, xyz, f1, nbr[i])
+            p1 = att(blk.pool1, x1)
+            x2, _ = lse(blk.lse2, xyz, p1, nbr[i], rel=enc)
+            p2 = att(blk.pool2, x2)
+            e = F.leaky_relu(shared(blk.mlp2, p2) + shared(blk.shortcut, y), 0.01)
+            n_sub = n // cfg.sub_sampling_ratio[i]
+            sub = ops.GatherMaxFunction.apply(e, nbr[i][:, :n_sub].to(torch.int32))
+            if i == 0:
+                skips.append(e)
+            skips.append(sub)
+            y, n = sub, n_sub
+        y = shared(self.mlp, y)
+        for i in range(cfg.num_layers):
+            up = y[torch.arange(B, device=dev)[:, None], itp[-i - 1][:, :, 0]]             # nearest_interpolation
+            y = shared(self.decoder[i], torch.cat([skips[-i - 2], up], -1))
+        y = shared(self.fc1[0], y)
+        y = shared(self.fc1[1], y)
+        y = self.fc1[2](y)
+        return shared(self.fc1[3], y)
 
     # ---- the reference's data path around forward (randlanet.py:115-239, 382-465), on the GPU ops ------------------
     def preprocess(self, data, attr):

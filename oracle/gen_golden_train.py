@@ -66,5 +66,49 @@ def main():
     print("loss", loss.item(), "logits", logits.shape, "grads", len(keep), {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
 
 
+RANDLA_TRAIN_CFG = dict(num_neighbors=16, num_layers=3, num_points=1024, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
+                        dim_features=8, dim_output=[16, 32, 64], ignored_label_inds=[0], grid_size=0.06)
+
+
+def randla_train_inputs():
+    rng = np.random.default_rng(8)
+    pts = np.stack([synth_data.semantickitti_patch(70 + b, 1024) for b in range(2)])
+    feats = np.concatenate([pts, rng.random((2, 1024, 3), dtype=np.float32)], 2)
+    labels = rng.integers(0, 9, (2, 1024)).astype(np.int64)
+    return pts, feats, labels
+
+
+def randla_main():
+    """tests/golden/train_randlanet.npz: the same for the REAL reference RandLANet (train mode; fc1's Dropout switched to eval on
+    both sides: its mask is a device-specific random stream)."""
+    from oracle import ops as oops
+    from oracle import randlanet_ref as R
+    rl = importlib.import_module("ml3d.torch.models.randlanet")
+    sl = importlib.import_module("ml3d.torch.modules.losses.semseg_loss")
+    cfg = dict(RANDLA_TRAIN_CFG)
+    model = rl.RandLANet(**cfg)
+    model.load_state_dict(R.make_state_dict(cfg, 55))
+    model.device = torch.device("cpu")
+    model.train()
+    model.fc1[2].eval()
+    pts, feats, labels = randla_train_inputs()
+    inp = R.build_inputs(pts, feats, cfg, oops.knn_search)
+    logits = model(inp)
+    scores, lab = sl.filter_valid_label(logits, torch.from_numpy(labels), cfg["num_classes"], cfg["ignored_label_inds"], "cpu")
+    loss = torch.nn.CrossEntropyLoss()(scores, lab)
+    loss.backward()
+    named = dict(model.named_parameters())
+    keep = ["fc0.weight", "bn0.weight", "encoder.0.mlp1.conv.weight", "encoder.0.lse1.mlp.conv.weight", "encoder.0.pool1.score_fn.0.weight",
+            "encoder.1.pool2.mlp.conv.weight", "encoder.1.lse2.mlp.batch_norm.bias", "encoder.2.shortcut.conv.weight", "mlp.conv.weight",
+            "decoder.0.conv.weight", "decoder.2.conv.bias", "fc1.3.conv.weight"]
+    out = dict(logits=logits.detach().numpy(), loss=np.float64(loss.item()), n_valid=np.int64(len(lab)))
+    for k in keep:
+        out["grad:" + k] = named[k].grad.numpy()
+    out["running_mean:bn0"] = model.bn0.running_mean.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_randlanet.npz"), **out)
+    print("randla loss", loss.item(), "logits", logits.shape, {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
+
+
 if __name__ == "__main__":
     main()
+    randla_main()

@@ -76,3 +76,47 @@ def test_an_optimisation_step_lowers_the_loss_and_inference_sees_the_new_weights
     with torch.no_grad():
         after = m(batch)
     assert (after - before).abs().max() > 1e-3          # the fused inference kernels repacked the trained weights
+
+
+def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir):
+    """RandLANet in train mode (BatchNorm on batch statistics, random_sample through ops.GatherMaxFunction = HIP forward +
+    hand-written HIP backward, the HIP neighbour pyramid feeding the indices) against one forward + backward of the REAL
+    reference module (tests/golden/train_randlanet.npz)."""
+    from oracle import randlanet_ref as R
+    from oracle.gen_golden_train import RANDLA_TRAIN_CFG, randla_train_inputs
+    from ml3d.torch.models import RandLANet
+    g = np.load(os.path.join(golden_dir, "train_randlanet.npz"))
+    cfg = dict(RANDLA_TRAIN_CFG)
+    m = RandLANet(**cfg, device="cuda:0")
+    m.load_state_dict(R.make_state_dict(cfg, 55))
+    m.train()
+    m.fc1[2].eval()                       # (Dropout: a device-specific random stream; off on both sides)
+    pts, feats, labels = randla_train_inputs()
+    logits = m({"coords": [torch.from_numpy(pts).cuda()], "features": torch.from_numpy(feats).cuda()})
+    assert logits.requires_grad and np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= 1e-4
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    loss, lab, _ = m.get_loss(loss_obj, logits, {"data": {"labels": torch.from_numpy(labels)}}, "cuda:0")
+    assert int(lab.numel()) == int(g["n_valid"]) and abs(float(loss) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            want, got = g[key], named[key[5:]].grad.detach().cpu().numpy()
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= max(2e-6, 1e-3 * float(np.abs(want).max())), (key, float(np.abs(got - want).max()), float(np.abs(want).max()))
+            checked += 1
+    assert checked == 12
+    assert np.abs(m.bn0.running_mean.cpu().numpy() - g["running_mean:bn0"]).max() <= 1e-5
+    # and the op alone: the gradient of random_sample lands on the first maximal neighbour
+    from ml3d import ops
+    f = torch.randn((2, 64, 8), device="cuda", requires_grad=True)
+    idx = torch.randint(0, 64, (2, 16, 16), device="cuda", dtype=torch.int32)
+    out = ops.GatherMaxFunction.apply(f, idx)
+    ref = f[torch.arange(2, device="cuda")[:, None, None], idx.long()].max(2)[0]
+    assert torch.equal(out, ref)
+    gr = torch.randn_like(out)
+    out.backward(gr)
+    g1 = f.grad.clone(); f.grad = None
+    ref.backward(gr)
+    assert (g1 - f.grad).abs().max() <= 1e-6
