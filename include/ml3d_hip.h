@@ -485,7 +485,8 @@ int ml3d_patch_recenter(float* pts, int64_t k, int dims_mask, const float* extra
 
 /* ---- RandLA-Net random_sample as a differentiable op (training side, SURVEY.md §8 f4, ABI 5) ------------------ */
 /* ml3d_randla_gather_max: out[b, i, c] = max_k features[b, pool_idx[b, i, k], c], i < n_out (randlanet.py:300-327;   */
-/*   pool_idx = the first n_out rows of the level's [n_in, 16] neighbour matrix, batch-local indices).                  */
+/*   pool_idx = the level's WHOLE neighbour matrix [batch, n_in, 16] (batch-local indices): item b's pooling rows are  */
+/*   its first n_out, row stride n_in (randlanet.py:222-223).                                                          */
 /* ml3d_randla_gather_max_backward: grad_features [batch, n_in, c] (zeroed here) += grad_out at the FIRST maximal    */
 /*   neighbour of every (b, i, c), float atomics (loss.backward() of semantic_segmentation.py:423 through              */
 /*   ml3d.ops.GatherMaxFunction).                                                                                       */

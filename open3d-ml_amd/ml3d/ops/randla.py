@@ -81,34 +81,37 @@ def randla_forward(desc, params, features, points, neighbor_idx, interp_idx, out
 
 # ---- training side: random_sample as a differentiable op ------------------------------------------------------
 class GatherMaxFunction(torch.autograd.Function):
-    """``RandLANet.random_sample`` (randlanet.py:300-327): features [B, n_in, C] point-major, pool_idx int32 [B, n_out, 16] ->
+    """``RandLANet.random_sample`` (randlanet.py:300-327): features [B, n_in, C] point-major, ``neighbor_idx`` int32
+    [B, n_in, 16] (the level's neighbour matrix: the pooling rows are its first ``n_out``, randlanet.py:222-223) ->
     [B, n_out, C], the max over the 16 listed neighbours; HIP forward, hand-written HIP backward (the gradient goes to the
     first maximal neighbour, like ``torch.max``)."""
 
     @staticmethod
-    def forward(ctx, features, pool_idx):
+    def forward(ctx, features, neighbor_idx, n_out):
         lib = _abi.get()
-        _need_gpu(features, pool_idx)
+        _need_gpu(features, neighbor_idx)
         features = features.contiguous()
-        pool_idx = pool_idx.to(torch.int32).contiguous()
         B, n_in, c = features.shape
-        n_out = pool_idx.shape[1]
+        if neighbor_idx.dtype != torch.int32 or not neighbor_idx.is_contiguous() or tuple(neighbor_idx.shape) != (B, n_in, 16):
+            raise RuntimeError("GatherMaxFunction: neighbor_idx must be a contiguous int32 [B, n_in, 16] tensor")
+        n_out = int(n_out)
         out = torch.empty((B, n_out, c), dtype=torch.float32, device=features.device)
         with torch.cuda.device(features.device):
-            rc = lib.ml3d_randla_gather_max(features.data_ptr(), pool_idx.data_ptr(), B, n_in, n_out, c, out.data_ptr(), _stream())
+            rc = lib.ml3d_randla_gather_max(features.data_ptr(), neighbor_idx.data_ptr(), B, n_in, n_out, c, out.data_ptr(), _stream())
         _abi.check(rc, "ml3d_randla_gather_max")
-        ctx.save_for_backward(features, pool_idx)
+        ctx.save_for_backward(features, neighbor_idx)
+        ctx.n_out = n_out
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _abi.get()
-        features, pool_idx = ctx.saved_tensors
+        features, neighbor_idx = ctx.saved_tensors
         B, n_in, c = features.shape
         g = g.contiguous()
         gf = torch.empty_like(features)
         with torch.cuda.device(features.device):
-            rc = lib.ml3d_randla_gather_max_backward(features.data_ptr(), pool_idx.data_ptr(), g.data_ptr(), B, n_in, pool_idx.shape[1],
+            rc = lib.ml3d_randla_gather_max_backward(features.data_ptr(), neighbor_idx.data_ptr(), g.data_ptr(), B, n_in, ctx.n_out,
                                                      c, gf.data_ptr(), _stream())
         _abi.check(rc, "ml3d_randla_gather_max_backward")
-        return gf, None
+        return gf, None, None

@@ -222,7 +222,7 @@ class RandLANet(nn.Module):
             p2 = att(blk.pool2, x2)
             e = F.leaky_relu(shared(blk.mlp2, p2) + shared(blk.shortcut, y), 0.01)
             n_sub = n // cfg.sub_sampling_ratio[i]
-            sub = ops.GatherMaxFunction.apply(e, nbr[i][:, :n_sub].to(torch.int32))
+            sub = ops.GatherMaxFunction.apply(e, nbr[i].to(torch.int32).contiguous(), n_sub)
             if i == 0:
                 skips.append(e)
             skips.append(sub)

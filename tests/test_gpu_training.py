@@ -20,6 +20,7 @@ def _setup():
     cfg = dict(TRAIN_CFG)
     m = KPFCNN(**cfg, device="cuda:0")
     m.load_state_dict(K.make_state_dict(cfg, 77))
+    m.to("cuda:0")                       # (the pipeline's model.to(device), semantic_segmentation.py:333: trainable parameters on the GPU)
     spheres, cols, labels = train_inputs()
     pts, columns = np.concatenate(spheres), np.concatenate(cols)
     np.random.seed(31)
@@ -89,6 +90,7 @@ def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir
     cfg = dict(RANDLA_TRAIN_CFG)
     m = RandLANet(**cfg, device="cuda:0")
     m.load_state_dict(R.make_state_dict(cfg, 55))
+    m.to("cuda:0")
     m.train()
     m.fc1[2].eval()                       # (Dropout: a device-specific random stream; off on both sides)
     pts, feats, labels = randla_train_inputs()
@@ -111,9 +113,9 @@ def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir
     # and the op alone: the gradient of random_sample lands on the first maximal neighbour
     from ml3d import ops
     f = torch.randn((2, 64, 8), device="cuda", requires_grad=True)
-    idx = torch.randint(0, 64, (2, 16, 16), device="cuda", dtype=torch.int32)
-    out = ops.GatherMaxFunction.apply(f, idx)
-    ref = f[torch.arange(2, device="cuda")[:, None, None], idx.long()].max(2)[0]
+    idx = torch.randint(0, 64, (2, 64, 16), device="cuda", dtype=torch.int32)
+    out = ops.GatherMaxFunction.apply(f, idx, 16)
+    ref = f[torch.arange(2, device="cuda")[:, None, None], idx[:, :16].long()].max(2)[0]
     assert torch.equal(out, ref)
     gr = torch.randn_like(out)
     out.backward(gr)
