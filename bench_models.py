@@ -244,6 +244,15 @@ def run_pointpillars(args, rank, world, dev, dist):
             torch.cuda.synchronize()
         t2.restore()
         alone[tag] = t2.mean_ms()
+    # one sweep at a time, synchronised per sweep: what a detection request sees (upload + voxelize + forward + decode + NMS + D2H)
+    lat = []
+    for i in range(24):
+        t0 = time.perf_counter()
+        boxes = m.bbox_head.get_bboxes(*m([hosts[i % B].to(dev, non_blocking=True)]))
+        _ = [t.cpu() for t in boxes[0]]
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = lat[4:]
     if rank != 0:
         return None
     (x, w, *_), y = shapes
@@ -263,6 +272,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                       "h2d_in_timed_region": True, "decode_nms_in_timed_region": True, "d2h_of_detections_in_timed_region": True,
                       "boxes_last_step": n_boxes[0], "streams": 2 * lanes if overlap else 1, "lanes": lanes if overlap else 1,
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
+           "latency_single_sweep_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "sweeps": len(lat)},
            "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
@@ -370,6 +380,15 @@ def run_kpconv(args, rank, world, dev, dist):
         m(KPConvBatch(pts, lens, cfg, device=dev))
         torch.cuda.synchronize()
     t2.restore()
+    # one sphere at a time, synchronised per sphere: upload + batch build (9 read-backs) + forward + arg-max back on the host
+    lat = []
+    for i in range(24):
+        sp = torch.from_numpy(spheres[i % B]).pin_memory()
+        t0 = time.perf_counter()
+        lab = torch.argmax(m(KPConvBatch(sp.to(dev, non_blocking=True), [len(sp)], cfg, device=dev)), 1).to(torch.uint8).cpu()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = lat[4:]
     if rank != 0:
         return None
     (q, s, inds, x, kp, w, *_), y = shapes
@@ -391,6 +410,7 @@ def run_kpconv(args, rank, world, dev, dist):
                                   "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, " (build of step i+1 overlapped with the forward of step i on two HIP streams)" if overlap else ""),
                       "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
                       "parallelism": "frame-parallel x%d" % world},
+           "latency_single_sphere_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "spheres": len(lat)},
            "roofline": {"bound": "mfma", "kernel": "kp_agg_mfma<2> + gemm_tile (KPConv %d->%d, %d queries x %d neighbour columns)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,

@@ -270,8 +270,9 @@ struct KnnJobs {
 };
 
 #ifndef KNN_WAVES
-#define KNN_WAVES 6        // register budget 512 / 6 = 85: six waves per SIMD -- 1.68 ms against 1.76 ms at the compiler's own 96
-#endif                    // (five waves), two runs each; 4: 1.83, 8 (spills): 2.08 (profiles/r02_knn_tile_experiment.md)
+#define KNN_WAVES 5        // register budget 512 / 5 = 96.  Round 2 ran six waves per SIMD (80 registers: 1.68 against 1.76 ms); with the
+#endif                    // shell walk of round 4 six waves spill 19 registers to scratch (+70 % FETCH_SIZE, +40 % WRITE_SIZE:
+                          // profiles/r04_pmc_fetch.csv) for no gain: 1.42 ms / 5992 frames/s at six, 1.38 ms / 6041 at five (gpurun r4j)
 template <int K, bool SUB>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0

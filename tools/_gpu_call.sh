@@ -1,6 +1,13 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r4h
-timeout 900 python -m pytest tests/test_gpu_training.py -q > gpurun_out/r4h/train.log 2>&1; tail -8 gpurun_out/r4h/train.log
-grep -n "Fatal\|fault\|Error\|error\|File \"/.*repo" gpurun_out/r4h/train.log | head -30
+LIB=open3d-ml_amd/ml3d/lib
+cp $LIB/libml3d_hip.so /tmp/base.so
+for v in base knn_w5 knn_np knn_w5np; do
+  if [ $v = base ]; then cp /tmp/base.so $LIB/libml3d_hip.so; else cp $LIB/ab/$v.so $LIB/libml3d_hip.so; fi
+  echo "== $v: $(python tools/knn_only.py 7 2>&1 | tail -1)"
+  echo "   bench: $(python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-workloads 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('%.0f frames/s step %.2f ms' % (d['value'], d['ms_per_step']))")"
+done
+cp /tmp/base.so $LIB/libml3d_hip.so
