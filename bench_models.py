@@ -411,7 +411,7 @@ def run_kpconv(args, rank, world, dev, dist):
                       "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
                       "parallelism": "frame-parallel x%d" % world},
            "latency_single_sphere_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "spheres": len(lat)},
-           "roofline": {"bound": "mfma", "kernel": "kp_agg_mfma<2> + gemm_tile (KPConv %d->%d, %d queries x %d neighbour columns)" % (cin, cout, nq, H),
+           "roofline": {"bound": "mfma", "kernel": "kp_agg_gemm32 (KPConv %d->%d, %d queries x %d neighbour columns: MFMA aggregation + the [480 x 32] product in one kernel)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "frac_reference_formulation": flops_dense / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,

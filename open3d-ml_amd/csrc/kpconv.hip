@@ -25,6 +25,7 @@
 
 #include "gemm.h"
 #include "grid.h"
+#include <gfx950_ops.h>
 #include "ml3d_hip.h"
 
 namespace ml3d {
@@ -189,20 +190,19 @@ __device__ __forceinline__ float kp_influence1(float dx, float dy, float dz, con
 }
 
 template <int NT>
-struct KpRow {                       // one neighbour as lane (k, j) sees it: position + its NT channels
-    float sx, sy, sz;
+struct KpRow {                       // one neighbour as lane (k, j) sees it: its influence on kernel point k + its NT channels
+    float w;                         // (PSH = false: w, wy, wz hold the neighbour's position until it is consumed)
+    float wy, wz;
     float xv[NT];
-    int idx;
+    bool real;
 };
 
 template <int NT>
 __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int idx, int k) {
-    // UNCONDITIONAL loads (a shadow lane reads row 0 and is zeroed when consumed): loads inside an `if (idx >= 0)` leave the
+    // UNCONDITIONAL load (a shadow lane reads row 0 and is zeroed when consumed): loads inside an `if (idx >= 0)` leave the
     // number of outstanding requests unknown, and the compiler then waits for ALL of them before the previous group's use
-    r.idx = idx;
+    r.real = idx >= 0;
     const int64_t i = idx < 0 ? 0 : idx;
-    const float* sp = A.s_pts + 3 * i;
-    r.sx = sp[0]; r.sy = sp[1]; r.sz = sp[2];
     const float* xr = A.x + i * A.c_total + A.c_off + k * NT;
     if constexpr (NT == 1) r.xv[0] = xr[0];
     else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(xr); r.xv[0] = v.x; r.xv[1] = v.y; }
@@ -211,6 +211,114 @@ __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int i
         for (int t = 0; t < NT / 4; ++t) {
             const float4 v = reinterpret_cast<const float4*>(xr)[t];
             r.xv[4 * t] = v.x; r.xv[4 * t + 1] = v.y; r.xv[4 * t + 2] = v.z; r.xv[4 * t + 3] = v.w;
+        }
+    }
+}
+
+// one query's weighted sum on the matrix unit: lane (k = lane & 15, j = lane >> 4) ends with acc[n][r] = wf[kernel point 4 j + r]
+// [channel k NT + n].  `ia`, `ib`: the lane's column of the query's index row (columns lane and 64 + lane, -1 past the row),
+// requested by the caller one query ahead.
+template <int NT, int MODE, bool DEF, bool PSH>
+__device__ __forceinline__ void kp_agg_query(const KpArgs& A, int64_t q, int lane, int ia, int ib, float qx, float qy, float qz,
+                                             float kx, float ky, float kz, bool kreal,
+                                             float __attribute__((ext_vector_type(4))) (&acc)[NT]) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int k = lane & 15, j = lane >> 4;
+    const int32_t* row_cur = A.inds + q * A.h;
+    // DEF: this query's kernel points = the layer's + its offsets (lane k owns point k; the 16 lanes j of a point agree)
+    float kxq = kx, kyq = ky, kzq = kz, modq = 1.0f;
+    if constexpr (DEF) {
+        if (kreal) {
+            const float* o = A.off + q * (int64_t)A.off_dim;
+            kxq = fmaf(o[3 * k], A.extent, kx); kyq = fmaf(o[3 * k + 1], A.extent, ky); kzq = fmaf(o[3 * k + 2], A.extent, kz);
+            if (A.off_dim > 3 * KP_K) modq = 2.0f / (1.0f + expf(-o[3 * KP_K + k]));      // 2 sigmoid (kpconv.py:1023-1024)
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // rows wider than 128 columns (the deformable layers search with deform_radius) are walked 128 columns at a time; the
+    // first block's indices were requested under the previous query, later blocks are read here
+    for (int cb = 0; cb < A.h; cb += 128) {
+        if (cb > 0) {
+            ia = cb + lane < A.h ? row_cur[cb + lane] : -1;
+            ib = cb + 64 + lane < A.h ? row_cur[cb + 64 + lane] : -1;
+        }
+        if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
+        if (ib < 0 || ib >= A.ns) ib = -1;
+        const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
+        const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
+        const int groups = (count + 3) >> 2;
+        // PSH: the neighbours' positions relative to the query are loaded ONE column per lane (6 independent loads per 128
+        // columns) and the 16 lanes that weigh a neighbour fetch them with cross-lane reads.  !PSH: every lane loads its
+        // group's neighbour itself -- three more dependent loads per group (16 lanes reading the same 12 bytes), no LDS-pipe
+        // traffic.  Measured: the fused 32 -> 32 kernel (4 waves per SIMD to hide latency with) 1.00 -> 0.90 ms with PSH; the
+        // KPConv step with PSH in the stand-alone aggregations too (6-8 waves per SIMD) 9.17 against 8.65 ms.
+        float nxa = 0.f, nya = 0.f, nza = 0.f, nxb = 0.f, nyb = 0.f, nzb = 0.f;
+        if constexpr (PSH) {
+            const float* pa = A.s_pts + 3 * (int64_t)(ia < 0 ? 0 : ia);
+            const float* pb = A.s_pts + 3 * (int64_t)(ib < 0 ? 0 : ib);
+            nxa = pa[0] - qx; nya = pa[1] - qy; nza = pa[2] - qz;
+            nxb = pb[0] - qx; nyb = pb[1] - qy; nzb = pb[2] - qz;
+        }
+        // this lane's neighbour of group g (wave-uniform choice of the register: g is uniform); idx -1 past the last group
+        auto fetch = [&](KpRow<NT>& r, int g) {
+            const int c = 4 * g + j;
+            const bool lo = c < 64;
+            const int v = __shfl(lo ? ia : ib, c & 63);
+            const int idx = g < groups ? v : -1;
+            if constexpr (PSH) {
+                const float nx = __shfl(lo ? nxa : nxb, c & 63), ny = __shfl(lo ? nya : nyb, c & 63),
+                            nz = __shfl(lo ? nza : nzb, c & 63);
+                kp_row_load<NT>(r, A, idx, k);
+                const float w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
+                r.w = (kreal && idx >= 0) ? w : 0.f;
+            } else {
+                const float* sp = A.s_pts + 3 * (int64_t)(idx < 0 ? 0 : idx);
+                r.w = sp[0]; r.wy = sp[1]; r.wz = sp[2];
+                kp_row_load<NT>(r, A, idx, k);
+            }
+        };
+        auto consume = [&](const KpRow<NT>& r) {
+            float w = r.w;
+            if constexpr (!PSH) {
+                const float nx = r.w - qx, ny = r.wy - qy, nz = r.wz - qz;
+                w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
+                w = (kreal && r.real) ? w : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, r.real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
+        };
+        // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is
+        // consumed (a rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
+        // (a third row buffer -- two groups in flight -- measured slower in the fused kernel: 0.94 against 0.89 ms)
+        KpRow<NT> ra, rb;
+        fetch(ra, 0);
+        for (int g = 0; g < groups; g += 2) {
+            // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for both before the first
+            //  MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the younger is in
+            //  flight)
+            fetch(rb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(ra, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(rb);              // (unconditional: past the last group the index is -1, a zero MFMA -- under an `if`
+                                      //  the compiler sinks rb's loads into the branch, right in front of their use)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (DEF) {
+        // modulations scale kernel point kk's row of the weighted features (kpconv.py:1147-1149); this lane holds rows
+        // 4 j .. 4 j + 3, lane kk holds modulation kk
+        if (A.off_dim > 3 * KP_K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = __shfl(modq, 4 * j + r);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n][r] *= m;
+            }
         }
     }
 }
@@ -246,80 +354,11 @@ __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
     for (; t < per_xcd; t += stride) {
         const int64_t q = qbase + t;
         if (q >= A.nq) break;
-        int ia = lane < A.h ? ia_n : -1, ib = 64 + lane < A.h ? ib_n : -1;
+        const int ia = lane < A.h ? ia_n : -1, ib = 64 + lane < A.h ? ib_n : -1;
         const float qx = qx_n, qy = qy_n, qz = qz_n;
-        const int32_t* row_cur = A.inds + q * A.h;
         request(t + stride);
-        // DEF: this query's kernel points = the layer's + its offsets (lane k owns point k; the 16 lanes j of a point agree)
-        float kxq = kx, kyq = ky, kzq = kz, modq = 1.0f;
-        if constexpr (DEF) {
-            if (kreal) {
-                const float* o = A.off + q * (int64_t)A.off_dim;
-                kxq = fmaf(o[3 * k], A.extent, kx); kyq = fmaf(o[3 * k + 1], A.extent, ky); kzq = fmaf(o[3 * k + 2], A.extent, kz);
-                if (A.off_dim > 3 * KP_K) modq = 2.0f / (1.0f + expf(-o[3 * KP_K + k]));      // 2 sigmoid (kpconv.py:1023-1024)
-            }
-        }
         f32x4 acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // rows wider than 128 columns (the deformable layers search with deform_radius) are walked 128 columns at a time; the
-        // first block's indices were requested under the previous query, later blocks are read here
-        for (int cb = 0; cb < A.h; cb += 128) {
-            if (cb > 0) {
-                ia = cb + lane < A.h ? row_cur[cb + lane] : -1;
-                ib = cb + 64 + lane < A.h ? row_cur[cb + 64 + lane] : -1;
-            }
-            if (ia < 0 || ia >= A.ns) ia = -1;                           // shadow neighbour (kpconv.py:1048-1051)
-            if (ib < 0 || ib >= A.ns) ib = -1;
-            const unsigned long long ma = __ballot(ia >= 0), mb = __ballot(ib >= 0);
-            const int count = mb ? 128 - __builtin_clzll(mb) : (ma ? 64 - __builtin_clzll(ma) : 0);   // last real column + 1
-            const int groups = (count + 3) >> 2;
-            // this lane's column of group g (wave-uniform choice of the index register: g is uniform); -1 past the last group
-            auto column = [&](int g) -> int {
-                const int c = 4 * g + j;
-                const int v = __shfl(c < 64 ? ia : ib, c & 63);
-                return g < groups ? v : -1;
-            };
-            auto consume = [&](const KpRow<NT>& r) {
-                const float nx = r.sx - qx, ny = r.sy - qy, nz = r.sz - qz;
-                float w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
-                const bool real = r.idx >= 0;
-                w = (kreal && real) ? w : 0.f;
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
-            };
-            // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is
-            // consumed (a rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
-            KpRow<NT> ra, rb;
-            kp_row_load<NT>(ra, A, column(0), k);
-            for (int g = 0; g < groups; g += 2) {
-                // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for all four before the
-                //  first MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the
-                //  younger is in flight)
-                kp_row_load<NT>(rb, A, column(g + 1), k);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(ra);
-                __builtin_amdgcn_sched_barrier(0);
-                kp_row_load<NT>(ra, A, column(g + 2), k);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(rb);              // (unconditional: past the last group the column is -1, a zero MFMA -- under an `if`
-                                          //  the compiler sinks rb's loads into the branch, right in front of their use)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr (DEF) {
-            // modulations scale kernel point kk's row of the weighted features (kpconv.py:1147-1149); this lane stores rows
-            // 4 j .. 4 j + 3, lane kk holds modulation kk
-            if (A.off_dim > 3 * KP_K) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m = __shfl(modq, 4 * j + r);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[n][r] *= m;
-                }
-            }
-        }
+        kp_agg_query<NT, MODE, DEF, false>(A, q, lane, ia, ib, qx, qy, qz, kx, ky, kz, kreal, acc);
         // D: lane (column k, j) holds kernel points 4 j .. 4 j + 3 of channels k NT .. k NT + NT - 1
         float* o = A.wf + q * (int64_t)(KP_K * A.c_total) + A.c_off + k * NT;
 #pragma unroll
@@ -337,6 +376,134 @@ __global__ void __launch_bounds__(256) kp_agg_mfma(KpArgs A) {
                 }
             }
         }
+    }
+}
+
+// the [15 * Cin] x [Cout] product that follows the aggregation, for the kernels that carry it themselves
+struct KpOut {
+    const float* weights;         // [15 * cin][cout]
+    const float* bias;            // [cout] or null
+    int act; float slope; int cout;
+    float* out;                   // [nq, cout]
+};
+
+// ---- the Cin = 32 -> Cout = 32 block in ONE kernel (the KPConv of the full-resolution resnet bottlenecks of every reference
+// config: 640 000 queries per 64-sphere step) -- north_star's "LDS-tiled gather-GEMM", built on the MFMA aggregation.
+// The two-kernel form writes wf [Nq, 480] to HBM and reads it back in the GEMM: 2 x 1.23 GB per launch, ~9x the op's algorithmic
+// bytes (profiles/r04_pmc_kp_*.csv).  Here a workgroup of four waves owns a tile of 16 queries: every wave aggregates four of
+// them with kp_agg_query and parks its D registers -- which ARE wf -- in an LDS tile [16][480] (pitch 516: conflict-free 8-byte
+// reads); after one LDS barrier the tile is the A operand of `tile x W`: wave w multiplies K slice [120 w, 120 w + 120) against
+// ITS rows of the kernel weights, 60 values per lane that live in registers for the whole (persistent) kernel; the four partial
+// [16 x 32] blocks cross LDS (in the tile's own memory), are summed with bias + activation and leave as 128-byte rows.
+// Round 3's kp_fused32 had the same second half on a packed-FMA aggregation (168 registers, 50 KB of LDS: 3 waves per SIMD,
+// slower than two kernels); the MFMA aggregation needs a third of the registers.
+constexpr int KF_TQ = 16;                 // queries per tile
+constexpr int KF_PITCH = 516;             // floats per tile row: 516 = 8 * 64 + 4 -> rows land 4 banks apart
+
+template <int MODE>
+__global__ void __launch_bounds__(256) ML3D_WAVES_PER_SIMD(4) kp_agg_gemm32(KpArgs A, KpOut O) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile[KF_TQ * KF_PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane & 15, j = lane >> 4;
+    const bool kreal = k < KP_K;
+    const float kx = kreal ? A.kp[3 * k] : 0.f, ky = kreal ? A.kp[3 * k + 1] : 0.f, kz = kreal ? A.kp[3 * k + 2] : 0.f;
+    // this lane's share of the kernel weights: B operand of step s, column tile t = W[120 wave + 30 j + s][16 t + k]
+    // (K index 120 wave + 30 j + s: lane (i, j) of the A operand reads 30 CONSECUTIVE tile floats -- any bijection of the K
+    //  indices onto (step, j) sums the same products)
+    float wb[2][30];
+#pragma unroll
+    for (int s = 0; s < 30; ++s) {
+        const float* wr = O.weights + (int64_t)(120 * wave + 30 * j + s) * 32 + k;
+        wb[0][s] = wr[0];
+        wb[1][s] = wr[16];
+    }
+    const int64_t tiles = (A.nq + KF_TQ - 1) / KF_TQ;
+    const int64_t per_xcd = (tiles + 7) / 8;
+    const int64_t tbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t stride = (int64_t)(gridDim.x >> 3);
+    int ia_n, ib_n;
+    float qx_n, qy_n, qz_n;
+    auto request = [&](int64_t q) {
+        const int64_t qc = q < A.nq ? q : 0;
+        const int32_t* row = A.inds + qc * A.h;
+        ia_n = row[lane < A.h ? lane : A.h - 1];
+        ib_n = row[64 + lane < A.h ? 64 + lane : A.h - 1];
+        const float* qp = A.q_pts + 3 * qc;
+        qx_n = qp[0]; qy_n = qp[1]; qz_n = qp[2];
+    };
+    int64_t tt = (int64_t)(blockIdx.x >> 3);
+    if (tt < per_xcd && tbase + tt < tiles) request((tbase + tt) * KF_TQ + 4 * wave);
+    for (; tt < per_xcd && tbase + tt < tiles; tt += stride) {
+        const int64_t q0 = (tbase + tt) * KF_TQ;
+        // ---- aggregate: wave w fills rows 4 w .. 4 w + 3 of the tile
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = q0 + 4 * wave + u;
+            const int ia = lane < A.h ? ia_n : -1, ib = 64 + lane < A.h ? ib_n : -1;
+            const float qx = qx_n, qy = qy_n, qz = qz_n;
+            // the next query of this wave: in this tile, or the first one of its next tile
+            const int64_t qn = u < 3 ? q + 1 : (tbase + tt + stride) * KF_TQ + 4 * wave;
+            request((u < 3 || (tt + stride < per_xcd && tbase + tt + stride < tiles)) ? qn : 0);
+            f32x4 acc[2];
+            if (q < A.nq) kp_agg_query<2, MODE, false, true>(A, q, lane, ia, ib, qx, qy, qz, kx, ky, kz, kreal, acc);
+            else { acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; }
+            float* trow = tile + (4 * wave + u) * KF_PITCH + 2 * k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 4 * j + r;
+                if (kk < KP_K) *reinterpret_cast<float2*>(trow + kk * 32) = make_float2(acc[0][r], acc[1][r]);
+            }
+        }
+        block_sync_lds();
+        // ---- multiply: [16 x 120] slice of the tile x this wave's [120 x 32] rows of W
+        f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        {
+            const float* arow = tile + k * KF_PITCH + 120 * wave + 30 * j;          // A operand: lane (i = k, j)
+            // (read in chunks of 10: all 30 A values at once, on top of the 60 weights, spill)
+#pragma unroll
+            for (int s0 = 0; s0 < 30; s0 += 10) {
+                float av[10];
+#pragma unroll
+                for (int s = 0; s < 10; s += 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(arow + s0 + s);
+                    av[s] = v.x; av[s + 1] = v.y;
+                }
+#pragma unroll
+                for (int s = 0; s < 10; ++s) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wb[0][s0 + s], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wb[1][s0 + s], c1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        block_sync_lds();               // every wave has read the tile: its memory takes the four partial blocks
+        {
+            // D: lane (col k, j) holds rows 4 j .. 4 j + 3 -> part[wave][row][col], pitch 36
+            float* part = tile + wave * (KF_TQ * 36);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part[(4 * j + r) * 36 + k] = c0[r];
+                part[(4 * j + r) * 36 + 16 + k] = c1[r];
+            }
+        }
+        block_sync_lds();
+        {
+            // 512 outputs, two per thread: (row = tid / 16, cols 2 (tid % 16), + 1)
+            const int row = threadIdx.x >> 4, col = 2 * (threadIdx.x & 15);
+            float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const float2 p = *reinterpret_cast<const float2*>(tile + w4 * (KF_TQ * 36) + row * 36 + col);
+                v.x += p.x; v.y += p.y;
+            }
+            if (O.bias) { v.x += O.bias[col]; v.y += O.bias[col + 1]; }
+            if (O.act == 1) { v.x = v.x > 0.f ? v.x : v.x * O.slope; v.y = v.y > 0.f ? v.y : v.y * O.slope; }
+            else if (O.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+            const int64_t q = q0 + row;
+            if (q < A.nq) *reinterpret_cast<float2*>(O.out + q * 32 + col) = v;
+        }
+        block_sync_lds();               // the partial blocks are consumed before the next tile's rows are written
     }
 }
 
@@ -388,13 +555,6 @@ __global__ void __launch_bounds__(256) kp_weighted_small(KpArgs A) {
 // the output channels) -- for the [15 * Cin] x [Cout] product against the LDS-resident kernel weights, bias (folded BN) and
 // activation included.
 // ------------------------------------------------------------------------------------------------------------------
-struct KpOut {
-    const float* weights;         // [15 * cin][cout]
-    const float* bias;            // [cout] or null
-    int act; float slope; int cout;
-    float* out;                   // [nq, cout]
-};
-
 template <int CIN, int NV>       // NV = cout / 32 float4 column groups per lane
 __global__ void __launch_bounds__(256) kp_small_fused(KpArgs A, KpOut O) {
     constexpr int KC = KP_K * CIN;                    // rows of the weight matrix
@@ -521,9 +681,20 @@ static bool small_fused_ok(const KpArgs& a, const KpOut& o) {
            ((((uintptr_t)o.weights) | ((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 15) == 0;
 }
 
-// (A one-kernel Cin = 32 -> Cout = 32 block -- a persistent workgroup aggregating 16 queries into an LDS tile and multiplying it
-//  with register-resident kernel weights -- was built in round 3, parity-green and SLOWER than the two kernels: 1.69 against
-//  1.45 ms, 168 registers + 50 KB of LDS = 3 waves per SIMD; removed in round 4)
+// the one-kernel block takes cin = cout = 32, rigid, 16-byte aligned features and 8-byte aligned outputs
+static bool agg_gemm32_ok(const KpArgs& a, const KpOut& o) {
+    return a.cin == 32 && o.cout == 32 && !a.off && a.h > 0 && a.ns > 0 && a.nq > 0 &&
+           ((((uintptr_t)a.x) & 15) | (((uintptr_t)o.out) & 7)) == 0;
+}
+
+static void launch_agg_gemm32(const KpArgs& a, const KpOut& o, hipStream_t st) {
+    const int64_t tiles = (a.nq + KF_TQ - 1) / KF_TQ;
+    int64_t nb = (tiles + 7) / 8 * 8;
+    if (nb > 256 * 4) nb = 256 * 4;                               // persistent: 33 KB of LDS -> 4 workgroups per CU
+    if (a.influence == 0) hipLaunchKernelGGL((kp_agg_gemm32<0>), dim3((unsigned)nb), dim3(256), 0, st, a, o);
+    else if (a.influence == 1) hipLaunchKernelGGL((kp_agg_gemm32<1>), dim3((unsigned)nb), dim3(256), 0, st, a, o);
+    else hipLaunchKernelGGL((kp_agg_gemm32<2>), dim3((unsigned)nb), dim3(256), 0, st, a, o);
+}
 
 // max over the listed neighbours (shadow rows are zeros) / feature of the first listed neighbour
 __global__ void gather_pool_k(const float* __restrict__ x, int64_t ns, int c, const int32_t* __restrict__ inds,
@@ -704,6 +875,10 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
             case 4: launch_small_fused<4>(a, ko, st); break;
             default: launch_small_fused<5>(a, ko, st); break;
         }
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
+    if (max_neighbors > 0 && agg_gemm32_ok(a, ko)) {
+        launch_agg_gemm32(a, ko, st);
         return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
     }
     int rc = launch_weighted(a, st);

@@ -22,7 +22,7 @@ def table(path):
 
 OPS = {   # bench_models.py's roofline key -> (kernel-name substrings that make up the op, units per launch); tables from
           # `rocprofv3 --pmc ... -- python tools/roofline_ops.py kp|pp` (only that op runs there)
-    "kpconv_block_32_32": (("kp_agg_mfma", "kp_weighted", "gemm_tile", "splitk", "reduce"), 64),
+    "kpconv_block_32_32": (("kp_agg_gemm32",), 64),
     "pp_conv3x3_64": (("gemm_tile",), 16),
 }
 

@@ -1,7 +1,7 @@
 """GPU box: run ONLY the op that `workloads.*.roofline` of the bench line prices, a few times, so that a rocprofv3 --pmc pass
 attributes HBM traffic to it alone.  usage: python tools/roofline_ops.py kp|pp [reps]
-  kp  the first resnet block's KPConv of the 64-sphere Toronto3D batch (32 -> 32 channels, 640 000 queries): kp_agg_mfma +
-      gemm_tile (+ split-K reduce), the op bench_models.run_kpconv times as `kpconv_rigid` call #1
+  kp  the first resnet block's KPConv of the 64-sphere Toronto3D batch (32 -> 32 channels, 640 000 queries): kp_agg_gemm32
+      (aggregation + product in one kernel), the op bench_models.run_kpconv times as `kpconv_rigid` call #1
   pp  SECOND's second convolution of 16 KITTI sweeps (3x3, 64 -> 64, stride 1, 248 x 216): bench_models.run_pointpillars's
       `conv2d_nhwc` call #1"""
 import os
