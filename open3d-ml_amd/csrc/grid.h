@@ -114,6 +114,22 @@ __device__ __forceinline__ void wave_lds_sync() {
 // On gfx950 every VALU instruction is issue time the f32 MFMAs cannot use, so the hot epilogues use this.
 __device__ __forceinline__ float fmax_raw(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 
+// inclusive scan / sum across the 64 lanes of a wave
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full workgroup fence: it drains vmcnt too,
 // i.e. every wave sits at the barrier until its outstanding global loads have landed and its global stores are
 // acknowledged.  Kernels whose cross-wave communication is all in LDS use this one instead, so prefetches and

@@ -431,20 +431,6 @@ __global__ void grid_hist(const float* __restrict__ pts, Segs S, int64_t n_total
 // (the first version walked them 256 at a time: 0.56 ms of a single CU).
 constexpr int SCAN_TILE = 4096;
 
-__device__ __forceinline__ int wave_inclusive_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 __global__ void __launch_bounds__(256) scan_block_sums(const int* __restrict__ a, int64_t n, int* block_sums) {
     __shared__ int ws[4];

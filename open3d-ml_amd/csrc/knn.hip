@@ -292,6 +292,9 @@ knn_query_multi(KnnJobs J, int k, int index_local, int vec_store) {
 // as its wave retires instead of when four have (1.65 against 1.71 ms per 64-frame launch, +0.5-1 % frames/s: gpurun r4e).
 static int knn_block() { return 64; }
 
+// (16 or 32 queries per wave for launches that cannot fill the chip's wave slots -- the five levels of ONE frame are 940 full
+//  waves on 5120 slots -- measured: 0.363 -> 0.342 ms at batch 1, i.e. a launch that small is not bound by what shares a wave
+//  (the suspect: its slowest single query, an outlier walking hundreds of near-empty rows, two dependent loads each).  Removed.)
 template <bool SUB>
 static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
     const int T = knn_block();

@@ -82,6 +82,39 @@ struct LinArgs {
     float slope;
 };
 
+// fc0 (+ folded bn0 + lrelu 0.2) and the first encoder layer's mlp1 (8 -> 8, lrelu 0.2) in one pass over the input rows
+// (randlanet.py:266-271, 680): one thread per point, both weight sets in scalar registers (`__restrict__`: scalar loads), 12-36
+// bytes in and two 32-byte rows out.  As two launches -- the generic linear_act, 4 rows x 1 column per thread, then an 8 -> 8
+// chain -- this was 0.12 + 0.04 ms per 64-frame step for 0.22 GB of traffic.
+__global__ void __launch_bounds__(256)
+head_fc0_mlp1(const float* __restrict__ x, int c0, const float* __restrict__ w0, const float* __restrict__ b0,
+              const float* __restrict__ w1, const float* __restrict__ b1, int64_t m, float* __restrict__ feat,
+              float* __restrict__ f1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float f[8], g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = b0[c];
+    const float* xr = x + i * c0;
+    for (int j = 0; j < c0; ++j) {
+        const float v = xr[j];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = fmaf(v, w0[j * 8 + c], f[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { f[c] = lrelu(f[c], 0.2f); g[c] = b1[c]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[c] = fmaf(f[j], w1[j * 8 + c], g[c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[c] = lrelu(g[c], 0.2f);
+    float4* fo = reinterpret_cast<float4*>(feat + i * 8);
+    float4* go = reinterpret_cast<float4*>(f1 + i * 8);
+    fo[0] = make_float4(f[0], f[1], f[2], f[3]); fo[1] = make_float4(f[4], f[5], f[6], f[7]);
+    go[0] = make_float4(g[0], g[1], g[2], g[3]); go[1] = make_float4(g[4], g[5], g[6], g[7]);
+}
+
 constexpr int LIN_RM = 4;  // rows per thread
 
 __global__ void __launch_bounds__(256) linear_act(LinArgs A) {
@@ -1107,18 +1140,51 @@ constexpr int A16_XP = 20;           // X row pitch
 // (the lse weights arrive as separate __restrict__ kernel arguments: with `noalias` the compiler may read them with
 //  scalar loads inside the tile loop -- SGPR operands of the packed FMAs -- instead of one uniform VECTOR load per
 //  16 bytes of weights per tile, which is what it must do for pointers that could alias the stores to A.out)
-template <int STAGE, bool ORD>
-__global__ void __launch_bounds__(256, 6)
+// EPI (d_in = 8: the first encoder layer of every reference config): the per-point Linears that follow the stage run on the
+// wave's pooled rows before they leave the CU -- stage 1: pool1.mlp (16 -> 8, lrelu 0.2) so `out` is p1 [m, 8]; stage 2:
+// pool2.mlp (16 -> 16, lrelu 0.2), then lrelu_0.01(mlp2(.) + shortcut(feat_in)) as one [24] x [32] product so `out` is the
+// layer's output [m, 32] (randlanet.py:639, 690-692).  A wave parks the pooled rows of FOUR tiles (16 points) in an LDS patch
+// and then runs the Linears as 16x16x4 MFMAs with all 16 rows real; the [m, 16] pooled arrays and the chain launches that read
+// them back disappear.  (Per tile -- 4 real rows of 16 -- the 16 extra MFMAs of stage 2 cost more than the chain launch they
+// replace: 0.96 against 0.67 + 0.16 ms; on gfx950 an f32 MFMA is issue time the VALU-bound stage cannot spare.)
+template <int STAGE> struct A16Epi {
+    static constexpr int EP = STAGE == 1 ? 20 : 24;      // pitch of a parked row: [pooled / pool2 output (16) | feat_in (8)] (+ pad)
+};
+
+template <int STAGE, bool ORD, bool EPI>
+__global__ void __launch_bounds__(256, (EPI && STAGE == 2) ? 5 : 6)       // (stage 2 + epilogue: 30.4 KB of LDS, five workgroups per CU)
 lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __restrict__ lse1_b,
                 const float* __restrict__ lse2_wt, const float* __restrict__ lse2_b) {
     constexpr int D = 16, H = 8;
     __shared__ __attribute__((aligned(16))) float X[A16_TP * RK * A16_XP];
+    constexpr int EP = A16Epi<STAGE>::EP;
+    __shared__ __attribute__((aligned(16))) float E[EPI ? 4 * 16 * EP : 4];      // [wave][4 tiles x 4 points][EP]
+    __shared__ __attribute__((aligned(16))) uint32_t EM[EPI ? 4 * 16 : 4];        // their output rows (~0u: none)
+    // stage 2's epilogue weights live in LDS (20 registers otherwise, on a kernel that has 80):
+    // [mlp2 (16 rows) ; shortcut (8 rows)] x 32 | pool2.mlp [16][16] | pool2 bias [16] | mlp2 + shortcut bias [32]
+    constexpr int WC_POOL = 24 * 32, WC_PB = WC_POOL + 256, WC_CB = WC_PB + 16, WC_N = WC_CB + 32;
+    __shared__ float WC[(EPI && STAGE == 2) ? WC_N : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, col = lane & 15;
     float bs[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bs[s] = A.score_wt[(4 * g + s) * D + col];
     const float sbias = A.score_b[col];
+    // EPI stage 1: B operands of pool1.mlp (16 -> 8; K index 4 g + s as for the scores) and its bias, in registers
+    float wp[4] = {0.f, 0.f, 0.f, 0.f}, pbias = 0.f;
+    if constexpr (EPI && STAGE == 1) {
+        if (col < H) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wp[s] = A.pool_wt[(4 * g + s) * H + col];
+            pbias = A.pool_b[col];
+        }
+    }
+    if constexpr (EPI && STAGE == 2) {
+        for (int i = tid; i < WC_N; i += 256)
+            WC[i] = i < 16 * 32 ? A.mlp2_wt[i] : i < WC_POOL ? A.short_wt[i - 16 * 32] : i < WC_PB ? A.pool_wt[i - WC_POOL] :
+                    i < WC_CB ? A.pool_b[i - WC_PB] : A.mlp2_b[i - WC_CB] + A.short_b[i - WC_CB];
+        __syncthreads();
+    }
     // tile bookkeeping is wave-uniform and 32-bit (launcher: m_total, n0 < 2^30, n >= 16): the VALU shares the SIMD's
     // issue cycles with the f32 MFMAs on gfx950, a 64-bit division per lane would cost more than the tile's MFMAs
     const uint32_t tiles = (uint32_t)((A.m_total + A16_TP - 1) / A16_TP);
@@ -1183,6 +1249,7 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
             g0 = gf[0]; g1 = gf[1];
         }
     };
+    int parked = 0;                      // EPI: tiles whose pooled rows wait in the wave's LDS patch
     int64_t cur = next_tile();
     if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
     while (cur >= 0) {
@@ -1247,6 +1314,13 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
         if (nxt >= 0) request_data((uint32_t)nxt);
         // ---- MFMA: wave w owns points 4w .. 4w+3 of the tile ------------------------------------------
         constexpr float LOG2E = 1.4426950408889634f;                         // exp(s - max) = exp2(s * log2e - max * log2e)
+        // EPI: this lane's point of the epilogue is point g of the wave (whose X rows it helped build: mrow_cur is its row)
+        const uint32_t m_own = ORD ? mrow_cur : m_base + (uint32_t)(tid >> 4);
+        const bool own_ok = m_base + (uint32_t)(tid >> 4) < m_tot;
+        float fin = 0.f, keep = 0.f;
+        if constexpr (EPI && STAGE == 2) {
+            if (own_ok && col < 8) fin = A.feat_in[(int64_t)m_own * 8 + col];         // (in flight under the four points' MFMAs)
+        }
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             const float* Xp = Xw + pp * RK * A16_XP;
@@ -1274,25 +1348,97 @@ lfa_attn_mfma16(LfaArgs A, const float* __restrict__ lse1_wt, const float* __res
             const uint32_t m = ORD ? (uint32_t)__builtin_amdgcn_readlane((int)mrow_cur, 16 * pp) : mi;
             // (v_rcp_f32 + multiply: 2 instructions against ~10 for the IEEE division, 1 ulp -- this kernel is VALU-issue bound,
             //  profiles/r03_pmc_forward.md; the 1e-4 parity gate has five orders of magnitude of room)
-            if (g == 0 && mi < m_tot) A.out[(int64_t)m * D + col] = ag * __builtin_amdgcn_rcpf(sum);
+            const float pooled = ag * __builtin_amdgcn_rcpf(sum);
+            if constexpr (EPI) {
+                keep = pp == g ? pooled : keep;
+                (void)m; (void)mi;
+            } else {
+                if (g == 0 && mi < m_tot) A.out[(int64_t)m * D + col] = pooled;
+            }
+        }
+        if constexpr (EPI) {
+            float* Ew = E + wave * 16 * EP;
+            uint32_t* Mw = EM + wave * 16;
+            const int slot = 4 * parked + g;                                  // (parked: wave-uniform)
+            Ew[slot * EP + col] = keep;
+            if constexpr (STAGE == 2) { if (col < 8) Ew[slot * EP + 16 + col] = fin; }
+            if (col == 0) Mw[slot] = own_ok ? m_own : 0xffffffffu;
+            ++parked;
+            if (parked == 4 || nxt < 0) {
+                // rows of tiles not parked this time hold older (or no) data: every output row depends on its own input row
+                // only, and their row id says "none"
+                if (col == 0) { for (int t4 = parked; t4 < 4; ++t4) Mw[4 * t4 + g] = 0xffffffffu; }
+                parked = 0;
+                wave_lds_sync();
+                const float* er = Ew + col * EP;                              // A operand: row i = col, K = 4 g + s
+                const float4 a = *reinterpret_cast<const float4*>(er + 4 * g);
+                if constexpr (STAGE == 2) {
+                    pbias = WC[WC_PB + col];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) wp[s] = WC[WC_POOL + (4 * g + s) * D + col];
+                }
+                f32x4 y = {pbias, pbias, pbias, pbias};
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wp[0], y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wp[1], y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wp[2], y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wp[3], y, 0, 0, 0);
+                // D: lane (col, g) holds rows 4 g .. 4 g + 3, column col
+                const uint4 mo4 = *reinterpret_cast<const uint4*>(Mw + 4 * g);
+                const uint32_t mo[4] = {mo4.x, mo4.y, mo4.z, mo4.w};
+                if constexpr (STAGE == 1) {
+                    if (col < H) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (mo[r] != 0xffffffffu) A.out[(int64_t)mo[r] * H + col] = lrelu(y[r], 0.2f);
+                    }
+                } else {
+                    // pool2's output rows replace the pooled ones (every lane's A read above is older than these writes: one
+                    // wave, LDS operations in order), the shortcut's input sits behind them
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ew[(4 * g + r) * EP + col] = lrelu(y[r], 0.2f);
+                    wave_lds_sync();
+                    // K = 24: steps 0..3 take k = 4 g + s (the pool2 output), steps 4, 5 take k = 16 + 2 g + s' (the layer input)
+                    const float4 a0 = *reinterpret_cast<const float4*>(er + 4 * g);
+                    const float2 a1 = *reinterpret_cast<const float2*>(er + 16 + 2 * g);
+                    const float av[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
+                    const float cb0 = WC[WC_CB + col], cb1 = WC[WC_CB + 16 + col];
+                    f32x4 z0 = {cb0, cb0, cb0, cb0}, z1 = {cb1, cb1, cb1, cb1};
+#pragma unroll
+                    for (int s6 = 0; s6 < 6; ++s6) {
+                        const int krow = s6 < 4 ? 4 * g + s6 : 16 + 2 * g + (s6 - 4);
+                        z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s6], WC[krow * 32 + col], z0, 0, 0, 0);
+                        z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s6], WC[krow * 32 + 16 + col], z1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mo[r] != 0xffffffffu) {
+                            float* o = A.out + (int64_t)mo[r] * 32;
+                            o[col] = lrelu(z0[r], 0.01f);
+                            o[16 + col] = lrelu(z1[r], 0.01f);
+                        }
+                    }
+                }
+            }
         }
         wave_lds_sync();
         cur = nxt;
     }
 }
 
+// epilogue: the stage's per-point Linears inside the kernel (a.out = p1 [m, 8] / the layer output [m, 32]); needs a.d_in == 8
 template <int STAGE>
-static int launch_attn_mfma16(LfaArgs a, hipStream_t st) {
+static int launch_attn_mfma16(LfaArgs a, hipStream_t st, bool epilogue) {
     int64_t tiles = (a.m_total + A16_TP - 1) / A16_TP;
     const bool xcd_on = knobs().attn_xcd;
     a.xcd_chunk = xcd_on ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
     const int cap = knobs().attn16_grid;
     unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
-    if (a.order)
-        hipLaunchKernelGGL((lfa_attn_mfma16<STAGE, true>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
-    else
-        hipLaunchKernelGGL((lfa_attn_mfma16<STAGE, false>), dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a, a.lse1_wt, a.lse1_b, a.lse2_wt, a.lse2_b);
+    };
+    if (epilogue) { if (a.order) go(lfa_attn_mfma16<STAGE, true, true>); else go(lfa_attn_mfma16<STAGE, false, true>); }
+    else { if (a.order) go(lfa_attn_mfma16<STAGE, true, false>); else go(lfa_attn_mfma16<STAGE, false, false>); }
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
@@ -1863,7 +2009,17 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
 
     // fc0 + bn0 + lrelu(0.2)            (randlanet.py:266-271)
     float* feat = take(B * n[0] * d->dim_features);
-    {
+    // every reference config: 8 features into a 16-wide first layer -> fc0 and that layer's mlp1 share one launch
+    float* f1_head = nullptr;
+    if (!force_valu && !no_fuse && d->dim_features == 8 && d->dim_output[0] == 16) {
+        f1_head = take(B * n[0] * 8);
+        const int64_t m = B * n[0];
+        T.begin(1000);
+        hipLaunchKernelGGL(head_fc0_mlp1, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, features, d->in_channels, P(0), P(1),
+                           P(2), P(3), m, feat, f1_head);
+        T.end(1000);
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    } else {
         LinArgs a = {};
         a.a0 = features; a.c0 = d->in_channels; a.wt = P(0); a.bias = P(1); a.out = feat;
         a.m_total = B * n[0]; a.cout = d->dim_features; a.act = 1; a.slope = 0.2f;
@@ -1874,11 +2030,11 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     for (int l = 0; l < Lr; ++l) {
         const int dd = d->dim_output[l], h = dd / 2, sb = 2 + 18 * l;
         const int64_t M = B * n[l];
-        float* f1 = take(M * h);
+        float* f1 = (l == 0 && f1_head) ? f1_head : take(M * h);
         float* p1 = take(M * h);
         float* enc = take(M * 2 * dd);
         float* samp = take(B * n[l + 1] * 2 * dd);
-        {   // mlp1: SharedMLP(d_in, d/2) lrelu 0.2   (randlanet.py:680)
+        if (!(l == 0 && f1_head)) {   // mlp1: SharedMLP(d_in, d/2) lrelu 0.2   (randlanet.py:680)
             LinArgs a = {};
             a.a0 = feat; a.c0 = d_in; a.wt = P(sb + 0); a.bias = P(sb + 1); a.out = f1;
             a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
@@ -1904,6 +2060,10 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             float* agg = take(M * dd);
             float* p2 = take(M * dd);
             LfaArgs q1 = s1; q1.out = agg;
+            // first layer of every reference config (16 wide, 8 features in): the per-point Linears behind both stages run
+            // inside the attention kernels (lfa_attn_mfma16<.., EPI>), `agg` is never written
+            const bool epi16 = dd == 16 && d_in == 8 && !no_fuse;
+            if (epi16) q1.out = p1;
             // D >= 128: the feature half of the score Linear once per POINT (gscore = f . W_top^T, into the p2 scratch,
             // which is otherwise idle until pool2), gathered by the attention kernel instead of recomputed per neighbour
             const bool split_on = knobs().attn_split;
@@ -1922,7 +2082,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             if (split) { rc = point_scores(f1, s1.score_wt, s1.score_b, 8 * l + 7); if (rc) return rc; q1.gscore = p2; }
             T.begin(8 * l + 1);
             switch (dd) {
-                case 16: rc = launch_attn_mfma16<1>(q1, st); break;
+                case 16: rc = launch_attn_mfma16<1>(q1, st, epi16); break;
                 case 32: rc = launch_attn_mfma<32, 1>(q1, st); break;
                 case 64: rc = launch_attn_mfma<64, 1>(q1, st); break;
                 case 128: rc = launch_attn_mfma<128, 1>(q1, st); break;
@@ -1930,17 +2090,17 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             }
             T.end(8 * l + 1);
             if (rc) return rc;
-            {   // pool1.mlp: SharedMLP(d, d/2) lrelu 0.2            (randlanet.py:639)
+            if (!epi16) {   // pool1.mlp: SharedMLP(d, d/2) lrelu 0.2            (randlanet.py:639)
                 LinArgs a = {};
                 a.a0 = agg; a.c0 = dd; a.wt = P(sb + 6); a.bias = P(sb + 7); a.out = p1;
                 a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
                 T.begin(8 * l + 4); rc = launch_linear_auto(a, st); T.end(8 * l + 4); if (rc) return rc;
             }
-            LfaArgs q2 = s2; q2.out = agg;
+            LfaArgs q2 = s2; q2.out = epi16 ? enc : agg;
             if (split) { rc = point_scores(p1, s2.score_wt, s2.score_b, 8 * l + 7); if (rc) return rc; q2.gscore = p2; }
             T.begin(8 * l + 2);
             switch (dd) {
-                case 16: rc = launch_attn_mfma16<2>(q2, st); break;
+                case 16: rc = launch_attn_mfma16<2>(q2, st, epi16); break;
                 case 32: rc = launch_attn_mfma<32, 2>(q2, st); break;
                 case 64: rc = launch_attn_mfma<64, 2>(q2, st); break;
                 case 128: rc = launch_attn_mfma<128, 2>(q2, st); break;
@@ -1961,7 +2121,9 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             ch.out = enc; ch.m_total = M;
             // (fused when the shape has a compiled per-wave instance: the first two encoder layers of every reference
             //  config; wide layers run faster as two tile GEMMs than through any chain kernel: 0.69 -> 0.35 ms at 128 channels)
-            if (!no_fuse && M >= fuse_rows && chain_compiled(ch)) {
+            if (epi16) {
+                // (done inside stage 2)
+            } else if (!no_fuse && M >= fuse_rows && chain_compiled(ch)) {
                 T.begin(8 * l + 5); rc = launch_chain_auto(ch, st); T.end(8 * l + 5); if (rc) return rc;
             } else {
                 {

@@ -81,10 +81,14 @@ CFGS = [
     # level sizes 1100 / 275 / 68 / 17 per cloud: tiles of the attention kernels (16, 2 and 4 points) straddle clouds
     dict(num_neighbors=16, num_layers=3, num_classes=7, sub_sampling_ratio=[4, 4, 4], in_channels=3,
          dim_features=8, dim_output=[16, 64, 128]),
+    # 16 features into the 16-wide first layer: NOT the shape of the fused head / attention epilogues (8 features, every reference
+    # config) -> fc0, mlp1, pool1.mlp and the pool2 | mlp2 | shortcut chain as separate launches around lfa_attn_mfma16
+    dict(num_neighbors=16, num_layers=2, num_classes=6, sub_sampling_ratio=[4, 4], in_channels=4,
+         dim_features=16, dim_output=[16, 64]),
 ]
 
 
-@pytest.mark.parametrize("ci,B,N", [(0, 2, 1024), (1, 3, 515), (2, 3, 1100)])
+@pytest.mark.parametrize("ci,B,N", [(0, 2, 1024), (1, 3, 515), (2, 3, 1100), (3, 2, 600)])
 def test_randla_forward_matches_oracle(ci, B, N):
     cfg = CFGS[ci]
     rng = np.random.default_rng(3)

@@ -191,6 +191,21 @@ def test_nearest_to_center_is_the_sampler_query_in_sklearn_order():
     assert all(idx[i] < idx[i + 1] for i in range(0, 100, 2)) and np.array_equal(d2[0::2], d2[1::2])
 
 
+def test_nearest_to_center_on_a_cloud_longer_than_the_short_sort():
+    """The radix sort under it has two forms: <= 128 blocks of 1024 keys every scatter block derives its offsets from the raw
+    block histograms, longer arrays go through the histogram scan.  140 000 points = 137 blocks; numpy's stable argsort of the
+    same float64 keys is the reference (duplicates included: ties in ascending index)."""
+    rng = np.random.default_rng(12)
+    pts = np.concatenate([synth_data.semantickitti_patch(3, 70000), synth_data.semantickitti_patch(3, 70000)])
+    pts[70000:] += rng.integers(0, 2, (70000, 1)).astype(np.float32) * np.float32(0.25)       # half of them exact duplicates
+    c = pts[17] + np.float32(0.5)
+    idx, d2 = emu.nearest_to_center(pts, c, 4096)
+    d = pts.astype(np.float64) - c.astype(np.float64)
+    key = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    ref = np.argsort(key, kind="stable")[:4096]
+    assert np.array_equal(idx, ref) and np.array_equal(d2, key[ref])
+
+
 def test_vote_update_follows_numpy_float16_promotion():
     """randlanet.py:457-462: test_probs (float16) = 0.95 * test_probs + 0.05 * softmax(logits) (float32)."""
     import torch

@@ -1,16 +1,19 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp
-LIB=open3d-ml_amd/ml3d/lib
-cp $LIB/libml3d_hip.so /tmp/base.so
-run() {
-  echo "== $1: $(python tools/roofline_ops.py kp 9 2>&1 | tail -1)"
-  echo "   bench: $(python bench.py --workload kpconv --steps 10 --warmup 3 --no-cpu-baseline --no-latency 2>/dev/null | python -c "
+mkdir -p gpurun_out/r4m
+timeout 900 python -m pytest tests/test_gpu_randlanet.py tests/test_gpu_configs.py -x -q -k "randla" 2>&1 | tail -3
+python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-overlap --no-latency --no-workloads --breakdown > gpurun_out/r4m/breakdown.json 2> gpurun_out/r4m/breakdown.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4m/breakdown.json').readline())
+print(d['value'], d['ms_per_step'])
+b=d['breakdown_ms']
+print({k: round(b[k],3) for k in sorted(b, key=lambda k:int(k.split(':')[1])) if k.startswith('fwd:') and int(k.split(':')[1]) < 8 or k=='fwd:1000'})
+print('fwd sum', sum(v for k,v in b.items() if k.startswith('fwd')))
+PY
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-workloads 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); r=d.get('roofline',{}); print('%.0f %s step %.2f ms; block %.3f ms frac %.3f alone %.3f ms' % (d['value'], d['unit'], d['ms_per_step'], r.get('avg_launch_ms',-1), r.get('frac',-1), r.get('avg_launch_ms_alone',-1)))")"
-}
-ML3D_KP_FUSED32=0 run unfused
-run fused_d2
-cp $LIB/ab/kf_d3.so $LIB/libml3d_hip.so
-run fused_d3
-cp /tmp/base.so $LIB/libml3d_hip.so
+d=json.loads(sys.stdin.readline()); print('%.0f frames/s step %.2f ms' % (d['value'], d['ms_per_step']))"
+python tools/latency_only.py 100 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('B1', d['batch_1']['ms_per_frame_median'], 'B4', d['batch_4']['ms_per_frame_median'])"
