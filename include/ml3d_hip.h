@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 5
+#define ML3D_ABI_VERSION 6
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -496,6 +496,19 @@ int ml3d_randla_gather_max(const float* features, const int32_t* pool_idx, int64
 int ml3d_randla_gather_max_backward(const float* features, const int32_t* pool_idx, const float* grad_out,
                                     int64_t batch, int64_t n_in, int64_t n_out, int channels,
                                     float* grad_features, void* stream);
+
+/* ---- RandLA-Net attentive pooling as a differentiable op (training side, SURVEY.md §8 f4, ABI 6) ------------------ */
+/* ml3d_randla_attentive_pool: out[r, c] = sum_k softmax_k(scores[r, :, c])[k] * x[r, k, c] for point-major               */
+/*   scores, x [rows, k, channels] (k <= 32): AttentivePooling.forward up to its SharedMLP (randlanet.py:622-637 --        */
+/*   `scores = softmax(score_fn(x), dim=-2); features = sum(scores * x, dim=-2)` in the reference's channel-major layout). */
+/* ml3d_randla_attentive_pool_backward: grad_x = p * grad_out, grad_scores = p * (x - out) * grad_out with p the softmax  */
+/*   recomputed from `scores`; `out` = the forward result (ml3d.ops.AttentivePoolFunction).                               */
+int ml3d_randla_attentive_pool(const float* scores, const float* x, int64_t rows, int k, int channels,
+                               float* out, void* stream);
+
+int ml3d_randla_attentive_pool_backward(const float* scores, const float* x, const float* out,
+                                        const float* grad_out, int64_t rows, int k, int channels,
+                                        float* grad_scores, float* grad_x, void* stream);
 
 /* ml3d_argmax_labels: out_labels[i] = argmax_c scores[i, c] as uint8 (num_classes <= 256; first  */
 /*   maximum, NaN = maximum, like torch.argmax) -- the predicted labels that leave the GPU          */

@@ -1813,6 +1813,52 @@ gather_max_adjoint(const float* __restrict__ feat, const int32_t* __restrict__ n
     atomicAdd(gfeat + arg * c + ch, gout[r * c + ch]);
 }
 
+// attentive pooling as a differentiable op for training (randlanet.py:622-637 without the trailing SharedMLP):
+//   out[r, c] = sum_k softmax_k(scores[r, :, c])[k] x[r, k, c]
+// one thread per (row, channel) -- lanes run along the channels, so every access is a coalesced row segment -- the K values of
+// both operands in registers, max-subtracted exponentials like torch.softmax.  Backward recomputes the softmax p from the saved
+// inputs (nothing of size [rows, K, C] is kept between the passes): dx = p g, dscores = p (x - out) g.
+constexpr int AP_KMAX = 32;
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+attentive_pool_k(const float* __restrict__ scores, const float* __restrict__ x, const float* __restrict__ out_saved,
+                 const float* __restrict__ gout, int64_t rows, int k, int c, float* __restrict__ out,
+                 float* __restrict__ gscores, float* __restrict__ gx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * c) return;
+    const int ch = (int)(e % c);
+    const int64_t r = e / c;
+    const float* sp = scores + r * k * c + ch;
+    const float* xp = x + r * k * c + ch;
+    float sv[AP_KMAX], xv[AP_KMAX];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < AP_KMAX; ++j) {
+        if (j < k) { sv[j] = sp[(int64_t)j * c]; xv[j] = xp[(int64_t)j * c]; mx = fmaxf(mx, sv[j]); }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < AP_KMAX; ++j) {
+        if (j < k) { sv[j] = expf(sv[j] - mx); sum += sv[j]; }
+    }
+    if constexpr (!BWD) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < AP_KMAX; ++j) if (j < k) acc = fmaf(sv[j] / sum, xv[j], acc);
+        out[e] = acc;
+    } else {
+        const float g = gout[e], o = out_saved[e];
+#pragma unroll
+        for (int j = 0; j < AP_KMAX; ++j) {
+            if (j < k) {
+                const float pg = sv[j] / sum * g;
+                gx[r * k * c + (int64_t)j * c + ch] = pg;
+                gscores[r * k * c + (int64_t)j * c + ch] = pg * (xv[j] - o);
+            }
+        }
+    }
+}
+
 struct Tracer {
     const ml3d_trace* t;
     hipStream_t st;
@@ -2293,5 +2339,31 @@ extern "C" int ml3d_randla_gather_max_backward(const float* features, const int3
     const int64_t total = batch * n_out * channels;
     hipLaunchKernelGGL(gather_max_adjoint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, features, pool_idx, grad_out,
                        grad_features, n_in, n_out, batch, channels);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+// ---- attentive pooling as a stand-alone differentiable op (training side) ---------------------------------
+extern "C" int ml3d_randla_attentive_pool(const float* scores, const float* x, int64_t rows, int k, int channels, float* out,
+                                          void* stream) {
+    if (rows < 0 || k <= 0 || channels <= 0) return ML3D_E_INVALID;
+    if (k > AP_KMAX) return ML3D_E_UNSUPPORTED;
+    if (rows == 0) return 0;
+    if (!scores || !x || !out) return ML3D_E_INVALID;
+    const int64_t total = rows * channels;
+    hipLaunchKernelGGL((attentive_pool_k<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, x,
+                       nullptr, nullptr, rows, k, channels, out, nullptr, nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_randla_attentive_pool_backward(const float* scores, const float* x, const float* out, const float* grad_out,
+                                                   int64_t rows, int k, int channels, float* grad_scores, float* grad_x,
+                                                   void* stream) {
+    if (rows < 0 || k <= 0 || channels <= 0) return ML3D_E_INVALID;
+    if (k > AP_KMAX) return ML3D_E_UNSUPPORTED;
+    if (rows == 0) return 0;
+    if (!scores || !x || !out || !grad_out || !grad_scores || !grad_x) return ML3D_E_INVALID;
+    const int64_t total = rows * channels;
+    hipLaunchKernelGGL((attentive_pool_k<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, x,
+                       out, grad_out, rows, k, channels, nullptr, grad_scores, grad_x);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }

@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 5          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 6          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -62,6 +62,8 @@ SYMBOLS = [
     "ml3d_vote_update",
     "ml3d_randla_gather_max",
     "ml3d_randla_gather_max_backward",
+    "ml3d_randla_attentive_pool",
+    "ml3d_randla_attentive_pool_backward",
     "ml3d_argmax_labels",
     "ml3d_randla_pyramid_workspace_bytes",
     "ml3d_randla_knn_pyramid",
@@ -193,6 +195,10 @@ def bind(lib):
     lib.ml3d_randla_gather_max.argtypes = [vp, vp, i64, i64, i64, i32, vp, vp]
     lib.ml3d_randla_gather_max_backward.restype = C.c_int
     lib.ml3d_randla_gather_max_backward.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp]
+    lib.ml3d_randla_attentive_pool.restype = C.c_int
+    lib.ml3d_randla_attentive_pool.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    lib.ml3d_randla_attentive_pool_backward.restype = C.c_int
+    lib.ml3d_randla_attentive_pool_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_argmax_labels.restype = C.c_int

@@ -115,3 +115,39 @@ class GatherMaxFunction(torch.autograd.Function):
                                                      c, gf.data_ptr(), _stream())
         _abi.check(rc, "ml3d_randla_gather_max_backward")
         return gf, None, None
+
+
+class AttentivePoolFunction(torch.autograd.Function):
+    """The pooling of ``AttentivePooling.forward`` (randlanet.py:622-637) up to its SharedMLP, point-major:
+    ``scores``, ``x`` [..., K, C] -> ``sum_k softmax_k(scores) * x`` [..., C].  HIP forward; hand-written HIP backward that
+    recomputes the softmax from the saved inputs, so no [rows, K, C] probability tensor lives between the passes."""
+
+    @staticmethod
+    def forward(ctx, scores, x):
+        lib = _abi.get()
+        _need_gpu(scores, x)
+        if scores.shape != x.shape or x.dim() < 3:
+            raise RuntimeError("AttentivePoolFunction: scores and x must share one [..., K, C] shape")
+        scores, x = scores.contiguous().float(), x.contiguous().float()
+        k, c = x.shape[-2], x.shape[-1]
+        rows = x.numel() // (k * c)
+        out = torch.empty(x.shape[:-2] + (c,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_randla_attentive_pool(scores.data_ptr(), x.data_ptr(), rows, k, c, out.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_attentive_pool")
+        ctx.save_for_backward(scores, x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        scores, x, out = ctx.saved_tensors
+        k, c = x.shape[-2], x.shape[-1]
+        rows = x.numel() // (k * c)
+        g = g.contiguous().float()
+        gs, gx = torch.empty_like(scores), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_randla_attentive_pool_backward(scores.data_ptr(), x.data_ptr(), out.data_ptr(), g.data_ptr(), rows, k, c,
+                                                         gs.data_ptr(), gx.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_attentive_pool_backward")
+        return gs, gx

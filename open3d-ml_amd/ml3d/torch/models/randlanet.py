@@ -165,8 +165,9 @@ class RandLANet(nn.Module):
         """``RandLANet.forward`` in TRAINING mode (randlanet.py:241-298 with :533-692), differentiable: point-major
         ``[B, N, C]`` tensors, every 1x1 (transposed) convolution as the Linear it is, BatchNorm2d(eps 1e-6) on the batch
         statistics over all rows (NOT folded), the neighbour pyramid from the HIP search when the dict carries none,
-        ``random_sample`` through ``ops.GatherMaxFunction`` (HIP forward + hand-written HIP backward); the gathers of the
-        encodings and the attentive pooling run on torch's autograd (their fused inference kernels have no adjoint yet).
+        ``random_sample`` through ``ops.GatherMaxFunction`` and the softmax-weighted sums of the two attentive poolings through
+        ``ops.AttentivePoolFunction`` (HIP forward + hand-written HIP backward each); the gathers of the encodings and the
+        Linears run on torch's autograd.
         Dropout(0.5) of fc1 is live, like in the reference."""
         import torch.nn.functional as F
         cfg, dev = self.cfg, self.device
@@ -206,8 +207,7 @@ class RandLANet(nn.Module):
             return torch.cat([gather(f, idx), enc], -1), enc
 
         def att(m, x):              # AttentivePooling.forward (randlanet.py:622-639): softmax over the K neighbours
-            scores = torch.softmax(m.score_fn[0](x), dim=-2)
-            return shared(m.mlp, (scores * x).sum(-2))
+            return shared(m.mlp, ops.AttentivePoolFunction.apply(m.score_fn[0](x), x))
 
         y = F.linear(feat, self.fc0.weight, self.fc0.bias)
         y = F.leaky_relu(F.batch_norm(y.reshape(-1, y.shape[-1]), self.bn0.running_mean, self.bn0.running_var, self.bn0.weight,

@@ -337,3 +337,35 @@ for cin, cout, strided, infl in ((32, 16, False, 1), (8, 24, True, 1), (4, 32, F
     assert (w.grad - gw_ref).abs().max() <= 1e-4 * sc(gw_ref), (cin, float((w.grad - gw_ref).abs().max()))
 print("ok")
 ''')
+
+
+def test_attentive_pool_and_gather_max_functions_match_torch_autograd():
+    """ops.AttentivePoolFunction against torch's autograd through the reference's formulation (randlanet.py:631-637:
+    ``softmax(scores, dim=K)`` then ``sum(scores * x, dim=K)``), and ops.GatherMaxFunction against ``torch.max`` over the
+    gathered neighbours (randlanet.py:318-327): outputs and every input gradient, for 8 / 16 / 100 channels, K = 16 and K = 5."""
+    _run(r'''
+from ml3d import ops
+rng = np.random.default_rng(4)
+for B, N, K, C in ((2, 70, 16, 16), (1, 33, 16, 100), (3, 9, 5, 8)):
+    s = torch.from_numpy((rng.standard_normal((B, N, K, C)) * 3).astype(np.float32)).requires_grad_(True)
+    x = torch.from_numpy(rng.standard_normal((B, N, K, C)).astype(np.float32)).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32))
+    ref = (torch.softmax(s, dim=-2) * x).sum(-2)
+    ref.backward(g)
+    gs_ref, gx_ref = s.grad.clone(), x.grad.clone()
+    s.grad = None; x.grad = None
+    out = ops.AttentivePoolFunction.apply(s, x)
+    out.backward(g)
+    assert (out - ref).abs().max() <= 1e-5 and (s.grad - gs_ref).abs().max() <= 1e-5 and (x.grad - gx_ref).abs().max() <= 1e-5, (K, C)
+for B, n_in, n_out, C in ((2, 64, 16, 32), (1, 40, 40, 8)):
+    f = torch.from_numpy(rng.standard_normal((B, n_in, C)).astype(np.float32)).requires_grad_(True)
+    idx = torch.from_numpy(rng.integers(0, n_in, (B, n_in, 16)).astype(np.int32))
+    g = torch.from_numpy(rng.standard_normal((B, n_out, C)).astype(np.float32))
+    ref = f[torch.arange(B)[:, None, None], idx[:, :n_out].long()].max(2)[0]
+    ref.backward(g)
+    gf_ref = f.grad.clone(); f.grad = None
+    out = ops.GatherMaxFunction.apply(f, idx, n_out)
+    out.backward(g)
+    assert torch.equal(out, ref) and (f.grad - gf_ref).abs().max() <= 1e-5
+print("ok")
+''')
