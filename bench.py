@@ -336,9 +336,6 @@ class _StubFrameStream:
 
 
 def main():
-    if os.environ.get("ML3D_BENCH_WATCHDOG"):          # debugging aid: python tracebacks of every thread after N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["ML3D_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

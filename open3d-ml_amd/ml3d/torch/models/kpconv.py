@@ -696,7 +696,7 @@ class KPConvBatch:
                 #  searched again; the upsample radius is twice the POOL radius, concat_batcher.py:262-263)
                 pool_plan = ops.radius_plan_dense(pool_p, pts, pool_lens, lens, r_pool, long_rows=r_pool > r_normal,
                                                   grid_from=conv_plan if (r_pool == r_conv and r_pool == r_normal) else None)
-                up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_pool)
+                up_plan = ops.radius_plan_dense(pts, pool_p, lens, pool_lens, 2 * r_pool, long_rows=r_pool > r_normal)
                 ops.resolve_plans(pool_plan, up_plan)
                 pool_i = ops.radius_fill_dense(pool_plan, pts.shape[0])
                 up_i = ops.radius_fill_dense(up_plan, pool_p.shape[0])
