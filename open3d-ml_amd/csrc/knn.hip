@@ -63,9 +63,9 @@ constexpr int KNN_GROUP = 3;
 // SUB: also track the nearest candidate whose index is below n_sub -- the RandLA pyramid's 1-NN interpolation target
 // (level l + 1 is the prefix [:n_sub] of level l, randlanet.py:222-224), found in the same scan as the k-NN
 template <int K, bool SUB>
-__device__ __forceinline__ void scan_run(const GridView& G, int cell_a, int cell_b, float qx, float qy,
+__device__ __forceinline__ void scan_run(const GridView& G, int p0, int p1, float qx, float qy,
                                          float qz, double (&best)[K], int n_sub, double& best1) {
-    int p0 = G.cell_start[cell_a], p1 = G.cell_start[cell_b + 1];
+    // [p0, p1): the run's slice of the cell-sorted array (the caller read the two cell_start entries, one row ahead).
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
     // per group instead of one per candidate); indices past the run are clamped to its last point and skipped
     for (int p = p0; p < p1; p += KNN_GROUP) {
@@ -121,21 +121,36 @@ __device__ __forceinline__ void scan_shell(const GridView& G, const GridSeg& g, 
     const int xa = max(cx - r_out, 0), xb = min(cx + r_out, dxm);
     const int ya = max(cy - r_out, 0), yb = min(cy + r_out, dym);
     const int za = max(cz - r_out, 0), zb = min(cz + r_out, dzm);
+    // a row's cells [xa, xb] are one run, or -- where the row crosses the box already read -- the two ends [xa, lb] and [ra, xb];
+    // either way four cell_start entries describe it (an empty end: two equal entries).  They are requested ONE ROW AHEAD: a row
+    // costs two dependent round trips (bounds, then candidates), and a lane in a sparse region walks hundreds of near-empty rows
+    // in which the bounds are all there is -- the time of a small launch is its slowest lane's.
+    const int lb = min(cx - r_in - 1, xb), ra = max(cx + r_in + 1, xa);      // (meaningful for rows inside the inner box's y, z range)
+    const int i1 = max(lb + 1, xa), i2 = min(ra, xb + 1);
+    auto request = [&](int y, int z, int (&b)[4]) {
+        const int32_t* cs = G.cell_start + g.cell_base + g.dims[0] * (y + g.dims[1] * z);
+        b[0] = cs[xa]; b[1] = cs[i1]; b[2] = cs[i2]; b[3] = cs[xb + 1];
+    };
+    int nb[4];
+    request(ya, za, nb);
     for (int z = za; z <= zb; ++z) {
         const int az = z > cz ? z - cz : cz - z;
         const float ez = axis_gap(qz, g.lo[2], g.c, z, g.margin);
         for (int y = ya; y <= yb; ++y) {
+            const int cur[4] = {nb[0], nb[1], nb[2], nb[3]};
+            // the next row of the walk (past the end: this one again)
+            const bool last_y = y == yb;
+            const int yn = last_y ? (z < zb ? ya : y) : y + 1, zn = last_y && z < zb ? z + 1 : z;
+            request(yn, zn, nb);
             const int ay = y > cy ? y - cy : cy - y;
             const float ey = axis_gap(qy, g.lo[1], g.c, y, g.margin);
             if ((ez * ez + ey * ey) * 0.999999f > bound) continue;
-            const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);
             if (r_in == 0 || az > r_in || ay > r_in) {
-                scan_run<K, SUB>(G, row + xa, row + xb, qx, qy, qz, best, n_sub, best1);
+                scan_run<K, SUB>(G, cur[0], cur[3], qx, qy, qz, best, n_sub, best1);
             } else {
                 // (inlined copies of the scan: a one-copy loop over the two ends costs 9 % -- 1.73 against 1.59 ms alone)
-                const int lb = min(cx - r_in - 1, dxm), ra = max(cx + r_in + 1, 0);
-                if (xa <= lb) scan_run<K, SUB>(G, row + xa, row + lb, qx, qy, qz, best, n_sub, best1);
-                if (ra <= xb) scan_run<K, SUB>(G, row + ra, row + xb, qx, qy, qz, best, n_sub, best1);
+                scan_run<K, SUB>(G, cur[0], cur[1], qx, qy, qz, best, n_sub, best1);
+                scan_run<K, SUB>(G, cur[2], cur[3], qx, qy, qz, best, n_sub, best1);
             }
         }
     }
