@@ -64,7 +64,7 @@ typedef float kp_v2f __attribute__((ext_vector_type(2)));
 // kp_influence above rounds every product: the two differ in the last ulp, so which kernel a layer takes (kp_small_fused /
 // kp_weighted on this form, kp_weighted_small on the scalar one) shows in the last bit of the influence weights.  KPConv
 // features are a FLOAT row of SURVEY.md §8 (tolerance 1e-4 on the logits, tests/test_gpu_kpconv.py), never a bit-exact one
-// -- unlike the index ops, whose d2 must stay unfused -- and ML3D_KP_SMALL_FUSED=0 is an A/B of speed, not of bits.
+// -- unlike the index ops, whose d2 must stay unfused.
 __device__ __forceinline__ kp_v2f kp_influence2(kp_v2f dx, kp_v2f dy, kp_v2f dz, const KpArgs& A) {
     const kp_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
     if (A.influence == 0) return (kp_v2f){1.0f, 1.0f};
@@ -780,7 +780,6 @@ static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
 }
 
 // the MFMA aggregation takes cin in {16, 32, 64, 128, 256} and 16-byte aligned features / wf
-// (ML3D_KP_AGG_MFMA=0, read once: the packed-FMA kernels for A/B runs)
 static bool agg_mfma_ok(const KpArgs& a) {
     const int c = a.cin;
     return (c == 16 || c == 32 || c == 64 || c == 128 || c == 256 || (c == 512 && a.off)) && a.h > 0 && a.ns > 0 &&

@@ -1880,8 +1880,8 @@ static int launch_linear(const LinArgs& a, hipStream_t st) {
 }
 
 static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
-    // default: the register-prefetching tile GEMM of gemm.hip; ML3D_RANDLA_LINEAR=valu forces the scalar kernel
-    const int lin_mode = knobs().linear;                  // 0 default, 2 "valu"
+    // the register-prefetching tile GEMM of gemm.hip (lin_mode 2 = the scalar kernel: a settled A/B, Knobs::linear stays 0)
+    const int lin_mode = knobs().linear;
     const bool shaped = knobs().mlp_shaped;
     if (lin_mode == 0 && shaped && !a.a1 && a.m_total >= knobs().fuse_rows) {     // (tests lower the row threshold)
         // narrow Linears over many rows: the barrier-free per-wave kernel with a compiled shape
@@ -2037,8 +2037,8 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     if (workspace_bytes < ml3d_randla_forward_workspace_bytes(d)) return ML3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Tracer T = {trace, st};
-    const bool force_valu = knobs().force_valu;                // A/B knob ML3D_RANDLA_PATH: "valu" forces the v1 kernels,
-    const bool no_fuse = knobs().no_fuse;                      // "unfused": one launch per Linear
+    const bool force_valu = knobs().force_valu;                // (settled A/B switches of rounds 1-3, fixed false: the generic VALU
+    const bool no_fuse = knobs().no_fuse;                      //  kernels / one launch per Linear)
     const int64_t fuse_rows = knobs().fuse_rows;               // tuning/test knob: rows from which pool2+mlp2 fuse
     const int Lr = d->num_layers;
     const int64_t B = d->batch;

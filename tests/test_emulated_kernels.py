@@ -79,7 +79,8 @@ CFGS = [
     dict(num_neighbors=16, num_layers=2, num_classes=5, sub_sampling_ratio=[4, 2], in_channels=6,
          dim_features=8, dim_output=[8, 32]),
     # level sizes 1100 / 275 / 68 / 17 per cloud: tiles of the attention kernels (16, 2 and 4 points) straddle clouds
-    dict(num_neighbors=16, num_layers=3, num_classes=7, sub_sampling_ratio=[4, 4, 4], in_channels=3,
+    # (in_channels 6 -- xyz + colours, the S3DIS / Semantic3D configs -- through the fused fc0 + mlp1 head kernel)
+    dict(num_neighbors=16, num_layers=3, num_classes=7, sub_sampling_ratio=[4, 4, 4], in_channels=6,
          dim_features=8, dim_output=[16, 64, 128]),
     # 16 features into the 16-wide first layer: NOT the shape of the fused head / attention epilogues (8 features, every reference
     # config) -> fc0, mlp1, pool1.mlp and the pool2 | mlp2 | shortcut chain as separate launches around lfa_attn_mfma16

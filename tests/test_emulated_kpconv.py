@@ -140,6 +140,14 @@ for infl, name in ((1, "linear"), (2, "gaussian")):
         ref = torch.matmul(wf, tw).sum(0)
     ref = torch.relu(ref).numpy()
     assert rc == 0 and np.abs(out - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())) and (out[-1] == 0).all(), name
+# rows wider than 128 columns (a dense cloud under a wide radius): the aggregation walks them 128 columns at a time, and the
+# one-kernel block re-reads the neighbours' positions per 128-column slab
+q2 = q[::37]
+inds2 = K.batch_neighbors(q2, s, [len(q2)], [len(s)], 0.45)
+assert inds2.shape[1] > 128
+rc, out = emu.kpconv_rigid(q2, s, inds2, x, kp, w, 0.3, act=2, influence=1)
+ref = torch.relu(K.kpconv_rigid(torch.from_numpy(q2), ts, torch.from_numpy(inds2.astype(np.int64)), tx, tk, tw, 0.3)).numpy()
+assert rc == 0 and np.abs(out - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
 print("ok")
 """
 
