@@ -383,8 +383,6 @@ class PointPillars(nn.Module):
     def head_maps_nhwc(self, inputs):
         """The three head maps as ONE NHWC tensor [B, H, W, A*C + A*7 + A*2] (what the fused head GEMM writes) + the
         channel split."""
-        if self.training:
-            raise RuntimeError("PointPillars (MI355X build) implements the inference forward only; call .eval()")
         _abi.require_gpu(self.device, "PointPillars.forward")
         points = inputs.point if hasattr(inputs, 'point') else inputs
         neck = self.extract_feats(points)
@@ -405,9 +403,57 @@ class PointPillars(nn.Module):
             off += c
         return self.bbox_head.boxes_device(*views)
 
+    def train(self, mode=True):
+        """(the folded-BatchNorm parameter pack of the fused inference kernels is stale once training touches the weights)"""
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _forward_train(self, inputs):
+        """``PointPillars.forward`` in TRAINING mode (point_pillars.py:102-138), differentiable down to every parameter:
+        the voxelization on the HIP ops (the training-side ``max_voxels[0]``; indices only, nothing to differentiate), then
+        the pillar decorations, PFN layers (point_pillars.py:417-453, 512-555) and the scatter (:577-616) as batched torch
+        expressions, and SECOND / SECONDFPN / the 1x1 heads through this class's own ``nn.Conv2d`` / ``ConvTranspose2d`` /
+        ``BatchNorm`` modules (BatchNorm on batch statistics) on torch's autograd -- the fused NHWC inference kernels have no
+        adjoint.  Same maps as the reference's training forward to float32 rounding."""
+        dev = self.device
+        points = inputs.point if hasattr(inputs, 'point') else inputs
+        voxels, num_points, coors = self.voxelize(points)                         # [M, P, C], [M], [M, 4] (sample, z, y, x)
+        ve = self.voxel_encoder
+        voxels = voxels.float()
+        cnt = num_points.to(voxels.dtype).view(-1, 1, 1)
+        xyz = voxels[:, :, :3]
+        f_cluster = xyz - xyz.sum(1, keepdim=True) / cnt
+        cx = coors[:, 3].to(voxels.dtype).view(-1, 1) * ve.vx + ve.x_offset
+        cy = coors[:, 2].to(voxels.dtype).view(-1, 1) * ve.vy + ve.y_offset
+        f_center = torch.stack([voxels[:, :, 0] - cx, voxels[:, :, 1] - cy], -1)
+        x = torch.cat([voxels, f_cluster, f_center], -1)
+        live = torch.arange(voxels.shape[1], device=dev).view(1, -1) < num_points.view(-1, 1)      # slots past a pillar's points
+        x = x * live.unsqueeze(-1).to(x.dtype)
+        for pfn in ve.pfn_layers:
+            y = pfn.linear(x)
+            y = torch.relu(pfn.norm(y.transpose(1, 2)).transpose(1, 2))           # BatchNorm1d over the channels of [M, C, P]
+            y_max = y.max(1, keepdim=True)[0]
+            x = y_max if pfn.last_vfe else torch.cat([y, y_max.expand(-1, y.shape[1], -1)], 2)
+        feat = x.squeeze(1)                                                       # [M, C]
+        B = len(points)
+        ny, nx, C = self.middle_encoder.ny, self.middle_encoder.nx, feat.shape[1]
+        canvas = torch.zeros((B, ny * nx, C), dtype=feat.dtype, device=dev)
+        canvas[coors[:, 0].long(), (coors[:, 2] * nx + coors[:, 3]).long()] = feat
+        x = canvas.view(B, ny, nx, C).permute(0, 3, 1, 2).contiguous()
+        outs = []
+        for block in self.backbone.blocks:
+            x = block(x)
+            outs.append(x)
+        x = torch.cat([de(o) for de, o in zip(self.neck.deblocks, outs)], 1)
+        h = self.bbox_head
+        return h.conv_cls(x), h.conv_reg(x), h.conv_dir_cls(x)
+
     def forward(self, inputs):
         """``inputs.point``: list of [N_i, 3+C] clouds (point_pillars.py:133-138).  Returns (cls_score, bbox_pred,
         dir_cls_preds) as NCHW tensors like ``Anchor3DHead.forward``."""
+        if self.training:
+            _abi.require_gpu(self.device, "PointPillars.forward (training)")
+            return self._forward_train(inputs)
         heads, split = self.head_maps_nhwc(inputs)
         outs, off = [], 0
         for c in split:
@@ -481,8 +527,8 @@ class PointPillars(nn.Module):
         sine-difference yaw term and the two-bin direction loss over the positives, each averaged by the number of positives.
         ``results`` = the three head maps of ``forward``; ``inputs.labels`` / ``inputs.bboxes`` = per-sample ground truth
         (``ObjectDetectBatch``).  Runs on the maps' device; the validation pass of the reference's ``ObjectDetection.run_valid``
-        calls it under ``no_grad`` (object_detection.py:190-193).  Gradients flow into the head maps only as far as the forward
-        that produced them is differentiable -- the fused HIP forward is inference-only."""
+        calls it under ``no_grad`` (object_detection.py:190-193).  In ``.train()`` mode ``forward`` is differentiable
+        (``_forward_train``), so ``sum(get_loss(...).values()).backward()`` reaches every parameter."""
         from ..modules import assign_anchor_targets
         scores, bboxes, dirs = results
         head = self.bbox_head

@@ -109,6 +109,63 @@ def randla_main():
     print("randla loss", loss.item(), "logits", logits.shape, {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
 
 
+PP_LOSS_CFG = {"focal": {"gamma": 2.0, "alpha": 0.25, "loss_weight": 1.0}, "smooth_l1": {"beta": 0.11, "loss_weight": 2.0},
+               "cross_entropy": {"loss_weight": 0.2}}
+
+
+def pp_train_inputs():
+    """Two synthetic sweeps cropped to the small config's range (xyz only: in_channels 3) + ground-truth boxes."""
+    from oracle import pointpillars_ref as P
+    from oracle.gen_golden_loss import loss_inputs
+    cfg = synth_weights.POINTPILLARS_SMALL_CFG
+    clouds = [P.crop_for_cfg(synth_data.kitti_sweep(80 + i), cfg)[:, :3].copy() for i in range(2)]
+    _, boxes, labels = loss_inputs(cfg, 12, (4, 6))
+    return clouds, boxes, labels
+
+
+def pointpillars_main():
+    """tests/golden/train_pointpillars.npz: ONE training forward + backward of the REAL reference PointPillars (small two-PFN-layer
+    config, train mode: BatchNorm on batch statistics, the training-side max_voxels), the sum of the three ``get_loss`` terms
+    (object_detection.py:273-283), loss.backward(): head maps (strided), loss terms, gradients of a spread of parameters."""
+    from oracle import pointpillars_ref as P
+    pp = importlib.import_module("ml3d.torch.models.point_pillars")
+    cfg = synth_weights.POINTPILLARS_SMALL_CFG
+    model = pp.PointPillars(device="cpu", augment={}, loss=PP_LOSS_CFG, **cfg)
+    model.load_state_dict(P.make_state_dict(cfg, 21))
+    model.train()
+    clouds, boxes, labels = pp_train_inputs()
+
+    class _In:
+        point = [torch.from_numpy(c) for c in clouds]
+        bboxes = boxes
+    _In.labels = labels
+    maps = model(_In)
+    terms = model.get_loss(maps, _In)
+    loss = sum(terms.values())
+    loss.backward()
+    named = dict(model.named_parameters())
+    keep = ["voxel_encoder.pfn_layers.0.linear.weight", "voxel_encoder.pfn_layers.1.norm.weight", "backbone.blocks.0.0.weight",
+            "backbone.blocks.1.3.weight", "backbone.blocks.2.1.bias", "neck.deblocks.0.0.weight", "neck.deblocks.2.0.weight",
+            "neck.deblocks.1.1.weight", "bbox_head.conv_cls.weight", "bbox_head.conv_reg.bias", "bbox_head.conv_dir_cls.weight"]
+    out = dict(cls=maps[0].detach().numpy()[:, :, ::2, ::2], reg=maps[1].detach().numpy()[:, :, ::2, ::2],
+               dir=maps[2].detach().numpy()[:, :, ::2, ::2],
+               loss=np.array([float(terms["loss_cls"]), float(terms["loss_bbox"]), float(terms["loss_dir"])], np.float64),
+               n_points=np.asarray([len(c) for c in clouds]))
+    for k in keep:
+        out["grad:" + k] = named[k].grad.numpy()
+    out["running_mean:backbone.blocks.0.1"] = dict(model.named_buffers())["backbone.blocks.0.1.running_mean"].numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_pointpillars.npz"), **out)
+    print("pointpillars loss", out["loss"], "maps", maps[0].shape, {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
+
+
 if __name__ == "__main__":
-    main()
-    randla_main()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "kpconv"):
+        main()
+    else:
+        os.chdir(tempfile.mkdtemp())
+        ref_shim.reference_modules()
+    if which in ("all", "randlanet"):
+        randla_main()
+    if which in ("all", "pointpillars"):
+        pointpillars_main()

@@ -369,3 +369,50 @@ for B, n_in, n_out, C in ((2, 64, 16, 32), (1, 40, 40, 8)):
     assert torch.equal(out, ref) and (f.grad - gf_ref).abs().max() <= 1e-5
 print("ok")
 ''')
+
+
+def test_pointpillars_training_forward_and_gradients_match_the_reference():
+    """``PointPillars`` in ``.train()`` mode (voxelize on the library, decorations / PFN / scatter as batched torch expressions,
+    SECOND / FPN / heads on the class's own torch modules) against ONE training forward + backward of the REAL reference model
+    (tests/golden/train_pointpillars.npz, oracle/gen_golden_train.py: the sum of the three ``get_loss`` terms,
+    object_detection.py:273-283): head maps, loss terms, parameter gradients, a BatchNorm running mean."""
+    _run(r'''
+from ml3d.torch.models import PointPillars
+from oracle import pointpillars_ref as P
+from oracle.gen_golden_train import pp_train_inputs, PP_LOSS_CFG
+import synth_weights
+g = np.load(os.path.join(ROOT, "tests", "golden", "train_pointpillars.npz"))
+cfg = synth_weights.POINTPILLARS_SMALL_CFG
+m = PointPillars(device="cpu", loss=PP_LOSS_CFG, **cfg)
+m.load_state_dict(P.make_state_dict(cfg, 21))
+m.train()
+clouds, boxes, labels = pp_train_inputs()
+assert [len(c) for c in clouds] == list(g["n_points"])
+class In:
+    point = [torch.from_numpy(c) for c in clouds]
+    bboxes = boxes
+In.labels = labels
+maps = m(In)
+for name, t in zip(("cls", "reg", "dir"), maps):
+    want = g[name]
+    assert t.requires_grad and np.abs(t.detach().numpy()[:, :, ::2, ::2] - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), name
+terms = m.get_loss(maps, In)
+got = np.array([float(terms["loss_cls"]), float(terms["loss_bbox"]), float(terms["loss_dir"])])
+assert np.abs(got - g["loss"]).max() <= 1e-4 * np.abs(g["loss"]).max(), (got, g["loss"])
+sum(terms.values()).backward()
+named = dict(m.named_parameters())
+checked = 0
+for key in g.files:
+    if key.startswith("grad:"):
+        want, have = g[key], named[key[5:]].grad.numpy()
+        assert np.abs(have - want).max() <= 1e-3 * float(np.abs(want).max()), (key, float(np.abs(have - want).max()), float(np.abs(want).max()))
+        checked += 1
+assert checked == 11
+rm = dict(m.named_buffers())["backbone.blocks.0.1.running_mean"].numpy()
+assert np.abs(rm - g["running_mean:backbone.blocks.0.1"]).max() <= 1e-5
+# back to inference: the fused kernels see the weights as they are now
+m.eval()
+out = m(In)
+assert not out[0].requires_grad and out[0].shape == maps[0].shape
+print("ok")
+''')

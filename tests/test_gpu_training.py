@@ -1,4 +1,4 @@
-"""GPU: the training side of the rigid KPConv (narrow): KPFCNN in train mode -- every KPConv through
+"""GPU: the training side (narrow) of all three models.  Rigid KPConv: KPFCNN in train mode -- every KPConv through
 ``ops.KPConvFunction`` (HIP aggregation forward, hand-written HIP scatter backward), BatchNorm on batch statistics -- against ONE
 forward + backward of the REAL reference KPFCNN on PyTorch-CPU (tests/golden/train_kpconv.npz, oracle/gen_golden_train.py:
 semantic_segmentation.py:412-437's loss.backward() on the reference's module)."""
@@ -122,3 +122,45 @@ def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir
     g1 = f.grad.clone(); f.grad = None
     ref.backward(gr)
     assert (g1 - f.grad).abs().max() <= 1e-6
+
+
+def test_pointpillars_training_forward_and_gradients_match_the_reference(golden_dir):
+    """``PointPillars`` in ``.train()`` mode on the MI355X (voxelize on the HIP ops; PFN / scatter / SECOND / FPN / heads on
+    torch's autograd with this class's own modules) against the REAL reference model's training forward + backward
+    (tests/golden/train_pointpillars.npz): head maps, the three ``get_loss`` terms, parameter gradients."""
+    import synth_weights
+    from ml3d.torch.models import PointPillars
+    from oracle import pointpillars_ref as P
+    from oracle.gen_golden_train import PP_LOSS_CFG, pp_train_inputs
+    g = np.load(os.path.join(golden_dir, "train_pointpillars.npz"))
+    cfg = synth_weights.POINTPILLARS_SMALL_CFG
+    m = PointPillars(device="cuda:0", loss=PP_LOSS_CFG, **cfg)
+    m.load_state_dict(P.make_state_dict(cfg, 21))
+    m.to("cuda:0")
+    m.train()
+    clouds, boxes, labels = pp_train_inputs()
+
+    class In:
+        point = [torch.from_numpy(c).cuda() for c in clouds]
+        bboxes = [b.cuda() for b in boxes]
+    In.labels = [l.cuda() for l in labels]
+    maps = m(In)
+    for name, t in zip(("cls", "reg", "dir"), maps):
+        want = g[name]
+        assert t.requires_grad and np.abs(t.detach().cpu().numpy()[:, :, ::2, ::2] - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), name
+    terms = m.get_loss(maps, In)
+    got = np.array([float(terms["loss_cls"]), float(terms["loss_bbox"]), float(terms["loss_dir"])])
+    assert np.abs(got - g["loss"]).max() <= 1e-4 * np.abs(g["loss"]).max(), (got, g["loss"])
+    sum(terms.values()).backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            want, have = g[key], named[key[5:]].grad.detach().cpu().numpy()
+            assert np.abs(have - want).max() <= 1e-3 * float(np.abs(want).max()), (key, float(np.abs(have - want).max()))
+            checked += 1
+    assert checked == 11
+    m.eval()
+    with torch.no_grad():
+        out = m(In)
+    assert out[0].shape == maps[0].shape and not out[0].requires_grad
