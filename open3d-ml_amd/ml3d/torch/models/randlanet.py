@@ -264,19 +264,48 @@ class RandLANet(nn.Module):
                 feat -= bias
                 feat /= scale
 
+    def _training_augment(self, pc):
+        """The augmentations the in-scope YAMLs add for the TRAINING split (randlanet.py:198-203 ->
+        ml3d/datasets/augment/augmentation.py:68-146, 375-382), in the reference's order and with its draws from the model's
+        generator (``default_rng(generator)`` hands the SAME generator back, so the pipeline's seed decides them): a yaw
+        rotation by ``2 pi u``, an isotropic scale ``u (max_s - min_s) + min_s``, Gaussian jitter ``noise_std N(0, 1)`` --
+        float32 like the reference's.  Anything else the reference's augmenter knows (dropout, flips, colour jitter) is refused."""
+        aug = dict(self.cfg.get('augment', {}) or {})
+        aug.pop('recenter', None)
+        aug.pop('normalize', None)
+        unknown = [k for k in aug if k not in ('rotate', 'scale', 'noise')]
+        if unknown:
+            raise NotImplementedError("RandLANet (MI355X build): training augmentation %s is not implemented" % unknown)
+        rng = self.rng
+        if 'rotate' in aug:
+            method = (aug['rotate'] or {}).get('method', 'vertical')
+            if method != 'vertical':
+                raise NotImplementedError("RandLANet (MI355X build): rotate.method %r (only 'vertical')" % method)
+            theta = rng.random() * 2 * np.pi
+            c, s_ = np.cos(theta), np.sin(theta)
+            pc = np.matmul(pc, np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=np.float32))
+        if 'scale' in aug:
+            c = aug['scale'] or {}
+            lo, hi = c.get('min_s', 1.), c.get('max_s', 1.)
+            factor = rng.random(pc.shape[1]) * (hi - lo) + lo if c.get('scale_anisotropic', False) else rng.random() * (hi - lo) + lo
+            pc = pc * factor
+        if 'noise' in aug:
+            std = (aug['noise'] or {}).get('noise_std', 0.001)
+            pc = pc + (rng.standard_normal((pc.shape[0], pc.shape[1])) * std).astype(np.float32)
+        return pc
+
     def transform(self, data, attr, min_possibility_idx=None):
         """Patch crop by the pipeline's point sampler, recentring, feature assembly and the neighbour pyramid
         (randlanet.py:156-239).  The 8 ``knn_search`` calls of the reference run as ONE GPU pyramid call; the index lists
         come back as int32 DEVICE tensors (``forward`` consumes them in place; ``.cpu().long()`` gives the reference's
         arrays), everything else as numpy like the reference."""
         cfg = self.cfg
-        if attr['split'] in ['training', 'train']:
-            raise NotImplementedError("RandLANet (MI355X build): inference transform only (SURVEY.md §8 f4)")
+        training = attr['split'] in ['training', 'train']
         sampler = getattr(self, 'trans_point_sampler', None)
         if sampler is None:
             raise RuntimeError("RandLANet.transform: set model.trans_point_sampler (the pipeline takes it from the dataset "
                                "split's sampler, semantic_segmentation.py:156) or use inference_begin()")
-        if self._device_loop_serves(data, sampler):
+        if not training and self._device_loop_serves(data, sampler):
             return self._transform_device()
         pc = data['point'].copy()
         label = data['label'].copy()
@@ -288,6 +317,8 @@ class RandLANet(nn.Module):
         if feat is not None:
             feat = feat[selected_idxs]
         self._validation_augment(pc, feat)
+        if training:
+            pc = self._training_augment(pc)
         feat = pc.copy() if feat is None else np.concatenate([pc, feat], axis=1)
         if cfg.in_channels != feat.shape[1]:
             raise RuntimeError("Wrong feature dimension, please update in_channels(3 + feature_dimension) in config")

@@ -70,6 +70,15 @@ def main():
         out["sem_" + tag + "_labels"] = vl.numpy()
         out["sem_" + tag + "_scores_sum"] = np.float64(vs.double().sum())
         out["sem_" + tag + "_loss"] = np.float64(torch.nn.CrossEntropyLoss(weight=w)(vs, vl))
+    # the training-split augmentations of the RandLA-Net YAMLs (rotate / scale / noise) through the reference's own augmenter,
+    # drawing from a seeded generator the way RandLANet.transform hands its model generator over (randlanet.py:198-203)
+    aug = importlib.import_module("ml3d.datasets.augment.augmentation")
+    pc = (np.random.default_rng(3).random((700, 3)).astype(np.float32) - 0.5) * np.float32([20, 20, 4])
+    pc[:, :2] -= pc[:, :2].mean(0)
+    train_cfg = {"rotate": {"method": "vertical"}, "scale": {"min_s": 0.9, "max_s": 1.1}, "noise": {"noise_std": 0.001}}
+    a = aug.SemsegAugmentation(train_cfg)
+    apc, _, _ = a.augment(pc.copy(), None, np.zeros(700, np.int32), train_cfg, seed=np.random.default_rng(41))
+    out.update(aug_in=pc, aug_out=apc, aug_seed=41)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "losses.npz"), **out)
     print("written")
 

@@ -101,6 +101,7 @@ def randla_forward(cfg, sd, points, feats, nbr, itp, order=None):
     out = np.zeros((B, N, cfg["num_classes"]), np.float32)
     points = np.ascontiguousarray(points, np.float32)
     feats = np.ascontiguousarray(feats, np.float32)
+    assert feats.shape == (B, N, cfg["in_channels"]), (feats.shape, cfg["in_channels"])      # (the library reads in_channels floats per row)
     if order is not None:
         order = [np.ascontiguousarray(o, np.int32) for o in order]
         rc = L.ml3d_randla_forward_ordered(C.byref(desc), params.ctypes.data, feats.ctypes.data, points.ctypes.data,

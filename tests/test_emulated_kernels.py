@@ -116,12 +116,14 @@ import test_emulated_kernels as T
 ci, B, N, seed_pts, seed_w = (int(v) for v in sys.argv[1:6])
 cfg = T.CFGS[ci]
 pts = synth_data.uniform_cloud(seed_pts, B * N).reshape(B, N, 3)
+feats = pts.copy() if cfg["in_channels"] == 3 else np.concatenate(
+    [pts, np.random.default_rng(seed_pts).random((B, N, cfg["in_channels"] - 3), dtype=np.float32)], 2)
 sd = R.make_state_dict(cfg, seed_w)
-inp = R.build_inputs(pts, pts.copy(), cfg, oops.knn_search)
+inp = R.build_inputs(pts, feats, cfg, oops.knn_search)
 ref = R.forward(sd, cfg, inp).numpy()
 nbr = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["neighbor_indices"]]
 itp = [np.ascontiguousarray(x.numpy().astype(np.int32)) for x in inp["interp_idx"]]
-rc, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
+rc, out = emu.randla_forward(cfg, sd, pts, feats, nbr, itp)
 assert rc == 0, rc
 err = float(np.abs(out - ref).max())
 assert err <= 1e-4, err
@@ -188,8 +190,10 @@ def test_randla_forward_with_a_tile_order_is_bit_identical(ci, B, N, kind):
             o = o[:, ::-1] if kind == "reversed" else np.stack([rng.permutation(row) for row in o])
             order.append(np.ascontiguousarray(o.reshape(-1)))
             n //= r
-    rc0, base = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp)
-    rc1, out = emu.randla_forward(cfg, sd, pts, pts.copy(), nbr, itp, order=order)
+    feats = pts.copy() if cfg["in_channels"] == 3 else np.concatenate(
+        [pts, np.random.default_rng(2).random((B, N, cfg["in_channels"] - 3), dtype=np.float32)], 2)
+    rc0, base = emu.randla_forward(cfg, sd, pts, feats, nbr, itp)
+    rc1, out = emu.randla_forward(cfg, sd, pts, feats, nbr, itp, order=order)
     assert rc0 == 0 and rc1 == 0
     assert np.array_equal(out, base)
 

@@ -88,3 +88,20 @@ def test_segmentation_models_get_loss_and_optimizers():
     d = KPFCNN(**dict(synth_weights.KPCONV_DEFORM_SMALL_CFG, device="cpu"))
     with pytest.raises(NotImplementedError):
         d.get_loss(loss, torch.randn((10, 8)), {"data": types.SimpleNamespace(labels=torch.zeros(10, dtype=torch.long))}, "cpu")
+
+
+def test_randlanet_training_split_augmentation_is_the_reference_augmenters(golden):
+    """RandLANet.transform for the TRAINING split adds the YAMLs' rotate / scale / noise (randlanet.py:198-203): same order, same
+    draws from the model's generator, same float32 arithmetic as the reference's SemsegAugmentation (golden from the real class,
+    oracle/gen_golden_loss.py) -- bit for bit; augmentations the in-scope YAMLs do not use are refused."""
+    from ml3d.torch.models import RandLANet
+    aug = {"recenter": {"dim": [0, 1]}, "normalize": {"feat": {"method": "linear", "bias": 0, "scale": 255}},
+           "rotate": {"method": "vertical"}, "scale": {"min_s": 0.9, "max_s": 1.1}, "noise": {"noise_std": 0.001}}
+    m = RandLANet(**dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG, num_points=1024, device="cpu", augment=aug))
+    m.rng = np.random.default_rng(int(golden["aug_seed"]))
+    out = m._training_augment(golden["aug_in"].copy())
+    assert out.dtype == np.float32 and np.array_equal(out, golden["aug_out"])
+    m2 = RandLANet(**dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG, num_points=1024, device="cpu",
+                          augment={"RandomDropout": {"dropout_ratio": 0.2}}))
+    with pytest.raises(NotImplementedError):
+        m2._training_augment(golden["aug_in"].copy())

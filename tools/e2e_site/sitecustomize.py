@@ -3,7 +3,7 @@ reference's unchanged ``scripts/run_pipeline.py`` starts, without touching that 
 
   * third-party packages the reference imports and this image lacks: ``addict`` (tests/stubs) and ``tensorboard``
     (``torch.utils.tensorboard`` is replaced by an inert SummaryWriter when the real one cannot be imported);
-  * ML3D_E2E_SEED: python's ``random``, ``numpy.random`` and torch seeded at the ENTRY of the pipeline's ``run_test``
+  * ML3D_E2E_SEED: python's ``random``, ``numpy.random`` and torch seeded at the ENTRY of the pipeline's ``run_test`` / ``run_train``
     (run_pipeline.py seeds only its own Generator; the samplers and KPFCNN's test-time augmentation draw from the global
     streams, and the reference's KPFCNN constructor consumes numpy draws for its kernel-point optimisation that the native
     constructor does not -- the two sides must draw the same numbers DURING the test to be comparable);
@@ -61,14 +61,32 @@ if os.environ.get("ML3D_E2E_SIDE"):
         from ml3d.torch import pipelines as _pl
         seed = int(os.environ["ML3D_E2E_SEED"])
         for cls in (_pl.SemanticSegmentation, _pl.ObjectDetection):
-            orig = cls.run_test
+            for entry in ("run_test", "run_train"):
+                orig = getattr(cls, entry)
 
-            def run_test(self, _orig=orig):
-                random.seed(seed)
-                _np.random.seed(seed)
-                _torch.manual_seed(seed)
-                return _orig(self)
-            cls.run_test = functools.wraps(orig)(run_test)
+                def seeded(self, _orig=orig, _entry=entry):
+                    random.seed(seed)
+                    _np.random.seed(seed)
+                    _torch.manual_seed(seed)
+                    if _entry == "run_train":
+                        # (harness output only: the loss of EVERY step -- the pipeline logs the epoch mean; Adam turns last-bit
+                        #  gradient noise of near-zero gradients into +-lr steps, so the first step is the tight comparison)
+                        # Dropout masks are drawn per tensor ELEMENT: the reference keeps fc1's activations channel-major
+                        # [B, C, N, 1], the native training forward point-major [B, N, C] (and on a GPU the stream differs
+                        # anyway), so the same seed gives the two sides different masks.  Off on BOTH sides for this run.
+                        for mod in self.model.modules():
+                            if isinstance(mod, _torch.nn.Dropout):
+                                mod.p = 0.0
+                        gl, n = self.model.get_loss, [0]
+
+                        def get_loss(*a, **k):
+                            out = gl(*a, **k)
+                            print("e2e-step-loss %d %s %.6f" % (n[0], "train" if self.model.training else "valid", float(out[0])), flush=True)
+                            n[0] += 1
+                            return out
+                        self.model.get_loss = get_loss
+                    return _orig(self)
+                setattr(cls, entry, functools.wraps(orig)(seeded))
     if os.environ["ML3D_E2E_SIDE"] == "reference":
         from oracle import ref_shim
         ref_shim.install()

@@ -83,8 +83,15 @@ def run(args):
     os.makedirs(out, exist_ok=True)
     ds = {"semantic3d": os.path.join(work, "Semantic3D"), "kitti": os.path.join(work, "KITTI")}
     fams = list(FAMILIES) if args.family == "all" else [args.family]
-    if any(FAMILIES[f][1] == "semantic3d" for f in fams) and not glob.glob(os.path.join(ds["semantic3d"], "*.txt")):
-        synth_datasets.write_semantic3d(ds["semantic3d"], half=2.5 if args.small else 9.0, density=0.1 if args.small else 0.35)
+    train = args.split == "train"
+    if train:
+        fams = [f for f in fams if f != "pointpillars"]     # (pointpillars_kitti.yml's ObjectSample augmentation needs a ground-truth database)
+    if any(FAMILIES[f][1] == "semantic3d" for f in fams) and (not glob.glob(os.path.join(ds["semantic3d"], "*.txt")) or
+                                                              (train and not glob.glob(os.path.join(ds["semantic3d"], "*.labels")))):
+        # --split train: four labelled clouds, two of them under the names the YAMLs list in `val_files` (semantic3d.py:92-99)
+        synth_datasets.write_semantic3d(ds["semantic3d"], half=2.5 if args.small else 9.0, density=0.1 if args.small else 0.35,
+                                        n_train=4 if train else 0,
+                                        val_names=("bildstein_station1_xyz_intensity_rgb", "domfountain_station1_xyz_intensity_rgb") if train else ())
     if "pointpillars" in fams and not os.path.isdir(ds["kitti"]):
         synth_datasets.write_kitti(ds["kitti"], n_test=1 if args.small else 2, n_train=1 if args.small else 2)
     rc_all = 0
@@ -103,7 +110,7 @@ def run(args):
         shutil.rmtree(run_dir, ignore_errors=True)
         os.makedirs(run_dir)
         dev = "cuda" if (args.side == "native" and not args.emu) else "cpu"
-        argv = ["torch", "-c", cfg, "--dataset_path", ds[kind], "--ckpt_path", ckpt, "--split", "test", "--device", dev,
+        argv = ["torch", "-c", cfg, "--dataset_path", ds[kind], "--ckpt_path", ckpt, "--split", args.split, "--device", dev,
                 "--main_log_dir", os.path.join(run_dir, "logs"),
                 "--dataset.use_cache", "False", "--dataset.test_result_folder", res_dir,
                 "--dataset.cache_dir", os.path.join(run_dir, "cache")]
@@ -115,6 +122,12 @@ def run(args):
         if fam == "pointpillars":
             # every training sweep is a validation sweep (kitti.py:64-69), loaders in-process
             argv += ["--dataset.val_split", "0", "--pipeline.num_workers", "0", "--pipeline.pin_memory", "False"]
+        if train:
+            # ONE epoch (range(0, max_epoch + 1), semantic_segmentation.py:407) of a few optimisation steps + a validation pass,
+            # loaders in-process (the transforms call the GPU ops), a checkpoint at the end
+            argv += ["--pipeline.max_epoch", "0", "--pipeline.batch_size", "2", "--pipeline.val_batch_size", "2",
+                     "--pipeline.num_workers", "0", "--pipeline.pin_memory", "False", "--pipeline.save_ckpt_freq", "1",
+                     "--dataset.steps_per_epoch_train", str(args.train_steps * 2), "--dataset.steps_per_epoch_valid", "2"]
         env = dict(os.environ, ML3D_E2E_SIDE=args.side, ML3D_E2E_SEED="7", PYTHONHASHSEED="0", PYTHONWARNINGS="ignore", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "16"))
         pp = [os.path.join(ROOT, "tools", "e2e_site")]
         if args.side == "native":
@@ -136,6 +149,14 @@ def run(args):
         for ln in (keep[-40:] if p.returncode == 0 else lines[-60:]):
             print("   | " + ln[:220])
         os.makedirs(res_dir, exist_ok=True)
+        if train:
+            # what a training run leaves behind: its epoch summary (save_logs, semantic_segmentation.py:520-560) and the checkpoint
+            with open(os.path.join(res_dir, "train.log"), "w") as f:
+                f.write("\n".join([ln[ln.index("e2e-step-loss"):].strip() for ln in p.stdout.replace("\r", "\n").splitlines() if "e2e-step-loss" in ln] +
+                                  [ln.split(" - ", 2)[-1] for ln in lines if " semantic_segmentation - " in ln and
+                                   any(k in ln for k in ("Loss train", "Mean acc", "Mean IoU", "EPOCH"))]) + "\n")
+            for ck in glob.glob(os.path.join(run_dir, "logs", "**", "ckpt_*.pth"), recursive=True):
+                shutil.copy(ck, os.path.join(res_dir, os.path.basename(ck)))
         if fam == "pointpillars":
             # (the reference's ObjectDetectBatch never fills ``attr`` (concat_batcher.py:503-519), so ObjectDetection.run_test's
             #  save_test_result(results, data.attr) writes nothing on either side: what a detection run leaves behind is its log)
@@ -177,7 +198,32 @@ def compare(a_dir, b_dir):
             ok = False
             continue
         for x, y in zip(fa, fb):
-            if x.endswith(".log"):
+            if x.endswith("train.log"):
+                import re
+                ta, tb = open(x).read(), open(y).read()
+                sa = [float(l.split()[-1]) for l in ta.splitlines() if l.startswith("e2e-step-loss")]
+                sb = [float(l.split()[-1]) for l in tb.splitlines() if l.startswith("e2e-step-loss")]
+                ea = [float(v) for l in ta.splitlines() if not l.startswith("e2e") for v in re.findall(r"[-+]?\d+\.\d+", l)]
+                eb = [float(v) for l in tb.splitlines() if not l.startswith("e2e") for v in re.findall(r"[-+]?\d+\.\d+", l)]
+                same = len(sa) == len(sb) and len(sa) > 0 and len(ea) == len(eb)
+                d0 = abs(sa[0] - sb[0]) if same else float("nan")
+                dmax = max(abs(p - q) / max(1.0, abs(q)) for p, q in zip(sa, sb)) if same else float("nan")
+                de = max([abs(p - q) for p, q in zip(ea, eb)] or [float("nan")]) if same else float("nan")
+                print("[compare] %s train.log: %d step losses -- first step |d| %.2g (native %.6f, reference %.6f), worst later step "
+                      "%.2g relative (after Adam updates); epoch summary (loss / acc / IoU, 3 decimals) max |d| %.3g" % (
+                          fam, len(sa), d0, sa[0] if sa else 0, sb[0] if sb else 0, dmax, de))
+                print("\n".join("      native    | " + l for l in ta.splitlines() if not l.startswith("e2e")))
+                print("\n".join("      reference | " + l for l in tb.splitlines() if not l.startswith("e2e")))
+                ok &= same and d0 <= 2e-4 and dmax <= 2e-2 and de <= 3e-2
+            elif x.endswith(".pth"):
+                import torch
+                sa, sb = torch.load(x, map_location="cpu")["model_state_dict"], torch.load(y, map_location="cpu")["model_state_dict"]
+                keys = [k for k in sb if sb[k].dtype.is_floating_point]
+                rel = sorted(float((sa[k].float() - sb[k].float()).abs().max()) / max(1e-3, float(sb[k].float().abs().max())) for k in keys)
+                print("[compare] %s %s: %d tensors after the optimisation steps, relative difference median %.2g, worst %.2g" % (
+                    fam, os.path.basename(x), len(sb), rel[len(rel) // 2], rel[-1]))
+                ok &= set(sa) == set(sb)
+            elif x.endswith(".log"):
                 ta, tb = open(x).read(), open(y).read()
                 print("[compare] %s %s: %d lines, identical %s\n%s" % (fam, os.path.basename(x), ta.count("\n"), ta == tb,
                                                                        "\n".join("      " + l for l in ta.splitlines()[:3])))
@@ -207,6 +253,8 @@ def main():
     ap.add_argument("--work", default="/tmp/ml3d_e2e")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--split", default="test", choices=["test", "train"])
+    ap.add_argument("--train-steps", type=int, default=3, help="--split train: optimisation steps (batches of 2) in the one epoch")
     ap.add_argument("--sampler-index", default="sklearn", choices=["sklearn", "gpu"])
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--compare", nargs=2, metavar=("NATIVE_OUT", "REFERENCE_OUT"))

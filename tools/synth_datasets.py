@@ -14,8 +14,9 @@ import numpy as np
 import synth_data
 
 
-def write_semantic3d(root, n_test=1, n_train=0, half=9.0, density=0.35, seed=40):
-    """-> list of written cloud names.  A ``2 half`` m urban tile per cloud (~120 k points at the defaults)."""
+def write_semantic3d(root, n_test=1, n_train=0, half=9.0, density=0.35, seed=40, val_names=()):
+    """-> list of written cloud names.  A ``2 half`` m urban tile per cloud (~120 k points at the defaults).  ``val_names``: the
+    LAST labelled clouds get these file names (entries of the YAML's ``val_files``: the validation split, semantic3d.py:92-99)."""
     os.makedirs(root, exist_ok=True)
     names = []
     for i in range(n_test + n_train):
@@ -23,6 +24,9 @@ def write_semantic3d(root, n_test=1, n_train=0, half=9.0, density=0.35, seed=40)
         pts, rgb = d["point"], d["feat"]
         inten = (np.abs(pts[:, 2]) * 40.0 % 255.0).astype(np.float32)
         name = "synth%02d_xyz_intensity_rgb" % i
+        j = i - (n_test + n_train - len(val_names))
+        if 0 <= j < len(val_names) and i >= n_test:
+            name = val_names[j]
         rows = np.concatenate([pts, inten[:, None], np.round(rgb)], 1)
         np.savetxt(os.path.join(root, name + ".txt"), rows, fmt="%.3f %.3f %.3f %d %d %d %d")
         if i >= n_test:
