@@ -579,8 +579,8 @@ int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, 
     if (B <= 0) return 0;
     if (target_occ <= 0.f) target_occ = 4.0f;
     int sb = (B + 63) / 64;
-    (void)hipMemsetAsync(ws.bitmap, 0, sizeof(unsigned) * GRID_LEVELS * (size_t)ws.bitmap_words, stream);
-    (void)hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    // (bitmap and cell table are neighbours in the workspace, grid_ws_carve: one fill instead of two)
+    (void)hipMemsetAsync(ws.bitmap, 0, (size_t)((char*)(ws.cells + ws.total_cells + 2) - (char*)ws.bitmap), stream);
     hipLaunchKernelGGL(grid_bbox_init, dim3(sb), dim3(64), 0, stream, ws.bbox, ws.occ, B);
     ML3D_LAUNCH_CHECK();
     if (n > 0) {

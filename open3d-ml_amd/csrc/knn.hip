@@ -677,23 +677,32 @@ patch_bump(const int32_t* __restrict__ sel, const float* __restrict__ d2, const 
     possibility[sel[j]] += (double)__fmul_rn(t, t);                 // float64 += float32 square
 }
 
-// one workgroup: 5 120 rows per stage transposed into LDS (column-major) by all threads, then threads 0..2 add their column IN
-// ROW ORDER: the chain is the 45 056 dependent additions, so everything else is kept off it -- 16-byte LDS reads, eight of
-// them (32 values) in flight under the 32 adds of the previous block, two register blocks in ping-pong (no copies)
+// one workgroup, two LDS stages of 2 560 rows (column-major): waves 1..3 transpose stage i + 1 in while threads 0..2 of wave 0 add
+// their column of stage i IN ROW ORDER -- the chain is the 45 056 dependent additions, so everything else is kept off it: the
+// next stage's global reads and LDS writes run beside it, 16-byte LDS reads, eight of them (32 values) in flight under the 32
+// adds of the previous block, two register blocks in ping-pong (no copies)
 __global__ void __launch_bounds__(256)
 patch_mean_seq(const float* __restrict__ pts, int64_t k, float* __restrict__ mean_out) {
-    constexpr int ROWS = 5120;            // 60 KB of LDS per stage
-    __shared__ __attribute__((aligned(16))) float buf[3 * ROWS];
-    float s = 0.f;
-    for (int64_t base = 0; base < k; base += ROWS) {
+    constexpr int ROWS = 2560;            // 30 KB of LDS per stage
+    __shared__ __attribute__((aligned(16))) float buf[2][3 * ROWS];
+    auto fill = [&](int64_t base, float* dst, int first, int step) {
+        if (base >= k) return;
         const int rows = (int)min<int64_t>(ROWS, k - base);
-        for (int e = threadIdx.x; e < rows * 3; e += 256) {
+        for (int e = first; e < rows * 3; e += step) {
             const int r = e / 3, c = e - 3 * r;
-            buf[c * ROWS + r] = pts[3 * base + e];
+            dst[c * ROWS + r] = pts[3 * base + e];
         }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            const float* col = buf + threadIdx.x * ROWS;
+    };
+    fill(0, buf[0], threadIdx.x, 256);
+    __syncthreads();
+    float s = 0.f;
+    int stage = 0;
+    for (int64_t base = 0; base < k; base += ROWS, stage ^= 1) {
+        const int rows = (int)min<int64_t>(ROWS, k - base);
+        if (threadIdx.x >= 64) {
+            fill(base + ROWS, buf[stage ^ 1], threadIdx.x - 64, 192);
+        } else if (threadIdx.x < 3) {
+            const float* col = buf[stage] + threadIdx.x * ROWS;
             const float4* col4 = reinterpret_cast<const float4*>(col);
             int r = 0;
             if (rows >= 64) {

@@ -302,3 +302,23 @@ def test_pyramid_search_is_exact_on_degenerate_clouds():
             assert np.array_equal(nbr[l][i], oops.knn_search(lv[i], lv[i], 16)), (l, i)
             assert np.array_equal(itp[l][i], oops.knn_search(lv[i][:n_sub], lv[i], 1)), (l, i)
         lv = lv[:, :n_sub]
+
+
+@pytest.mark.parametrize("k", [1, 63, 64, 100, 2560, 2561, 5200, 7777])
+def test_patch_recenter_means_are_numpys_sequential_float32_sums(k):
+    """ml3d_patch_recenter subtracts the column means numpy computes for a float32 [k, 3] array -- a row-by-row sequential sum
+    (randlanet.py:185-191 through Augmentation.recenter) -- bit for bit: stage boundaries of the two-stage LDS pipeline
+    (2 560 rows), the 64-row unrolled body and its tails."""
+    L = emu.lib()
+    rng = np.random.default_rng(k)
+    pts = ((rng.random((k, 3)) - 0.3) * np.float32([60, 40, 5])).astype(np.float32)
+    extra = rng.random((k, 2)).astype(np.float32) * 255
+    out = pts.copy()
+    feats = np.zeros((k, 5), np.float32)
+    scratch = np.zeros(64, np.uint8)
+    rc = L.ml3d_patch_recenter(out.ctypes.data, k, 3, extra.ctypes.data, 2, 0.0, 255.0, feats.ctypes.data, scratch.ctypes.data, 64, None)
+    assert rc == 0
+    ref = pts.copy()
+    ref[:, [0, 1]] = ref[:, [0, 1]] - ref.mean(0)[[0, 1]]
+    assert np.array_equal(out, ref)
+    assert np.array_equal(feats[:, :3], ref) and np.array_equal(feats[:, 3:], (extra - np.float32(0.0)) / np.float32(255.0))
