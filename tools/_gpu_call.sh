@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp
-timeout 1500 bash tools/gpu_e2e_train.sh 2>&1 | grep -v "it/s\]\|s/it\]" | tail -45 | cut -c1-260
+timeout 600 python -m pytest tests/test_gpu_training.py -x -q -k pointpillars 2>&1 | tail -40 | cut -c1-250
