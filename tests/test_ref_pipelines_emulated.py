@@ -51,3 +51,24 @@ def test_reference_pipelines_drive_the_native_models_and_match_the_reference_cpu
     assert np.array_equal(a["labels"], b["labels"])
     assert (np.abs(a["boxes"] - b["boxes"]) / np.maximum(1.0, np.abs(b["boxes"]))).max() <= 1e-4
     assert np.abs(a["scores"] - b["scores"]).max() <= 1e-4
+
+
+def test_reference_run_pipeline_script_trains_the_native_models_like_the_reference(tmp_path):
+    """The reference's UNCHANGED ``scripts/run_pipeline.py torch -c <yaml> --split train`` (SemanticSegmentation.run_train,
+    semantic_segmentation.py:317-470: dataloader + transform + batcher, get_optimizer, train-mode forward, get_loss, backward,
+    optimizer.step, validation, checkpoint) on the native RandLA-Net and KPFCNN -- shrunken YAML sizes, the library emulated --
+    against the reference side: the first step's loss to 2e-4, later steps and the epoch summary within the drift of a few
+    optimisation steps (tools/run_pipeline_e2e.py --compare; the MI355X run at the YAML sizes is
+    profiles/r04_run_pipeline_train_e2e.log)."""
+    work, out = str(tmp_path / "work"), str(tmp_path / "out")
+    emu.lib()
+    tool = os.path.join(ROOT, "tools", "run_pipeline_e2e.py")
+    env = dict(os.environ)
+    env.pop("OPEN3D_ML_ROOT", None)
+    for side in (["--side", "reference"], ["--side", "native", "--emu"]):
+        r = subprocess.run([sys.executable, tool, "--family", "all", "--split", "train", "--small", "--ref", REF, "--work", work,
+                            "--out", out] + side, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, tool, "--compare", out, out], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "[compare] OK" in r.stdout, r.stdout[-4000:]
+    assert "randlanet train.log: 4 step losses" in r.stdout and "kpconv train.log: 4 step losses" in r.stdout
