@@ -396,10 +396,13 @@ class KPFCNN(nn.Module):
         ``ops.KPConvFunction`` -- HIP aggregation forward, hand-written HIP scatter backward, GEMMs for the weight products --
         around it the reference's own module arithmetic on torch's autograd: BatchNorm1d on the batch statistics (NOT folded:
         the inference kernels fold the running statistics, which training must update), LeakyReLU, bias-free Linears, the
-        max / closest pools as indexed gathers.  Deformable blocks are refused (their offset regulariser is out of scope)."""
+        max / closest pools as indexed gathers.  DEFORMABLE blocks (kpconv.py:1011-1159): the inner rigid convolution that
+        produces the offsets is ``ops.KPConvFunction`` too; the deformed convolution itself -- whose influences depend on the
+        trained offsets -- is written out in torch ([Nq, H, K] squared distances, linear influences, one matmul per block) so
+        that autograd carries the gradient into the offsets; the block keeps ``min_d2`` / ``deformed_KP`` for the regulariser
+        of ``get_loss``.  The reference's pruning of the neighbour rows (:1071-1103) is skipped: it only drops neighbours whose
+        linear influence -- and its gradient -- is zero for every kernel point."""
         import torch.nn.functional as F
-        if any('deformable' in b for b in self.cfg.architecture):
-            raise NotImplementedError("KPFCNN (MI355X build): training of deformable blocks is out of scope (SURVEY.md §8 f4)")
         dev = self.device
         _abi.require_gpu(dev, "KPFCNN.forward (training)")
         lr = self.cfg.get('l_relu', 0.1)
@@ -428,8 +431,13 @@ class KPFCNN(nn.Module):
             q_pts = pts[L + 1] if strided else pts[L]
             inds = pools[L] if strided else nbrs[L]
             conv = blk.KPConv
-            kp_apply = lambda xin: ops.KPConvFunction.apply(xin, conv.weights, q_pts, pts[L], inds, conv.kernel_points,
-                                                            conv.KP_extent, infl)
+            if conv.deformable:
+                if self.cfg.KP_influence != 'linear' or self.cfg.get('aggregation_mode', 'sum') != 'sum':
+                    raise NotImplementedError("KPFCNN (MI355X build): deformable training with KP_influence 'linear' / sum only")
+                kp_apply = lambda xin, conv=conv, q_pts=q_pts, sp=pts[L], inds=inds: self._deformable_train(conv, q_pts, sp, inds, xin, infl)
+            else:
+                kp_apply = lambda xin, conv=conv, q_pts=q_pts, sp=pts[L], inds=inds: ops.KPConvFunction.apply(
+                    xin, conv.weights, q_pts, sp, inds, conv.kernel_points, conv.KP_extent, infl)
             if isinstance(blk, SimpleBlock):
                 x = F.leaky_relu(bn(blk.batch_norm, kp_apply(x)), lr)
                 continue
@@ -448,6 +456,49 @@ class KPFCNN(nn.Module):
             else:
                 x = unary(blk, x)
         return unary(self.head_softmax, unary(self.head_mlp, x))
+
+    @staticmethod
+    def _deformable_train(conv, q_pts, s_pts, inds, x, infl):
+        """One deformable KPConv in training mode (kpconv.py:1011-1066, 1105-1159, linear influence, sum aggregation)."""
+        K = conv.K
+        oc = conv.offset_conv
+        off = ops.KPConvFunction.apply(x, oc.weights, q_pts, s_pts, inds, oc.kernel_points, oc.KP_extent, infl) + conv.offset_bias
+        if conv.modulated:
+            unscaled, mod = off[:, :3 * K].reshape(-1, K, 3), 2 * torch.sigmoid(off[:, 3 * K:])
+        else:
+            unscaled, mod = off.reshape(-1, K, 3), None
+        conv.deformed_KP = unscaled * conv.KP_extent + conv.kernel_points                 # [Nq, K, 3]
+        far = torch.cat([s_pts, torch.zeros_like(s_pts[:1]) + 1e6], 0)                    # the shadow neighbour's position
+        nb = far[inds.long()] - q_pts.unsqueeze(1)                                        # [Nq, H, 3]
+        sq = ((nb.unsqueeze(2) - conv.deformed_KP.unsqueeze(1)) ** 2).sum(3)              # [Nq, H, K]
+        conv.min_d2 = sq.min(1)[0]
+        w = torch.clamp(1 - torch.sqrt(sq) / conv.KP_extent, min=0.0).transpose(1, 2)     # [Nq, K, H]
+        nx = torch.cat([x, torch.zeros_like(x[:1])], 0)[inds.long()]                      # [Nq, H, Cin]
+        wf = torch.matmul(w, nx)                                                          # [Nq, K, Cin]
+        if mod is not None:
+            wf = wf * mod.unsqueeze(2)
+        return torch.matmul(wf.permute(1, 0, 2), conv.weights).sum(0)
+
+    def _offset_regulariser(self):
+        """``p2p_fitting_regularizer`` (kpconv.py:2167-2206) over the deformable blocks of the last training forward: every
+        deformed kernel point should sit on an input point (L1 of the normalised squared distance to the closest neighbour,
+        weight 2) and keep its distance from the other kernel points (squared hinge at ``repulse_extent``, the others detached)."""
+        cfg = self.cfg
+        l1 = torch.nn.L1Loss()
+        fitting, repulsive, K = 0, 0, int(cfg.num_kernel_points)
+        for m in self.modules():
+            if isinstance(m, KPConv) and m.deformable:
+                if getattr(m, 'min_d2', None) is None:
+                    raise RuntimeError("KPFCNN.get_loss: no training forward has run through the deformable blocks")
+                d2 = m.min_d2 / (m.KP_extent ** 2)
+                fitting = fitting + l1(d2, torch.zeros_like(d2))
+                locs = m.deformed_KP / m.KP_extent
+                for i in range(K):
+                    others = torch.cat([locs[:, :i], locs[:, i + 1:]], 1).detach()
+                    dist = torch.sqrt(((others - locs[:, i:i + 1]) ** 2).sum(2))
+                    rep = (torch.clamp_max(dist - cfg.get('repulse_extent', 1.2), 0.0) ** 2).sum(1)
+                    repulsive = repulsive + l1(rep, torch.zeros_like(rep)) / K
+        return cfg.get('deform_fitting_power', 1.0) * (2 * fitting + repulsive)
 
     # ---- the reference's data path around forward (kpconv.py:353-633), on the GPU ops ---------------------------------
     def preprocess(self, data, attr):
@@ -622,17 +673,21 @@ class KPFCNN(nn.Module):
         return optimizer, torch.optim.lr_scheduler.ExponentialLR(optimizer, cfg_pipeline.scheduler_gamma)
 
     def get_loss(self, Loss, results, inputs, device):
-        """kpconv.py:315-351 for rigid architectures: class-weighted cross entropy over the non-ignored points; the
-        regulariser of the deformable offsets (kpconv.py:2167-2206) needs the per-layer ``min_d2`` / deformed kernel points of
-        a training forward, which the fused inference kernels do not materialise -> refused for deformable configs."""
+        """kpconv.py:315-351: class-weighted cross entropy over the non-ignored points + the point-to-point regulariser of the
+        deformable offsets (kpconv.py:2167-2206; zero for rigid architectures), which reads the ``min_d2`` / ``deformed_KP``
+        the TRAINING forward left on the deformable blocks (the fused inference kernels do not materialise them: after an
+        eval-mode forward of a deformable model the regulariser is the one of the last training forward, like on the reference,
+        or refused if there was none)."""
         from ..modules import valid_scores_and_labels
         cfg = self.cfg
-        if any('deformable' in b for b in cfg.architecture):
-            raise NotImplementedError("KPFCNN (MI355X build): the offset regulariser of deformable blocks is training-side "
-                                      "state the inference kernels do not produce (SURVEY.md §8 f4)")
         scores, labels = valid_scores_and_labels(results, inputs['data'].labels, cfg.num_classes, cfg.ignored_label_inds, device)
         self.output_loss = Loss.weighted_CrossEntropyLoss(scores, labels)
-        self.reg_loss = torch.zeros((), device=scores.device)
+        if any('deformable' in b for b in cfg.architecture):
+            if cfg.get('deform_fitting_mode', 'point2point') != 'point2point':
+                raise ValueError('Unknown fitting mode: ' + str(cfg.deform_fitting_mode))
+            self.reg_loss = self._offset_regulariser()
+        else:
+            self.reg_loss = torch.zeros((), device=scores.device)
         return self.output_loss + self.reg_loss, labels, scores
 
 

@@ -66,6 +66,54 @@ def main():
     print("loss", loss.item(), "logits", logits.shape, "grads", len(keep), {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
 
 
+DEFORM_TRAIN_CFG = dict(synth_weights.KPCONV_DEFORM_SMALL_CFG, first_features_dim=32, modulated=True, in_features_dim=4,
+                        deform_fitting_mode="point2point", deform_fitting_power=1.0, repulse_extent=1.2)
+
+
+def deform_train_inputs():
+    spheres = [synth_data.toronto3d_sphere(71, 700, radius=2.0), synth_data.toronto3d_sphere(72, 600, radius=2.0)]
+    rng = np.random.default_rng(6)
+    cols = [np.concatenate([s, rng.random((len(s), 3), dtype=np.float32)], 1) for s in spheres]
+    labels = [rng.integers(0, 6, len(s)).astype(np.int32) for s in spheres]
+    return spheres, cols, labels
+
+
+def deform_main():
+    """tests/golden/train_kpconv_deform.npz: one training forward + backward of the REAL reference KPFCNN with three DEFORMABLE,
+    modulated blocks: logits, cross entropy AND the point-to-point offset regulariser of get_loss (kpconv.py:315-351, 2167-2206),
+    gradients of the offset convolutions' weights / biases and of a spread of other parameters."""
+    from oracle import kpconv_ref as K
+    kp = importlib.import_module("ml3d.torch.models.kpconv")
+    cb = importlib.import_module("ml3d.torch.dataloaders.concat_batcher")
+    cfg = dict(DEFORM_TRAIN_CFG)
+    np.random.seed(5)
+    model = kp.KPFCNN(**cfg)
+    model.load_state_dict(K.make_state_dict(cfg, 78))
+    model.train()
+    spheres, cols, labels = deform_train_inputs()
+    data = dict(p_list=spheres, f_list=cols, l_list=labels, p0_list=[np.zeros(3) for _ in spheres],
+                s_list=[np.ones(3, np.float32) for _ in spheres], R_list=[np.eye(3, dtype=np.float32) for _ in spheres],
+                r_inds_list=[np.zeros(0) for _ in spheres], r_mask_list=[np.zeros(0) for _ in spheres],
+                val_labels_list=[np.zeros(0) for _ in spheres], cfg=model.cfg)
+    model.cfg.batch_limit = 10 ** 9
+    np.random.seed(32)
+    batch = cb.KPConvBatch([{"data": data}])
+    logits = model(batch)
+    Loss = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    loss, lab, scores = model.get_loss(Loss, logits, {"data": batch}, "cpu")
+    loss.backward()
+    named = dict(model.named_parameters())
+    keep = [k for k in named if "offset" in k and named[k].grad is not None] + \
+           [k for k in named if k.endswith("KPConv.weights") and "offset" not in k][:4] + ["head_softmax.mlp.weight"]
+    out = dict(logits=logits.detach().numpy(), loss=np.float64(loss.item()), output_loss=np.float64(float(model.output_loss)),
+               reg_loss=np.float64(float(model.reg_loss)), n_valid=np.int64(len(lab)))
+    for k in keep:
+        out["grad:" + k] = named[k].grad.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_kpconv_deform.npz"), **out)
+    print("deform loss", loss.item(), "ce", float(model.output_loss), "reg", float(model.reg_loss), "grads", len(keep),
+          {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:3]})
+
+
 RANDLA_TRAIN_CFG = dict(num_neighbors=16, num_layers=3, num_points=1024, num_classes=8, sub_sampling_ratio=[4, 4, 2], in_channels=6,
                         dim_features=8, dim_output=[16, 32, 64], ignored_label_inds=[0], grid_size=0.06)
 
@@ -169,3 +217,5 @@ if __name__ == "__main__":
         randla_main()
     if which in ("all", "pointpillars"):
         pointpillars_main()
+    if which in ("all", "deform"):
+        deform_main()

@@ -416,3 +416,44 @@ out = m(In)
 assert not out[0].requires_grad and out[0].shape == maps[0].shape
 print("ok")
 ''')
+
+
+def test_deformable_kpfcnn_training_forward_regulariser_and_gradients_match_the_reference():
+    """KPFCNN with three DEFORMABLE, modulated blocks in ``.train()`` mode against ONE training forward + backward of the REAL
+    reference model (tests/golden/train_kpconv_deform.npz): logits, the cross entropy, the point-to-point offset regulariser of
+    ``get_loss`` (kpconv.py:2167-2206), and the gradients -- those of the offset convolutions included, which only flow if the
+    influences are differentiated with respect to the deformed kernel points."""
+    _run(r'''
+from ml3d.torch.dataloaders import kpconv_input_features
+from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+from oracle import kpconv_ref as K
+from oracle.gen_golden_train import DEFORM_TRAIN_CFG, deform_train_inputs
+g = np.load(os.path.join(ROOT, "tests", "golden", "train_kpconv_deform.npz"))
+cfg = dict(DEFORM_TRAIN_CFG)
+m = KPFCNN(**cfg, device="cpu")
+m.load_state_dict(K.make_state_dict(cfg, 78))
+spheres, cols, labels = deform_train_inputs()
+pts, columns = np.concatenate(spheres), np.concatenate(cols)
+np.random.seed(32)
+batch = KPConvBatch(pts, [len(s) for s in spheres], cfg, features=kpconv_input_features(pts, columns, cfg["in_features_dim"]).astype(np.float32),
+                    device="cpu")
+batch.labels = torch.from_numpy(np.concatenate(labels).astype(np.int64))
+m.train()
+logits = m(batch)
+assert logits.requires_grad and np.abs(logits.detach().numpy() - g["logits"]).max() <= 1e-4 * max(1.0, float(np.abs(g["logits"]).max()))
+L = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+loss, lab, scores = m.get_loss(L, logits, {"data": batch}, "cpu")
+assert int(lab.numel()) == int(g["n_valid"])
+assert abs(float(m.output_loss) - float(g["output_loss"])) <= 1e-5 and abs(float(m.reg_loss) - float(g["reg_loss"])) <= 1e-4 * float(g["reg_loss"])
+assert abs(float(loss) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+loss.backward()
+named = dict(m.named_parameters())
+checked = 0
+for key in g.files:
+    if key.startswith("grad:"):
+        want, have = g[key], named[key[5:]].grad.numpy()
+        assert np.abs(have - want).max() <= 1e-3 * float(np.abs(want).max()), (key, float(np.abs(have - want).max()), float(np.abs(want).max()))
+        checked += 1
+assert checked == 11
+print("ok")
+''')

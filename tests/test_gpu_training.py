@@ -167,3 +167,40 @@ def test_pointpillars_training_forward_and_gradients_match_the_reference(golden_
     with torch.no_grad():
         out = m(In)
     assert out[0].shape == maps[0].shape and not out[0].requires_grad
+
+
+def test_deformable_kpfcnn_training_matches_the_reference(golden_dir):
+    """KPFCNN with three DEFORMABLE, modulated blocks in ``.train()`` mode on the MI355X (offset convolutions through
+    ``ops.KPConvFunction``, the deformed convolutions on torch's autograd) against the REAL reference's training forward +
+    backward (tests/golden/train_kpconv_deform.npz): logits, cross entropy, the point-to-point offset regulariser, gradients."""
+    from ml3d.torch.dataloaders import kpconv_input_features
+    from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+    from oracle.gen_golden_train import DEFORM_TRAIN_CFG, deform_train_inputs
+    g = np.load(os.path.join(golden_dir, "train_kpconv_deform.npz"))
+    cfg = dict(DEFORM_TRAIN_CFG)
+    m = KPFCNN(**cfg, device="cuda:0")
+    m.load_state_dict(K.make_state_dict(cfg, 78))
+    m.to("cuda:0")
+    spheres, cols, labels = deform_train_inputs()
+    pts, columns = np.concatenate(spheres), np.concatenate(cols)
+    np.random.seed(32)
+    batch = KPConvBatch(pts, [len(s) for s in spheres], cfg,
+                        features=kpconv_input_features(pts, columns, cfg["in_features_dim"]).astype(np.float32), device="cuda:0")
+    batch.labels = torch.from_numpy(np.concatenate(labels).astype(np.int64))
+    m.train()
+    logits = m(batch)
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= 1e-4 * max(1.0, float(np.abs(g["logits"]).max()))
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    loss, lab, scores = m.get_loss(loss_obj, logits, {"data": batch}, "cuda:0")
+    assert abs(float(m.output_loss) - float(g["output_loss"])) <= 1e-5
+    assert abs(float(m.reg_loss) - float(g["reg_loss"])) <= 1e-4 * float(g["reg_loss"])
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            want, have = g[key], named[key[5:]].grad.detach().cpu().numpy()
+            assert np.abs(have - want).max() <= 2e-3 * float(np.abs(want).max()), (key, float(np.abs(have - want).max()))
+            checked += 1
+    assert checked == 11
+

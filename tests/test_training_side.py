@@ -85,9 +85,10 @@ def test_segmentation_models_get_loss_and_optimizers():
     opt, _ = k.get_optimizer(types.SimpleNamespace(learning_rate=0.01, deform_lr_factor=0.1, momentum=0.9, weight_decay=1e-3,
                                                    scheduler_gamma=0.99))
     assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == pytest.approx(0.001)
+    # deformable blocks: the offset regulariser reads what the TRAINING forward left on them -- refused before there was one
     d = KPFCNN(**dict(synth_weights.KPCONV_DEFORM_SMALL_CFG, device="cpu"))
-    with pytest.raises(NotImplementedError):
-        d.get_loss(loss, torch.randn((10, 8)), {"data": types.SimpleNamespace(labels=torch.zeros(10, dtype=torch.long))}, "cpu")
+    with pytest.raises(RuntimeError):
+        d.get_loss(loss, torch.randn((10, 5)), {"data": types.SimpleNamespace(labels=torch.randint(0, 6, (10,)))}, "cpu")
 
 
 def test_randlanet_training_split_augmentation_is_the_reference_augmenters(golden):
