@@ -189,6 +189,14 @@ __device__ __forceinline__ float kp_influence1(float dx, float dy, float dz, con
     return expf(-d2 / A.gauss_den);
 }
 
+__device__ __forceinline__ uint32_t ml3d_umul24(uint32_t a, uint32_t b) {       // v_mul_u32_u24: full rate (v_mul_lo_u32 is quarter rate)
+#ifdef ML3D_HIPEMU
+    return a * b;
+#else
+    return __umul24(a, b);
+#endif
+}
+
 template <int NT>
 struct KpRow {                       // one neighbour as lane (k, j) sees it: its influence on kernel point k + its NT channels
     float w;                         // (PSH = false: w, wy, wz hold the neighbour's position until it is consumed)
@@ -202,8 +210,11 @@ __device__ __forceinline__ void kp_row_load(KpRow<NT>& r, const KpArgs& A, int i
     // UNCONDITIONAL load (a shadow lane reads row 0 and is zeroed when consumed): loads inside an `if (idx >= 0)` leave the
     // number of outstanding requests unknown, and the compiler then waits for ALL of them before the previous group's use
     r.real = idx >= 0;
-    const int64_t i = idx < 0 ? 0 : idx;
-    const float* xr = A.x + i * A.c_total + A.c_off + k * NT;
+    // (32-bit BYTE offset from the scalar base -- one 24-bit multiply-add instead of a 64-bit multiply and a 64-bit shift-add;
+    //  agg_mfma_ok: fewer than 2^24 support rows, a row shorter than 2^24 bytes, the feature matrix below 4 GB)
+    const uint32_t i = (uint32_t)(idx < 0 ? 0 : idx);
+    const float* xr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A.x) +
+                                                     (ml3d_umul24(i, (uint32_t)A.c_total * 4u) + (uint32_t)(A.c_off + k * NT) * 4u));
     if constexpr (NT == 1) r.xv[0] = xr[0];
     else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(xr); r.xv[0] = v.x; r.xv[1] = v.y; }
     else {
@@ -260,53 +271,60 @@ __device__ __forceinline__ void kp_agg_query(const KpArgs& A, int64_t q, int lan
             nxa = pa[0] - qx; nya = pa[1] - qy; nza = pa[2] - qz;
             nxb = pb[0] - qx; nyb = pb[1] - qy; nzb = pb[2] - qz;
         }
-        // this lane's neighbour of group g (wave-uniform choice of the register: g is uniform); idx -1 past the last group
-        auto fetch = [&](KpRow<NT>& r, int g) {
-            const int c = 4 * g + j;
-            const bool lo = c < 64;
-            const int v = __shfl(lo ? ia : ib, c & 63);
-            const int idx = g < groups ? v : -1;
-            if constexpr (PSH) {
-                const float nx = __shfl(lo ? nxa : nxb, c & 63), ny = __shfl(lo ? nya : nyb, c & 63),
-                            nz = __shfl(lo ? nza : nzb, c & 63);
-                kp_row_load<NT>(r, A, idx, k);
-                const float w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
-                r.w = (kreal && idx >= 0) ? w : 0.f;
-            } else {
-                const float* sp = A.s_pts + 3 * (int64_t)(idx < 0 ? 0 : idx);
-                r.w = sp[0]; r.wy = sp[1]; r.wz = sp[2];
-                kp_row_load<NT>(r, A, idx, k);
-            }
-        };
-        auto consume = [&](const KpRow<NT>& r) {
-            float w = r.w;
-            if constexpr (!PSH) {
-                const float nx = r.w - qx, ny = r.wy - qy, nz = r.wz - qz;
-                w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
-                w = (kreal && r.real) ? w : 0.f;
-            }
+        // The 128 columns are walked as two halves of 16 groups (columns 0..63 from the lane's first register set, 64..127 from
+        // its second): inside a half the cross-lane source of group g is simply lane 4 g + j -- no per-group select between the
+        // two sets (five VALU instructions per group in the fused kernel, which is issue-bound: profiles/r04_pmc_kp_sq1.csv).
+        for (int half = 0; half < 2; ++half) {
+            const int gh = min(16, groups - 16 * half);               // groups of this half (wave-uniform)
+            if (gh <= 0) break;
+            const int ci = half ? ib : ia;
+            const float cnx = half ? nxb : nxa, cny = half ? nyb : nya, cnz = half ? nzb : nza;
+            // this lane's neighbour of group g of the half; idx -1 past its last group (the prefetch runs two groups ahead)
+            auto fetch = [&](KpRow<NT>& r, int g) {
+                const int src = (4 * g + j) & 63;
+                const int v = __shfl(ci, src);
+                const int idx = g < gh ? v : -1;
+                if constexpr (PSH) {
+                    const float nx = __shfl(cnx, src), ny = __shfl(cny, src), nz = __shfl(cnz, src);
+                    kp_row_load<NT>(r, A, idx, k);
+                    const float w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
+                    r.w = (kreal && idx >= 0) ? w : 0.f;
+                } else {
+                    const float* sp = A.s_pts + 3 * (int64_t)(idx < 0 ? 0 : idx);
+                    r.w = sp[0]; r.wy = sp[1]; r.wz = sp[2];
+                    kp_row_load<NT>(r, A, idx, k);
+                }
+            };
+            auto consume = [&](const KpRow<NT>& r) {
+                float w = r.w;
+                if constexpr (!PSH) {
+                    const float nx = r.w - qx, ny = r.wy - qy, nz = r.wz - qz;
+                    w = kp_influence1<MODE>(nx - kxq, ny - kyq, nz - kzq, A);
+                    w = (kreal && r.real) ? w : 0.f;
+                }
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, r.real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
-        };
-        // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is
-        // consumed (a rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
-        // (a third row buffer -- two groups in flight -- measured slower in the fused kernel: 0.94 against 0.89 ms)
-        KpRow<NT> ra, rb;
-        fetch(ra, 0);
-        for (int g = 0; g < groups; g += 2) {
-            // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for both before the first
-            //  MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the younger is in
-            //  flight)
-            fetch(rb, g + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(ra);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(ra, g + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(rb);              // (unconditional: past the last group the index is -1, a zero MFMA -- under an `if`
-                                      //  the compiler sinks rb's loads into the branch, right in front of their use)
-            __builtin_amdgcn_sched_barrier(0);
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, r.real ? r.xv[n] : 0.f, acc[n], 0, 0, 0);
+            };
+            // two STATIC row buffers, the loop unrolled by two: the loads of group g + 1 are in flight while group g is
+            // consumed (a rotating `cur = nxt` form made the compiler wait for the loads it had just issued)
+            // (a third row buffer -- two groups in flight -- measured slower in the fused kernel: 0.94 against 0.89 ms)
+            KpRow<NT> ra, rb;
+            fetch(ra, 0);
+            for (int g = 0; g < gh; g += 2) {
+                // (sched_barrier: the scheduler otherwise issues both rows' loads together and waits for both before the first
+                //  MFMA -- the request counter retires in order, so a use may only wait for the OLDER row while the younger is
+                //  in flight)
+                fetch(rb, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(ra);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(ra, g + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(rb);              // (unconditional: past the last group the index is -1, a zero MFMA -- under an `if`
+                                          //  the compiler sinks rb's loads into the branch, right in front of their use)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if constexpr (DEF) {
@@ -681,9 +699,14 @@ static bool small_fused_ok(const KpArgs& a, const KpOut& o) {
            ((((uintptr_t)o.weights) | ((uintptr_t)o.bias) | ((uintptr_t)o.out)) & 15) == 0;
 }
 
+// kp_row_load addresses a neighbour's feature row with a 24-bit x 24-bit multiply into a 32-bit byte offset
+static bool kp_rows_32bit(const KpArgs& a) {
+    return a.ns < (1 << 24) && (int64_t)a.c_total * 4 < (1 << 24) && (int64_t)a.ns * a.c_total * 4 < ((int64_t)1 << 32);
+}
+
 // the one-kernel block takes cin = cout = 32, rigid, 16-byte aligned features and 8-byte aligned outputs
 static bool agg_gemm32_ok(const KpArgs& a, const KpOut& o) {
-    return a.cin == 32 && o.cout == 32 && !a.off && a.h > 0 && a.ns > 0 && a.nq > 0 &&
+    return a.cin == 32 && o.cout == 32 && !a.off && a.h > 0 && a.ns > 0 && a.nq > 0 && kp_rows_32bit(a) &&
            ((((uintptr_t)a.x) & 15) | (((uintptr_t)o.out) & 7)) == 0;
 }
 
@@ -783,7 +806,7 @@ static void launch_agg_mfma(const KpArgs& a, hipStream_t st) {
 static bool agg_mfma_ok(const KpArgs& a) {
     const int c = a.cin;
     return (c == 16 || c == 32 || c == 64 || c == 128 || c == 256 || (c == 512 && a.off)) && a.h > 0 && a.ns > 0 &&
-           a.nq > 0 &&
+           a.nq > 0 && kp_rows_32bit(a) &&
            ((((uintptr_t)a.x) | ((uintptr_t)a.wf)) & 15) == 0;
 }
 

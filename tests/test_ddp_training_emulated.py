@@ -90,7 +90,7 @@ def kpconv(r):
     m = KPFCNN(**cfg, device="cpu")
     m.load_state_dict(K.make_state_dict(cfg, 77))
     m.train()
-    spheres = [synth_data.toronto3d_sphere(63 + 2 * r + i, 600) for i in range(2)]
+    spheres = [synth_data.toronto3d_sphere(63 + 2 * r + i, 350) for i in range(2)]
     rng = np.random.default_rng(5 + r)
     cols = np.concatenate([np.concatenate([s_, rng.random((len(s_), 3), dtype=np.float32)], 1) for s_ in spheres])
     pts = np.concatenate(spheres)
