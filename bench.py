@@ -532,8 +532,8 @@ def main():
                               "avg_launch_ms": ms, "bytes_per_launch": kb, "avg_launch_ms_alone": alone.get((kind, tag)),
                               "frac_alone": (kb / (alone[(kind, tag)] * 1e-3) / 1e9 / PEAK_HBM_GBS) if alone.get((kind, tag)) else None,
                               "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU-issue bound "
-                                      "(714 M wave-instructions per launch, ~410 candidate steps per wave for ~150 candidates "
-                                      "per lane: profiles/r03_pmc_knn_sq.csv), not HBM-bound: DESIGN.md §3.2"})
+                                      "(738 M wave-instructions per launch, ~410 candidate steps per wave for ~150 candidates "
+                                      "per lane: profiles/r04_pmc_knn_sq.csv), not HBM-bound: DESIGN.md §3.2"})
             else:
                 layer, stage = tag // 8, tag % 8
                 d = CFG["dim_output"][layer]

@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 6
+#define ML3D_ABI_VERSION 7
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -407,6 +407,22 @@ int ml3d_pp_boxes(const float* cls, const float* reg, const float* dir, const in
                   int num_anchors, int num_classes, int64_t hw, float score_threshold,
                   float iou_threshold, float dir_offset, float* out_rows, int32_t* out_total,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* the nms_pre top-k of Anchor3DHead.get_bboxes_single (ABI 7) — replaces      */
+/* `max_scores.topk(self.nms_pre)`, ml3d/torch/models/point_pillars.py:985-992 */
+/* (the reference calls torch.topk per sample; this takes every sample of the */
+/* batch in one call).  values [rows, n] f32 row-major, 0 <= k <= min(n, 4096) */
+/* (k beyond 4096: ML3D_E_UNSUPPORTED; the reference's configs use 100..4096). */
+/* out_index int64 [rows, k]: the k largest of every row in DESCENDING value,  */
+/* equal values by ASCENDING index (also at the k-th value: of its ties the    */
+/* lowest indices are taken — torch leaves that order unspecified), NaN above  */
+/* +inf (torch.topk's convention).  out_value f32 [rows, k] or NULL.           */
+/* ------------------------------------------------------------------------- */
+size_t ml3d_topk_rows_workspace_bytes(int64_t rows, int64_t n, int64_t k);
+
+int ml3d_topk_rows(const float* values, int64_t rows, int64_t n, int64_t k, int64_t* out_index,
+                   float* out_value, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* pairwise rotated box IoU for the detection metric —       */

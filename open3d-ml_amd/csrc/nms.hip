@@ -191,7 +191,7 @@ nms_reduce(const u64* __restrict__ mask, const uint32_t* __restrict__ order, int
 // Anchor3DHead.get_bboxes for a WHOLE BATCH without host read-backs (ml3d/torch/models/point_pillars.py:945-1025;
 // BBoxCoder.decode, ml3d/torch/utils/objdet_helper.py:286-313; multiclass_nms, :316-350).  The per-sample, per-class loop of
 // the reference (B x C calls of nms, each behind a nonzero() that synchronises) becomes four launches:
-//   pp_anchor_scores   max over the classes of sigmoid(cls) per anchor            -> the key of the nms_pre top-k (caller)
+//   pp_anchor_scores   max over the classes of sigmoid(cls) per anchor            -> the key of the nms_pre top-k (ml3d_topk_rows, below)
 //   pp_decode          the selected candidates: anchor + deltas -> boxes, class scores, direction bit, BEV corners form
 //   nmsb_order / nmsb_mask / nmsb_reduce   P = B x C independent NMS problems over the k candidates of a sample: a candidate
 //                      takes part in class c iff its score_c > score_thr (point_pillars.py:1001); greedy order = descending
@@ -370,6 +370,171 @@ pp_collect(const float* __restrict__ box, const float* __restrict__ score, const
     dst[8] = (float)c;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ml3d_topk_rows -- `max_scores.topk(nms_pre)` of Anchor3DHead.get_bboxes_single (ml3d/torch/models/point_pillars.py:985-992)
+// for every sample of the batch at once: rows x n scores (n = H * W * A = 321 408 anchors at KITTI), the k <= 4096 largest of
+// every row.  An MSB radix SELECT on the order-preserving key: three histogram passes over 11 + 11 + 10 key bits (the prologue
+// of a pass re-derives the digits chosen so far from the earlier tables, so no "pick" launch sits between two passes), one
+// compaction pass, one single-workgroup bitonic sort of the k selected (key, index) pairs.  The rows are a few MB: the cost is
+// the six dependent launches, not the traffic (torch.topk's multi-block radix select + its result sort: ~20 launches).
+// Order: descending value, ties by ascending index, NaN above +inf (torch.topk's convention).  Ties AT the k-th value are
+// resolved by index as well, so the result is a pure function of the input (torch leaves that order unspecified).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TOPK_BINS = 2048;                 // bins of a level's table (level 2 uses the first 1024)
+constexpr int TOPK_CHUNK = 4096;                // elements per workgroup: 256 threads x 16 CONSECUTIVE elements
+
+__device__ __forceinline__ unsigned topk_key(float x) { return x != x ? 0u : ~f2ord(x); }       // ascending key = descending value
+__device__ __forceinline__ int topk_shift(int level) { return level == 0 ? 21 : level == 1 ? 10 : 0; }
+__device__ __forceinline__ unsigned topk_digit(unsigned key, int level) { return (key >> topk_shift(level)) & (level == 2 ? 1023u : 2047u); }
+
+// the digit of `level` the k-th smallest key falls in, given that level's table of the keys that share the digits chosen
+// before: *bin = smallest b with count(bins <= b) >= krem; krem becomes the rank INSIDE that bin.  Whole workgroup (256).
+__device__ void topk_pick(const int* __restrict__ table, int& krem, unsigned& bin, int* sh /* [8] */) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int loc[TOPK_BINS / 256], s = 0;
+#pragma unroll
+    for (int i = 0; i < TOPK_BINS / 256; ++i) { loc[i] = table[t * (TOPK_BINS / 256) + i]; s += loc[i]; }
+    const int incl = wave_inclusive_scan(s);
+    __syncthreads();                                        // (sh is reused from one level to the next)
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    int excl = incl - s;
+    for (int w = 0; w < wv; ++w) excl += sh[w];
+    __syncthreads();
+    if (excl < krem && krem <= excl + s) {                  // exactly one thread: the table holds >= krem keys
+        int run = excl;
+#pragma unroll
+        for (int i = 0; i < TOPK_BINS / 256; ++i) {
+            if (krem <= run + loc[i]) { sh[4] = t * (TOPK_BINS / 256) + i; sh[5] = krem - run; break; }
+            run += loc[i];
+        }
+    }
+    __syncthreads();
+    bin = (unsigned)sh[4];
+    krem = sh[5];
+}
+
+// tables [rows][3][TOPK_BINS] (zeroed by the host); pass `level` counts the keys that match the digits of the levels before
+__global__ void __launch_bounds__(256)
+topk_hist(const float* __restrict__ x, int64_t n, int k, int level, int* __restrict__ tables) {
+    __shared__ int hist[TOPK_BINS];
+    __shared__ int sh[8];
+    const int64_t row = blockIdx.y;
+    int* tab = tables + row * 3 * TOPK_BINS;
+    unsigned prefix = 0;                                    // the key's bits above this level's digit
+    int krem = k;
+    for (int l = 0; l < level; ++l) {
+        unsigned b;
+        topk_pick(tab + l * TOPK_BINS, krem, b, sh);
+        prefix |= b << topk_shift(l);
+    }
+    for (int i = threadIdx.x; i < TOPK_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const float* xr = x + row * n;
+    const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK;
+    const unsigned above = level == 0 ? 0u : (0xffffffffu << topk_shift(level - 1));
+#pragma unroll 4
+    for (int j = 0; j < TOPK_CHUNK / 256; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) {
+            const unsigned key = topk_key(xr[i]);
+            if ((key & above) == prefix) atomicAdd(&hist[topk_digit(key, level)], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TOPK_BINS; i += 256)
+        if (hist[i]) atomicAdd(&tab[level * TOPK_BINS + i], hist[i]);
+}
+
+// sel [rows][k] <- (key << 32 | index) of the k selected elements of a row, in no particular order: every key below the
+// threshold key T, and the krem lowest-indexed ones among the keys equal to T.  counters [rows][2] (zeroed): slots handed out.
+__global__ void __launch_bounds__(256)
+topk_take(const float* __restrict__ x, int64_t n, int k, const int* __restrict__ tables, int* __restrict__ counters,
+          u64* __restrict__ sel) {
+    __shared__ int sh[8];
+    const int64_t row = blockIdx.y;
+    const int* tab = tables + row * 3 * TOPK_BINS;
+    unsigned T = 0;
+    int krem = k, n_equal = 0;
+    for (int l = 0; l < 3; ++l) {
+        unsigned b;
+        topk_pick(tab + l * TOPK_BINS, krem, b, sh);
+        T |= b << topk_shift(l);
+        if (l == 2) n_equal = tab[2 * TOPK_BINS + b];       // keys equal to T in the whole row
+    }
+    const int n_less = k - krem;                            // keys below T: all of them are selected
+    const float* xr = x + row * n;
+    u64* out = sel + row * k;
+    int* cnt = counters + 2 * row;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK, first = base + (int64_t)t * 16;
+    unsigned key[16];
+    int eq_mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t i = first + j;
+        key[j] = i < n ? topk_key(xr[i]) : 0xffffffffu;
+        if (i < n && key[j] < T) out[atomicAdd(&cnt[0], 1)] = ((u64)key[j] << 32) | (u64)(uint32_t)i;
+        eq_mine += (i < n && key[j] == T) ? 1 : 0;
+    }
+    if (n_equal == krem) {                                  // the usual case: every key equal to T is taken, any slot will do
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (first + j < n && key[j] == T) out[n_less + atomicAdd(&cnt[1], 1)] = ((u64)T << 32) | (u64)(uint32_t)(first + j);
+        return;
+    }
+    // ties AT the threshold: the krem lowest indices.  A thread owns 16 consecutive elements, so the rank of an equal
+    // element = equals of the row before this workgroup's chunk + equals of the threads before + equals before it in the thread.
+    const int incl = wave_inclusive_scan(eq_mine);
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    int rank = incl - eq_mine;
+    for (int w = 0; w < wv; ++w) rank += sh[w];
+    const int eq_block = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    if (eq_block == 0) return;                              // (uniform)
+    int before = 0;                                         // recount of the chunks before this one: only workgroups that hold a
+    for (int64_t i = t; i < base; i += 256) before += topk_key(xr[i]) == T ? 1 : 0;      // tie get here, and ties are rare
+    before = wave_sum(before);
+    if (lane == 0) sh[wv] = before;
+    __syncthreads();
+    rank += sh[0] + sh[1] + sh[2] + sh[3];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (first + j < n && key[j] == T) {
+            if (rank < krem) out[n_less + rank] = ((u64)T << 32) | (u64)(uint32_t)(first + j);
+            ++rank;
+        }
+    }
+}
+
+// one workgroup per row: bitonic sort of the k selected pairs (padded to a power of two with ~0) in LDS, ascending
+// (key, index) = descending value, ties by ascending index
+__global__ void __launch_bounds__(256)
+topk_sort(const u64* __restrict__ sel, int k, int kp2, int64_t* __restrict__ out_index, float* __restrict__ out_value,
+          const float* __restrict__ x, int64_t n) {
+    __shared__ u64 keys[NMSB_MAX];
+    const int64_t row = blockIdx.x;
+    for (int i = threadIdx.x; i < kp2; i += 256) keys[i] = i < k ? sel[row * k + i] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= kp2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = threadIdx.x; p < kp2 / 2; p += 256) {
+                const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1)), hi = lo | stride;
+                const bool up = (lo & size) == 0;
+                const u64 a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const int64_t idx = (int64_t)(uint32_t)keys[i];
+        out_index[row * k + i] = idx;
+        if (out_value) out_value[row * k + i] = x[row * n + idx];
+    }
+}
+
 static inline size_t nms_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace ml3d
@@ -418,6 +583,36 @@ extern "C" int ml3d_pp_anchor_scores(const float* cls, const int64_t* cls_stride
     const ml3d::HeadMap mc = {cls, cls_strides[0], cls_strides[1], cls_strides[2]};
     hipLaunchKernelGGL(ml3d::pp_anchor_scores, dim3((unsigned)((batch * hw + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        mc, batch, num_anchors, num_classes, hw, out_scores);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" size_t ml3d_topk_rows_workspace_bytes(int64_t rows, int64_t n, int64_t k) {
+    if (rows < 0 || n < 0 || k < 0 || k > n || k > NMSB_MAX) return 0;
+    const size_t R = (size_t)(rows > 0 ? rows : 1);
+    return nms_align(4 * R * (3 * TOPK_BINS + 2)) /* tables + counters */ + nms_align(8 * R * (size_t)(k > 0 ? k : 1)) /* sel */ + 512;
+}
+
+extern "C" int ml3d_topk_rows(const float* values, int64_t rows, int64_t n, int64_t k, int64_t* out_index, float* out_value,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows < 0 || n < 0 || k < 0 || k > n || n > 0x7fffffffll || rows > 65535) return ML3D_E_INVALID;
+    if (k > NMSB_MAX) return ML3D_E_UNSUPPORTED;
+    if (rows == 0 || k == 0) return 0;
+    if (!values || !out_index || !workspace) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_topk_rows_workspace_bytes(rows, n, k)) return ML3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int* tables = (int*)p;
+    int* counters = tables + (size_t)rows * 3 * TOPK_BINS;
+    p += nms_align(4 * (size_t)rows * (3 * TOPK_BINS + 2));
+    u64* sel = (u64*)p;
+    if (hipMemsetAsync(tables, 0, 4 * (size_t)rows * (3 * TOPK_BINS + 2), st) != hipSuccess) return ML3D_E_LAUNCH;
+    const dim3 grid((unsigned)((n + TOPK_CHUNK - 1) / TOPK_CHUNK), (unsigned)rows);
+    for (int level = 0; level < 3; ++level)
+        hipLaunchKernelGGL(ml3d::topk_hist, grid, dim3(256), 0, st, values, n, (int)k, level, tables);
+    hipLaunchKernelGGL(ml3d::topk_take, grid, dim3(256), 0, st, values, n, (int)k, tables, counters, sel);
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    hipLaunchKernelGGL(ml3d::topk_sort, dim3((unsigned)rows), dim3(256), 0, st, sel, (int)k, kp2, out_index, out_value, values, n);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

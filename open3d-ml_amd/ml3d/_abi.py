@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 6          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 7          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -50,6 +50,8 @@ SYMBOLS = [
     "ml3d_nms_workspace_bytes",
     "ml3d_nms",
     "ml3d_pp_anchor_scores",
+    "ml3d_topk_rows_workspace_bytes",
+    "ml3d_topk_rows",
     "ml3d_pp_boxes_workspace_bytes",
     "ml3d_pp_boxes",
     "ml3d_iou_bev",
@@ -173,6 +175,10 @@ def bind(lib):
     lib.ml3d_nms.argtypes = [vp, vp, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_pp_anchor_scores.restype = C.c_int
     lib.ml3d_pp_anchor_scores.argtypes = [vp, vp, i64, i32, i32, i64, vp, vp]
+    lib.ml3d_topk_rows_workspace_bytes.restype = sz
+    lib.ml3d_topk_rows_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.ml3d_topk_rows.restype = C.c_int
+    lib.ml3d_topk_rows.argtypes = [vp, i64, i64, i64, vp, vp, vp, sz, vp]
     lib.ml3d_pp_boxes_workspace_bytes.restype = sz
     lib.ml3d_pp_boxes_workspace_bytes.argtypes = [i64, i64, i32]
     lib.ml3d_pp_boxes.restype = C.c_int

@@ -120,6 +120,41 @@ def nms(boxes, scores, nms_overlap_thresh):
     return keep[:int(count.item())]
 
 
+def topk_rows(values, k, with_values=False):
+    """The ``nms_pre`` top-k of ``Anchor3DHead.get_bboxes_single`` (``max_scores.topk(self.nms_pre)``, point_pillars.py:985-992)
+    for all rows at once: ``values`` float32 [rows, n] (or [n]) -> int64 indices [rows, k] (or [k]) of the k largest of every
+    row in descending value, equal values by ascending index, NaN first -- a HIP radix select (``ml3d_topk_rows``), no
+    ``torch.topk``.  ``with_values=True`` also returns the values."""
+    lib = _abi.get()
+    _need_gpu(values)
+    v = values.detach()
+    flat = v.dim() == 1
+    if flat:
+        v = v.unsqueeze(0)
+    if v.dim() != 2:
+        raise RuntimeError("topk_rows: values must be [rows, n] or [n]")
+    v = v.contiguous().float()
+    rows, n = v.shape
+    k = int(k)
+    if k < 0 or k > n:
+        raise RuntimeError("topk_rows: k = %d outside [0, %d]" % (k, n))
+    dev = v.device
+    idx = torch.empty((rows, k), dtype=torch.int64, device=dev)
+    val = torch.empty((rows, k), dtype=torch.float32, device=dev) if with_values else None
+    if rows * k > 0:
+        wsb = lib.ml3d_topk_rows_workspace_bytes(rows, n, k)
+        if wsb == 0:
+            raise RuntimeError("topk_rows: k = %d is beyond the kernel's 4096 candidates per row" % k)
+        ws = _ws(wsb, dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_topk_rows(v.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr() if with_values else None,
+                                    ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_topk_rows")
+    if flat:
+        idx, val = idx[0], (val[0] if with_values else None)
+    return (idx, val) if with_values else idx
+
+
 def _head_map(t):
     """[B, ch, H, W] float32 head map in any layout whose (H, W) plane has ONE pixel stride (NCHW tensors, channel slices of
     an NHWC tensor viewed as NCHW) -> (tensor, (batch, channel, pixel) element strides); anything else is made contiguous."""
@@ -155,7 +190,7 @@ def pointpillars_boxes(cls_scores, bbox_preds, dir_preds, anchors, nms_pre, scor
             smax = torch.empty((B, n_anchor), dtype=torch.float32, device=dev)
             rc = lib.ml3d_pp_anchor_scores(cls_scores.data_ptr(), strides, B, A, C_, H * W, smax.data_ptr(), _stream())
             _abi.check(rc, "ml3d_pp_anchor_scores")
-            cand = torch.topk(smax, int(nms_pre), dim=1)[1].contiguous()
+            cand = topk_rows(smax, int(nms_pre))
         else:
             cand = torch.arange(n_anchor, dtype=torch.int64, device=dev).repeat(B, 1).contiguous()
         k = cand.shape[1]

@@ -191,7 +191,7 @@ class Anchor3DHead(nn.Module):
         bbox_preds = bbox_preds.permute(1, 2, 0).reshape(-1, self.box_code_size)
         if scores.shape[0] > self.nms_pre:
             max_scores, _ = scores.max(dim=1)
-            _, topk = max_scores.topk(self.nms_pre)
+            topk = ops.topk_rows(max_scores, self.nms_pre)      # HIP radix select; ties by ascending anchor index
             anchors, bbox_preds, scores, dir_scores = anchors[topk], bbox_preds[topk], scores[topk], dir_scores[topk]
         bboxes = self.decode(anchors, bbox_preds)
         idxs = []

@@ -209,6 +209,23 @@ def nms(boxes, scores, nms_overlap_thresh):
     return keep[:m].copy()
 
 
+def topk_rows(values, k):
+    """Restates ``max_scores.topk(self.nms_pre)`` of Anchor3DHead.get_bboxes_single (ml3d/torch/models/point_pillars.py:985-992)
+    for every row of ``values`` [rows, n]: indices [rows, k] of the k largest in descending value, NaN above +inf (torch.topk's
+    convention).  torch leaves the order of EQUAL values unspecified; the canonical order fixed here is ascending index (also for
+    the ties at the k-th value).  Pinned to torch.topk itself in tests/test_oracle_ops.py: values identical, indices identical
+    wherever a row's values are distinct."""
+    v = _f32(values)
+    v = v.reshape(1, -1) if v.ndim == 1 else v
+    nan = np.isnan(v)
+    key = np.where(nan, np.float32(np.inf), v)
+    out = np.empty((v.shape[0], int(k)), np.int64)
+    for r in range(v.shape[0]):
+        # lexsort: last key is the primary one -- NaN first, then descending value, then ascending index
+        out[r] = np.lexsort((np.arange(v.shape[1]), -key[r].astype(np.float64), ~nan[r]))[:int(k)]
+    return out
+
+
 def _corner_form(cx, cy, dx, dy, r):
     hx, hy = np.float32(0.5) * dx, np.float32(0.5) * dy
     return np.stack([cx - hx, cy - hy, cx + hx, cy + hy, r], -1).astype(np.float32)

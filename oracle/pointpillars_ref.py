@@ -187,7 +187,9 @@ def get_bboxes_single(cfg, cls_scores, bbox_preds, dir_preds, nms_fn=None):
     bbox_preds = bbox_preds.permute(1, 2, 0).reshape(-1, 7)
     if scores.shape[0] > hd["nms_pre"]:
         max_scores, _ = scores.max(dim=1)
-        _, topk = max_scores.topk(hd["nms_pre"])
+        _, topk = max_scores.topk(hd["nms_pre"])      # torch's own top-k, as the reference calls it: EQUAL scores come out in an order torch
+        # does not specify (it differs between its CPU and GPU kernels); oops.topk_rows fixes one for the primitive's tests, and the
+        # goldens from the real reference that run through ties at the cut (pointpillars_argoverse) are reproduced only with this call
         anchors, bbox_preds, scores, dir_scores = anchors[topk], bbox_preds[topk], scores[topk], dir_scores[topk]
     bboxes = decode(anchors, bbox_preds)
     idxs = []

@@ -378,6 +378,21 @@ def nms(boxes, scores, thr):
     return keep[:int(cnt[0])]
 
 
+def topk_rows(values, k, want_values=True):
+    """ml3d_topk_rows on a [rows, n] float32 array -> (index int64 [rows, k], value float32 [rows, k] | None)."""
+    L = lib()
+    v = np.ascontiguousarray(values, np.float32)
+    rows, n = v.shape
+    idx = np.full((rows, k), -7, np.int64)
+    val = np.full((rows, k), -7, np.float32) if want_values else None
+    wsb = L.ml3d_topk_rows_workspace_bytes(rows, n, k)
+    ws = _ws(max(wsb, 1))
+    rc = L.ml3d_topk_rows(v.ctypes.data, rows, n, k, idx.ctypes.data, val.ctypes.data if want_values else None,
+                          ws.ctypes.data, wsb, None)
+    assert rc == 0, rc
+    return idx, val
+
+
 def nearest_to_center(points, center, k):
     L = lib()
     points = np.ascontiguousarray(points, np.float32)

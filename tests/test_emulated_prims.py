@@ -322,3 +322,31 @@ def test_patch_recenter_means_are_numpys_sequential_float32_sums(k):
     ref[:, [0, 1]] = ref[:, [0, 1]] - ref.mean(0)[[0, 1]]
     assert np.array_equal(out, ref)
     assert np.array_equal(feats[:, :3], ref) and np.array_equal(feats[:, 3:], (extra - np.float32(0.0)) / np.float32(255.0))
+
+
+def test_topk_rows_matches_the_oracle_and_torch_topk():
+    """ml3d_topk_rows (the nms_pre top-k, point_pillars.py:985-992): indices identical to the oracle's canonical order, values
+    identical to torch.topk's -- random rows, heavy ties, all-equal rows, NaN / inf, k = n, k = 1, a KITTI-sized row."""
+    import torch
+    from test_oracle_ops import _topk_cases
+    rng = np.random.default_rng(5)
+    kitti = (1 / (1 + np.exp(-(rng.standard_normal((2, 321408)) * 3 - 6)))).astype(np.float32)
+    kitti[1, ::7] = kitti[1, 3]                          # 45 916 copies of one value straddling the threshold region
+    for v, k in _topk_cases() + [(kitti, 100), (kitti, 4096)]:
+        idx, val = emu.topk_rows(v, k)
+        assert np.array_equal(idx, oops.topk_rows(v, k)), (v.shape, k)
+        assert np.array_equal(val, torch.topk(torch.from_numpy(v), k, dim=1)[0].numpy(), equal_nan=True)
+
+
+def test_topk_rows_argument_checks():
+    L = emu.lib()
+    v = np.zeros((2, 10), np.float32)
+    idx = np.zeros((2, 10), np.int64)
+    ws = np.zeros(1 << 20, np.uint8)
+    assert L.ml3d_topk_rows(v.ctypes.data, 2, 10, 11, idx.ctypes.data, None, ws.ctypes.data, ws.size, None) == -1       # k > n
+    assert L.ml3d_topk_rows(v.ctypes.data, 2, 10, 5, idx.ctypes.data, None, ws.ctypes.data, 8, None) == -2            # workspace
+    assert L.ml3d_topk_rows(None, 2, 10, 5, idx.ctypes.data, None, ws.ctypes.data, ws.size, None) == -1
+    assert L.ml3d_topk_rows(v.ctypes.data, 0, 10, 5, idx.ctypes.data, None, ws.ctypes.data, ws.size, None) == 0
+    big = np.zeros((1, 5000), np.float32)
+    assert L.ml3d_topk_rows(big.ctypes.data, 1, 5000, 4097, idx.ctypes.data, None, ws.ctypes.data, ws.size, None) == -4   # k > 4096
+    assert L.ml3d_topk_rows_workspace_bytes(1, 5000, 4097) == 0

@@ -216,3 +216,22 @@ def test_argmax_labels_matches_torch_argmax():
     t = _t(s)
     got = ops.argmax_labels(t)
     assert got.dtype == torch.uint8 and torch.equal(got.long(), torch.argmax(t, -1))
+
+
+def test_topk_rows_is_the_nms_pre_topk_bit_exact():
+    """ml3d_topk_rows (replaces ``max_scores.topk(nms_pre)``, point_pillars.py:985-992): indices == the oracle's canonical order
+    (descending value, ties by ascending index), values == torch.topk's -- the small cases of the CPU suite plus a KITTI-sized
+    batch (8 samples x 321 408 anchors, nms_pre 100 and 4096) with a block of equal scores across the threshold."""
+    from ml3d import ops
+    from test_oracle_ops import _topk_cases
+    rng = np.random.default_rng(5)
+    kitti = (1 / (1 + np.exp(-(rng.standard_normal((8, 321408)) * 3 - 6)))).astype(np.float32)
+    kitti[1, ::7] = kitti[1, 3]
+    kitti[2] = 0.25
+    for v, k in _topk_cases() + [(kitti, 100), (kitti, 4096)]:
+        idx, val = ops.topk_rows(_t(v), k, with_values=True)
+        assert idx.dtype == torch.int64 and tuple(idx.shape) == (v.shape[0], k)
+        assert np.array_equal(idx.cpu().numpy(), oops.topk_rows(v, k)), (v.shape, k)
+        assert np.array_equal(val.cpu().numpy(), torch.topk(torch.from_numpy(v), k, dim=1)[0].numpy(), equal_nan=True)
+    one = ops.topk_rows(_t(kitti[0]), 100)                       # the per-sample call of get_bboxes_single
+    assert np.array_equal(one.cpu().numpy(), oops.topk_rows(kitti[:1], 100)[0])

@@ -252,3 +252,38 @@ def test_nms_keep_lists_match_a_greedy_loop_over_the_float64_iou():
             keep.append(int(i))
             dead |= iou[i] > thr
         assert ops.nms(boxes, scores, thr).tolist() == keep, trial
+
+
+def _topk_cases():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 7000)).astype(np.float32)
+    x[0, 5], x[0, 6000], x[1, 3] = np.nan, np.inf, -np.inf
+    x[1, 100:200] = np.nan
+    sig = (1 / (1 + np.exp(-(rng.standard_normal((2, 60000)) * 3 - 6)))).astype(np.float32)       # head-like: most scores tiny
+    return [(rng.standard_normal((3, 10000)).astype(np.float32), 100), (rng.random((2, 5000), dtype=np.float32), 4096),
+            (np.round(rng.random((4, 9000)) * 20).astype(np.float32) / 20, 300),                   # 21 distinct values: ties everywhere
+            (np.zeros((2, 4500), np.float32), 17), (x, 150), (rng.standard_normal((1, 37)).astype(np.float32), 37),
+            (rng.standard_normal((5, 4097)).astype(np.float32), 1), (sig, 100), (rng.random((0, 50), dtype=np.float32), 5),
+            (rng.random((3, 50), dtype=np.float32), 0)]
+
+
+def test_topk_rows_is_torch_topk_with_ties_by_ascending_index():
+    """The nms_pre top-k (point_pillars.py:985-992): values == torch.topk's, indices == torch.topk's wherever a row's values are
+    distinct, and the canonical tie order (ascending index) wherever they are not."""
+    import torch
+    for v, k in _topk_cases():
+        idx = ops.topk_rows(v, k)
+        assert idx.shape == (v.shape[0], k)
+        tv, ti = torch.topk(torch.from_numpy(v), k, dim=1)
+        got = np.take_along_axis(v, idx, 1)
+        assert np.array_equal(got, tv.numpy(), equal_nan=True)
+        for r in range(v.shape[0]):
+            if np.unique(v[r]).size == v.shape[1] and not np.isnan(v[r]).any():
+                assert np.array_equal(idx[r], ti[r].numpy())
+            assert np.unique(idx[r]).size == k
+            same = got[r, 1:] == got[r, :-1]
+            assert (np.diff(idx[r])[same] > 0).all()                   # equal values: ascending index
+            if k and k < v.shape[1] and not np.isnan(got[r, -1]):      # ties AT the k-th value: the lowest indices are the ones taken
+                tied = np.flatnonzero(v[r] == got[r, -1])
+                taken = idx[r][got[r] == got[r, -1]]
+                assert np.array_equal(taken, tied[:taken.size])
