@@ -705,23 +705,33 @@ patch_mean_seq(const float* __restrict__ pts, int64_t k, float* __restrict__ mea
             const float* col = buf[stage] + threadIdx.x * ROWS;
             const float4* col4 = reinterpret_cast<const float4*>(col);
             int r = 0;
-            if (rows >= 64) {
+            // blocks of 256 rows as STRAIGHT-LINE code, eight groups of 32 rows: the 16-byte LDS reads of group g + 1 are issued,
+            // then the 32 dependent adds of group g run under them -- two register sets in ping-pong with nothing carried
+            // around a loop (the rolled two-block loop this replaces paid a v_mov per add for half of the rows, the phi copies
+            // of its prefetch registers); only a block's first group is exposed, once per 256 adds.  The scheduling barriers keep
+            // the compiler from hoisting all 64 reads to the top (it did: the first add then waited for 46 of them).
+            for (; r + 256 <= rows; r += 256) {
+                const float4* c4 = col4 + r / 4;
                 float4 a[8], b[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = col4[i];
-                for (; r + 96 <= rows; r += 64) {
+                for (int i = 0; i < 8; ++i) a[i] = c4[i];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) b[i] = col4[(r + 32) / 4 + i];
+                for (int g = 0; g < 8; g += 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[i] = c4[8 * (g + 1) + i];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, a[i].x); s = __fadd_rn(s, a[i].y); s = __fadd_rn(s, a[i].z); s = __fadd_rn(s, a[i].w); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 2 < 8) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) a[i] = col4[(r + 64) / 4 + i];
+                        for (int i = 0; i < 8; ++i) a[i] = c4[8 * (g + 2) + i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, b[i].x); s = __fadd_rn(s, b[i].y); s = __fadd_rn(s, b[i].z); s = __fadd_rn(s, b[i].w); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { s = __fadd_rn(s, a[i].x); s = __fadd_rn(s, a[i].y); s = __fadd_rn(s, a[i].z); s = __fadd_rn(s, a[i].w); }
-                r += 32;
             }
             for (; r < rows; ++r) s = __fadd_rn(s, col[r]);
         }
