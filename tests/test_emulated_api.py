@@ -136,6 +136,45 @@ print("ok")
 ''')
 
 
+def test_batched_get_bboxes_at_the_large_nms_pre_of_the_lyft_and_waymo_configs():
+    """The batched decode at ``nms_pre`` = 1100 and 4096 (pointpillars_{argoverse,lyft,nuscenes}.yml: 1000, pointpillars_waymo.yml:
+    4096): 18 and 64 mask words per problem, so ``nmsb_reduce`` walks many 64-row LDS stages and ``ml3d_topk_rows`` sorts 2048 / 4096
+    keys -- against the oracle's loop formulation.  Hundreds of detections per sample: two scores one ulp apart (the kernel's
+    sigmoid against torch's) may swap places, so the rows are compared in a canonical order."""
+    _run(r'''
+from oracle import pointpillars_ref as P
+from ml3d.torch.models.point_pillars import PointPillars
+import copy
+cfg = P.SMALL_CFG
+
+def canon(b, s, l):
+    b, s, l = np.asarray(b), np.asarray(s), np.asarray(l)
+    o = np.lexsort((np.round(b[:, 1], 3), np.round(b[:, 0], 3), -np.round(s, 5), l))
+    return b[o], s[o], l[o]
+
+for nms_pre, H, W, thr in ((1100, 24, 26, 0.3), (4096, 40, 56, 0.55)):
+    c2 = copy.deepcopy(cfg)
+    c2["head"] = dict(c2["head"], nms_pre=nms_pre, score_thr=thr)
+    m2 = PointPillars(device="cpu", **c2)
+    A, C = m2.bbox_head.num_anchors, len(c2["classes"])
+    assert H * W * A > nms_pre
+    rng = np.random.default_rng(nms_pre)
+    cls = torch.from_numpy((rng.standard_normal((2, A * C, H, W)) * 2).astype(np.float32))
+    reg = torch.from_numpy((rng.standard_normal((2, A * 7, H, W)) * 0.3).astype(np.float32))
+    dr = torch.from_numpy(rng.standard_normal((2, A * 2, H, W)).astype(np.float32))
+    boxes, scores, labels = m2.bbox_head.get_bboxes(cls, reg, dr)
+    for i in range(2):
+        rb, rs, rl = P.get_bboxes_single(c2, cls[i], reg[i], dr[i])
+        assert len(rl) > 300 and len(rl) == len(labels[i]), (nms_pre, i, len(rl), len(labels[i]))
+        gb, gs, gl = canon(boxes[i].numpy(), scores[i].numpy(), labels[i].numpy())
+        ob, os_, ol = canon(rb.numpy(), rs.numpy(), rl.numpy())
+        assert np.array_equal(gl, ol), (nms_pre, i)
+        assert np.abs(gs - os_).max() <= 1e-6
+        assert (np.abs(gb - ob) / np.maximum(1.0, np.abs(ob))).max() <= 1e-4
+print("ok")
+''')
+
+
 def test_pointpillars_stream_returns_each_steps_detections_one_step_later():
     """``ml3d.engine.PointPillarsStream`` (what bench.py --workload pointpillars times): upload -> forward -> batched decode +
     NMS -> asynchronous copy back; ``submit`` hands out the previous step's lists, identical to ``get_bboxes`` of a plain
