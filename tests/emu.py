@@ -378,6 +378,17 @@ def nms(boxes, scores, thr):
     return keep[:int(cnt[0])]
 
 
+def box_iou(boxes_a, boxes_b, mode3d):
+    """ml3d_iou_bev ([n,5] / [m,5]) or ml3d_iou_3d ([n,7] / [m,7]) -> float32 [n, m]."""
+    L = lib()
+    a, b = np.ascontiguousarray(boxes_a, np.float32), np.ascontiguousarray(boxes_b, np.float32)
+    out = np.full((len(a), len(b)), -7, np.float32)
+    fn = L.ml3d_iou_3d if mode3d else L.ml3d_iou_bev
+    rc = fn(a.ctypes.data, b.ctypes.data, len(a), len(b), out.ctypes.data, None)
+    assert rc == 0, rc
+    return out
+
+
 def topk_rows(values, k, want_values=True):
     """ml3d_topk_rows on a [rows, n] float32 array -> (index int64 [rows, k], value float32 [rows, k] | None)."""
     L = lib()

@@ -350,3 +350,27 @@ def test_topk_rows_argument_checks():
     big = np.zeros((1, 5000), np.float32)
     assert L.ml3d_topk_rows(big.ctypes.data, 1, 5000, 4097, idx.ctypes.data, None, ws.ctypes.data, ws.size, None) == -4   # k > 4096
     assert L.ml3d_topk_rows_workspace_bytes(1, 5000, 4097) == 0
+
+
+def test_pairwise_box_iou_matches_the_oracle_twin():
+    """ml3d_iou_bev / ml3d_iou_3d (ml3d/metrics/mAP.py:85-88) through the emulator against the oracle twin on the mAP call shapes
+    (40 x 25 boxes, identical pairs, disjoint pairs): the same float32 operation order, the same libm -> equal to the last bit
+    (the MI355X test allows 1e-5 for the device's sinf / cosf); 1000 pairs cross more than one 64-pair workgroup."""
+    rng = np.random.default_rng(4)
+
+    def boxes(n):
+        b = np.zeros((n, 7), np.float32)
+        b[:, [0, 2]] = rng.uniform(-10, 10, (n, 2))
+        b[:, 1] = rng.uniform(0.5, 2.0, n)
+        b[:, 3:6] = rng.uniform(0.5, 4.0, (n, 3))
+        b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+        return b
+    pred, tgt = boxes(40), boxes(25)
+    tgt[:5] = pred[:5]
+    cols = [0, 2, 3, 5, 6]
+    bev = emu.box_iou(pred[:, cols], tgt[:, cols], False)
+    assert np.array_equal(bev, oops.iou_bev(pred[:, cols], tgt[:, cols]))
+    assert np.allclose(np.diag(bev[:5, :5]), 1.0, atol=1e-5) and (bev == 0).any()
+    i3 = emu.box_iou(pred, tgt, True)
+    assert np.array_equal(i3, oops.iou_3d(pred, tgt)) and (i3 <= bev + 1e-6).all()
+    assert emu.box_iou(np.zeros((0, 5), np.float32), tgt[:, cols], False).shape == (0, 25)
