@@ -15,6 +15,11 @@ import torch
 
 
 def _stack(values):
+    if len(values) == 1 and isinstance(values[0], torch.Tensor):
+        # test_batch_size 1 (every in-scope YAML's inference batch): a batch of ONE tensor is that tensor with a leading axis --
+        # a view, where torch.stack launches a copy kernel per entry (19 per RandLA-Net item: every level's points, neighbour,
+        # pooling and interpolation lists).  The transforms hand out freshly allocated tensors, so nothing else writes to them.
+        return values[0].unsqueeze(0)
     return torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(v) for v in values], 0)
 
 

@@ -404,7 +404,7 @@ class RandLANet(nn.Module):
             return None            # (the host path raises the reference's "Wrong feature dimension" error)
         rec = aug.get('recenter', None)
         nf = norm.get('feat', {}) if norm else {}
-        return dict(points=tree._pts(), feat=feat, label=torch.from_numpy(np.ascontiguousarray(data['label'])).to(dev),
+        return dict(points=tree._pts(), feat=feat, label=torch.from_numpy(np.ascontiguousarray(data['label'])).to(dev).long(),
                     possibility=torch.from_numpy(self.possibility).to(dev), data=data,
                     dims=tuple(rec.get('dim', [0, 1, 2])) if rec else (), bias=float(nf.get('bias', 0)), scale=float(nf.get('scale', 1)))
 
@@ -430,7 +430,7 @@ class RandLANet(nn.Module):
         inputs['interp_idx'] = [t[0] for t in itp]
         inputs['features'] = feats
         inputs['point_inds'] = sel
-        inputs['labels'] = st['label'][sel.long()].long()
+        inputs['labels'] = st['label'][sel]          # (int64 labels cast once per cloud, int32 index: one gather per patch, not three kernels)
         return inputs
 
     def _min_possibility(self):

@@ -55,3 +55,33 @@ def test_pack_matches_layout_slots():
     for t, o in zip(tensors, off[:-1]):
         assert np.array_equal(buf[o:o + t.size], t.reshape(-1).astype(np.float32))
     assert (off % 4 == 0).all()      # 16-byte aligned slots
+
+
+def test_default_batcher_collates_like_the_reference_and_a_batch_of_one_is_a_view():
+    """``DefaultBatcher.collate_fn`` (default_batcher.py:34-85) on what ``RandLANet.transform`` returns: per-level lists of
+    tensors / arrays stacked along a new leading axis, numbers to tensors, strings passed through.  A batch of ONE tensor comes
+    back as a view (no copy kernel per entry), with the values and shape torch.stack would give."""
+    from ml3d.torch.dataloaders import DefaultBatcher
+    rng = np.random.default_rng(0)
+
+    def item(seed):
+        r = np.random.default_rng(seed)
+        return {"data": {"coords": [torch.from_numpy(r.random((n, 3), dtype=np.float32)) for n in (16, 4)],
+                         "neighbor_indices": [torch.from_numpy(r.integers(0, n, (n, 5)).astype(np.int32)) for n in (16, 4)],
+                         "features": r.random((16, 3), dtype=np.float32), "labels": r.integers(0, 5, 16), "point_inds": np.arange(16)},
+                "attr": {"split": "test", "idx": seed}}
+    collate = DefaultBatcher().collate_fn
+    for items in ([item(1)], [item(1), item(2), item(3)]):
+        out = collate(items)
+        B = len(items)
+        assert out["attr"]["split"] == ["test"] * B and out["attr"]["idx"].tolist() == [it["attr"]["idx"] for it in items]
+        for key in ("coords", "neighbor_indices"):
+            for l in range(2):
+                want = torch.stack([it["data"][key][l] for it in items], 0)
+                got = out["data"][key][l]
+                assert got.shape == want.shape and got.dtype == want.dtype and torch.equal(got, want) and got.is_contiguous()
+        assert torch.equal(out["data"]["features"], torch.stack([torch.as_tensor(it["data"]["features"]) for it in items], 0))
+        assert out["data"]["labels"].shape == (B, 16)
+    one = item(7)
+    out = collate([one])
+    assert out["data"]["coords"][0].data_ptr() == one["data"]["coords"][0].data_ptr()          # the view, not a copy
