@@ -415,7 +415,8 @@ pp_collect(const float* __restrict__ box, const float* __restrict__ score, const
 constexpr int TOPK_BINS = 2048;                 // bins of a level's table (level 2 uses the first 1024)
 constexpr int TOPK_CHUNK = 4096;                // elements per workgroup: 256 threads x 16 CONSECUTIVE elements
 
-__device__ __forceinline__ unsigned topk_key(float x) { return x != x ? 0u : ~f2ord(x); }       // ascending key = descending value
+// ascending key = descending value; NaN first; -0.0 and +0.0 are EQUAL values (one key), like every comparison-based top-k
+__device__ __forceinline__ unsigned topk_key(float x) { return x != x ? 0u : ~f2ord(x == 0.f ? 0.f : x); }
 __device__ __forceinline__ int topk_shift(int level) { return level == 0 ? 21 : level == 1 ? 10 : 0; }
 __device__ __forceinline__ unsigned topk_digit(unsigned key, int level) { return (key >> topk_shift(level)) & (level == 2 ? 1023u : 2047u); }
 

@@ -264,6 +264,8 @@ def _topk_cases():
             (np.round(rng.random((4, 9000)) * 20).astype(np.float32) / 20, 300),                   # 21 distinct values: ties everywhere
             (np.zeros((2, 4500), np.float32), 17), (x, 150), (rng.standard_normal((1, 37)).astype(np.float32), 37),
             (rng.standard_normal((5, 4097)).astype(np.float32), 1), (sig, 100), (rng.random((0, 50), dtype=np.float32), 5),
+            (np.where(rng.random((2, 3000)) < 0.5, np.float32(-0.0), np.float32(0.0)) * (rng.random((2, 3000)) < 0.9), 40),   # -0.0 == +0.0
+
             (rng.random((3, 50), dtype=np.float32), 0)]
 
 
