@@ -144,7 +144,8 @@ iou_pairs(const float* __restrict__ A, const float* __restrict__ B, int64_t n, i
 __global__ void nms_keys(const float* __restrict__ scores, int64_t n, u64* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = ((u64)(~f2ord(scores[i])) << 32) | (u64)(uint32_t)i;
+    const float sc = scores[i];
+    keys[i] = ((u64)(~f2ord(sc == 0.f ? 0.f : sc)) << 32) | (u64)(uint32_t)i;      // (-0.0 and +0.0: one score, ties by index)
     vals[i] = (uint32_t)i;
 }
 
@@ -284,7 +285,7 @@ nmsb_order(const float* __restrict__ scores, int64_t n, float score_thr, uint32_
     if (threadIdx.x == 0) cnt = 0;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
         const float sc = scores[p * n + i];
-        keys[i] = sc > score_thr ? (((u64)(~f2ord(sc)) << 32) | (u64)(uint32_t)i) : ~0ull;
+        keys[i] = sc > score_thr ? (((u64)(~f2ord(sc == 0.f ? 0.f : sc)) << 32) | (u64)(uint32_t)i) : ~0ull;
     }
     __syncthreads();
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {

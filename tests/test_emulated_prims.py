@@ -268,6 +268,10 @@ def test_nms_no_boxes_one_box_and_identical_boxes():
     b3 = np.repeat(b, 3, 0)
     keep = emu.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5)
     assert keep.tolist() == oops.nms(b3, np.array([0.1, 0.9, 0.5], np.float32), 0.5).tolist() == [1]
+    # equal scores, among them -0.0 and +0.0 (ONE value): disjoint boxes all survive, in index order
+    far = np.array([[10 * i, 0, 10 * i + 2, 1, 0.1 * i] for i in range(6)], np.float32)
+    sc = np.array([0.0, -0.0, 0.0, -0.0, 0.5, 0.5], np.float32)
+    assert emu.nms(far, sc, 0.5).tolist() == oops.nms(far, sc, 0.5).tolist() == [4, 5, 0, 1, 2, 3]
 
 
 def test_argmax_labels_is_torch_argmax_first_maximum_and_nan():
