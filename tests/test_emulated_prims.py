@@ -378,3 +378,34 @@ def test_pairwise_box_iou_matches_the_oracle_twin():
     i3 = emu.box_iou(pred, tgt, True)
     assert np.array_equal(i3, oops.iou_3d(pred, tgt)) and (i3 <= bev + 1e-6).all()
     assert emu.box_iou(np.zeros((0, 5), np.float32), tgt[:, cols], False).shape == (0, 25)
+
+
+def test_topk_rows_property_random_shapes_and_tie_patterns():
+    """ml3d_topk_rows against the oracle on random (rows, n, k) and value patterns -- continuous, few distinct values, constant,
+    with NaN / inf sprinkled in; n around the 4096-element workgroup chunk and the 16-element thread slice, k up to 4096."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None, derandomize=True)
+    @given(st.integers(1, 3), st.sampled_from([1, 2, 15, 16, 17, 255, 4095, 4096, 4097, 8191, 9000, 20000]),
+           st.integers(0, 2 ** 31 - 1), st.sampled_from(["normal", "few", "const", "special"]), st.floats(0.0, 1.0))
+    def check(rows, n, seed, kind, kfrac):
+        rng = np.random.default_rng(seed)
+        if kind == "normal":
+            v = rng.standard_normal((rows, n)).astype(np.float32)
+        elif kind == "few":
+            v = rng.integers(0, 4, (rows, n)).astype(np.float32) * 0.25
+        elif kind == "const":
+            v = np.full((rows, n), rng.standard_normal(), np.float32)
+        else:
+            v = rng.standard_normal((rows, n)).astype(np.float32)
+            m = rng.random((rows, n))
+            v[m < 0.02] = np.nan
+            v[(m >= 0.02) & (m < 0.04)] = np.inf
+            v[(m >= 0.04) & (m < 0.06)] = -np.inf
+            v[(m >= 0.06) & (m < 0.10)] = -0.0
+            v[(m >= 0.10) & (m < 0.14)] = 0.0
+        k = min(n, 4096, max(0, int(round(kfrac * min(n, 4096)))))
+        idx, val = emu.topk_rows(v, k)
+        assert np.array_equal(idx, oops.topk_rows(v, k)), (rows, n, k, kind, seed)
+        assert np.array_equal(val, np.take_along_axis(v, idx, 1), equal_nan=True)
+    check()
