@@ -175,6 +175,40 @@ print("ok")
 ''')
 
 
+def test_batched_nms_walk_at_the_stage_and_word_boundaries():
+    """``nmsb_reduce`` stages 64 mask rows at a time and a mask word holds 64 candidates: problems with EXACTLY 63 / 64 / 65 / 127 /
+    128 / 129 / 200 participating candidates (class 0: that many anchors above the score threshold, class 1: none), boxes drawn
+    so that many overlap -- kept sets and order against the oracle's loop formulation."""
+    _run(r'''
+from oracle import pointpillars_ref as P
+from ml3d.torch.models.point_pillars import PointPillars
+import copy
+cfg = P.SMALL_CFG
+c2 = copy.deepcopy(cfg)
+c2["head"] = dict(c2["head"], nms_pre=256, score_thr=0.5)
+m2 = PointPillars(device="cpu", **c2)
+A, C = m2.bbox_head.num_anchors, len(c2["classes"])
+H, W = 10, 12
+assert C == 2 and H * W * A > 256
+for nv in (63, 64, 65, 127, 128, 129, 200):
+    rng = np.random.default_rng(nv)
+    cls = np.full((1, A * C, H, W), -8.0, np.float32)
+    flat = cls.reshape(1, A, C, H * W)                               # channel = a * C + c
+    pick = rng.choice(A * H * W, nv, replace=False)
+    flat[0, pick // (H * W), 0, pick % (H * W)] = (0.5 + rng.random(nv) * 4).astype(np.float32)     # distinct scores above 0.5
+    cls = torch.from_numpy(cls)
+    reg = torch.from_numpy((rng.standard_normal((1, A * 7, H, W)) * 0.15).astype(np.float32))       # small deltas: neighbours overlap
+    dr = torch.from_numpy(rng.standard_normal((1, A * 2, H, W)).astype(np.float32))
+    boxes, scores, labels = m2.bbox_head.get_bboxes(cls, reg, dr)
+    rb, rs, rl = P.get_bboxes_single(c2, cls[0], reg[0], dr[0])
+    assert 0 < len(rl) < nv and (rl == 0).all()               # some survive, some are suppressed
+    assert np.array_equal(labels[0].numpy(), rl.numpy()), (nv, len(rl), len(labels[0]))
+    assert np.abs(scores[0].numpy() - rs.numpy()).max() <= 1e-6
+    assert (np.abs(boxes[0].numpy() - rb.numpy()) / np.maximum(1.0, np.abs(rb.numpy()))).max() <= 1e-4
+print("ok")
+''')
+
+
 def test_pointpillars_stream_returns_each_steps_detections_one_step_later():
     """``ml3d.engine.PointPillarsStream`` (what bench.py --workload pointpillars times): upload -> forward -> batched decode +
     NMS -> asynchronous copy back; ``submit`` hands out the previous step's lists, identical to ``get_bboxes`` of a plain
