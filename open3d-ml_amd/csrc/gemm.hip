@@ -662,10 +662,15 @@ size_t gemm_partial_bytes(int64_t M, int N, int K) {
 // residual, and enough 128-row tiles to fill the 256 CUs -- medium problems (the 62 x 54 and 31 x 27 maps of SECOND's deeper
 // blocks at 8 sweeps) fill the chip better with the 64 x 64 tiles of gemm_tile.  Returns the column-tile width to use, 0 = no.
 static int big_bn(int64_t M, int N, int K, const float* Bm, const Epilogue& ep) {
-    // ML3D_GEMM_BIG_MIN_TILES (read once, at the first call): workgroups below which gemm_tile keeps the problem -- a TEST hook:
-    // the emulator tests set 1 to push small problems (of any depth) through this kernel.  Shallow K (RandLA's per-point
-    // Linears, K = 32 .. 128: one or two chunks, nothing to pipeline) stays on gemm_tile.
+    // workgroups below which gemm_tile keeps the problem.  A constant in the product library (no environment reads, no process-wide
+    // state: SURVEY.md §8b); only the HOST EMULATOR build of the tests (-DML3D_TEST_HOOKS, tests/hipemu/build_emu.sh) reads
+    // ML3D_GEMM_BIG_MIN_TILES, once, so that its suites can push small problems (of any depth) through this kernel.  Shallow K
+    // (RandLA's per-point Linears, K = 32 .. 128: one or two chunks, nothing to pipeline) stays on gemm_tile.
+#ifdef ML3D_TEST_HOOKS
     static const int64_t min_tiles = [] { const char* e = getenv("ML3D_GEMM_BIG_MIN_TILES"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+#else
+    constexpr int64_t min_tiles = 256;
+#endif
     const int min_k = min_tiles <= 1 ? 0 : 256;
     if ((N & 3) || (K % GM_KC) != 0 || K < min_k || (((uintptr_t)Bm) & 15) != 0 || ep.res_gather) return 0;
     const int64_t rows = (M + G2_BM - 1) / G2_BM;

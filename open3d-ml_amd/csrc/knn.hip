@@ -357,11 +357,9 @@ __global__ void order_from_grid(const float4* __restrict__ sorted, int64_t n_tot
     out[i] = (int32_t)((i / n_per_item) * n_per_item + (int64_t)__float_as_int(sorted[i].w));
 }
 
-static float tuning_occ() {
-    // tuning knob only (speed, never results); read once, at the first call
-    static const float v = [] { const char* e = getenv("ML3D_KNN_OCC"); return e ? (float)atof(e) : 0.f; }();
-    return v;
-}
+// grid occupancy target handed to grid_build: 0 = the builder's own choice (mean occupancy of the non-empty cells ~4).  A constant:
+// the library reads nothing from the environment and keeps no process-wide state.
+static constexpr float tuning_occ() { return 0.f; }
 
 }  // namespace ml3d
 

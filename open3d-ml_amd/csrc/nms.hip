@@ -61,6 +61,10 @@ __device__ float poly_intersection_area(const P2* A, const P2* B, P2* sh) {
             const P2 ed = {__fsub_rn(p1.x, p0.x), __fsub_rn(p1.y, p0.y)};
             int nn = 0;
             for (int i = 0; i < nc; ++i) {
+                // a vertex appends at most two; convex input never passes 8, but inf / NaN corners can alternate the sign test
+                // (4 -> 6 -> 9 -> 13 -> 19): such a pair has no meaningful overlap -- area 0 (the oracle's rule too) instead of
+                // writing into the other list / the next lane's neighbours in LDS
+                if (nn + 2 > POLY_MAX) return 0.f;
                 const P2 s = cur[i * 64], t = cur[(i + 1 == nc ? 0 : i + 1) * 64];
                 const P2 vs = {__fsub_rn(s.x, p0.x), __fsub_rn(s.y, p0.y)}, vt = {__fsub_rn(t.x, p0.x), __fsub_rn(t.y, p0.y)};
                 const float ds = cross2(ed, vs), dt = cross2(ed, vt);

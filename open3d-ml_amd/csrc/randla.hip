@@ -37,9 +37,10 @@ struct Knobs {
 };
 // The A/B switches of rounds 1-3 are settled (numbers in DESIGN.md §3.3, §9): XCD-aware tile walk, split score Linear, split
 // decoder, decoder-last + fc1 chain and shaped MLP chains are ON wherever their shape conditions hold; the generic VALU kernels
-// and the per-layer launches remain as the fallback for widths / sizes the MFMA kernels do not cover.  One value is still read
-// from the environment, once: ML3D_RANDLA_FUSE_ROWS, the row count from which per-point chains fuse (the emulator tests lower
-// it so that small levels reach the fused kernels).
+// and the per-layer launches remain as the fallback for widths / sizes the MFMA kernels do not cover.  The product library
+// reads nothing from the environment (no process-wide state); only the tests' HOST EMULATOR build
+// (-DML3D_TEST_HOOKS) reads ML3D_RANDLA_FUSE_ROWS, once: the row count from which per-point chains fuse, lowered there so that
+// small levels reach the fused kernels.
 static const Knobs& knobs() {
     static const Knobs k = [] {
         Knobs v;
@@ -48,8 +49,10 @@ static const Knobs& knobs() {
         v.linear = 0;
         v.attn_grid = 2560;
         v.attn16_grid = 4096;
-        const char* e = getenv("ML3D_RANDLA_FUSE_ROWS");
-        v.fuse_rows = e ? atoll(e) : 64 * 1024;
+        v.fuse_rows = 64 * 1024;
+#ifdef ML3D_TEST_HOOKS
+        if (const char* e = getenv("ML3D_RANDLA_FUSE_ROWS")) v.fuse_rows = atoll(e);
+#endif
         return v;
     }();
     return k;
@@ -1762,7 +1765,7 @@ gather_max(const float* __restrict__ feat, const int32_t* __restrict__ nidx, flo
     int64_t r = e / c;
     int64_t b = r / n_out, i = r - b * n_out;
     const int32_t* id = nidx + (b * n_in + i) * RK;
-    float v = -3.0e38f;
+    float v = -__builtin_inff();           // (not a finite seed: a row of -inf features pools to -inf, like torch.max)
 #pragma unroll
     for (int k = 0; k < RK; ++k) v = fmaxf(v, feat[(b * n_in + id[k]) * c + ch]);
     out[r * c + ch] = v;
@@ -1782,7 +1785,8 @@ gather_max4(const float* __restrict__ feat, const int32_t* __restrict__ nidx, fl
     const uint32_t i = order ? (uint32_t)order[(size_t)b * n_out + j] - b * n_out : j;
     const int32_t* id = nidx + ((size_t)b * n_in + i) * RK;
     const float4* base = reinterpret_cast<const float4*>(feat + (size_t)b * n_in * (4 * cv)) + q;
-    float4 v = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    const float ninf = -__builtin_inff();  // (not a finite seed: a row of -inf features pools to -inf, like torch.max)
+    float4 v = make_float4(ninf, ninf, ninf, ninf);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const float4 x = base[(uint32_t)id[k] * cv];
@@ -1802,10 +1806,12 @@ gather_max_adjoint(const float* __restrict__ feat, const int32_t* __restrict__ n
     const int64_t r = e / c;
     const int64_t b = r / n_out, i = r - b * n_out;
     const int32_t* id = nidx + (b * n_in + i) * RK;
-    float v = -3.0e38f;
-    int64_t arg = 0;
+    // the first listed neighbour is the incumbent: a row whose K values are all NaN (or below every finite seed) still sends
+    // its gradient to one of ITS neighbours, like torch.max's backward, never to row 0 of batch item 0
+    int64_t arg = b * n_in + id[0];
+    float v = feat[arg * c + ch];
 #pragma unroll
-    for (int k = 0; k < RK; ++k) {
+    for (int k = 1; k < RK; ++k) {
         const int64_t row = b * n_in + id[k];
         const float x = feat[row * c + ch];
         if (x > v) { v = x; arg = row; }

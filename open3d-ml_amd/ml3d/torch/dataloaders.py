@@ -19,8 +19,12 @@ def _stack(values):
         # test_batch_size 1 (every in-scope YAML's inference batch): a batch of ONE tensor is that tensor with a leading axis --
         # a view, where torch.stack launches a copy kernel per entry (19 per RandLA-Net item: every level's points, neighbour,
         # pooling and interpolation lists).  The transforms hand out freshly allocated tensors, so nothing else writes to them.
-        return values[0].unsqueeze(0)
-    return torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(v) for v in values], 0)
+        out = values[0].unsqueeze(0)
+    else:
+        out = torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(v) for v in values], 0)
+    if all(getattr(v, '_ml3d_prefix_of_neighbors', False) for v in values):
+        out._ml3d_prefix_of_neighbors = True          # RandLANet.transform's mark on sub_idx (models/randlanet.py, _mark_prefix)
+    return out
 
 
 def default_collate(batch):

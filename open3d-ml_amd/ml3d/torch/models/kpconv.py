@@ -350,10 +350,17 @@ class KPFCNN(nn.Module):
             q_pts = pts[L + 1] if strided else pts[L]
             inds = pools[L] if strided else nbrs[L]
             c = p['conv']
-            conv = (lambda xin: ops.kpconv_rigid(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)) \
-                if c['ow'] is None else \
-                (lambda xin: ops.kpconv_deformable(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], c['ow'],
-                                                   c['ob'], 1, lr, infl))
+            if c['ow'] is None:
+                conv = lambda xin: ops.kpconv_rigid(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)
+            else:
+                def conv(xin, m=blk.KPConv):
+                    # the reference sets min_d2 / deformed_KP in EVERY forward, eval included (kpconv.py:1058,1074): its
+                    # validation loss regularises the CURRENT batch.  The fused kernel does not materialise them, so the
+                    # block keeps this call's inputs and `_offset_regulariser` derives the two tensors on demand
+                    m.min_d2 = m.deformed_KP = None
+                    m._geom_inputs = (q_pts, pts[L], inds, xin, infl)
+                    return ops.kpconv_deformable(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], c['ow'],
+                                                 c['ob'], 1, lr, infl)
             if isinstance(blk, SimpleBlock):
                 x = conv(x)
             else:
@@ -458,8 +465,9 @@ class KPFCNN(nn.Module):
         return unary(self.head_softmax, unary(self.head_mlp, x))
 
     @staticmethod
-    def _deformable_train(conv, q_pts, s_pts, inds, x, infl):
-        """One deformable KPConv in training mode (kpconv.py:1011-1066, 1105-1159, linear influence, sum aggregation)."""
+    def _deformable_geometry(conv, q_pts, s_pts, inds, x, infl):
+        """Offsets -> deformed kernel points and their squared distances to the neighbours (kpconv.py:1011-1066): sets
+        ``conv.deformed_KP`` [Nq, K, 3] and ``conv.min_d2`` [Nq, K], returns ([Nq, H, K] squared distances, modulations)."""
         K = conv.K
         oc = conv.offset_conv
         off = ops.KPConvFunction.apply(x, oc.weights, q_pts, s_pts, inds, oc.kernel_points, oc.KP_extent, infl) + conv.offset_bias
@@ -472,6 +480,13 @@ class KPFCNN(nn.Module):
         nb = far[inds.long()] - q_pts.unsqueeze(1)                                        # [Nq, H, 3]
         sq = ((nb.unsqueeze(2) - conv.deformed_KP.unsqueeze(1)) ** 2).sum(3)              # [Nq, H, K]
         conv.min_d2 = sq.min(1)[0]
+        return sq, mod
+
+    @staticmethod
+    def _deformable_train(conv, q_pts, s_pts, inds, x, infl):
+        """One deformable KPConv in training mode (kpconv.py:1011-1066, 1105-1159, linear influence, sum aggregation)."""
+        conv._geom_inputs = None
+        sq, mod = KPFCNN._deformable_geometry(conv, q_pts, s_pts, inds, x, infl)
         w = torch.clamp(1 - torch.sqrt(sq) / conv.KP_extent, min=0.0).transpose(1, 2)     # [Nq, K, H]
         nx = torch.cat([x, torch.zeros_like(x[:1])], 0)[inds.long()]                      # [Nq, H, Cin]
         wf = torch.matmul(w, nx)                                                          # [Nq, K, Cin]
@@ -489,7 +504,12 @@ class KPFCNN(nn.Module):
         for m in self.modules():
             if isinstance(m, KPConv) and m.deformable:
                 if getattr(m, 'min_d2', None) is None:
-                    raise RuntimeError("KPFCNN.get_loss: no training forward has run through the deformable blocks")
+                    geom = getattr(m, '_geom_inputs', None)
+                    if geom is None:
+                        raise RuntimeError("KPFCNN.get_loss: no forward has run through the deformable blocks")
+                    with torch.no_grad():          # an eval-mode forward: the current batch's geometry, no gradient
+                        self._deformable_geometry(m, *geom)
+                    m._geom_inputs = None
                 d2 = m.min_d2 / (m.KP_extent ** 2)
                 fitting = fitting + l1(d2, torch.zeros_like(d2))
                 locs = m.deformed_KP / m.KP_extent
@@ -675,9 +695,9 @@ class KPFCNN(nn.Module):
     def get_loss(self, Loss, results, inputs, device):
         """kpconv.py:315-351: class-weighted cross entropy over the non-ignored points + the point-to-point regulariser of the
         deformable offsets (kpconv.py:2167-2206; zero for rigid architectures), which reads the ``min_d2`` / ``deformed_KP``
-        the TRAINING forward left on the deformable blocks (the fused inference kernels do not materialise them: after an
-        eval-mode forward of a deformable model the regulariser is the one of the last training forward, like on the reference,
-        or refused if there was none)."""
+        of the LAST forward, eval included, as on the reference (kpconv.py:1058,1074): the training forward leaves them on the
+        deformable blocks; the fused inference kernels do not materialise them, so after an eval-mode forward they are
+        derived here, without gradient, from the inputs that forward handed to the block (validation loss of run_train)."""
         from ..modules import valid_scores_and_labels
         cfg = self.cfg
         scores, labels = valid_scores_and_labels(results, inputs['data'].labels, cfg.num_classes, cfg.ignored_label_inds, device)

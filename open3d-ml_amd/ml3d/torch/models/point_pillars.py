@@ -191,7 +191,12 @@ class Anchor3DHead(nn.Module):
         bbox_preds = bbox_preds.permute(1, 2, 0).reshape(-1, self.box_code_size)
         if scores.shape[0] > self.nms_pre:
             max_scores, _ = scores.max(dim=1)
-            topk = ops.topk_rows(max_scores, self.nms_pre)      # HIP radix select; ties by ascending anchor index
+            if self.nms_pre <= 4096:
+                topk = ops.topk_rows(max_scores, self.nms_pre)  # HIP radix select; ties by ascending anchor index
+            else:
+                # beyond the select kernel's 4096 candidates per row (no in-scope YAML: nms_pre tops out at 4096): the same
+                # order -- descending, NaN first, equal scores by ascending anchor -- from a stable device sort
+                topk = torch.sort(max_scores, descending=True, stable=True)[1][:self.nms_pre]
             anchors, bbox_preds, scores, dir_scores = anchors[topk], bbox_preds[topk], scores[topk], dir_scores[topk]
         bboxes = self.decode(anchors, bbox_preds)
         idxs = []

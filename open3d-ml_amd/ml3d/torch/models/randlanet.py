@@ -60,6 +60,13 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+def _mark_prefix(t):
+    """``sub_idx`` as ``transform`` builds it -- the prefix rows of the level's neighbour matrix (randlanet.py:222-223) -- carries
+    this mark so that ``forward`` can skip the device-draining comparison for exactly these tensors and nothing else."""
+    t._ml3d_prefix_of_neighbors = True
+    return t
+
+
 class RandLANet(nn.Module):
 
     def __init__(self, name='RandLANet', num_neighbors=16, num_layers=4, num_points=4096 * 11,
@@ -144,8 +151,9 @@ class RandLANet(nn.Module):
                 # random_sample (randlanet.py:300-327) pools through sub_idx; the kernels take it as the PREFIX of the
                 # level's neighbour matrix, which is what transform builds (randlanet.py:222-223).  Anything else is refused.
                 for l, (sub, nb) in enumerate(zip(inputs['sub_idx'], nbr)):
-                    if sub.is_cuda and sub.dtype == torch.int32 and sub.shape[-2] <= nb.shape[-2]:
-                        continue      # this class's own transform (int32 device lists, prefix views): comparing would drain the GPU
+                    if getattr(sub, '_ml3d_prefix_of_neighbors', False) and sub.shape[-2] <= nb.shape[-2]:
+                        continue      # marked by this class's own transform (prefix views of the device lists; the mark survives
+                        #               this package's batcher only): comparing would drain the GPU.  Any other sub_idx is compared
                     sub = sub.to(dev)
                     if sub.shape[-2] > nb.shape[-2] or not torch.equal(sub.to(torch.int32), nb[..., :sub.shape[-2], :]):
                         raise RuntimeError("RandLANet.forward: sub_idx[%d] is not the prefix of neighbor_indices[%d]" % (l, l))
@@ -331,7 +339,7 @@ class RandLANet(nn.Module):
             n = n // cfg.sub_sampling_ratio[i]
         inputs['coords'] = coords
         inputs['neighbor_indices'] = [t[0] for t in nbr]
-        inputs['sub_idx'] = [nbr[i][0, :pc.shape[0] // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))]
+        inputs['sub_idx'] = [_mark_prefix(nbr[i][0, :pc.shape[0] // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))])
                              for i in range(cfg.num_layers)]
         inputs['interp_idx'] = [t[0] for t in itp]
         inputs['features'] = feat
@@ -426,7 +434,7 @@ class RandLANet(nn.Module):
             n = n // cfg.sub_sampling_ratio[i]
         inputs['coords'] = coords
         inputs['neighbor_indices'] = [t[0] for t in nbr]
-        inputs['sub_idx'] = [nbr[i][0, :k // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))] for i in range(cfg.num_layers)]
+        inputs['sub_idx'] = [_mark_prefix(nbr[i][0, :k // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))]) for i in range(cfg.num_layers)]
         inputs['interp_idx'] = [t[0] for t in itp]
         inputs['features'] = feats
         inputs['point_inds'] = sel

@@ -109,7 +109,16 @@ def deform_main():
                reg_loss=np.float64(float(model.reg_loss)), n_valid=np.int64(len(lab)))
     for k in keep:
         out["grad:" + k] = named[k].grad.numpy()
+    # the reference's validation loop: an EVAL-mode forward (running statistics as the training forward above left them) whose
+    # get_loss regularises the deformed kernel points of THAT forward (kpconv.py:1058,1074 run in eval mode too)
+    model.eval()
+    with torch.no_grad():
+        logits_e = model(batch)
+        model.get_loss(Loss, logits_e, {"data": batch}, "cpu")
+    out.update(eval_logits=logits_e.numpy(), eval_output_loss=np.float64(float(model.output_loss)),
+               eval_reg_loss=np.float64(float(model.reg_loss)))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_kpconv_deform.npz"), **out)
+    print("eval ce", float(model.output_loss), "eval reg", float(model.reg_loss))
     print("deform loss", loss.item(), "ce", float(model.output_loss), "reg", float(model.reg_loss), "grads", len(keep),
           {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:3]})
 

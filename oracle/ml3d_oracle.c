@@ -562,6 +562,7 @@ static float poly_intersection_area(const pt2_t* A, const pt2_t* B) {
         pt2_t ed = {p1.x - p0.x, p1.y - p0.y};
         int nn = 0;
         for (int i = 0; i < nc; ++i) {
+            if (nn + 2 > 16) return 0.f;    /* degenerate (inf / NaN corners): the lists would overflow -- no overlap */
             pt2_t s = cur[i], t = cur[(i + 1) % nc];
             pt2_t vs = {s.x - p0.x, s.y - p0.y}, vt = {t.x - p0.x, t.y - p0.y};
             float ds = cross2(ed, vs), dt = cross2(ed, vt);

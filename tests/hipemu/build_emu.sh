@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 exec 9>"$OUT/.lock"
 flock 9
 SRCS=$(ls "$ROOT"/open3d-ml_amd/csrc/*.hip)
-FLAGS="-std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value -Wno-deprecated-declarations ${HIPEMU_EXTRA}"
+FLAGS="-std=c++17 -O1 -g -fPIC -DML3D_TEST_HOOKS -ffp-contract=off -fno-fast-math -Wno-unused-value -Wno-deprecated-declarations ${HIPEMU_EXTRA}"
 OBJS=""
 RELINK=0
 [ -f "$OUT/libml3d_emu.so" ] || RELINK=1

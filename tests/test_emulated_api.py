@@ -440,6 +440,20 @@ for B, n_in, n_out, C in ((2, 64, 16, 32), (1, 40, 40, 8)):
     out = ops.GatherMaxFunction.apply(f, idx, n_out)
     out.backward(g)
     assert torch.equal(out, ref) and (f.grad - gf_ref).abs().max() <= 1e-5
+# ADVICE r4: a pooled row whose 16 neighbour values are all -inf (or NaN) must send its gradient to one of ITS neighbours
+# (the first listed, like torch.max's backward on ties), never to row 0 of batch item 0
+f = torch.from_numpy(rng.standard_normal((2, 24, 4)).astype(np.float32))
+idx = torch.from_numpy(rng.integers(8, 24, (2, 24, 16)).astype(np.int32))
+f[1, 8:, 2] = float("-inf")
+f = f.requires_grad_(True)
+g = torch.ones((2, 6, 4))
+ref = f[torch.arange(2)[:, None, None], idx[:, :6].long()].max(2)[0]
+ref.backward(g)
+gf_ref = f.grad.clone(); f.grad = None
+out = ops.GatherMaxFunction.apply(f, idx, 6)
+out.backward(g)
+assert torch.equal(out, ref) and torch.equal(f.grad, gf_ref), (f.grad - gf_ref).abs().max()
+assert f.grad[0, 0].abs().sum() == 0 and f.grad[1, :, 2].sum() == 6
 print("ok")
 ''')
 

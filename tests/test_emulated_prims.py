@@ -261,6 +261,31 @@ def test_subsample_empty_input_and_all_points_in_one_voxel():
     assert out[0].shape == (1, 3) and np.array_equal(out[0], ref[0]) and np.asarray(out[1]).tolist() == [1]
 
 
+def test_nms_and_iou_survive_inf_nan_and_duplicate_boxes():
+    """inf / NaN corners can alternate the Sutherland-Hodgman sign test so that a clipped list outgrows its 16 LDS
+    slots (4 -> 6 -> 9 -> 13 -> 19).  Such pairs now count as area 0 in the kernel AND in the oracle: the keep list still
+    equals the oracle's, the IoU matrix of the finite boxes is untouched, nothing is written outside a lane's own slots."""
+    rng = np.random.default_rng(12)
+    n = 96
+    c = rng.random((n, 2), dtype=np.float32) * 6
+    wh = 0.5 + rng.random((n, 2), dtype=np.float32) * 3
+    b = np.concatenate([c - wh / 2, c + wh / 2, (rng.random((n, 1), dtype=np.float32) * 2 - 1) * np.pi], 1).astype(np.float32)
+    b[5] = b[4]; b[17] = b[4]                                   # duplicates
+    b[9, 0] = np.inf; b[21, 2] = -np.inf; b[33, 4] = np.nan     # degenerate corners / angle
+    b[40] = [np.nan, 0, np.inf, 1, 0.3]; b[41] = [0, np.nan, 1, np.inf, np.inf]
+    b[50, :4] = [1e30, -1e30, 3e38, 3e38]
+    s = rng.random(n, dtype=np.float32)
+    for thr in (0.01, 0.3, 0.7):
+        assert np.array_equal(emu.nms(b, s, thr), oops.nms(b, s, thr))
+    # pairwise IoU (centre / size form): rows and columns of finite boxes equal a run without the degenerate ones
+    ctr = np.concatenate([c, wh, b[:, 4:5]], 1).astype(np.float32)
+    bad = np.array([9, 21, 33, 40, 41, 50])
+    ctr[bad] = b[bad]
+    full = emu.box_iou(ctr, ctr, False)
+    good = np.setdiff1d(np.arange(n), bad)
+    assert np.array_equal(full[np.ix_(good, good)], emu.box_iou(ctr[good], ctr[good], False))
+
+
 def test_nms_no_boxes_one_box_and_identical_boxes():
     assert emu.nms(np.zeros((0, 5), np.float32), np.zeros(0, np.float32), 0.5).tolist() == []
     b = np.array([[0, 0, 2, 1, 0.3]], np.float32)

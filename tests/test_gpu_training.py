@@ -203,4 +203,14 @@ def test_deformable_kpfcnn_training_matches_the_reference(golden_dir):
             assert np.abs(have - want).max() <= 2e-3 * float(np.abs(want).max()), (key, float(np.abs(have - want).max()))
             checked += 1
     assert checked == 11
+    # the validation loop of run_train: an EVAL-mode forward (fused inference kernels), then get_loss -- the regulariser must be
+    # the CURRENT batch's (kpconv.py:1058,1074 set min_d2 / deformed_KP in eval mode too), not the training forward's 7.0
+    m.eval()
+    with torch.no_grad():
+        logits_e = m(batch)
+        m.get_loss(loss_obj, logits_e, {"data": batch}, "cuda:0")
+    assert np.abs(logits_e.cpu().numpy() - g["eval_logits"]).max() <= 1e-4 * max(1.0, float(np.abs(g["eval_logits"]).max()))
+    assert abs(float(m.output_loss) - float(g["eval_output_loss"])) <= 1e-5
+    assert abs(float(m.reg_loss) - float(g["eval_reg_loss"])) <= 1e-4 * float(g["eval_reg_loss"])
+    assert abs(float(g["eval_reg_loss"]) - float(g["reg_loss"])) > 1.0          # (the two really differ on this fixture)
 
