@@ -91,6 +91,16 @@ def knn_bytes(cfg, n_levels, batch):
     return tot * batch
 
 
+def _sq(kernel_key):
+    """VALU-issue roofline of a kernel from the committed SQ counter pass (profiles/traffic.json "sq", tools/make_traffic.py --sq):
+    SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles; None if not collected."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return tj["sq"][kernel_key]
+    except Exception:
+        return None
+
+
 def _traffic(kernel_key, batch):
     """HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json: per-frame figures)."""
     try:
@@ -282,19 +292,21 @@ def device_identity(dev):
                                       getattr(pr, "pci_device_id", 0))
 
 
-def ranks_seen(dev, world, dist, stub=False):
-    """{"world_size", "devices"}: the process group's own view of the job (every rank's device identity, all-gathered).
+def ranks_seen(dev, world, dist, stub=False, placement=None):
+    """{"world_size", "devices", "cpu_map"}: the process group's own view of the job (every rank's device identity and host
+    placement -- NUMA node of its GPU, the CPUs it is pinned to, its host thread count -- all-gathered).
     Two ranks on one GPU would share its HBM and CUs and still print n_gpus = N: that is an error here."""
-    me = device_identity(dev)
+    me = (device_identity(dev), placement)
     if world > 1:
-        ids = [None] * world
-        dist.all_gather_object(ids, me)
+        both = [None] * world
+        dist.all_gather_object(both, me)
         ws = dist.get_world_size()
     else:
-        ids, ws = [me], 1
+        both, ws = [me], 1
+    ids = [b[0] for b in both]
     if not stub and len(set(ids)) != len(ids):
         raise SystemExit("bench.py: %d ranks share devices %s -- one process per GPU" % (ws, ids))
-    return {"world_size": int(ws), "devices": ids}
+    return {"world_size": int(ws), "devices": ids, "cpu_map": [b[1] for b in both]}
 
 
 class _HostEvent:
@@ -361,13 +373,25 @@ def main():
         # no torchrun around us: be the launcher (N ranks, one per GPU), never a silent single rank
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], stub=args.stub))
 
-    # host-side glue (collate, small CPU tensor ops) must not fan out over every core of a 256-thread host: an OpenMP
-    # fork-join across 256 threads costs milliseconds per tiny op, and 8 ranks share the node (cpu_baseline runs its own sweep)
-    HOST_THREADS = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)))))
-    torch.set_num_threads(HOST_THREADS)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)))
+    # host placement: every rank is pinned to its own slice of the CPUs of ITS GPU's NUMA node (/sys/bus/pci/devices/<id>/
+    # numa_node), and its host-side glue (collate, small CPU tensor ops, the launches and read-backs of a KPConv batch build --
+    # that step is host-bound) uses at most 16 of them: an OpenMP fork-join across a 256-thread host costs milliseconds per
+    # tiny op, and 8 ranks share the node (cpu_baseline runs its own thread sweep at N = 1)
+    from ml3d import dist as mdist
+    pci = None
+    if not args.stub and torch.cuda.is_available() and torch.cuda.device_count() >= local_world:
+        pci = []
+        for i in range(local_world):
+            pr = torch.cuda.get_device_properties(i)
+            pci.append("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                             getattr(pr, "pci_device_id", 0)))
+    placement = mdist.bind_rank(local, local_world, pci)
+    HOST_THREADS = placement["host_threads"]
+    torch.set_num_threads(HOST_THREADS)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     stub = args.stub
@@ -382,11 +406,10 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
-    from ml3d import dist as mdist
     if world > 1:
         import torch.distributed as dist
         mdist.init("gloo" if stub else "nccl", dev)
-    seen = ranks_seen(dev, world, dist, stub)
+    seen = ranks_seen(dev, world, dist, stub, placement)
 
     if args.workload != "randlanet":
         import bench_models
@@ -531,9 +554,15 @@ def main():
                               "frac": kb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic("knn_query_multi<16, true>", B),
                               "avg_launch_ms": ms, "bytes_per_launch": kb, "avg_launch_ms_alone": alone.get((kind, tag)),
                               "frac_alone": (kb / (alone[(kind, tag)] * 1e-3) / 1e9 / PEAK_HBM_GBS) if alone.get((kind, tag)) else None,
-                              "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU-issue bound "
-                                      "(738 M wave-instructions per launch, ~410 candidate steps per wave for ~150 candidates "
-                                      "per lane: profiles/r04_pmc_knn_sq.csv), not HBM-bound: DESIGN.md §3.2"})
+                              "note": "algorithmic bytes per SURVEY.md §8d (5.69 MB / frame); the search is VALU-issue bound, "
+                                      "not HBM-bound (valu_frac below; DESIGN.md §3.2)"})
+                sq = _sq("knn_query_multi<16, true>")
+                if sq:
+                    # the bound the kernel actually sits on: SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (PMC pass of the launch alone)
+                    cands[-1]["valu_frac"] = sq.get("valu_frac_of_busy_cycles")
+                    cands[-1]["valu_frac_at_2p4ghz"] = sq.get("valu_frac_at_2p4ghz")
+                    cands[-1]["valu_insts_per_launch"] = sq.get("insts_valu_per_launch")
+                    cands[-1]["valu_source"] = "profiles/%s" % sq.get("source")
             else:
                 layer, stage = tag // 8, tag % 8
                 d = CFG["dim_output"][layer]
@@ -611,6 +640,11 @@ def main():
                 except Exception as e:      # a side measurement must never take the headline line down
                     wl[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["workloads"] = wl
+            # the HBM-bound primitives each side workload timed in ITS timed region (a10 radius search, a11 grid
+            # subsample, a15 voxelize, a17 pillar scatter) join this line's list, so that one line covers all eight components
+            for name in ("kpconv", "pointpillars"):
+                for e in (wl.get(name) or {}).get("roofline_other", []) or []:
+                    out["roofline_other"].append(dict(e, workload=name))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

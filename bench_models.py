@@ -12,6 +12,25 @@ import numpy as np
 import torch
 
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def _hbm_entry(component, kernel, nbytes, ms_in, ms_alone, traffic_key, units, note, launches=None, extra=None):
+    """One HBM-bound primitive of SURVEY.md §8(d) as a roofline object: ALGORITHMIC bytes of one batch-size launch / its event
+    time (inside the timed region when there is one, alone otherwise) against the 8 TB/s peak; `traffic` = PMC bytes of the
+    same op run alone (profiles/traffic.json, tools/roofline_ops.py), per launch."""
+    ms = ms_in if ms_in else ms_alone
+    e = {"bound": "hbm", "component": component, "kernel": kernel, "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+         "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": _traffic(traffic_key, units),
+         "avg_launch_ms": ms, "timed": "inside the timed region (co-running streams)" if ms_in else "alone, after the timed region",
+         "avg_launch_ms_alone": ms_alone,
+         "frac_alone": (nbytes / (ms_alone * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms_alone else None,
+         "bytes_per_launch": float(nbytes), "units_per_launch": units, "note": note}
+    if launches is not None:
+        e["launches_timed"] = launches
+    if extra:
+        e.update(extra)
+    return e
 
 
 def _traffic(key, units):
@@ -26,16 +45,35 @@ def _traffic(key, units):
         return None
 
 
+def _rocprof_name(key, default):
+    """the kernel's name as rocprofv3 prints it in the committed PMC pass (profiles/traffic.json), so that the bench line and the
+    profile tables name the same kernel"""
+    import json
+    import os
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+        k = tj["kernels"][key]
+        name = k.get("rocprof_name") or k["rocprof_names"][0]
+        return name.replace("void ml3d::", "").replace("ml3d::", "").split("(")[0]
+    except Exception:
+        return default
+
+
 class _CallTimer:
     """Wraps one function of ml3d.ops and brackets its `which`-th call of every step with HIP events."""
 
-    def __init__(self, ops, name, which):
+    def __init__(self, ops, name, which, method=False):
+        """``method=True``: ``ops`` is a class and ``name`` one of its methods (installed as a plain function so that it binds)"""
         self.ops, self.name, self.which = ops, name, which
         self.orig = getattr(ops, name)
         self.count = 0
         self.events = []
         self.shapes = None
-        setattr(ops, name, self)
+        if method:
+            timer = self
+            setattr(ops, name, lambda *a, **k: timer(*a, **k))
+        else:
+            setattr(ops, name, self)
 
     def new_step(self):
         self.count = 0
@@ -211,10 +249,14 @@ def run_pointpillars(args, rank, world, dev, dist):
     # first lane's forward of every step -- the launch shape the timed path issues (B / lanes sweeps), with the other lane
     # co-running, bracketed by HIP events on the lane's own compute stream (the stream the kernel is launched on)
     timer = None if stub else _CallTimer(ops, "conv2d_nhwc", 1)
+    # the two HBM-bound front-end primitives (a15 voxelize, a16-a17 pillar gather + PFN + canvas scatter), the
+    # first lane's launch of every step, bracketed the same way
+    t_vox = None if stub else _CallTimer(ops, "voxelize", 0)
+    t_pf = None if stub else _CallTimer(ops, "pillar_features", 0)
     timed_step = step
     if timer is not None:
         def timed_step():
-            timer.new_step()
+            timer.new_step(); t_vox.new_step(); t_pf.new_step()
             step()
     dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
@@ -230,20 +272,25 @@ def run_pointpillars(args, rank, world, dev, dist):
                 assert torch.equal(last[0][r], want), "rank %d's detections did not arrive intact" % r
         return _stub_line("pointpillars", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
-    timer.restore()
+    timer.restore(); t_vox.restore(); t_pf.restore()
     in_region = timer.samples_ms()[args.warmup:]            # (the warm-up steps' launches are not part of the figure)
     shapes = timer.shapes
+    vox_in, pf_in = t_vox.samples_ms()[args.warmup:], t_pf.samples_ms()[args.warmup:]
+    vox_shapes, pf_shapes = t_vox.shapes, t_pf.shapes
     # the same convolution ALONE on the GPU, as a whole-batch launch and as a lane-shaped one: what the co-running lane costs it
     clouds = [h.to(dev) for h in hosts]
     alone = {}
+    prim_alone = {}
     for tag, sub in (("lane", clouds[:max(1, B // lanes)] if overlap else clouds), ("batch", clouds)):
         t2 = _CallTimer(ops, "conv2d_nhwc", 1)
+        tv, tp = _CallTimer(ops, "voxelize", 0), _CallTimer(ops, "pillar_features", 0)
         for _ in range(5):
-            t2.new_step()
+            t2.new_step(); tv.new_step(); tp.new_step()
             m(sub)
             torch.cuda.synchronize()
-        t2.restore()
+        t2.restore(); tv.restore(); tp.restore()
         alone[tag] = t2.mean_ms()
+        prim_alone[tag] = (tv.mean_ms(), tp.mean_ms(), tv.shapes, tp.shapes)
     # one sweep at a time, synchronised per sweep: what a detection request sees (upload + voxelize + forward + decode + NMS + D2H)
     lat = []
     for i in range(24):
@@ -273,7 +320,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                       "boxes_last_step": n_boxes[0], "streams": 2 * lanes if overlap else 1, "lanes": lanes if overlap else 1,
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
            "latency_single_sweep_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "sweeps": len(lat)},
-           "roofline": {"bound": "mfma", "kernel": "gemm_tile<ConvLoader> (SECOND block 0, 3x3 %d->%d on %dx%d)" % (x.shape[3], Co, OH, OW),
+           "roofline": {"bound": "mfma", "kernel": "%s (SECOND block 0, 3x3 %d->%d on %dx%d)" % (_rocprof_name("pp_conv3x3_64", "gemm_tile2<ConvLoader2, 64, 32, false>"), x.shape[3], Co, OH, OW),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops,
@@ -284,6 +331,35 @@ def run_pointpillars(args, rank, world, dev, dist):
                         "end_to_end_tflops": e2e_tflops, "end_to_end_frac": e2e_tflops / PEAK_F32_TFLOPS,
                         "end_to_end_note": "68.3 GFLOP per frame (SURVEY.md §8d) x frames/s per GPU: every kernel of the step, "
                                            "H2D, voxelize, decode and NMS included"}}
+    # ---- the HBM-bound front end as roofline objects ------------------------------------------
+    def vox_bytes(shapes):
+        (pts3, *_), v = shapes
+        n, mv, kk = int(pts3.shape[0]), int(v.voxel_coords.shape[0]), int(v.voxel_point_indices.shape[0])
+        # xyz read + (x, y, z) int32 voxel coordinates + int64 row splits + int64 point indices written: what the op's boundary
+        # moves.  (§8d's figure also counts a dense [M, 32, 4] gather -- 512 B per pillar -- that this design never writes: the
+        # pillar kernel gathers straight from the points)
+        return 12.0 * n + 12.0 * mv + 8.0 * (mv + 1) + 8.0 * kk, n, mv, kk
+
+    def pf_bytes(shapes):
+        (pts4, v, *_), canvas = shapes
+        n, mv = int(pts4.shape[0]), int(v.voxel_coords.shape[0])
+        return 16.0 * n + 256.0 * mv + 4.0 * canvas.numel(), n, mv     # §8d: canvas write (54.9 MB per sweep) + 256 B per pillar
+    lane_units = max(1, B // lanes) if overlap else B
+    vb, vn, vm, vk = vox_bytes(vox_shapes)
+    pb, pn, pm = pf_bytes(pf_shapes)
+    va, pa = prim_alone["lane" if overlap else "batch"][:2]
+    other = [
+        _hbm_entry("a15 voxelize (point_pillars.py:328-382)", "vox_* + rs_hist / rs_scatter (hash-free sort voxelize: count + fill)",
+                   vb, float(np.mean(vox_in)) if vox_in else None, va, "pp_voxelize", lane_units,
+                   "%d in-range points -> %d pillars (%d kept points) of %d sweeps in one call; the interval holds the op's one host "
+                   "read-back (pillar count) between count and fill" % (vn, vm, vk, lane_units), len(vox_in)),
+        _hbm_entry("a16-a17 pillar gather + PFN + canvas scatter (point_pillars.py:512-616)",
+                   "pillar_pfn + canvas fill (hipMemsetAsync)", pb, float(np.mean(pf_in)) if pf_in else None, pa,
+                   "pp_pillar_features", lane_units,
+                   "%d pillars of %d sweeps -> NHWC canvas %s: zero fill + one 256-byte row per pillar" %
+                   (pm, lane_units, "x".join(str(int(d)) for d in pf_shapes[1].shape)), len(pf_in)),
+    ]
+    out["roofline_other"] = other
     if not args.no_cpu_baseline and world == 1:
         from oracle import pointpillars_ref as P          # the checker, used here only as the timed CPU baseline
         pts = [torch.from_numpy(c) for c in clouds_np[:1]]
@@ -351,10 +427,18 @@ def run_kpconv(args, rank, world, dev, dist):
     # step's forward, bracketed by HIP events on the stream it is launched on (the pipeline's compute stream), the next batch's
     # build co-running on the other stream
     timer = None if stub else _CallTimer(ops, "kpconv_rigid", 1)
+    # the HBM-bound primitives of the batch build (a10 fixed-radius search, a11 grid subsample): the full-resolution
+    # layer's conv search (gather launch + expand launch) and pooling subsample (count + fill) of every step's build, bracketed
+    # on the build stream, the previous step's forward co-running
+    prim = {} if stub else {"gather": _CallTimer(ops, "radius_plan_dense", 0), "expand": _CallTimer(ops, "radius_fill_dense", 0),
+                            "count": _CallTimer(ops, "grid_subsampling_plan", 0),
+                            "fill": _CallTimer(ops._SubsamplePlan, "fill", 0, method=True)}
     timed_step = step
     if timer is not None:
         def timed_step():
             timer.new_step()
+            for t in prim.values():
+                t.new_step()
             step()
     dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
@@ -371,15 +455,27 @@ def run_kpconv(args, rank, world, dev, dist):
     timer.restore()
     in_region = timer.samples_ms()[max(0, args.warmup - 1):]     # (the pipeline runs a step's forward one submit later)
     shapes = timer.shapes
+    prim_in, prim_shapes = {}, {}
+    for k, t in prim.items():
+        t.restore()
+        prim_in[k], prim_shapes[k] = t.samples_ms()[args.warmup:], t.shapes
     # the same op with nothing else on the GPU: five SEQUENTIAL steps after the timed region
     m(KPConvBatch(pts, lens, cfg, device=dev))           # (untimed: the caller-stream allocator pool is cold after a pipelined run)
     torch.cuda.synchronize()
     t2 = _CallTimer(ops, "kpconv_rigid", 1)
+    prim2 = {"gather": _CallTimer(ops, "radius_plan_dense", 0), "expand": _CallTimer(ops, "radius_fill_dense", 0),
+             "count": _CallTimer(ops, "grid_subsampling_plan", 0), "fill": _CallTimer(ops._SubsamplePlan, "fill", 0, method=True)}
     for _ in range(5):
         t2.new_step()
+        for t in prim2.values():
+            t.new_step()
         m(KPConvBatch(pts, lens, cfg, device=dev))
         torch.cuda.synchronize()
     t2.restore()
+    prim_alone = {}
+    for k, t in prim2.items():
+        t.restore()
+        prim_alone[k] = t.mean_ms()
     # one sphere at a time, synchronised per sphere: upload + batch build (9 read-backs) + forward + arg-max back on the host
     lat = []
     for i in range(24):
@@ -423,6 +519,31 @@ def run_kpconv(args, rank, world, dev, dist):
                         "frac_alone": flops_exec / (t2.mean_ms() * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         # the op's ALGORITHMIC HBM bytes: index matrix + positions + feature rows in, output rows out
                         "algorithmic_bytes_per_launch": 4.0 * nq * H + 12.0 * (nq + s.shape[0]) + 4.0 * cin * s.shape[0] + 4.0 * cout * nq}}
+    # ---- the HBM-bound primitives of the build as roofline objects ------------------------------
+    (rq, rs_, *_), _plan = prim_shapes["gather"]
+    dense = prim_shapes["expand"][1]
+    rnq, rns, rH = int(rq.shape[0]), int(rs_.shape[0]), int(dense.shape[1])
+    rad_bytes = 12.0 * (rnq + rns) + 4.0 * rnq * rH                    # §8d: xyz of queries + supports read, dense int32 rows written
+    (spts, *_), _sp = prim_shapes["count"]
+    pooled = prim_shapes["fill"][1][0]
+    sn, sm = int(spts.shape[0]), int(pooled.shape[0])
+    sub_bytes = 12.0 * sn + 12.0 * sm                                  # §8d: points read, barycentres written
+    mean = lambda xs: float(np.mean(xs)) if xs else None
+    rad_in = (mean(prim_in["gather"]) + mean(prim_in["expand"])) if prim_in["gather"] and prim_in["expand"] else None
+    sub_in = (mean(prim_in["count"]) + mean(prim_in["fill"])) if prim_in["count"] and prim_in["fill"] else None
+    out["roofline_other"] = [
+        _hbm_entry("a10 fixed-radius search -> dense rows (kpconv.py:2002-2034)", "grid build + radius_gather + radius_expand",
+                   rad_bytes, rad_in, prim_alone["gather"] + prim_alone["expand"], "kp_radius_dense", B,
+                   "layer-0 conv search of the batch: %d queries = supports, r = %.3g m -> int32 [%d, %d] padded with the shadow "
+                   "index; two event intervals summed (grid build + gather, then expand): the host read-back of the longest row "
+                   "between them overlaps the subsample's count and is not in the figure" %
+                   (rnq, cfg['first_subsampling_dl'] * cfg['conv_radius'], rnq, rH), len(prim_in["gather"])),
+        _hbm_entry("a11 batch grid subsample (kpconv.py:2037-2164)", "rotate_points + vox_keys + rs_hist / rs_scatter + sub_* (count + fill)",
+                   sub_bytes, sub_in, prim_alone["count"] + prim_alone["fill"], "kp_subsample", B,
+                   "layer-0 pooling grid of the batch: %d points -> %d barycentres at dl = %.3g m on randomly oriented grids; two "
+                   "event intervals summed (count, fill): the read-back of the pooled size between them is not in the figure" %
+                   (sn, sm, 2 * cfg['first_subsampling_dl']), len(prim_in["count"])),
+    ]
     if not args.no_cpu_baseline and world == 1:
         from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline
         sp = spheres[0]

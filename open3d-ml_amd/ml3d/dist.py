@@ -129,3 +129,81 @@ class PredictionGather:
             if w is not None:
                 w.wait()
                 self.pending[i] = None
+
+
+# ---- host placement of the ranks (one process per GPU on a multi-socket node) ---------------------------------------------
+def _parse_cpulist(text):
+    """'0-15,128-143' -> [0..15, 128..143] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(pci_bus_id, sysfs="/sys"):
+    """NUMA node of the PCI function ``dddd:bb:dd.f`` (``/sys/bus/pci/devices/<id>/numa_node``); -1 when the platform does not
+    say (single-socket hosts, containers without sysfs)."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def plan_rank_cpus(local_rank, gpu_nodes, allowed, sysfs="/sys", max_threads=16):
+    """Which CPUs rank ``local_rank`` of ``len(gpu_nodes)`` local ranks should run on.
+
+    ``gpu_nodes[i]`` = NUMA node of local rank i's GPU (-1 = unknown), ``allowed`` = the CPUs this job may use
+    (``os.sched_getaffinity(0)``).  Ranks whose GPUs hang off the same node share that node's allowed CPUs in equal contiguous
+    slices (rank order); ranks with an unknown node split ``allowed`` evenly among ALL ranks instead -- either way no two ranks
+    of a node share a core, and the host threads of a rank (collate, the ~100 small launches and read-backs of a KPConv batch
+    build) stay next to their GPU's memory controller and PCIe root.  Returns (sorted CPU list, numa node, host thread count =
+    min(max_threads, CPUs)).  The reference spawns its ranks without placement (scripts/run_pipeline.py:195-216)."""
+    allowed = sorted(allowed)
+    n = len(gpu_nodes)
+    node = gpu_nodes[local_rank]
+    pool, peers = None, None
+    if node >= 0:
+        try:
+            with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+                on_node = set(_parse_cpulist(f.read()))
+            pool = [c for c in allowed if c in on_node]
+            peers = [i for i in range(n) if gpu_nodes[i] == node]
+        except (OSError, ValueError):
+            pool = None
+    if not pool or len(pool) < len(peers or [0]):
+        node, pool, peers = -1, allowed, list(range(n))
+    k, m = peers.index(local_rank), len(peers)
+    per = max(1, len(pool) // m)
+    mine = pool[k * per:(k + 1) * per] or pool[-1:]
+    return mine, node, max(1, min(int(max_threads), len(mine)))
+
+
+def bind_rank(local_rank, local_world, device_pci_ids=None, sysfs="/sys", max_threads=16):
+    """Pin this process to its slice (``plan_rank_cpus``) with ``os.sched_setaffinity`` and return
+    {"numa_node", "cpus" (cpulist string), "host_threads"} -- the rank -> CPU map bench.py prints in ``ranks_seen``.
+    ``device_pci_ids``: PCI bus id of every LOCAL rank's GPU in rank order (None: unknown, e.g. the CPU dry run)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    nodes = [gpu_numa_node(p, sysfs) if p else -1 for p in (device_pci_ids or [None] * local_world)]
+    cpus, node, threads = plan_rank_cpus(local_rank, nodes, allowed, sysfs, max_threads)
+    if hasattr(os, "sched_setaffinity") and local_world > 1:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    # compress to the kernel's cpulist form
+    runs, start, prev = [], None, None
+    for c in cpus:
+        if start is None:
+            start = prev = c
+        elif c == prev + 1:
+            prev = c
+        else:
+            runs.append((start, prev)); start = prev = c
+    if start is not None:
+        runs.append((start, prev))
+    return {"numa_node": node, "cpus": ",".join("%d" % a if a == b else "%d-%d" % (a, b) for a, b in runs),
+            "host_threads": threads, "bound": local_world > 1}

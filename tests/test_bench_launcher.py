@@ -12,6 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
+for _p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def _run(argv, timeout=300):
@@ -39,6 +42,20 @@ def test_self_launch_two_ranks_over_gloo(workload):
 def test_self_launch_three_ranks_headline():
     out = _line(_run(["--gpus", "3", "--stub", "--steps", "2", "--warmup", "1", "--frames-per-step", "1"]))
     assert out["n_gpus"] == 3 and out["ranks_seen"]["world_size"] == 3 and out["self_launched"] is True
+
+
+def test_self_launch_eight_ranks_are_pinned_to_disjoint_cpus():
+    """The driver's 8-GPU launch shape: eight ranks over gloo, each pinned to its own CPU slice
+    (ml3d.dist.bind_rank; no GPUs here, so the slices are an even split of the allowed CPUs), the map printed in ranks_seen."""
+    out = _line(_run(["--gpus", "8", "--stub", "--steps", "2", "--warmup", "1", "--frames-per-step", "1"], timeout=600))
+    assert out["n_gpus"] == 8 and out["ranks_seen"]["world_size"] == 8 and out["gathered_ranks_checked"] == 8
+    cmap = out["ranks_seen"]["cpu_map"]
+    assert len(cmap) == 8 and all(m["host_threads"] >= 1 and m["bound"] for m in cmap)
+    from ml3d.dist import _parse_cpulist
+    sets = [set(_parse_cpulist(m["cpus"])) for m in cmap]
+    assert all(sets)
+    if len(os.sched_getaffinity(0)) >= 8:              # enough cores: no two ranks share one
+        assert sum(len(x) for x in sets) == len(set().union(*sets))
 
 
 def test_single_rank_stub_needs_no_process_group():

@@ -25,6 +25,26 @@ def tol_for(g, base=1e-4):
     return base * max(1.0, float(g["logit_scale"]) / 16.0) if "logit_scale" in g else base
 
 
+def record(name, **kv):
+    """The MEASURED figures of every YAML (max |delta| of the logits / head maps, label agreement, the margin of every flipped
+    label, unmatched boxes) go to gpurun_out/parity_per_yaml.jsonl on the GPU box; tools/parity_table.py turns the file into
+    profiles/rNN_parity_per_yaml.md (the tolerances below are justified by that table, not by argument)."""
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(HERE))
+    d = os.path.join(root, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_per_yaml.jsonl"), "a") as f:
+        f.write(json.dumps(dict(name=name, **kv)) + "\n")
+
+
+def flips(out2d, ref_argmax):
+    """(agreement, [top1 - top2 margin of OUR logits at every point whose label differs from the reference's])"""
+    am = out2d.argmax(-1)
+    bad = np.nonzero(am.astype(np.int8).reshape(-1) != ref_argmax.reshape(-1))[0]
+    flat = out2d.reshape(-1, out2d.shape[-1])
+    srt = np.sort(flat[bad], axis=1)
+    return float(1.0 - len(bad) / max(1, flat.shape[0])), [float(x) for x in (srt[:, -1] - srt[:, -2])[:50]]
+
+
 def test_all_sixteen_in_scope_configs_have_a_golden():
     fam = [n.split("_")[0] for n in NAMES]
     assert len(NAMES) == 16 and fam.count("randlanet") == 6 and fam.count("kpconv") == 5 and fam.count("pointpillars") == 5
@@ -55,8 +75,12 @@ def test_randlanet_yaml(golden_dir, name):
     out = m({"coords": [t], "features": torch.from_numpy(feats).cuda()})
     torch.cuda.synchronize()
     out = out.cpu().numpy()
-    assert np.abs(out[:, ::64] - g["logits_every64"]).max() <= tol_for(g)
-    assert (out.argmax(-1).astype(np.int8) == g["argmax"]).mean() >= 0.9999
+    err = float(np.abs(out[:, ::64] - g["logits_every64"]).max())
+    agree, margins = flips(out, g["argmax"])
+    record(name, family="randlanet", max_abs_delta=err, tol=tol_for(g), logit_scale=float(g["logit_scale"]) if "logit_scale" in g else None,
+           ref_abs_max=float(np.abs(g["logits_every64"]).max()), label_agreement=agree, flipped_margins=margins, points=int(out.shape[1]))
+    assert err <= tol_for(g)
+    assert agree >= 0.9999
 
 
 def kpconv_inputs(mcfg, g):
@@ -98,8 +122,13 @@ def test_kpconv_yaml(golden_dir, name):
     torch.cuda.synchronize()
     out = out.cpu().numpy()
     deform = any("deformable" in b for b in mcfg["architecture"])
-    assert np.abs(out[::8] - g["logits_every8"]).max() <= tol_for(g) * (2.0 if deform else 1.0)
-    assert (out.argmax(1).astype(np.int8) == g["argmax"]).mean() >= 0.9995
+    err = float(np.abs(out[::8] - g["logits_every8"]).max())
+    agree, margins = flips(out, g["argmax"])
+    record(name, family="kpconv", max_abs_delta=err, tol=tol_for(g) * (2.0 if deform else 1.0),
+           logit_scale=float(g["logit_scale"]) if "logit_scale" in g else None, ref_abs_max=float(np.abs(g["logits_every8"]).max()),
+           label_agreement=agree, flipped_margins=margins, points=int(out.shape[0]), deformable=deform)
+    assert err <= tol_for(g) * (2.0 if deform else 1.0)
+    assert agree >= 0.9995
 
 
 @pytest.mark.parametrize("name", [n for n in NAMES if n.startswith("pointpillars")])
@@ -124,10 +153,12 @@ def test_pointpillars_yaml(golden_dir, name):
     outs = m(In())
     torch.cuda.synchronize()
     s = int(g["stride"])
+    errs = {}
     for nm, t in zip(("cls", "reg", "dir"), outs):
         a = t.cpu().numpy()
         assert list(a.shape) == list(g[nm + "_shape"])
-        assert np.abs(a[:, :, ::s, ::s] - g[nm]).max() <= 1e-4, nm
+        errs[nm] = float(np.abs(a[:, :, ::s, ::s] - g[nm]).max())
+        assert errs[nm] <= 1e-4, nm
         assert abs(a.astype(np.float64).sum() - float(g[nm + "_sum"])) <= 1e-5 * float(g[nm + "_abssum"]) + 1e-3
     # decode + rotated NMS at the YAML's nms_pre / score_thr / per-class thresholds.  The pseudo-trained heads saturate
     # (dozens of anchors at sigmoid = 0.9999999), so the nms_pre cut runs through float32 TIES and head maps that agree to
@@ -151,4 +182,7 @@ def test_pointpillars_yaml(golden_dir, name):
                 miss += 1
         return miss
     budget = max(3, len(rb) // 40)
-    assert unmatched(rb, rs, rl, b, sc, lb) <= budget and unmatched(b, sc, lb, rb, rs, rl) <= budget
+    u1, u2 = unmatched(rb, rs, rl, b, sc, lb), unmatched(b, sc, lb, rb, rs, rl)
+    record(name, family="pointpillars", max_abs_delta=max(errs.values()), head_map_delta=errs, tol=1e-4, boxes_ref=int(len(rb)),
+           boxes_gpu=int(len(b)), unmatched_ref_in_gpu=int(u1), unmatched_gpu_in_ref=int(u2), budget=int(budget))
+    assert u1 <= budget and u2 <= budget

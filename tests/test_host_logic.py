@@ -85,3 +85,39 @@ def test_default_batcher_collates_like_the_reference_and_a_batch_of_one_is_a_vie
     one = item(7)
     out = collate([one])
     assert out["data"]["coords"][0].data_ptr() == one["data"]["coords"][0].data_ptr()          # the view, not a copy
+
+
+def test_rank_placement_follows_the_gpus_numa_nodes(tmp_path):
+    """ml3d.dist.plan_rank_cpus / gpu_numa_node on a fake sysfs: an 8-GPU, 2-socket node (GPUs 0-3 on node 0, 4-7 on node 1, 32
+    CPUs per node of which the job may use all): every rank gets a contiguous quarter of ITS node's CPUs, no overlap, 8 host
+    threads each (the slice is smaller than the 16-thread cap); unknown nodes fall back to an even split of the allowed set."""
+    from ml3d import dist as mdist
+    sysfs = tmp_path / "sys"
+    ids = ["0000:%02x:00.0" % (0x10 + i) for i in range(8)]
+    for i, p in enumerate(ids):
+        d = sysfs / "bus" / "pci" / "devices" / p
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % (i // 4))
+    for n, cl in ((0, "0-15,64-79"), (1, "16-31,80-95")):
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % n)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    nodes = [mdist.gpu_numa_node(p, str(sysfs)) for p in ids]
+    assert nodes == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert mdist.gpu_numa_node("0000:ff:00.0", str(sysfs)) == -1
+    allowed = set(range(96))
+    plans = [mdist.plan_rank_cpus(r, nodes, allowed, str(sysfs)) for r in range(8)]
+    node_cpus = {0: set(mdist._parse_cpulist("0-15,64-79")), 1: set(mdist._parse_cpulist("16-31,80-95"))}
+    seen = set()
+    for r, (cpus, node, threads) in enumerate(plans):
+        assert node == r // 4 and len(cpus) == 8 and threads == 8 and set(cpus) <= node_cpus[node]
+        assert not (seen & set(cpus))
+        seen |= set(cpus)
+    assert plans[0][0] == list(range(0, 8)) and plans[3][0] == list(range(72, 80))
+    # the job is confined to 16 CPUs of node 0 only (a cgroup): ranks of node 1 have no CPU there -> even split of what is allowed
+    few = set(range(16))
+    cpus, node, threads = mdist.plan_rank_cpus(5, nodes, few, str(sysfs))
+    assert node == -1 and cpus == [10, 11] and threads == 2
+    # no NUMA information at all (containers, the CPU dry run): even split, 16-thread cap
+    cpus, node, threads = mdist.plan_rank_cpus(1, [-1, -1], set(range(64)), str(sysfs))
+    assert node == -1 and cpus == list(range(32, 64)) and threads == 16

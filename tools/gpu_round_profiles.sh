@@ -32,10 +32,25 @@ pmc kp_fetch FETCH_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py kp 4
 pmc kp_write WRITE_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py kp 4
 pmc pp_fetch FETCH_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py pp 4
 pmc pp_write WRITE_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py pp 4
+prim() {    # traffic.json key, roofline_ops mode: FETCH / WRITE passes of one primitive alone -> its traffic entry
+  local key=$1 mode=$2
+  pmc ${mode}_fetch FETCH_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py $mode 4
+  pmc ${mode}_write WRITE_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py $mode 4
+  PRIM_ARGS="$PRIM_ARGS $key:$mode"
+}
+PRIM_ARGS=""
+prim kp_radius_dense radius
+prim kp_subsample subsample
+prim pp_voxelize voxelize
+prim pp_pillar_features pillars
 pmc knn_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_WAVES" python $GRAFT_REPO_ROOT/tools/knn_only.py 3
 cp profiles/traffic.json /tmp/traffic_before.json
 python tools/make_traffic.py $OUT/${TAG}_pmc_fetch.csv $OUT/${TAG}_pmc_write.csv 64
 python tools/make_traffic.py --op kpconv_block_32_32 $OUT/${TAG}_pmc_kp_fetch.csv $OUT/${TAG}_pmc_kp_write.csv
 python tools/make_traffic.py --op pp_conv3x3_64 $OUT/${TAG}_pmc_pp_fetch.csv $OUT/${TAG}_pmc_pp_write.csv
+for kv in $PRIM_ARGS; do
+  python tools/make_traffic.py --prim ${kv%%:*} $OUT/${TAG}_pmc_${kv##*:}_fetch.csv $OUT/${TAG}_pmc_${kv##*:}_write.csv 5
+done
+python tools/make_traffic.py --sq "knn_query_multi<16, true>" $OUT/${TAG}_pmc_knn_sq.csv
 cp profiles/traffic.json $OUT/traffic.json
 ls -la $OUT

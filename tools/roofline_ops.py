@@ -3,7 +3,11 @@ attributes HBM traffic to it alone.  usage: python tools/roofline_ops.py kp|pp [
   kp  the first resnet block's KPConv of the 64-sphere Toronto3D batch (32 -> 32 channels, 640 000 queries): kp_agg_gemm32
       (aggregation + product in one kernel), the op bench_models.run_kpconv times as `kpconv_rigid` call #1
   pp  SECOND's second convolution of 16 KITTI sweeps (3x3, 64 -> 64, stride 1, 248 x 216): bench_models.run_pointpillars's
-      `conv2d_nhwc` call #1"""
+      `conv2d_nhwc` call #1
+  radius | subsample | voxelize | pillars   the four HBM-bound primitives of SURVEY.md §8(d) at the batch shapes of the bench
+      (64 Toronto3D spheres: layer-0 conv search r = 0.2 m / layer-0 pooling grid 0.16 m; 8 KITTI sweeps = one lane's launch:
+      voxelize / pillar gather + PFN + canvas scatter), each ALONE in the process, `launches` times after its inputs are on
+      the device -- the `roofline_other` entries of `bench.py --workload kpconv | pointpillars`"""
 import os
 import sys
 
@@ -35,6 +39,45 @@ if which == "kp":
     run = lambda: ops.kpconv_rigid(batch.points[0], batch.points[0], batch.neighbors[0], x, c['kp'], c['w'], c['b'], c['extent'],
                                    1, 0.2, 1)
     units = 64
+elif which in ("radius", "subsample"):
+    spheres = [synth_data.toronto3d_sphere(i) for i in range(64)]
+    lens = [len(s) for s in spheres]
+    pts = torch.from_numpy(np.concatenate(spheres)).to(dev)
+    units = 64
+    if which == "radius":
+        run = lambda: ops.radius_neighbors_dense(pts, pts, lens, lens, 0.2)
+    else:
+        from ml3d.torch.models.kpconv import random_grid_rotations
+        np.random.seed(0)
+        R = torch.from_numpy(random_grid_rotations(64)).to(dev)
+        run = lambda: ops.batch_grid_subsampling(pts, lens, 0.16, R)
+elif which in ("voxelize", "pillars"):
+    from ml3d.torch.models.point_pillars import PointPillars
+    cfg = W.POINTPILLARS_KITTI_CFG
+    m = PointPillars(device=dev, **cfg)
+    m.load_state_dict(W.pointpillars_state_dict(cfg, 2024))
+    clouds = [torch.from_numpy(W.crop_for_cfg(synth_data.kitti_sweep(i), cfg)).to(dev) for i in range(8)]
+    units = 8
+    name = "voxelize" if which == "voxelize" else "pillar_features"
+    calls, origs = {}, {}
+
+    class _Captured(Exception):
+        pass
+    for nm in ("voxelize", "pillar_features"):          # the model's own call, captured with its arguments; the forward stops there
+        origs[nm] = getattr(ops, nm)                     # (nothing downstream of the op runs in this process: its PMC pass sees the op alone)
+        def grab(*a, _n=nm, **k):
+            if _n == name:
+                calls[_n] = (a, k)
+                raise _Captured()
+            return origs[_n](*a, **k)
+        setattr(ops, nm, grab)
+    try:
+        m(clouds)
+    except _Captured:
+        pass
+    torch.cuda.synchronize()
+    a, k = calls[name]
+    run = lambda: origs[name](*a, **k)
 else:
     x = torch.randn((16, 248, 216, 64), device=dev)
     w = torch.randn((9 * 64, 64), device=dev) * 0.05
@@ -51,3 +94,5 @@ for _ in range(reps):
     torch.cuda.synchronize()
     ts.append(ev[0].elapsed_time(ev[1]))
 print("%s: %d units per launch, median %.4f ms over %d launches" % (which, units, float(np.median(ts)), reps))
+# (for tools/make_traffic.py --op: the op ran reps + 1 times in this process)
+print("LAUNCHES %d" % (reps + 1))

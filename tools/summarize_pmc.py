@@ -12,6 +12,15 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
         a = acc[(r["Kernel_Name"], r["Counter_Name"])]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
+# the same pass's kernel trace (rocprofv3 --kernel-trace --pmc ...): mean duration per kernel, as a pseudo counter DURATION_NS
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        try:
+            a = acc[(r["Kernel_Name"], "DURATION_NS")]
+            a[0] += 1
+            a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        except (KeyError, ValueError):
+            break
 with open(sys.argv[2], "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
