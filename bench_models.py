@@ -403,7 +403,7 @@ def run_kpconv(args, rank, world, dev, dist):
         pts = host_pts.to(dev)
         np.random.seed(0)
         from ml3d.engine import KPConvPipeline
-        pipe = KPConvPipeline(m, cfg, dev)
+        pipe = KPConvPipeline(m, cfg, dev, threaded=bool(int(os.environ.get("ML3D_KP_THREADED", "0"))))
 
     def finish(res):
         if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)
@@ -428,17 +428,23 @@ def run_kpconv(args, rank, world, dev, dist):
     # build co-running on the other stream
     timer = None if stub else _CallTimer(ops, "kpconv_rigid", 1)
     # the HBM-bound primitives of the batch build (a10 fixed-radius search, a11 grid subsample): the full-resolution
-    # layer's conv search (gather launch + expand launch) and pooling subsample (count + fill) of every step's build, bracketed
-    # on the build stream, the previous step's forward co-running
-    prim = {} if stub else {"gather": _CallTimer(ops, "radius_plan_dense", 0), "expand": _CallTimer(ops, "radius_fill_dense", 0),
-                            "count": _CallTimer(ops, "grid_subsampling_plan", 0),
-                            "fill": _CallTimer(ops._SubsamplePlan, "fill", 0, method=True)}
+    # layer's conv search (grid build + gather, then expand) and pooling subsample (count, then fill) of every step's build,
+    # bracketed by HIP events the one-call build records on ITS stream (ML3DKpBatchDesc.trace_events), the previous step's
+    # forward co-running
+    from ml3d.ops import search as _search
+    prim_ev = []
+
+    def new_trace():
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        for e in evs:
+            e.record()                   # materialises the hipEvent_t handles
+        _search.KPBATCH_TRACE = evs
+        return evs
     timed_step = step
     if timer is not None:
         def timed_step():
             timer.new_step()
-            for t in prim.values():
-                t.new_step()
+            prim_ev.append(new_trace())
             step()
     dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
@@ -455,27 +461,30 @@ def run_kpconv(args, rank, world, dev, dist):
     timer.restore()
     in_region = timer.samples_ms()[max(0, args.warmup - 1):]     # (the pipeline runs a step's forward one submit later)
     shapes = timer.shapes
-    prim_in, prim_shapes = {}, {}
-    for k, t in prim.items():
-        t.restore()
-        prim_in[k], prim_shapes[k] = t.samples_ms()[args.warmup:], t.shapes
+    _search.KPBATCH_TRACE = None
+
+    def prim_ms(evs):
+        """(conv search ms, subsample ms) of one build from its 8 events: two intervals each (the size read-back between a
+        search's gather and its expand, between the subsample's count and its fill, is not in the figure)"""
+        try:
+            return (evs[0].elapsed_time(evs[1]) + evs[2].elapsed_time(evs[3]), evs[4].elapsed_time(evs[5]) + evs[6].elapsed_time(evs[7]))
+        except Exception:
+            return None
+    prim_in = [x for x in (prim_ms(e) for e in prim_ev[args.warmup:]) if x]
     # the same op with nothing else on the GPU: five SEQUENTIAL steps after the timed region
     m(KPConvBatch(pts, lens, cfg, device=dev))           # (untimed: the caller-stream allocator pool is cold after a pipelined run)
     torch.cuda.synchronize()
     t2 = _CallTimer(ops, "kpconv_rigid", 1)
-    prim2 = {"gather": _CallTimer(ops, "radius_plan_dense", 0), "expand": _CallTimer(ops, "radius_fill_dense", 0),
-             "count": _CallTimer(ops, "grid_subsampling_plan", 0), "fill": _CallTimer(ops._SubsamplePlan, "fill", 0, method=True)}
+    alone_ev = []
     for _ in range(5):
         t2.new_step()
-        for t in prim2.values():
-            t.new_step()
-        m(KPConvBatch(pts, lens, cfg, device=dev))
+        alone_ev.append(new_trace())
+        last_batch = KPConvBatch(pts, lens, cfg, device=dev)
+        m(last_batch)
         torch.cuda.synchronize()
     t2.restore()
-    prim_alone = {}
-    for k, t in prim2.items():
-        t.restore()
-        prim_alone[k] = t.mean_ms()
+    _search.KPBATCH_TRACE = None
+    prim_alone = [x for x in (prim_ms(e) for e in alone_ev) if x]
     # one sphere at a time, synchronised per sphere: upload + batch build (9 read-backs) + forward + arg-max back on the host
     lat = []
     for i in range(24):
@@ -520,29 +529,27 @@ def run_kpconv(args, rank, world, dev, dist):
                         # the op's ALGORITHMIC HBM bytes: index matrix + positions + feature rows in, output rows out
                         "algorithmic_bytes_per_launch": 4.0 * nq * H + 12.0 * (nq + s.shape[0]) + 4.0 * cin * s.shape[0] + 4.0 * cout * nq}}
     # ---- the HBM-bound primitives of the build as roofline objects ------------------------------
-    (rq, rs_, *_), _plan = prim_shapes["gather"]
-    dense = prim_shapes["expand"][1]
-    rnq, rns, rH = int(rq.shape[0]), int(rs_.shape[0]), int(dense.shape[1])
+    rnq = rns = int(last_batch.points[0].shape[0])
+    rH = int(last_batch.neighbors[0].shape[1])
     rad_bytes = 12.0 * (rnq + rns) + 4.0 * rnq * rH                    # §8d: xyz of queries + supports read, dense int32 rows written
-    (spts, *_), _sp = prim_shapes["count"]
-    pooled = prim_shapes["fill"][1][0]
-    sn, sm = int(spts.shape[0]), int(pooled.shape[0])
+    sn, sm = rnq, int(last_batch.points[1].shape[0])
     sub_bytes = 12.0 * sn + 12.0 * sm                                  # §8d: points read, barycentres written
-    mean = lambda xs: float(np.mean(xs)) if xs else None
-    rad_in = (mean(prim_in["gather"]) + mean(prim_in["expand"])) if prim_in["gather"] and prim_in["expand"] else None
-    sub_in = (mean(prim_in["count"]) + mean(prim_in["fill"])) if prim_in["count"] and prim_in["fill"] else None
+    col = lambda rows, i: float(np.mean([r[i] for r in rows])) if rows else None
+    out["build"] = {"library_calls": 1, "host_syncs_per_batch": int(getattr(last_batch, "host_syncs", -1)),
+                    "note": "ml3d_kpconv_batch_build: the 5-layer chain (13 radius searches, 4 grid subsamplings) enqueued from C++, "
+                            "one blocking size read-back per layer"}
     out["roofline_other"] = [
         _hbm_entry("a10 fixed-radius search -> dense rows (kpconv.py:2002-2034)", "grid build + radius_gather + radius_expand",
-                   rad_bytes, rad_in, prim_alone["gather"] + prim_alone["expand"], "kp_radius_dense", B,
+                   rad_bytes, col(prim_in, 0), col(prim_alone, 0), "kp_radius_dense", B,
                    "layer-0 conv search of the batch: %d queries = supports, r = %.3g m -> int32 [%d, %d] padded with the shadow "
                    "index; two event intervals summed (grid build + gather, then expand): the host read-back of the longest row "
-                   "between them overlaps the subsample's count and is not in the figure" %
-                   (rnq, cfg['first_subsampling_dl'] * cfg['conv_radius'], rnq, rH), len(prim_in["gather"])),
-        _hbm_entry("a11 batch grid subsample (kpconv.py:2037-2164)", "rotate_points + vox_keys + rs_hist / rs_scatter + sub_* (count + fill)",
-                   sub_bytes, sub_in, prim_alone["count"] + prim_alone["fill"], "kp_subsample", B,
+                   "between them is not in the figure" %
+                   (rnq, cfg['first_subsampling_dl'] * cfg['conv_radius'], rnq, rH), len(prim_in)),
+        _hbm_entry("a11 batch grid subsample (kpconv.py:2037-2164)", "rotate_points + sub_keys + rs_hist / rs_scatter + sub_* (count + fill)",
+                   sub_bytes, col(prim_in, 1), col(prim_alone, 1), "kp_subsample", B,
                    "layer-0 pooling grid of the batch: %d points -> %d barycentres at dl = %.3g m on randomly oriented grids; two "
-                   "event intervals summed (count, fill): the read-back of the pooled size between them is not in the figure" %
-                   (sn, sm, 2 * cfg['first_subsampling_dl']), len(prim_in["count"])),
+                   "event intervals summed (rotation + count, fill + rotation back): the read-back of the pooled size between them "
+                   "is not in the figure" % (sn, sm, 2 * cfg['first_subsampling_dl']), len(prim_in)),
     ]
     if not args.no_cpu_baseline and world == 1:
         from oracle import kpconv_ref as K                # the checker, used here only as the timed CPU baseline

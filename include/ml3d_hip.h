@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 7
+#define ML3D_ABI_VERSION 8
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -204,6 +204,63 @@ int ml3d_subsample_fill(const float* points, const float* features, int64_t feat
 int ml3d_rotate_points(const float* points, const int64_t* row_splits, int64_t batch,
                        int64_t n_points, const float* rotations, int transpose, float* out,
                        void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* The WHOLE batch build of KPConv segmentation inference in one call          */
+/*   replaces the per-layer loop of KPConvBatch.segmentation_inputs            */
+/*   (ml3d/torch/dataloaders/concat_batcher.py:186-305): per layer l the conv  */
+/*   neighbours (radius[l]), the pooled points (grid dl[l], optionally on a    */
+/*   rotated grid: kpconv.py:2059-2110), the pool neighbours (radius[l]) and   */
+/*   the upsample neighbours (2 radius[l]) as dense int32 matrices padded with */
+/*   the shadow index, exactly what ml3d_radius_dense_gather / _expand,        */
+/*   ml3d_subsample_count / _fill and ml3d_rotate_points produce layer by      */
+/*   layer -- enqueued from C++ with ONE blocking size read-back per layer.    */
+/* Layers 0 .. num_layers - 2 pool; the last one only has its conv search.     */
+/*  points [n_points,3] (device), lengths_host int64[batch] (HOST),            */
+/*  rotations: num_layers - 1 device pointers to float32 [batch,3,3] (or NULL  */
+/*   / NULL entries: axis-aligned grids).                                      */
+/*  arena (device, caller-owned): pooled points and matrices are placed in it  */
+/*   as their sizes become known; `out` (HOST) gets byte offsets into it       */
+/*   (-1: empty / layer 0's points are the caller's), rows and columns.        */
+/*   out_lengths_host int32[num_layers * batch] (HOST): per-item point counts. */
+/*  host_scratch: PINNED host memory (ml3d_kpconv_batch_host_scratch_bytes).   */
+/* Returns 0, ML3D_E_WORKSPACE (arena too small: out->arena_used = bytes        */
+/* needed so far -- retry with a larger arena), ML3D_KPBATCH_FALLBACK (a row   */
+/* longer than desc->cap: use the two-phase per-layer searches for this batch) */
+/* or another negative error.  Results identical to the per-layer calls.       */
+/* ------------------------------------------------------------------------- */
+#define ML3D_KPBATCH_MAX_LAYERS 8
+#define ML3D_KPBATCH_FALLBACK 1
+typedef struct {
+    int32_t num_layers;
+    int32_t cap;                                   /* stash width of the one-traversal search (<= 256; 128 in the Python path) */
+    int32_t has_conv[ML3D_KPBATCH_MAX_LAYERS];     /* the layer has convolution blocks (concat_batcher.py:219-234)            */
+    float radius[ML3D_KPBATCH_MAX_LAYERS];         /* conv / pool radius of layer l (the upsample search uses 2 radius[l])     */
+    float dl[ML3D_KPBATCH_MAX_LAYERS];             /* pooling grid of layer l (unused for the last layer)                      */
+    /* optional hipEvent_t handles (NULL: off) recorded on `stream` around four pieces of LAYER 0, for measurement:            */
+    /* [0,1] conv search (grid build + gather)  [2,3] its expand  [4,5] subsampling count (+ rotation)  [6,7] subsampling fill */
+    void* trace_events[8];
+} ML3DKpBatchDesc;
+typedef struct {
+    int64_t n_points, points_offset;               /* level l: rows, byte offset of float32 [n,3] in the arena (-1: layer 0)   */
+    int64_t conv_offset, conv_cols;                /* int32 [n_points, conv_cols]                                              */
+    int64_t pool_offset, pool_cols;                /* int32 [n_points of level l+1, pool_cols]                                 */
+    int64_t up_offset, up_cols;                    /* int32 [n_points, up_cols]                                                */
+} ML3DKpLayerOut;
+typedef struct {
+    int32_t num_layers, host_syncs;
+    int64_t arena_used;
+    ML3DKpLayerOut layer[ML3D_KPBATCH_MAX_LAYERS];
+} ML3DKpBatchOut;
+
+size_t ml3d_kpconv_batch_workspace_bytes(int64_t n_points, int64_t batch, int num_layers, int cap);
+size_t ml3d_kpconv_batch_host_scratch_bytes(int64_t batch, int num_layers);
+int ml3d_kpconv_batch_build(const float* points, const int64_t* lengths_host, int64_t batch,
+                            int64_t n_points, const ML3DKpBatchDesc* desc,
+                            const float* const* rotations, void* arena, size_t arena_bytes,
+                            ML3DKpBatchOut* out, int32_t* out_lengths_host, void* workspace,
+                            size_t workspace_bytes, void* host_scratch, size_t host_scratch_bytes,
+                            void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* KPConv (rigid) inference blocks — BatchNorm folded by the caller            */

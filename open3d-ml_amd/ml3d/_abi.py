@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 7          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 8          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -36,6 +36,7 @@ SYMBOLS = [
     "ml3d_subsample_count",
     "ml3d_subsample_fill",
     "ml3d_rotate_points",
+    "ml3d_kpconv_batch_workspace_bytes", "ml3d_kpconv_batch_host_scratch_bytes", "ml3d_kpconv_batch_build",
     "ml3d_kpconv_workspace_bytes",
     "ml3d_kpconv_rigid", "ml3d_kpconv_deformable", "ml3d_kpconv_weighted", "ml3d_kpconv_weighted_backward",
     "ml3d_linear_workspace_bytes",
@@ -137,6 +138,12 @@ def bind(lib):
     lib.ml3d_subsample_fill.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.ml3d_rotate_points.restype = C.c_int
     lib.ml3d_rotate_points.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
+    lib.ml3d_kpconv_batch_workspace_bytes.restype = sz
+    lib.ml3d_kpconv_batch_workspace_bytes.argtypes = [i64, i64, i32, i32]
+    lib.ml3d_kpconv_batch_host_scratch_bytes.restype = sz
+    lib.ml3d_kpconv_batch_host_scratch_bytes.argtypes = [i64, i32]
+    lib.ml3d_kpconv_batch_build.restype = C.c_int
+    lib.ml3d_kpconv_batch_build.argtypes = [vp, vp, i64, i64, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp]
     lib.ml3d_kpconv_workspace_bytes.restype = sz
     lib.ml3d_kpconv_workspace_bytes.argtypes = [i64, i32, i32, i32]
     lib.ml3d_kpconv_rigid.restype = C.c_int
@@ -293,3 +300,24 @@ def ptr_table(ptrs):
     """HOST array of device pointers (kept alive by the caller)."""
     arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs])
     return arr
+
+
+# ---- ml3d_kpconv_batch_build (include/ml3d_hip.h): the host-side structs ---------------------------------------------------
+KPBATCH_MAX_LAYERS = 8
+KPBATCH_FALLBACK = 1
+
+
+class KpBatchDesc(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("cap", C.c_int32), ("has_conv", C.c_int32 * KPBATCH_MAX_LAYERS),
+                ("radius", C.c_float * KPBATCH_MAX_LAYERS), ("dl", C.c_float * KPBATCH_MAX_LAYERS),
+                ("trace_events", C.c_void_p * 8)]
+
+
+class KpLayerOut(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("points_offset", C.c_int64), ("conv_offset", C.c_int64), ("conv_cols", C.c_int64),
+                ("pool_offset", C.c_int64), ("pool_cols", C.c_int64), ("up_offset", C.c_int64), ("up_cols", C.c_int64)]
+
+
+class KpBatchOut(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("host_syncs", C.c_int32), ("arena_used", C.c_int64),
+                ("layer", KpLayerOut * KPBATCH_MAX_LAYERS)]

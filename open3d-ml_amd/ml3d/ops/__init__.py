@@ -9,7 +9,7 @@ All kernels are enqueued on torch's CURRENT stream.
 from ._gates import KnnResult, RadiusResult, VoxelizeResult   # noqa: F401
 from .search import (knn_search, pyramid_sizes, randla_knn_pyramid, resolve_plans, fixed_radius_search,   # noqa: F401
                      radius_plan_dense, radius_fill_dense, radius_neighbors_dense, ragged_to_dense, _RadiusPlan,
-                     _DenseRadiusPlan)
+                     _DenseRadiusPlan, kpconv_batch_build)
 from .randla import randla_forward, GatherMaxFunction, AttentivePoolFunction   # noqa: F401
 from .voxel import (voxelize, subsample_batch, subsample, rotate_points, grid_subsampling_plan,   # noqa: F401
                     batch_grid_subsampling, _SubsamplePlan)

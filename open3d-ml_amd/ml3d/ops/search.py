@@ -304,3 +304,113 @@ def ragged_to_dense(values, row_splits, out_col_size, default_value):
                                       out.data_ptr(), _stream())
     _abi.check(rc, "ml3d_ragged_to_dense")
     return out
+
+
+# ---- the whole KPConv batch build in one library call (ml3d_kpconv_batch_build) --------------------------------------------
+_ARENA_HINT = {}        # (device, 2^k bucket of n_points) -> arena bytes the last build of that size class needed (a sizing hint)
+_PINNED = {}            # (device, stream, bytes bucket) -> pinned host scratch for the size read-backs, reused across batches
+
+
+class KpBatchArena:
+    """Result of ``kpconv_batch_build``: the arena tensor (device uint8) + typed views into it, per layer."""
+
+    def __init__(self, arena, out, lengths, points0, has_conv):
+        self.arena, self.host_syncs = arena, int(out.host_syncs)
+        self.points, self.neighbors, self.pools, self.upsamples, self.lengths = [], [], [], [], []
+        dev = arena.device
+        e_i = torch.empty((0, 1), dtype=torch.int32, device=dev)
+
+        def view(off, rows, cols, dtype):
+            n = int(rows) * int(cols)
+            return arena[int(off):int(off) + 4 * n].view(dtype).view(int(rows), int(cols))
+        L = int(out.num_layers)
+        for l in range(L):
+            o = out.layer[l]
+            self.points.append(points0 if l == 0 else view(o.points_offset, o.n_points, 3, torch.float32))
+        for l in range(L):
+            o = out.layer[l]
+            n, n_next = int(o.n_points), (int(out.layer[l + 1].n_points) if l + 1 < L else 0)
+            if o.conv_offset >= 0:
+                self.neighbors.append(view(o.conv_offset, n, o.conv_cols, torch.int32))
+            elif has_conv[l]:       # a level of 0 points or rows of 0 columns: the per-layer path's empty [n, cols]
+                self.neighbors.append(torch.empty((n, int(o.conv_cols)), dtype=torch.int32, device=dev))
+            else:                   # no convolution blocks on this layer: the [0, 1] placeholder
+                self.neighbors.append(e_i)
+            if l + 1 < L:
+                self.pools.append(view(o.pool_offset, n_next, o.pool_cols, torch.int32) if o.pool_offset >= 0
+                                  else torch.empty((n_next, int(o.pool_cols)), dtype=torch.int32, device=dev))
+                self.upsamples.append(view(o.up_offset, n, o.up_cols, torch.int32) if o.up_offset >= 0
+                                      else torch.empty((n, int(o.up_cols)), dtype=torch.int32, device=dev))
+            else:
+                self.pools.append(e_i)
+                self.upsamples.append(e_i)
+            self.lengths.append(lengths[l])
+
+
+KPBATCH_TRACE = None     # measurement hook (bench_models.py): a list of 8 torch.cuda.Event(enable_timing=True), already recorded
+#                          once, that the next build records around layer 0's conv search / expand / subsample count / fill
+
+
+def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, cap=128):
+    """``KPConvBatch.segmentation_inputs`` (ml3d/torch/dataloaders/concat_batcher.py:186-305) for rigid architectures in ONE
+    library call: ``radii[l]`` / ``dls[l]`` the conv radius and pooling grid of layer l, ``has_conv[l]`` whether the layer has
+    convolution blocks, ``rotations``: per pooling layer a float32 [B,3,3] device tensor or None.  Every layer but the last
+    pools.  Returns a ``KpBatchArena`` (matrices identical to the per-layer ``radius_plan_dense`` / ``grid_subsampling_plan``
+    calls) or None when some row outgrew the ``cap``-wide stash of the one-traversal search -- the caller then takes the
+    per-layer two-phase path for this batch."""
+    lib = _abi.get()
+    _need_gpu(points)
+    pts = points.contiguous().float()
+    dev = pts.device
+    L, B, n0 = len(radii), len(lengths), int(pts.shape[0])
+    if L > _abi.KPBATCH_MAX_LAYERS or L < 1:
+        raise RuntimeError("kpconv_batch_build: 1 .. %d layers" % _abi.KPBATCH_MAX_LAYERS)
+    desc = _abi.KpBatchDesc()
+    desc.num_layers, desc.cap = L, int(cap)
+    for l in range(L):
+        desc.has_conv[l], desc.radius[l], desc.dl[l] = int(bool(has_conv[l])), float(radii[l]), float(dls[l]) if l + 1 < L else 0.0
+    if KPBATCH_TRACE is not None:
+        for i, ev in enumerate(KPBATCH_TRACE):
+            desc.trace_events[i] = ev.cuda_event
+    lens = (C.c_int64 * B)(*[int(v) for v in lengths])
+    if rotations is not None and L > 1 and all(isinstance(r, np.ndarray) for r in rotations[:L - 1]):
+        # host orientations (the random draws of batch_grid_subsampling): ONE upload for all pooling layers
+        stack = torch.from_numpy(np.ascontiguousarray(np.stack(rotations[:L - 1]), dtype=np.float32)).to(dev)
+        rot_t = [stack[l] for l in range(L - 1)]
+    else:
+        rot_t = [None if (rotations is None or rotations[l] is None) else
+                 torch.as_tensor(rotations[l], dtype=torch.float32).to(device=dev).contiguous() for l in range(L - 1)]
+    rot_p = (C.c_void_p * max(1, L - 1))(*[None if t is None else t.data_ptr() for t in rot_t]) if L > 1 else None
+    wsb = lib.ml3d_kpconv_batch_workspace_bytes(n0, B, L, int(cap))
+    if wsb == 0:
+        raise RuntimeError("kpconv_batch_build: unsupported sizes")
+    ws = _ws(wsb, dev)
+    hsb = int(lib.ml3d_kpconv_batch_host_scratch_bytes(B, L))
+    stream = _stream()
+    hkey = (str(dev), stream, (hsb + 4095) // 4096)
+    pinned = _PINNED.get(hkey)
+    if pinned is None:
+        if len(_PINNED) >= 16:
+            _PINNED.clear()
+        pinned = _PINNED[hkey] = torch.empty(((hsb + 4095) // 4096) * 4096, dtype=torch.uint8).pin_memory()
+    out = _abi.KpBatchOut()
+    out_lens = (C.c_int32 * (L * B))()
+    bucket = (str(dev), max(1, n0).bit_length())
+    # first guess: what the last batch of this size class took (+25 %), else ~3 matrices of 48 columns over 1.6 N rows + points
+    arena_bytes = int(_ARENA_HINT.get(bucket, 0) * 1.25) or int(n0 * 1.6 * (3 * 48 * 4 + 12)) + (1 << 20)
+    for attempt in range(6):
+        arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_kpconv_batch_build(pts.data_ptr(), C.addressof(lens), B, n0, C.addressof(desc), rot_p and C.addressof(rot_p),
+                                             arena.data_ptr(), arena_bytes, C.addressof(out), C.addressof(out_lens), ws.data_ptr(), wsb,
+                                             pinned.data_ptr(), pinned.numel(), stream)
+        if rc == -2 and out.arena_used > arena_bytes:        # ML3D_E_WORKSPACE: the arena was short -- grow and redo the batch
+            arena_bytes = int(max(2 * arena_bytes, 2 * out.arena_used))
+            continue
+        break
+    if rc == _abi.KPBATCH_FALLBACK:
+        return None
+    _abi.check(rc, "ml3d_kpconv_batch_build")
+    _ARENA_HINT[bucket] = int(out.arena_used)
+    lengths_t = [torch.tensor(list(out_lens[l * B:(l + 1) * B]), dtype=torch.int32) for l in range(L)]
+    return KpBatchArena(arena, out, lengths_t, pts, [bool(h) for h in has_conv])

@@ -721,7 +721,9 @@ class KPConvBatch:
     (kpconv.py:2059-2080), ``None`` keeps axis-aligned grids, or a list of float32 [B,3,3] arrays per pooling
     layer."""
 
-    def __init__(self, points, lengths, cfg, features=None, rotations="random", device='cuda'):
+    def __init__(self, points, lengths, cfg, features=None, rotations="random", device='cuda', one_call=True):
+        """``one_call=False`` forces the per-layer path (the whole-batch library call is tried first otherwise; both produce the
+        same matrices -- tests/test_gpu_kpconv.py, tests/test_emulated_api.py)."""
         dev = torch.device(device)
         _abi.require_gpu(dev, "KPConvBatch")
         self.cfg = cfg
@@ -731,6 +733,8 @@ class KPConvBatch:
             features = torch.ones((pts.shape[0], 1), dtype=torch.float32, device=dev)     # in_features_dim == 1
         self.features = torch.as_tensor(features, dtype=torch.float32).to(dev).contiguous()
         self.points, self.neighbors, self.pools, self.upsamples, self.lengths, self.rotations = [], [], [], [], [], []
+        if one_call and self._build_in_one_call(pts, lens, cfg, rotations, dev):
+            return
         r_normal = cfg['first_subsampling_dl'] * cfg['conv_radius']
         layer_blocks = []
         e_i = torch.empty((0, 1), dtype=torch.int32, device=dev)
@@ -792,6 +796,54 @@ class KPConvBatch:
                 break
 
 
+def _kpconv_build_in_one_call(self, pts, lens, cfg, rotations, dev):
+    """The rigid architectures' batch build as ONE library call (``ops.kpconv_batch_build`` -> ``ml3d_kpconv_batch_build``: every
+    launch of the 5-layer chain enqueued from C++, one blocking size read-back per layer instead of two per pooling layer, no
+    interpreter between two kernels).  Returns False -- nothing appended, no random draw consumed -- when the architecture is
+    not the plain ``[blocks..., pool/strided]* [blocks..., global/upsample]`` shape or has deformable blocks (their 6 x wider
+    searches take the two-phase path), and when a row outgrows the one-traversal stash: the per-layer loop then runs."""
+    arch = list(cfg['architecture'])
+    if any('deformable' in b for b in arch):
+        return False
+    has_conv, closing, blocks = [], [], 0
+    for block in arch:
+        if not ('pool' in block or 'strided' in block or 'global' in block or 'upsample' in block):
+            blocks += 1
+            continue
+        has_conv.append(blocks > 0)
+        closing.append('pool' in block or 'strided' in block)
+        blocks = 0
+        if not closing[-1]:
+            break
+    L = len(closing)
+    if L == 0 or closing[-1] or not all(closing[:-1]) or L > _abi.KPBATCH_MAX_LAYERS or not lens:
+        return False
+    r_normal = cfg['first_subsampling_dl'] * cfg['conv_radius']
+    radii, dls = [], []
+    for l in range(L):
+        radii.append(r_normal)
+        dls.append(2 * r_normal / cfg['conv_radius'])
+        r_normal *= 2
+    state = np.random.get_state() if isinstance(rotations, str) else None
+    if isinstance(rotations, str):
+        R = [random_grid_rotations(len(lens)) for _ in range(L - 1)]          # (the per-layer loop draws them in this order too)
+    elif rotations is None:
+        R = [None] * (L - 1)
+    else:
+        R = [rotations[l] for l in range(L - 1)]
+    res = ops.kpconv_batch_build(pts, lens, radii, dls, has_conv, R)
+    if res is None:
+        if state is not None:
+            np.random.set_state(state)          # the per-layer path draws the same orientations again
+        return False
+    self.points, self.neighbors, self.pools, self.upsamples = res.points, res.neighbors, res.pools, res.upsamples
+    self.lengths = res.lengths
+    self.rotations = R
+    self._arena = res.arena                     # (the views keep it alive anyway)
+    self.host_syncs = res.host_syncs
+    return True
+
+
 def _kpconv_batch_to(self, device):
     """``KPConvBatch.to`` of the reference (concat_batcher.py:327-341; the pipelines call it, semantic_segmentation.py:236):
     the matrices are built on the device already -- only a different device would mean a copy."""
@@ -803,6 +855,7 @@ def _kpconv_batch_to(self, device):
     return self
 
 
+KPConvBatch._build_in_one_call = _kpconv_build_in_one_call
 KPConvBatch.to = _kpconv_batch_to
 KPConvBatch.pin_memory = lambda self: self
 

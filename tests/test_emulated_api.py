@@ -265,6 +265,66 @@ print("ok")
 ''')
 
 
+def test_kpconv_batch_build_in_one_call_equals_the_per_layer_loop_and_the_oracle():
+    """``ml3d_kpconv_batch_build`` (the whole 5-layer batch build enqueued from C++, one size read-back per layer) against the
+    per-layer Python loop it replaces and against the oracle's ``segmentation_inputs`` (concat_batcher.py:186-305): every
+    matrix, the pooled points, the per-item lengths and the consumed random draws identical -- rotated and axis-aligned grids,
+    a first layer without convolution blocks, a batch item that pools to a handful of points; a row longer than the stash
+    falls back to the per-layer path (same results), a short arena grows."""
+    _run(r'''
+import synth_data, synth_weights as W
+from oracle import kpconv_ref as K
+from ml3d import ops
+from ml3d.ops import search
+from ml3d.torch.models.kpconv import KPConvBatch
+cfg = dict(W.TORONTO3D_CFG)
+spheres = [synth_data.toronto3d_sphere(i, 2500 if i else 60, radius=2.0 if i else 1.2) for i in range(4)]
+pts, lens = np.concatenate(spheres), [len(s) for s in spheres]
+def same(a, b):
+    assert len(a.points) == len(b.points)
+    for l in range(len(a.points)):
+        assert torch.equal(a.points[l], b.points[l]), l
+        assert torch.equal(a.lengths[l], b.lengths[l]) and a.lengths[l].dtype == b.lengths[l].dtype, l
+        for name in ("neighbors", "pools", "upsamples"):
+            x, y = getattr(a, name)[l], getattr(b, name)[l]
+            assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), (name, l, x.shape, y.shape)
+for rot in ("random", None):
+    np.random.seed(11); one = KPConvBatch(pts, lens, cfg, rotations=rot, device="cpu")
+    after_one = np.random.rand()
+    np.random.seed(11); loop = KPConvBatch(pts, lens, cfg, rotations=rot, device="cpu", one_call=False)
+    after_loop = np.random.rand()
+    assert getattr(one, "host_syncs", None) == cfg["num_layers"] and not hasattr(loop, "host_syncs")
+    assert after_one == after_loop
+    same(one, loop)
+    if rot is not None:
+        assert all(np.array_equal(a, b) for a, b in zip(one.rotations, loop.rotations))
+        np.random.seed(11); seg = K.segmentation_inputs(pts, lens, cfg)
+        for l in range(cfg["num_layers"]):
+            for name in ("neighbors", "pools", "upsamples"):
+                m = getattr(one, name)[l].numpy()
+                if m.size or np.asarray(seg[name][l]).size:
+                    assert np.array_equal(m, seg[name][l]), (name, l)
+# an architecture whose first layer has no convolution blocks, three layers
+cfg3 = dict(cfg, num_layers=3, architecture=["resnetb_strided", "resnetb", "resnetb_strided", "resnetb", "nearest_upsample", "unary"])
+np.random.seed(3); one = KPConvBatch(pts, lens, cfg3, device="cpu")
+np.random.seed(3); loop = KPConvBatch(pts, lens, cfg3, device="cpu", one_call=False)
+assert one.host_syncs == 3 and one.neighbors[0].shape == (0, 1)
+same(one, loop)
+# a stash of 16 entries overflows on the first layer -> None (the caller's per-layer path); KPConvBatch hides that
+r0 = cfg["first_subsampling_dl"] * cfg["conv_radius"]
+t = torch.from_numpy(pts)
+assert ops.kpconv_batch_build(t, lens, [r0, 2 * r0], [2 * r0 / 2.5, 0], [True, True], None, cap=16) is None
+# a short arena: the call reports the bytes it needs and the wrapper grows the arena (same result)
+search._ARENA_HINT.clear()
+search._ARENA_HINT[(str(t.device), max(1, len(pts)).bit_length())] = 4096
+np.random.seed(11); small = KPConvBatch(pts, lens, cfg, device="cpu")
+np.random.seed(11); loop = KPConvBatch(pts, lens, cfg, device="cpu", one_call=False)
+same(small, loop)
+assert search._ARENA_HINT[(str(t.device), max(1, len(pts)).bit_length())] > 4096
+print("ok")
+''')
+
+
 def test_kpfcnn_with_deformable_blocks_matches_the_real_reference_golden():
     """``KPFCNN`` with ``resnetb_deformable`` / ``resnetb_deformable_strided`` blocks (kpconv_parislille3d.yml:28-32; here the
     three-layer KPCONV_DEFORM_SMALL_CFG): GPU-side batch build (deform radius on the deformable layers) and forward through the

@@ -4,8 +4,9 @@ the REAL reference model on PyTorch-CPU by oracle/gen_golden_configs.py (tests/g
 ``model`` section, the seeds and the strided results).  Here the NATIVE class is built from that same dict and run on the
 MI355X at the YAML's own sizes (num_points 40 960 .. 81 920, batch_limit 10 000 .. 50 000, 400x400 .. 640x640 canvases,
 nms_pre up to 4096, max_voxels up to 60 000, two PFN layers, 5-layer / 512-wide RandLA-Net, KP_extent 1.2, 13-block KPFCNN,
-deformable blocks).  Indices / voxel ids exact, floats <= 1e-4 (scaled with the logit magnitude where that exceeds 16:
-the pseudo-trained 13-block KPFCNNs without reduce_fc reach |logit| ~ 60, where 1e-4 is 13 ulp)."""
+deformable blocks).  Indices / voxel ids exact, floats <= 1e-4 (relative 4.4e-6 where the reference's |logit| exceeds 23: the
+pseudo-trained 13-block KPFCNNs without reduce_fc reach |logit| 67 .. 187).  Every run appends its MEASURED deviations to
+gpurun_out/parity_per_yaml.jsonl; the committed table is profiles/r05_parity_per_yaml.md."""
 import glob
 import json
 import os
@@ -22,7 +23,12 @@ NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "g
 
 
 def tol_for(g, base=1e-4):
-    return base * max(1.0, float(g["logit_scale"]) / 16.0) if "logit_scale" in g else base
+    """1e-4 absolute (north_star), relaxed only where the reference's own logits are large: 4.4e-6 of the largest |logit| of the
+    golden -- 2x the worst MEASURED deviation (profiles/r05_parity_per_yaml.md: kpconv_semantickitti 3.81e-4 at |logit| 187 =
+    2.04e-6 relative, kpconv_s3dis 1.45e-4 at 67 = 2.16e-6; every other YAML is inside the plain 1e-4 by 3x or more).  f32
+    accumulation-order noise grows with the magnitude (1 ulp at 187 is 1.5e-5); until round 4 this was 6.25e-6 relative and
+    another factor 2 for deformable blocks, neither of which the measurements need."""
+    return max(base, 4.4e-6 * float(g["logit_scale"])) if "logit_scale" in g else base
 
 
 def record(name, **kv):
@@ -124,11 +130,11 @@ def test_kpconv_yaml(golden_dir, name):
     deform = any("deformable" in b for b in mcfg["architecture"])
     err = float(np.abs(out[::8] - g["logits_every8"]).max())
     agree, margins = flips(out, g["argmax"])
-    record(name, family="kpconv", max_abs_delta=err, tol=tol_for(g) * (2.0 if deform else 1.0),
+    record(name, family="kpconv", max_abs_delta=err, tol=tol_for(g),
            logit_scale=float(g["logit_scale"]) if "logit_scale" in g else None, ref_abs_max=float(np.abs(g["logits_every8"]).max()),
            label_agreement=agree, flipped_margins=margins, points=int(out.shape[0]), deformable=deform)
-    assert err <= tol_for(g) * (2.0 if deform else 1.0)
-    assert agree >= 0.9995
+    assert err <= tol_for(g)
+    assert agree >= 0.9999            # SURVEY.md §8(c); measured 1.0 on all five YAMLs (profiles/r05_parity_per_yaml.md)
 
 
 @pytest.mark.parametrize("name", [n for n in NAMES if n.startswith("pointpillars")])
@@ -162,12 +168,12 @@ def test_pointpillars_yaml(golden_dir, name):
         assert abs(a.astype(np.float64).sum() - float(g[nm + "_sum"])) <= 1e-5 * float(g[nm + "_abssum"]) + 1e-3
     # decode + rotated NMS at the YAML's nms_pre / score_thr / per-class thresholds.  The pseudo-trained heads saturate
     # (dozens of anchors at sigmoid = 0.9999999), so the nms_pre cut runs through float32 TIES and head maps that agree to
-    # 1e-4 may keep different tied candidates: the box sets are compared as sets with a 2.5 % budget of unmatched boxes
+    # 1e-4 may keep different tied candidates: the box sets are compared as sets with a 0.4 % budget of unmatched boxes
     # (decode + NMS on IDENTICAL inputs is exact: test_gpu_pointpillars.py, test_emulated_api.py)
     boxes, scores, labels = m.bbox_head.get_bboxes(*outs)
     b, sc, lb = boxes[0].cpu().numpy(), scores[0].cpu().numpy(), labels[0].cpu().numpy()
     rb, rs, rl = g["boxes"], g["scores"], g["labels"]
-    assert abs(len(b) - len(rb)) <= max(3, len(rb) // 40), (len(b), len(rb))
+    assert abs(len(b) - len(rb)) <= max(3, len(rb) // 250), (len(b), len(rb))
 
     def unmatched(xa, sa, la, xb, sb, lbb):
         miss = 0
@@ -181,7 +187,8 @@ def test_pointpillars_yaml(golden_dir, name):
             if d[j] > 1e-3 or abs(sb[cand[j]] - sa[i]) > 1e-4:
                 miss += 1
         return miss
-    budget = max(3, len(rb) // 40)
+    # measured (profiles/r05_parity_per_yaml.md): 0 .. 11 unmatched of 236 .. 6948 boxes (<= 0.16 %); the budget is ~2x that
+    budget = max(6, len(rb) // 250)
     u1, u2 = unmatched(rb, rs, rl, b, sc, lb), unmatched(b, sc, lb, rb, rs, rl)
     record(name, family="pointpillars", max_abs_delta=max(errs.values()), head_map_delta=errs, tol=1e-4, boxes_ref=int(len(rb)),
            boxes_gpu=int(len(b)), unmatched_ref_in_gpu=int(u1), unmatched_gpu_in_ref=int(u2), budget=int(budget))

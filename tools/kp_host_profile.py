@@ -30,7 +30,7 @@ spheres = [synth_data.toronto3d_sphere(i) for i in range(64)]
 lens = [len(s) for s in spheres]
 host = torch.from_numpy(np.concatenate(spheres)).pin_memory()
 np.random.seed(0)
-pipe = KPConvPipeline(m, cfg, dev)
+pipe = KPConvPipeline(m, cfg, dev, threaded=bool(int(os.environ.get("ML3D_KP_THREADED", "0"))))
 
 
 def step():
