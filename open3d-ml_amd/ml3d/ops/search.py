@@ -387,7 +387,7 @@ def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, ca
     ws = _ws(wsb, dev)
     hsb = int(lib.ml3d_kpconv_batch_host_scratch_bytes(B, L))
     stream = _stream()
-    hkey = (str(dev), stream, (hsb + 4095) // 4096)
+    hkey = (str(dev), getattr(stream, "value", stream), (hsb + 4095) // 4096)      # (the stream handle is a ctypes c_void_p)
     pinned = _PINNED.get(hkey)
     if pinned is None:
         if len(_PINNED) >= 16:
