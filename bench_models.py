@@ -402,8 +402,11 @@ def run_kpconv(args, rank, world, dev, dist):
         host_pts = torch.from_numpy(np.concatenate(spheres)).pin_memory()     # the stacked spheres of a step arrive from the HOST
         pts = host_pts.to(dev)
         np.random.seed(0)
-        from ml3d.engine import KPConvPipeline
-        pipe = KPConvPipeline(m, cfg, dev, threaded=bool(int(os.environ.get("ML3D_KP_THREADED", "0"))))
+        from ml3d.engine import KPConvPipeline, KPConvPipelineN
+        # ML3D_KP_BUILDERS (A/B knob): batch builds in flight, each on its own stream and host thread (1 = the two-stream
+        # pipeline of rounds 2-4: one build under one forward)
+        builders = max(1, int(os.environ.get("ML3D_KP_BUILDERS", "2")))
+        pipe = KPConvPipelineN(m, cfg, dev, builders=builders) if builders > 1 else KPConvPipeline(m, cfg, dev)
 
     def finish(res):
         if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)
@@ -438,7 +441,7 @@ def run_kpconv(args, rank, world, dev, dist):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         for e in evs:
             e.record()                   # materialises the hipEvent_t handles
-        _search.KPBATCH_TRACE = evs
+        _search.KPBATCH_TRACE.append(evs)
         return evs
     timed_step = step
     if timer is not None:
@@ -448,7 +451,9 @@ def run_kpconv(args, rank, world, dev, dist):
             step()
     dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
-    finish(pipe.flush())
+    rest = pipe.flush()
+    for r in (rest if isinstance(rest, list) else [rest]):
+        finish(r)
     if stub:
         if rank == 0 and world > 1:
             k = last[1] - 1
@@ -461,7 +466,7 @@ def run_kpconv(args, rank, world, dev, dist):
     timer.restore()
     in_region = timer.samples_ms()[max(0, args.warmup - 1):]     # (the pipeline runs a step's forward one submit later)
     shapes = timer.shapes
-    _search.KPBATCH_TRACE = None
+    del _search.KPBATCH_TRACE[:]
 
     def prim_ms(evs):
         """(conv search ms, subsample ms) of one build from its 8 events: two intervals each (the size read-back between a
@@ -483,7 +488,7 @@ def run_kpconv(args, rank, world, dev, dist):
         m(last_batch)
         torch.cuda.synchronize()
     t2.restore()
-    _search.KPBATCH_TRACE = None
+    del _search.KPBATCH_TRACE[:]
     prim_alone = [x for x in (prim_ms(e) for e in alone_ev) if x]
     # one sphere at a time, synchronised per sphere: upload + batch build (9 read-backs) + forward + arg-max back on the host
     lat = []

@@ -334,6 +334,88 @@ class KPConvPipeline:
         self.compute.synchronize()
 
 
+class KPConvPipelineN:
+    """``KPConvPipeline`` with SEVERAL batch builds in flight (default two), each on its own HIP stream, driven by its own host
+    thread.  Why: the one-call build (``ml3d_kpconv_batch_build``) is a DEPENDENT chain of ~300 small launches cut by one
+    blocking size read-back per layer -- ~6-7 ms of stream time for ~3 ms of kernels (round-5 profile: the chain is bound by
+    per-launch latency, not by the host and not by the CUs), so ONE chain at a time leaves the GPU half idle.  The library call
+    releases the interpreter lock while it waits, so two builder threads keep two chains in flight while the caller's thread
+    enqueues the forward of the oldest finished batch on the compute stream.
+
+    ``submit(points, lengths)`` starts the build of this batch and returns the ``Result`` of the batch submitted ``builders``
+    calls earlier (None until then); ``flush()`` returns the list of the remaining results, oldest first.  Batches are
+    forwarded in submission order; the random grid orientations are drawn on the caller's thread at submit time, in the order
+    the sequential loop draws them (kpconv.py:2059-2080), so results are bit-identical to ``model(KPConvBatch(...))`` run in
+    sequence with the same seed."""
+    Result = KPConvPipeline.Result
+
+    def __init__(self, model, cfg, device, builders=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.model, self.cfg = model, cfg
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("KPConvPipelineN needs an MI355X device; there is no CPU fallback")
+        self.n = max(1, int(builders))
+        with torch.cuda.device(self.device):
+            self.build_streams = [torch.cuda.Stream(priority=-1) for _ in range(self.n)]
+            self.compute = torch.cuda.Stream(priority=0)
+        self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="kpconv-build")
+        self.inflight = []            # futures of (batch, built event), submission order
+        self.alive = []
+        self.count = 0
+        self.pool_layers = sum(1 for b in cfg['architecture'] if 'pool' in b or 'strided' in b)
+
+    def _build(self, slot, points, lengths, features, rotations, ready):
+        from .torch.models.kpconv import KPConvBatch
+        st = self.build_streams[slot]
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
+            st.wait_event(ready)                   # the caller's inputs
+            batch = KPConvBatch(points, lengths, self.cfg, features=features, rotations=rotations, device=self.device)
+            built = torch.cuda.Event()
+            built.record(st)
+            if torch.is_tensor(points) and points.is_cuda:
+                points.record_stream(st)
+        return batch, built
+
+    def _forward(self, fut):
+        batch, built = fut.result()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.compute):
+            self.compute.wait_event(built)
+            logits = self.model(batch)
+            done = torch.cuda.Event()
+            done.record(self.compute)
+        res = KPConvPipeline.Result(logits, done, batch)
+        self.alive = [r for r in self.alive if not r.done.query()]
+        self.alive.append(res)
+        while len(self.alive) > self.n + 1:
+            self.alive.pop(0).done.synchronize()
+        return res
+
+    def submit(self, points, lengths, features=None, rotations="random"):
+        from .torch.models.kpconv import random_grid_rotations
+        if isinstance(rotations, str):            # drawn HERE, in submission order (the builder threads must not race on np.random)
+            rotations = [random_grid_rotations(len(lengths)) for _ in range(self.pool_layers)]
+        with torch.cuda.device(self.device):
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+        self.inflight.append(self.pool.submit(self._build, self.count % self.n, points, lengths, features, rotations, ready))
+        self.count += 1
+        if len(self.inflight) > self.n:
+            return self._forward(self.inflight.pop(0))
+        return None
+
+    def flush(self):
+        out = []
+        while self.inflight:
+            out.append(self._forward(self.inflight.pop(0)))
+        return out
+
+    def synchronize(self):
+        for s in self.build_streams:
+            s.synchronize()
+        self.compute.synchronize()
+
+
 class _PointPillarsLane:
     """One lane of ``PointPillarsStream``.  Host sweeps in, detections out (PointPillars detection, frame-parallel rows a15-a19).
     Two HIP streams: the pinned host sweeps of step i + 1 are uploaded on the copy stream while step i

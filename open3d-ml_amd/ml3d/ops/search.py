@@ -347,8 +347,9 @@ class KpBatchArena:
             self.lengths.append(lengths[l])
 
 
-KPBATCH_TRACE = None     # measurement hook (bench_models.py): a list of 8 torch.cuda.Event(enable_timing=True), already recorded
-#                          once, that the next build records around layer 0's conv search / expand / subsample count / fill
+KPBATCH_TRACE = []       # measurement hook (bench_models.py): a FIFO of event lists -- each 8 torch.cuda.Event(enable_timing=True),
+#                          already recorded once -- one of which the next build takes and records around layer 0's conv search /
+#                          expand / subsample count / fill (list.pop is atomic: builds may start on several host threads)
 
 
 def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, cap=128):
@@ -369,8 +370,12 @@ def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, ca
     desc.num_layers, desc.cap = L, int(cap)
     for l in range(L):
         desc.has_conv[l], desc.radius[l], desc.dl[l] = int(bool(has_conv[l])), float(radii[l]), float(dls[l]) if l + 1 < L else 0.0
-    if KPBATCH_TRACE is not None:
-        for i, ev in enumerate(KPBATCH_TRACE):
+    try:
+        trace = KPBATCH_TRACE.pop(0)
+    except IndexError:
+        trace = None
+    if trace is not None:
+        for i, ev in enumerate(trace):
             desc.trace_events[i] = ev.cuda_event
     lens = (C.c_int64 * B)(*[int(v) for v in lengths])
     if rotations is not None and L > 1 and all(isinstance(r, np.ndarray) for r in rotations[:L - 1]):

@@ -137,6 +137,37 @@ def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
             assert a.shape == b.shape and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("builders", [2, 3])
+def test_pipeline_with_several_builds_in_flight_is_bit_identical_to_the_sequential_loop(builders):
+    """ml3d.engine.KPConvPipelineN (what bench.py --workload kpconv times since round 5): two / three one-call batch builds in
+    flight on their own HIP streams and host threads, forwards in submission order -- logits identical to
+    model(KPConvBatch(..)) run one after the other with the same seed (the grid orientations are drawn at submit time)."""
+    from ml3d.engine import KPConvPipelineN
+    from ml3d.torch.models.kpconv import KPConvBatch
+    sd = K.make_state_dict(CFG, 77)
+    m = _model(sd)
+    batches = [[synth_data.toronto3d_sphere(40 + 3 * i + j, 2500 + 400 * j + 150 * i) for j in range(3)] for i in range(7)]
+    dev = torch.device("cuda:0")
+    inputs = [(torch.from_numpy(np.concatenate(b)).to(dev), [len(s) for s in b]) for b in batches]
+    np.random.seed(5)
+    seq = [m(KPConvBatch(p, l, CFG, device=dev)).cpu().numpy() for p, l in inputs]
+    for rep in range(2):
+        np.random.seed(5)
+        pipe = KPConvPipelineN(m, CFG, dev, builders=builders)
+        got = []
+        for i, (p, l) in enumerate(inputs):
+            r = pipe.submit(p, l)
+            assert (r is None) == (i < builders)
+            if r is not None:
+                got.append(r)
+        got += pipe.flush()
+        assert pipe.flush() == []
+        outs = [r.wait().cpu().numpy() for r in got]
+        assert len(outs) == len(seq)
+        for a, b in zip(outs, seq):
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+
 def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_per_sphere():
     """The configuration bench.py --workload kpconv times: 64 input spheres (~640 000 points) per batch through
     ``KPConvPipeline``.  Only at this size are deep split-K, the 32-bit offset epilogue (wf is 1.2 GB) and the three-launch
