@@ -183,6 +183,7 @@ def latency(dev, sd, frames_timed=200, frames_warm=20):
     attr = {"split": "test"}
     collate = DefaultBatcher().collate_fn
     out = {"api": "RandLANet.transform -> DefaultBatcher -> forward -> update_probs (float16 votes on the device)",
+           "hip_graphs": bool(getattr(model, "use_graphs", False)),
            "cloud_points_raw": int(sweep.shape[0]), "cloud_points_sub": int(model.inference_data["point"].shape[0]),
            "preprocess_ms_once_per_cloud": pre_ms, "frames_timed": frames_timed, "frames_warmup": frames_warm}
     for B in (1, 4):
@@ -212,6 +213,9 @@ def latency(dev, sd, frames_timed=200, frames_warm=20):
         ts = np.asarray(ts)
         out["batch_%d" % B] = {"ms_per_frame_median": float(np.median(ts)), "ms_per_frame_p95": float(np.percentile(ts, 95)),
                                "frames_per_s": float(1e3 / np.median(ts)), "steps": int(ts.size)}
+    st = getattr(model, "_dev_loop", None) or {}
+    out["hip_graphs_captured"] = {"patch": st.get("graph") is not None, "forward": st.get("fwd_graph") is not None,
+                                  "failed": st.get("graph_failed") or st.get("fwd_failed")}
     return out
 
 

@@ -386,6 +386,7 @@ def run_kpconv(args, rank, world, dev, dist):
     B = args.frames_per_step                               # 64 spheres per step by default, like the RandLA line
     overlap = not getattr(args, "no_overlap", False)
     last = [None, 0]
+    builders = 1
     if stub:
         host_pts, lens, pipe = torch.zeros((4, 3)), [4], _StubLogits(rank)
     else:
@@ -517,8 +518,9 @@ def run_kpconv(args, rank, world, dev, dist):
            "step_ms_p95": float(np.percentile(iv, 95)), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "KPConv (rigid) Toronto3D inference, %d synthetic 10000-point input spheres per step per "
-                                  "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, " (build of step i+1 overlapped with the forward of step i on two HIP streams)" if overlap else ""),
+                                  "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, (" (%d one-call batch builds in flight on their own HIP streams / host threads under the forwards on another)" % builders if builders > 1 else " (build of step i+1 overlapped with the forward of step i on two HIP streams)") if overlap else ""),
                       "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
+                      "builds_in_flight": builders if overlap else 1,
                       "parallelism": "frame-parallel x%d" % world},
            "latency_single_sphere_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "spheres": len(lat)},
            "roofline": {"bound": "mfma", "kernel": "kp_agg_gemm32 (KPConv %d->%d, %d queries x %d neighbour columns: MFMA aggregation + the [480 x 32] product in one kernel)" % (cin, cout, nq, H),

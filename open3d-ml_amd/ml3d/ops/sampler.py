@@ -44,13 +44,14 @@ def nearest_to_center(points, center, k, return_distances=False):
     return (idx, d2) if return_distances else idx
 
 
-def device_patch(points, possibility, center_index, perm, k, recenter_dims=(), extra=None, feat_bias=0.0, feat_scale=1.0):
+def device_patch(points, possibility, center_index, perm, k, recenter_dims=(), extra=None, feat_bias=0.0, feat_scale=1.0, out=None):
     """One step of the spatially regular patch loop (semseg_spatially_regular.py:64-111 + randlanet.py:185-212) with nothing
     read back: ``points`` float32 [n, 3], ``possibility`` float64 [n] (bumped IN PLACE), ``center_index`` a 1-element DEVICE
     index tensor (the argmin of the possibilities), ``perm`` the host-drawn shuffle of 0..k-1 as a device int32 tensor,
     ``extra`` optional float32 [n, c] per-point features.  Returns (patch points [k, 3] recentred on ``recenter_dims``,
     features [k, 3 + c], selected cloud indices int32 [k]) -- the arithmetic and its ORDER are numpy's (float32 squared
-    distances left to right, sequential float32 column sums for the mean): the patch feeds an exact neighbour search."""
+    distances left to right, sequential float32 column sums for the mean): the patch feeds an exact neighbour search.
+    ``out``: optional preallocated (points [k, 3] float32, features [k, 3 + c] float32, indices [k] int32) to write into."""
     lib = _abi.get()
     _need_gpu(points, possibility, center_index, perm)
     dev = points.device
@@ -63,11 +64,17 @@ def device_patch(points, possibility, center_index, perm, k, recenter_dims=(), e
     cand = torch.empty(k, dtype=torch.int32, device=dev)
     wsb = lib.ml3d_nearest_to_center_workspace_bytes(n)
     ws = _ws(wsb, dev)
-    pts = torch.empty((k, 3), dtype=torch.float32, device=dev)
-    sel = torch.empty(k, dtype=torch.int32, device=dev)
-    scratch = torch.empty(4 * k + 64, dtype=torch.uint8, device=dev)
     n_extra = 0 if extra is None else int(extra.shape[1])
-    feats = torch.empty((k, 3 + n_extra), dtype=torch.float32, device=dev)
+    if out is None:
+        pts = torch.empty((k, 3), dtype=torch.float32, device=dev)
+        sel = torch.empty(k, dtype=torch.int32, device=dev)
+        feats = torch.empty((k, 3 + n_extra), dtype=torch.float32, device=dev)
+    else:
+        pts, feats, sel = out
+        if tuple(pts.shape) != (k, 3) or tuple(feats.shape) != (k, 3 + n_extra) or sel.numel() != k or pts.dtype != torch.float32 or \
+                feats.dtype != torch.float32 or sel.dtype != torch.int32 or not (pts.is_contiguous() and feats.is_contiguous() and sel.is_contiguous()):
+            raise RuntimeError("device_patch: out = (float32 [k, 3], float32 [k, 3 + c], int32 [k]), contiguous")
+    scratch = torch.empty(4 * k + 64, dtype=torch.uint8, device=dev)
     ex = None
     mask = 0
     for d in recenter_dims:

@@ -24,6 +24,8 @@ def _stack(values):
         out = torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(v) for v in values], 0)
     if all(getattr(v, '_ml3d_prefix_of_neighbors', False) for v in values):
         out._ml3d_prefix_of_neighbors = True          # RandLANet.transform's mark on sub_idx (models/randlanet.py, _mark_prefix)
+    if len(values) == 1 and getattr(values[0], '_ml3d_arena', None) is not None:
+        out._ml3d_arena = values[0]._ml3d_arena       # a batch of ONE device-loop patch stays recognisable to RandLANet.forward
     return out
 
 

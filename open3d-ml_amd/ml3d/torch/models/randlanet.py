@@ -8,6 +8,8 @@ it folds BatchNorm into packed weights once (``_randla_pack``) and calls the han
 HIP kernels through the C ABI (``ml3d.ops.randla_knn_pyramid`` + ``randla_forward``).
 There is no CPU execution path: on a non-GPU device ``forward`` raises.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -103,6 +105,9 @@ class RandLANet(nn.Module):
                                  SharedMLP(32, cfg.num_classes, bn=False))
         self._packed = None       # (device, params tensor)
         self._engines = {}
+        # HIP graphs around the device patch loop's per-patch sequence and the batch-of-one forward (see _transform_device,
+        # _forward_graphed); ML3D_RANDLA_GRAPHS=0 turns them off for A/B runs
+        self.use_graphs = os.environ.get("ML3D_RANDLA_GRAPHS", "1") != "0"
         self.eval()
 
     # ---- packed weights ---------------------------------------------------------------------------
@@ -141,6 +146,9 @@ class RandLANet(nn.Module):
             return self._forward_train(inputs)
         dev = self.device
         _abi.require_gpu(dev, "RandLANet.forward")
+        fast = self._forward_graphed(inputs)
+        if fast is not None:
+            return fast
         coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
         pts = coords.to(dev, torch.float32).contiguous()
         feat = inputs['features'].to(dev, torch.float32).contiguous()
@@ -162,6 +170,67 @@ class RandLANet(nn.Module):
         B, N, _ = pts.shape
         desc = _abi.make_desc(self.cfg, B, N)
         return ops.randla_forward(desc, self.packed_params(dev), feat, pts, nbr, itp)
+
+    def _forward_graphed(self, inputs):
+        """Batch-of-one forward of a patch that ``_transform_device`` produced (recognised by its arena): the patch arena is copied
+        into the static inputs of a captured graph of ``ops.randla_forward`` (one copy kernel), the graph replayed, the static
+        scores cloned.  None: not such a patch / graphs off -> the eager path."""
+        st = getattr(self, '_dev_loop', None)
+        feats = inputs.get('features') if isinstance(inputs, dict) else None
+        mark = getattr(feats, '_ml3d_arena', None)
+        if st is None or mark is None or not getattr(self, 'use_graphs', True) or st.get('fwd_failed') or st.get('layout') is None:
+            return None
+        arena, lay_id = mark
+        lay, nbytes = st['layout']
+        if lay_id != id(lay) or arena.numel() != nbytes or feats.dim() != 3 or feats.shape[0] != 1:
+            return None
+        # every tensor the kernels will read must be the arena's own view (a caller may have swapped list entries)
+        base, L = arena.data_ptr(), int(self.cfg.num_layers)
+        coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
+        try:
+            ok = feats.data_ptr() == base + lay['feats'][0] and coords.data_ptr() == base + lay['pts'][0] and \
+                all(inputs['neighbor_indices'][l].data_ptr() == base + lay['nbr%d' % l][0] and
+                    inputs['interp_idx'][l].data_ptr() == base + lay['itp%d' % l][0] for l in range(L))
+        except Exception:
+            ok = False
+        if not ok:
+            return None
+        dev = self.device
+        fg = st.get('fwd_graph')
+        params = self.packed_params(dev)
+        if fg is not None and fg['params'] is not params:
+            fg = None                                            # the weights were repacked: capture again
+        if fg is None:
+            try:
+                with torch.cuda.device(dev):
+                    a_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    a_in.copy_(arena)
+                    v = self._arena_views(a_in, lay)
+                    k = int(self.cfg.num_points)
+                    desc = _abi.make_desc(self.cfg, 1, k)
+                    nbr = [v['nbr%d' % l] for l in range(L)]
+                    itp = [v['itp%d' % l] for l in range(L)]
+                    scores = torch.empty((1, k, int(self.cfg.num_classes)), dtype=torch.float32, device=dev)
+                    run = lambda: ops.randla_forward(desc, params, v['feats'][None], v['pts'][None], nbr, itp, out=scores)
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        run()
+                    torch.cuda.current_stream().wait_stream(side)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        run()
+                fg = st['fwd_graph'] = dict(graph=graph, arena=a_in, scores=scores, params=params, desc=desc)
+            except Exception as e:
+                st['fwd_failed'] = "%s: %s" % (type(e).__name__, e)
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                return None
+        fg['arena'].copy_(arena)
+        fg['graph'].replay()
+        return fg['scores'].clone()
 
     # ---- training forward (SURVEY.md §8 f4) -----------------------------------------------------------------------------------
     def train(self, mode=True):
@@ -420,26 +489,119 @@ class RandLANet(nn.Module):
         st = getattr(self, '_dev_loop', None)
         return st is not None and data is st['data'] and sampler == self._possibility_sampler
 
-    def _transform_device(self):
-        cfg, st, dev = self.cfg, self._dev_loop, self.device
+    # ---- the patch arena: every per-patch tensor the loop hands to the batcher / forward, in ONE device buffer ------------------
+    def _arena_layout(self):
+        """name -> (byte offset, shape, dtype) of the per-patch tensors inside one uint8 arena, and its size: patch points, features,
+        selected indices, labels, and per level the neighbour / interpolation index lists (the sub_idx lists are prefixes)."""
+        cfg, st = self.cfg, self._dev_loop
+        k, K = int(cfg.num_points), int(cfg.num_neighbors)
+        c = 3 + (0 if st['feat'] is None else int(st['feat'].shape[1]))
+        n = ops.pyramid_sizes(k, cfg.sub_sampling_ratio)
+        items = [('pts', (k, 3), torch.float32), ('feats', (k, c), torch.float32), ('sel', (k,), torch.int32), ('labels', (k,), torch.int64)]
+        for l in range(cfg.num_layers):
+            items += [('nbr%d' % l, (1, n[l], K), torch.int32), ('itp%d' % l, (1, n[l], 1), torch.int32)]
+        lay, off = {}, 0
+        for name, shape, dt in items:
+            nb = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            lay[name] = (off, shape, dt)
+            off = (off + nb + 255) & ~255
+        return lay, off
+
+    @staticmethod
+    def _arena_views(arena, lay):
+        out = {}
+        for name, (off, shape, dt) in lay.items():
+            nb = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            out[name] = arena[off:off + nb].view(dt).view(*shape)
+        return out
+
+    def _patch_into(self, v, perm):
+        """The device patch loop's step (centre argmin -> crop -> recentre -> neighbour pyramid -> labels) writing into the
+        arena views ``v``; no host synchronisation, nothing allocated that outlives the call except through ``v``."""
+        cfg, st = self.cfg, self._dev_loop
         k = int(cfg.num_points)
         center = torch.argmin(st['possibility']).reshape(1)
-        perm = torch.from_numpy(self.rng.permutation(k).astype(np.int32)).to(dev, non_blocking=True)
-        pts, feats, sel = ops.device_patch(st['points'], st['possibility'], center, perm, k, st['dims'], st['feat'],
-                                           st['bias'], st['scale'])
-        nbr, itp = ops.randla_knn_pyramid(pts[None], cfg.sub_sampling_ratio, cfg.num_neighbors)
+        ops.device_patch(st['points'], st['possibility'], center, perm, k, st['dims'], st['feat'], st['bias'], st['scale'],
+                         out=(v['pts'], v['feats'], v['sel']))
+        ops.randla_knn_pyramid(v['pts'][None], cfg.sub_sampling_ratio, cfg.num_neighbors,
+                               out=([v['nbr%d' % l] for l in range(cfg.num_layers)], [v['itp%d' % l] for l in range(cfg.num_layers)]))
+        torch.index_select(st['label'], 0, v['sel'].long(), out=v['labels'])      # (int64 labels cast once per cloud)
+
+    def _inputs_from_arena(self, arena, lay):
+        cfg = self.cfg
+        k = int(cfg.num_points)
+        v = self._arena_views(arena, lay)
         inputs, coords, n = dict(), [], k
         for i in range(cfg.num_layers):
-            coords.append(pts[:n])
+            coords.append(v['pts'][:n])
             n = n // cfg.sub_sampling_ratio[i]
+        nbr = [v['nbr%d' % l] for l in range(cfg.num_layers)]
         inputs['coords'] = coords
         inputs['neighbor_indices'] = [t[0] for t in nbr]
         inputs['sub_idx'] = [_mark_prefix(nbr[i][0, :k // int(np.prod(cfg.sub_sampling_ratio[:i + 1]))]) for i in range(cfg.num_layers)]
-        inputs['interp_idx'] = [t[0] for t in itp]
-        inputs['features'] = feats
-        inputs['point_inds'] = sel
-        inputs['labels'] = st['label'][sel]          # (int64 labels cast once per cloud, int32 index: one gather per patch, not three kernels)
+        inputs['interp_idx'] = [v['itp%d' % l][0] for l in range(cfg.num_layers)]
+        inputs['features'] = v['feats']
+        inputs['point_inds'] = v['sel']
+        inputs['labels'] = v['labels']
+        # the forward recognises a patch of this loop by its arena (``_stack`` of this package's batcher carries the mark through a
+        # batch of one): one copy into the forward graph's static inputs instead of ~30 launches
+        inputs['features']._ml3d_arena = (arena, id(lay))
         return inputs
+
+    def _transform_device(self):
+        """One patch of the device-resident loop.  With HIP graphs on (the default on a HIP device; ``self.use_graphs = False`` or
+        a failed capture turn them off): the ~60 launches of the step are ONE graph replay that writes the patch into a static
+        arena, and the caller gets a CLONE of that arena (one copy kernel) -- fresh tensors per patch, like the eager loop."""
+        cfg, st, dev = self.cfg, self._dev_loop, self.device
+        k = int(cfg.num_points)
+        if st.get('layout') is None:
+            st['layout'] = self._arena_layout()
+        lay, nbytes = st['layout']
+        perm_host = torch.from_numpy(self.rng.permutation(k).astype(np.int32))
+        g = self._patch_graph(lay, nbytes) if getattr(self, 'use_graphs', True) else None
+        if g is None:
+            arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._patch_into(self._arena_views(arena, lay), perm_host.to(dev, non_blocking=True))
+            return self._inputs_from_arena(arena, lay)
+        g['perm'].copy_(perm_host, non_blocking=True)          # (pageable host memory: staged before the call returns)
+        g['graph'].replay()
+        return self._inputs_from_arena(g['arena'].clone(), lay)
+
+    def _patch_graph(self, lay, nbytes):
+        st, dev = self._dev_loop, self.device
+        if dev.type != 'cuda' or not hasattr(torch.cuda, 'CUDAGraph'):
+            return None
+        g = st.get('graph')
+        if g is not None or st.get('graph_failed'):
+            return g
+        try:
+            with torch.cuda.device(dev):
+                arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                perm = torch.empty(int(self.cfg.num_points), dtype=torch.int32, device=dev)
+                v = self._arena_views(arena, lay)
+                # one eager pass on a side stream first (allocator pools, lazy module loading), WITHOUT touching the loop's state:
+                # the possibilities are bumped by every crop, so they are saved and restored around warm-up and capture
+                keep = st['possibility'].clone()
+                perm.copy_(torch.arange(perm.numel(), dtype=torch.int32))
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._patch_into(v, perm)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._patch_into(v, perm)
+                torch.cuda.current_stream().synchronize()
+                st['possibility'].copy_(keep)
+            g = st['graph'] = dict(graph=graph, arena=arena, perm=perm)
+        except Exception as e:                                  # capture is an optimisation: the eager loop is always there
+            st['graph_failed'] = "%s: %s" % (type(e).__name__, e)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            g = None
+        return g
 
     def _min_possibility(self):
         st = getattr(self, '_dev_loop', None)
@@ -468,6 +630,9 @@ class RandLANet(nn.Module):
         data = self.transform(self.inference_data, attr)
         batch = {k: ([t[None] if isinstance(t, torch.Tensor) else torch.as_tensor(t)[None] for t in v]
                      if isinstance(v, list) else torch.as_tensor(v)[None]) for k, v in data.items()}
+        mark = getattr(data['features'], '_ml3d_arena', None)
+        if mark is not None:
+            batch['features']._ml3d_arena = mark      # (a batch of one device-loop patch: see _forward_graphed)
         self.inference_input = {'data': batch, 'attr': attr}
         return self.inference_input
 

@@ -239,3 +239,53 @@ def test_device_resident_patch_loop_equals_the_host_loop_at_the_yaml_size():
         assert np.array_equal(x["sel"], y["sel"]) and np.array_equal(x["pts"], y["pts"]) and np.array_equal(x["nbr"], y["nbr"])
         assert np.array_equal(x["logits"], y["logits"])
     assert np.array_equal(pa, pb) and np.array_equal(va, vb)
+
+
+def test_graphed_patch_loop_is_bit_identical_to_the_eager_loop():
+    """HIP graphs around the per-patch sequence of the model-class API (``RandLANet.transform`` -> batcher -> ``forward`` ->
+    ``update_probs`` at ``test_batch_size: 1``, randlanet_semantickitti.yml:38-45): the device patch loop's ~60 launches replayed
+    as one captured graph into a static arena + one clone, the forward as a second graph behind one arena copy.  Six patches
+    with graphs on against the same six with ``use_graphs = False``: identical indices, coordinates, neighbour lists, labels,
+    scores, possibilities and votes; the returned tensors of one patch are untouched by the next patch's replay; a batch of
+    TWO patches (stacked copies: no arena mark) takes the eager forward and still matches."""
+    from ml3d.torch.dataloaders import DefaultBatcher
+    from ml3d.torch.models import RandLANet
+    cfg = dict(num_neighbors=16, num_layers=4, num_points=8192, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+               dim_features=8, dim_output=[16, 64, 128, 256], grid_size=0.06, augment={"recenter": {"dim": [0, 1]}})
+    sweep = synth_data.lidar_sweep(4300)
+    data = dict(point=sweep, feat=None, label=(np.arange(sweep.shape[0]) % 19).astype(np.int32))
+    sd = R.make_state_dict(cfg, 14)
+    collate = DefaultBatcher().collate_fn
+    attr = {"split": "test"}
+    runs = []
+    for graphs in (True, False):
+        m = RandLANet(**cfg, device="cuda:0", seed=33)
+        m.load_state_dict(sd)
+        m.use_graphs = graphs
+        m.inference_begin(dict(data))
+        got, held = [], []
+        for i in range(6):
+            B = 2 if i == 4 else 1
+            items = [{"data": m.transform(m.inference_data, attr), "attr": attr} for _ in range(B)]
+            inputs = collate(items)
+            scores = m(inputs["data"])
+            m.update_probs(inputs, scores, m.test_probs)
+            d = inputs["data"]
+            held.append((d["coords"][0], d["neighbor_indices"][0], scores, d["coords"][0].clone(), d["neighbor_indices"][0].clone(),
+                         scores.clone()))
+            got.append(dict(sel=d["point_inds"].cpu().numpy(), pts=d["coords"][0].cpu().numpy(), lab=d["labels"].cpu().numpy(),
+                            nbr=[t.cpu().numpy() for t in d["neighbor_indices"]], itp=[t.cpu().numpy() for t in d["interp_idx"]],
+                            feats=d["features"].cpu().numpy(), logits=scores.cpu().numpy()))
+        torch.cuda.synchronize()
+        for a, b, c, a0, b0, c0 in held:          # what a patch returned is its own: later replays did not write into it
+            assert torch.equal(a, a0) and torch.equal(b, b0) and torch.equal(c, c0)
+        st = m._dev_loop
+        assert (st.get("graph") is not None and st.get("fwd_graph") is not None) == graphs, (st.get("graph_failed"), st.get("fwd_failed"))
+        runs.append((got, st["possibility"].cpu().numpy(), m.test_probs.cpu().numpy()))
+    (a, pa, va), (b, pb, vb) = runs
+    for x, y in zip(a, b):
+        for key in ("sel", "pts", "lab", "feats", "logits"):
+            assert np.array_equal(x[key], y[key]), key
+        for key in ("nbr", "itp"):
+            assert all(np.array_equal(p, q) for p, q in zip(x[key], y[key])), key
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
