@@ -83,6 +83,10 @@ int bbox_compute(const float* points, Segs segs, int64_t n_total, unsigned* bbox
 // in-place inclusive scan of a[0 .. n) (int32); block_sums must hold (n + 1023) / 1024 + 1 ints
 int scan_inclusive_i32(int* a, int64_t n, int* block_sums, hipStream_t stream);
 
+// zero `bytes` (a multiple of 4) at a 16-byte aligned device address with a fill KERNEL: what every op that may be captured into a
+// HIP graph uses instead of hipMemsetAsync (ROCm 7.2: a graph's memset node did not clear its target on later replays, grid.hip)
+void zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 // order-preserving float <-> uint so atomicMin/atomicMax work on floats
 __device__ __forceinline__ unsigned f2ord(float f) {
     unsigned u = __float_as_uint(f);

@@ -536,6 +536,27 @@ __global__ void grid_scatter(const float* __restrict__ pts, Segs S, int64_t n_to
     sorted[pos] = make_float4(x, y, z, __int_as_float((int)local));
 }
 
+// Zero fill of the cell tables as a KERNEL, not hipMemsetAsync: on ROCm 7.2 a memset node of a captured HIP graph (the model-class
+// patch loop replays this build as a graph) did not reliably clear the table on the second and later replays -- the stale
+// histogram sent grid_scatter out of bounds ("write access to a read-only page", gpurun r5g).  16-byte stores, tail by words;
+// both pointers in the workspace are 256-byte aligned (grid_ws_carve) and the lengths multiples of 4.
+__global__ void __launch_bounds__(256) grid_zero(uint4* __restrict__ p, size_t n16, uint32_t* __restrict__ tail, int ntail) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < n16; j += step) p[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < (size_t)ntail) tail[i] = 0u;
+}
+
+void zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    if ((((uintptr_t)ptr) & 15) || (bytes & 3)) { (void)hipMemsetAsync(ptr, 0, bytes, stream); return; }
+    const size_t n16 = bytes / 16;
+    const int ntail = (int)((bytes - 16 * n16) / 4);
+    const size_t want = (n16 + 255) / 256;
+    const unsigned nb = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(grid_zero, dim3(nb), dim3(256), 0, stream, (uint4*)ptr, n16, (uint32_t*)((char*)ptr + 16 * n16), ntail);
+}
+
 #define ML3D_LAUNCH_CHECK()                         \
     do {                                            \
         if (hipGetLastError() != hipSuccess) return -3; \
@@ -580,7 +601,7 @@ int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, 
     if (target_occ <= 0.f) target_occ = 4.0f;
     int sb = (B + 63) / 64;
     // (bitmap and cell table are neighbours in the workspace, grid_ws_carve: one fill instead of two)
-    (void)hipMemsetAsync(ws.bitmap, 0, (size_t)((char*)(ws.cells + ws.total_cells + 2) - (char*)ws.bitmap), stream);
+    zero_async(ws.bitmap, (size_t)((char*)(ws.cells + ws.total_cells + 2) - (char*)ws.bitmap), stream);
     hipLaunchKernelGGL(grid_bbox_init, dim3(sb), dim3(64), 0, stream, ws.bbox, ws.occ, B);
     ML3D_LAUNCH_CHECK();
     if (n > 0) {
@@ -629,7 +650,7 @@ int grid_build_fixed(const float* points, Segs S, const GridWs& ws, float cell, 
     int B = ws.batch;
     if (B <= 0) return 0;
     int sb = (B + 63) / 64;
-    (void)hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    zero_async(ws.cells, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
     if (bbox_compute(points, S, ws.n_total, ws.bbox, ws.occ, stream)) return -3;
     hipLaunchKernelGGL(grid_setup0, dim3(sb), dim3(64), 0, stream, S, ws.bbox, ws.segs, B);
     ML3D_LAUNCH_CHECK();
@@ -641,7 +662,7 @@ int grid_build_fixed(const float* points, Segs S, const GridWs& ws, float cell, 
 int grid_build_derived(const float* points, Segs S, const GridWs& ws, const GridWs& parent, hipStream_t stream) {
     int B = ws.batch;
     if (B <= 0) return 0;
-    (void)hipMemsetAsync(ws.cells, 0, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
+    zero_async(ws.cells, sizeof(int) * (size_t)(ws.total_cells + 2), stream);
     hipLaunchKernelGGL(grid_setup_derived, dim3((B + 63) / 64), dim3(64), 0, stream, S, parent.segs, ws.segs, B);
     ML3D_LAUNCH_CHECK();
     return grid_sort(points, S, ws, stream);

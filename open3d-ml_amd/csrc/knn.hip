@@ -766,7 +766,7 @@ extern "C" int ml3d_patch_crop(const float* points, int64_t n_points, const int3
     hipStream_t st = (hipStream_t)stream;
     unsigned* mx = (unsigned*)scratch;
     float* d2 = (float*)((char*)scratch + 64);
-    if (hipMemsetAsync(mx, 0, sizeof(unsigned), st) != hipSuccess) return ML3D_E_LAUNCH;
+    zero_async(mx, 16, st);       // (a fill kernel, not hipMemsetAsync: this call is replayed inside HIP graphs -- grid.h; 64 bytes reserved)
     const dim3 grid((unsigned)((k + 255) / 256)), block(256);
     hipLaunchKernelGGL(patch_gather, grid, block, 0, st, points, cand, perm, center_dev, k, out_pts, out_sel, d2, mx);
     hipLaunchKernelGGL(patch_bump, grid, block, 0, st, out_sel, d2, mx, k, possibility);

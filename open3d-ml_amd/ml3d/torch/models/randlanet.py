@@ -561,9 +561,15 @@ class RandLANet(nn.Module):
         g = self._patch_graph(lay, nbytes) if getattr(self, 'use_graphs', True) else None
         if g is None:
             arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._patch_into(self._arena_views(arena, lay), perm_host.to(dev, non_blocking=True))
+            self._patch_into(self._arena_views(arena, lay), perm_host.to(dev))
             return self._inputs_from_arena(arena, lay)
-        g['perm'].copy_(perm_host, non_blocking=True)          # (pageable host memory: staged before the call returns)
+        # the shuffle goes through ONE pinned staging buffer: its previous upload has long finished, but the event makes that a
+        # fact before the buffer is overwritten (an asynchronous copy out of pageable memory that is freed right after the call
+        # faulted on the MI355X: "write access to a read-only page")
+        g['uploaded'].synchronize()
+        g['perm_pinned'].copy_(perm_host)
+        g['perm'].copy_(g['perm_pinned'], non_blocking=True)
+        g['uploaded'].record()
         g['graph'].replay()
         return self._inputs_from_arena(g['arena'].clone(), lay)
 
@@ -593,7 +599,10 @@ class RandLANet(nn.Module):
                     self._patch_into(v, perm)
                 torch.cuda.current_stream().synchronize()
                 st['possibility'].copy_(keep)
-            g = st['graph'] = dict(graph=graph, arena=arena, perm=perm)
+                uploaded = torch.cuda.Event()
+                uploaded.record()
+            g = st['graph'] = dict(graph=graph, arena=arena, perm=perm, uploaded=uploaded,
+                                   perm_pinned=torch.empty(perm.numel(), dtype=torch.int32).pin_memory())
         except Exception as e:                                  # capture is an optimisation: the eager loop is always there
             st['graph_failed'] = "%s: %s" % (type(e).__name__, e)
             try:
