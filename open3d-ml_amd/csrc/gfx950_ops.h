@@ -15,6 +15,16 @@ __device__ __forceinline__ void key_minmax(double a, double b, double& lo, doubl
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
 }
+// One slot of the sorted insertion of a key x into a register-resident ascending list: slot <- min(slot, x), x <- max(slot, x),
+// the slot updated IN PLACE.  (key_minmax's two fresh outputs per compare-exchange made the compiler rotate the whole list
+// back into its loop-carried registers after every insertion: 16 v_mov_b64 + 15 s_nop on top of the 31 useful instructions --
+// round-5 listing of knn_query_multi<16, true>.)  The keys are never NaN, so the raw instructions are exact.
+__device__ __forceinline__ void key_insert_step(double& slot, double& x) {
+    double t;
+    asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(slot), "v"(x));
+    asm("v_min_f64 %0, %0, %1" : "+v"(slot) : "v"(x));
+    x = t;
+}
 __device__ __forceinline__ double key_min(double a, double b) {
     double lo;
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));

@@ -65,6 +65,7 @@ struct GridWs {
     int batch;
 };
 
+constexpr int GRID_SORTED_SLACK = 4;     // float4 entries kept readable behind GridWs::sorted (see grid_ws_bytes)
 size_t grid_ws_bytes(int64_t n_total, int64_t batch);
 // carve `ws` (must hold grid_ws_bytes) — returns false if too small
 bool grid_ws_carve(void* ws, size_t bytes, int64_t n_total, int64_t batch, GridWs* out);

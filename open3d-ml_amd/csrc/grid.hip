@@ -30,7 +30,8 @@ size_t grid_ws_bytes(int64_t n_total, int64_t batch) {
     b += align_up(sizeof(unsigned) * GRID_LEVELS * (size_t)bw);
     b += align_up(sizeof(int) * (size_t)(tc + 2));
     b += align_up(sizeof(int) * (size_t)nb);
-    b += align_up(sizeof(float4) * (size_t)(n_total > 0 ? n_total : 1));
+    // (+ GRID_SORTED_SLACK entries behind the cell-sorted array: the k-NN scan reads a few entries past a run's end, knn.hip scan_run)
+    b += align_up(sizeof(float4) * (size_t)((n_total > 0 ? n_total : 1) + GRID_SORTED_SLACK));
     return b + 256;
 }
 

@@ -52,9 +52,12 @@ struct QuerySrc {
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {
     if (key < best[K - 1]) {
-        best[K - 1] = key;
+        // front to back, every slot in place: slot j keeps min(slot, x) and hands max(slot, x) on -- the key settles at its rank,
+        // everything behind it moves down one, the old last entry falls off the end (31 instructions for K = 16; no register
+        // rotation: key_insert_step, gfx950_ops.h)
+        double x = key;
 #pragma unroll
-        for (int j = K - 1; j > 0; --j) key_minmax(best[j - 1], best[j], best[j - 1], best[j]);
+        for (int j = 0; j < K; ++j) key_insert_step(best[j], x);
     }
 }
 
@@ -68,14 +71,28 @@ __device__ __forceinline__ void scan_run(const GridView& G, int p0, int p1, floa
     // [p0, p1): the run's slice of the cell-sorted array (the caller read the two cell_start entries, one row ahead).
     // candidates in groups of KNN_GROUP: the 16-byte loads of a group are in flight together (one exposed memory latency
     // per group instead of one per candidate); indices past the run are clamped to its last point and skipped
-    for (int p = p0; p < p1; p += KNN_GROUP) {
+    // (addressing: the array base is wave-uniform (SGPR pair), the lane's position a 32-bit BYTE offset -- `global_load ... v_off,
+    //  s[base]` with the group's three loads as immediate offsets -- so a group costs one add and one compare.  The last group of
+    //  a run may read up to KNN_GROUP - 1 entries PAST the run -- the next cell's points, or the slack grid_ws_bytes keeps behind
+    //  the array -- which the `< end` test below discards: clamping every index to the run cost three VALU instructions per
+    //  candidate in a loop that is VALU-issue bound (n_total < 2^28: the launcher's GRID_CAP check, so byte offsets fit 32 bits).
+    //  The squared distance pairs x with y -- an even-aligned register pair of the 16-byte load, one v_pk_add_f32 / v_pk_mul_f32
+    //  without moves -- in the canonical order ((dx dx) + (dy dy)) + (dz dz), no fma.)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const char* __restrict__ base = reinterpret_cast<const char*>(G.sorted);
+    const uint32_t end = (uint32_t)p1 * 16u;
+    const v2f qxy = {qx, qy};
+    for (uint32_t off = (uint32_t)p0 * 16u; off < end; off += 16u * KNN_GROUP) {
         float4 c[KNN_GROUP];
 #pragma unroll
-        for (int j = 0; j < KNN_GROUP; ++j) c[j] = G.sorted[min(p + j, p1 - 1)];
+        for (int j = 0; j < KNN_GROUP; ++j) c[j] = *reinterpret_cast<const float4*>(base + off + 16u * j);
 #pragma unroll
         for (int j = 0; j < KNN_GROUP; ++j) {
-            if (!(p + j < p1)) continue;
-            const float d2 = dist2_canon(qx, qy, qz, c[j].x, c[j].y, c[j].z);
+            if (!(off + 16u * j < end)) continue;
+            v2f dxy = qxy - (v2f){c[j].x, c[j].y};
+            dxy = dxy * dxy;
+            const float dz = qz - c[j].z;
+            const float d2 = (dxy.x + dxy.y) + dz * dz;
             const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
             const double kd = __longlong_as_double((long long)key);
             if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));

@@ -106,8 +106,12 @@ class RandLANet(nn.Module):
         self._packed = None       # (device, params tensor)
         self._engines = {}
         # HIP graphs around the device patch loop's per-patch sequence and the batch-of-one forward (see _transform_device,
-        # _forward_graphed); ML3D_RANDLA_GRAPHS=0 turns them off for A/B runs
-        self.use_graphs = os.environ.get("ML3D_RANDLA_GRAPHS", "1") != "0"
+        # _forward_graphed).  OFF by default: measured on the MI355X / ROCm 7.2 (profiles/r05_latency_graphs_ab.log) a replay of
+        # the ~60-node patch graph + the ~35-node forward graph is no faster than launching the kernels (1.69-1.71 against
+        # 1.64 ms per frame at batch 1: the chain is bound by the GPU's dependent-dispatch latency, not by the host) and shows
+        # 90 ms outliers.  ML3D_RANDLA_GRAPHS=1 / ``model.use_graphs = True`` turn them on; results are bit-identical either way
+        # (tests/test_gpu_api.py).
+        self.use_graphs = os.environ.get("ML3D_RANDLA_GRAPHS", "0") == "1"
         self.eval()
 
     # ---- packed weights ---------------------------------------------------------------------------
