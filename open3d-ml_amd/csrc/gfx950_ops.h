@@ -25,6 +25,11 @@ __device__ __forceinline__ void key_insert_step(double& slot, double& x) {
     asm("v_min_f64 %0, %0, %1" : "+v"(slot) : "v"(x));
     x = t;
 }
+// acc <- min(acc, key) for the lanes where `take` holds, as ONE predicated v_min_f64 (exec masking: the volatile asm keeps the
+// compiler from turning the condition into a 64-bit select -- two v_cndmask_b32 per candidate in a VALU-issue-bound loop)
+__device__ __forceinline__ void key_min_if(bool take, double& acc, double key) {
+    if (take) asm volatile("v_min_f64 %0, %0, %1" : "+v"(acc) : "v"(key));
+}
 __device__ __forceinline__ double key_min(double a, double b) {
     double lo;
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));

@@ -95,7 +95,7 @@ __device__ __forceinline__ void scan_run(const GridView& G, int p0, int p1, floa
             const float d2 = (dxy.x + dxy.y) + dz * dz;
             const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(c[j].w);
             const double kd = __longlong_as_double((long long)key);
-            if (SUB) best1 = key_min(best1, __float_as_int(c[j].w) < n_sub ? kd : __longlong_as_double((long long)KEY_EMPTY));
+            if (SUB) key_min_if(__float_as_int(c[j].w) < n_sub, best1, kd);      // (prefix candidates only: level l + 1 = [:n_sub])
             topk_insert<K>(best, kd);
         }
     }
