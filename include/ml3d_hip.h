@@ -181,7 +181,7 @@ int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* voxel_size_
 /* output = barycentre (float32 sums in original point order / count),         */
 /* feature mean, majority label (ties: smallest); voxels ascending linear key. */
 /*  count: out_lengths int64[batch], out_stats int64[2] = {total M, error}     */
-/*         (error != 0: an item spans >= 2^48 voxels — unsupported).           */
+/*         (error != 0: an item spans >= 2^40 voxels — unsupported).           */
 /*  fill : out_points [M,3], out_features [M,feature_dim] / out_labels [M]     */
 /*         when the inputs are non-NULL.  Same workspace as count.             */
 /* ------------------------------------------------------------------------- */

@@ -229,7 +229,7 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
         }
         if (l + 1 == L) break;
         // ---- pooled level l + 1 ------------------------------------------------------------------------------------------------
-        if (hrec[3]) return ML3D_E_UNSUPPORTED;            // an item spans >= 2^48 voxels at this dl
+        if (hrec[3]) return ML3D_E_UNSUPPORTED;            // an item spans >= 2^40 voxels at this dl
         const int64_t m_next = hrec[2];
         n[l + 1] = m_next;
         for (int64_t b = 0; b < batch; ++b) out_lengths_host[(size_t)(l + 1) * (size_t)batch + b] = (int32_t)hrec[8 + b];

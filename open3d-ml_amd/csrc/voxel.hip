@@ -210,7 +210,10 @@ __global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restric
 }
 
 // ---- grid subsample ------------------------------------------------------------------------------------
-constexpr int SUB_ITEM_SHIFT = 48;   // key = item << 48 | linear voxel id
+// key = item << 40 | linear voxel id.  40 bits per item (a 10 000^3 grid: 600 m of extent at the 0.06 m of the raw-sweep front
+// end) instead of round 1's 48: the stable radix sort of the keys runs 8 bits per pass in an even number of passes, so a 64-item batch
+// takes 6 passes (47 key bits) instead of 8 (55) -- a quarter of the sort's launches, which are what the batch build's subsampling costs
+constexpr int SUB_ITEM_SHIFT = 40;
 
 __global__ void sub_setup(const unsigned* __restrict__ bbox, Segs S, float dl, float* __restrict__ seg, int64_t* err) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,7 +234,7 @@ __global__ void sub_setup(const unsigned* __restrict__ bbox, Segs S, float dl, f
         o[3 + a] = __int_as_float(G);
         cells *= (double)G;
     }
-    if (cells >= 281474976710656.0) *err = 1;   // 2^48 voxels per item
+    if (cells >= 1099511627776.0) *err = 1;     // 2^40 voxels per item
 }
 
 __global__ void sub_keys(const float* __restrict__ pts, Segs S, int64_t n, float dl, const float* __restrict__ seg,

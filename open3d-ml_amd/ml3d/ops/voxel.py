@@ -87,7 +87,7 @@ def subsample_batch(points, batches_len, features=None, classes=None, sampleDl=0
         _abi.check(rc, "ml3d_subsample_count")
         M, err = (int(x) for x in stats.tolist())
         if err:
-            raise RuntimeError("subsample: a batch item spans >= 2^48 voxels at this sampleDl (unsupported)")
+            raise RuntimeError("subsample: a batch item spans >= 2^40 voxels at this sampleDl (unsupported)")
         fd = 0 if feats is None else feats.shape[1]
         op = torch.empty((M, 3), dtype=torch.float32, device=dev)
         of = None if feats is None else torch.empty((M, fd), dtype=torch.float32, device=dev)
@@ -174,7 +174,7 @@ class _SubsamplePlan:
         if self.M is None:
             self.M, err = (int(x) for x in (self.stats.tolist() if values is None else values))
             if err:
-                raise RuntimeError("subsample: a batch item spans >= 2^48 voxels at this sampleDl (unsupported)")
+                raise RuntimeError("subsample: a batch item spans >= 2^40 voxels at this sampleDl (unsupported)")
         return self
 
     def fill(self):
