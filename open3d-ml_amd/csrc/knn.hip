@@ -47,7 +47,7 @@ struct QuerySrc {
 // and four selects.  d2 == 0 gives a denormal double, which f64 min/max preserve (f64 denormals are never flushed on
 // gfx950).  Measured (tools/micro/valu_rates.hip, profiles/r02_micro_valu_rates.log): v_min_f64 / v_max_f64 issue at the
 // rate of v_min_u32; the integer form (v_cmp_lt_u64 + 4 v_cndmask) is 7.6x slower.
-// (Measured and removed, numbers in DESIGN.md §3.2: a branchless insertion, a pending queue merged by sorting networks, an
+// (Measured and removed, numbers in profiles/DESIGN_rounds_1_to_4.md §3.2: a branchless insertion, a pending queue merged by sorting networks, an
 // LDS-transposed index store.)
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], double key) {

@@ -35,7 +35,7 @@ struct Knobs {
     int attn_grid, attn16_grid;
     long long fuse_rows;
 };
-// The A/B switches of rounds 1-3 are settled (numbers in DESIGN.md §3.3, §9): XCD-aware tile walk, split score Linear, split
+// The A/B switches of rounds 1-3 are settled (numbers in profiles/DESIGN_rounds_1_to_4.md §3.3, §9): XCD-aware tile walk, split score Linear, split
 // decoder, decoder-last + fc1 chain and shaped MLP chains are ON wherever their shape conditions hold; the generic VALU kernels
 // and the per-layer launches remain as the fallback for widths / sizes the MFMA kernels do not cover.  The product library
 // reads nothing from the environment (no process-wide state); only the tests' HOST EMULATOR build

@@ -310,7 +310,7 @@ class KPFCNN(nn.Module):
         return ops.linear(x, p['wt'], p['b'], a2=a2, gather=gather, residual=residual,
                           act=p['act'] if act is None else act, slope=p['slope'] if slope is None else slope)
 
-    _SPLIT_DECODER = True        # decoder step split by linearity (+2 %); False = one gather + concat GEMM
+    _SPLIT_DECODER = True        # decoder step split by linearity (+2 %, profiles/DESIGN_rounds_1_to_4.md §3.7); False = one gather + concat GEMM
     _FUSE_SHORTCUT = True        # unary2 + shortcut Linear as ONE GEMM over the concatenated K
 
     def _upsample_concat_unary(self, p, x, skip, up):

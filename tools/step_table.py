@@ -1,5 +1,5 @@
 """Per-STEP view of a rocprofv3 kernel table: ms per step, launches per step and register / LDS use per kernel, plus the GPU-busy
-total per step (sum over streams) -- the numbers DESIGN.md §3 / §8 argue with.
+total per step (sum over streams) -- the numbers profiles/DESIGN_rounds_1_to_4.md §3 / §8 argue with.
 usage: python tools/step_table.py <results.db | kernel_stats.csv> <steps> [top]
   <steps> = timed + warm-up steps of the profiled command (bench.py: --steps + --warmup)"""
 import csv
