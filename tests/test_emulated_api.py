@@ -325,6 +325,37 @@ print("ok")
 ''')
 
 
+def test_kpconv_batch_build_in_one_call_edge_cases():
+    """The one-call batch build on degenerate batches -- a single item, an EMPTY item between two spheres, one-point items,
+    forty coincident points -- equals the per-layer loop matrix for matrix (rotated and axis-aligned pooling grids)."""
+    _run(r'''
+import synth_data, synth_weights as W
+from ml3d.torch.models.kpconv import KPConvBatch
+cfg = dict(W.TORONTO3D_CFG)
+def same(a, b):
+    assert len(a.points) == len(b.points)
+    for l in range(len(a.points)):
+        assert torch.equal(a.points[l], b.points[l]), ("points", l)
+        assert torch.equal(a.lengths[l], b.lengths[l]), ("lengths", l, a.lengths[l], b.lengths[l])
+        for name in ("neighbors", "pools", "upsamples"):
+            x, y = getattr(a, name)[l], getattr(b, name)[l]
+            assert x.shape == y.shape and torch.equal(x, y), (name, l, x.shape, y.shape)
+cases = {
+  "one item": [synth_data.toronto3d_sphere(3, 1500, radius=2.0)],
+  "empty item in the middle": [synth_data.toronto3d_sphere(3, 800, radius=1.5), np.zeros((0, 3), np.float32), synth_data.toronto3d_sphere(4, 700, radius=1.5)],
+  "one point items": [np.array([[0.1, 0.2, 0.3]], np.float32), synth_data.toronto3d_sphere(5, 600, radius=1.5), np.array([[5., 5., 5.]], np.float32)],
+  "coincident points": [np.repeat(np.array([[1., 2., 3.]], np.float32), 40, 0), synth_data.toronto3d_sphere(6, 500, radius=1.2)],
+}
+for name, spheres in cases.items():
+    pts, lens = np.concatenate(spheres).astype(np.float32), [len(s) for s in spheres]
+    for rot in ("random", None):
+        np.random.seed(2); one = KPConvBatch(pts, lens, cfg, rotations=rot, device="cpu")
+        np.random.seed(2); loop = KPConvBatch(pts, lens, cfg, rotations=rot, device="cpu", one_call=False)
+        same(one, loop)
+        print(name, rot, "ok; one-call:", hasattr(one, "host_syncs"), [int(p.shape[0]) for p in one.points])
+''')
+
+
 def test_kpfcnn_with_deformable_blocks_matches_the_real_reference_golden():
     """``KPFCNN`` with ``resnetb_deformable`` / ``resnetb_deformable_strided`` blocks (kpconv_parislille3d.yml:28-32; here the
     three-layer KPCONV_DEFORM_SMALL_CFG): GPU-side batch build (deform radius on the deformable layers) and forward through the
