@@ -356,7 +356,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("ML3D_BENCH_BATCH", 64)))
+    ap.add_argument("--frames-per-step", type=int, default=None,
+                    help="units per step and GPU; default: 128 frames (randlanet; ML3D_BENCH_BATCH overrides), 96 spheres (kpconv), "
+                         "16 sweeps (pointpillars)")
     ap.add_argument("--distinct-frames", type=int, default=8,
                     help="distinct synthetic frames generated per rank (tiled with seeded rigid transforms)")
     ap.add_argument("--workload", choices=["randlanet", "kpconv", "pointpillars"], default="randlanet",
@@ -429,7 +431,9 @@ def main():
 
     from ml3d.engine import RandLAFrameStream, make_trace
 
-    B, N = args.frames_per_step, CFG["num_points"]
+    # 128 frames per step (round 5; 64 until then): same box, alternating -- 6153 / 6220 frames/s at 64, 6292 at 96, 6301 / 6316 at 128,
+    # 6273 at 192 (profiles/r05_batch_sweep.log): the tails of the step's ~50 launches are amortised over twice the work
+    B, N = args.frames_per_step or int(os.environ.get("ML3D_BENCH_BATCH", 128)), CFG["num_points"]
     overlap = not args.no_overlap and not stub
     if stub:
         N = 257
@@ -565,7 +569,8 @@ def main():
                     # the bound the kernel actually sits on: SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (PMC pass of the launch alone)
                     cands[-1]["valu_frac"] = sq.get("valu_frac_of_busy_cycles")
                     cands[-1]["valu_frac_at_2p4ghz"] = sq.get("valu_frac_at_2p4ghz")
-                    cands[-1]["valu_insts_per_launch"] = sq.get("insts_valu_per_launch")
+                    # (the PMC pass profiles a 64-frame launch: tools/knn_only.py; the count scales with the frames)
+                    cands[-1]["valu_insts_per_launch"] = sq.get("insts_valu_per_launch") and sq["insts_valu_per_launch"] * B / 64.0
                     cands[-1]["valu_source"] = "profiles/%s" % sq.get("source")
             else:
                 layer, stage = tag // 8, tag % 8

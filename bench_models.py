@@ -200,7 +200,7 @@ def run_pointpillars(args, rank, world, dev, dist):
     from ml3d import dist as mdist
     import os
     stub = bool(getattr(args, "stub", False))
-    B = args.frames_per_step if args.frames_per_step != 64 else 16    # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
+    B = args.frames_per_step or 16                         # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
     n_boxes = [0]
     last = [None, 0]            # (what rank 0 received for the last delivered step, number of delivered steps)
     overlap = not getattr(args, "no_overlap", False)
@@ -383,7 +383,9 @@ def run_kpconv(args, rank, world, dev, dist):
     stub = bool(getattr(args, "stub", False))
     # spheres per step: the batch build is launch/latency-bound (~550 small launches + 9 host read-backs per batch whatever
     # its size), so throughput follows the batch (round 2, pipelined: 16 -> 3219, 32 -> 4400, 48 -> 4748, 63 -> 5002 spheres/s)
-    B = args.frames_per_step                               # 64 spheres per step by default, like the RandLA line
+    # 96 spheres per step by default (round 5; 64 until then).  Same box: 8257 / 8268 spheres/s at 64, 8708 at 96, 8609 / 8526 at 128
+    # (profiles/r05_batch_sweep.log) -- the build chain's per-launch latencies are amortised over more rows
+    B = args.frames_per_step or 96
     overlap = not getattr(args, "no_overlap", False)
     last = [None, 0]
     builders = 1

@@ -25,7 +25,7 @@ pmc() {     # out csv name, counters (quoted), command...
 stats randla --steps 20 --warmup 5 --no-cpu-baseline --no-workloads --no-latency
 stats kp --workload kpconv --steps 10 --warmup 3 --no-cpu-baseline --no-latency
 stats pp --workload pointpillars --steps 10 --warmup 3 --no-cpu-baseline --no-latency
-STEP="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-workloads --no-latency"
+STEP="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames-per-step 64 --no-overlap --no-cpu-baseline --no-workloads --no-latency"
 pmc fetch FETCH_SIZE $STEP
 pmc write WRITE_SIZE $STEP
 pmc kp_fetch FETCH_SIZE python $GRAFT_REPO_ROOT/tools/roofline_ops.py kp 4
