@@ -15,7 +15,16 @@
  *    (`*_workspace_bytes` tells how much), ragged results are two-phase
  *    (count -> caller allocates -> fill);
  *  - return value 0 = ok, <0 = ML3D_E_* (the Python wrappers raise RuntimeError);
- *  - no global state: re-entrant, one stream per call.
+ *  - no global state: re-entrant, one stream per call; no environment reads;
+ *  - `nothing synchronises` has ONE exception, ml3d_kpconv_batch_build, whose
+ *    point is to do a batch build's size read-backs inside the call;
+ *  - HIP graph capture (hipStreamBeginCapture on `stream`): the RandLA path
+ *    (ml3d_randla_knn_pyramid*, ml3d_randla_forward*, ml3d_nearest_to_center_dev,
+ *    ml3d_patch_crop / _recenter, ml3d_vote_update) contains kernel nodes only
+ *    and replays correctly (tests/test_gpu_api.py).  Other entry points clear
+ *    buffers with hipMemsetAsync, and on ROCm 7.2 a captured graph's memset
+ *    node was observed NOT to clear its target on later replays:
+ *    do not capture them until that is fixed upstream.
  *  - index results are bit-exact w.r.t. the canonical orders documented in
  *    oracle/ml3d_oracle.c; float results are within 1e-4 abs of the reference
  *    PyTorch-CPU forward.
