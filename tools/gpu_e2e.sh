@@ -16,5 +16,5 @@ tar xzf .refpack/open3d_ml_ref.tgz -C /tmp/o3dml_ref
   echo "== reference side (build container, PyTorch-CPU + oracle ops):"
   grep "^== \[.*exit" .refpack/e2e_reference/reference.log || true
   python tools/run_pipeline_e2e.py --compare "$OUT" .refpack/e2e_reference
-} 2>&1 | tee "$OUT/r04_run_pipeline_e2e.log"
+} 2>&1 | tee "$OUT/r05_run_pipeline_e2e.log"
 find "$OUT" -name "*.labels" -delete
