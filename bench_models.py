@@ -222,7 +222,8 @@ def run_pointpillars(args, rank, world, dev, dist):
         # ML3D_PP_LANES (A/B knob, default 2): the step's sweeps are dealt to this many independent pipelines (own HIP streams)
         # -- while one lane's convolution drains its last, partly filled round of tiles the other lane's kernels fill the idle CUs
         lanes = max(1, min(B, int(os.environ.get("ML3D_PP_LANES", "2"))))
-        pipe = PointPillarsStream(m, dev, lanes=lanes)
+        # ML3D_PP_THREADED (A/B knob, default 1): one host thread per lane
+        pipe = PointPillarsStream(m, dev, lanes=lanes, threaded=os.environ.get("ML3D_PP_THREADED", "1") == "1")
 
     def deliver(res):
         """a step's detections (host tensors): counted; N > 1: every rank's [n_i, 9] rows -> rank 0 (the ragged gather)"""

@@ -491,9 +491,18 @@ class PointPillarsStream:
     ``submit`` returns the detections of the PREVIOUS step (three lists in the order of that step's sweeps; None on the first
     call), ``flush`` the last step's."""
 
-    def __init__(self, model, device, lanes=2):
+    def __init__(self, model, device, lanes=2, threaded=True):
+        """``threaded`` (default since round 5): every lane's ``submit`` runs on its own host thread.  A lane's step blocks the host
+        once, in the voxelization's size read-back; with one host thread lane 1 is not even enqueued while lane 0 waits there.
+        Measured, alternating on one box (``profiles/r05_pp_threaded_ab.log``): 1408 / 1407 / 1421 frames/s threaded against 1347 /
+        1404 / 1339 -- the single-threaded pipeline's two per-process modes (rounds 3-4: 1310 or 1400, drawn per process) are the
+        slow and the fast interleaving of the two lanes' host work; with a thread per lane only the fast one is left."""
         self.lanes = [_PointPillarsLane(model, device) for _ in range(max(1, int(lanes)))]
         self.compute = self.lanes[-1].compute          # (the stream whose completion events pace a step in the bench)
+        self.pool = None
+        if threaded and len(self.lanes) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=len(self.lanes), thread_name_prefix="pp-lane")
 
     @staticmethod
     def _merge(parts):
@@ -507,7 +516,11 @@ class PointPillarsStream:
         THEIR share of the previous step here, so the merged result always is exactly the previous step's detections, in order."""
         n, k = len(host_clouds), len(self.lanes)
         use = max(1, min(k, n))
-        parts = [self.lanes[i].submit(host_clouds[i * n // use:(i + 1) * n // use]) for i in range(use)]
+        if self.pool is not None and use > 1:
+            futs = [self.pool.submit(self.lanes[i].submit, host_clouds[i * n // use:(i + 1) * n // use]) for i in range(use)]
+            parts = [f.result() for f in futs]
+        else:
+            parts = [self.lanes[i].submit(host_clouds[i * n // use:(i + 1) * n // use]) for i in range(use)]
         parts += [self.lanes[i].flush() for i in range(use, k)]
         return self._merge(parts)
 

@@ -135,14 +135,15 @@ def test_two_lane_stream_returns_the_single_lane_detections():
     steps = [_clouds(cfg, range(16 * s, 16 * s + 16)) for s in range(3)]
     hosts = [[torch.from_numpy(c).pin_memory() for c in st] for st in steps]
     runs = []
-    for lanes in (1, 2):
-        pipe = PointPillarsStream(m, "cuda", lanes=lanes)
+    for lanes, threaded in ((1, False), (2, False), (2, True)):          # (2 lanes on one host thread / one thread per lane: round 5)
+        pipe = PointPillarsStream(m, "cuda", lanes=lanes, threaded=threaded)
         got = [pipe.submit(h) for h in hosts] + [pipe.flush()]
         assert got[0] is None and pipe.flush() is None
         runs.append(got[1:])
-    for one, two in zip(*runs):
-        assert len(one[0]) == len(two[0]) == 16
-        for i in range(16):
-            assert torch.equal(one[2][i], two[2][i]) and len(one[2][i]) > 0, i
-            assert (one[1][i] - two[1][i]).abs().max().item() <= 1e-5
-            assert (one[0][i] - two[0][i]).abs().max().item() <= 1e-4
+    for other in runs[1:]:
+        for one, two in zip(runs[0], other):
+            assert len(one[0]) == len(two[0]) == 16
+            for i in range(16):
+                assert torch.equal(one[2][i], two[2][i]) and len(one[2][i]) > 0, i
+                assert (one[1][i] - two[1][i]).abs().max().item() <= 1e-5
+                assert (one[0][i] - two[0][i]).abs().max().item() <= 1e-4
