@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=None,
                     help="units per step and GPU; default: 128 frames (randlanet; ML3D_BENCH_BATCH overrides), 96 spheres (kpconv), "
-                         "16 sweeps (pointpillars)")
+                         "32 sweeps (pointpillars)")
     ap.add_argument("--distinct-frames", type=int, default=8,
                     help="distinct synthetic frames generated per rank (tiled with seeded rigid transforms)")
     ap.add_argument("--workload", choices=["randlanet", "kpconv", "pointpillars"], default="randlanet",

@@ -200,7 +200,9 @@ def run_pointpillars(args, rank, world, dev, dist):
     from ml3d import dist as mdist
     import os
     stub = bool(getattr(args, "stub", False))
-    B = args.frames_per_step or 16                         # sweeps per step (round 1: 4: 955, 8: 1092, 16: 1134 frames/s)
+    # sweeps per step: 32 on two threaded lanes (round 5; 16 until then).  One box, threaded lanes: 2 x 16: 1387-1424 frames/s,
+    # 2 x 32: 1451 / 1462, 3 x 24: 1410-1479, 3 x 48: 1453, 4 x 32: 1405 (profiles/r05_pp_lanes_sweep.log)
+    B = args.frames_per_step or 32
     n_boxes = [0]
     last = [None, 0]            # (what rank 0 received for the last delivered step, number of delivered steps)
     overlap = not getattr(args, "no_overlap", False)
