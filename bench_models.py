@@ -391,7 +391,7 @@ def run_kpconv(args, rank, world, dev, dist):
     B = args.frames_per_step or 96
     overlap = not getattr(args, "no_overlap", False)
     last = [None, 0]
-    builders = 1
+    builders = fwd_streams = 1
     if stub:
         host_pts, lens, pipe = torch.zeros((4, 3)), [4], _StubLogits(rank)
     else:
@@ -412,7 +412,12 @@ def run_kpconv(args, rank, world, dev, dist):
         # ML3D_KP_BUILDERS (A/B knob): batch builds in flight, each on its own stream and host thread (1 = the two-stream
         # pipeline of rounds 2-4: one build under one forward)
         builders = max(1, int(os.environ.get("ML3D_KP_BUILDERS", "2")))
-        pipe = KPConvPipelineN(m, cfg, dev, builders=builders) if builders > 1 else KPConvPipeline(m, cfg, dev)
+        # ML3D_KP_FORWARD_STREAMS (A/B knob, default 2): consecutive batches' forwards alternate between two compute streams -- the deep
+        # layers' small kernels of one batch run under the large ones of the next: 9076 / 9034 / 9012 against 8587 / 8560 / 8601 spheres/s
+        # alternating on one box (profiles/r05_kp_forward_streams_ab.log); three builders + two streams: 8563
+        fwd_streams = max(1, int(os.environ.get("ML3D_KP_FORWARD_STREAMS", "2")))
+        pipe = KPConvPipelineN(m, cfg, dev, builders=builders, forward_streams=fwd_streams) if (builders > 1 or fwd_streams > 1) \
+            else KPConvPipeline(m, cfg, dev)
 
     def finish(res):
         if res is not None and world > 1:       # (every rank's batch has its own point count: the ragged gather)
@@ -455,7 +460,7 @@ def run_kpconv(args, rank, world, dev, dist):
             timer.new_step()
             prim_ev.append(new_trace())
             step()
-    dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=pipe.compute if overlap else
+    dt = _timed(timed_step, args.steps, args.warmup, world, dist, dev, ev_stream=(lambda: pipe.compute) if overlap else
                 (lambda: torch.cuda.current_stream(dev)), intervals=iv)
     rest = pipe.flush()
     for r in (rest if isinstance(rest, list) else [rest]):
@@ -525,7 +530,7 @@ def run_kpconv(args, rank, world, dev, dist):
            "config": {"workload": "KPConv (rigid) Toronto3D inference, %d synthetic 10000-point input spheres per step per "
                                   "GPU (kpconv_toronto3d.yml): radius search + grid subsample batch build, then forward%s" % (B, (" (%d one-call batch builds in flight on their own HIP streams / host threads under the forwards on another)" % builders if builders > 1 else " (build of step i+1 overlapped with the forward of step i on two HIP streams)") if overlap else ""),
                       "frames_per_step_per_gpu": B, "points_per_step": int(sum(lens)), "h2d_in_timed_region": True,
-                      "builds_in_flight": builders if overlap else 1,
+                      "builds_in_flight": builders if overlap else 1, "forward_streams": fwd_streams if overlap else 1,
                       "parallelism": "frame-parallel x%d" % world},
            "latency_single_sphere_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "spheres": len(lat)},
            "roofline": {"bound": "mfma", "kernel": "kp_agg_gemm32 (KPConv %d->%d, %d queries x %d neighbour columns: MFMA aggregation + the [480 x 32] product in one kernel)" % (cin, cout, nq, H),

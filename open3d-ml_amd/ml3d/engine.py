@@ -349,7 +349,9 @@ class KPConvPipelineN:
     sequence with the same seed."""
     Result = KPConvPipeline.Result
 
-    def __init__(self, model, cfg, device, builders=2):
+    def __init__(self, model, cfg, device, builders=2, forward_streams=1):
+        """``forward_streams``: consecutive batches' forwards alternate between this many compute streams (the deep layers' small
+        kernels of one batch under the large ones of the next); 1 = every forward on one stream."""
         from concurrent.futures import ThreadPoolExecutor
         self.model, self.cfg = model, cfg
         self.device = torch.device(device)
@@ -358,7 +360,9 @@ class KPConvPipelineN:
         self.n = max(1, int(builders))
         with torch.cuda.device(self.device):
             self.build_streams = [torch.cuda.Stream(priority=-1) for _ in range(self.n)]
-            self.compute = torch.cuda.Stream(priority=0)
+            self.computes = [torch.cuda.Stream(priority=0) for _ in range(max(1, int(forward_streams)))]
+            self.compute = self.computes[0]       # (the stream of the most recently enqueued forward)
+        self.forwards = 0
         self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="kpconv-build")
         self.inflight = []            # futures of (batch, built event), submission order
         self.alive = []
@@ -379,15 +383,17 @@ class KPConvPipelineN:
 
     def _forward(self, fut):
         batch, built = fut.result()
-        with torch.cuda.device(self.device), torch.cuda.stream(self.compute):
-            self.compute.wait_event(built)
+        st = self.compute = self.computes[self.forwards % len(self.computes)]
+        self.forwards += 1
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
+            st.wait_event(built)
             logits = self.model(batch)
             done = torch.cuda.Event()
-            done.record(self.compute)
+            done.record(st)
         res = KPConvPipeline.Result(logits, done, batch)
         self.alive = [r for r in self.alive if not r.done.query()]
         self.alive.append(res)
-        while len(self.alive) > self.n + 1:
+        while len(self.alive) > self.n + len(self.computes):
             self.alive.pop(0).done.synchronize()
         return res
 
@@ -411,9 +417,8 @@ class KPConvPipelineN:
         return out
 
     def synchronize(self):
-        for s in self.build_streams:
+        for s in self.build_streams + self.computes:
             s.synchronize()
-        self.compute.synchronize()
 
 
 class _PointPillarsLane:

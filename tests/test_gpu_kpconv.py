@@ -137,8 +137,8 @@ def test_pipeline_build_under_forward_is_bit_identical_to_the_sequential_loop():
             assert a.shape == b.shape and np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("builders", [2, 3])
-def test_pipeline_with_several_builds_in_flight_is_bit_identical_to_the_sequential_loop(builders):
+@pytest.mark.parametrize("builders,fwd_streams", [(2, 1), (3, 1), (2, 2), (1, 2)])
+def test_pipeline_with_several_builds_in_flight_is_bit_identical_to_the_sequential_loop(builders, fwd_streams):
     """ml3d.engine.KPConvPipelineN (what bench.py --workload kpconv times since round 5): two / three one-call batch builds in
     flight on their own HIP streams and host threads, forwards in submission order -- logits identical to
     model(KPConvBatch(..)) run one after the other with the same seed (the grid orientations are drawn at submit time)."""
@@ -153,7 +153,7 @@ def test_pipeline_with_several_builds_in_flight_is_bit_identical_to_the_sequenti
     seq = [m(KPConvBatch(p, l, CFG, device=dev)).cpu().numpy() for p, l in inputs]
     for rep in range(2):
         np.random.seed(5)
-        pipe = KPConvPipelineN(m, CFG, dev, builders=builders)
+        pipe = KPConvPipelineN(m, CFG, dev, builders=builders, forward_streams=fwd_streams)     # (forwards alternate between streams)
         got = []
         for i, (p, l) in enumerate(inputs):
             r = pipe.submit(p, l)
