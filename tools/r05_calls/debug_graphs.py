@@ -1,9 +1,9 @@
-"""GPU box: which captured piece of the patch loop misbehaves.  usage: python tools/debug_graphs.py <piece>
+"""GPU box: which captured piece of the patch loop misbehaves.  usage: python tools/r05_calls/debug_graphs.py <piece>
 pieces: argmin | patch | pyramid | labels | forward  (each captures ONLY that piece into a graph, replays it 3 times, checks vs eager)"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,8 +1,8 @@
-"""GPU box: the REAL graphed patch loop, piecewise.  usage: python tools/debug_graphs2.py patch|both [patches]"""
+"""GPU box: the REAL graphed patch loop, piecewise.  usage: python tools/r05_calls/debug_graphs2.py patch|both [patches]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,9 +1,9 @@
 """GPU box: the patch loop with only ONE part of the per-patch sequence captured, the rest eager, data changing between replays.
-usage: python tools/debug_graphs3.py crop|pyramid|labels|argmin [patches]"""
+usage: python tools/r05_calls/debug_graphs3.py crop|pyramid|labels|argmin [patches]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd")):
     sys.path.insert(0, p)
 import numpy as np
