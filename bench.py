@@ -597,6 +597,11 @@ def main():
                        "frames_per_step_per_gpu": B, "num_points": N, "parallelism": "frame-parallel x%d" % world,
                        "h2d_in_timed_region": True, "argmax_in_timed_region": True, "streams": 4 if overlap else 1},
             "roofline": cands[0], "roofline_other": cands[1:],
+            # the whole step on the reference's formulation (~14 GFLOP per frame through LFA x 4, the per-point MLPs and
+            # the decoder): what the GPU delivers end to end, searches, upload and argmax included -- independent of how streams overlap
+            "end_to_end": {"tflops": 14.0e9 * (B * K * world / dt) / world / 1e12,
+                           "frac_of_f32_mfma_peak": 14.0e9 * (B * K * world / dt) / world / 1e12 / PEAK_F32_TFLOPS,
+                           "note": "14 GFLOP per frame (SURVEY.md §8d, reference formulation) x frames/s per GPU"},
         }
         if args.breakdown:
             bd = {}

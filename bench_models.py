@@ -330,6 +330,9 @@ def run_pointpillars(args, rank, world, dev, dist):
                         "sweeps_per_launch": int(Bm), "launches_timed": len(in_region),
                         "timed": "inside the timed region, on the lane's compute stream, the other lane co-running",
                         "avg_launch_ms_alone_lane_shape": alone["lane"], "avg_launch_ms_alone_whole_batch": alone["batch"],
+                        # (two lanes of 16 sweeps each fill the GPU on their own: in the step they TIME-SHARE it, so the in-step launch
+                        #  time is a share of the GPU, not the kernel's efficiency -- that is `frac_alone_lane_shape` / `end_to_end_frac`)
+                        "frac_alone_lane_shape": flops / (alone["lane"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "frac_alone_whole_batch": 2.0 * B * OH * OW * Co * w.shape[0] / (alone["batch"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "end_to_end_tflops": e2e_tflops, "end_to_end_frac": e2e_tflops / PEAK_F32_TFLOPS,
                         "end_to_end_note": "68.3 GFLOP per frame (SURVEY.md §8d) x frames/s per GPU: every kernel of the step, "
@@ -544,7 +547,13 @@ def run_kpconv(args, rank, world, dev, dist):
                         "avg_launch_ms_alone": t2.mean_ms(),
                         "frac_alone": flops_exec / (t2.mean_ms() * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         # the op's ALGORITHMIC HBM bytes: index matrix + positions + feature rows in, output rows out
-                        "algorithmic_bytes_per_launch": 4.0 * nq * H + 12.0 * (nq + s.shape[0]) + 4.0 * cin * s.shape[0] + 4.0 * cout * nq}}
+                        "algorithmic_bytes_per_launch": 4.0 * nq * H + 12.0 * (nq + s.shape[0]) + 4.0 * cin * s.shape[0] + 4.0 * cout * nq,
+                        # with two forward streams (and two builds) in flight an in-step launch time is a SHARE of the GPU, not the
+                        # kernel's efficiency: the whole step on the reference's formulation is the figure that does not depend on overlap
+                        "end_to_end_tflops": 11.5e9 * (B * args.steps * world / dt) / world / 1e12,
+                        "end_to_end_frac": 11.5e9 * (B * args.steps * world / dt) / world / 1e12 / PEAK_F32_TFLOPS,
+                        "end_to_end_note": "11.5 GFLOP per sphere (SURVEY.md §8d: KPConv aggregation + products + unary / decoder Linears, "
+                                           "reference formulation) x spheres/s per GPU: every kernel of the step, H2D and the batch build included"}}
     # ---- the HBM-bound primitives of the build as roofline objects ------------------------------
     rnq = rns = int(last_batch.points[0].shape[0])
     rH = int(last_batch.neighbors[0].shape[1])
