@@ -642,7 +642,15 @@ def main():
             torch.cuda.empty_cache()
             wl = {}
             for name in ("kpconv", "pointpillars"):
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "30", "--warmup", "8"]       # (a fresh process: the
+                # warm-up: 30 KPConv steps / 12 PointPillars steps.  The FIRST process on a cold box needs them: its caching-allocator
+                # pools (two builder streams + two forward streams for KPConv) keep growing for ~25 steps, and every growth is a
+                # hipMalloc that stalls the step for 20-80 ms (profiles/r05_kp_cold_box.log: 5822 spheres/s with 8 warm-up steps as
+                # the first process on a box, 9071 / 9010 in the next two processes)
+                # ... and timed regions of ~1.3 s (120 KPConv steps, 60 PointPillars steps) instead of 0.3 s: a cold box showed sporadic
+                # GPU-wide stalls of 30-80 ms in its first process whatever the pipeline configuration (same log), and one of them
+                # in a 0.3 s region is a 15-25 % error
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "120" if name == "kpconv" else "60",
+                       "--warmup", "30" if name == "kpconv" else "12"]       # (a fresh process: the
                 # first steps still grow the allocator pools of both streams -- with 3 warm-up steps a cold box showed 13 ms outliers
                 # among 8.8 ms steps)
                 if args.no_cpu_baseline:

@@ -349,9 +349,14 @@ class KPConvPipelineN:
     sequence with the same seed."""
     Result = KPConvPipeline.Result
 
-    def __init__(self, model, cfg, device, builders=2, forward_streams=1):
+    def __init__(self, model, cfg, device, builders=2, forward_streams=1, reuse_buffers=True):
         """``forward_streams``: consecutive batches' forwards alternate between this many compute streams (the deep layers' small
-        kernels of one batch under the large ones of the next); 1 = every forward on one stream."""
+        kernels of one batch under the large ones of the next); 1 = every forward on one stream.
+        ``reuse_buffers`` (default): the builds draw their workspace and output arena from a ring of ``builders + forward_streams +
+        2`` buffer sets owned by the pipeline instead of fresh allocations -- nothing of the build goes through the caching
+        allocator in steady state (on a cold box every pool growth was a 20-80 ms stall: ``profiles/r05_kp_cold_box.log``).  A
+        ``Result.batch``'s tensors alias its ring entry: they are valid until that many more batches have been submitted (the logits
+        are the result's own)."""
         from concurrent.futures import ThreadPoolExecutor
         self.model, self.cfg = model, cfg
         self.device = torch.device(device)
@@ -363,18 +368,27 @@ class KPConvPipelineN:
             self.computes = [torch.cuda.Stream(priority=0) for _ in range(max(1, int(forward_streams)))]
             self.compute = self.computes[0]       # (the stream of the most recently enqueued forward)
         self.forwards = 0
+        self.ring = [dict() for _ in range(self.n + len(self.computes) + 2)] if reuse_buffers else None
+        self.ring_done = [None] * (len(self.ring) if self.ring else 0)       # the forward that last read a ring entry's arena
         self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="kpconv-build")
         self.inflight = []            # futures of (batch, built event), submission order
         self.alive = []
         self.count = 0
         self.pool_layers = sum(1 for b in cfg['architecture'] if 'pool' in b or 'strided' in b)
 
-    def _build(self, slot, points, lengths, features, rotations, ready):
+    def _build(self, slot, points, lengths, features, rotations, ready, ring_index):
         from .torch.models.kpconv import KPConvBatch
         st = self.build_streams[slot]
+        buffers = None
+        if self.ring is not None:
+            buffers = self.ring[ring_index]
+            prev = self.ring_done[ring_index]
+            if prev is not None:
+                st.wait_event(prev)                # the forward that read this entry's previous batch (enqueued long ago)
         with torch.cuda.device(self.device), torch.cuda.stream(st):
             st.wait_event(ready)                   # the caller's inputs
-            batch = KPConvBatch(points, lengths, self.cfg, features=features, rotations=rotations, device=self.device)
+            batch = KPConvBatch(points, lengths, self.cfg, features=features, rotations=rotations, device=self.device, buffers=buffers)
+            batch._ring_index = ring_index
             built = torch.cuda.Event()
             built.record(st)
             if torch.is_tensor(points) and points.is_cuda:
@@ -391,6 +405,8 @@ class KPConvPipelineN:
             done = torch.cuda.Event()
             done.record(st)
         res = KPConvPipeline.Result(logits, done, batch)
+        if self.ring is not None:
+            self.ring_done[getattr(batch, '_ring_index', 0)] = done
         self.alive = [r for r in self.alive if not r.done.query()]
         self.alive.append(res)
         while len(self.alive) > self.n + len(self.computes):
@@ -404,7 +420,8 @@ class KPConvPipelineN:
         with torch.cuda.device(self.device):
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
-        self.inflight.append(self.pool.submit(self._build, self.count % self.n, points, lengths, features, rotations, ready))
+        ring_index = self.count % len(self.ring) if self.ring is not None else 0
+        self.inflight.append(self.pool.submit(self._build, self.count % self.n, points, lengths, features, rotations, ready, ring_index))
         self.count += 1
         if len(self.inflight) > self.n:
             return self._forward(self.inflight.pop(0))

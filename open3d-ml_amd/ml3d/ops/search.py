@@ -352,13 +352,18 @@ KPBATCH_TRACE = []       # measurement hook (bench_models.py): a FIFO of event l
 #                          expand / subsample count / fill (list.pop is atomic: builds may start on several host threads)
 
 
-def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, cap=128):
+def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, cap=128, buffers=None):
     """``KPConvBatch.segmentation_inputs`` (ml3d/torch/dataloaders/concat_batcher.py:186-305) for rigid architectures in ONE
     library call: ``radii[l]`` / ``dls[l]`` the conv radius and pooling grid of layer l, ``has_conv[l]`` whether the layer has
     convolution blocks, ``rotations``: per pooling layer a float32 [B,3,3] device tensor or None.  Every layer but the last
     pools.  Returns a ``KpBatchArena`` (matrices identical to the per-layer ``radius_plan_dense`` / ``grid_subsampling_plan``
     calls) or None when some row outgrew the ``cap``-wide stash of the one-traversal search -- the caller then takes the
-    per-layer two-phase path for this batch."""
+    per-layer two-phase path for this batch.
+    ``buffers``: optional dict a pipeline keeps per build slot -- its ``'workspace'`` and ``'arena'`` tensors (uint8, on the device)
+    are reused when large enough and replaced IN the dict when they had to grow, so that a steady stream of batches allocates
+    nothing (a fresh multi-hundred-MB block per batch makes the caching allocator grow its per-stream pools for dozens of steps,
+    and every growth is a hipMalloc that stalls the step: 20-80 ms on a cold box).  The caller owns the reuse discipline: the
+    returned views alias ``buffers['arena']`` until the next build that is handed the same dict."""
     lib = _abi.get()
     _need_gpu(points)
     pts = points.contiguous().float()
@@ -389,7 +394,11 @@ def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, ca
     wsb = lib.ml3d_kpconv_batch_workspace_bytes(n0, B, L, int(cap))
     if wsb == 0:
         raise RuntimeError("kpconv_batch_build: unsupported sizes")
-    ws = _ws(wsb, dev)
+    ws = buffers.get('workspace') if buffers is not None else None
+    if ws is None or ws.numel() < wsb or ws.device != dev:
+        ws = _ws(int(wsb * 1.1) if buffers is not None else wsb, dev)
+        if buffers is not None:
+            buffers['workspace'] = ws
     hsb = int(lib.ml3d_kpconv_batch_host_scratch_bytes(B, L))
     stream = _stream()
     hkey = (str(dev), getattr(stream, "value", stream), (hsb + 4095) // 4096)      # (the stream handle is a ctypes c_void_p)
@@ -403,14 +412,21 @@ def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, ca
     bucket = (str(dev), max(1, n0).bit_length())
     # first guess: what the last batch of this size class took (+25 %), else ~3 matrices of 48 columns over 1.6 N rows + points
     arena_bytes = int(_ARENA_HINT.get(bucket, 0) * 1.25) or int(n0 * 1.6 * (3 * 48 * 4 + 12)) + (1 << 20)
+    kept = buffers.get('arena') if buffers is not None else None
     for attempt in range(6):
-        arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
+        if kept is not None and kept.numel() >= arena_bytes and kept.device == dev:
+            arena, arena_bytes = kept, kept.numel()
+        else:
+            arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
+            if buffers is not None:
+                kept = buffers['arena'] = arena
         with torch.cuda.device(dev):
             rc = lib.ml3d_kpconv_batch_build(pts.data_ptr(), C.addressof(lens), B, n0, C.addressof(desc), rot_p and C.addressof(rot_p),
-                                             arena.data_ptr(), arena_bytes, C.addressof(out), C.addressof(out_lens), ws.data_ptr(), wsb,
+                                             arena.data_ptr(), arena_bytes, C.addressof(out), C.addressof(out_lens), ws.data_ptr(), ws.numel(),
                                              pinned.data_ptr(), pinned.numel(), stream)
         if rc == -2 and out.arena_used > arena_bytes:        # ML3D_E_WORKSPACE: the arena was short -- grow and redo the batch
             arena_bytes = int(max(2 * arena_bytes, 2 * out.arena_used))
+            kept = None
             continue
         break
     if rc == _abi.KPBATCH_FALLBACK:

@@ -721,9 +721,10 @@ class KPConvBatch:
     (kpconv.py:2059-2080), ``None`` keeps axis-aligned grids, or a list of float32 [B,3,3] arrays per pooling
     layer."""
 
-    def __init__(self, points, lengths, cfg, features=None, rotations="random", device='cuda', one_call=True):
+    def __init__(self, points, lengths, cfg, features=None, rotations="random", device='cuda', one_call=True, buffers=None):
         """``one_call=False`` forces the per-layer path (the whole-batch library call is tried first otherwise; both produce the
-        same matrices -- tests/test_gpu_kpconv.py, tests/test_emulated_api.py)."""
+        same matrices -- tests/test_gpu_kpconv.py, tests/test_emulated_api.py).  ``buffers``: see ``ops.kpconv_batch_build`` (a
+        pipeline's reusable workspace / arena; the batch's tensors then alias the arena until that dict is used again)."""
         dev = torch.device(device)
         _abi.require_gpu(dev, "KPConvBatch")
         self.cfg = cfg
@@ -733,7 +734,7 @@ class KPConvBatch:
             features = torch.ones((pts.shape[0], 1), dtype=torch.float32, device=dev)     # in_features_dim == 1
         self.features = torch.as_tensor(features, dtype=torch.float32).to(dev).contiguous()
         self.points, self.neighbors, self.pools, self.upsamples, self.lengths, self.rotations = [], [], [], [], [], []
-        if one_call and self._build_in_one_call(pts, lens, cfg, rotations, dev):
+        if one_call and self._build_in_one_call(pts, lens, cfg, rotations, dev, buffers):
             return
         r_normal = cfg['first_subsampling_dl'] * cfg['conv_radius']
         layer_blocks = []
@@ -796,7 +797,7 @@ class KPConvBatch:
                 break
 
 
-def _kpconv_build_in_one_call(self, pts, lens, cfg, rotations, dev):
+def _kpconv_build_in_one_call(self, pts, lens, cfg, rotations, dev, buffers=None):
     """The rigid architectures' batch build as ONE library call (``ops.kpconv_batch_build`` -> ``ml3d_kpconv_batch_build``: every
     launch of the 5-layer chain enqueued from C++, one blocking size read-back per layer instead of two per pooling layer, no
     interpreter between two kernels).  Returns False -- nothing appended, no random draw consumed -- when the architecture is
@@ -831,7 +832,7 @@ def _kpconv_build_in_one_call(self, pts, lens, cfg, rotations, dev):
         R = [None] * (L - 1)
     else:
         R = [rotations[l] for l in range(L - 1)]
-    res = ops.kpconv_batch_build(pts, lens, radii, dls, has_conv, R)
+    res = ops.kpconv_batch_build(pts, lens, radii, dls, has_conv, R, buffers=buffers)
     if res is None:
         if state is not None:
             np.random.set_state(state)          # the per-layer path draws the same orientations again
