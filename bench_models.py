@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 PEAK_F32_TFLOPS = 157.3
+PEAK_BF16_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16), measured 2495
 PEAK_HBM_GBS = 8000.0
 
 
@@ -86,6 +87,7 @@ class _CallTimer:
             e1.record()
             self.events.append((e0, e1))
             self.shapes = (a, r)
+            self.kwargs = k
         else:
             r = self.orig(*a, **k)
         self.count += 1
@@ -309,6 +311,11 @@ def run_pointpillars(args, rank, world, dev, dist):
     Bm, OH, OW, Co = y.shape
     flops = 2.0 * Bm * OH * OW * Co * w.shape[0]
     ms = float(np.mean(in_region))
+    # the matrix pipe the convolution ran on.  bf16x3 (default): every float32 product is six bf16 MFMA products (three-way split of
+    # both operands, gemm_tile_bf3) -- `achieved` counts the bf16 flops the kernel EXECUTES (6 x the algorithmic ones) against the
+    # dense bf16 peak; `f32_equivalent_tflops` is the algorithmic rate, which the f32 MFMA pipe (157.3 TF) could not reach
+    bf3 = getattr(timer, "kwargs", {}).get("packed") is not None
+    mult, peak = (6.0, PEAK_BF16_TFLOPS) if bf3 else (1.0, PEAK_F32_TFLOPS)
     # the whole forward's algorithmic flops (68.3 GFLOP per KITTI frame through backbone + neck + heads)
     e2e_tflops = 68.3e9 * (B * args.steps * world / dt) / world / 1e12
     out = {"metric": "point-cloud frames/sec (PointPillars KITTI inference: voxelize + pillar features + BEV backbone + heads)",
@@ -316,6 +323,10 @@ def run_pointpillars(args, rank, world, dev, dist):
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_median": float(np.median(iv)),
            "step_ms_p95": float(np.percentile(iv, 95)), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "dtype_note": ("float32 tensors and accumulation; SECOND's 3x3 convolutions multiply on the bf16 matrix pipe with both operands "
+                          "split exactly into three bf16 (six MFMA products per float32 product): error against float64 equal to the f32 "
+                          "MFMA kernel's (profiles/r05_bf16x3_conv.log), the 1e-4 parity tests run on this path") if bf3 else
+                         "float32 end to end (ML3D_PP_CONV=f32)",
            "config": {"workload": "PointPillars KITTI detection, %d synthetic KITTI-shaped sweeps per step per GPU "
                                   "(pointpillars_kitti.yml): host->device upload + voxelize + pillar features + BEV backbone + "
                                   "heads + box decode + rotated NMS" % B, "frames_per_step_per_gpu": B,
@@ -323,17 +334,24 @@ def run_pointpillars(args, rank, world, dev, dist):
                       "boxes_last_step": n_boxes[0], "streams": 2 * lanes if overlap else 1, "lanes": lanes if overlap else 1,
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
            "latency_single_sweep_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "sweeps": len(lat)},
-           "roofline": {"bound": "mfma", "kernel": "%s (SECOND block 0, 3x3 %d->%d on %dx%d)" % (_rocprof_name("pp_conv3x3_64", "gemm_tile2<ConvLoader2, 64, 32, false>"), x.shape[3], Co, OH, OW),
-                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+           "roofline": {"bound": "mfma", "kernel": "%s (SECOND block 0, 3x3 %d->%d on %dx%d)" % (
+                            _rocprof_name("pp_conv3x3_64", "gemm_tile_bf3<ConvLoader2, 64>") if bf3 else "gemm_tile2<ConvLoader2, 64, 32, false>",
+                            x.shape[3], Co, OH, OW),
+                        "matrix_pipe": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 products per float32 product: exact three-way bf16 split of "
+                                       "both operands, float accumulation -- float32-equivalent results" if bf3 else "f32 MFMA",
+                        "achieved": mult * flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": mult * flops / (ms * 1e-3) / 1e12 / peak,
+                        "f32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                         "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops,
+                        "executed_flops_per_launch": mult * flops,
                         "sweeps_per_launch": int(Bm), "launches_timed": len(in_region),
                         "timed": "inside the timed region, on the lane's compute stream, the other lane co-running",
                         "avg_launch_ms_alone_lane_shape": alone["lane"], "avg_launch_ms_alone_whole_batch": alone["batch"],
                         # (two lanes of 16 sweeps each fill the GPU on their own: in the step they TIME-SHARE it, so the in-step launch
                         #  time is a share of the GPU, not the kernel's efficiency -- that is `frac_alone_lane_shape` / `end_to_end_frac`)
-                        "frac_alone_lane_shape": flops / (alone["lane"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                        "frac_alone_whole_batch": 2.0 * B * OH * OW * Co * w.shape[0] / (alone["batch"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                        "frac_alone_lane_shape": mult * flops / (alone["lane"] * 1e-3) / 1e12 / peak,
+                        "f32_equivalent_tflops_alone_lane_shape": flops / (alone["lane"] * 1e-3) / 1e12,
+                        "frac_alone_whole_batch": mult * 2.0 * B * OH * OW * Co * w.shape[0] / (alone["batch"] * 1e-3) / 1e12 / peak,
                         "end_to_end_tflops": e2e_tflops, "end_to_end_frac": e2e_tflops / PEAK_F32_TFLOPS,
                         "end_to_end_note": "68.3 GFLOP per frame (SURVEY.md §8d) x frames/s per GPU: every kernel of the step, "
                                            "H2D, voxelize, decode and NMS included"}}

@@ -47,7 +47,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 8
+#define ML3D_ABI_VERSION 9
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -407,6 +407,26 @@ int ml3d_conv2d_nhwc(const float* in, int64_t batch, int h, int w, int cin,
                      int pad, int act, float slope, int cout, float* out,
                      int64_t out_pixel_stride, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* The same convolution on the bf16 matrix pipe, float32-equivalent: both      */
+/* operands are split exactly into three bf16 (x = h + m + l) and the product   */
+/* is accumulated in float from the six largest cross terms -- error below the  */
+/* float32 rounding of the sum itself ("bf16x3"), 2.7x the MFMA rate.*/
+/* ml3d_gemm_pack_bf16x3 splits the SAME weight matrix ml3d_conv2d_nhwc takes   */
+/* ([k = kh*kw*cin, n = cout] float, k % 32 == 0 else ML3D_E_UNSUPPORTED) once  */
+/* into `packed` (ml3d_gemm_pack_bf16x3_bytes(k, n) bytes, 16-byte aligned).    */
+/* ml3d_conv2d_nhwc_bf16x3: cin % 32 == 0 and 32-bit element offsets, else      */
+/* ML3D_E_UNSUPPORTED (callers keep ml3d_conv2d_nhwc for those); needs no       */
+/* workspace.  Non-finite inputs give NaN where the f32 kernel gives inf.       */
+size_t ml3d_gemm_pack_bf16x3_bytes(int k, int n);
+
+int ml3d_gemm_pack_bf16x3(const float* weights, int k, int n, void* packed, size_t packed_bytes,
+                          void* stream);
+
+int ml3d_conv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin,
+                            const void* packed, const float* bias, int kh, int kw, int stride,
+                            int pad, int act, float slope, int cout, float* out,
+                            int64_t out_pixel_stride, void* stream);
 
 /* ConvTranspose2d with kernel == stride + folded BN + activation (SECONDFPN    */
 /*   deblocks, point_pillars.py:712-717, 749): GEMM + pixel-shuffle store.      */

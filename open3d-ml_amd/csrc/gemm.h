@@ -69,4 +69,12 @@ int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Ep
 int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws,
               size_t partial_bytes, hipStream_t stream);
 
+// ---- the same convolution on the bf16 matrix pipe (gemm.hip, gemm_tile_bf3): float32-equivalent products from three-way bf16
+// splits of both operands.  The weights are split once by gemm_pack_bf16x3 ([K, N] float, K % 32 == 0 -> gemm_pack_bf16x3_bytes
+// bytes, 16-byte aligned); gemm_conv_bf16x3_ok tells whether a problem is eligible (cin % 32 == 0, 32-bit offsets).
+size_t gemm_pack_bf16x3_bytes(int K, int N);
+int gemm_pack_bf16x3(const float* Bm, int K, int N, void* packed, hipStream_t stream);
+bool gemm_conv_bf16x3_ok(const ConvA& A);
+int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t stream);
+
 }  // namespace ml3d

@@ -5,12 +5,15 @@
 
 #include <type_traits>
 
+#include <gfx950_ops.h>
+
 #include "grid.h"
 #include "ml3d_hip.h"
 
 namespace ml3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GM_BM = 64;        // rows of C per workgroup
 constexpr int GM_BN = 64;        // columns of C per workgroup
@@ -52,10 +55,12 @@ __device__ __forceinline__ void store_block32(const f32x16& acc, float b, float 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ur = (r & 3) + 8 * (r >> 2);                // uniform part of the row; the lane's half adds 4 * hi
-        if (!FULL && ur + 4 * hi >= rows_left) continue;
+        // (the scalar offsets come BEFORE the row predicate: every lane takes part in every readfirstlane)
         const int so_c = __builtin_amdgcn_readfirstlane(ur * (int)ldc);
+        const int so_r = RES ? __builtin_amdgcn_readfirstlane(ur * (int)ldr) : 0;
+        if (!FULL && ur + 4 * hi >= rows_left) continue;
         float v = acc[r] + b;
-        if (RES) v += rp[__builtin_amdgcn_readfirstlane(ur * (int)ldr)];
+        if (RES) v += rp[so_r];
         cp[so_c] = gm_act_t<ACT>(v, slope);
     }
 }
@@ -381,6 +386,71 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
     }
 }
 
+constexpr int G2_BM = 128;
+
+// ---- epilogue of the 128-row kernels (bias + residual + activation, or the pixel-shuffle store) -------------------------
+// a wave's RT x CT blocks of 32 x 32: rows m0 + 64 wr + 32 i + mfma32_row(r, hi), columns n0 + 32 CT wc + 32 j + cl
+template <int RT, int CT>
+__device__ __forceinline__ void tile2_epilogue(f32x16 (&acc)[RT][CT], const Epilogue& ep, float* __restrict__ C, int64_t ldc,
+                                               int64_t M, int N, int64_t m0, int n0, int wr, int wc, int hi, int cl) {
+    if (fast_store_ok(ep, ldc, N)) {
+        const int64_t mw0 = m0 + __builtin_amdgcn_readfirstlane(wr) * 64;        // (scalar: uniform row offsets below)
+        dispatch_act_full(ep.act, m0 + G2_BM <= M, [&](auto act_c, auto full_c) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = n0 + wc * (32 * CT) + 32 * j + cl;
+                if (col < N) {
+                    float b = ep.bias ? ep.bias[col] : 0.f;
+                    if (ep.bias2) b += ep.bias2[col];
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+                        store_block32<decltype(act_c)::value, decltype(full_c)::value, false>(acc[i][j], b, ep.slope, C, ldc, nullptr,
+                                                                                              0, mw0 + i * 32, M, col, hi);
+                }
+            }
+        });
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = n0 + wc * (32 * CT) + 32 * j + cl;
+        if (col >= N) continue;
+        if (ep.ps > 0) {
+            const int co = col % ep.ps_cout, dd = col / ep.ps_cout;
+            const int dy = dd / ep.ps, dx = dd % ep.ps;
+            const float b = ep.bias ? ep.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
+                    if (m < M) {
+                        const int x = (int)(m % ep.ps_w);
+                        const int64_t t = m / ep.ps_w;
+                        const int y = (int)(t % ep.ps_h);
+                        const int64_t bi = t / ep.ps_h;
+                        const int64_t opix = (bi * ep.ps_h * ep.ps + (int64_t)y * ep.ps + dy) * ((int64_t)ep.ps_w * ep.ps) + (int64_t)x * ep.ps + dx;
+                        C[opix * ldc + co] = gm_act(acc[i][j][r] + b, ep.act, ep.slope);
+                    }
+                }
+            continue;
+        }
+        float b = ep.bias ? ep.bias[col] : 0.f;
+        if (ep.bias2) b += ep.bias2[col];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
+                if (m < M) {
+                    float v = acc[i][j][r] + b;
+                    if (ep.residual) v += ep.residual[m * ep.ldr + col];
+                    C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
+                }
+            }
+    }
+}
+
 // ---- 128-row tile kernel: register-blocked MFMA ----------------------------------------------------------------------
 // The 64 x 64 kernel above gives every wave ONE 32 x 32 accumulator: each MFMA needs its own A and B value from LDS and the
 // loader's address arithmetic is paid per 16 MFMAs.  On gfx950 the f32 MFMAs do not overlap VALU / LDS issue
@@ -390,8 +460,6 @@ gemm_tile(Loader L, const float* __restrict__ Bm, int N, int bvec, Epilogue ep, 
 // MFMAs.  The conv loader keeps ONE int per staged row (element offset of the receptive field's corner) and a 9-bit mask
 // of the taps that fall inside the image; a K chunk lies inside one tap (C % 32 == 0), so per chunk a staged float4
 // costs a bit test and an add.  Interior rows never see a branch.
-constexpr int G2_BM = 128;
-
 struct ConvLoader2 {
     ConvA A;
     int64_t M;
@@ -422,7 +490,41 @@ struct ConvLoader2 {
         if (!((c.taps >> tap) & 1u)) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(A.in + (c.off + (ky * A.W + kx) * A.C + ci));
     }
+    // the same walk over K without the per-chunk divisions: (tap, element offset of the tap + channel origin) carried from chunk to
+    // chunk on the scalar unit (~100 SALU instructions per chunk less than load4's k0 / C, tap / KW)
+    struct Walk { int tap, kx, ci, toff; };
+    __device__ __forceinline__ Walk walk_begin() const { Walk w; w.tap = 0; w.kx = 0; w.ci = 0; w.toff = 0; return w; }
+    __device__ __forceinline__ void walk_next(Walk& w, int kc) const {
+        w.ci += kc;
+        w.toff += kc;
+        if (w.ci >= A.C) {                       // next tap: the pixel to the right (contiguous with this one's channels), or the
+                                                 // first pixel of the next image row
+            w.ci = 0;
+            ++w.tap;
+            ++w.kx;
+            if (w.kx == A.KW) { w.kx = 0; w.toff += (A.W - A.KW) * A.C; }
+        }
+    }
+    __device__ __forceinline__ float4 load4w(const Ctx& c, const Walk& w, int kq) const {
+        if (!((c.taps >> w.tap) & 1u)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(A.in + (c.off + w.toff + kq));
+    }
 };
+
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with
+// the identity mapping the 128-row tiles that share input rows (the 3 x 3 taps of neighbouring pixels) sit on 8 different L2s
+// and each XCD streams nearly the whole image.  Here XCD x owns a CONTIGUOUS run of tiles (the column tiles of one row tile
+// adjacent), so concurrently running neighbours hit one L2: SECOND's convolutions at 16 sweeps, f32 kernel, 0.691 -> 0.612, 0.643 ->
+// 0.586, 0.622 -> 0.590, 0.670 -> 0.641 ms (profiles/r05_bf16x3_conv.log).
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const unsigned lin = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = lin & 7u, slot = lin >> 3;
+    const unsigned base = total >> 3, rem = total & 7u;
+    const unsigned t = xcd * base + (xcd < rem ? xcd : rem) + slot;
+    bx = (int)(t / gy);
+    by = (int)(t - (unsigned)bx * gy);
+}
 
 template <class Loader, int BN, int KC, bool PF2>
 __global__ void __launch_bounds__(256)
@@ -438,8 +540,10 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, cl = lane & 31;
     const int wr = wave & 1, wc = wave >> 1;     // wave's 64-row half / column half
-    const int64_t m0 = (int64_t)blockIdx.x * G2_BM;
-    const int n0 = blockIdx.y * BN;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int64_t m0 = (int64_t)tbx * G2_BM;
+    const int n0 = tby * BN;
     const int K = L.K;
 
     // staging: A rows (tid / (KC / 4)) + (1024 / KC) j, k offset 4 (tid % (KC / 4));  B rows (tid / (BN / 4)) + (1024 / BN) j,
@@ -541,62 +645,167 @@ gemm_tile2(Loader L, const float* __restrict__ Bm, int N, Epilogue ep, float* __
             block_sync_lds();
         }
     }
-    // ---- epilogue (bias + residual + activation, or the pixel-shuffle store) ---------------------------------------
-    if (fast_store_ok(ep, ldc, N)) {
-        const int64_t mw0 = m0 + __builtin_amdgcn_readfirstlane(wr) * 64;        // (scalar: uniform row offsets below)
-        dispatch_act_full(ep.act, m0 + G2_BM <= L.M, [&](auto act_c, auto full_c) {
+    tile2_epilogue<RT, CT>(acc, ep, C, ldc, L.M, N, m0, n0, wr, wc, hi, cl);
+}
+
+// ---- 128-row tile kernel on the bf16 matrix pipe: float32 products from three-way bf16 splits ---------------------------
+// v_mfma_f32_32x32x16_bf16 does 16x the multiply-adds per cycle of the f32 MFMA above.  A float x is EXACTLY h + m + l with
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (8 + 8 + 8 mantissa bits), and a product of two bf16 is exact in the
+// float accumulator, so
+//      a b  =  ah bh + (ah bm + am bh) + (am bm + ah bl + al bh)  +  O(2^-25 |a b|)
+// -- six bf16 MFMAs per 16-deep step against eight f32 MFMAs of the same duration each: 2.7x the matrix rate, at an error
+// below float32's own rounding of the sum (tests/test_emulated_api.py and tests/test_gpu_prims.py measure it against a float64
+// product beside the f32 kernel; non-finite inputs give NaN where the f32 kernel gives inf).  B (the weights) is split ONCE by
+// gemm_pack_bf16x3 into chunk-major planes [K / 32][3][Npad][32] bf16, so a workgroup's B tile of a chunk is one contiguous
+// run per plane; A is split on its way from the staging registers to LDS (22 VALU per float4, under the MFMAs of the chunk
+// before).  LDS rows are 32 bf16 + 8 of padding (80 bytes: the 16 lanes of one ds_read_b128 phase hit 64 distinct banks).
+constexpr int BF_KC = 32;                       // K chunk: two MFMA steps of 16
+constexpr int BF_P = BF_KC;                     // LDS row pitch in bf16: 64 bytes = four 16-byte granules, XOR-swizzled (below)
+// LDS layout of a plane: row-major [rows][32 bf16], the 16-byte granule g of row r stored at granule g ^ ((r >> 2) & 3).  The 16
+// lanes of one ds_read_b128 service group ({0-3, 12-15, 20-27}, ... of the wave: MI355X_MICROARCH.md, LDS) read one granule of 16
+// rows whose (r & 3, (r >> 2) & 3) pairs are all different -> 16 distinct 4-bank slots; a ds_write_b64 / b128 group covers two
+// whole rows 16 dwords apart -> the 32 write banks once.  (Rows padded to 80 bytes read conflict-free too but every store group
+// hit 4 banks twice: SQ_LDS_BANK_CONFLICT 34.7 M cycles per launch of the 64 -> 64 layer = 72 per wave and chunk, all stores.)
+__device__ __forceinline__ int bf_swz(int row) { return (row >> 2) & 3; }
+
+__device__ __forceinline__ void bf16_split3(float4 v, uint2& h, uint2& m, uint2& l) {
+    // (sub_f32: single v_sub_f32 -- the compiler pairs adjacent float subtractions into v_pk_add_f32, which costs ~13 cycles more
+    //  than two plain ones beside MFMAs: MI355X_MICROARCH.md, "price of one filler")
+    h.x = bf16_pack2(v.x, v.y); h.y = bf16_pack2(v.z, v.w);
+    const float r0 = sub_f32(v.x, __uint_as_float(h.x << 16)), r1 = sub_f32(v.y, __uint_as_float(h.x & 0xffff0000u));
+    const float r2 = sub_f32(v.z, __uint_as_float(h.y << 16)), r3 = sub_f32(v.w, __uint_as_float(h.y & 0xffff0000u));
+    m.x = bf16_pack2(r0, r1); m.y = bf16_pack2(r2, r3);
+    l.x = bf16_pack2(sub_f32(r0, __uint_as_float(m.x << 16)), sub_f32(r1, __uint_as_float(m.x & 0xffff0000u)));
+    l.y = bf16_pack2(sub_f32(r2, __uint_as_float(m.y << 16)), sub_f32(r3, __uint_as_float(m.y & 0xffff0000u)));
+}
+
+template <class Loader, int BN>
+__global__ void __launch_bounds__(256)
+gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue ep, float* __restrict__ C, int64_t ldc) {
+    constexpr int RT = 2, CT = BN / 64;
+    constexpr int NA4 = BF_KC / 8;              // A float4 per thread and chunk
+    constexpr int NB = 3 * BN * 4 / 256;        // B uint4 (8 bf16) per thread and chunk
+    constexpr int APL = G2_BM * BF_P, BPL = BN * BF_P;      // bf16 per plane
+    __shared__ __attribute__((aligned(16))) uint16_t As[3 * APL];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[3 * BPL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    const int wr = wave & 1, wc = wave >> 1;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int64_t m0 = (int64_t)tbx * G2_BM;
+    const int n0 = tby * BN;
+    const int K = L.K;
+
+    constexpr int ATH = BF_KC / 4, ARS = 256 / ATH;
+    const int ar = tid / ATH, aq = (tid % ATH) * 4;
+    const int asw = (((aq >> 3) ^ bf_swz(ar)) << 3) + (aq & 4);          // (ARS = 32: every staged row of the thread has ar's swizzle)
+    static_assert(ARS % 16 == 0, "staged rows share the swizzle");
+    typename Loader::Ctx cx[NA4];
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const int col = n0 + wc * (32 * CT) + 32 * j + cl;
-                if (col < N) {
-                    float b = ep.bias ? ep.bias[col] : 0.f;
-                    if (ep.bias2) b += ep.bias2[col];
+    for (int j = 0; j < NA4; ++j) cx[j] = L.prepare(m0 + ar + ARS * j);
+    // B item t = tid + 256 j: 16-byte quarter t & 3 of column (t >> 2) % BN of plane t / (4 BN)
+    const u32x4* bsrc[NB];
+    int bdst[NB];
 #pragma unroll
-                    for (int i = 0; i < RT; ++i)
-                        store_block32<decltype(act_c)::value, decltype(full_c)::value, false>(acc[i][j], b, ep.slope, C, ldc, nullptr,
-                                                                                              0, mw0 + i * 32, L.M, col, hi);
-                }
-            }
-        });
-        return;
+    for (int j = 0; j < NB; ++j) {
+        const int t = tid + 256 * j, q = t & 3, col = (t >> 2) % BN, pl = t / (4 * BN);
+        bsrc[j] = Bp + ((int64_t)pl * Npad + n0 + col) * 4 + q;
+        bdst[j] = pl * BPL + col * BF_P + (q ^ bf_swz(col)) * 8;
     }
+    const int64_t bstep = (int64_t)3 * Npad * 4;          // uint4 per chunk
+
+    float4 ra[NA4];
+    u32x4 rb[NB];            // (a native vector, not HIP's uint4 struct: the array of structs went through scratch)
+    typename Loader::Walk wk = L.walk_begin();
+    int64_t bo = 0;
+    auto fetch = [&]() {                          // the next chunk, in K order
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        const int col = n0 + wc * (32 * CT) + 32 * j + cl;
-        if (col >= N) continue;
-        if (ep.ps > 0) {
-            const int co = col % ep.ps_cout, dd = col / ep.ps_cout;
-            const int dy = dd / ep.ps, dx = dd % ep.ps;
-            const float b = ep.bias ? ep.bias[co] : 0.f;
+        for (int j = 0; j < NA4; ++j) ra[j] = L.load4w(cx[j], wk, aq);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[j] = bsrc[j][bo];
+        L.walk_next(wk, BF_KC);
+        bo += bstep;
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            uint2 h, m, l;
+            bf16_split3(ra[j], h, m, l);
+            uint16_t* d = As + (ar + ARS * j) * BF_P + asw;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + APL) = m;
+            *reinterpret_cast<uint2*>(d + 2 * APL) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = rb[j];
+    };
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // the lane's row of the A / B tile (row offsets 32 i, 32 j keep cl's swizzle); granule 2 s + hi of MFMA step s
+    const uint16_t* arow = As + (wr * 64 + cl) * BF_P;
+    const uint16_t* brow = Bs + (wc * (32 * CT) + cl) * BF_P;
+    const int gs[2] = {(hi ^ bf_swz(cl)) * 8, ((2 + hi) ^ bf_swz(cl)) * 8};
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < BF_KC / 16; ++s) {
+            u32x4 a[RT][3], b[CT][3];
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
-                    if (m < L.M) {
-                        const int x = (int)(m % ep.ps_w);
-                        const int64_t t = m / ep.ps_w;
-                        const int y = (int)(t % ep.ps_h);
-                        const int64_t bi = t / ep.ps_h;
-                        const int64_t opix = (bi * ep.ps_h * ep.ps + (int64_t)y * ep.ps + dy) * ((int64_t)ep.ps_w * ep.ps) + (int64_t)x * ep.ps + dx;
-                        C[opix * ldc + co] = gm_act(acc[i][j][r] + b, ep.act, ep.slope);
-                    }
-                }
-            continue;
+                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const u32x4*>(arow + p * APL + i * 32 * BF_P + gs[s]);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const u32x4*>(brow + p * BPL + j * 32 * BF_P + gs[s]);
+            // smallest terms first; a term's RT x CT MFMAs are independent, so back-to-back issues never wait on an accumulator
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) acc[i][j] = mfma_bf16_32x32x16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
         }
-        float b = ep.bias ? ep.bias[col] : 0.f;
-        if (ep.bias2) b += ep.bias2[col];
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
-                if (m < L.M) {
-                    float v = acc[i][j][r] + b;
-                    if (ep.residual) v += ep.residual[m * ep.ldr + col];
-                    C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
-                }
-            }
+    };
+
+    fetch();
+    stash();
+    block_sync_lds();
+    for (int k0 = 0; k0 < K; k0 += BF_KC) {
+        const bool more = k0 + BF_KC < K;
+        if (more) fetch();
+        mfma_chunk();
+        block_sync_lds();
+        if (more) {
+            stash();
+            block_sync_lds();
+        }
+    }
+    tile2_epilogue<RT, CT>(acc, ep, C, ldc, L.M, N, m0, n0, wr, wc, hi, cl);
+}
+
+// B [K, N] float (row-major) -> chunk-major bf16 planes [K / 32][3][Npad][32]; columns N .. Npad - 1 are zero
+__global__ void gemm_pack_bf16x3_kernel(const float* __restrict__ Bm, int K, int N, int Npad, uint16_t* __restrict__ out) {
+    const int64_t total = (int64_t)K * Npad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Npad), k = (int)(i / Npad);
+        const float x = n < N ? Bm[(int64_t)k * N + n] : 0.f;
+        const uint32_t h = bf16_pack2(x, 0.f) & 0xffffu;
+        const float r = x - __uint_as_float(h << 16);
+        const uint32_t m = bf16_pack2(r, 0.f) & 0xffffu;
+        const uint32_t l = bf16_pack2(r - __uint_as_float(m << 16), 0.f) & 0xffffu;
+        const int64_t base = ((int64_t)(k / BF_KC) * 3 * Npad + n) * BF_KC + (k % BF_KC);
+        out[base] = (uint16_t)h;
+        out[base + (int64_t)Npad * BF_KC] = (uint16_t)m;
+        out[base + (int64_t)2 * Npad * BF_KC] = (uint16_t)l;
     }
 }
 
@@ -771,6 +980,43 @@ static int gemm_launch(const Loader& L, const float* Bm, int N, const Epilogue& 
         if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     }
     return 0;
+}
+
+// ---- bf16x3 convolution ------------------------------------------------------------------------------------------------
+static int bf3_npad(int N) { return (N + 127) / 128 * 128; }
+
+size_t gemm_pack_bf16x3_bytes(int K, int N) {
+    if (K <= 0 || N <= 0 || (K % BF_KC) != 0) return 0;
+    return (size_t)3 * (size_t)bf3_npad(N) * (size_t)K * sizeof(uint16_t);
+}
+
+int gemm_pack_bf16x3(const float* Bm, int K, int N, void* packed, hipStream_t st) {
+    if (!Bm || !packed || K <= 0 || N <= 0 || (K % BF_KC) != 0 || (((uintptr_t)packed) & 15) != 0) return ML3D_E_INVALID;
+    const int Npad = bf3_npad(N);
+    const int64_t total = (int64_t)K * Npad;
+    const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gemm_pack_bf16x3_kernel, dim3(nb), dim3(256), 0, st, Bm, K, N, Npad, (uint16_t*)packed);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+// the convolutions the bf16x3 kernel takes: whole 32-deep chunks inside one tap, 32-bit image offsets, at most 32 taps.
+// Every eligible problem runs there whatever its size (a 128-row tile per workgroup; narrow outputs take 64-column tiles).
+bool gemm_conv_bf16x3_ok(const ConvA& A) {
+    const int64_t M = (int64_t)A.B * A.OH * A.OW;
+    return A.in && (A.C % BF_KC) == 0 && A.KH * A.KW <= 32 && M < 0x7fffffffll &&
+           (int64_t)A.B * A.H * A.W * A.C < 0x7fffffffll - (int64_t)(A.pad + 1) * (A.W + 1) * A.C;
+}
+
+int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t st) {
+    if (!gemm_conv_bf16x3_ok(A) || !packed || !C || N <= 0 || ep.res_gather) return ML3D_E_INVALID;
+    ConvLoader2 L2;
+    L2.A = A; L2.M = (int64_t)A.B * A.OH * A.OW; L2.K = A.KH * A.KW * A.C;
+    if (L2.M <= 0) return 0;
+    const int Npad = bf3_npad(N);
+    const unsigned gm = (unsigned)((L2.M + G2_BM - 1) / G2_BM);
+    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128)), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc);
+    else hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 64>), dim3(gm, 1u), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
 int gemm_rows(const RowsA& A, const float* Bm, int64_t M, int N, int K, const Epilogue& ep, float* C, int64_t ldc,

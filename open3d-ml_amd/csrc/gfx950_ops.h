@@ -2,6 +2,7 @@
 // (The host emulator of the test-suite shadows this header with portable equivalents: tests/hipemu/include.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 // register budget of a kernel: exactly n waves per SIMD (512 / n VGPRs per lane)
 #define ML3D_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
@@ -34,6 +35,29 @@ __device__ __forceinline__ double key_min(double a, double b) {
     double lo;
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
     return lo;
+}
+
+// ---- bf16 matrix path (gemm.hip: f32-equivalent products as six bf16 MFMAs over a three-way split of both operands) ---------
+// two floats -> two bf16 (round to nearest even), packed low | high << 16: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t bf16_pack2(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// a - b as ONE v_sub_f32 (opaque to the SLP vectoriser, which would pair two of them into a v_pk_add_f32)
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[l % 32][8 (l / 32) + e] and B[8 (l / 32) + e][l % 32], e = 0 .. 7 (eight bf16 = four dwords
+// each); the 32 x 32 float result has the layout of every 32 x 32 MFMA (row (r & 3) + 8 (r >> 2) + 4 (l / 32), column l % 32)
+typedef float ml3d_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t ml3d_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x16 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 // "does any ACTIVE lane of this wave see pred" in DIVERGENT control flow (lanes whose loops have different trip counts): a ballot

@@ -273,6 +273,33 @@ extern "C" int ml3d_conv2d_nhwc(const float* in, int64_t batch, int h, int w, in
     return gemm_conv(A, weights, cout, ep, out, out_pixel_stride, p, avail, (hipStream_t)stream);
 }
 
+// ---- the same convolution on the bf16 matrix pipe (gemm.h: three-way bf16 splits, float32-equivalent result) ---------------
+extern "C" size_t ml3d_gemm_pack_bf16x3_bytes(int k, int n) { return gemm_pack_bf16x3_bytes(k, n); }
+
+extern "C" int ml3d_gemm_pack_bf16x3(const float* weights, int k, int n, void* packed, size_t packed_bytes, void* stream) {
+    if (!weights || !packed || k <= 0 || n <= 0) return ML3D_E_INVALID;
+    if (k % 32) return ML3D_E_UNSUPPORTED;
+    if (packed_bytes < gemm_pack_bf16x3_bytes(k, n)) return ML3D_E_WORKSPACE;
+    return gemm_pack_bf16x3(weights, k, n, packed, (hipStream_t)stream);
+}
+
+extern "C" int ml3d_conv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin, const void* packed,
+                                       const float* bias, int kh, int kw, int stride, int pad, int act, float slope,
+                                       int cout, float* out, int64_t out_pixel_stride, void* stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 ||
+        !in || !packed || !out || out_pixel_stride < cout)
+        return ML3D_E_INVALID;
+    ConvA A;
+    A.in = in; A.B = (int)batch; A.H = h; A.W = w; A.C = cin;
+    A.OH = (h + 2 * pad - kh) / stride + 1;
+    A.OW = (w + 2 * pad - kw) / stride + 1;
+    A.KH = kh; A.KW = kw; A.stride = stride; A.pad = pad;
+    if (A.OH <= 0 || A.OW <= 0) return ML3D_E_INVALID;
+    if (!gemm_conv_bf16x3_ok(A)) return ML3D_E_UNSUPPORTED;
+    Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
+    return gemm_conv_bf16x3(A, packed, cout, ep, out, out_pixel_stride, (hipStream_t)stream);
+}
+
 extern "C" int ml3d_deconv2d_nhwc(const float* in, int64_t batch, int h, int w, int cin, const float* weights,
                                   const float* bias, int stride, int act, float slope, int cout, float* out,
                                   int64_t out_pixel_stride, void* workspace, size_t workspace_bytes, void* stream) {

@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 8          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 9          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -46,6 +46,9 @@ SYMBOLS = [
     "ml3d_pillar_features",
     "ml3d_conv2d_workspace_bytes",
     "ml3d_conv2d_nhwc",
+    "ml3d_gemm_pack_bf16x3_bytes",
+    "ml3d_gemm_pack_bf16x3",
+    "ml3d_conv2d_nhwc_bf16x3",
     "ml3d_deconv2d_nhwc",
     "ml3d_nhwc_to_nchw",
     "ml3d_nms_workspace_bytes",
@@ -172,6 +175,12 @@ def bind(lib):
     lib.ml3d_conv2d_workspace_bytes.argtypes = [i64, i32, i32, i32, i32, i32, i32]
     lib.ml3d_conv2d_nhwc.restype = C.c_int
     lib.ml3d_conv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp, sz, vp]
+    lib.ml3d_gemm_pack_bf16x3_bytes.restype = sz
+    lib.ml3d_gemm_pack_bf16x3_bytes.argtypes = [i32, i32]
+    lib.ml3d_gemm_pack_bf16x3.restype = C.c_int
+    lib.ml3d_gemm_pack_bf16x3.argtypes = [vp, i32, i32, vp, sz, vp]
+    lib.ml3d_conv2d_nhwc_bf16x3.restype = C.c_int
+    lib.ml3d_conv2d_nhwc_bf16x3.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp]
     lib.ml3d_deconv2d_nhwc.restype = C.c_int
     lib.ml3d_deconv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, f32, i32, vp, i64, vp, sz, vp]
     lib.ml3d_nhwc_to_nchw.restype = C.c_int
@@ -305,6 +314,7 @@ def ptr_table(ptrs):
 # ---- ml3d_kpconv_batch_build (include/ml3d_hip.h): the host-side structs ---------------------------------------------------
 KPBATCH_MAX_LAYERS = 8
 KPBATCH_FALLBACK = 1
+E_UNSUPPORTED = -4         # ML3D_E_UNSUPPORTED
 
 
 class KpBatchDesc(C.Structure):

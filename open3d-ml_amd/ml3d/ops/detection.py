@@ -49,8 +49,27 @@ def pillar_features(points, vox, in_channels, max_num_points, vx, vy, x_offset, 
     return canvas
 
 
-def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=None, out_channel_offset=0):
-    """Conv2d + folded BN + activation on NHWC maps (SECOND, point_pillars.py:640-682)."""
+def pack_bf16x3(weights):
+    """Split a [K, N] float weight matrix (K % 32 == 0) once into the three bf16 planes `conv2d_nhwc(..., packed=)` multiplies
+    with on the bf16 matrix pipe (float32-equivalent result: include/ml3d_hip.h, ml3d_gemm_pack_bf16x3).  Returns a uint8
+    tensor, or None when the matrix is not eligible (the caller keeps the f32 kernel)."""
+    lib = _abi.get()
+    _need_gpu(weights)
+    K, N = int(weights.shape[0]), int(weights.shape[1])
+    nbytes = int(lib.ml3d_gemm_pack_bf16x3_bytes(K, N))
+    if nbytes == 0:
+        return None
+    w = weights.contiguous()
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.ml3d_gemm_pack_bf16x3(w.data_ptr(), K, N, packed.data_ptr(), nbytes, _stream())
+    _abi.check(rc, "ml3d_gemm_pack_bf16x3")
+    return packed
+
+
+def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=None, out_channel_offset=0, packed=None):
+    """Conv2d + folded BN + activation on NHWC maps (SECOND, point_pillars.py:640-682).  `packed` = pack_bf16x3(weights) runs the
+    same product on the bf16 matrix pipe (three-way split, float32-equivalent); `weights` still gives the shape."""
     lib = _abi.get()
     _need_gpu(x, weights, bias)
     B, H, W, Cin = x.shape
@@ -59,6 +78,14 @@ def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=Non
     if out is None:
         out = torch.empty((B, OH, OW, cout), dtype=torch.float32, device=x.device)
     ld = out.shape[3]
+    if packed is not None:
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_conv2d_nhwc_bf16x3(x.data_ptr(), B, H, W, Cin, packed.data_ptr(),
+                                             None if bias is None else bias.data_ptr(), kh, kw, stride, pad, act, slope, cout,
+                                             out.data_ptr() + 4 * out_channel_offset, ld, _stream())
+        if rc != _abi.E_UNSUPPORTED:
+            _abi.check(rc, "ml3d_conv2d_nhwc_bf16x3")
+            return out
     wsb = lib.ml3d_conv2d_workspace_bytes(B, OH, OW, Cin, cout, kh, kw)
     ws = _ws(wsb, x.device)
     with torch.cuda.device(x.device):

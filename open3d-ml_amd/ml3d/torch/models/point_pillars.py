@@ -8,6 +8,8 @@ batched voxelize -> fused pillar gather + PillarFeatureNet + scatter into an NHW
 Anchor3DHead as f32-MFMA implicit GEMMs -> the reference's three NCHW head tensors.
 There is no CPU execution path.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -261,6 +263,14 @@ class Anchor3DHead(nn.Module):
         return self.split_rows(*self.boxes_device(cls_scores, bbox_preds, dir_preds))
 
 
+def _conv_path():
+    """'bf16x3' (default) or 'f32': which matrix pipe SECOND's convolutions run on (A/B knob, read when the weights are packed)."""
+    v = os.environ.get("ML3D_PP_CONV", "bf16x3").strip().lower()
+    if v not in ("bf16x3", "f32"):
+        raise ValueError("ML3D_PP_CONV must be 'bf16x3' or 'f32', got %r" % v)
+    return v
+
+
 def _bn_affine(bn):
     s = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
     return s, bn.bias.detach().double().cpu() - bn.running_mean.detach().double().cpu() * s
@@ -320,8 +330,11 @@ class PointPillars(nn.Module):
                     w = conv.weight.detach().double().cpu() * s[:, None, None, None]          # [co, ci, ky, kx]
                     co, ci, kh, kw = w.shape
                     wk = w.permute(2, 3, 1, 0).reshape(kh * kw * ci, co).contiguous()          # [(ky,kx,ci), co]
-                    convs.append(dict(w=wk.float().to(dev), b=t.float().to(dev), stride=conv.stride[0], k=kh,
-                                      pad=conv.padding[0]))
+                    wd = wk.float().to(dev)
+                    # the split weights of the bf16 matrix path (ops.pack_bf16x3: float32-equivalent products, 2.7x the MFMA
+                    # rate); None (cin % 32 != 0, or ML3D_PP_CONV=f32) keeps the f32 MFMA kernel
+                    pk = ops.pack_bf16x3(wd) if (wd.is_cuda and ci % 32 == 0 and _conv_path() == 'bf16x3') else None
+                    convs.append(dict(w=wd, b=t.float().to(dev), stride=conv.stride[0], k=kh, pad=conv.padding[0], packed=pk))
                 P['blocks'].append(convs)
             for db in self.neck.deblocks:
                 up, bn = db[0], db[1]
@@ -371,7 +384,7 @@ class PointPillars(nn.Module):
         outs = []
         for convs in P['blocks']:
             for c in convs:
-                x = ops.conv2d_nhwc(x, c['w'], c['b'], c['k'], c['k'], c['stride'], c['pad'], act=2)
+                x = ops.conv2d_nhwc(x, c['w'], c['b'], c['k'], c['k'], c['stride'], c['pad'], act=2, packed=c['packed'])
             outs.append(x)
         ctot = sum(d['cout'] for d in P['deblocks'])
         d0 = P['deblocks'][0]

@@ -337,6 +337,36 @@ def conv2d_nhwc(x, w, bias, stride, pad, act=2, kh=3, kw=3):
     return rc, out
 
 
+def pack_bf16x3(w):
+    """[K, N] float -> the three bf16 planes of ml3d_gemm_pack_bf16x3 (uint8 array), or (rc, None)."""
+    L = lib()
+    w = np.ascontiguousarray(w, np.float32)
+    K, N = w.shape
+    nbytes = int(L.ml3d_gemm_pack_bf16x3_bytes(K, N))
+    buf = np.zeros(max(nbytes, 16) + 16, np.uint8)
+    off = (-buf.ctypes.data) % 16
+    packed = buf[off:off + max(nbytes, 16)]
+    rc = L.ml3d_gemm_pack_bf16x3(w.ctypes.data, K, N, packed.ctypes.data, nbytes, None)
+    return rc, packed
+
+
+def conv2d_nhwc_bf16x3(x, w, bias, stride, pad, act=2, kh=3, kw=3, out=None, ch_off=0):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    B, H, W, Cin = x.shape
+    cout = w.shape[1]
+    rc, packed = pack_bf16x3(w)
+    if rc != 0:
+        return rc, None
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = np.zeros((B, OH, OW, cout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, B, H, W, Cin, packed.ctypes.data, None if b is None else b.ctypes.data, kh, kw,
+                                   stride, pad, act, 0.0, cout, out.ctypes.data + 4 * ch_off, out.shape[3], None)
+    return rc, out
+
+
 def deconv2d_nhwc(x, w, bias, stride, cout, out=None, ch_off=0, act=2):
     L = lib()
     x = np.ascontiguousarray(x, np.float32)

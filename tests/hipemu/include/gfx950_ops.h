@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 
 #define ML3D_WAVES_PER_SIMD(n)
 
@@ -15,4 +16,13 @@ static inline void key_insert_step(double& slot, double& x) { const double t = s
 // (lanes are independent fibers here: a ballot in divergent loops cannot rendezvous; the lane's own predicate is a valid answer
 //  for every caller -- see the product header)
 static inline bool wave_any_active(bool pred) { return pred; }
+// two floats -> two bf16 (round to nearest even) packed low | high << 16: v_cvt_pk_bf16_f32
+static inline uint32_t bf16_pack2(float a, float b) {
+    auto one = [](float x) { uint32_t u; memcpy(&u, &x, 4); if ((u & 0x7f800000u) == 0x7f800000u) return u >> 16; u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+    return one(a) | (one(b) << 16);
+}
+static inline float sub_f32(float a, float b) { return a - b; }
+typedef float ml3d_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t ml3d_u32x4 __attribute__((ext_vector_type(4)));
+static inline ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x16 c) { return hipemu_mfma_32x32x16_bf16(a, b, c); }
 }  // namespace ml3d

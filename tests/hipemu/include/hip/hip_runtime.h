@@ -301,6 +301,31 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
     }
     return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l % 32][k = 8 (l / 32) + e] and B[k = 8 (l / 32) + e][j = l % 32], e = 0..7, as eight
+// bf16 packed in four dwords.  Every product of two bf16 is exact in float; the 16 products and C are summed here in double and
+// rounded to float ONCE (the hardware's internal adder is not documented bit for bit -- measured on an MI355X the kernel's error
+// against a float64 product equals the f32 MFMA kernel's, profiles/r05_bf16x3_conv.log -- so tests of kernels built on this
+// instruction carry a tolerance, not an equality)
+typedef uint32_t hipemu_u32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c) {
+    uint32_t ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    auto vw = hipemu::wave_exchange(ab, sizeof(ab));
+    const int lane = vw.lane;
+    auto bf = [](const uint32_t* w, int e) { uint32_t u = (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16); float f; memcpy(&f, &u, 4); return f; };
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        double acc = (double)c[r];
+        for (int half = 0; half < 2; ++half) {
+            uint32_t pa[8], pb[8];
+            memcpy(pa, vw.peer(row + 32 * half), sizeof(pa));
+            memcpy(pb, vw.peer(col + 32 * half), sizeof(pb));
+            for (int e = 0; e < 8; ++e) acc += (double)bf(pa, e) * (double)bf(pb + 4, e);
+        }
+        d[r] = (float)acc;
+    }
+    return d;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 

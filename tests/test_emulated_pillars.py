@@ -136,3 +136,80 @@ rc, out = emu.linear(a, wt, bias)
 assert rc == 0 and np.abs(out - (a @ wt + bias)).max() < 2e-4
 print("OK")
 ''')
+
+
+# ---- the same convolution on the bf16 matrix pipe (gemm_tile_bf3: three-way bf16 split of both operands) -----------------------
+def _bf16_planes(packed, K, N):
+    """decode ml3d_gemm_pack_bf16x3's layout [K / 32][3][Npad][32] bf16 -> three float64 [K, N] matrices"""
+    npad = (N + 127) // 128 * 128
+    u = np.frombuffer(packed.tobytes(), np.uint16)[: 3 * npad * K].reshape(K // 32, 3, npad, 32)
+    f = (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    return [f[:, p].transpose(0, 2, 1).reshape(K, npad)[:, :N] for p in range(3)], f[:, :, N:, :]
+
+
+def test_bf16x3_weight_split_is_exact():
+    """h + m + l == w for every float (normal range), each plane is bf16 and the padding columns are zero"""
+    rng = np.random.default_rng(3)
+    K, N = 96, 70
+    w = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-20, 20, (K, N)))).astype(np.float32)
+    w[0, :4] = [0.0, -0.0, 1.0, -3.0e38]
+    rc, packed = emu.pack_bf16x3(w)
+    assert rc == 0
+    (h, m, l), pad = _bf16_planes(packed, K, N)
+    assert np.array_equal(h + m + l, w.astype(np.float64))
+    assert np.all(np.abs(m) <= np.abs(h) * 2.0 ** -8 + 1e-300) and np.all(np.abs(l) <= np.abs(h) * 2.0 ** -16 + 1e-300)
+    assert not pad.any()
+
+
+@pytest.mark.parametrize("cin,cout,stride,hw,act", [
+    (32, 64, 1, (13, 11), 2),        # 64-column tiles, ragged last row tile
+    (64, 128, 2, (12, 14), 2),       # 128-column tiles, M = 84 < one row tile
+    (64, 192, 2, (12, 14), 0),       # two column tiles, the second half empty; no activation
+    (32, 20, 1, (5, 5), 1),          # N < 64 and not a multiple of 4; leaky relu
+    (96, 132, 2, (31, 9), 2),        # cin = 3 chunks per tap, N = 128 + 4
+    (64, 64, 1, (16, 16), 2)])       # whole tiles only
+def test_bf16x3_conv_matches_float64(cin, cout, stride, hw, act):
+    """error against a float64 convolution: of the order of the f32 MFMA kernel's own (both far inside the 1e-4 bar)"""
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((2, cin) + hw).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.0), 2: F.relu(ref)}[act].permute(0, 2, 3, 1).numpy()
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    rc, out = emu.conv2d_nhwc_bf16x3(x.transpose(0, 2, 3, 1), wk, b, stride, 1, act=act)
+    rc32, out32 = emu.conv2d_nhwc(x.transpose(0, 2, 3, 1), wk, b, stride, 1, act=act)
+    assert rc == 0 and rc32 == 0
+    e, e32 = np.abs(out - ref).max(), np.abs(out32 - ref).max()
+    assert e <= 1e-5 and e <= 4 * e32 + 1e-6, (e, e32)
+
+
+def test_bf16x3_conv_1x1_no_bias_into_a_concat_slice():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((1, 9, 7, 64)).astype(np.float32)
+    w = (rng.standard_normal((64, 48)) * 0.2).astype(np.float32)
+    big = np.full((1, 9, 7, 100), 7.0, np.float32)
+    rc, out = emu.conv2d_nhwc_bf16x3(x, w, None, 1, 0, act=0, kh=1, kw=1, out=big, ch_off=40)
+    assert rc == 0
+    ref = x.astype(np.float64).reshape(-1, 64) @ w.astype(np.float64)
+    assert np.abs(out[..., 40:88].reshape(-1, 48) - ref).max() <= 1e-5
+    assert (out[..., :40] == 7.0).all() and (out[..., 88:] == 7.0).all()
+
+
+def test_bf16x3_rejects_what_it_cannot_run():
+    L = emu.lib()
+    assert L.ml3d_gemm_pack_bf16x3_bytes(40, 64) == 0 and L.ml3d_gemm_pack_bf16x3_bytes(64, 0) == 0
+    assert L.ml3d_gemm_pack_bf16x3_bytes(64, 70) == 3 * 128 * 64 * 2
+    w = np.zeros((40, 64), np.float32)
+    buf = np.zeros(1 << 16, np.uint8)
+    assert L.ml3d_gemm_pack_bf16x3(w.ctypes.data, 40, 64, buf.ctypes.data, buf.nbytes, None) == -4       # K % 32
+    w = np.zeros((64, 64), np.float32)
+    assert L.ml3d_gemm_pack_bf16x3(w.ctypes.data, 64, 64, buf.ctypes.data, 100, None) == -2              # packed buffer too small
+    assert L.ml3d_gemm_pack_bf16x3(None, 64, 64, buf.ctypes.data, buf.nbytes, None) == -1
+    x = np.zeros((1, 4, 4, 48), np.float32)
+    out = np.zeros((1, 4, 4, 64), np.float32)
+    rc = L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, 1, 4, 4, 48, buf.ctypes.data, None, 3, 3, 1, 1, 2, 0.0, 64, out.ctypes.data, 64, None)
+    assert rc == -4                                                                                       # cin % 32
+    x = np.zeros((1, 4, 4, 64), np.float32)
+    assert L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, 1, 4, 4, 64, None, None, 3, 3, 1, 1, 2, 0.0, 64, out.ctypes.data, 64, None) == -1
+    assert L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, 1, 4, 4, 64, buf.ctypes.data, None, 3, 3, 1, 1, 2, 0.0, 64, out.ctypes.data, 32, None) == -1

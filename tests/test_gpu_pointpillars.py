@@ -147,3 +147,50 @@ def test_two_lane_stream_returns_the_single_lane_detections():
                 assert torch.equal(one[2][i], two[2][i]) and len(one[2][i]) > 0, i
                 assert (one[1][i] - two[1][i]).abs().max().item() <= 1e-5
                 assert (one[0][i] - two[0][i]).abs().max().item() <= 1e-4
+
+
+# ---- SECOND's convolutions on the bf16 matrix pipe (three-way bf16 split, gemm_tile_bf3) ----------------------------------------
+@pytest.mark.parametrize("cin,cout,stride,hw", [(64, 64, 1, (248, 216)), (64, 128, 2, (248, 216)), (128, 256, 2, (124, 108)),
+                                                (256, 256, 1, (62, 54)), (32, 20, 1, (17, 9))])
+def test_bf16x3_convolution_is_float32_equivalent(cin, cout, stride, hw):
+    """The layer shapes of pointpillars_kitti.yml (2 sweeps) + a ragged one: |out - float64| of the bf16x3 kernel is of the order of the
+    f32 MFMA kernel's own rounding (<= 2x + 1e-6; measured equal, profiles/r05_bf16x3_conv.log) and far inside the 1e-4 bar."""
+    from ml3d import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    dev = torch.device("cuda:0")
+    x = torch.randn((2,) + hw + (cin,), generator=g).relu_().to(dev)
+    w = (torch.randn((9 * cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    pk = ops.pack_bf16x3(w)
+    assert pk is not None and pk.dtype == torch.uint8
+    o32 = ops.conv2d_nhwc(x, w, b, 3, 3, stride, 1, act=2)
+    obf = ops.conv2d_nhwc(x, w, b, 3, 3, stride, 1, act=2, packed=pk)
+    w4 = w.double().view(3, 3, cin, cout).permute(3, 2, 0, 1).contiguous()
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w4, b.double(), stride=stride, padding=1)).permute(0, 2, 3, 1)
+    e32, ebf = float((o32.double() - ref).abs().max()), float((obf.double() - ref).abs().max())
+    assert ebf <= 2 * e32 + 1e-6 and ebf <= 2e-5, (ebf, e32)
+    assert ops.pack_bf16x3(torch.zeros((9 * 48, 64), device=dev)) is None          # K = 432 is not a multiple of 32: f32 kernel
+
+
+def test_both_convolution_paths_give_the_same_detections(monkeypatch):
+    """ML3D_PP_CONV=f32 (f32 MFMA) and the default (bf16x3) on the same sweeps: head maps within 2e-5, identical detections."""
+    cfg = P.KITTI_CFG
+    sd = P.make_state_dict(cfg, 2024)
+    clouds = [torch.from_numpy(c).cuda() for c in _clouds(cfg, [0, 5, 9])]
+    res = {}
+    for path in ("f32", "bf16x3"):
+        monkeypatch.setenv("ML3D_PP_CONV", path)
+        m = _model(cfg, sd)
+        P_ = m.packed_params(m.device)
+        assert all((c['packed'] is not None) == (path == "bf16x3") for blk in P_['blocks'] for c in blk)
+        outs = m(clouds)
+        res[path] = (outs, m.bbox_head.get_bboxes(*outs))
+    for a, b in zip(res["f32"][0], res["bf16x3"][0]):
+        assert (a - b).abs().max().item() <= 2e-5
+    for i in range(len(clouds)):
+        bf, sf, lf = (res["f32"][1][k][i] for k in range(3))
+        bb, sb, lb = (res["bf16x3"][1][k][i] for k in range(3))
+        assert torch.equal(lf, lb) and (sf - sb).abs().max().item() <= 1e-5 and (bf - bb).abs().max().item() <= 1e-4
+    monkeypatch.setenv("ML3D_PP_CONV", "fp8")
+    with pytest.raises(ValueError):
+        _model(cfg, sd).packed_params(torch.device("cuda:0"))

@@ -3,7 +3,7 @@ attributes HBM traffic to it alone.  usage: python tools/roofline_ops.py kp|pp [
   kp  the first resnet block's KPConv of the 64-sphere Toronto3D batch (32 -> 32 channels, 640 000 queries): kp_agg_gemm32
       (aggregation + product in one kernel), the op bench_models.run_kpconv times as `kpconv_rigid` call #1
   pp  SECOND's second convolution of 16 KITTI sweeps (3x3, 64 -> 64, stride 1, 248 x 216): bench_models.run_pointpillars's
-      `conv2d_nhwc` call #1
+      `conv2d_nhwc` call #1, on the bf16x3 path the model runs (pp_f32: the f32 MFMA kernel on the same problem)
   radius | subsample | voxelize | pillars   the four HBM-bound primitives of SURVEY.md §8(d) at the batch shapes of the bench
       (64 Toronto3D spheres: layer-0 conv search r = 0.2 m / layer-0 pooling grid 0.16 m; 8 KITTI sweeps = one lane's launch:
       voxelize / pillar gather + PFN + canvas scatter), each ALONE in the process, `launches` times after its inputs are on
@@ -82,7 +82,9 @@ else:
     x = torch.randn((16, 248, 216, 64), device=dev)
     w = torch.randn((9 * 64, 64), device=dev) * 0.05
     b = torch.randn(64, device=dev)
-    run = lambda: ops.conv2d_nhwc(x, w, b, 3, 3, 1, 1, act=2)
+    # pp: the path the model runs (bf16x3 weights, gemm_tile_bf3); pp_f32: the f32 MFMA kernel (gemm_tile2) on the same problem
+    pk = ops.pack_bf16x3(w) if which != "pp_f32" else None
+    run = lambda: ops.conv2d_nhwc(x, w, b, 3, 3, 1, 1, act=2, packed=pk)
     units = 16
 run()
 torch.cuda.synchronize()
