@@ -428,6 +428,19 @@ int ml3d_conv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int ci
                             int pad, int act, float slope, int cout, float* out,
                             int64_t out_pixel_stride, void* stream);
 
+/* The same path for dense rows: ml3d_linear_bf16x3 = act(a[rows, k] . W + bias)*/
+/* with `packed` = ml3d_gemm_pack_bf16x3 of W [k, n] (lda % 4 == 0, a 16-byte    */
+/* aligned, k % 32 == 0, else ML3D_E_UNSUPPORTED), and ml3d_deconv2d_nhwc_bf16x3 */
+/* = ml3d_deconv2d_nhwc (below) with `packed` of its [cin, s*s*cout] matrix.     */
+int ml3d_linear_bf16x3(const float* a, int64_t lda, int64_t rows, int k, const void* packed,
+                       const float* bias, int n, int act, float slope, float* out, int64_t ldc,
+                       void* stream);
+
+int ml3d_deconv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin,
+                              const void* packed, const float* bias, int stride, int act,
+                              float slope, int cout, float* out, int64_t out_pixel_stride,
+                              void* stream);
+
 /* ConvTranspose2d with kernel == stride + folded BN + activation (SECONDFPN    */
 /*   deblocks, point_pillars.py:712-717, 749): GEMM + pixel-shuffle store.      */
 /* weights [ci, (dy*stride + dx)*cout + co] (= the reference's [cin, cout, k, k]*/

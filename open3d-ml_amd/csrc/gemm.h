@@ -75,6 +75,9 @@ int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float*
 size_t gemm_pack_bf16x3_bytes(int K, int N);
 int gemm_pack_bf16x3(const float* Bm, int K, int N, void* packed, hipStream_t stream);
 bool gemm_conv_bf16x3_ok(const ConvA& A);
+// dense rows a[M, K] (lda % 4 == 0, 16-byte aligned, K % 32 == 0, else ML3D_E_UNSUPPORTED): Linears and kernel == stride deconvolutions
+int gemm_rows_bf16x3(const float* a, int64_t lda, int64_t M, int K, const void* packed, int N, const Epilogue& ep, float* C,
+                     int64_t ldc, hipStream_t stream);
 int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t stream);
 
 }  // namespace ml3d

@@ -511,6 +511,22 @@ struct ConvLoader2 {
     }
 };
 
+// dense rows [M, K] (lda floats apart, float4-addressable) for the 128-row kernels: deconvolutions as GEMMs, head Linears
+struct RowsLoader2 {
+    const float* a;
+    int64_t lda;
+    int64_t M;
+    int K;
+    struct Ctx { const float* p; };
+    __device__ __forceinline__ Ctx prepare(int64_t m) const { Ctx c; c.p = m < M ? a + m * lda : nullptr; return c; }
+    struct Walk { int k; };
+    __device__ __forceinline__ Walk walk_begin() const { Walk w; w.k = 0; return w; }
+    __device__ __forceinline__ void walk_next(Walk& w, int kc) const { w.k += kc; }
+    __device__ __forceinline__ float4 load4w(const Ctx& c, const Walk& w, int kq) const {
+        return c.p ? *reinterpret_cast<const float4*>(c.p + w.k + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
 // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with
 // the identity mapping the 128-row tiles that share input rows (the 3 x 3 taps of neighbouring pixels) sit on 8 different L2s
 // and each XCD streams nearly the whole image.  Here XCD x owns a CONTIGUOUS run of tiles (the column tiles of one row tile
@@ -1005,6 +1021,21 @@ bool gemm_conv_bf16x3_ok(const ConvA& A) {
     const int64_t M = (int64_t)A.B * A.OH * A.OW;
     return A.in && (A.C % BF_KC) == 0 && A.KH * A.KW <= 32 && M < 0x7fffffffll &&
            (int64_t)A.B * A.H * A.W * A.C < 0x7fffffffll - (int64_t)(A.pad + 1) * (A.W + 1) * A.C;
+}
+
+// dense rows: the transposed convolutions (kernel == stride: a GEMM + pixel-shuffle store) and the head Linear of PointPillars
+int gemm_rows_bf16x3(const float* a, int64_t lda, int64_t M, int K, const void* packed, int N, const Epilogue& ep, float* C,
+                     int64_t ldc, hipStream_t st) {
+    if (!a || !packed || !C || N <= 0 || K <= 0 || M < 0 || ep.res_gather) return ML3D_E_INVALID;
+    if ((K % BF_KC) != 0 || (lda & 3) != 0 || (((uintptr_t)a) & 15) != 0) return ML3D_E_UNSUPPORTED;
+    if (M == 0) return 0;
+    RowsLoader2 L;
+    L.a = a; L.lda = lda; L.M = M; L.K = K;
+    const int Npad = bf3_npad(N);
+    const unsigned gm = (unsigned)((M + G2_BM - 1) / G2_BM);
+    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128)), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc);
+    else hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 64>), dim3(gm, 1u), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
 int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t st) {

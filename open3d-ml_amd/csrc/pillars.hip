@@ -318,6 +318,24 @@ extern "C" int ml3d_deconv2d_nhwc(const float* in, int64_t batch, int h, int w, 
                      (hipStream_t)stream);
 }
 
+extern "C" int ml3d_deconv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin, const void* packed,
+                                         const float* bias, int stride, int act, float slope, int cout, float* out,
+                                         int64_t out_pixel_stride, void* stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || stride <= 0 || !in || !packed || !out ||
+        out_pixel_stride < cout)
+        return ML3D_E_INVALID;
+    Epilogue ep = {bias, nullptr, 0, act, slope, stride, h, w, cout};
+    return gemm_rows_bf16x3(in, cin, batch * h * w, cin, packed, stride * stride * cout, ep, out, out_pixel_stride,
+                            (hipStream_t)stream);
+}
+
+extern "C" int ml3d_linear_bf16x3(const float* a, int64_t lda, int64_t rows, int k, const void* packed, const float* bias,
+                                  int n, int act, float slope, float* out, int64_t ldc, void* stream) {
+    if (rows < 0 || k <= 0 || n <= 0 || lda < k || ldc < n || !a || !packed || !out) return ML3D_E_INVALID;
+    Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
+    return gemm_rows_bf16x3(a, lda, rows, k, packed, n, ep, out, ldc, (hipStream_t)stream);
+}
+
 extern "C" int ml3d_nhwc_to_nchw(const float* in, int64_t in_pixel_stride, int channel_offset, int channels,
                                  int64_t batch, int64_t hw, float* out, void* stream) {
     if (batch <= 0 || hw <= 0 || channels <= 0 || channel_offset < 0 || !in || !out ||

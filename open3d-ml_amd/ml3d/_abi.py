@@ -49,6 +49,8 @@ SYMBOLS = [
     "ml3d_gemm_pack_bf16x3_bytes",
     "ml3d_gemm_pack_bf16x3",
     "ml3d_conv2d_nhwc_bf16x3",
+    "ml3d_linear_bf16x3",
+    "ml3d_deconv2d_nhwc_bf16x3",
     "ml3d_deconv2d_nhwc",
     "ml3d_nhwc_to_nchw",
     "ml3d_nms_workspace_bytes",
@@ -181,6 +183,10 @@ def bind(lib):
     lib.ml3d_gemm_pack_bf16x3.argtypes = [vp, i32, i32, vp, sz, vp]
     lib.ml3d_conv2d_nhwc_bf16x3.restype = C.c_int
     lib.ml3d_conv2d_nhwc_bf16x3.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp]
+    lib.ml3d_linear_bf16x3.restype = C.c_int
+    lib.ml3d_linear_bf16x3.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, f32, vp, i64, vp]
+    lib.ml3d_deconv2d_nhwc_bf16x3.restype = C.c_int
+    lib.ml3d_deconv2d_nhwc_bf16x3.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, f32, i32, vp, i64, vp]
     lib.ml3d_deconv2d_nhwc.restype = C.c_int
     lib.ml3d_deconv2d_nhwc.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, f32, i32, vp, i64, vp, sz, vp]
     lib.ml3d_nhwc_to_nchw.restype = C.c_int

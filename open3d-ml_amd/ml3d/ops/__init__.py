@@ -15,6 +15,6 @@ from .voxel import (voxelize, subsample_batch, subsample, rotate_points, grid_su
                     batch_grid_subsampling, _SubsamplePlan)
 from .kpconv import (kpconv_rigid, kpconv_deformable, linear, gather_pool, kpconv_weighted, kpconv_weighted_backward,   # noqa: F401
                      KPConvFunction)
-from .detection import (pillar_features, conv2d_nhwc, pack_bf16x3, deconv2d_nhwc, nhwc_to_nchw, nms, pointpillars_boxes,   # noqa: F401
+from .detection import (pillar_features, conv2d_nhwc, pack_bf16x3, linear_bf16x3, deconv2d_nhwc, nhwc_to_nchw, nms, pointpillars_boxes,   # noqa: F401
                         iou_bev, iou_3d, topk_rows)
 from .sampler import nearest_to_center, argmax_labels, vote_update, device_patch   # noqa: F401

@@ -96,14 +96,40 @@ def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=Non
     return out
 
 
-def deconv2d_nhwc(x, weights, bias, stride, cout, act=2, slope=0.0, out=None, out_channel_offset=0):
-    """ConvTranspose2d(kernel == stride) + folded BN + activation (SECONDFPN, point_pillars.py:712-717, 749)."""
+def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0):
+    """act(a @ W + bias) on the bf16 matrix pipe, `packed` = pack_bf16x3(W [K, n]) (float32-equivalent: pack_bf16x3).  Returns None
+    when the problem is not eligible (K % 32, alignment): the caller keeps ops.linear."""
+    lib = _abi.get()
+    _need_gpu(a, bias)
+    if a.dtype != torch.float32 or not a.is_contiguous():
+        raise RuntimeError("linear_bf16x3: float32 contiguous rows required")
+    m, k = a.shape
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = lib.ml3d_linear_bf16x3(a.data_ptr(), k, m, k, packed.data_ptr(), None if bias is None else bias.data_ptr(), int(n),
+                                    int(act), float(slope), out.data_ptr(), int(n), _stream())
+    if rc == _abi.E_UNSUPPORTED:
+        return None
+    _abi.check(rc, "ml3d_linear_bf16x3")
+    return out
+
+
+def deconv2d_nhwc(x, weights, bias, stride, cout, act=2, slope=0.0, out=None, out_channel_offset=0, packed=None):
+    """ConvTranspose2d(kernel == stride) + folded BN + activation (SECONDFPN, point_pillars.py:712-717, 749).  `packed` =
+    pack_bf16x3(weights): the same GEMM on the bf16 matrix pipe."""
     lib = _abi.get()
     _need_gpu(x, weights, bias)
     B, H, W, Cin = x.shape
     if out is None:
         out = torch.empty((B, H * stride, W * stride, cout), dtype=torch.float32, device=x.device)
     ld = out.shape[3]
+    if packed is not None:
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_deconv2d_nhwc_bf16x3(x.data_ptr(), B, H, W, Cin, packed.data_ptr(), None if bias is None else bias.data_ptr(),
+                                               stride, act, slope, cout, out.data_ptr() + 4 * out_channel_offset, ld, _stream())
+        if rc != _abi.E_UNSUPPORTED:
+            _abi.check(rc, "ml3d_deconv2d_nhwc_bf16x3")
+            return out
     wsb = lib.ml3d_conv2d_workspace_bytes(B, H, W, Cin, stride * stride * cout, 1, 1)
     ws = _ws(wsb, x.device)
     with torch.cuda.device(x.device):

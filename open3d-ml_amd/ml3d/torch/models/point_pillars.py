@@ -264,7 +264,7 @@ class Anchor3DHead(nn.Module):
 
 
 def _conv_path():
-    """'bf16x3' (default) or 'f32': which matrix pipe SECOND's convolutions run on (A/B knob, read when the weights are packed)."""
+    """'bf16x3' (default) or 'f32': which matrix pipe SECOND's convolutions, SECONDFPN's transposed convolutions and the head Linear run on (A/B knob, read when the weights are packed)."""
     v = os.environ.get("ML3D_PP_CONV", "bf16x3").strip().lower()
     if v not in ("bf16x3", "f32"):
         raise ValueError("ML3D_PP_CONV must be 'bf16x3' or 'f32', got %r" % v)
@@ -342,7 +342,9 @@ class PointPillars(nn.Module):
                 w = up.weight.detach().double().cpu() * s[None, :, None, None]                # [ci, co, k, k]
                 ci, co, k, _ = w.shape
                 wk = w.permute(0, 2, 3, 1).reshape(ci, k * k * co).contiguous()                # [ci, (dy,dx,co)]
-                P['deblocks'].append(dict(w=wk.float().to(dev), b=t.float().to(dev), stride=k, cout=co))
+                wd = wk.float().to(dev)
+                pk = ops.pack_bf16x3(wd) if (wd.is_cuda and ci % 32 == 0 and _conv_path() == 'bf16x3') else None
+                P['deblocks'].append(dict(w=wd, b=t.float().to(dev), stride=k, cout=co, packed=pk))
             h = self.bbox_head
             ws, bs = [], []
             for conv in (h.conv_cls, h.conv_reg, h.conv_dir_cls):
@@ -351,6 +353,8 @@ class PointPillars(nn.Module):
             P['head_w'] = torch.cat(ws, 1).contiguous().float().to(dev)
             P['head_b'] = torch.cat(bs).float().to(dev)
             P['head_split'] = [w.shape[1] for w in ws]
+            hw = P['head_w']
+            P['head_packed'] = ops.pack_bf16x3(hw) if (hw.is_cuda and hw.shape[0] % 32 == 0 and _conv_path() == 'bf16x3') else None
             self._packed = (dev, P)
         return self._packed[1]
 
@@ -394,7 +398,7 @@ class PointPillars(nn.Module):
         for o, d in zip(outs, P['deblocks']):
             if o.shape[1] * d['stride'] != H0 or o.shape[2] * d['stride'] != W0:
                 raise RuntimeError("SECONDFPN: upsampled maps do not share one size")
-            ops.deconv2d_nhwc(o, d['w'], d['b'], d['stride'], d['cout'], act=2, out=neck, out_channel_offset=off)
+            ops.deconv2d_nhwc(o, d['w'], d['b'], d['stride'], d['cout'], act=2, out=neck, out_channel_offset=off, packed=d['packed'])
             off += d['cout']
         return neck
 
@@ -406,7 +410,12 @@ class PointPillars(nn.Module):
         neck = self.extract_feats(points)
         P = self.packed_params(self.device)
         B, H, W, Cn = neck.shape
-        return ops.linear(neck.view(B * H * W, Cn), P['head_w'], P['head_b']).view(B, H, W, -1), P['head_split']
+        rows, out = neck.view(B * H * W, Cn), None
+        if P['head_packed'] is not None:
+            out = ops.linear_bf16x3(rows, P['head_packed'], P['head_w'].shape[1], P['head_b'])
+        if out is None:
+            out = ops.linear(rows, P['head_w'], P['head_b'])
+        return out.view(B, H, W, -1), P['head_split']
 
     @torch.no_grad()
     def detect(self, inputs):

@@ -367,6 +367,36 @@ def conv2d_nhwc_bf16x3(x, w, bias, stride, pad, act=2, kh=3, kw=3, out=None, ch_
     return rc, out
 
 
+def linear_bf16x3(a, w, bias, act=0):
+    L = lib()
+    a = np.ascontiguousarray(a, np.float32)
+    rc, packed = pack_bf16x3(w)
+    if rc != 0:
+        return rc, None
+    m, k = a.shape
+    n = w.shape[1]
+    out = np.zeros((m, n), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = L.ml3d_linear_bf16x3(a.ctypes.data, k, m, k, packed.ctypes.data, None if b is None else b.ctypes.data, n, act, 0.0,
+                              out.ctypes.data, n, None)
+    return rc, out
+
+
+def deconv2d_nhwc_bf16x3(x, w, bias, stride, cout, out=None, ch_off=0, act=2):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    B, H, W, Cin = x.shape
+    rc, packed = pack_bf16x3(w)
+    if rc != 0:
+        return rc, None
+    b = np.ascontiguousarray(bias, np.float32)
+    if out is None:
+        out = np.zeros((B, H * stride, W * stride, cout), np.float32)
+    rc = L.ml3d_deconv2d_nhwc_bf16x3(x.ctypes.data, B, H, W, Cin, packed.ctypes.data, b.ctypes.data, stride, act, 0.0, cout,
+                                     out.ctypes.data + 4 * ch_off, out.shape[3], None)
+    return rc, out
+
+
 def deconv2d_nhwc(x, w, bias, stride, cout, out=None, ch_off=0, act=2):
     L = lib()
     x = np.ascontiguousarray(x, np.float32)

@@ -213,3 +213,43 @@ def test_bf16x3_rejects_what_it_cannot_run():
     x = np.zeros((1, 4, 4, 64), np.float32)
     assert L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, 1, 4, 4, 64, None, None, 3, 3, 1, 1, 2, 0.0, 64, out.ctypes.data, 64, None) == -1
     assert L.ml3d_conv2d_nhwc_bf16x3(x.ctypes.data, 1, 4, 4, 64, buf.ctypes.data, None, 3, 3, 1, 1, 2, 0.0, 64, out.ctypes.data, 32, None) == -1
+
+
+@pytest.mark.parametrize("stride", [1, 2, 4])
+def test_bf16x3_deconv_pixel_shuffle_into_concat_slice(stride):
+    """SECONDFPN's transposed convolution (kernel == stride) as a dense-row GEMM on the bf16x3 path + pixel-shuffle store"""
+    rng = np.random.default_rng(stride)
+    cin, cout = 64, 32
+    x = rng.standard_normal((2, cin, 6, 5)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, stride, stride)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = F.relu(F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride))
+    wk = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(cin, stride * stride * cout))   # [ci, (dy,dx,co)]
+    big = np.full((2, 6 * stride, 5 * stride, 80), -1.0, np.float32)
+    rc, out = emu.deconv2d_nhwc_bf16x3(x.transpose(0, 2, 3, 1), wk, b, stride, cout, out=big, ch_off=40)
+    assert rc == 0
+    assert np.abs(out[..., 40:72] - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-5
+    assert (out[..., :40] == -1).all() and (out[..., 72:] == -1).all()
+
+
+@pytest.mark.parametrize("m,k,n,act", [(300, 384, 72, 0), (129, 32, 20, 2), (64, 96, 200, 1), (0, 64, 8, 0)])
+def test_bf16x3_linear_matches_float64(m, k, n, act):
+    """the head Linear's shape (K = 384, N = 72) and ragged ones; zero rows is a no-op"""
+    rng = np.random.default_rng(m + k + n)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    rc, out = emu.linear_bf16x3(a, w, b, act=act)
+    assert rc == 0 and out.shape == (m, n)
+    ref = a.astype(np.float64) @ w.astype(np.float64) + b
+    ref = {0: ref, 1: np.where(ref > 0, ref, 0.0), 2: np.maximum(ref, 0.0)}[act]
+    if m:
+        assert np.abs(out - ref).max() <= 1e-5
+    # rows that are not float4-addressable / K not a multiple of 32 are refused, not mis-computed
+    L = emu.lib()
+    buf = np.zeros(1 << 16, np.uint8)
+    a2 = np.zeros((4, 64), np.float32)
+    o2 = np.zeros((4, 8), np.float32)
+    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 66, 4, 64, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 8, None) == -4
+    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 64, 4, 48, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 8, None) == -4
+    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 64, 4, 64, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 4, None) == -1

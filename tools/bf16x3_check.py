@@ -40,13 +40,7 @@ def main():
         dd = float((obf - o32).abs().max())
         sc = float(ref.abs().max())
         ms = []
-        import ctypes
-        from ml3d import _abi
-        lib = ctypes.CDLL(_abi.LIB_PATH)
-        for swz, packed in ((0, None), (0, pk), (1, None), (1, pk)):
-            if hasattr(lib, "ml3d_debug_set_swizzle"):
-                lib.ml3d_debug_set_swizzle(swz)
-                torch.cuda.synchronize()
+        for packed in (None, pk):
             for _ in range(3):
                 ops.conv2d_nhwc(x, w, b, 3, 3, stride, 1, act=2, packed=packed, out=o32)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,10 +54,8 @@ def main():
         fl = 2.0 * B * OH * OW * cout * 9 * cin
         tot[0] += ms[0] * cnt
         tot[1] += ms[1] * cnt
-        print("%3d %3d s%d %dx%d | %.3g %.3g %.3g %.3g | %.4f %.4f %.2fx | %.1f %.1f | swizzled: %.4f %.4f -> %.1f %.1f TF" %
-              (cin, cout, stride, H, W, e32, ebf, dd, sc, ms[0], ms[1], ms[0] / ms[1], fl / ms[0] * 1e-9, fl / ms[1] * 1e-9,
-               ms[2], ms[3], fl / ms[2] * 1e-9, fl / ms[3] * 1e-9))
-        ms = ms[2:]
+        print("%3d %3d s%d %dx%d | %.3g %.3g %.3g %.3g | %.4f %.4f %.2fx | %.1f %.1f" %
+              (cin, cout, stride, H, W, e32, ebf, dd, sc, ms[0], ms[1], ms[0] / ms[1], fl / ms[0] * 1e-9, fl / ms[1] * 1e-9))
     print("backbone convolutions of one forward (16 layers): f32 %.3f ms, bf16x3 %.3f ms" % (tot[0], tot[1]))
 
 
