@@ -294,6 +294,19 @@ int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const int32_t* nei
                       const float* weights, const float* bias, int act, float slope, int cout,
                       float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same convolution with the [15 cin, cout] contraction on the bf16 matrix  */
+/* pipe: `packed` = ml3d_gemm_pack_bf16x3(weights, 15 * cin, cout) (see the      */
+/* PointPillars section: exact three-way bf16 split, float32-equivalent).  Both  */
+/* matrices are passed: convolutions served by the fused small-channel kernels   */
+/* (cin <= 32) and ineligible shapes use `weights`.                              */
+int ml3d_kpconv_rigid_bf16x3(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                             int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                             const float* features, int cin, const float* kernel_points,
+                             int num_kernel_points, float kp_extent, int kp_influence_mode,
+                             const float* weights, const void* packed, const float* bias, int act,
+                             float slope, int cout, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ml3d_kpconv_deformable replaces the deformable branch of KPConv.forward                      */
 /*   (kpconv.py:1011-1066, 1139-1159) once the inner convolution has run: offset_features        */
 /*   [Nq, offset_dim] = offset_conv(q, s, idx, x) + offset_bias (one ml3d_kpconv_rigid call with */
@@ -428,13 +441,21 @@ int ml3d_conv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int ci
                             int pad, int act, float slope, int cout, float* out,
                             int64_t out_pixel_stride, void* stream);
 
-/* The same path for dense rows: ml3d_linear_bf16x3 = act(a[rows, k] . W + bias)*/
-/* with `packed` = ml3d_gemm_pack_bf16x3 of W [k, n] (lda % 4 == 0, a 16-byte    */
-/* aligned, k % 32 == 0, else ML3D_E_UNSUPPORTED), and ml3d_deconv2d_nhwc_bf16x3 */
-/* = ml3d_deconv2d_nhwc (below) with `packed` of its [cin, s*s*cout] matrix.     */
-int ml3d_linear_bf16x3(const float* a, int64_t lda, int64_t rows, int k, const void* packed,
-                       const float* bias, int n, int act, float slope, float* out, int64_t ldc,
-                       void* stream);
+/* The same path for dense rows: ml3d_linear_bf16x3 =                            */
+/*   act([a[rows, k1] | a2[rows, k2]] . W + bias + residual)                     */
+/* with `packed` = ml3d_gemm_pack_bf16x3 of W [k1 + k2, n] (a2 may be NULL with  */
+/* k2 = 0; each block float4-addressable: lda % 4 == 0, 16-byte aligned; k1 and  */
+/* k1 + k2 multiples of 32; else ML3D_E_UNSUPPORTED -- callers keep ml3d_linear).*/
+/* Small-rows / deep-k problems are split along k into `workspace`               */
+/* (ml3d_linear_bf16x3_workspace_bytes; NULL: unsplit).                          */
+/* ml3d_deconv2d_nhwc_bf16x3 = ml3d_deconv2d_nhwc (below) with `packed` of its   */
+/* [cin, s*s*cout] matrix.                                                        */
+size_t ml3d_linear_bf16x3_workspace_bytes(int64_t rows, int n, int k);
+
+int ml3d_linear_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2,
+                       int64_t rows, const void* packed, const float* bias, const float* residual,
+                       int64_t ldr, int n, int act, float slope, float* out, int64_t ldc,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 int ml3d_deconv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin,
                               const void* packed, const float* bias, int stride, int act,

@@ -75,9 +75,12 @@ int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float*
 size_t gemm_pack_bf16x3_bytes(int K, int N);
 int gemm_pack_bf16x3(const float* Bm, int K, int N, void* packed, hipStream_t stream);
 bool gemm_conv_bf16x3_ok(const ConvA& A);
-// dense rows a[M, K] (lda % 4 == 0, 16-byte aligned, K % 32 == 0, else ML3D_E_UNSUPPORTED): Linears and kernel == stride deconvolutions
-int gemm_rows_bf16x3(const float* a, int64_t lda, int64_t M, int K, const void* packed, int N, const Epilogue& ep, float* C,
-                     int64_t ldc, hipStream_t stream);
+// dense rows [a[M, k1] | a2[M, k2]] (each block float4-addressable, k1 and k1 + k2 multiples of 32, no gathered residual, else
+// ML3D_E_UNSUPPORTED): Linears, KPConv's contraction, kernel == stride deconvolutions.  Small-M / deep-K problems are split along K into partial_ws (gemm_partial_bytes_bf16x3 bytes; without it
+// the problem runs unsplit)
+size_t gemm_partial_bytes_bf16x3(int64_t M, int N, int K);
+int gemm_rows_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2, int64_t M, const void* packed,
+                     int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws, size_t partial_bytes, hipStream_t stream);
 int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t stream);
 
 }  // namespace ml3d

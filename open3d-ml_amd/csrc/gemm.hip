@@ -493,7 +493,7 @@ struct ConvLoader2 {
     // the same walk over K without the per-chunk divisions: (tap, element offset of the tap + channel origin) carried from chunk to
     // chunk on the scalar unit (~100 SALU instructions per chunk less than load4's k0 / C, tap / KW)
     struct Walk { int tap, kx, ci, toff; };
-    __device__ __forceinline__ Walk walk_begin() const { Walk w; w.tap = 0; w.kx = 0; w.ci = 0; w.toff = 0; return w; }
+    __device__ __forceinline__ Walk walk_begin(int /* k0 == 0: convolutions are never split along K */) const { Walk w; w.tap = 0; w.kx = 0; w.ci = 0; w.toff = 0; return w; }
     __device__ __forceinline__ void walk_next(Walk& w, int kc) const {
         w.ci += kc;
         w.toff += kc;
@@ -511,19 +511,29 @@ struct ConvLoader2 {
     }
 };
 
-// dense rows [M, K] (lda floats apart, float4-addressable) for the 128-row kernels: deconvolutions as GEMMs, head Linears
+// dense rows [M, k1 | k2] (one or two column blocks, each float4-addressable, k1 % 32 == 0 so that a chunk lies inside one block) for
+// the 128-row kernels: Linears, "unary2 + shortcut" over concatenated inputs, KPConv's contraction, deconvolutions as GEMMs
 struct RowsLoader2 {
     const float* a;
     int64_t lda;
+    const float* a2;        // second block (columns k1 ..) or null
+    int64_t lda2;
+    int k1;
     int64_t M;
     int K;
-    struct Ctx { const float* p; };
-    __device__ __forceinline__ Ctx prepare(int64_t m) const { Ctx c; c.p = m < M ? a + m * lda : nullptr; return c; }
+    struct Ctx { const float* p1; const float* p2; };
+    __device__ __forceinline__ Ctx prepare(int64_t m) const {
+        Ctx c;
+        c.p1 = m < M ? a + m * lda : nullptr;
+        c.p2 = (m < M && a2) ? a2 + m * lda2 - k1 : nullptr;      // (indexed by the global column k >= k1)
+        return c;
+    }
     struct Walk { int k; };
-    __device__ __forceinline__ Walk walk_begin() const { Walk w; w.k = 0; return w; }
+    __device__ __forceinline__ Walk walk_begin(int k0) const { Walk w; w.k = k0; return w; }
     __device__ __forceinline__ void walk_next(Walk& w, int kc) const { w.k += kc; }
     __device__ __forceinline__ float4 load4w(const Ctx& c, const Walk& w, int kq) const {
-        return c.p ? *reinterpret_cast<const float4*>(c.p + w.k + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = w.k < k1 ? c.p1 : c.p2;                   // (uniform choice: the chunk's block)
+        return p ? *reinterpret_cast<const float4*>(p + w.k + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
 
@@ -697,7 +707,8 @@ __device__ __forceinline__ void bf16_split3(float4 v, uint2& h, uint2& m, uint2&
 
 template <class Loader, int BN>
 __global__ void __launch_bounds__(256)
-gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue ep, float* __restrict__ C, int64_t ldc) {
+gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue ep, float* __restrict__ C, int64_t ldc, int kper,
+              float* __restrict__ partial) {
     constexpr int RT = 2, CT = BN / 64;
     constexpr int NA4 = BF_KC / 8;              // A float4 per thread and chunk
     constexpr int NB = 3 * BN * 4 / 256;        // B uint4 (8 bf16) per thread and chunk
@@ -711,7 +722,10 @@ gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue 
     xcd_tile(tbx, tby);
     const int64_t m0 = (int64_t)tbx * G2_BM;
     const int n0 = tby * BN;
-    const int K = L.K;
+    // split K: blockIdx.z owns [kb, ke) and, when `partial` is set, stores its raw sums to partial[z] (gemm_reduce adds the
+    // slices and applies the epilogue)
+    const int kb = blockIdx.z * kper;
+    const int ke = kb + kper < L.K ? kb + kper : L.K;
 
     constexpr int ATH = BF_KC / 4, ARS = 256 / ATH;
     const int ar = tid / ATH, aq = (tid % ATH) * 4;
@@ -733,8 +747,8 @@ gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue 
 
     float4 ra[NA4];
     u32x4 rb[NB];            // (a native vector, not HIP's uint4 struct: the array of structs went through scratch)
-    typename Loader::Walk wk = L.walk_begin();
-    int64_t bo = 0;
+    typename Loader::Walk wk = L.walk_begin(kb);
+    int64_t bo = (int64_t)(kb / BF_KC) * bstep;
     auto fetch = [&]() {                          // the next chunk, in K order
 #pragma unroll
         for (int j = 0; j < NA4; ++j) ra[j] = L.load4w(cx[j], wk, aq);
@@ -795,8 +809,8 @@ gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue 
     fetch();
     stash();
     block_sync_lds();
-    for (int k0 = 0; k0 < K; k0 += BF_KC) {
-        const bool more = k0 + BF_KC < K;
+    for (int k0 = kb; k0 < ke; k0 += BF_KC) {
+        const bool more = k0 + BF_KC < ke;
         if (more) fetch();
         mfma_chunk();
         block_sync_lds();
@@ -804,6 +818,11 @@ gemm_tile_bf3(Loader L, const u32x4* __restrict__ Bp, int N, int Npad, Epilogue 
             stash();
             block_sync_lds();
         }
+    }
+    if (partial) {
+        const Epilogue raw = {nullptr, nullptr, 0, 0, 0.f, 0, 0, 0, 0};
+        tile2_epilogue<RT, CT>(acc, raw, partial + (int64_t)blockIdx.z * L.M * N, N, L.M, N, m0, n0, wr, wc, hi, cl);
+        return;
     }
     tile2_epilogue<RT, CT>(acc, ep, C, ldc, L.M, N, m0, n0, wr, wc, hi, cl);
 }
@@ -1023,19 +1042,65 @@ bool gemm_conv_bf16x3_ok(const ConvA& A) {
            (int64_t)A.B * A.H * A.W * A.C < 0x7fffffffll - (int64_t)(A.pad + 1) * (A.W + 1) * A.C;
 }
 
-// dense rows: the transposed convolutions (kernel == stride: a GEMM + pixel-shuffle store) and the head Linear of PointPillars
-int gemm_rows_bf16x3(const float* a, int64_t lda, int64_t M, int K, const void* packed, int N, const Epilogue& ep, float* C,
-                     int64_t ldc, hipStream_t st) {
-    if (!a || !packed || !C || N <= 0 || K <= 0 || M < 0 || ep.res_gather) return ML3D_E_INVALID;
-    if ((K % BF_KC) != 0 || (lda & 3) != 0 || (((uintptr_t)a) & 15) != 0) return ML3D_E_UNSUPPORTED;
+// split-K of the dense-row problems: with fewer 128-row tiles than workgroup slots (2 per CU) and a deep K, K is cut so that ~1.5
+// rounds of workgroups are in flight, at least 4 chunks per slice (KPConv's contractions at the coarse layers: M = 2 400 .. 35 000
+// rows, K = 15 Cin = 1 920 .. 7 680)
+static int bf3_splits(int64_t M, int N, int K) {
+    const int64_t tiles = ((M + G2_BM - 1) / G2_BM) * (N > 64 ? (N + 127) / 128 : 1);
+    const int64_t slots = 256 * (N > 64 ? 2 : 4);          // resident workgroups: LDS 49 KB / 37 KB, 174 / 116 registers
+    if (K < 512 || tiles >= 3 * slots) return 1;
+    if (tiles >= 512) {
+        // one to three rounds of workgroups: a last round that is mostly empty costs as much as a full one (1 101 tiles on 1 024
+        // slots = 2 rounds).  Cut K into s <= 4 slices where that shortens the schedule: cost = rounds(s) / s + the reduce pass
+        int best = 1;
+        double best_cost = (double)((tiles + slots - 1) / slots);
+        for (int c = 2; c <= 4 && c <= K / 128; ++c) {
+            const double cost = (double)((tiles * c + slots - 1) / slots) / c + 0.1;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
+        }
+        return best;
+    }
+    int64_t s = (768 + tiles - 1) / tiles;
+    if (s > K / 128) s = K / 128;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+}
+
+size_t gemm_partial_bytes_bf16x3(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = bf3_splits(M, N, K);
+    return s > 1 ? sizeof(float) * (size_t)s * (size_t)M * (size_t)N : 0;
+}
+
+// dense rows: Linears, KPConv's contraction over (kernel point, channel), the transposed convolutions of PointPillars
+// (kernel == stride: a GEMM + pixel-shuffle store)
+int gemm_rows_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2, int64_t M, const void* packed,
+                     int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws, size_t partial_bytes, hipStream_t st) {
+    const int K = k1 + k2;
+    if (!a || !packed || !C || N <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2) || M < 0) return ML3D_E_INVALID;
+    if (ep.res_gather || (K % BF_KC) != 0 || (k1 % BF_KC) != 0 || (lda & 3) != 0 || (((uintptr_t)a) & 15) != 0 ||
+        (k2 > 0 && ((lda2 & 3) != 0 || (((uintptr_t)a2) & 15) != 0)))
+        return ML3D_E_UNSUPPORTED;
     if (M == 0) return 0;
     RowsLoader2 L;
-    L.a = a; L.lda = lda; L.M = M; L.K = K;
+    L.a = a; L.lda = lda; L.a2 = k2 > 0 ? a2 : nullptr; L.lda2 = lda2; L.k1 = k1; L.M = M; L.K = K;
     const int Npad = bf3_npad(N);
+    int splits = bf3_splits(M, N, K);
+    if (splits > 1 && (!partial_ws || partial_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N)) splits = 1;
+    int kper = ((K + splits - 1) / splits + BF_KC - 1) / BF_KC * BF_KC;
+    splits = (K + kper - 1) / kper;
+    float* partial = splits > 1 ? (float*)partial_ws : nullptr;
     const unsigned gm = (unsigned)((M + G2_BM - 1) / G2_BM);
-    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128)), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc);
-    else hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 64>), dim3(gm, 1u), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc);
-    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128), (unsigned)splits), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc, kper, partial);
+    else hipLaunchKernelGGL((gemm_tile_bf3<RowsLoader2, 64>), dim3(gm, 1u, (unsigned)splits), dim3(256), 0, st, L, (const u32x4*)packed, N, Npad, ep, C, ldc, kper, partial);
+    if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    if (splits > 1) {
+        const int64_t total = M * N;
+        const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gemm_reduce, dim3(nb), dim3(256), 0, st, partial, splits, M, N, ep, C, ldc);
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+    }
+    return 0;
 }
 
 int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& ep, float* C, int64_t ldc, hipStream_t st) {
@@ -1045,8 +1110,8 @@ int gemm_conv_bf16x3(const ConvA& A, const void* packed, int N, const Epilogue& 
     if (L2.M <= 0) return 0;
     const int Npad = bf3_npad(N);
     const unsigned gm = (unsigned)((L2.M + G2_BM - 1) / G2_BM);
-    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128)), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc);
-    else hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 64>), dim3(gm, 1u), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc);
+    if (N > 64) hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 128>), dim3(gm, (unsigned)((N + 127) / 128)), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc, L2.K, (float*)nullptr);
+    else hipLaunchKernelGGL((gemm_tile_bf3<ConvLoader2, 64>), dim3(gm, 1u), dim3(256), 0, st, L2, (const u32x4*)packed, N, Npad, ep, C, ldc, L2.K, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

@@ -854,7 +854,8 @@ using namespace ml3d;
 extern "C" size_t ml3d_kpconv_workspace_bytes(int64_t n_queries, int cin, int cout, int num_kernel_points) {
     if (n_queries < 0 || cin <= 0 || cout <= 0 || num_kernel_points != KP_K) return 0;
     size_t b = kp_align(sizeof(float) * (size_t)(n_queries > 0 ? n_queries : 1) * KP_K * (size_t)cin);
-    b += kp_align(gemm_partial_bytes(n_queries, cout, KP_K * cin));
+    const size_t p32 = gemm_partial_bytes(n_queries, cout, KP_K * cin), pbf = gemm_partial_bytes_bf16x3(n_queries, cout, KP_K * cin);
+    b += kp_align(p32 > pbf ? p32 : pbf);
     return b + 512;
 }
 
@@ -862,7 +863,8 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
                       int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
                       const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
                       const float* offset_features, int offset_dim, const float* weights, const float* bias, int act,
-                      float slope, int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                      float slope, int cout, float* out, void* workspace, size_t workspace_bytes, void* stream,
+                      const void* packed = nullptr) {
     if (n_queries < 0 || n_supports < 0 || max_neighbors < 0 || cin <= 0 || cout <= 0 || !(kp_extent > 0.f) ||
         kp_influence_mode < 0 || kp_influence_mode > 2 || max_neighbors > 0x7fffffff)
         return ML3D_E_INVALID;
@@ -911,6 +913,11 @@ static int kpconv_run(const float* q_pts, const float* s_pts, const int32_t* nei
     A.a2 = nullptr; A.lda2 = 0; A.k2 = 0;
     A.gather_on_a2 = 0; A.g_rows_per_item = 0; A.g_src_rows_per_item = 0;
     Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
+    if (packed) {           // the contraction on the bf16 matrix pipe (gemm.h: three-way split of both operands); ineligible -> f32 below
+        const int rcb = gemm_rows_bf16x3(wf, (int64_t)KP_K * cin, KP_K * cin, nullptr, 0, 0, n_queries, packed, cout, ep, out, cout, p,
+                                         gemm_partial_bytes_bf16x3(n_queries, cout, KP_K * cin), st);
+        if (rcb != ML3D_E_UNSUPPORTED) return rcb;
+    }
     return gemm_rows(A, weights, n_queries, cout, KP_K * cin, ep, out, cout, p,
                      gemm_partial_bytes(n_queries, cout, KP_K * cin), st);
 }
@@ -1019,6 +1026,19 @@ extern "C" int ml3d_kpconv_rigid(const float* q_pts, const float* s_pts, const i
     return kpconv_run(q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, kernel_points,
                       num_kernel_points, kp_extent, kp_influence_mode, nullptr, 0, weights, bias, act, slope, cout, out,
                       workspace, workspace_bytes, stream);
+}
+
+// ml3d_kpconv_rigid with the [15 cin, cout] contraction on the bf16 matrix pipe: `packed` = ml3d_gemm_pack_bf16x3 of `weights`
+// (both are passed: the fused small-channel kernels and ineligible shapes keep the float matrix)
+extern "C" int ml3d_kpconv_rigid_bf16x3(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                        int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                        const float* kernel_points, int num_kernel_points, float kp_extent, int kp_influence_mode,
+                                        const float* weights, const void* packed, const float* bias, int act, float slope,
+                                        int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!packed) return ML3D_E_INVALID;
+    return kpconv_run(q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, kernel_points,
+                      num_kernel_points, kp_extent, kp_influence_mode, nullptr, 0, weights, bias, act, slope, cout, out,
+                      workspace, workspace_bytes, stream, packed);
 }
 
 extern "C" int ml3d_kpconv_deformable(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,

@@ -325,15 +325,22 @@ extern "C" int ml3d_deconv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, 
         out_pixel_stride < cout)
         return ML3D_E_INVALID;
     Epilogue ep = {bias, nullptr, 0, act, slope, stride, h, w, cout};
-    return gemm_rows_bf16x3(in, cin, batch * h * w, cin, packed, stride * stride * cout, ep, out, out_pixel_stride,
-                            (hipStream_t)stream);
+    return gemm_rows_bf16x3(in, cin, cin, nullptr, 0, 0, batch * h * w, packed, stride * stride * cout, ep, out, out_pixel_stride,
+                            nullptr, 0, (hipStream_t)stream);
 }
 
-extern "C" int ml3d_linear_bf16x3(const float* a, int64_t lda, int64_t rows, int k, const void* packed, const float* bias,
-                                  int n, int act, float slope, float* out, int64_t ldc, void* stream) {
-    if (rows < 0 || k <= 0 || n <= 0 || lda < k || ldc < n || !a || !packed || !out) return ML3D_E_INVALID;
-    Epilogue ep = {bias, nullptr, 0, act, slope, 0, 0, 0, 0};
-    return gemm_rows_bf16x3(a, lda, rows, k, packed, n, ep, out, ldc, (hipStream_t)stream);
+extern "C" size_t ml3d_linear_bf16x3_workspace_bytes(int64_t rows, int n, int k) { return gemm_partial_bytes_bf16x3(rows, n, k) + 512; }
+
+extern "C" int ml3d_linear_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2, int64_t rows,
+                                  const void* packed, const float* bias, const float* residual, int64_t ldr, int n, int act,
+                                  float slope, float* out, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows < 0 || k1 <= 0 || k2 < 0 || n <= 0 || lda < k1 || (k2 > 0 && (!a2 || lda2 < k2)) || ldc < n || !a || !packed || !out ||
+        act < 0 || act > 2 || (residual && ldr < n))
+        return ML3D_E_INVALID;
+    Epilogue ep = {bias, residual, ldr, act, slope, 0, 0, 0, 0};
+    char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
+    const size_t avail = workspace && workspace_bytes > 256 ? workspace_bytes - 256 : 0;
+    return gemm_rows_bf16x3(a, lda, k1, a2, lda2, k2, rows, packed, n, ep, out, ldc, p, avail, (hipStream_t)stream);
 }
 
 extern "C" int ml3d_nhwc_to_nchw(const float* in, int64_t in_pixel_stride, int channel_offset, int channels,

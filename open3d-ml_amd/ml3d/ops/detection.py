@@ -96,18 +96,25 @@ def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=Non
     return out
 
 
-def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0):
-    """act(a @ W + bias) on the bf16 matrix pipe, `packed` = pack_bf16x3(W [K, n]) (float32-equivalent: pack_bf16x3).  Returns None
-    when the problem is not eligible (K % 32, alignment): the caller keeps ops.linear."""
+def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0, a2=None, residual=None):
+    """act([a | a2] @ W + bias + residual) on the bf16 matrix pipe, `packed` = pack_bf16x3(W [K, n]) (float32-equivalent: pack_bf16x3).
+    Returns None when the problem is not eligible (block widths % 32, alignment): the caller keeps ops.linear."""
     lib = _abi.get()
-    _need_gpu(a, bias)
-    if a.dtype != torch.float32 or not a.is_contiguous():
-        raise RuntimeError("linear_bf16x3: float32 contiguous rows required")
-    m, k = a.shape
+    _need_gpu(a, bias, a2, residual)
+    for t in (a, a2, residual):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise RuntimeError("linear_bf16x3: float32 contiguous rows required")
+    m, k1 = a.shape
+    k2 = 0 if a2 is None else int(a2.shape[1])
+    if (k1 % 32) or (k2 % 32):
+        return None
     out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    wsb = int(lib.ml3d_linear_bf16x3_workspace_bytes(m, int(n), k1 + k2))
+    ws = _ws(wsb, a.device)
     with torch.cuda.device(a.device):
-        rc = lib.ml3d_linear_bf16x3(a.data_ptr(), k, m, k, packed.data_ptr(), None if bias is None else bias.data_ptr(), int(n),
-                                    int(act), float(slope), out.data_ptr(), int(n), _stream())
+        rc = lib.ml3d_linear_bf16x3(a.data_ptr(), k1, k1, None if a2 is None else a2.data_ptr(), k2, k2, m, packed.data_ptr(),
+                                    None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
+                                    int(n), int(n), int(act), float(slope), out.data_ptr(), int(n), ws.data_ptr(), wsb, _stream())
     if rc == _abi.E_UNSUPPORTED:
         return None
     _abi.check(rc, "ml3d_linear_bf16x3")

@@ -21,11 +21,12 @@ def _ws(nbytes, device):
     return _gates._ws(nbytes, device)
 
 def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias, extent, act=1, slope=0.1,
-                 influence=1, offset_features=None):
+                 influence=1, offset_features=None, packed=None):
     """KPConv rigid aggregation + folded BN + activation (kpconv.py:1048-1159, 1357-1358).
     weights_kc_o: [15 * cin, cout] (BN-folded), neighb_inds int32 [Nq, H] with shadow index Ns.
     ``offset_features`` [Nq, 45 | 60]: the DEFORMABLE convolution (kpconv.py:1011-1066) -- kernel point k of query q at
-    ``kernel_points[k] + offset_features[q, 3k:3k+3] * extent``, columns 45.. = modulation logits (see ``kpconv_deformable``)."""
+    ``kernel_points[k] + offset_features[q, 3k:3k+3] * extent``, columns 45.. = modulation logits (see ``kpconv_deformable``).
+    ``packed`` = ops.pack_bf16x3(weights_kc_o): the [15 cin, cout] contraction runs on the bf16 matrix pipe (float32-equivalent)."""
     lib = _abi.get()
     _need_gpu(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o)
     dev = x.device
@@ -58,6 +59,14 @@ def kpconv_rigid(q_pts, s_pts, neighb_inds, x, kernel_points, weights_kc_o, bias
                                             weights_kc_o.data_ptr(), None if bias is None else bias.data_ptr(), int(act),
                                             float(slope), cout, out.data_ptr(), ws.data_ptr(), wsb, _stream())
         _abi.check(rc, "ml3d_kpconv_deformable")
+        return out
+    if packed is not None:
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_kpconv_rigid_bf16x3(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, x.data_ptr(),
+                                              cin, kernel_points.data_ptr(), K, float(extent), int(influence),
+                                              weights_kc_o.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(),
+                                              int(act), float(slope), cout, out.data_ptr(), ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_kpconv_rigid_bf16x3")
         return out
     with torch.cuda.device(dev):
         rc = lib.ml3d_kpconv_rigid(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, x.data_ptr(),

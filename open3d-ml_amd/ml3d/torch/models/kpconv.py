@@ -277,6 +277,15 @@ class KPFCNN(nn.Module):
             d['ow'] = conv.offset_conv.weights.detach().float().reshape(conv.K * conv.in_channels, conv.offset_dim) \
                 .contiguous().to(dev)
             d['ob'] = conv.offset_bias.detach().float().contiguous().to(dev)
+        # the [15 cin, cout] contraction on the bf16 matrix pipe (ops.pack_bf16x3: exact three-way split, float32-equivalent);
+        # cin >= 64: narrower convolutions run in the fused kernels, which keep the float matrix.  ML3D_KP_GEMM=f32 (A/B knob)
+        # keeps the f32 MFMA kernel everywhere.  (The unary / shortcut Linears stay on gemm_tile: K = 96 .. 320 is three to ten chunks,
+        # the 128-row kernel has nothing to pipeline there -- measured, forward 5.50 ms with only the contractions on bf16x3, 5.53 with
+        # the dense Linears of the two finest levels as well, profiles/r05_kp_bf16x3_ab.log)
+        d['packed'] = None
+        if d['w'].is_cuda and conv.in_channels >= 64 and conv.in_channels % 32 == 0 and not conv.deformable and \
+                os.environ.get("ML3D_KP_GEMM", "bf16x3") != "f32":
+            d['packed'] = ops.pack_bf16x3(d['w'])
         return d
 
     def packed_params(self, dev):
@@ -351,7 +360,8 @@ class KPFCNN(nn.Module):
             inds = pools[L] if strided else nbrs[L]
             c = p['conv']
             if c['ow'] is None:
-                conv = lambda xin: ops.kpconv_rigid(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl)
+                conv = lambda xin: ops.kpconv_rigid(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], 1, lr, infl,
+                                                    packed=c['packed'])
             else:
                 def conv(xin, m=blk.KPConv):
                     # the reference sets min_d2 / deformed_KP in EVERY forward, eval included (kpconv.py:1058,1074): its

@@ -237,7 +237,8 @@ def subsample_batch(points, lengths, dl, features=None, labels=None):
     return op, lens, of, ol
 
 
-def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1, offset_features=None):
+def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1, offset_features=None,
+                 bf16x3=False):
     L = lib()
     q_pts, s_pts, x = (np.ascontiguousarray(a, np.float32) for a in (q_pts, s_pts, x))
     inds = np.ascontiguousarray(inds, np.int32)
@@ -255,6 +256,15 @@ def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, s
                                       x.ctypes.data, cin, kp.ctypes.data, K, extent, influence, off.ctypes.data,
                                       off.shape[1], w.ctypes.data, None if b is None else b.ctypes.data, act, slope, cout,
                                       out.ctypes.data, ws.ctypes.data, wsb, None)
+        return rc, out
+    if bf16x3:
+        rcp, packed = pack_bf16x3(w)
+        if rcp != 0:
+            return rcp, None
+        rc = L.ml3d_kpconv_rigid_bf16x3(q_pts.ctypes.data, s_pts.ctypes.data, inds.ctypes.data, nq, len(s_pts), H, x.ctypes.data,
+                                        cin, kp.ctypes.data, K, extent, influence, w.ctypes.data, packed.ctypes.data,
+                                        None if b is None else b.ctypes.data, act, slope, cout, out.ctypes.data, ws.ctypes.data, wsb,
+                                        None)
         return rc, out
     rc = L.ml3d_kpconv_rigid(q_pts.ctypes.data, s_pts.ctypes.data, inds.ctypes.data, nq, len(s_pts), H, x.ctypes.data,
                              cin, kp.ctypes.data, K, extent, influence, w.ctypes.data,
@@ -367,18 +377,24 @@ def conv2d_nhwc_bf16x3(x, w, bias, stride, pad, act=2, kh=3, kw=3, out=None, ch_
     return rc, out
 
 
-def linear_bf16x3(a, w, bias, act=0):
+def linear_bf16x3(a, w, bias, act=0, a2=None, residual=None):
     L = lib()
     a = np.ascontiguousarray(a, np.float32)
     rc, packed = pack_bf16x3(w)
     if rc != 0:
         return rc, None
-    m, k = a.shape
+    m, k1 = a.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    a2 = None if a2 is None else np.ascontiguousarray(a2, np.float32)
+    res = None if residual is None else np.ascontiguousarray(residual, np.float32)
     n = w.shape[1]
     out = np.zeros((m, n), np.float32)
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
-    rc = L.ml3d_linear_bf16x3(a.ctypes.data, k, m, k, packed.ctypes.data, None if b is None else b.ctypes.data, n, act, 0.0,
-                              out.ctypes.data, n, None)
+    wsb = L.ml3d_linear_bf16x3_workspace_bytes(m, n, k1 + k2)
+    ws = _ws(wsb)
+    rc = L.ml3d_linear_bf16x3(a.ctypes.data, k1, k1, None if a2 is None else a2.ctypes.data, k2, k2, m, packed.ctypes.data,
+                              None if b is None else b.ctypes.data, None if res is None else res.ctypes.data, n, n, act, 0.0,
+                              out.ctypes.data, n, ws.ctypes.data, wsb, None)
     return rc, out
 
 

@@ -243,3 +243,28 @@ def test_gather_pools_match_reference_ops():
     inds[7] = 500                                                    # a row of shadow indices only
     assert np.array_equal(emu.gather_pool(x, inds, 0), K.max_pool(torch.from_numpy(x), torch.from_numpy(inds).long()).numpy())
     assert np.array_equal(emu.gather_pool(x, inds, 1), K.closest_pool(torch.from_numpy(x), torch.from_numpy(inds).long()).numpy())
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 300), (128, 128, 130), (256, 64, 70), (64, 200, 140), (32, 32, 300)])
+def test_kpconv_rigid_contraction_on_the_bf16x3_path(cin, cout, n):
+    """ml3d_kpconv_rigid_bf16x3: the [15 cin, cout] contraction through gemm_tile_bf3 (three-way bf16 split), split along K where the
+    problem has few row tiles (K = 960 .. 3840 here: 2 .. 30 slices + gemm_reduce); cin = 32 stays in the fused kernel and must give
+    the float path's result bit for bit."""
+    rng = np.random.default_rng(cin * 1000 + cout + 1)
+    p, inds = _layer(21, n, 0.2)
+    x = rng.standard_normal((len(p), cin)).astype(np.float32)
+    kp = K.synthetic_kernel_points(0.2)
+    w = (rng.standard_normal((15, cin, cout)) * (1.0 / np.sqrt(cin * 4))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    rc, out = emu.kpconv_rigid(p, p, inds, x, kp, w, 0.08, bias=b, act=1, slope=0.2, bf16x3=True)
+    rc32, out32 = emu.kpconv_rigid(p, p, inds, x, kp, w, 0.08, bias=b, act=1, slope=0.2)
+    assert rc == 0 and rc32 == 0
+    ref = K.kpconv_rigid(torch.from_numpy(p), torch.from_numpy(p), torch.from_numpy(inds).long(), torch.from_numpy(x),
+                         torch.from_numpy(kp), torch.from_numpy(w), 0.08)
+    ref = torch.nn.functional.leaky_relu(ref + torch.from_numpy(b), 0.2).numpy()
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(out - ref).max() <= TOL * scale
+    if cin == 32:
+        assert np.array_equal(out, out32)
+    else:
+        assert np.abs(out - out32).max() <= 2e-5 * scale

@@ -250,6 +250,25 @@ def test_bf16x3_linear_matches_float64(m, k, n, act):
     buf = np.zeros(1 << 16, np.uint8)
     a2 = np.zeros((4, 64), np.float32)
     o2 = np.zeros((4, 8), np.float32)
-    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 66, 4, 64, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 8, None) == -4
-    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 64, 4, 48, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 8, None) == -4
-    assert L.ml3d_linear_bf16x3(a2.ctypes.data, 64, 4, 64, buf.ctypes.data, None, 8, 0, 0.0, o2.ctypes.data, 4, None) == -1
+    call = lambda lda, k1, ldc: L.ml3d_linear_bf16x3(a2.ctypes.data, lda, k1, None, 0, 0, 4, buf.ctypes.data, None, None, 0, 8, 0, 0.0,
+                                                     o2.ctypes.data, ldc, None, 0, None)
+    assert call(66, 64, 8) == -4 and call(64, 48, 8) == -4 and call(64, 64, 4) == -1
+
+
+@pytest.mark.parametrize("m,k1,k2,n,act,res", [(300, 64, 128, 256, 1, False), (129, 32, 64, 128, 2, True), (2000, 96, 0, 40, 0, True),
+                                               (40, 512, 512, 64, 1, False)])
+def test_bf16x3_linear_two_blocks_residual_split_k(m, k1, k2, n, act, res):
+    """[a | a2] . W + bias + residual: KPFCNN's "unary2 + shortcut" GEMM over concatenated inputs; the last case (40 rows, K = 1024) is
+    cut along K into 8 slices + gemm_reduce"""
+    rng = np.random.default_rng(m + k1 + n)
+    a = rng.standard_normal((m, k1)).astype(np.float32)
+    a2 = rng.standard_normal((m, k2)).astype(np.float32) if k2 else None
+    w = (rng.standard_normal((k1 + k2, n)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+    rc, out = emu.linear_bf16x3(a, w, b, act=act, a2=a2, residual=r)
+    assert rc == 0
+    x = a if a2 is None else np.concatenate([a, a2], 1)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b + (r if res else 0.0)
+    ref = {0: ref, 1: np.where(ref > 0, ref, 0.0), 2: np.maximum(ref, 0.0)}[act]
+    assert np.abs(out - ref).max() <= 2e-5

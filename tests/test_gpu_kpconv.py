@@ -346,3 +346,39 @@ def test_parislille3d_architecture_runs_natively_and_matches_the_oracle():
     ref = K.forward(sd, cfg, K.to_torch_batch(seg), torch.ones((len(pts), 1))).numpy()
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
     assert (out.cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.999
+
+
+def test_contractions_on_the_bf16x3_kernel_match_the_f32_kernel(monkeypatch):
+    """ML3D_KP_GEMM=f32 (every GEMM on the f32 MFMA kernels) against the default (the [15 cin, cout] contractions of the convolutions
+    with cin >= 64 on gemm_tile_bf3, split along K on the coarse levels): logits within 2e-5 of each other relative to their scale --
+    the two paths differ by float rounding only -- and the same labels.  Also the op alone at one coarse-level shape."""
+    from ml3d import ops
+    sd = K.make_state_dict(CFG, 7)
+    spheres = [synth_data.toronto3d_sphere(i, 6000) for i in range(4)]
+    batch = _gpu_batch(spheres, 3)
+    out = {}
+    for path in ("f32", "bf16x3"):
+        monkeypatch.setenv("ML3D_KP_GEMM", path)
+        m = _model(sd)
+        P = m.packed_params(m.device)
+        wide = [p['conv'] for p in P['enc'] if p['conv']['w'].shape[0] >= 15 * 64]
+        assert wide and all((c['packed'] is not None) == (path == "bf16x3") for c in wide)
+        assert all(p['conv']['packed'] is None for p in P['enc'] if p['conv']['w'].shape[0] < 15 * 64)
+        out[path] = m(batch).float()
+    scale = float(out["f32"].abs().max())
+    assert float((out["f32"] - out["bf16x3"]).abs().max()) <= 2e-5 * max(1.0, scale)
+    assert float((out["f32"].argmax(1) == out["bf16x3"].argmax(1)).float().mean()) >= 0.9999
+    # the op: 128 -> 128 channels on ~2 300 queries (K = 1 920: several K slices + gemm_reduce)
+    rng = np.random.default_rng(5)
+    s = synth_data.toronto3d_sphere(30, 9000)
+    q = K.batch_grid_subsampling(s, [len(s)], 0.08)[0].astype(np.float32)
+    inds = K.batch_neighbors(q, s, [len(q)], [len(s)], 0.12)
+    dev = torch.device("cuda:0")
+    tq, ts, ti = torch.from_numpy(q).to(dev), torch.from_numpy(s).to(dev), torch.from_numpy(inds).to(dev).int()
+    x = torch.from_numpy(rng.standard_normal((len(s), 128)).astype(np.float32)).to(dev)
+    kp = torch.from_numpy(K.synthetic_kernel_points(0.12)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((15 * 128, 128)) * 0.03).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal(128).astype(np.float32)).to(dev)
+    o32 = ops.kpconv_rigid(tq, ts, ti, x, kp, w, b, 0.06)
+    obf = ops.kpconv_rigid(tq, ts, ti, x, kp, w, b, 0.06, packed=ops.pack_bf16x3(w))
+    assert float((o32 - obf).abs().max()) <= 2e-5 * max(1.0, float(o32.abs().max()))
