@@ -45,6 +45,11 @@ __device__ __forceinline__ uint32_t bf16_pack2(float a, float b) {
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// x of the lanes whose bit is clear in `lanes` (= __ballot(ok), a scalar pair) becomes 0, IN PLACE: a conditional select the compiler
+// cannot turn into a copy of the register on the path that skips it
+__device__ __forceinline__ void keep_if(uint32_t& x, bool /* ok: the host emulator's form */, unsigned long long lanes) {
+    asm("v_cndmask_b32 %0, 0, %0, %1" : "+v"(x) : "s"(lanes));
+}
 // a - b as ONE v_sub_f32 (opaque to the SLP vectoriser, which would pair two of them into a v_pk_add_f32)
 __device__ __forceinline__ float sub_f32(float a, float b) {
     float d;

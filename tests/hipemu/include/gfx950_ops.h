@@ -22,6 +22,7 @@ static inline uint32_t bf16_pack2(float a, float b) {
     return one(a) | (one(b) << 16);
 }
 static inline float sub_f32(float a, float b) { return a - b; }
+static inline void keep_if(uint32_t& x, bool ok, unsigned long long) { if (!ok) x = 0u; }
 typedef float ml3d_f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t ml3d_u32x4 __attribute__((ext_vector_type(4)));
 static inline ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x16 c) { return hipemu_mfma_32x32x16_bf16(a, b, c); }

@@ -272,3 +272,28 @@ def test_bf16x3_linear_two_blocks_residual_split_k(m, k1, k2, n, act, res):
     ref = x.astype(np.float64) @ w.astype(np.float64) + b + (r if res else 0.0)
     ref = {0: ref, 1: np.where(ref > 0, ref, 0.0), 2: np.maximum(ref, 0.0)}[act]
     assert np.abs(out - ref).max() <= 2e-5
+
+
+def test_bf16x3_stride1_convolutions_through_both_kernels():
+    """3 x 3 / stride 1 / pad 1 takes conv3x3s1_bf3 (the input window staged once per 16-channel chunk, border taps read a zero pixel);
+    ML3D_CONV_WINDOW=0 (a test hook of the emulator build) sends the same problems through gemm_tile_bf3.  Shapes: image rows shorter
+    and longer than a 128-pixel tile, a tile spanning two images of the batch, one-pixel-wide and one-pixel-high maps, N in one and two
+    column tiles."""
+    code = r'''
+import numpy as np, torch, torch.nn.functional as F
+import emu
+rng = np.random.default_rng(1)
+for cin, cout, hw, nb in [(32, 64, (13, 11), 2), (64, 128, (3, 140), 1), (32, 200, (9, 16), 3), (64, 40, (1, 37), 2), (32, 64, (45, 1), 2),
+                          (96, 64, (16, 16), 1)]:
+    x = rng.standard_normal((nb, cin) + hw).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=1, padding=1))
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    rc, out = emu.conv2d_nhwc_bf16x3(x.transpose(0, 2, 3, 1), wk, b, 1, 1)
+    assert rc == 0
+    assert np.abs(out - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-5, (cin, cout, hw)
+print("OK")
+'''
+    for window in ("1", "0"):
+        _run_in_subprocess_with_big_gemm(code, ML3D_CONV_WINDOW=window)
