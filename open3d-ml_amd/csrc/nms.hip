@@ -38,59 +38,101 @@ __device__ __forceinline__ void box_corners(const float* b, P2* c) {
     }
 }
 
-// Sutherland-Hodgman: the convex quadrilateral A clipped by the four half-planes of B, then the shoelace area.  The vertex lists are
-// indexed dynamically (an edge appends 0, 1 or 2 vertices per input vertex), which as local arrays put them in SCRATCH (272 B per lane:
-// every vertex read / write a global-memory round trip).  They live in LDS instead: `sh` holds 2 lists x POLY_MAX vertices x 64 lanes,
-// lane-interleaved (vertex i of a lane at sh[i * 64 + lane]: lanes that touch the same i hit 64 different banks), a lane only ever
-// touches its own slots (no synchronisation), the two lists swap roles after an edge instead of being copied.  Arithmetic and its
-// order are unchanged (the oracle's).
+// Sutherland-Hodgman: the convex quadrilateral A clipped by the four half-planes of B, then the shoelace area.  An edge appends 0, 1 or
+// 2 vertices per input vertex, i.e. the output position is data dependent.  History: as local arrays the two vertex lists went to
+// SCRATCH (round 3: every vertex access a global-memory round trip); as lane-interleaved LDS lists (round 4-5) the kernel was fast
+// but its results were NOT stable under co-running kernels: with the bf16x3 convolutions of another stream on the same CUs (62.5 KB of
+// LDS per workgroup, two per CU) nmsb_mask returned different mask bits for lanes 48..63 in ~45 % of the launches, on identical inputs
+// (profiles/r05_nms_corun_diagnosis.md; quiet GPU, f32 convolutions, rocBLAS, fills as co-runners: never).  The lists therefore live
+// in REGISTERS now: every index is a compile-time constant after unrolling, the data-dependent append is a select per slot that can
+// be its target (vertex i of an edge can only land in slots 0 .. 2 i + 1).  Arithmetic and its order are unchanged (the oracle's).
 constexpr int POLY_MAX = 16;
-constexpr int POLY_LDS = 2 * POLY_MAX * 64;           // P2 elements per 64-lane wave
+struct PolyList { float x[POLY_MAX], y[POLY_MAX]; };
 
-__device__ float poly_intersection_area(const P2* A, const P2* B, P2* sh) {
-    const int lane = threadIdx.x & 63;
-    P2* cur = sh + lane;
-    P2* nxt = sh + POLY_MAX * 64 + lane;
+// L[at] = v for a data-dependent `at` < SLOTS
+template <int SLOTS>
+__device__ __forceinline__ void poly_put(PolyList& L, int at, P2 v) {
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const bool hit = q == at;
+        L.x[q] = hit ? v.x : L.x[q];
+        L.y[q] = hit ? v.y : L.y[q];
+    }
+}
+
+// one input vertex of one clipping edge: s = cur[I], t = its successor; appends to nxt at nn.  Returns false when the list would overflow.
+template <int I>
+__device__ __forceinline__ bool poly_clip_vertex(const PolyList& cur, int nc, PolyList& nxt, int& nn, P2 p0, P2 ed) {
+    // a vertex appends at most two; convex input never passes 8, but inf / NaN corners can alternate the sign test
+    // (4 -> 6 -> 9 -> 13 -> 19): such a pair has no meaningful overlap -- area 0 (the oracle's rule too)
+    if (nn + 2 > POLY_MAX) return false;
+    const P2 s = {cur.x[I], cur.y[I]};
+    constexpr int J = I + 1 < POLY_MAX ? I + 1 : 0;
+    const bool wrap = I + 1 == nc;
+    const P2 t = {wrap ? cur.x[0] : cur.x[J], wrap ? cur.y[0] : cur.y[J]};
+    const P2 vs = {__fsub_rn(s.x, p0.x), __fsub_rn(s.y, p0.y)}, vt = {__fsub_rn(t.x, p0.x), __fsub_rn(t.y, p0.y)};
+    const float ds = cross2(ed, vs), dt = cross2(ed, vt);
+    constexpr int SLOTS = 2 * I + 2 < POLY_MAX ? 2 * I + 2 : POLY_MAX;
+    if (ds >= 0.f) { poly_put<SLOTS>(nxt, nn, s); ++nn; }
+    if ((ds >= 0.f) != (dt >= 0.f)) {
+        const float u = __fdiv_rn(ds, __fsub_rn(ds, dt));
+        P2 ip;
+        ip.x = __fadd_rn(s.x, __fmul_rn(u, __fsub_rn(t.x, s.x)));
+        ip.y = __fadd_rn(s.y, __fmul_rn(u, __fsub_rn(t.y, s.y)));
+        poly_put<SLOTS>(nxt, nn, ip);
+        ++nn;
+    }
+    return true;
+}
+
+template <int I>
+__device__ __forceinline__ bool poly_clip_from(const PolyList& cur, int nc, PolyList& nxt, int& nn, P2 p0, P2 ed) {
+    if constexpr (I < POLY_MAX) {
+        if (I < nc) {
+            if (!poly_clip_vertex<I>(cur, nc, nxt, nn, p0, ed)) return false;
+            return poly_clip_from<I + 1>(cur, nc, nxt, nn, p0, ed);
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ float poly_intersection_area(const P2* A, const P2* B) {
+    PolyList cur, nxt;
+#pragma unroll
+    for (int i = 0; i < POLY_MAX; ++i) { cur.x[i] = i < 4 ? A[i].x : 0.f; cur.y[i] = i < 4 ? A[i].y : 0.f; nxt.x[i] = 0.f; nxt.y[i] = 0.f; }
     int nc = 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i * 64] = A[i];
-#pragma unroll
+#pragma unroll 1
     for (int e = 0; e < 4; ++e) {
         if (nc > 0) {
-            const P2 p0 = B[e], p1 = B[(e + 1) & 3];
+            // (selects, not B[e]: a dynamically indexed local array is promoted to LDS by the compiler)
+            const P2 p0 = e == 0 ? B[0] : e == 1 ? B[1] : e == 2 ? B[2] : B[3];
+            const P2 p1 = e == 0 ? B[1] : e == 1 ? B[2] : e == 2 ? B[3] : B[0];
             const P2 ed = {__fsub_rn(p1.x, p0.x), __fsub_rn(p1.y, p0.y)};
             int nn = 0;
-            for (int i = 0; i < nc; ++i) {
-                // a vertex appends at most two; convex input never passes 8, but inf / NaN corners can alternate the sign test
-                // (4 -> 6 -> 9 -> 13 -> 19): such a pair has no meaningful overlap -- area 0 (the oracle's rule too) instead of
-                // writing into the other list / the next lane's neighbours in LDS
-                if (nn + 2 > POLY_MAX) return 0.f;
-                const P2 s = cur[i * 64], t = cur[(i + 1 == nc ? 0 : i + 1) * 64];
-                const P2 vs = {__fsub_rn(s.x, p0.x), __fsub_rn(s.y, p0.y)}, vt = {__fsub_rn(t.x, p0.x), __fsub_rn(t.y, p0.y)};
-                const float ds = cross2(ed, vs), dt = cross2(ed, vt);
-                if (ds >= 0.f) nxt[64 * nn++] = s;
-                if ((ds >= 0.f) != (dt >= 0.f)) {
-                    const float u = __fdiv_rn(ds, __fsub_rn(ds, dt));
-                    P2 ip;
-                    ip.x = __fadd_rn(s.x, __fmul_rn(u, __fsub_rn(t.x, s.x)));
-                    ip.y = __fadd_rn(s.y, __fmul_rn(u, __fsub_rn(t.y, s.y)));
-                    nxt[64 * nn++] = ip;
-                }
-            }
+            if (!poly_clip_from<0>(cur, nc, nxt, nn, p0, ed)) return 0.f;
             nc = nn;
-            P2* sw = cur; cur = nxt; nxt = sw;
+#pragma unroll
+            for (int i = 0; i < POLY_MAX; ++i) { cur.x[i] = nxt.x[i]; cur.y[i] = nxt.y[i]; }
         }
     }
     if (nc < 3) return 0.f;
     float a = 0.f;
-    for (int i = 0; i < nc; ++i) a = __fadd_rn(a, cross2(cur[i * 64], cur[(i + 1 == nc ? 0 : i + 1) * 64]));
+#pragma unroll
+    for (int i = 0; i < POLY_MAX; ++i) {
+        if (i < nc) {
+            const int j = i + 1 < POLY_MAX ? i + 1 : 0;
+            const bool wrap = i + 1 == nc;
+            const P2 s = {cur.x[i], cur.y[i]}, t = {wrap ? cur.x[0] : cur.x[j], wrap ? cur.y[0] : cur.y[j]};
+            a = __fadd_rn(a, cross2(s, t));
+        }
+    }
     return __fmul_rn(0.5f, fabsf(a));
 }
 
-__device__ __forceinline__ float iou_bev(const float* a, const P2* ca, const float* b, P2* sh) {
+__device__ __forceinline__ float iou_bev(const float* a, const P2* ca, const float* b) {
     P2 cb[4];
     box_corners(b, cb);
-    const float ia = poly_intersection_area(ca, cb, sh);
+    const float ia = poly_intersection_area(ca, cb);
     const float aa = __fmul_rn(__fsub_rn(a[2], a[0]), __fsub_rn(a[3], a[1]));
     const float ab = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
     const float un = __fsub_rn(__fadd_rn(aa, ab), ia);
@@ -110,7 +152,6 @@ __device__ __forceinline__ void center_to_corner_form(float cx, float cy, float 
 
 __global__ void __launch_bounds__(64)
 iou_pairs(const float* __restrict__ A, const float* __restrict__ B, int64_t n, int64_t m, int mode3d, float* __restrict__ out) {
-    __shared__ P2 poly[POLY_LDS];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * m) return;
     const int64_t i = t / m, j = t - i * m;
@@ -127,7 +168,7 @@ iou_pairs(const float* __restrict__ A, const float* __restrict__ B, int64_t n, i
     P2 ca[4], cb[4];
     box_corners(a, ca);
     box_corners(b, cb);
-    const float inter = poly_intersection_area(ca, cb, poly);
+    const float inter = poly_intersection_area(ca, cb);
     const float aa = __fmul_rn(__fsub_rn(a[2], a[0]), __fsub_rn(a[3], a[1]));
     const float ab = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
     float num = inter, den;
@@ -160,7 +201,6 @@ nms_mask(const float* __restrict__ boxes, const uint32_t* __restrict__ order, in
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb) return;
     __shared__ float bb[64][5];
-    __shared__ P2 poly[POLY_LDS];
     const int t = threadIdx.x;
     const int64_t bj = (int64_t)cb * 64 + t;
     if (bj < n) {
@@ -178,7 +218,7 @@ nms_mask(const float* __restrict__ boxes, const uint32_t* __restrict__ order, in
     u64 bits = 0ull;
     const int cols = (int)((n - (int64_t)cb * 64) < 64 ? (n - (int64_t)cb * 64) : 64);
     for (int j = (rb == cb ? t + 1 : 0); j < cols; ++j)
-        if (iou_bev(ba, ca, bb[j], poly) > thr) bits |= 1ull << j;
+        if (iou_bev(ba, ca, bb[j]) > thr) bits |= 1ull << j;
     mask[a * words + cb] = bits;
 }
 
@@ -311,7 +351,6 @@ nmsb_order(const float* __restrict__ scores, int64_t n, float score_thr, uint32_
 __global__ void __launch_bounds__(64)
 nmsb_mask(const float* __restrict__ bev, const uint32_t* __restrict__ order, const int32_t* __restrict__ nvalid, int64_t n,
           int C, float thr, int words, u64* __restrict__ mask) {
-    __shared__ P2 poly[POLY_LDS];
     const int64_t p = blockIdx.z, a = blockIdx.y;
     const int cb = blockIdx.x, lane = threadIdx.x;
     const int64_t nv = nvalid[p];
@@ -334,7 +373,7 @@ nmsb_mask(const float* __restrict__ bev, const uint32_t* __restrict__ order, con
         if (!(dx * dx + dy * dy > reach * reach)) {        // (NaN / inf boxes take the full test, like ml3d_nms)
             P2 ca[4];
             box_corners(ba, ca);
-            sup = iou_bev(ba, ca, bj, poly) > thr;
+            sup = iou_bev(ba, ca, bj) > thr;
         }
     }
     const u64 bits = __ballot(sup);
@@ -605,7 +644,7 @@ extern "C" int ml3d_nms(const float* boxes, const float* scores, int64_t n, floa
     hipLaunchKernelGGL(nms_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, n, keys, order);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (sort_pairs_u64(keys, order, n, 64, sw, st)) return ML3D_E_LAUNCH;
-    (void)hipMemsetAsync(mask, 0, sizeof(u64) * (size_t)(n * words), st);
+    zero_async(mask, sizeof(u64) * (size_t)(n * words), st);
     hipLaunchKernelGGL(nms_mask, dim3((unsigned)words, (unsigned)words), dim3(64), 0, st, boxes, order, n, iou_threshold,
                        words, mask);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
@@ -643,7 +682,7 @@ extern "C" int ml3d_topk_rows(const float* values, int64_t rows, int64_t n, int6
     int* counters = tables + (size_t)rows * 3 * TOPK_BINS;
     p += nms_align(4 * (size_t)rows * (3 * TOPK_BINS + 2));
     u64* sel = (u64*)p;
-    if (hipMemsetAsync(tables, 0, 4 * (size_t)rows * (3 * TOPK_BINS + 2), st) != hipSuccess) return ML3D_E_LAUNCH;
+    zero_async(tables, 4 * (size_t)rows * (3 * TOPK_BINS + 2), st);        // (a fill kernel, not hipMemsetAsync: grid.h)
     const dim3 grid((unsigned)((n + TOPK_CHUNK - 1) / TOPK_CHUNK), (unsigned)rows);
     for (int level = 0; level < 3; ++level)
         hipLaunchKernelGGL(ml3d::topk_hist, grid, dim3(256), 0, st, values, n, (int)k, level, tables);

@@ -209,7 +209,7 @@ extern "C" int ml3d_pillar_features(const float* points, int64_t point_stride, i
     if (in_channels > 8 || max_num_points > PF_MAXP || num_layers > 4) return ML3D_E_UNSUPPORTED;
     if (units_host[num_layers - 1] != canvas_channels) return ML3D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(canvas, 0, sizeof(float) * (size_t)batch * ny * nx * canvas_channels, st);
+    zero_async(canvas, sizeof(float) * (size_t)batch * ny * nx * canvas_channels, st);        // (a fill kernel, not hipMemsetAsync: grid.h)
     if (n_pillars == 0) return 0;
     if (!points || !voxel_coords || !point_indices || !point_row_splits || !batch_splits) return ML3D_E_INVALID;
     if (workspace_bytes < ml3d_pillar_features_workspace_bytes(n_pillars, max_num_points, num_layers, units_host))
