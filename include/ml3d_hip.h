@@ -47,7 +47,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 9
+#define ML3D_ABI_VERSION 10
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -785,6 +785,70 @@ int ml3d_randla_forward_ordered(const ml3d_randla_desc* desc_host, const float* 
                                 const int32_t* const* tile_order_host, float* out_scores,
                                 void* workspace, size_t workspace_bytes, void* stream,
                                 const ml3d_trace* trace_host);
+
+/* ------------------------------------------------------------------------------------------------------------------------------ */
+/* Training side on hand-written HIP, forward AND backward (ABI 10; open3d-ml_amd/csrc/train.hip).  What the       */
+/* reference leaves to torch.autograd around loss.backward() (ml3d/torch/pipelines/semantic_segmentation.py:412-437) for the      */
+/* modules of the two segmentation models: every Linear / 1x1 convolution (SharedMLP randlanet.py:503-518, UnaryBlock             */
+/* kpconv.py:1288-1293), BatchNorm on the batch statistics (+ LeakyReLU), the index gathers / pools and the attentive pooling     */
+/* stage.  ml3d.ops.{LinearFunction, BatchNormActFunction, GatherRowsFunction, GatherPoolFunction, AttentionStageFunction} bind   */
+/* them into autograd graphs; outputs are caller-owned, reductions across workgroups are float atomics.                           */
+/* ------------------------------------------------------------------------------------------------------------------------------ */
+/* ml3d_gemm_tn: c[i, j] = sum_r a[r, i] * b[r, j]  (a [m, lda] k columns, b [m, ldb] n columns, c [k, ldc]; c is zeroed here).    */
+/*   Weight gradient of y = x W^T: grad_W [out, in] = gemm_tn(a = grad_y, b = x); of KPConv's contraction: grad_W [15 cin, cout]  */
+/*   = gemm_tn(a = wf, b = grad_out) (kpconv.py:1139-1159).  col_sums_a (optional, [k]) <- sum_r a[r, :] (the bias gradient).     */
+int ml3d_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int k, int n,
+                 float* c, int64_t ldc, float* col_sums_a, void* stream);
+
+/* ml3d_batchnorm_train_forward: y = act(gamma * (x - mean) * invstd + beta) with mean / biased variance of THIS batch over the    */
+/*   rows of x [rows, channels] (torch.nn.functional.batch_norm(training=True); BatchNorm2d over [B, C, N, K] = rows B*N*K).       */
+/*   act: 0 none, 1 LeakyReLU(slope).  save_mean / save_var (biased) / save_invstd [channels] are returned for the backward and    */
+/*   for the caller's running-statistics update.  gamma / beta may be NULL (1 / 0).                                                */
+/* ml3d_batchnorm_train_backward: grad_x, grad_gamma, grad_beta from (x, y, grad_y, saved statistics).                             */
+size_t ml3d_batchnorm_train_workspace_bytes(int channels);
+
+int ml3d_batchnorm_train_forward(const float* x, int64_t rows, int channels, const float* gamma,
+                                 const float* beta, float eps, int act, float slope, float* y,
+                                 float* save_mean, float* save_var, float* save_invstd,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+int ml3d_batchnorm_train_backward(const float* x, const float* y, const float* grad_y, int64_t rows,
+                                  int channels, const float* gamma, const float* save_mean,
+                                  const float* save_invstd, int act, float slope, float* grad_x,
+                                  float* grad_gamma, float* grad_beta, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
+/* ml3d_gather_rows: out[r, :] = x[index[r * index_stride], :] (rows outside [0, n_src) read zeros: the shadow neighbour);         */
+/*   nearest_interpolation (randlanet.py:329-350), closest_pool (kpconv.py:821-838).  ml3d_scatter_add_rows is its adjoint         */
+/*   (grad_x [n_src, channels] zeroed here).  ml3d_gather_pool_backward: adjoint of ml3d_gather_pool (mode 0 max_pool: the        */
+/*   gradient goes to the first maximal neighbour in list order, dropped when that is the shadow row; mode 1 closest_pool).        */
+int ml3d_gather_rows(const float* x, int64_t n_src, int channels, const int32_t* index,
+                     int64_t index_stride, int64_t m, float* out, void* stream);
+
+int ml3d_scatter_add_rows(const float* grad_out, int64_t n_src, int channels, const int32_t* index,
+                          int64_t index_stride, int64_t m, float* grad_x, void* stream);
+
+int ml3d_gather_pool_backward(const float* features, int64_t n_supports, int channels,
+                              const int32_t* inds, int64_t n_queries, int64_t max_neighbors, int mode,
+                              const float* grad_out, float* grad_features, void* stream);
+
+/* ml3d_randla_attention_stage: one attentive pooling of LocalFeatureAggregation in training form, fused (randlanet.py:596-605,     */
+/*   617, 631-637): x[p, k, :] = [ f[b, idx[p, k], :c1] | enc[p, k, :c2] ], s = x W^T + bias, out[p, c] = sum_k softmax_k(s)[k, c]   */
+/*   x[p, k, c].  f [batch, n, c1], enc [batch, n, k, c2], neighbor_idx int32 [batch, n, k] (item-local), weight [d, d] (the         */
+/*   Linear's [out, in]) and weight_t its transpose, d = c1 + c2; out [batch, n, d].  k must be 16, d even and <= 256               */
+/*   (ML3D_E_UNSUPPORTED otherwise: the caller keeps the unfused ops).  The backward recomputes x, s and the softmax and returns    */
+/*   grad_f [batch, n, c1], grad_enc [batch, n, k, c2], grad_weight [d, d], grad_bias [d] (all zeroed here, accumulated with        */
+/*   atomics): no [batch, n, k, d] tensor exists in either pass.                                                                     */
+int ml3d_randla_attention_stage(const float* f, const float* enc, const int32_t* neighbor_idx,
+                                const float* weight_t, const float* bias, int64_t batch, int64_t n,
+                                int k, int c1, int c2, float* out, void* stream);
+
+int ml3d_randla_attention_stage_backward(const float* f, const float* enc, const int32_t* neighbor_idx,
+                                         const float* weight, const float* weight_t, const float* bias,
+                                         const float* out, const float* grad_out, int64_t batch,
+                                         int64_t n, int k, int c1, int c2, float* grad_f,
+                                         float* grad_enc, float* grad_weight, float* grad_bias,
+                                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 9          # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 10         # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -84,6 +84,10 @@ SYMBOLS = [
     "ml3d_randla_knn_pyramid_traced",
     "ml3d_randla_knn_pyramid_ordered",
     "ml3d_randla_forward_ordered",
+    "ml3d_gemm_tn",
+    "ml3d_batchnorm_train_workspace_bytes", "ml3d_batchnorm_train_forward", "ml3d_batchnorm_train_backward",
+    "ml3d_gather_rows", "ml3d_scatter_add_rows", "ml3d_gather_pool_backward",
+    "ml3d_randla_attention_stage", "ml3d_randla_attention_stage_backward",
 ]
 
 
@@ -234,6 +238,24 @@ def bind(lib):
     lib.ml3d_randla_attentive_pool.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     lib.ml3d_randla_attentive_pool_backward.restype = C.c_int
     lib.ml3d_randla_attentive_pool_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    lib.ml3d_gemm_tn.restype = C.c_int
+    lib.ml3d_gemm_tn.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp, vp]
+    lib.ml3d_batchnorm_train_workspace_bytes.restype = sz
+    lib.ml3d_batchnorm_train_workspace_bytes.argtypes = [i32]
+    lib.ml3d_batchnorm_train_forward.restype = C.c_int
+    lib.ml3d_batchnorm_train_forward.argtypes = [vp, i64, i32, vp, vp, f32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_batchnorm_train_backward.restype = C.c_int
+    lib.ml3d_batchnorm_train_backward.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, i32, f32, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_gather_rows.restype = C.c_int
+    lib.ml3d_gather_rows.argtypes = [vp, i64, i32, vp, i64, i64, vp, vp]
+    lib.ml3d_scatter_add_rows.restype = C.c_int
+    lib.ml3d_scatter_add_rows.argtypes = [vp, i64, i32, vp, i64, i64, vp, vp]
+    lib.ml3d_gather_pool_backward.restype = C.c_int
+    lib.ml3d_gather_pool_backward.argtypes = [vp, i64, i32, vp, i64, i64, i32, vp, vp, vp]
+    lib.ml3d_randla_attention_stage.restype = C.c_int
+    lib.ml3d_randla_attention_stage.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp]
+    lib.ml3d_randla_attention_stage_backward.restype = C.c_int
+    lib.ml3d_randla_attention_stage_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_argmax_labels.restype = C.c_int

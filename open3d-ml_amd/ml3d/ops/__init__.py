@@ -18,3 +18,5 @@ from .kpconv import (kpconv_rigid, kpconv_deformable, linear, gather_pool, kpcon
 from .detection import (pillar_features, conv2d_nhwc, pack_bf16x3, linear_bf16x3, deconv2d_nhwc, nhwc_to_nchw, nms, pointpillars_boxes,   # noqa: F401
                         iou_bev, iou_3d, topk_rows)
 from .sampler import nearest_to_center, argmax_labels, vote_update, device_patch   # noqa: F401
+from .train import (gemm_tn, LinearFunction, BatchNormActFunction, batch_norm_act, GatherRowsFunction, GatherPoolFunction,   # noqa: F401
+                    AttentionStageFunction, attention_stage_supported)

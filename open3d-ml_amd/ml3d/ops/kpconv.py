@@ -181,7 +181,7 @@ def kpconv_weighted_backward(q_pts, s_pts, neighb_inds, grad_wf, cin, kernel_poi
 class KPConvFunction(torch.autograd.Function):
     """``KPConv.forward`` of the rigid branch (kpconv.py:1005-1159, no bias / norm / activation: those are the caller's modules in
     training) with hand-written forward AND backward: forward = HIP aggregation + ``wf @ W``; backward: ``dW = wf^T @ g``,
-    ``dwf = g @ W^T`` (library GEMMs) and the HIP scatter ``ml3d_kpconv_weighted_backward`` for the features.  Geometry (points,
+    ``dwf = g @ W^T`` (this library's MFMA GEMMs: ``ml3d_gemm_tn`` / ``ml3d_linear``) and the HIP scatter ``ml3d_kpconv_weighted_backward`` for the features.  Geometry (points,
     neighbour lists, kernel points) gets no gradient -- the reference does not train it either (kpconv.py:959-963)."""
 
     @staticmethod
@@ -191,7 +191,7 @@ class KPConvFunction(torch.autograd.Function):
         wf = kpconv_weighted(q_pts, s_pts, neighb_inds, x, kernel_points, extent, influence)
         ctx.save_for_backward(wf, weights, q_pts, s_pts, neighb_inds, kernel_points)
         ctx.geom = (float(extent), int(influence), int(cin))
-        return wf @ weights.reshape(K * cin, cout)
+        return linear(wf, weights.reshape(K * cin, cout).contiguous())
 
     @staticmethod
     def backward(ctx, g):
@@ -201,8 +201,9 @@ class KPConvFunction(torch.autograd.Function):
         g = g.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            dw = (wf.t() @ g).reshape(K, cin, cout)
+            from .train import gemm_tn
+            dw = gemm_tn(wf, g).reshape(K, cin, cout)
         if ctx.needs_input_grad[0]:
-            dwf = (g @ weights.reshape(K * cin, cout).t()).contiguous()
+            dwf = linear(g, weights.reshape(K * cin, cout).t().contiguous())
             dx = kpconv_weighted_backward(q_pts, s_pts, neighb_inds, dwf, cin, kernel_points, extent, influence)
         return dx, dw, None, None, None, None, None, None

@@ -1,0 +1,252 @@
+"""The training side of the segmentation models on hand-written HIP, forward AND backward (csrc/train.hip).
+
+What the reference leaves to ``torch.autograd`` around ``loss.backward()`` (ml3d/torch/pipelines/semantic_segmentation.py:412-437):
+every Linear / 1x1 convolution, BatchNorm on the batch statistics (+ LeakyReLU), the index gathers / pools, and the attentive
+pooling stage of RandLA-Net.  Each class below is a ``torch.autograd.Function`` whose two passes are C-ABI calls into
+``libml3d_hip.so``; torch carries the graph, the optimiser and the loss, nothing else."""
+import torch
+
+from .. import _abi
+from . import _gates
+from .kpconv import linear
+
+
+def _stream():
+    return _gates._stream()
+
+
+def _need_gpu(*tensors):
+    return _gates._need_gpu(*tensors)
+
+
+def _f32(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def gemm_tn(a, b, with_col_sums=False):
+    """``a^T b`` over the rows: a [m, k], b [m, n] -> [k, n] (+ the column sums of a, [k]) on ``ml3d_gemm_tn``."""
+    lib = _abi.get()
+    _need_gpu(a, b)
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape
+    n = b.shape[1]
+    if b.shape[0] != m:
+        raise RuntimeError("gemm_tn: a and b must share their rows")
+    c = torch.empty((k, n), dtype=torch.float32, device=a.device)
+    sums = torch.empty(k, dtype=torch.float32, device=a.device) if with_col_sums else None
+    with torch.cuda.device(a.device):
+        rc = lib.ml3d_gemm_tn(a.data_ptr(), k, b.data_ptr(), n, m, k, n, c.data_ptr(), n,
+                              None if sums is None else sums.data_ptr(), _stream())
+    _abi.check(rc, "ml3d_gemm_tn")
+    return (c, sums) if with_col_sums else c
+
+
+class LinearFunction(torch.autograd.Function):
+    """``y = x W^T (+ bias)`` for x [..., in], W [out, in] (``nn.Linear``'s layout; a 1x1 ``Conv2d`` weight ``[out, in, 1, 1]``
+    viewed as such): forward on ``ml3d_linear`` (f32 MFMA), backward ``grad_x = grad_y W`` on ``ml3d_linear`` and
+    ``grad_W = grad_y^T x``, ``grad_bias = sum grad_y`` on ``ml3d_gemm_tn``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight, bias)
+        x2 = _f32(x.reshape(-1, x.shape[-1]))
+        w = _f32(weight)
+        y = linear(x2, w.t().contiguous(), None if bias is None else _f32(bias))
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.lead = tuple(x.shape[:-1])
+        return y.reshape(ctx.lead + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        g2 = _f32(gy.reshape(-1, w.shape[0]))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(g2, w, None).reshape(ctx.lead + (w.shape[1],))
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.has_bias:
+                gw, gb = gemm_tn(g2, x2, with_col_sums=True)
+            else:
+                gw = gemm_tn(g2, x2)
+        return gx, gw, gb
+
+
+class BatchNormActFunction(torch.autograd.Function):
+    """Training-mode batch normalisation over the rows of x [..., C] (``F.batch_norm(..., training=True)``: statistics of THIS
+    batch, biased variance) fused with LeakyReLU(``slope``) when ``slope`` is not None: ``ml3d_batchnorm_train_forward /
+    _backward``.  ``running_mean / running_var`` are updated in place like torch does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        lib = _abi.get()
+        _need_gpu(x, gamma, beta)
+        c = x.shape[-1]
+        x2 = _f32(x.reshape(-1, c))
+        rows = x2.shape[0]
+        if rows < 2:
+            raise ValueError("BatchNormActFunction: expected more than 1 row per channel when training")
+        g = None if gamma is None else _f32(gamma)
+        b = None if beta is None else _f32(beta)
+        dev = x2.device
+        y = torch.empty_like(x2)
+        mean, var, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+        wsb = lib.ml3d_batchnorm_train_workspace_bytes(c)
+        ws = _gates._ws(wsb, dev)
+        act = 0 if slope is None else 1
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_batchnorm_train_forward(x2.data_ptr(), rows, c, None if g is None else g.data_ptr(),
+                                                  None if b is None else b.data_ptr(), float(eps), act, float(slope or 0.0),
+                                                  y.data_ptr(), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(), ws.data_ptr(), wsb,
+                                                  _stream())
+        _abi.check(rc, "ml3d_batchnorm_train_forward")
+        if running_mean is not None and running_var is not None:
+            with torch.no_grad():
+                mom = 0.1 if momentum is None else float(momentum)
+                running_mean.mul_(1.0 - mom).add_(mean.to(running_mean.dtype), alpha=mom)
+                running_var.mul_(1.0 - mom).add_(var.to(running_var.dtype), alpha=mom * rows / (rows - 1))
+        ctx.save_for_backward(x2, y, g if g is not None else mean.new_empty(0), mean, invstd)
+        ctx.has_gamma, ctx.has_beta = gamma is not None, beta is not None
+        ctx.act, ctx.slope, ctx.shape = act, float(slope or 0.0), tuple(x.shape)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _abi.get()
+        x2, y, g, mean, invstd = ctx.saved_tensors
+        rows, c = x2.shape
+        g2 = _f32(gy.reshape(rows, c))
+        dev = x2.device
+        gx = torch.empty_like(x2)
+        gg, gb = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(2))
+        wsb = lib.ml3d_batchnorm_train_workspace_bytes(c)
+        ws = _gates._ws(wsb, dev)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_batchnorm_train_backward(x2.data_ptr(), y.data_ptr(), g2.data_ptr(), rows, c,
+                                                   g.data_ptr() if ctx.has_gamma else None, mean.data_ptr(), invstd.data_ptr(), ctx.act,
+                                                   ctx.slope, gx.data_ptr(), gg.data_ptr(), gb.data_ptr(), ws.data_ptr(), wsb, _stream())
+        _abi.check(rc, "ml3d_batchnorm_train_backward")
+        return (gx.reshape(ctx.shape), gg if ctx.has_gamma else None, gb if ctx.has_beta else None, None, None, None, None, None)
+
+
+def batch_norm_act(x, bn, slope=None):
+    """``bn`` (an ``nn.BatchNorm1d / 2d`` in training mode) over the rows of the point-major x [..., C] + LeakyReLU(slope)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                      bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, slope)
+
+
+class GatherRowsFunction(torch.autograd.Function):
+    """``x[index]`` for x [n, C] and an int32 row index [m] (a row outside [0, n) reads zeros: the shadow neighbour of
+    kpconv.py:809-811) with the scatter-add adjoint: nearest_interpolation (randlanet.py:329-350), closest_pool
+    (kpconv.py:821-838)."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        lib = _abi.get()
+        _need_gpu(x, index)
+        x = _f32(x)
+        if index.dtype != torch.int32 or index.dim() != 1 or not index.is_contiguous():
+            raise RuntimeError("GatherRowsFunction: index must be a contiguous int32 vector")
+        n, c = x.shape
+        m = index.shape[0]
+        out = torch.empty((m, c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_gather_rows(x.data_ptr(), n, c, index.data_ptr(), 1, m, out.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_gather_rows")
+        ctx.save_for_backward(index)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        index, = ctx.saved_tensors
+        g = _f32(g)
+        m, c = g.shape
+        gx = torch.empty((ctx.n, c), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.ml3d_scatter_add_rows(g.data_ptr(), ctx.n, c, index.data_ptr(), 1, m, gx.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_scatter_add_rows")
+        return gx, None
+
+
+class GatherPoolFunction(torch.autograd.Function):
+    """``max_pool`` / ``closest_pool`` of KPConv's blocks (kpconv.py:821-858) on ``ml3d_gather_pool`` with the hand-written
+    adjoint ``ml3d_gather_pool_backward`` (max: first maximal neighbour in list order; shadow rows count as zeros and take no
+    gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, inds, mode):
+        from .kpconv import gather_pool
+        x = _f32(x)
+        out = gather_pool(x, inds, mode)
+        ctx.save_for_backward(x, inds)
+        ctx.mode = 0 if mode == "max" else 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        x, inds = ctx.saved_tensors
+        g = _f32(g)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_gather_pool_backward(x.data_ptr(), x.shape[0], x.shape[1], inds.data_ptr(), inds.shape[0], inds.shape[1],
+                                               ctx.mode, g.data_ptr(), gx.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_gather_pool_backward")
+        return gx, None, None
+
+
+def attention_stage_supported(k, c1, c2):
+    d = c1 + c2
+    return k == 16 and d <= 256 and d % 2 == 0
+
+
+class AttentionStageFunction(torch.autograd.Function):
+    """One attentive pooling of ``LocalFeatureAggregation`` in training form as ONE kernel per pass (randlanet.py:596-605, 617,
+    631-637): ``f`` [B, N, c1] per-point features, ``enc`` [B, N, K, c2] encoded relative positions, ``idx`` int32 [B, N, K],
+    the score Linear's ``weight`` [d, d] / ``bias`` [d] (d = c1 + c2) -> ``sum_k softmax_k(x W^T + b) * x`` [B, N, d] with
+    ``x = [f[idx] | enc]``.  Neither pass materialises a [B, N, K, d] tensor; the backward recomputes the softmax."""
+
+    @staticmethod
+    def forward(ctx, f, enc, idx, weight, bias):
+        lib = _abi.get()
+        _need_gpu(f, enc, idx, weight, bias)
+        f, enc, w = _f32(f), _f32(enc), _f32(weight)
+        b = None if bias is None else _f32(bias)
+        B, n, c1 = f.shape
+        K, c2 = enc.shape[2], enc.shape[3]
+        if idx.dtype != torch.int32 or not idx.is_contiguous() or tuple(idx.shape) != (B, n, K) or tuple(enc.shape[:2]) != (B, n):
+            raise RuntimeError("AttentionStageFunction: idx must be a contiguous int32 [B, N, K] tensor matching enc [B, N, K, c2]")
+        d = c1 + c2
+        if tuple(w.shape) != (d, d):
+            raise RuntimeError("AttentionStageFunction: weight must be [%d, %d]" % (d, d))
+        wt = w.t().contiguous()
+        out = torch.empty((B, n, d), dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            rc = lib.ml3d_randla_attention_stage(f.data_ptr(), enc.data_ptr(), idx.data_ptr(), wt.data_ptr(),
+                                                 None if b is None else b.data_ptr(), B, n, K, c1, c2, out.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_attention_stage")
+        ctx.save_for_backward(f, enc, idx, w, wt, b if b is not None else w.new_empty(0), out)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        f, enc, idx, w, wt, b, out = ctx.saved_tensors
+        B, n, c1 = f.shape
+        K, c2 = enc.shape[2], enc.shape[3]
+        d = c1 + c2
+        g = _f32(g)
+        gf, genc, gw = torch.empty_like(f), torch.empty_like(enc), torch.empty_like(w)
+        gb = torch.empty(d, dtype=torch.float32, device=f.device) if ctx.has_bias else None
+        with torch.cuda.device(f.device):
+            rc = lib.ml3d_randla_attention_stage_backward(f.data_ptr(), enc.data_ptr(), idx.data_ptr(), w.data_ptr(), wt.data_ptr(),
+                                                          b.data_ptr() if ctx.has_bias else None, out.data_ptr(), g.data_ptr(), B, n, K,
+                                                          c1, c2, gf.data_ptr(), genc.data_ptr(), gw.data_ptr(),
+                                                          None if gb is None else gb.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_randla_attention_stage_backward")
+        return gf, genc, None, gw, gb

@@ -410,10 +410,12 @@ class KPFCNN(nn.Module):
     # ---- training forward: rigid architectures, differentiable ------------------------------------
     def _forward_train(self, batch):
         """``KPFCNN.forward`` in TRAINING mode (kpconv.py:270-291 with the blocks of :1343-1461): every KPConv is
-        ``ops.KPConvFunction`` -- HIP aggregation forward, hand-written HIP scatter backward, GEMMs for the weight products --
-        around it the reference's own module arithmetic on torch's autograd: BatchNorm1d on the batch statistics (NOT folded:
-        the inference kernels fold the running statistics, which training must update), LeakyReLU, bias-free Linears, the
-        max / closest pools as indexed gathers.  DEFORMABLE blocks (kpconv.py:1011-1159): the inner rigid convolution that
+        ``ops.KPConvFunction`` -- HIP aggregation forward, hand-written HIP scatter backward, the weight products on the
+        library's MFMA GEMMs both ways -- and around it (``ML3D_TRAIN_OPS=hip``, the default; csrc/train.hip) hand-written HIP in
+        both passes as well: bias-free Linears as ``ops.LinearFunction``, BatchNorm1d on the batch statistics (NOT folded: the
+        inference kernels fold the running statistics, which training must update) + LeakyReLU as ``ops.BatchNormActFunction``,
+        the max / closest pools as ``ops.GatherPoolFunction``; torch carries the graph, the concatenations and the residual
+        add.  ``ML3D_TRAIN_OPS=torch`` keeps those modules on torch's autograd (rounds 3-4, the A/B side).  DEFORMABLE blocks (kpconv.py:1011-1159): the inner rigid convolution that
         produces the offsets is ``ops.KPConvFunction`` too; the deformed convolution itself -- whose influences depend on the
         trained offsets -- is written out in torch ([Nq, H, K] squared distances, linear influences, one matmul per block) so
         that autograd carries the gradient into the offsets; the block keeps ``min_d2`` / ``deformed_KP`` for the regulariser
@@ -428,12 +430,17 @@ class KPFCNN(nn.Module):
         idx = lambda lst: [t.to(dev).to(torch.int32).contiguous() for t in lst]
         nbrs, pools, ups = idx(batch.neighbors), idx(batch.pools), idx(batch.upsamples)
 
-        def bn(blk, x):             # BatchNormBlock.forward (kpconv.py:1238-1249): per-channel statistics over the N rows
-            return blk.batch_norm(x) if blk.use_bn else x + blk.bias
+        hip = os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch"
+
+        def bn_act(blk, x, slope):  # BatchNormBlock.forward (kpconv.py:1238-1249: per-channel statistics over the N rows) + LeakyReLU
+            if blk.use_bn and hip:
+                return ops.batch_norm_act(x, blk.batch_norm, slope)
+            x = blk.batch_norm(x) if blk.use_bn else x + blk.bias
+            return x if slope is None else F.leaky_relu(x, slope)
 
         def unary(ub, x):           # UnaryBlock.forward (kpconv.py:1288-1293)
-            x = bn(ub.batch_norm, ub.mlp(x))
-            return x if ub.no_relu else F.leaky_relu(x, ub.l_relu)
+            y = ops.LinearFunction.apply(x, ub.mlp.weight, None) if hip else ub.mlp(x)
+            return bn_act(ub.batch_norm, y, None if ub.no_relu else ub.l_relu)
 
         def padded(x):              # the shadow neighbour's zero feature row (kpconv.py:809-811, 848-850)
             return torch.cat([x, torch.zeros_like(x[:1])], 0)
@@ -456,12 +463,17 @@ class KPFCNN(nn.Module):
                 kp_apply = lambda xin, conv=conv, q_pts=q_pts, sp=pts[L], inds=inds: ops.KPConvFunction.apply(
                     xin, conv.weights, q_pts, sp, inds, conv.kernel_points, conv.KP_extent, infl)
             if isinstance(blk, SimpleBlock):
-                x = F.leaky_relu(bn(blk.batch_norm, kp_apply(x)), lr)
+                x = bn_act(blk.batch_norm, kp_apply(x), lr)
                 continue
             y = x if isinstance(blk.unary1, nn.Identity) else unary(blk.unary1, x)
-            y = F.leaky_relu(bn(blk.batch_norm_conv, kp_apply(y)), lr)
+            y = bn_act(blk.batch_norm_conv, kp_apply(y), lr)
             y = unary(blk.unary2, y)
-            sc = padded(x)[inds.long()].max(1)[0] if strided else x                     # max_pool (kpconv.py:841-858)
+            if not strided:
+                sc = x
+            elif hip:
+                sc = ops.GatherPoolFunction.apply(x, inds, "max")                       # max_pool (kpconv.py:841-858)
+            else:
+                sc = padded(x)[inds.long()].max(1)[0]
             if not isinstance(blk.unary_shortcut, nn.Identity):
                 sc = unary(blk.unary_shortcut, sc)
             x = F.leaky_relu(y + sc, lr)
@@ -469,7 +481,11 @@ class KPFCNN(nn.Module):
             if bi in self.decoder_concats:
                 x = torch.cat([x, skip_x.pop()], dim=1)
             if isinstance(blk, NearestUpsampleBlock):
-                x = padded(x)[ups[blk.layer_ind - 1][:, 0].long()]                      # closest_pool (kpconv.py:821-838)
+                up = ups[blk.layer_ind - 1]
+                if hip:
+                    x = ops.GatherPoolFunction.apply(x, up, "closest")                  # closest_pool (kpconv.py:821-838)
+                else:
+                    x = padded(x)[up[:, 0].long()]
             else:
                 x = unary(blk, x)
         return unary(self.head_softmax, unary(self.head_mlp, x))

@@ -243,16 +243,21 @@ class RandLANet(nn.Module):
         return super().train(mode)
 
     def _forward_train(self, inputs):
-        """``RandLANet.forward`` in TRAINING mode (randlanet.py:241-298 with :533-692), differentiable: point-major
-        ``[B, N, C]`` tensors, every 1x1 (transposed) convolution as the Linear it is, BatchNorm2d(eps 1e-6) on the batch
-        statistics over all rows (NOT folded), the neighbour pyramid from the HIP search when the dict carries none,
-        ``random_sample`` through ``ops.GatherMaxFunction`` and the softmax-weighted sums of the two attentive poolings through
-        ``ops.AttentivePoolFunction`` (HIP forward + hand-written HIP backward each); the gathers of the encodings and the
-        Linears run on torch's autograd.
-        Dropout(0.5) of fc1 is live, like in the reference."""
+        """``RandLANet.forward`` in TRAINING mode (randlanet.py:241-298 with :533-692), differentiable, on hand-written HIP in BOTH
+        passes (``ML3D_TRAIN_OPS=hip``, the default; csrc/train.hip): point-major ``[B, N, C]`` tensors, every 1x1 (transposed)
+        convolution as ``ops.LinearFunction``, BatchNorm2d(eps 1e-6) on the batch statistics + LeakyReLU as
+        ``ops.BatchNormActFunction`` (NOT folded: training updates the statistics), each attentive pooling -- neighbour gather,
+        concat with the encoded relative positions, score Linear, softmax over K, weighted sum -- as ONE fused
+        ``ops.AttentionStageFunction`` (no ``[B, N, K, d]`` tensor in either pass), ``random_sample`` through
+        ``ops.GatherMaxFunction``, ``nearest_interpolation`` through ``ops.GatherRowsFunction``, the neighbour pyramid from the HIP
+        search when the dict carries none.  torch carries the graph, the concatenations, the residual add and Dropout(0.5) of fc1
+        (live, like in the reference).  ``ML3D_TRAIN_OPS=torch`` keeps rounds 3-4's formulation (Linear / BatchNorm / gathers on
+        torch's autograd around ``ops.AttentivePoolFunction`` / ``ops.GatherMaxFunction``) as the A/B side."""
+        import os
         import torch.nn.functional as F
         cfg, dev = self.cfg, self.device
         _abi.require_gpu(dev, "RandLANet.forward (training)")
+        hip = os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch"
         coords = inputs['coords'][0] if isinstance(inputs['coords'], (list, tuple)) else inputs['coords']
         pts = coords.to(dev, torch.float32).contiguous()
         feat = inputs['features'].to(dev, torch.float32)
@@ -262,55 +267,76 @@ class RandLANet(nn.Module):
         else:
             a, b = self.neighbor_pyramid(pts)
             nbr, itp = [t.long() for t in a], [t.long() for t in b]
+        nbr32 = [t.to(torch.int32).contiguous() for t in nbr]
         B = pts.shape[0]
+        rows = torch.arange(B, device=dev)
+
+        def lin(x, w, b):
+            return ops.LinearFunction.apply(x, w, b) if hip else F.linear(x, w, b)
+
+        def bn_act(bn, y, slope):
+            if hip:
+                return ops.batch_norm_act(y, bn, slope)
+            shp = y.shape
+            y = F.batch_norm(y.reshape(-1, shp[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
+                             bn.eps).reshape(shp)
+            return y if slope is None else F.leaky_relu(y, slope)
 
         def shared(m, x):           # SharedMLP.forward (randlanet.py:503-518) on [..., Cin] rows
             w = m.conv.weight[:, :, 0, 0]
             w = w.t() if isinstance(m.conv, nn.ConvTranspose2d) else w           # ConvTranspose2d stores [Cin, Cout]
-            y = F.linear(x, w, m.conv.bias)
+            y = lin(x, w, m.conv.bias)
+            act = m.activation_fn
+            slope = act.negative_slope if isinstance(act, nn.LeakyReLU) else None
             if m.batch_norm is not None:
-                bn = m.batch_norm
-                shp = y.shape
-                y = F.batch_norm(y.reshape(-1, shp[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
-                                 bn.eps).reshape(shp)
-            return m.activation_fn(y) if m.activation_fn is not None else y
+                y = bn_act(m.batch_norm, y, slope)
+                return y if (slope is not None or act is None) else act(y)
+            return act(y) if act is not None else y
 
         def gather(x, idx):         # x [B, N, C], idx [B, M, K] -> [B, M, K, C]
-            return x[torch.arange(B, device=dev)[:, None, None], idx]
+            return x[rows[:, None, None], idx]
 
-        def lse(m, xyz, f, idx, rel=None):      # LocalSpatialEncoding.forward (randlanet.py:557-605)
-            if rel is None:
+        def relative(xyz, idx):     # the 10 relative-position channels of LocalSpatialEncoding.forward (randlanet.py:575-594): no
+            with torch.no_grad():   # parameter and no trained input behind them
                 nb = gather(xyz, idx)
                 ctr = xyz[:, :, None, :].expand_as(nb)
                 d = ctr - nb
-                rel = torch.cat([torch.sqrt((d * d).sum(-1, keepdim=True)), d, ctr, nb], -1)
-            enc = shared(m.mlp, rel)
-            return torch.cat([gather(f, idx), enc], -1), enc
+                return torch.cat([torch.sqrt((d * d).sum(-1, keepdim=True)), d, ctr, nb], -1)
 
-        def att(m, x):              # AttentivePooling.forward (randlanet.py:622-639): softmax over the K neighbours
-            return shared(m.mlp, ops.AttentivePoolFunction.apply(m.score_fn[0](x), x))
+        def stage(pool, f, enc, l):  # LocalSpatialEncoding's gather + concat, then AttentivePooling.forward (randlanet.py:596-639)
+            sc = pool.score_fn[0]
+            if hip and ops.attention_stage_supported(nbr[l].shape[-1], f.shape[-1], enc.shape[-1]):
+                pooled = ops.AttentionStageFunction.apply(f, enc, nbr32[l], sc.weight, sc.bias)
+            else:
+                x = torch.cat([gather(f, nbr[l]), enc], -1)
+                pooled = ops.AttentivePoolFunction.apply(lin(x, sc.weight, sc.bias), x)
+            return shared(pool.mlp, pooled)
 
-        y = F.linear(feat, self.fc0.weight, self.fc0.bias)
-        y = F.leaky_relu(F.batch_norm(y.reshape(-1, y.shape[-1]), self.bn0.running_mean, self.bn0.running_var, self.bn0.weight,
-                                      self.bn0.bias, True, self.bn0.momentum, self.bn0.eps).reshape(y.shape), 0.2)
+        y = bn_act(self.bn0, lin(feat, self.fc0.weight, self.fc0.bias), 0.2)
         skips, n = [], pts.shape[1]
         for i, blk in enumerate(self.encoder):
             xyz = pts[:, :n]
             f1 = shared(blk.mlp1, y)
-            x1, enc = lse(blk.lse1, xyz, f1, nbr[i])
-            p1 = att(blk.pool1, x1)
-            x2, _ = lse(blk.lse2, xyz, p1, nbr[i], rel=enc)
-            p2 = att(blk.pool2, x2)
+            enc = shared(blk.lse1.mlp, relative(xyz, nbr[i]))
+            p1 = stage(blk.pool1, f1, enc, i)
+            enc2 = shared(blk.lse2.mlp, enc)
+            p2 = stage(blk.pool2, p1, enc2, i)
             e = F.leaky_relu(shared(blk.mlp2, p2) + shared(blk.shortcut, y), 0.01)
             n_sub = n // cfg.sub_sampling_ratio[i]
-            sub = ops.GatherMaxFunction.apply(e, nbr[i].to(torch.int32).contiguous(), n_sub)
+            sub = ops.GatherMaxFunction.apply(e, nbr32[i], n_sub)
             if i == 0:
                 skips.append(e)
             skips.append(sub)
             y, n = sub, n_sub
         y = shared(self.mlp, y)
         for i in range(cfg.num_layers):
-            up = y[torch.arange(B, device=dev)[:, None], itp[-i - 1][:, :, 0]]             # nearest_interpolation
+            sel = itp[-i - 1][:, :, 0]                                                       # nearest_interpolation
+            if hip:
+                nc = y.shape[1]
+                flat = (sel + rows[:, None] * nc).to(torch.int32).reshape(-1).contiguous()
+                up = ops.GatherRowsFunction.apply(y.reshape(B * nc, y.shape[2]), flat).reshape(B, sel.shape[1], y.shape[2])
+            else:
+                up = y[rows[:, None], sel]
             y = shared(self.decoder[i], torch.cat([skips[-i - 2], up], -1))
         y = shared(self.fc1[0], y)
         y = shared(self.fc1[1], y)

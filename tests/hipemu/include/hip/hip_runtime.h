@@ -342,6 +342,14 @@ static inline float atomicAdd(float* p, float v) {
     memcpy(&f, &old, 4);
     return f;
 }
+static inline double atomicAdd(double* p, double v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    unsigned long long old = __atomic_load_n(q, __ATOMIC_RELAXED), want;
+    double cur;
+    do { memcpy(&cur, &old, 8); cur += v; memcpy(&want, &cur, 8); } while (!__atomic_compare_exchange_n(q, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&cur, &old, 8);
+    return cur;
+}
 static inline int atomicMin(int* p, int v) { return __atomic_fetch_min(p, v, __ATOMIC_RELAXED); }
 static inline int atomicMax(int* p, int v) { return __atomic_fetch_max(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicMin(unsigned* p, unsigned v) { return __atomic_fetch_min(p, v, __ATOMIC_RELAXED); }

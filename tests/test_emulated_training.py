@@ -1,0 +1,212 @@
+"""CPU: the training side on hand-written HIP (csrc/train.hip, ``ml3d.ops.train``) executed on the HOST EMULATION of
+the same ``.hip`` sources: every new differentiable op against torch's autograd through the reference's formulation, then the two
+segmentation models in ``.train()`` mode -- every Linear, BatchNorm, gather / pool and attention stage on the HIP ops in BOTH passes --
+against ONE training forward + backward of the REAL reference modules (tests/golden/train_{randlanet,kpconv}.npz, written by
+oracle/gen_golden_train.py from /root/reference).  The -m gpu twins are tests/test_gpu_training.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not emu.available(), reason="clang++ for the host emulator not found")
+
+_PRELUDE = r'''
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, "open3d-ml_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.nn.functional as F
+import emu_runtime
+emu_runtime.install("ml3d")
+'''
+
+
+def _run(body, **env):
+    emu.lib()
+    r = subprocess.run([sys.executable, "-c", _PRELUDE % {"root": ROOT} + body], capture_output=True, text=True, timeout=1500,
+                       cwd="/tmp", env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_training_ops_match_torch_autograd():
+    """``ops.gemm_tn``, ``LinearFunction``, ``BatchNormActFunction`` (statistics, running buffers, fused LeakyReLU), ``GatherRowsFunction``,
+    ``GatherPoolFunction`` (max with shadow rows / closest) and the fused ``AttentionStageFunction`` (d = 16 / 64 / 128 / 256 and an
+    uneven c1 / c2 split, with and without bias; randlanet.py:596-605, 617, 631-637 written out in torch as the reference does):
+    outputs and every input gradient."""
+    _run(r'''
+from ml3d import ops
+rng = np.random.default_rng(0)
+T = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+# gemm_tn
+for m, k, n in ((1000, 70, 33), (5, 16, 16), (4097, 130, 200), (64, 8, 8)):
+    a, b = T(rng.standard_normal((m, k))), T(rng.standard_normal((m, n)))
+    c, s = ops.gemm_tn(a, b, with_col_sums=True)
+    ref = a.double().t() @ b.double()
+    assert (c - ref).abs().max() <= 1e-5 * max(1, m ** 0.5), (m, k, n, float((c - ref).abs().max()))
+    assert (s - a.double().sum(0)).abs().max() <= 1e-4
+print("gemm_tn ok")
+# Linear
+for shape, cout, bias in (((3, 50, 16, 10), 8, True), ((700, 64), 128, False), ((2, 9, 33), 5, True)):
+    x = T(rng.standard_normal(shape)).requires_grad_(True)
+    w = T(rng.standard_normal((cout, shape[-1])) * 0.3).requires_grad_(True)
+    b = T(rng.standard_normal(cout)).requires_grad_(True) if bias else None
+    g = T(rng.standard_normal(shape[:-1] + (cout,)))
+    ref = F.linear(x, w, b); ref.backward(g)
+    want = [x.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone()]
+    x.grad = None; w.grad = None
+    if b is not None: b.grad = None
+    out = ops.LinearFunction.apply(x, w, b); out.backward(g)
+    assert (out - ref).abs().max() <= 1e-5
+    got = [x.grad, w.grad, None if b is None else b.grad]
+    for a_, b_ in zip(got, want):
+        if b_ is not None:
+            assert (a_ - b_).abs().max() <= 2e-5 * max(1.0, float(b_.abs().max())), float((a_ - b_).abs().max())
+print("linear ok")
+# BatchNorm + act
+for shape, slope in (((4, 30, 16, 8), 0.2), ((500, 64), None), ((3, 7, 300), 0.1), ((10, 5), 0.0)):
+    c = shape[-1]
+    x = T(rng.standard_normal(shape) * 2 + 1).requires_grad_(True)
+    gam = T(rng.random(c) + 0.5).requires_grad_(True); bet = T(rng.standard_normal(c)).requires_grad_(True)
+    rm, rv = T(rng.standard_normal(c)), T(rng.random(c) + 0.5)
+    rm2, rv2 = rm.clone(), rv.clone()
+    g = T(rng.standard_normal(shape))
+    y = F.batch_norm(x.reshape(-1, c), rm, rv, gam, bet, True, 0.01, 1e-6).reshape(shape)
+    ref = y if slope is None else F.leaky_relu(y, slope)
+    ref.backward(g)
+    want = [x.grad.clone(), gam.grad.clone(), bet.grad.clone()]
+    x.grad = None; gam.grad = None; bet.grad = None
+    out = ops.BatchNormActFunction.apply(x, gam, bet, rm2, rv2, 0.01, 1e-6, slope)
+    out.backward(g)
+    assert (out - ref).abs().max() <= 2e-5, float((out - ref).abs().max())
+    assert (rm - rm2).abs().max() <= 1e-6 and (rv - rv2).abs().max() <= 1e-6
+    for a_, b_ in zip([x.grad, gam.grad, bet.grad], want):
+        assert (a_ - b_).abs().max() <= 5e-5 * max(1.0, float(b_.abs().max())), (shape, float((a_ - b_).abs().max()), float(b_.abs().max()))
+print("bn ok")
+# gathers
+x = T(rng.standard_normal((40, 12))).requires_grad_(True)
+idx = torch.from_numpy(rng.integers(0, 41, 100).astype(np.int32))
+g = T(rng.standard_normal((100, 12)))
+pad = torch.cat([x, torch.zeros_like(x[:1])])
+ref = pad[idx.long()]; ref.backward(g); want = x.grad.clone(); x.grad = None
+out = ops.GatherRowsFunction.apply(x, idx); out.backward(g)
+assert torch.equal(out, ref) and (x.grad - want).abs().max() <= 1e-5
+x.grad = None
+for mode in ("max", "closest"):
+    inds = torch.from_numpy(rng.integers(0, 41, (30, 7)).astype(np.int32))
+    g = T(rng.standard_normal((30, 12)))
+    pad = torch.cat([x, torch.zeros_like(x[:1])])
+    ref = pad[inds.long()].max(1)[0] if mode == "max" else pad[inds[:, 0].long()]
+    ref.backward(g); want = x.grad.clone(); x.grad = None
+    out = ops.GatherPoolFunction.apply(x, inds, mode); out.backward(g)
+    assert torch.equal(out, ref), mode
+    assert (x.grad - want).abs().max() <= 1e-5, (mode, float((x.grad - want).abs().max()))
+    x.grad = None
+print("gathers ok")
+# attention stage
+for B, n, c1, c2, bias in ((2, 37, 8, 8, True), (1, 130, 32, 32, True), (2, 9, 64, 64, False), (1, 5, 128, 128, True), (1, 21, 6, 10, True)):
+    K, d = 16, c1 + c2
+    f = T(rng.standard_normal((B, n, c1))).requires_grad_(True)
+    enc = T(rng.standard_normal((B, n, K, c2))).requires_grad_(True)
+    idx = torch.from_numpy(rng.integers(0, n, (B, n, K)).astype(np.int32))
+    w = T(rng.standard_normal((d, d)) * 0.3).requires_grad_(True)
+    b = T(rng.standard_normal(d)).requires_grad_(True) if bias else None
+    g = T(rng.standard_normal((B, n, d)))
+    x = torch.cat([f[torch.arange(B)[:, None, None], idx.long()], enc], -1)
+    s = F.linear(x, w, b)
+    ref = (torch.softmax(s, dim=-2) * x).sum(-2)
+    ref.backward(g)
+    want = [f.grad.clone(), enc.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone()]
+    f.grad = None; enc.grad = None; w.grad = None
+    if b is not None: b.grad = None
+    out = ops.AttentionStageFunction.apply(f, enc, idx, w, b)
+    out.backward(g)
+    assert (out - ref).abs().max() <= 2e-5, (d, float((out - ref).abs().max()))
+    got = [f.grad, enc.grad, w.grad, None if b is None else b.grad]
+    for name, a_, b_ in zip("f enc w b".split(), got, want):
+        if b_ is not None:
+            tol = 5e-5 * max(1.0, float(b_.abs().max())) if name != "b" else 2e-4
+            assert (a_ - b_).abs().max() <= tol, (d, name, float((a_ - b_).abs().max()), float(b_.abs().max()))
+    print("attention stage ok", B, n, c1, c2, flush=True)
+print("ok")
+''')
+
+
+_MODEL_CHECK = r'''
+loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+def check(m, logits, loss, g, n_grads, tol):
+    assert logits.requires_grad and np.abs(logits.detach().numpy() - g["logits"]).max() <= 1e-4
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked, worst = 0, 0.0
+    for key in g.files:
+        if key.startswith("grad:"):
+            want, got = g[key], named[key[5:]].grad.numpy()
+            assert got.shape == want.shape
+            err = float(np.abs(got - want).max())
+            assert err <= max(2e-6, tol * float(np.abs(want).max())), (key, err, float(np.abs(want).max()))
+            worst = max(worst, err / max(1e-12, float(np.abs(want).max())))
+            checked += 1
+    assert checked == n_grads
+    return worst
+'''
+
+
+@pytest.mark.parametrize("path", ["hip", "torch"])
+def test_randlanet_training_on_hip_ops_matches_the_reference(path):
+    """RandLANet in ``.train()`` mode against the REAL reference's training forward + backward (logits <= 1e-4, loss <= 1e-5, 12
+    parameter gradients <= 1e-3 of each tensor's largest entry, the BatchNorm running mean) with ``ML3D_TRAIN_OPS=hip`` (Linear /
+    BatchNorm / gathers / fused attention stages on csrc/train.hip) and ``=torch`` (the A/B side)."""
+    _run(_MODEL_CHECK + r'''
+from oracle import randlanet_ref as R
+from oracle.gen_golden_train import RANDLA_TRAIN_CFG, randla_train_inputs
+from ml3d.torch.models import RandLANet
+g = np.load(os.path.join(ROOT, "tests", "golden", "train_randlanet.npz"))
+cfg = dict(RANDLA_TRAIN_CFG)
+m = RandLANet(**cfg, device="cpu")
+m.load_state_dict(R.make_state_dict(cfg, 55))
+m.train()
+m.fc1[2].eval()
+pts, feats, labels = randla_train_inputs()
+logits = m({"coords": [torch.from_numpy(pts)], "features": torch.from_numpy(feats)})
+loss, lab, _ = m.get_loss(loss_obj, logits, {"data": {"labels": torch.from_numpy(labels)}}, "cpu")
+assert int(lab.numel()) == int(g["n_valid"])
+worst = check(m, logits, loss, g, 12, 1e-3)
+assert np.abs(m.bn0.running_mean.numpy() - g["running_mean:bn0"]).max() <= 1e-5
+print("ok, worst relative gradient error %.2g" % worst)
+''', ML3D_TRAIN_OPS=path)
+
+
+@pytest.mark.parametrize("path", ["hip", "torch"])
+def test_kpfcnn_training_on_hip_ops_matches_the_reference(path):
+    """KPFCNN (rigid) in ``.train()`` mode against the REAL reference's training forward + backward, both paths of ``ML3D_TRAIN_OPS``;
+    KPConv's weight products run on ``ml3d_linear`` / ``ml3d_gemm_tn`` in either."""
+    _run(_MODEL_CHECK + r'''
+from ml3d.torch.dataloaders import kpconv_input_features
+from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
+from oracle import kpconv_ref as K
+from oracle.gen_golden_train import TRAIN_CFG, train_inputs
+g = np.load(os.path.join(ROOT, "tests", "golden", "train_kpconv.npz"))
+cfg = dict(TRAIN_CFG)
+m = KPFCNN(**cfg, device="cpu")
+m.load_state_dict(K.make_state_dict(cfg, 77))
+spheres, cols, labels = train_inputs()
+pts, columns = np.concatenate(spheres), np.concatenate(cols)
+np.random.seed(31)
+batch = KPConvBatch(pts, [len(s) for s in spheres], cfg, features=kpconv_input_features(pts, columns, cfg["in_features_dim"]).astype(np.float32),
+                    device="cpu")
+batch.labels = torch.from_numpy(np.concatenate(labels).astype(np.int64))
+m.train()
+logits = m(batch)
+loss, lab, scores = m.get_loss(loss_obj, logits, {"data": batch}, "cpu")
+assert int(lab.numel()) == int(g["n_valid"])
+worst = check(m, logits, loss, g, 12, 1e-3)
+rm = dict(m.named_buffers())["encoder_blocks.0.batch_norm.batch_norm.running_mean"].numpy()
+assert np.abs(rm - g["running_mean:encoder_blocks.0"]).max() <= 1e-5
+print("ok, worst relative gradient error %.2g" % worst)
+''', ML3D_TRAIN_OPS=path)

@@ -30,7 +30,11 @@ def _setup():
     return cfg, m, batch
 
 
-def test_one_training_step_forward_and_gradients_match_the_reference(golden_dir):
+@pytest.mark.parametrize("train_ops", ["hip", "torch"])
+def test_one_training_step_forward_and_gradients_match_the_reference(golden_dir, monkeypatch, train_ops):
+    """(``ML3D_TRAIN_OPS=hip``, the default: Linear / BatchNorm + LeakyReLU / pools on csrc/train.hip in both passes; ``torch``: those
+    modules on torch's autograd -- the A/B side.  KPConv itself is ``ops.KPConvFunction`` in either.)"""
+    monkeypatch.setenv("ML3D_TRAIN_OPS", train_ops)
     g = np.load(os.path.join(golden_dir, "train_kpconv.npz"))
     cfg, m, batch = _setup()
     m.train()
@@ -79,10 +83,13 @@ def test_an_optimisation_step_lowers_the_loss_and_inference_sees_the_new_weights
     assert (after - before).abs().max() > 1e-3          # the fused inference kernels repacked the trained weights
 
 
-def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir):
+@pytest.mark.parametrize("train_ops", ["hip", "torch"])
+def test_randlanet_training_forward_and_gradients_match_the_reference(golden_dir, monkeypatch, train_ops):
     """RandLANet in train mode (BatchNorm on batch statistics, random_sample through ops.GatherMaxFunction = HIP forward +
     hand-written HIP backward, the HIP neighbour pyramid feeding the indices) against one forward + backward of the REAL
-    reference module (tests/golden/train_randlanet.npz)."""
+    reference module (tests/golden/train_randlanet.npz).  ``ML3D_TRAIN_OPS=hip`` (default): every Linear, BatchNorm + LeakyReLU,
+    nearest_interpolation and the FUSED attention stages on csrc/train.hip in both passes; ``torch``: rounds 3-4's formulation."""
+    monkeypatch.setenv("ML3D_TRAIN_OPS", train_ops)
     from oracle import randlanet_ref as R
     from oracle.gen_golden_train import RANDLA_TRAIN_CFG, randla_train_inputs
     from ml3d.torch.models import RandLANet
@@ -214,3 +221,113 @@ def test_deformable_kpfcnn_training_matches_the_reference(golden_dir):
     assert abs(float(m.reg_loss) - float(g["eval_reg_loss"])) <= 1e-4 * float(g["eval_reg_loss"])
     assert abs(float(g["eval_reg_loss"]) - float(g["reg_loss"])) > 1.0          # (the two really differ on this fixture)
 
+
+
+# ---- the training ops of csrc/train.hip against torch's own CUDA autograd, at sizes that span many workgroups --------------------
+def _close(a, b, tol):
+    return float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_linear_batchnorm_gather_functions_match_torch_autograd():
+    """``ops.LinearFunction`` (forward ml3d_linear, backward ml3d_linear + ml3d_gemm_tn), ``ops.BatchNormActFunction`` (batch
+    statistics in double, fused LeakyReLU, running buffers), ``ops.GatherRowsFunction`` / ``ops.GatherPoolFunction`` against the
+    same expressions on torch's autograd (rocBLAS / MIOpen-free elementwise reference), 2e5 rows."""
+    from ml3d import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    for shape, cout, bias in (((4, 11264, 16, 10), 8, True), ((200000, 64), 128, False), ((3, 999, 96), 19, True)):
+        x = rn(*shape).requires_grad_(True)
+        w = (rn(cout, shape[-1]) * 0.3).requires_grad_(True)
+        b = rn(cout).requires_grad_(True) if bias else None
+        gy = rn(*shape[:-1], cout)
+        ref = F.linear(x.double(), w.double(), None if b is None else b.double())
+        ref.backward(gy.double())
+        want = [x.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone()]
+        x.grad = w.grad = None
+        if b is not None:
+            b.grad = None
+        out = ops.LinearFunction.apply(x, w, b)
+        out.backward(gy)
+        assert _close(out, ref.float(), 2e-5)
+        rows = x.numel() // shape[-1]
+        for got, wnt in zip([x.grad, w.grad, None if b is None else b.grad], want):
+            if wnt is not None:
+                assert _close(got, wnt, 2e-6 * max(1.0, rows ** 0.5)), (shape, float((got - wnt).abs().max()), float(wnt.abs().max()))
+    for shape, slope in (((4, 2816, 16, 64), 0.2), ((300000, 32), None), ((7, 5), 0.1)):
+        c = shape[-1]
+        x = (rn(*shape) * 2 + 1).requires_grad_(True)
+        gam, bet = (torch.rand(c, device="cuda", generator=g) + 0.5).requires_grad_(True), rn(c).requires_grad_(True)
+        rm, rv = rn(c), torch.rand(c, device="cuda", generator=g) + 0.5
+        rm2, rv2 = rm.clone(), rv.clone()
+        gy = rn(*shape)
+        y = F.batch_norm(x.reshape(-1, c), rm, rv, gam, bet, True, 0.01, 1e-6).reshape(shape)
+        ref = y if slope is None else F.leaky_relu(y, slope)
+        ref.backward(gy)
+        want = [x.grad.clone(), gam.grad.clone(), bet.grad.clone()]
+        x.grad = gam.grad = bet.grad = None
+        out = ops.BatchNormActFunction.apply(x, gam, bet, rm2, rv2, 0.01, 1e-6, slope)
+        out.backward(gy)
+        assert _close(out, ref, 2e-5) and _close(rm2, rm, 1e-5) and _close(rv2, rv, 1e-5)
+        for got, wnt in zip([x.grad, gam.grad, bet.grad], want):
+            assert _close(got, wnt, 2e-4), (shape, float((got - wnt).abs().max()), float(wnt.abs().max()))
+    x = rn(5000, 48).requires_grad_(True)
+    idx = torch.randint(0, 5001, (70000,), device="cuda", generator=g).to(torch.int32)
+    gy = rn(70000, 48)
+    pad = torch.cat([x, torch.zeros_like(x[:1])])
+    ref = pad[idx.long()]
+    ref.backward(gy)
+    want = x.grad.clone(); x.grad = None
+    out = ops.GatherRowsFunction.apply(x, idx)
+    out.backward(gy)
+    assert torch.equal(out, ref) and _close(x.grad, want, 1e-5)
+    x.grad = None
+    for mode in ("max", "closest"):
+        inds = torch.randint(0, 5001, (20000, 23), device="cuda", generator=g).to(torch.int32)
+        gy = rn(20000, 48)
+        pad = torch.cat([x, torch.zeros_like(x[:1])])
+        ref = pad[inds.long()].max(1)[0] if mode == "max" else pad[inds[:, 0].long()]
+        ref.backward(gy)
+        want = x.grad.clone(); x.grad = None
+        out = ops.GatherPoolFunction.apply(x, inds, mode)
+        out.backward(gy)
+        assert torch.equal(out, ref) and _close(x.grad, want, 1e-5), mode
+        x.grad = None
+
+
+@pytest.mark.parametrize("B,n,c1,c2,bias", [(2, 11264, 8, 8, True), (4, 2816, 32, 32, True), (2, 1500, 64, 64, False), (3, 704, 128, 128, True),
+                                            (1, 333, 6, 10, True)])
+def test_fused_attention_stage_matches_the_unfused_formulation(B, n, c1, c2, bias):
+    """``ops.AttentionStageFunction`` (one kernel per pass, no [B, N, K, d] tensor) against the reference's formulation on torch's
+    autograd -- gather, concat, Linear, softmax over K, weighted sum (randlanet.py:596-605, 617, 631-637) -- in float64: the four
+    stage widths of randlanet_semantickitti.yml at multi-workgroup sizes and an uneven split; output and every gradient."""
+    from ml3d import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + c1)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    K, d = 16, c1 + c2
+    f, enc = rn(B, n, c1).requires_grad_(True), rn(B, n, K, c2).requires_grad_(True)
+    idx = torch.randint(0, n, (B, n, K), device="cuda", generator=g).to(torch.int32)
+    w = (rn(d, d) * 0.3).requires_grad_(True)
+    b = rn(d).requires_grad_(True) if bias else None
+    gy = rn(B, n, d)
+    x = torch.cat([f.double()[torch.arange(B, device="cuda")[:, None, None], idx.long()], enc.double()], -1)
+    s = F.linear(x, w.double(), None if b is None else b.double())
+    ref = (torch.softmax(s, dim=-2) * x).sum(-2)
+    ref.backward(gy.double())
+    want = [f.grad.clone(), enc.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone()]
+    f.grad = enc.grad = w.grad = None
+    if b is not None:
+        b.grad = None
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = ops.AttentionStageFunction.apply(f, enc, idx, w, b)
+    out.backward(gy)
+    torch.cuda.synchronize()
+    # nothing of size [B, N, K, d] was allocated by the two passes: the peak stays below ONE such tensor + the outputs they return
+    assert torch.cuda.max_memory_allocated() - base <= 4 * (B * n * K * d + 2 * B * n * K * c2 + 4 * B * n * d) + (8 << 20)
+    assert _close(out, ref.float(), 2e-5), float((out - ref.float()).abs().max())
+    for name, got, wnt in zip("f enc w b".split(), [f.grad, enc.grad, w.grad, None if b is None else b.grad], want):
+        if wnt is not None:
+            tol = 1e-4 if name != "b" else 1e-3          # (the bias gradient is a sum of terms that cancel exactly in exact arithmetic)
+            assert float((got - wnt).abs().max()) <= tol * max(1.0, float(wnt.abs().max())), (name, float((got - wnt).abs().max()), float(wnt.abs().max()))
