@@ -378,7 +378,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                    "%d in-range points -> %d pillars (%d kept points) of %d sweeps in one call; the interval holds the op's one host "
                    "read-back (pillar count) between count and fill" % (vn, vm, vk, lane_units), len(vox_in)),
         _hbm_entry("a16-a17 pillar gather + PFN + canvas scatter (point_pillars.py:512-616)",
-                   "pillar_pfn + canvas fill (hipMemsetAsync)", pb, float(np.mean(pf_in)) if pf_in else None, pa,
+                   "pillar_pfn + canvas fill (grid_zero)", pb, float(np.mean(pf_in)) if pf_in else None, pa,
                    "pp_pillar_features", lane_units,
                    "%d pillars of %d sweeps -> NHWC canvas %s: zero fill + one 256-byte row per pillar" %
                    (pm, lane_units, "x".join(str(int(d)) for d in pf_shapes[1].shape)), len(pf_in)),

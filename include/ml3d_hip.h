@@ -794,7 +794,8 @@ int ml3d_randla_forward_ordered(const ml3d_randla_desc* desc_host, const float* 
 /* stage.  ml3d.ops.{LinearFunction, BatchNormActFunction, GatherRowsFunction, GatherPoolFunction, AttentionStageFunction} bind   */
 /* them into autograd graphs; outputs are caller-owned, reductions across workgroups are float atomics.                           */
 /* ------------------------------------------------------------------------------------------------------------------------------ */
-/* ml3d_gemm_tn: c[i, j] = sum_r a[r, i] * b[r, j]  (a [m, lda] k columns, b [m, ldb] n columns, c [k, ldc]; c is zeroed here).    */
+/* ml3d_gemm_tn: c[i, j] = sum_r a[r, i] * b[r, j]  (a [m, lda] k columns, b [m, ldb] n columns, c [k, ldc]; c is zeroed here, the    */
+/*   row slices meet in it through float atomics).                                                                                 */
 /*   Weight gradient of y = x W^T: grad_W [out, in] = gemm_tn(a = grad_y, b = x); of KPConv's contraction: grad_W [15 cin, cout]  */
 /*   = gemm_tn(a = wf, b = grad_out) (kpconv.py:1139-1159).  col_sums_a (optional, [k]) <- sum_r a[r, :] (the bias gradient).     */
 int ml3d_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int k, int n,
@@ -836,19 +837,22 @@ int ml3d_gather_pool_backward(const float* features, int64_t n_supports, int cha
 /*   617, 631-637): x[p, k, :] = [ f[b, idx[p, k], :c1] | enc[p, k, :c2] ], s = x W^T + bias, out[p, c] = sum_k softmax_k(s)[k, c]   */
 /*   x[p, k, c].  f [batch, n, c1], enc [batch, n, k, c2], neighbor_idx int32 [batch, n, k] (item-local), weight [d, d] (the         */
 /*   Linear's [out, in]) and weight_t its transpose, d = c1 + c2; out [batch, n, d].  k must be 16, d even and <= 256               */
-/*   (ML3D_E_UNSUPPORTED otherwise: the caller keeps the unfused ops).  The backward recomputes x, s and the softmax and returns    */
-/*   grad_f [batch, n, c1], grad_enc [batch, n, k, c2], grad_weight [d, d], grad_bias [d] (all zeroed here, accumulated with        */
-/*   atomics): no [batch, n, k, d] tensor exists in either pass.                                                                     */
+/*   and, above d = 128, c1 <= 160 (ML3D_E_UNSUPPORTED otherwise: the caller keeps the unfused ops).  The backward recomputes x, s   */
+/*   and the softmax and returns grad_f [batch, n, c1] (zeroed here; the scatter through neighbor_idx uses float atomics),           */
+/*   grad_enc [batch, n, k, c2] (written), grad_weight [d, d] (the persistent workgroups' private partial sums in `workspace`,      */
+/*   added up by a second kernel: deterministic) and grad_bias [d]: no [batch, n, k, d] tensor exists in either pass.                */
 int ml3d_randla_attention_stage(const float* f, const float* enc, const int32_t* neighbor_idx,
                                 const float* weight_t, const float* bias, int64_t batch, int64_t n,
                                 int k, int c1, int c2, float* out, void* stream);
+
+size_t ml3d_randla_attention_stage_backward_workspace_bytes(int64_t batch, int64_t n, int c1, int c2);
 
 int ml3d_randla_attention_stage_backward(const float* f, const float* enc, const int32_t* neighbor_idx,
                                          const float* weight, const float* weight_t, const float* bias,
                                          const float* out, const float* grad_out, int64_t batch,
                                          int64_t n, int k, int c1, int c2, float* grad_f,
                                          float* grad_enc, float* grad_weight, float* grad_bias,
-                                         void* stream);
+                                         void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,9 @@ __device__ __forceinline__ int tr_row(int r, int hi) { return (r & 3) + 8 * (r >
 // ---------------------------------------------------------------------------------------------------------------------
 // C[i, j] += sum_r A[r, i] B[r, j]   (A [m, lda] uses k columns, B [m, ldb] uses n columns, C [k, ldc] zeroed by the host call)
 // One wave per (64 x 64 tile of C, slice of the rows): lane (hi, cl) feeds A[r + hi][i0 + cl] and B[r + hi][j0 + cl] -- both
-// coalesced 128-byte row segments -- into four 32 x 32 x 2 MFMAs per two rows; no LDS, no barrier.  The slices meet in C through
-// float atomics.
+// coalesced 128-byte row segments -- into four 32 x 32 x 2 MFMAs per two rows; no LDS, no barrier.  The <= 2048 / tiles row slices
+// meet in C (zeroed by the host call) through float atomics.  (Per-slice partial matrices + a summing kernel measured slower:
+// profiles/r05_train_randlanet_hip_kernel_stats_v2.csv.)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 gemm_tn_k(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb, int64_t m, int k, int n,
@@ -88,6 +89,21 @@ gemm_tn_k(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
 // atomic per (workgroup, column) leaves.  MODE 0: sum x (float, bias gradients); MODE 1: sum x, sum x^2 in double (BatchNorm
 // statistics); MODE 2: sum g', sum g' xhat in double with g' = gy * act'(y), xhat = (x - mean) invstd (BatchNorm backward).
 // ---------------------------------------------------------------------------------------------------------------------
+// (row, channel) of the flat element index e = row * c + channel, advanced by a fixed stride WITHOUT a division per element (a 64-bit
+// division is a ~150-instruction software loop on gfx950: it made the elementwise kernels compute-bound)
+struct RowCh {
+    int64_t row, drow;
+    int ch, dch, c;
+    __device__ __forceinline__ RowCh(int64_t first, int64_t stride, int c_) : c(c_) {
+        row = first / c_; ch = (int)(first - row * c_);
+        drow = stride / c_; dch = (int)(stride - drow * c_);
+    }
+    __device__ __forceinline__ void next() {
+        row += drow; ch += dch;
+        if (ch >= c) { ch -= c; ++row; }
+    }
+};
+
 struct BnRef { const float* y; const float* gy; const float* mean; const float* invstd; int act; float slope; };
 
 __device__ __forceinline__ float act_grad(float gy, float y, int act, float slope) {
@@ -113,6 +129,7 @@ col_reduce_k(const float* __restrict__ x, int64_t ld, int64_t m, int c, int64_t 
         if (live && col < c) {
             float mu = 0.f, is = 0.f;
             if (MODE == 2) { mu = R.mean[col]; is = R.invstd[col]; }
+#pragma unroll 4
             for (int64_t r = r0 + g; r < r1; r += groups) {
                 const float v = x[r * ld + col];
                 if (MODE == 0) f0 += v;
@@ -154,9 +171,10 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, int64_t m, int c,
 __global__ void __launch_bounds__(256)
 bn_apply_k(const float* __restrict__ x, int64_t total, int c, const float* __restrict__ gamma, const float* __restrict__ beta,
            const float* __restrict__ mean, const float* __restrict__ invstd, int act, float slope, float* __restrict__ y) {
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-        const int ch = (int)(e % c);
+    const int64_t step = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    RowCh w(e0, step, c);
+    for (int64_t e = e0; e < total; e += step, w.next()) {
+        const int ch = w.ch;
         float v = (x[e] - mean[ch]) * invstd[ch];
         v = v * (gamma ? gamma[ch] : 1.f) + (beta ? beta[ch] : 0.f);
         y[e] = act == 0 ? v : (v > 0.f ? v : v * slope);
@@ -176,8 +194,9 @@ bn_backward_apply_k(const float* __restrict__ x, const float* __restrict__ y, co
         if (gbeta) gbeta[first] = (float)sums[first];
     }
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = first; e < total; e += step) {
-        const int ch = (int)(e % c);
+    RowCh w(first, step, c);
+    for (int64_t e = first; e < total; e += step, w.next()) {
+        const int ch = w.ch;
         const float is = invstd[ch];
         const float xh = (x[e] - mean[ch]) * is;
         const float gp = act_grad(gy[e], y[e], act, slope);
@@ -192,10 +211,11 @@ bn_backward_apply_k(const float* __restrict__ x, const float* __restrict__ y, co
 __global__ void __launch_bounds__(256)
 gather_rows_k(const float* __restrict__ x, int64_t n_src, int c, const int32_t* __restrict__ idx, int64_t idx_stride, int64_t m,
               float* __restrict__ out) {
-    const int64_t total = m * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-        const int64_t r = e / c;
-        const int ch = (int)(e - r * c);
+    const int64_t total = m * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    RowCh w(e0, step, c);
+    for (int64_t e = e0; e < total; e += step, w.next()) {
+        const int64_t r = w.row;
+        const int ch = w.ch;
         const int64_t s = idx[r * idx_stride];
         out[e] = (s >= 0 && s < n_src) ? x[s * c + ch] : 0.f;           // (a shadow index reads the zero row)
     }
@@ -204,10 +224,11 @@ gather_rows_k(const float* __restrict__ x, int64_t n_src, int c, const int32_t* 
 __global__ void __launch_bounds__(256)
 scatter_add_rows_k(const float* __restrict__ g, int64_t n_src, int c, const int32_t* __restrict__ idx, int64_t idx_stride, int64_t m,
                    float* __restrict__ gx) {
-    const int64_t total = m * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-        const int64_t r = e / c;
-        const int ch = (int)(e - r * c);
+    const int64_t total = m * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    RowCh w(e0, step, c);
+    for (int64_t e = e0; e < total; e += step, w.next()) {
+        const int64_t r = w.row;
+        const int ch = w.ch;
         const int64_t s = idx[r * idx_stride];
         if (s >= 0 && s < n_src) atomicAdd(gx + s * c + ch, g[e]);
     }
@@ -218,10 +239,11 @@ scatter_add_rows_k(const float* __restrict__ g, int64_t n_src, int c, const int3
 __global__ void __launch_bounds__(256)
 max_pool_adjoint_k(const float* __restrict__ feat, int64_t ns, int c, const int32_t* __restrict__ inds, int64_t nq, int64_t H,
                    const float* __restrict__ g, float* __restrict__ gfeat) {
-    const int64_t total = nq * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-        const int64_t q = e / c;
-        const int ch = (int)(e - q * c);
+    const int64_t total = nq * (int64_t)c, step = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    RowCh w(e0, step, c);
+    for (int64_t e = e0; e < total; e += step, w.next()) {
+        const int64_t q = w.row;
+        const int ch = w.ch;
         int64_t arg = -1;
         float best = 0.f;
         for (int64_t h = 0; h < H; ++h) {
@@ -243,17 +265,21 @@ max_pool_adjoint_k(const float* __restrict__ feat, int64_t ns, int c, const int3
 // of 64: scores of the block on the MFMA (A from LDS, W^T rows from global / L2, coalesced), softmax + weighted sum with one thread
 // per (point, column).  Backward recomputes x, s and the probabilities p, forms gs[k, c] = g[c] p[k, c] (x[k, c] - out[c]) in
 // place of s, and takes
-//   gx = gs W (+ g p on the block's own columns)   -> scattered with atomics into grad_f (through idx) and grad_enc
-//   gW[c, :] += gs[:, c]^T x                        -> 64 x d accumulator tiles in registers across ALL tiles of the workgroup,
-//                                                      one atomic pass per workgroup at the end
-//   gbias[c] += sum_k gs[k, c]                      (zero up to rounding: softmax is shift invariant; kept for fidelity)
-// Workgroup (g, cb) owns column block cb of a persistent share g of the tiles, so the gW tile stays in registers.
+//   gx = gs W + g p     accumulated over the column blocks in MFMA registers; the enc half is WRITTEN (every element has one
+//                       owner), the f half scatters through idx with atomics (the inherent ones of an index_add)
+//   gW[c, :] += gs[:, c]^T x     into the workgroup's PRIVATE [d x d] partial (L2-resident, plain loads / stores); a second
+//                       kernel sums the partials of the <= 512 persistent workgroups -- no atomics, deterministic
+//   gbias[c] += sum_k gs[k, c]   (zero up to rounding: softmax is shift invariant; kept for fidelity)
+// (A first version split the column blocks over workgroups and met in grad_enc / grad_weight through atomics: ~90 M float atomics
+//  per launch, 3.1 ms per launch and 22 of the 41 ms of a RandLA-Net training step -- profiles/r05_train_randlanet_hip_kernel_stats_v1.csv.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AS_K = 16;                 // neighbours per point (num_neighbors of every in-scope configuration)
 constexpr int AS_CB = 64;                // score columns per pass
 constexpr int AS_DMAX = 256;             // widest stage (d = dim_output[l]); wider stages stay on the unfused path
 constexpr int AS_LDS_FLOATS = 64 * (128 + 1) + 64 * (AS_CB + 1);      // >= 32 * (256 + 1) + 32 * (AS_CB + 1)
 constexpr int AS_MAXT = 4;               // 32 x 32 accumulator tiles per wave
+// backward: R = 64 rows for d <= 64, 32 rows above; X [R][d | 1] + S [R][65] + GD [R][c1 | 1] (c1 < d)
+constexpr int AS_C1MAX = 160;            // widest f half of a stage wider than 128 (GD must fit: 61.8 KB of LDS per workgroup)
 
 struct AttnArgs {
     const float* f; const float* enc; const int32_t* idx; const float* w; const float* wt; const float* bias;
@@ -262,27 +288,33 @@ struct AttnArgs {
     const float* gout; float* gf; float* genc; float* gw; float* gbias;
 };
 
-// stage the R x d rows of tile `tile` (points tile * TP ...) into X (row pitch ldx); rows past the last point are zeros
+// stage the R x d rows of tile `tile` (points tile * TP ...) into X (row pitch ldx); rows past the last point are zeros.  The (row,
+// column) of a thread's elements advance incrementally and the batch item of a point comes from 32-bit arithmetic (the host call
+// refuses batch * n >= 2^31): no software division per element.
 template <int R>
 __device__ __forceinline__ void attn_stage_x(const AttnArgs& A, int64_t tile, float* X, int ldx) {
     constexpr int TP = R / AS_K;
     const int d = A.c1 + A.c2;
-    const int64_t npts = A.batch * A.n;
-    for (int e = threadIdx.x; e < R * d; e += 256) {
-        const int row = e / d, col = e - row * d;
-        const int64_t pt = tile * TP + row / AS_K;
+    const uint32_t npts = (uint32_t)(A.batch * A.n), n = (uint32_t)A.n;
+    const uint32_t pt0 = (uint32_t)tile * TP;
+    int row = (int)threadIdx.x / d, col = (int)threadIdx.x - row * d;
+    const int drow = 256 / d, dcol = 256 - drow * d;
+    for (; row < R; ) {
+        const uint32_t pt = pt0 + (uint32_t)(row / AS_K);
         float v = 0.f;
         if (pt < npts) {
             const int kk = row % AS_K;
             if (col < A.c1) {
-                const int64_t b = pt / A.n;
-                const int64_t src = A.idx[pt * AS_K + kk];
-                if (src >= 0 && src < A.n) v = A.f[(b * A.n + src) * A.c1 + col];
+                const uint32_t b = pt / n;
+                const int64_t src = A.idx[(int64_t)pt * AS_K + kk];
+                if (src >= 0 && src < A.n) v = A.f[((int64_t)b * A.n + src) * A.c1 + col];
             } else {
-                v = A.enc[(pt * AS_K + kk) * A.c2 + (col - A.c1)];
+                v = A.enc[((int64_t)pt * AS_K + kk) * A.c2 + (col - A.c1)];
             }
         }
         X[row * ldx + col] = v;
+        row += drow; col += dcol;
+        if (col >= d) { col -= d; ++row; }
     }
 }
 
@@ -298,7 +330,8 @@ __device__ __forceinline__ void attn_scores(const AttnArgs& A, const float* X, i
         const float* xr = X + (rt * 32 + cl) * ldx + hi;
         const float* wp = A.wt + (int64_t)hi * d + col;
         tr_f32x16 acc = tr_zero16();
-        for (int kk = 0; kk < d; kk += 2) {
+#pragma unroll 8
+        for (int kk = 0; kk < d; kk += 2) {                           // (8 rows of W^T in flight per wave: bound by their L2 latency)
             const float av = xr[kk];
             const float bv = cok ? wp[(int64_t)kk * d] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
@@ -346,96 +379,132 @@ attn_stage_fwd_k(AttnArgs A, int64_t n_tiles) {
     }
 }
 
-template <int R>
-__global__ void __launch_bounds__(256)
-attn_stage_bwd_k(AttnArgs A, int64_t n_tiles, int groups) {
+// DMAX = the widest stage of the class the kernel is instantiated for (16 / 64 / 128 / 256): it sizes the LDS (25 / 25 / 41 / 62 KB ->
+// 6 / 6 / 3 / 2 workgroups per CU) and picks the tile height (64 rows for d <= 16, 32 above)
+template <int DMAX>
+__global__ void __launch_bounds__(256) ML3D_WAVES_PER_SIMD(2)
+attn_stage_bwd_k(AttnArgs A, int64_t n_tiles, int groups, float* __restrict__ gw_partial) {
+    constexpr int R = DMAX <= 16 ? 64 : 32;
+    constexpr int C1MAX = DMAX <= 128 ? DMAX : AS_C1MAX;
     constexpr int TP = R / AS_K;
-    __shared__ float lds[AS_LDS_FLOATS];
-    const int d = A.c1 + A.c2, ldx = d | 1;
-    float* X = lds;
-    float* S = lds + R * ldx;
+    constexpr int RT = R / 32;
+    constexpr int NX = (RT * ((DMAX + 31) / 32) + 3) / 4;            // gx accumulator tiles per wave (1, 1, 1, 2)
+    __shared__ float lds[R * (DMAX + 1) + R * (AS_CB + 1) + R * (C1MAX + 1)];
+    const int d = A.c1 + A.c2, ldx = d | 1, ldg = A.c1 | 1;
+    float* X = lds;                                                   // [R][ldx]   the staged rows
+    float* S = X + R * ldx;                                           // [R][65]    scores, then gs, of the current column block
+    float* GD = S + R * (AS_CB + 1);                                  // [R][ldg]   the direct term p g of the f columns
     const int64_t npts = A.batch * A.n;
-    const int n_cb = (d + AS_CB - 1) / AS_CB;
-    const int cbi = blockIdx.x % n_cb, grp = blockIdx.x / n_cb;
-    const int cb0 = cbi * AS_CB;
+    const int grp = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hi = lane >> 5, cl = lane & 31;
     const int t = threadIdx.x;
     const int n_jt = (d + 31) / 32;                                   // 32-column tiles across d
-    // gW block [64 x d]: tiles (it in 0..1, jt in 0..n_jt-1), tile q = it * n_jt + jt on wave q % 4, slot q / 4
-    tr_f32x16 gw[AS_MAXT];
+    float* gwp = gw_partial + (int64_t)grp * d * d;                   // this workgroup's private [d x d] partial of grad_weight
+    float gb[AS_DMAX / AS_CB];                                        // thread t < TP * 64 owns score columns cb0 + t % 64
 #pragma unroll
-    for (int q = 0; q < AS_MAXT; ++q) gw[q] = tr_zero16();
-    float gb = 0.f;                                                   // thread t < TP * 64 owns score column cb0 + t % 64
+    for (int q = 0; q < AS_DMAX / AS_CB; ++q) gb[q] = 0.f;
     for (int64_t tile = grp; tile < n_tiles; tile += groups) {
+        const bool first = tile == grp;
         attn_stage_x<R>(A, tile, X, ldx);
+        tr_f32x16 gx[NX];                                        // gx tiles (rt, jt): q = rt * n_jt + jt on wave q % 4, slot q / 4
+#pragma unroll
+        for (int q = 0; q < NX; ++q) gx[q] = tr_zero16();
         __syncthreads();
-        attn_scores<R>(A, X, ldx, cb0, S);
-        __syncthreads();
-        if (t < TP * AS_CB) {
-            const int tp = t / AS_CB, c = t - tp * AS_CB, col = cb0 + c;
-            const int64_t pt = tile * TP + tp;
-            const bool on = col < d && pt < npts;
-            float sv[AS_K], mx = -3.0e38f;
+#pragma unroll 1
+        for (int cbi = 0; cbi * AS_CB < d; ++cbi) {
+            const int cb0 = cbi * AS_CB;
+            attn_scores<R>(A, X, ldx, cb0, S);
+            __syncthreads();
+            if (t < TP * AS_CB) {
+                const int tp = t / AS_CB, c = t - tp * AS_CB, col = cb0 + c;
+                const int64_t pt = tile * TP + tp;
+                const bool on = col < d && pt < npts;
+                float sv[AS_K], mx = -3.0e38f;
 #pragma unroll
-            for (int k = 0; k < AS_K; ++k) { sv[k] = S[(tp * AS_K + k) * (AS_CB + 1) + c]; mx = fmaxf(mx, sv[k]); }
-            float sum = 0.f;
+                for (int k = 0; k < AS_K; ++k) { sv[k] = S[(tp * AS_K + k) * (AS_CB + 1) + c]; mx = fmaxf(mx, sv[k]); }
+                float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < AS_K; ++k) { sv[k] = expf(sv[k] - mx); sum += sv[k]; }
-            const float g = on ? A.gout[pt * d + col] : 0.f, o = on ? A.out[pt * d + col] : 0.f;
-            const int64_t b = on ? pt / A.n : 0;
+                for (int k = 0; k < AS_K; ++k) { sv[k] = expf(sv[k] - mx); sum += sv[k]; }
+                const float g = on ? A.gout[pt * d + col] : 0.f, o = on ? A.out[pt * d + col] : 0.f;
+                float gbs = 0.f;
 #pragma unroll
-            for (int k = 0; k < AS_K; ++k) {
-                const float pg = on ? sv[k] / sum * g : 0.f;
-                const float gs = pg * (X[(tp * AS_K + k) * ldx + (on ? col : 0)] - o);
-                S[(tp * AS_K + k) * (AS_CB + 1) + c] = on ? gs : 0.f;
-                gb += on ? gs : 0.f;
-                if (on) {                                              // the direct term d out / d x = p g on the block's own columns
-                    if (col < A.c1) {
-                        const int64_t src = A.idx[pt * AS_K + k];
-                        if (src >= 0 && src < A.n) atomicAdd(A.gf + (b * A.n + src) * A.c1 + col, pg);
-                    } else {
-                        atomicAdd(A.genc + (pt * AS_K + k) * A.c2 + (col - A.c1), pg);
+                for (int k = 0; k < AS_K; ++k) {
+                    const int row = tp * AS_K + k;
+                    const float pg = on ? sv[k] / sum * g : 0.f;
+                    const float gs = on ? pg * (X[row * ldx + col] - o) : 0.f;
+                    S[row * (AS_CB + 1) + c] = gs;
+                    gbs += gs;
+                    if (on) {                                          // the direct term d out / d x = p g
+                        if (col < A.c1) GD[row * ldg + col] = pg;      // (f columns: joins gx in LDS before the scatter)
+                        else A.genc[(pt * AS_K + k) * A.c2 + (col - A.c1)] = pg;     // (enc columns: gx is added to it below)
                     }
                 }
-            }
-        }
-        __syncthreads();
-        // ---- gW[cb0 + i, j] += sum_rows gs[row, i] x[row, j]
 #pragma unroll
-        for (int q = 0; q < AS_MAXT; ++q) {
-            const int tq = q * 4 + wave;
-            if (tq < 2 * n_jt) {                                      // (wave-uniform)
+                for (int q = 0; q < AS_DMAX / AS_CB; ++q) gb[q] += q == cbi ? gbs : 0.f;
+            }
+            __syncthreads();
+            // ---- gW[cb0 + i, j] += sum_rows gs[row, i] x[row, j]: the partial lives in the workgroup's own [d x d] block of
+            //      gw_partial (L2-resident; plain loads / stores, no atomics); tiles (it in 0..1, jt) on wave q % 4
+#pragma unroll 1
+            for (int tq = wave; tq < 2 * n_jt; tq += 4) {
                 const int it = tq / n_jt, jt = tq - it * n_jt;
-                const bool jok = jt * 32 + cl < d;
+                const int j = jt * 32 + cl;
+                const bool jok = j < d;
                 const float* sp = S + hi * (AS_CB + 1) + it * 32 + cl;
-                const float* xp = X + hi * ldx + (jok ? jt * 32 + cl : 0);
-                tr_f32x16 acc = gw[q];
+                const float* xp = X + hi * ldx + (jok ? j : 0);
+                tr_f32x16 acc = tr_zero16();
+                if (!first && jok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = cb0 + it * 32 + tr_row(r, hi);
+                        if (i < d) acc[r] = gwp[(int64_t)i * d + j];
+                    }
+                }
+#pragma unroll 4
                 for (int r = 0; r < R; r += 2) {
                     const float av = sp[r * (AS_CB + 1)];
                     const float bv = jok ? xp[r * ldx] : 0.f;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
                 }
-                gw[q] = acc;
-            }
-        }
-        // ---- gx[row, j] = sum_c gs[row, c] W[cb0 + c, j]  -> grad_f (through idx) / grad_enc, atomics
-        constexpr int RT = R / 32;
+                if (jok) {
 #pragma unroll
-        for (int q = 0; q < AS_MAXT; ++q) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = cb0 + it * 32 + tr_row(r, hi);
+                        if (i < d) gwp[(int64_t)i * d + j] = acc[r];
+                    }
+                }
+            }
+            // ---- gx[row, j] += sum_c gs[row, c] W[cb0 + c, j]
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                const int tq = q * 4 + wave;
+                if (tq < RT * n_jt) {                                 // (wave-uniform)
+                    const int rt = tq / n_jt, jt = tq - rt * n_jt;
+                    const int j = jt * 32 + cl;
+                    const bool jok = j < d;
+                    const float* sp = S + (rt * 32 + cl) * (AS_CB + 1) + hi;
+                    tr_f32x16 acc = gx[q];
+#pragma unroll 8
+                    for (int cc = 0; cc < AS_CB; cc += 2) {               // (8 rows of W in flight per wave: the loop is bound by their L2 latency)
+                        const float av = sp[cc];
+                        const bool wok = jok && cb0 + cc + hi < d;
+                        const float bv = wok ? A.w[(int64_t)(cb0 + cc + hi) * d + j] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                    }
+                    gx[q] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- gx out: enc columns add to the direct term stored above (plain read-modify-write: every element has one owner),
+        //      f columns + their direct term scatter through idx with atomics
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
             const int tq = q * 4 + wave;
-            if (tq < RT * n_jt) {                                     // (wave-uniform)
+            if (tq < RT * n_jt) {
                 const int rt = tq / n_jt, jt = tq - rt * n_jt;
                 const int j = jt * 32 + cl;
-                const bool jok = j < d;
-                const float* sp = S + (rt * 32 + cl) * (AS_CB + 1) + hi;
-                tr_f32x16 acc = tr_zero16();
-                for (int cc = 0; cc < AS_CB; cc += 2) {
-                    const float av = sp[cc];
-                    const bool wok = jok && cb0 + cc + hi < d;
-                    const float bv = wok ? A.w[(int64_t)(cb0 + cc + hi) * d + j] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-                }
-                if (jok) {
+                if (j < d) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rt * 32 + tr_row(r, hi);
@@ -444,9 +513,11 @@ attn_stage_bwd_k(AttnArgs A, int64_t n_tiles, int groups) {
                             const int kk = row % AS_K;
                             if (j < A.c1) {
                                 const int64_t src = A.idx[pt * AS_K + kk];
-                                if (src >= 0 && src < A.n) atomicAdd(A.gf + ((pt / A.n) * A.n + src) * A.c1 + j, acc[r]);
+                                const int64_t b = (int64_t)((uint32_t)pt / (uint32_t)A.n);
+                                if (src >= 0 && src < A.n) atomicAdd(A.gf + (b * A.n + src) * A.c1 + j, gx[q][r] + GD[row * ldg + j]);
                             } else {
-                                atomicAdd(A.genc + (pt * AS_K + kk) * A.c2 + (j - A.c1), acc[r]);
+                                float* dst = A.genc + (pt * AS_K + kk) * A.c2 + (j - A.c1);
+                                *dst = *dst + gx[q][r];
                             }
                         }
                     }
@@ -455,23 +526,23 @@ attn_stage_bwd_k(AttnArgs A, int64_t n_tiles, int groups) {
         }
         __syncthreads();
     }
-    // ---- the workgroup's share of gW / gbias
+    if (A.gbias && t < TP * AS_CB) {
 #pragma unroll
-    for (int q = 0; q < AS_MAXT; ++q) {
-        const int tq = q * 4 + wave;
-        if (tq < 2 * n_jt) {
-            const int it = tq / n_jt, jt = tq - it * n_jt;
-            const int j = jt * 32 + cl;
-            if (j < d) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = cb0 + it * 32 + tr_row(r, hi);
-                    if (i < d) atomicAdd(A.gw + (int64_t)i * d + j, gw[q][r]);
-                }
-            }
-        }
+        for (int q = 0; q < AS_DMAX / AS_CB; ++q)
+            if (q * AS_CB + t % AS_CB < d) atomicAdd(A.gbias + q * AS_CB + t % AS_CB, gb[q]);
     }
-    if (A.gbias && t < TP * AS_CB && cb0 + t % AS_CB < d) atomicAdd(A.gbias + cb0 + t % AS_CB, gb);
+}
+
+// out[c][e] = sum of partial[g][e] over the groups g of chunk c (32 groups per chunk): one level of the tree that adds up the
+// persistent workgroups' private partial sums -- coalesced, fixed order (deterministic)
+__global__ void __launch_bounds__(256)
+sum_partials_k(const float* __restrict__ partial, int64_t elems, int groups, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    const int g0 = blockIdx.y * 32, g1 = g0 + 32 < groups ? g0 + 32 : groups;
+    float s = 0.f;
+    for (int g = g0; g < g1; ++g) s += partial[(int64_t)g * elems + e];
+    out[(int64_t)blockIdx.y * elems + e] = s;
 }
 
 static inline unsigned tr_blocks(int64_t total, int per, unsigned cap) {
@@ -496,8 +567,8 @@ extern "C" int ml3d_gemm_tn(const float* a, int64_t lda, const float* b, int64_t
     if (!a || !b) return ML3D_E_INVALID;
     const int tiles_i = (k + 63) / 64, tiles_j = (n + 63) / 64;
     const int64_t ntiles = (int64_t)tiles_i * tiles_j;
-    int64_t slices = (4096 + ntiles - 1) / ntiles;                      // ~4096 waves in flight
-    const int64_t max_slices = (m + 63) / 64;
+    int64_t slices = (2048 + ntiles - 1) / ntiles;                      // ~2048 waves in flight
+    const int64_t max_slices = (m + 127) / 128;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     int64_t rps = (m + slices - 1) / slices;
@@ -507,7 +578,7 @@ extern "C" int ml3d_gemm_tn(const float* a, int64_t lda, const float* b, int64_t
     hipLaunchKernelGGL(gemm_tn_k, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a, lda, b, ldb, m, k, n, rps, tiles_j, units, c, ldc);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (col_sums_a) {
-        const unsigned nb = tr_blocks(m, 256, 512);
+        const unsigned nb = tr_blocks(m, 256, 2048);
         const int64_t rpb = (m + nb - 1) / nb;
         BnRef none = {};
         hipLaunchKernelGGL((col_reduce_k<0>), dim3(nb), dim3(256), 0, st, a, lda, m, k, rpb, none, col_sums_a, (double*)nullptr);
@@ -531,7 +602,7 @@ extern "C" int ml3d_batchnorm_train_forward(const float* x, int64_t rows, int ch
     hipStream_t st = (hipStream_t)stream;
     double* sums = bn_ws(workspace);
     zero_async(sums, sizeof(double) * 2 * (size_t)channels, st);
-    const unsigned nb = tr_blocks(rows, 256, 512);
+    const unsigned nb = tr_blocks(rows, 256, 2048);
     const int64_t rpb = (rows + nb - 1) / nb;
     BnRef none = {};
     hipLaunchKernelGGL((col_reduce_k<1>), dim3(nb), dim3(256), 0, st, x, (int64_t)channels, rows, channels, rpb, none, (float*)nullptr, sums);
@@ -552,7 +623,7 @@ extern "C" int ml3d_batchnorm_train_backward(const float* x, const float* y, con
     hipStream_t st = (hipStream_t)stream;
     double* sums = bn_ws(workspace);
     zero_async(sums, sizeof(double) * 2 * (size_t)channels, st);
-    const unsigned nb = tr_blocks(rows, 256, 512);
+    const unsigned nb = tr_blocks(rows, 256, 2048);
     const int64_t rpb = (rows + nb - 1) / nb;
     BnRef ref = {y, grad_y, save_mean, save_invstd, act, slope};
     hipLaunchKernelGGL((col_reduce_k<2>), dim3(nb), dim3(256), 0, st, x, (int64_t)channels, rows, channels, rpb, ref, (float*)nullptr, sums);
@@ -610,7 +681,8 @@ extern "C" int ml3d_gather_pool_backward(const float* features, int64_t n_suppor
 static int attn_check(int64_t batch, int64_t n, int k, int c1, int c2) {
     if (batch < 0 || n < 0 || c1 <= 0 || c2 <= 0) return ML3D_E_INVALID;
     const int d = c1 + c2;
-    if (k != AS_K || d > AS_DMAX || (d & 1)) return ML3D_E_UNSUPPORTED;
+    if (batch * n >= ((int64_t)1 << 31) / 16) return ML3D_E_UNSUPPORTED;           // (32-bit point / row arithmetic inside the kernels)
+    if (k != AS_K || d > AS_DMAX || (d & 1) || (d > 128 && c1 > AS_C1MAX)) return ML3D_E_UNSUPPORTED;
     return 0;
 }
 
@@ -634,30 +706,64 @@ extern "C" int ml3d_randla_attention_stage(const float* f, const float* enc, con
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+static int attn_bwd_plan(int64_t npts, int d, int64_t* tiles) {
+    *tiles = d <= 16 ? (npts + 3) / 4 : (npts + 1) / 2;
+    int64_t g = *tiles < 2048 ? *tiles : 2048;
+    const int64_t cap = ((int64_t)160 << 20) / ((int64_t)d * d * 4);    // <= 160 MB of private partials (640 workgroups at d = 256)
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+extern "C" size_t ml3d_randla_attention_stage_backward_workspace_bytes(int64_t batch, int64_t n, int c1, int c2) {
+    if (batch <= 0 || n <= 0 || c1 <= 0 || c2 <= 0) return 0;
+    const int d = c1 + c2;
+    int64_t tiles;
+    const int64_t groups = attn_bwd_plan(batch * n, d, &tiles);
+    return sizeof(float) * (size_t)(groups + (groups + 31) / 32) * (size_t)d * (size_t)d + 256;
+}
+
 extern "C" int ml3d_randla_attention_stage_backward(const float* f, const float* enc, const int32_t* neighbor_idx, const float* weight,
                                                     const float* weight_t, const float* bias, const float* out, const float* grad_out,
                                                     int64_t batch, int64_t n, int k, int c1, int c2, float* grad_f, float* grad_enc,
-                                                    float* grad_weight, float* grad_bias, void* stream) {
+                                                    float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
+                                                    void* stream) {
     const int rc = attn_check(batch, n, k, c1, c2);
     if (rc) return rc;
     if (!grad_weight) return ML3D_E_INVALID;
     const int d = c1 + c2;
     hipStream_t st = (hipStream_t)stream;
-    zero_async(grad_weight, sizeof(float) * (size_t)d * (size_t)d, st);
     if (grad_bias) zero_async(grad_bias, sizeof(float) * (size_t)d, st);
     const int64_t npts = batch * n;
-    if (npts == 0) return 0;
-    if (!f || !enc || !neighbor_idx || !weight || !weight_t || !out || !grad_out || !grad_f || !grad_enc) return ML3D_E_INVALID;
+    if (npts == 0) { zero_async(grad_weight, sizeof(float) * (size_t)d * (size_t)d, st); return 0; }
+    if (!f || !enc || !neighbor_idx || !weight || !weight_t || !out || !grad_out || !grad_f || !grad_enc || !workspace) return ML3D_E_INVALID;
+    if (workspace_bytes < ml3d_randla_attention_stage_backward_workspace_bytes(batch, n, c1, c2)) return ML3D_E_WORKSPACE;
     zero_async(grad_f, sizeof(float) * (size_t)npts * (size_t)c1, st);
-    zero_async(grad_enc, sizeof(float) * (size_t)npts * AS_K * (size_t)c2, st);
     AttnArgs A = {};
     A.f = f; A.enc = enc; A.idx = neighbor_idx; A.w = weight; A.wt = weight_t; A.bias = bias; A.batch = batch; A.n = n; A.c1 = c1; A.c2 = c2;
     A.out = const_cast<float*>(out); A.gout = grad_out; A.gf = grad_f; A.genc = grad_enc; A.gw = grad_weight; A.gbias = grad_bias;
-    const int n_cb = (d + AS_CB - 1) / AS_CB;
-    const int64_t tiles = d <= 128 ? (npts + 3) / 4 : (npts + 1) / 2;
-    int groups = (int)(tiles < 512 ? tiles : 512);
-    if (groups < 1) groups = 1;
-    if (d <= 128) hipLaunchKernelGGL((attn_stage_bwd_k<64>), dim3((unsigned)(groups * n_cb)), dim3(256), 0, st, A, tiles, groups);
-    else hipLaunchKernelGGL((attn_stage_bwd_k<32>), dim3((unsigned)(groups * n_cb)), dim3(256), 0, st, A, tiles, groups);
+    float* partial = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int64_t tiles;
+    const int groups = attn_bwd_plan(npts, d, &tiles);
+    const dim3 grid((unsigned)groups), block(256);
+    if (d <= 16) hipLaunchKernelGGL((attn_stage_bwd_k<16>), grid, block, 0, st, A, tiles, groups, partial);
+    else if (d <= 64) hipLaunchKernelGGL((attn_stage_bwd_k<64>), grid, block, 0, st, A, tiles, groups, partial);
+    else if (d <= 128) hipLaunchKernelGGL((attn_stage_bwd_k<128>), grid, block, 0, st, A, tiles, groups, partial);
+    else hipLaunchKernelGGL((attn_stage_bwd_k<256>), grid, block, 0, st, A, tiles, groups, partial);
+    // the private partials -> grad_weight: 32 at a time, then the <= 64 chunk sums
+    const int64_t elems = (int64_t)d * d;
+    const int chunks = (groups + 31) / 32;
+    const unsigned eb = (unsigned)((elems + 255) / 256);
+    if (chunks == 1) {
+        hipLaunchKernelGGL(sum_partials_k, dim3(eb, 1), dim3(256), 0, st, partial, elems, groups, grad_weight);
+    } else {
+        float* level1 = partial + (int64_t)groups * elems;
+        hipLaunchKernelGGL(sum_partials_k, dim3(eb, (unsigned)chunks), dim3(256), 0, st, partial, elems, groups, level1);
+        if (chunks <= 32) {
+            hipLaunchKernelGGL(sum_partials_k, dim3(eb, 1), dim3(256), 0, st, level1, elems, chunks, grad_weight);
+        } else {                                                        // (chunks <= 64: the first-level buffer is free again)
+            hipLaunchKernelGGL(sum_partials_k, dim3(eb, (unsigned)((chunks + 31) / 32)), dim3(256), 0, st, level1, elems, chunks, partial);
+            hipLaunchKernelGGL(sum_partials_k, dim3(eb, 1), dim3(256), 0, st, partial, elems, (chunks + 31) / 32, grad_weight);
+        }
+    }
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }

@@ -87,7 +87,7 @@ SYMBOLS = [
     "ml3d_gemm_tn",
     "ml3d_batchnorm_train_workspace_bytes", "ml3d_batchnorm_train_forward", "ml3d_batchnorm_train_backward",
     "ml3d_gather_rows", "ml3d_scatter_add_rows", "ml3d_gather_pool_backward",
-    "ml3d_randla_attention_stage", "ml3d_randla_attention_stage_backward",
+    "ml3d_randla_attention_stage", "ml3d_randla_attention_stage_backward_workspace_bytes", "ml3d_randla_attention_stage_backward",
 ]
 
 
@@ -255,7 +255,9 @@ def bind(lib):
     lib.ml3d_randla_attention_stage.restype = C.c_int
     lib.ml3d_randla_attention_stage.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp]
     lib.ml3d_randla_attention_stage_backward.restype = C.c_int
-    lib.ml3d_randla_attention_stage_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.ml3d_randla_attention_stage_backward_workspace_bytes.restype = sz
+    lib.ml3d_randla_attention_stage_backward_workspace_bytes.argtypes = [i64, i64, i32, i32]
+    lib.ml3d_randla_attention_stage_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.ml3d_vote_update.restype = C.c_int
     lib.ml3d_vote_update.argtypes = [vp, vp, i64, i32, f32, vp, i64, vp]
     lib.ml3d_argmax_labels.restype = C.c_int

@@ -201,7 +201,7 @@ class GatherPoolFunction(torch.autograd.Function):
 
 def attention_stage_supported(k, c1, c2):
     d = c1 + c2
-    return k == 16 and d <= 256 and d % 2 == 0
+    return k == 16 and d <= 256 and d % 2 == 0 and (d <= 128 or c1 <= 160)
 
 
 class AttentionStageFunction(torch.autograd.Function):
@@ -243,10 +243,12 @@ class AttentionStageFunction(torch.autograd.Function):
         g = _f32(g)
         gf, genc, gw = torch.empty_like(f), torch.empty_like(enc), torch.empty_like(w)
         gb = torch.empty(d, dtype=torch.float32, device=f.device) if ctx.has_bias else None
+        wsb = lib.ml3d_randla_attention_stage_backward_workspace_bytes(B, n, c1, c2)
+        ws = _gates._ws(wsb, f.device)
         with torch.cuda.device(f.device):
             rc = lib.ml3d_randla_attention_stage_backward(f.data_ptr(), enc.data_ptr(), idx.data_ptr(), w.data_ptr(), wt.data_ptr(),
                                                           b.data_ptr() if ctx.has_bias else None, out.data_ptr(), g.data_ptr(), B, n, K,
                                                           c1, c2, gf.data_ptr(), genc.data_ptr(), gw.data_ptr(),
-                                                          None if gb is None else gb.data_ptr(), _stream())
+                                                          None if gb is None else gb.data_ptr(), ws.data_ptr(), wsb, _stream())
         _abi.check(rc, "ml3d_randla_attention_stage_backward")
         return gf, genc, None, gw, gb

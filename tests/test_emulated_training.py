@@ -108,7 +108,8 @@ for mode in ("max", "closest"):
     x.grad = None
 print("gathers ok")
 # attention stage
-for B, n, c1, c2, bias in ((2, 37, 8, 8, True), (1, 130, 32, 32, True), (2, 9, 64, 64, False), (1, 5, 128, 128, True), (1, 21, 6, 10, True)):
+for B, n, c1, c2, bias in ((2, 37, 8, 8, True), (1, 130, 32, 32, True), (2, 9, 64, 64, False), (1, 5, 128, 128, True), (1, 21, 6, 10, True),
+                           (1, 2100, 8, 8, True), (2, 530, 40, 56, True), (1, 4200, 8, 8, False)):      # (the last three: more tiles than persistent workgroups; 17 and 33 chunks of private partial sums)
     K, d = 16, c1 + c2
     f = T(rng.standard_normal((B, n, c1))).requires_grad_(True)
     enc = T(rng.standard_normal((B, n, K, c2))).requires_grad_(True)

@@ -193,7 +193,8 @@ def test_both_convolution_paths_give_the_same_detections(monkeypatch):
         d = (a - b).abs().max().item()
         assert d <= 5e-5, d
     # detections: the maps differ by a few 1e-5, so a candidate at the nms_pre cut or a pair at the IoU threshold may fall on the other
-    # side -- every f32 detection must have a bf16x3 twin (same label, score within 1e-4, box within 1e-3) except at most 1 % of them
+    # side -- every f32 detection must have a bf16x3 twin (same label, score within 1e-4, box within 2e-4 relative) except at most 1 % of them
+    # (measured, tools/r05_calls/diag_two_pipes.py on 6 sweeps: identical labels and counts, scores within 2e-6, boxes within 3e-5 relative)
     for i in range(len(clouds)):
         bf, sf, lf = (res["f32"][1][k][i].cpu() for k in range(3))
         bb, sb, lb = (res["bf16x3"][1][k][i].cpu() for k in range(3))
@@ -201,7 +202,8 @@ def test_both_convolution_paths_give_the_same_detections(monkeypatch):
         unmatched = 0
         for j in range(len(lf)):
             same = (lb == lf[j]).nonzero().flatten()
-            ok = len(same) > 0 and bool((((bb[same] - bf[j]).abs().amax(1) <= 1e-3) & ((sb[same] - sf[j]).abs() <= 1e-4)).any())
+            rel = (bb[same] - bf[j]).abs() / bf[j].abs().clamp(min=1.0)          # (random-init heads: exp(d) sizes of hundreds of metres)
+            ok = len(same) > 0 and bool(((rel.amax(1) <= 2e-4) & ((sb[same] - sf[j]).abs() <= 1e-4)).any())
             unmatched += 0 if ok else 1
         assert unmatched <= max(1, len(lf) // 100), (i, unmatched, len(lf))
     monkeypatch.setenv("ML3D_PP_CONV", "fp8")

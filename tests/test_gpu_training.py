@@ -325,7 +325,8 @@ def test_fused_attention_stage_matches_the_unfused_formulation(B, n, c1, c2, bia
     out.backward(gy)
     torch.cuda.synchronize()
     # nothing of size [B, N, K, d] was allocated by the two passes: the peak stays below ONE such tensor + the outputs they return
-    assert torch.cuda.max_memory_allocated() - base <= 4 * (B * n * K * d + 2 * B * n * K * c2 + 4 * B * n * d) + (8 << 20)
+    # (+ the backward's transient workspace, which does not grow with the number of points)
+    assert torch.cuda.max_memory_allocated() - base <= 4 * (B * n * K * d + 2 * B * n * K * c2 + 4 * B * n * d) + (176 << 20)         # (+ the <= 165 MB transient workspace of private grad_weight partials)
     assert _close(out, ref.float(), 2e-5), float((out - ref.float()).abs().max())
     for name, got, wnt in zip("f enc w b".split(), [f.grad, enc.grad, w.grad, None if b is None else b.grad], want):
         if wnt is not None:

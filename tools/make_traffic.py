@@ -23,7 +23,7 @@ def table(path):
 OPS = {   # bench_models.py's roofline key -> (kernel-name substrings that make up the op, units per launch); tables from
           # `rocprofv3 --pmc ... -- python tools/roofline_ops.py kp|pp` (only that op runs there)
     "kpconv_block_32_32": (("kp_agg_gemm32",), 64),
-    "pp_conv3x3_64": (("gemm_tile",), 16),
+    "pp_conv3x3_64": (("gemm_tile", "conv3x3s1_bf3"), 16),      # (round 5: the window-staged bf16x3 kernel on the default path)
 }
 PRIMS = {  # HBM-bound primitives (tools/roofline_ops.py radius|subsample|voxelize|pillars): EVERY kernel the op launches counts
            # -- grid build, scans, sorts, fills, torch's own helper kernels -- except the names excluded here (the H2D copies of the
@@ -31,7 +31,7 @@ PRIMS = {  # HBM-bound primitives (tools/roofline_ops.py radius|subsample|voxeli
     "kp_radius_dense": (None, ("copyBuffer",), 64),
     "kp_subsample": (None, ("copyBuffer",), 64),
     "pp_voxelize": (None, ("copyBuffer", "CatArray"), 8),       # (torch.cat of the sweeps happens before the op, once)
-    "pp_pillar_features": (("pillar_pfn", "pfn_next", "fillBufferAligned"), (), 8),
+    "pp_pillar_features": (("pillar_pfn", "pfn_next", "fillBufferAligned", "grid_zero"), (), 8),
 }
 
 

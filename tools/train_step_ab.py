@@ -1,7 +1,7 @@
 """GPU box: one training step (forward + loss + backward) of the two segmentation models at their YAML sizes, ML3D_TRAIN_OPS=hip
 (csrc/train.hip: Linear / BatchNorm / gathers / fused attention stages, both passes) against =torch (those modules on torch's autograd):
 ms per step (median of 5 after 2 warm-up steps) and the peak of torch's allocator during a step.
-usage: python tools/train_step_ab.py [randlanet|kpconv] [batch]"""
+usage: python tools/train_step_ab.py [randlanet|kpconv] [batch] [paths, e.g. hip or torch,hip]"""
 import os
 import sys
 import time
@@ -55,7 +55,8 @@ else:
     what = "KPFCNN Toronto3D, %d spheres, %d points" % (B, sum(len(s) for s in spheres))
 m.train()
 print(what)
-for path in ("torch", "hip", "torch", "hip"):
+paths = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("torch", "hip", "torch", "hip")
+for path in paths:
     os.environ["ML3D_TRAIN_OPS"] = path
     times = []
     for it in range(7):
