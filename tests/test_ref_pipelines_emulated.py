@@ -59,7 +59,11 @@ def test_reference_run_pipeline_script_trains_the_native_models_like_the_referen
     optimizer.step, validation, checkpoint) on the native RandLA-Net and KPFCNN -- shrunken YAML sizes, the library emulated --
     against the reference side: the first step's loss to 2e-4, later steps and the epoch summary within the drift of a few
     optimisation steps (tools/run_pipeline_e2e.py --compare; the MI355X run at the YAML sizes is
-    profiles/r04_run_pipeline_train_e2e.log)."""
+    profiles/r04_run_pipeline_train_e2e.log).  The later-step bounds are 6e-2 / 8e-2 here: with 500-point batches the deepest KPConv
+    levels hold 1-3 points, BatchNorm over them amplifies a float32 rounding difference ~2500x within three SGD steps -- the torch-autograd
+    path (bit-identical CPU kernels to the reference's, 1e-6 apart after one forward) drifts 3.4e-3, the HIP training ops (their own
+    summation orders, 1e-5 apart) 2.5e-2; gradients of both are pinned to the reference at 1e-3 per tensor by tests/test_emulated_training.py,
+    and on batches with >= 10 points per level the two paths stay within 1e-6 over four steps (profiles/r05_train_e2e_sensitivity.log)."""
     work, out = str(tmp_path / "work"), str(tmp_path / "out")
     emu.lib()
     tool = os.path.join(ROOT, "tools", "run_pipeline_e2e.py")
@@ -69,6 +73,7 @@ def test_reference_run_pipeline_script_trains_the_native_models_like_the_referen
         r = subprocess.run([sys.executable, tool, "--family", "all", "--split", "train", "--small", "--ref", REF, "--work", work,
                             "--out", out] + side, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
-    r = subprocess.run([sys.executable, tool, "--compare", out, out], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, tool, "--compare", out, out, "--later-tol", "6e-2", "--summary-tol", "8e-2"], cwd="/tmp", env=env,
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "[compare] OK" in r.stdout, r.stdout[-4000:]
     assert "randlanet train.log: 4 step losses" in r.stdout and "kpconv train.log: 4 step losses" in r.stdout
