@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5: per-column reductions with ~32 elements per thread (KPConv coarse levels): training tests, KPFCNN + RandLANet step, kernel table
+cd $GRAFT_REPO_ROOT
+exec < /dev/null
+export TMPDIR=/tmp
+O=gpurun_out/r5zv
+mkdir -p $O
+( timeout 200 python -m pytest tests/test_gpu_training.py -q 2>&1 | tail -1 ) > $O/pytest_training.log; cat $O/pytest_training.log
+( timeout 100 python tools/train_step_ab.py randlanet 4 hip,hip 2>&1 | grep -v "return float" | tail -2 ) > $O/train_ab_randlanet.log; cat $O/train_ab_randlanet.log
+( timeout 100 python tools/train_step_ab.py kpconv 8 hip,hip 2>&1 | grep -v "return float" | tail -4 ) > $O/train_ab_kpconv.log; cat $O/train_ab_kpconv.log
+rm -rf /tmp/kt; (cd /tmp && timeout 100 rocprofv3 --kernel-trace --stats -f csv -d /tmp/kt -o tr -- python $GRAFT_REPO_ROOT/tools/train_step_ab.py kpconv 8 hip > /tmp/kt.log 2>&1)
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/r05_train_kpconv_hip_kernel_stats.csv
+head -10 $O/r05_train_kpconv_hip_kernel_stats.csv | cut -c1-170
