@@ -206,6 +206,7 @@ def run_pointpillars(args, rank, world, dev, dist):
     # 2 x 32: 1451 / 1462, 3 x 24: 1410-1479, 3 x 48: 1453, 4 x 32: 1405 (profiles/r05_pp_lanes_sweep.log)
     B = args.frames_per_step or 32
     n_boxes = [0]
+    last_det = [None]
     last = [None, 0]            # (what rank 0 received for the last delivered step, number of delivered steps)
     overlap = not getattr(args, "no_overlap", False)
     if stub:
@@ -234,6 +235,7 @@ def run_pointpillars(args, rank, world, dev, dist):
         if res is None:
             return
         boxes, scores, labels = res
+        last_det[0] = res
         n_boxes[0] = sum(int(b.shape[0]) for b in boxes)
         if world > 1:
             rows = torch.cat([torch.cat([b, s[:, None], l[:, None].to(b.dtype)], 1) for b, s, l in zip(boxes, scores, labels)])
@@ -296,6 +298,22 @@ def run_pointpillars(args, rank, world, dev, dist):
         t2.restore(); tv.restore(); tp.restore()
         alone[tag] = t2.mean_ms()
         prim_alone[tag] = (tv.mean_ms(), tp.mean_ms(), tv.shapes, tp.shapes)
+    # self-check (outside the timed region): the LAST timed step's detections, produced by the pipelined lanes with their kernels
+    # overlapping on the GPU, against a quiet single-stream pass over the same sweeps (a kernel that is not stable under co-running
+    # kernels shows up here: DESIGN.md 9.10)
+    pipe_check = None
+    try:
+        if overlap and last_det[0] is not None:
+            qb, qs, ql = ([t.cpu() for t in lst] for lst in m.bbox_head.get_bboxes(*m(clouds)))
+            torch.cuda.synchronize()
+            pb, ps, pl = last_det[0]
+            same = [len(a) == len(b) and bool(torch.equal(a.cpu(), b)) for a, b in zip(pl, ql)]
+            ds = max([float((a.cpu() - b).abs().max()) for a, b, ok in zip(ps, qs, same) if ok and len(b)] or [0.0])
+            db = max([float((a.cpu() - b).abs().max()) for a, b, ok in zip(pb, qb, same) if ok and len(b)] or [0.0])
+            pipe_check = {"sweeps": len(ql), "sweeps_with_identical_labels": int(sum(same)), "max_score_delta": ds, "max_box_delta": db,
+                          "what": "last timed step of the two-lane pipeline against a quiet single-stream forward + decode of the same sweeps"}
+    except Exception as e:       # (the check must never cost the bench line)
+        pipe_check = {"error": repr(e)[:200]}
     # one sweep at a time, synchronised per sweep: what a detection request sees (upload + voxelize + forward + decode + NMS + D2H)
     lat = []
     for i in range(24):
@@ -334,6 +352,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                       "boxes_last_step": n_boxes[0], "streams": 2 * lanes if overlap else 1, "lanes": lanes if overlap else 1,
                       "points_per_sweep": [int(len(c)) for c in clouds_np][:4], "parallelism": "frame-parallel x%d" % world},
            "latency_single_sweep_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "sweeps": len(lat)},
+           "pipeline_matches_quiet_run": pipe_check,
            "roofline": {"bound": "mfma", "kernel": "%s (SECOND block 0, 3x3 %d->%d on %dx%d)" % (
                             _rocprof_name("pp_conv3x3_64", "gemm_tile_bf3<ConvLoader2, 64>") if bf3 else "gemm_tile2<ConvLoader2, 64, 32, false>",
                             x.shape[3], Co, OH, OW),
@@ -496,6 +515,26 @@ def run_kpconv(args, rank, world, dev, dist):
         return _stub_line("kpconv", B, args, world, dt, world) if rank == 0 else None
     torch.cuda.synchronize()
     timer.restore()
+    # self-check (outside the timed region): the LAST pipelined batch -- built on its own stream under other batches' forwards -- and its
+    # logits against a quiet rebuild with the same grid rotations + a quiet forward
+    pipe_check = None
+    try:
+        lastres = (rest if isinstance(rest, list) else [rest])[-1] if overlap and rest else None
+        if lastres is not None:
+            pb = lastres.batch
+            qbatch = KPConvBatch(host_pts.to(dev), lens, cfg, rotations=pb.rotations, device=dev)
+            qlogits = m(qbatch)
+            torch.cuda.synchronize()
+            same = all(len(a) == len(b) and all(x.shape == y.shape and bool(torch.equal(x, y)) for x, y in zip(a, b))
+                       for a, b in ((pb.points, qbatch.points), (pb.neighbors, qbatch.neighbors), (pb.pools, qbatch.pools),
+                                    (pb.upsamples, qbatch.upsamples)))
+            pl = lastres.logits
+            pipe_check = {"batch_matrices_identical": bool(same),
+                          "logits_max_delta": float((pl - qlogits).abs().max()) if pl.shape == qlogits.shape else None,
+                          "labels_identical": bool(pl.shape == qlogits.shape and torch.equal(pl.argmax(1), qlogits.argmax(1))),
+                          "what": "last pipelined batch (build + forward under co-running streams) against a quiet rebuild with the same grid rotations + forward"}
+    except Exception as e:       # (the check must never cost the bench line)
+        pipe_check = {"error": repr(e)[:200]}
     in_region = timer.samples_ms()[max(0, args.warmup - 1):]     # (the pipeline runs a step's forward one submit later)
     shapes = timer.shapes
     del _search.KPBATCH_TRACE[:]
@@ -555,6 +594,7 @@ def run_kpconv(args, rank, world, dev, dist):
                       "builds_in_flight": builders if overlap else 1, "forward_streams": fwd_streams if overlap else 1,
                       "parallelism": "frame-parallel x%d" % world},
            "latency_single_sphere_ms": {"median": float(np.median(lat)), "p95": float(np.percentile(lat, 95)), "spheres": len(lat)},
+           "pipeline_matches_quiet_run": pipe_check,
            "roofline": {"bound": "mfma", "kernel": "kp_agg_gemm32 (KPConv %d->%d, %d queries x %d neighbour columns: MFMA aggregation + the [480 x 32] product in one kernel)" % (cin, cout, nq, H),
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
