@@ -211,3 +211,56 @@ rm = dict(m.named_buffers())["encoder_blocks.0.batch_norm.batch_norm.running_mea
 assert np.abs(rm - g["running_mean:encoder_blocks.0"]).max() <= 1e-5
 print("ok, worst relative gradient error %.2g" % worst)
 ''', ML3D_TRAIN_OPS=path)
+
+
+def test_unsupported_stage_shapes_fall_back_and_bad_arguments_are_refused():
+    """A stage wider than the fused kernel (d = 512 of the 5-layer configs' last level) keeps the unfused ops inside the HIP path and still
+    agrees with the torch-autograd path; the C entries refuse what they cannot run (ML3D_E_UNSUPPORTED = -4) or do not understand
+    (ML3D_E_INVALID = -1) instead of mis-computing."""
+    _run(r'''
+import ctypes as C
+from ml3d import ops, _abi
+from ml3d.torch.models import RandLANet
+assert ops.attention_stage_supported(16, 8, 8) and ops.attention_stage_supported(16, 128, 128) and ops.attention_stage_supported(16, 100, 28)
+assert not ops.attention_stage_supported(16, 256, 256) and not ops.attention_stage_supported(8, 8, 8) and not ops.attention_stage_supported(16, 7, 8)
+assert not ops.attention_stage_supported(16, 200, 56)            # (c1 > 160 above d = 128: the f half of the direct term must fit in LDS)
+lib = _abi.get()
+z = np.zeros(64, np.float32)
+i = np.zeros(64, np.int32)
+p = lambda a: a.ctypes.data
+assert lib.ml3d_randla_attention_stage(p(z), p(z), p(i), p(z), None, 1, 1, 8, 2, 2, p(z), None) == -4          # K != 16
+assert lib.ml3d_randla_attention_stage(p(z), p(z), p(i), p(z), None, 1, 1, 16, 300, 300, p(z), None) == -4     # d > 256
+assert lib.ml3d_randla_attention_stage(p(z), p(z), p(i), p(z), None, 1, 1, 16, 3, 2, p(z), None) == -4         # d odd
+assert lib.ml3d_randla_attention_stage(p(z), p(z), p(i), p(z), None, 1, 1, 16, 0, 2, p(z), None) == -1
+assert lib.ml3d_randla_attention_stage(None, p(z), p(i), p(z), None, 1, 1, 16, 2, 2, p(z), None) == -1
+assert lib.ml3d_gemm_tn(p(z), 4, p(z), 4, 2, 4, 4, None, 4, None, None) == -1 and lib.ml3d_gemm_tn(p(z), 2, p(z), 4, 2, 4, 4, p(z), 4, None, None) == -1
+assert lib.ml3d_batchnorm_train_forward(p(z), 0, 4, None, None, 1e-5, 0, 0.0, p(z), p(z), p(z), p(z), p(z), 1024, None) == -1
+assert lib.ml3d_batchnorm_train_forward(p(z), 4, 4, None, None, 1e-5, 0, 0.0, p(z), p(z), p(z), p(z), p(z), 8, None) == -2      # workspace too small
+assert lib.ml3d_gather_rows(p(z), 4, 4, p(i), 0, 4, p(z), None) == -1
+# a 2-layer net whose second level is 512 wide: stage 1 fused, stage 2 on the unfused Functions -- both inside ML3D_TRAIN_OPS=hip
+cfg = dict(num_neighbors=16, num_layers=2, num_points=256, num_classes=5, sub_sampling_ratio=[4, 4], in_channels=3, dim_features=8,
+           dim_output=[16, 512])
+torch.manual_seed(3)
+m = RandLANet(**cfg, device="cpu")
+m.train()
+m.fc1[2].eval()
+rng = np.random.default_rng(2)
+pts = torch.from_numpy(rng.random((2, 256, 3)).astype(np.float32) * 4)
+lab = torch.from_numpy(rng.integers(0, 5, (2, 256)))
+res = {}
+for path in ("torch", "hip"):
+    os.environ["ML3D_TRAIN_OPS"] = path
+    m.zero_grad(set_to_none=True)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    logits = m({"coords": [pts], "features": pts.clone()})
+    loss = F.cross_entropy(logits.reshape(-1, 5), lab.reshape(-1))
+    loss.backward()
+    res[path] = (logits.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None})
+    m.load_state_dict(sd)
+a, b = res["torch"], res["hip"]
+assert (a[0] - b[0]).abs().max() <= 1e-4 * max(1.0, float(a[0].abs().max()))
+assert set(a[1]) == set(b[1]) and len(a[1]) > 40
+worst = max(float((a[1][k] - b[1][k]).abs().max()) / max(1e-6, float(a[1][k].abs().max())) for k in a[1] if float(a[1][k].abs().max()) > 1e-7)
+assert worst <= 2e-3, worst
+print("ok", worst)
+''')
