@@ -47,7 +47,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 10
+#define ML3D_ABI_VERSION 11
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -832,6 +832,22 @@ int ml3d_scatter_add_rows(const float* grad_out, int64_t n_src, int channels, co
 int ml3d_gather_pool_backward(const float* features, int64_t n_supports, int channels,
                               const int32_t* inds, int64_t n_queries, int64_t max_neighbors, int mode,
                               const float* grad_out, float* grad_features, void* stream);
+
+/* ml3d_kpconv_deformed_weighted: wf[q, k, c] = sum_h max(0, 1 - |s[inds[q, h]] - q - dkp[q, k]| / extent) * features[inds[q, h], c]    */
+/*   -- the aggregation of a DEFORMABLE KPConv in training (kpconv.py:1011-1066, 1105-1137; KP_influence linear, sum aggregation)      */
+/*   with the query's own kernel points deformed_kernel_points [n_queries, 15, 3] (= kernel_points + extent * offsets, the caller's    */
+/*   arithmetic); out_wf [n_queries, 15 * cin].  The backward returns grad_features [n_supports, cin] (zeroed here, atomics) and       */
+/*   grad_kernel_points [n_queries, 15, 3] (written): the gradient that reaches the offset convolution (ml3d.ops.KPConvDeformedFunction). */
+int ml3d_kpconv_deformed_weighted(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                                  int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                                  const float* features, int cin, const float* deformed_kernel_points,
+                                  int num_kernel_points, float kp_extent, float* out_wf, void* stream);
+
+int ml3d_kpconv_deformed_weighted_backward(const float* q_pts, const float* s_pts, const int32_t* neighb_inds,
+                                           int64_t n_queries, int64_t n_supports, int64_t max_neighbors,
+                                           const float* features, int cin, const float* deformed_kernel_points,
+                                           int num_kernel_points, float kp_extent, const float* grad_wf,
+                                           float* grad_features, float* grad_kernel_points, void* stream);
 
 /* ml3d_randla_attention_stage: one attentive pooling of LocalFeatureAggregation in training form, fused (randlanet.py:596-605,     */
 /*   617, 631-637): x[p, k, :] = [ f[b, idx[p, k], :c1] | enc[p, k, :c2] ], s = x W^T + bias, out[p, c] = sum_k softmax_k(s)[k, c]   */

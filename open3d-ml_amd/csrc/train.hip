@@ -5,6 +5,9 @@
 //                                       (SharedMLP.forward randlanet.py:503-518, BatchNormBlock.forward kpconv.py:1238-1249)
 //   * ml3d_gather_rows / ml3d_scatter_add_rows / ml3d_gather_pool_backward
 //                                       nearest_interpolation (randlanet.py:329-350), closest_pool / max_pool (kpconv.py:821-858)
+//   * ml3d_kpconv_deformed_weighted[_backward]
+//                                       the deformed KPConv's aggregation with per-query kernel points and its adjoint with respect
+//                                       to the features AND the kernel points (kpconv.py:1011-1066, 1105-1137)
 //   * ml3d_randla_attention_stage[_backward]
 //                                       gather + concat + score Linear + softmax over K + weighted sum of one attentive pooling
 //                                       (randlanet.py:596-605, 622-637) as ONE kernel each way: the [B, N, K, d] tensors of the
@@ -554,6 +557,108 @@ static inline unsigned tr_reduce_blocks(int64_t rows, int c) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The DEFORMED KPConv aggregation for training (kpconv.py:1011-1066, 1105-1137, KP_influence linear, sum aggregation): the kernel points
+// of query q are its own, dkp[q, k, :] = kernel_points[k] + extent * offsets[q, k, :], so the influences depend on TRAINED quantities:
+//   wf[q, k, c] = sum_h w[q, k, h] x[inds[q, h], c],   w = max(0, 1 - |s[inds[q, h]] - q - dkp[q, k]| / extent)
+// Forward: one wave per query, lane = channel (chunks of 64), lanes 0..14 compute the 15 influences of a neighbour once, every lane
+// takes them by broadcast.  Backward, same shape: dx[inds[q, h], c] += sum_k w dwf[q, k, c] (atomics: the scatter of an index_add),
+//   d dkp[q, k, :] = sum_h (sum_c dwf[q, k, c] x[inds[q, h], c]) * (nb - dkp[q, k]) / (|nb - dkp[q, k]| extent)      where w > 0
+// -- the inner sum over the channels is a wave reduction per kernel point.  Neither pass holds the reference's [Nq, H, Cin] gather.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DK = 15;                   // kernel points (every in-scope configuration)
+
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct DeformArgs {
+    const float* q_pts; const float* s_pts; const int32_t* inds; int64_t nq, ns; int h;
+    const float* x; int cin; const float* dkp; float extent;
+};
+
+__global__ void __launch_bounds__(256)
+kp_deformed_weighted_k(DeformArgs A, float* __restrict__ wf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= A.nq) return;                                           // (wave-uniform)
+    const float qx = A.q_pts[3 * q], qy = A.q_pts[3 * q + 1], qz = A.q_pts[3 * q + 2];
+    const int k = lane < DK ? lane : 0;
+    const float kx = A.dkp[(q * DK + k) * 3], ky = A.dkp[(q * DK + k) * 3 + 1], kz = A.dkp[(q * DK + k) * 3 + 2];
+    const int32_t* row = A.inds + q * A.h;
+    for (int c0 = 0; c0 < A.cin; c0 += 64) {
+        const int c = c0 + lane;
+        const bool live = c < A.cin;
+        float acc[DK];
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) acc[kk] = 0.f;
+        for (int h = 0; h < A.h; ++h) {
+            const int idx = row[h];
+            if (idx < 0 || idx >= A.ns) continue;                    // shadow neighbour (wave-uniform: the row is the wave's)
+            const float* sp = A.s_pts + 3 * (int64_t)idx;
+            const float dx = (sp[0] - qx) - kx, dy = (sp[1] - qy) - ky, dz = (sp[2] - qz) - kz;
+            // (the reference's operation sequence, 1 - sqrt(sq) / extent with sq = (dx^2 + dy^2) + dz^2: the same float32 value, so the
+            //  clamp's mask is the reference's bit for bit)
+            float w = 1.0f - sqrtf(dx * dx + dy * dy + dz * dz) / A.extent;
+            w = (lane < DK && w > 0.f) ? w : 0.f;
+            const float xv = live ? A.x[(int64_t)idx * A.cin + c] : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) acc[kk] = fmaf(__shfl(w, kk), xv, acc[kk]);
+        }
+        if (live) {
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) wf[(q * DK + kk) * A.cin + c] = acc[kk];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+kp_deformed_weighted_bwd_k(DeformArgs A, const float* __restrict__ dwf, float* __restrict__ dx, float* __restrict__ gkp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= A.nq) return;                                           // (wave-uniform)
+    const float qx = A.q_pts[3 * q], qy = A.q_pts[3 * q + 1], qz = A.q_pts[3 * q + 2];
+    const int k = lane < DK ? lane : 0;
+    const float kx = A.dkp[(q * DK + k) * 3], ky = A.dkp[(q * DK + k) * 3 + 1], kz = A.dkp[(q * DK + k) * 3 + 2];
+    const int32_t* row = A.inds + q * A.h;
+    float gx = 0.f, gy = 0.f, gz = 0.f;                               // lanes 0..14: the gradient of their kernel point
+    for (int c0 = 0; c0 < A.cin; c0 += 64) {
+        const int c = c0 + lane;
+        const bool live = c < A.cin;
+        float g[DK];
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) g[kk] = live ? dwf[(q * DK + kk) * A.cin + c] : 0.f;
+        for (int h = 0; h < A.h; ++h) {
+            const int idx = row[h];
+            if (idx < 0 || idx >= A.ns) continue;
+            const float* sp = A.s_pts + 3 * (int64_t)idx;
+            const float ddx = (sp[0] - qx) - kx, ddy = (sp[1] - qy) - ky, ddz = (sp[2] - qz) - kz;
+            const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            const float wpre = 1.0f - dist / A.extent;
+            const float w = (lane < DK && wpre > 0.f) ? wpre : 0.f;
+            const float xv = live ? A.x[(int64_t)idx * A.cin + c] : 0.f;
+            float v = 0.f, mine = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) {
+                v = fmaf(__shfl(w, kk), g[kk], v);
+                const float s = tr_wave_sum(g[kk] * xv);             // d loss / d w[q, kk, h] of this channel chunk
+                mine = lane == kk ? s : mine;
+            }
+            if (live) atomicAdd(dx + (int64_t)idx * A.cin + c, v);
+            if (lane < DK && wpre >= 0.f && dist > 0.f) {             // (torch.clamp's gradient mask is inclusive at the bound)
+                const float coef = mine / (A.extent * dist);
+                gx = fmaf(coef, ddx, gx); gy = fmaf(coef, ddy, gy); gz = fmaf(coef, ddz, gz);
+            }
+        }
+    }
+    if (lane < DK) {
+        gkp[(q * DK + lane) * 3] = gx; gkp[(q * DK + lane) * 3 + 1] = gy; gkp[(q * DK + lane) * 3 + 2] = gz;
+    }
+}
+
 static inline unsigned tr_blocks(int64_t total, int per, unsigned cap) {
     int64_t b = (total + per - 1) / per;
     if (b < 1) b = 1;
@@ -684,6 +789,49 @@ extern "C" int ml3d_gather_pool_backward(const float* features, int64_t n_suppor
     else
         hipLaunchKernelGGL(scatter_add_rows_k, dim3(tr_blocks(total, 256, 8192)), dim3(256), 0, st, grad_out, n_supports, channels, inds,
                            max_neighbors, n_queries, grad_features);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+
+static int deform_args(DeformArgs& a, const float* q_pts, const float* s_pts, const int32_t* inds, int64_t nq, int64_t ns, int64_t h,
+                       const float* x, int cin, const float* dkp, int num_kernel_points, float extent) {
+    if (nq < 0 || ns < 0 || h < 0 || h > 0x7fffffff || cin <= 0 || !(extent > 0.f)) return ML3D_E_INVALID;
+    if (num_kernel_points != DK) return ML3D_E_UNSUPPORTED;
+    if (nq > 0 && (!q_pts || !dkp || (h > 0 && (!inds || !s_pts || !x)))) return ML3D_E_INVALID;
+    a.q_pts = q_pts; a.s_pts = s_pts; a.inds = inds; a.nq = nq; a.ns = ns; a.h = (int)h; a.x = x; a.cin = cin; a.dkp = dkp;
+    a.extent = extent;
+    return 0;
+}
+
+extern "C" int ml3d_kpconv_deformed_weighted(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                             int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                             const float* deformed_kernel_points, int num_kernel_points, float kp_extent, float* out_wf,
+                                             void* stream) {
+    DeformArgs a;
+    const int rc = deform_args(a, q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, deformed_kernel_points,
+                               num_kernel_points, kp_extent);
+    if (rc) return rc;
+    if (n_queries == 0) return 0;
+    if (!out_wf) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(kp_deformed_weighted_k, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, out_wf);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
+extern "C" int ml3d_kpconv_deformed_weighted_backward(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                                      int64_t n_supports, int64_t max_neighbors, const float* features, int cin,
+                                                      const float* deformed_kernel_points, int num_kernel_points, float kp_extent,
+                                                      const float* grad_wf, float* grad_features, float* grad_kernel_points, void* stream) {
+    DeformArgs a;
+    const int rc = deform_args(a, q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, deformed_kernel_points,
+                               num_kernel_points, kp_extent);
+    if (rc) return rc;
+    if (!grad_features || (n_queries > 0 && !grad_kernel_points)) return ML3D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_supports > 0) zero_async(grad_features, sizeof(float) * (size_t)n_supports * (size_t)cin, st);
+    if (n_queries == 0) return 0;
+    if (!grad_wf) return ML3D_E_INVALID;
+    hipLaunchKernelGGL(kp_deformed_weighted_bwd_k, dim3((unsigned)((n_queries + 3) / 4)), dim3(256), 0, st, a, grad_wf, grad_features,
+                       grad_kernel_points);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 

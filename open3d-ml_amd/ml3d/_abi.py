@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 10         # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 11         # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -87,6 +87,7 @@ SYMBOLS = [
     "ml3d_gemm_tn",
     "ml3d_batchnorm_train_workspace_bytes", "ml3d_batchnorm_train_forward", "ml3d_batchnorm_train_backward",
     "ml3d_gather_rows", "ml3d_scatter_add_rows", "ml3d_gather_pool_backward",
+    "ml3d_kpconv_deformed_weighted", "ml3d_kpconv_deformed_weighted_backward",
     "ml3d_randla_attention_stage", "ml3d_randla_attention_stage_backward_workspace_bytes", "ml3d_randla_attention_stage_backward",
 ]
 
@@ -252,6 +253,10 @@ def bind(lib):
     lib.ml3d_scatter_add_rows.argtypes = [vp, i64, i32, vp, i64, i64, vp, vp]
     lib.ml3d_gather_pool_backward.restype = C.c_int
     lib.ml3d_gather_pool_backward.argtypes = [vp, i64, i32, vp, i64, i64, i32, vp, vp, vp]
+    lib.ml3d_kpconv_deformed_weighted.restype = C.c_int
+    lib.ml3d_kpconv_deformed_weighted.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, vp, vp]
+    lib.ml3d_kpconv_deformed_weighted_backward.restype = C.c_int
+    lib.ml3d_kpconv_deformed_weighted_backward.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, vp, vp, vp, vp]
     lib.ml3d_randla_attention_stage.restype = C.c_int
     lib.ml3d_randla_attention_stage.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp]
     lib.ml3d_randla_attention_stage_backward.restype = C.c_int

@@ -252,3 +252,43 @@ class AttentionStageFunction(torch.autograd.Function):
                                                           None if gb is None else gb.data_ptr(), ws.data_ptr(), wsb, _stream())
         _abi.check(rc, "ml3d_randla_attention_stage_backward")
         return gf, genc, None, gw, gb
+
+
+class KPConvDeformedFunction(torch.autograd.Function):
+    """The aggregation of a DEFORMABLE KPConv in training (kpconv.py:1011-1066, 1105-1137; linear influence, sum aggregation):
+    ``x`` [Ns, cin], ``deformed_kp`` [Nq, 15, 3] (the query's own kernel points, a function of the trained offsets), geometry ->
+    ``wf`` [Nq, 15 * cin].  HIP forward and hand-written HIP backward with respect to the features (a scatter) AND the kernel points
+    (what trains the offset convolution); the reference's ``[Nq, H, cin]`` neighbour gather exists in neither pass."""
+
+    @staticmethod
+    def forward(ctx, x, deformed_kp, q_pts, s_pts, neighb_inds, extent):
+        lib = _abi.get()
+        _need_gpu(x, deformed_kp, q_pts, s_pts, neighb_inds)
+        x, dkp = _f32(x), _f32(deformed_kp)
+        nq, ns = q_pts.shape[0], s_pts.shape[0]
+        H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
+        cin, K = x.shape[1], dkp.shape[1]
+        wf = torch.empty((nq, K * cin), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_kpconv_deformed_weighted(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, x.data_ptr(), cin,
+                                                   dkp.data_ptr(), K, float(extent), wf.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_kpconv_deformed_weighted")
+        ctx.save_for_backward(x, dkp, q_pts, s_pts, neighb_inds)
+        ctx.extent = float(extent)
+        return wf
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _abi.get()
+        x, dkp, q_pts, s_pts, neighb_inds = ctx.saved_tensors
+        nq, ns = q_pts.shape[0], s_pts.shape[0]
+        H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
+        cin, K = x.shape[1], dkp.shape[1]
+        g = _f32(g)
+        gx, gk = torch.empty_like(x), torch.zeros_like(dkp)
+        with torch.cuda.device(x.device):
+            rc = lib.ml3d_kpconv_deformed_weighted_backward(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H,
+                                                            x.data_ptr(), cin, dkp.data_ptr(), K, ctx.extent, g.data_ptr(), gx.data_ptr(),
+                                                            gk.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_kpconv_deformed_weighted_backward")
+        return gx, gk, None, None, None, None

@@ -513,6 +513,14 @@ class KPFCNN(nn.Module):
         """One deformable KPConv in training mode (kpconv.py:1011-1066, 1105-1159, linear influence, sum aggregation)."""
         conv._geom_inputs = None
         sq, mod = KPFCNN._deformable_geometry(conv, q_pts, s_pts, inds, x, infl)
+        if os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch":
+            # round 5: the aggregation and its adjoint -- with respect to the features AND the deformed kernel points, which is what
+            # trains the offset convolution -- on csrc/train.hip; no [Nq, H, Cin] gather (ops.KPConvDeformedFunction)
+            K, cin, cout = conv.weights.shape
+            wf = ops.KPConvDeformedFunction.apply(x, conv.deformed_KP, q_pts, s_pts, inds, conv.KP_extent)      # [Nq, K * Cin]
+            if mod is not None:
+                wf = (wf.view(-1, K, cin) * mod.unsqueeze(2)).reshape(-1, K * cin)
+            return ops.LinearFunction.apply(wf, conv.weights.reshape(K * cin, cout).t(), None)
         w = torch.clamp(1 - torch.sqrt(sq) / conv.KP_extent, min=0.0).transpose(1, 2)     # [Nq, K, H]
         nx = torch.cat([x, torch.zeros_like(x[:1])], 0)[inds.long()]                      # [Nq, H, Cin]
         wf = torch.matmul(w, nx)                                                          # [Nq, K, Cin]

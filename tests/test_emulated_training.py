@@ -264,3 +264,41 @@ worst = max(float((a[1][k] - b[1][k]).abs().max()) / max(1e-6, float(a[1][k].abs
 assert worst <= 2e-3, worst
 print("ok", worst)
 ''')
+
+
+def test_deformed_kpconv_aggregation_matches_torch_autograd():
+    """``ops.KPConvDeformedFunction`` (the deformable KPConv's aggregation with per-query kernel points, kpconv.py:1011-1066, 1105-1137)
+    against the reference's formulation on torch's autograd -- [Nq, H, K] distances, clamped linear influences, the [Nq, H, Cin] gather, one
+    matmul: the output, the feature gradient and the gradient of the deformed kernel points (what trains the offset convolution); shadow
+    neighbours in the rows, cin below / across / above one 64-lane chunk.  (The model-level pin is
+    tests/test_emulated_api.py::test_deformable_kpfcnn_training_forward_regulariser_and_gradients_match_the_reference, which runs on this path.)"""
+    _run(r'''
+from ml3d import ops
+rng = np.random.default_rng(0)
+T = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+for nq, ns, H, cin in ((40, 60, 9, 8), (25, 25, 14, 70), (7, 30, 5, 130)):
+    q = T(rng.random((nq, 3))); s_ = T(rng.random((ns, 3)))
+    inds = torch.from_numpy(rng.integers(0, ns + 3, (nq, H)).astype(np.int32))       # (values >= ns: shadow neighbours)
+    x = T(rng.standard_normal((ns, cin))).requires_grad_(True)
+    kp = T(rng.standard_normal((15, 3)) * 0.15)
+    dkp = (kp[None] + T(rng.standard_normal((nq, 15, 3)) * 0.05)).requires_grad_(True)
+    ext = 0.35
+    g = T(rng.standard_normal((nq, 15 * cin)))
+    far = torch.cat([s_, torch.zeros_like(s_[:1]) + 1e6], 0)
+    ii = inds.long().clamp(max=ns)
+    nb = far[ii] - q.unsqueeze(1)
+    sq = ((nb.unsqueeze(2) - dkp.unsqueeze(1)) ** 2).sum(3)
+    w = torch.clamp(1 - torch.sqrt(sq) / ext, min=0.0).transpose(1, 2)
+    nx = torch.cat([x, torch.zeros_like(x[:1])], 0)[ii]
+    ref = torch.matmul(w, nx).reshape(nq, 15 * cin)
+    ref.backward(g)
+    want = [x.grad.clone(), dkp.grad.clone()]
+    x.grad = None; dkp.grad = None
+    out = ops.KPConvDeformedFunction.apply(x, dkp, q, s_, inds, ext)
+    out.backward(g)
+    assert (out - ref).abs().max() <= 2e-5, float((out - ref).abs().max())
+    for name, a, b in zip(("x", "dkp"), (x.grad, dkp.grad), want):
+        assert (a - b).abs().max() <= 5e-5 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))
+    print("deformed aggregation ok", nq, ns, H, cin, "max|grad dkp|", float(want[1].abs().max()), flush=True)
+print("ok")
+''')

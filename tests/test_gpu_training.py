@@ -176,10 +176,14 @@ def test_pointpillars_training_forward_and_gradients_match_the_reference(golden_
     assert out[0].shape == maps[0].shape and not out[0].requires_grad
 
 
-def test_deformable_kpfcnn_training_matches_the_reference(golden_dir):
+@pytest.mark.parametrize("train_ops", ["hip", "torch"])
+def test_deformable_kpfcnn_training_matches_the_reference(golden_dir, monkeypatch, train_ops):
     """KPFCNN with three DEFORMABLE, modulated blocks in ``.train()`` mode on the MI355X (offset convolutions through
-    ``ops.KPConvFunction``, the deformed convolutions on torch's autograd) against the REAL reference's training forward +
-    backward (tests/golden/train_kpconv_deform.npz): logits, cross entropy, the point-to-point offset regulariser, gradients."""
+    ``ops.KPConvFunction``; the deformed convolutions through ``ops.KPConvDeformedFunction`` -- HIP aggregation + hand-written adjoint
+    with respect to the features and the deformed kernel points -- with ``ML3D_TRAIN_OPS=hip``, on torch's autograd with ``=torch``)
+    against the REAL reference's training forward + backward (tests/golden/train_kpconv_deform.npz): logits, cross entropy, the
+    point-to-point offset regulariser, gradients."""
+    monkeypatch.setenv("ML3D_TRAIN_OPS", train_ops)
     from ml3d.torch.dataloaders import kpconv_input_features
     from ml3d.torch.models.kpconv import KPFCNN, KPConvBatch
     from oracle.gen_golden_train import DEFORM_TRAIN_CFG, deform_train_inputs
@@ -332,3 +336,39 @@ def test_fused_attention_stage_matches_the_unfused_formulation(B, n, c1, c2, bia
         if wnt is not None:
             tol = 1e-4 if name != "b" else 1e-3          # (the bias gradient is a sum of terms that cancel exactly in exact arithmetic)
             assert float((got - wnt).abs().max()) <= tol * max(1.0, float(wnt.abs().max())), (name, float((got - wnt).abs().max()), float(wnt.abs().max()))
+
+
+def test_deformed_kpconv_aggregation_matches_torch_autograd():
+    """``ops.KPConvDeformedFunction`` against the reference's formulation on torch's autograd: output, feature gradient and the gradient of
+    the per-query kernel points, 20 000 queries, shadow neighbours in the rows.  (float32 reference: the kernel follows the reference's
+    operation sequence for the influence, so the clamp's mask -- where the kernel-point gradient is discontinuous -- is the same bit for
+    bit; the sums differ by rounding.  The kernel-point gradient is additionally held in the L1 norm.)"""
+    from ml3d import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    for nq, ns, H, cin in ((20000, 20000, 24, 64), (3000, 9000, 37, 200), (500, 500, 6, 8)):
+        q = torch.rand(nq, 3, device="cuda", generator=g)
+        s_ = torch.rand(ns, 3, device="cuda", generator=g)
+        inds = torch.randint(0, ns + 3, (nq, H), device="cuda", generator=g).to(torch.int32)
+        x = rn(ns, cin).requires_grad_(True)
+        kp = rn(15, 3) * 0.05
+        dkp = (kp[None] + rn(nq, 15, 3) * 0.02).requires_grad_(True)
+        ext = 0.12
+        gy = rn(nq, 15 * cin)
+        far = torch.cat([s_, torch.zeros_like(s_[:1]) + 1e6], 0)
+        ii = inds.long().clamp(max=ns)
+        nb = far[ii] - q.unsqueeze(1)
+        sq = ((nb.unsqueeze(2) - dkp.unsqueeze(1)) ** 2).sum(3)
+        w = torch.clamp(1 - torch.sqrt(sq) / ext, min=0.0).transpose(1, 2)
+        nx = torch.cat([x, torch.zeros_like(x[:1])], 0)[ii]
+        ref = torch.matmul(w, nx).reshape(nq, 15 * cin)
+        ref.backward(gy)
+        want = [x.grad.clone(), dkp.grad.clone()]
+        x.grad = dkp.grad = None
+        out = ops.KPConvDeformedFunction.apply(x, dkp, q, s_, inds, ext)
+        out.backward(gy)
+        assert _close(out, ref, 5e-5)
+        assert _close(x.grad, want[0], 2e-4), float((x.grad - want[0]).abs().max())
+        err = (dkp.grad - want[1]).abs()
+        assert float(err.sum()) <= 1e-4 * float(want[1].abs().sum()), (float(err.sum()), float(want[1].abs().sum()))
+        assert int((err > 1e-3 * max(1.0, float(want[1].abs().max()))).sum()) <= 3, int((err > 1e-3 * float(want[1].abs().max())).sum())
