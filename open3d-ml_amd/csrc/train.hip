@@ -825,7 +825,7 @@ extern "C" int ml3d_kpconv_deformed_weighted_backward(const float* q_pts, const 
     const int rc = deform_args(a, q_pts, s_pts, neighb_inds, n_queries, n_supports, max_neighbors, features, cin, deformed_kernel_points,
                                num_kernel_points, kp_extent);
     if (rc) return rc;
-    if (!grad_features || (n_queries > 0 && !grad_kernel_points)) return ML3D_E_INVALID;
+    if ((n_supports > 0 && !grad_features) || (n_queries > 0 && !grad_kernel_points)) return ML3D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (n_supports > 0) zero_async(grad_features, sizeof(float) * (size_t)n_supports * (size_t)cin, st);
     if (n_queries == 0) return 0;

@@ -300,5 +300,13 @@ for nq, ns, H, cin in ((40, 60, 9, 8), (25, 25, 14, 70), (7, 30, 5, 130)):
     for name, a, b in zip(("x", "dkp"), (x.grad, dkp.grad), want):
         assert (a - b).abs().max() <= 5e-5 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))
     print("deformed aggregation ok", nq, ns, H, cin, "max|grad dkp|", float(want[1].abs().max()), flush=True)
+for nq, ns, H, cin in ((3, 0, 0, 4), (0, 5, 3, 4), (4, 6, 0, 4)):                   # no supports / no queries / no neighbour columns
+    q, s_ = T(rng.random((nq, 3))), T(rng.random((ns, 3)))
+    inds = torch.from_numpy(rng.integers(0, ns + 3, (nq, H)).astype(np.int32))
+    x = T(rng.standard_normal((ns, cin))).requires_grad_(True)
+    dkp = T(rng.standard_normal((nq, 15, 3)) * 0.2).requires_grad_(True)
+    out = ops.KPConvDeformedFunction.apply(x, dkp, q, s_, inds, 0.35)
+    out.square().sum().backward()
+    assert out.shape == (nq, 15 * cin) and float(out.abs().sum()) == 0.0 and float(dkp.grad.abs().sum()) == 0.0 and float(x.grad.abs().sum()) == 0.0
 print("ok")
 ''')
