@@ -58,6 +58,7 @@ gemm_tn_k(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
     const int64_t r0 = slice * rows_per_slice;
     const int64_t r1 = r0 + rows_per_slice < m ? r0 + rows_per_slice : m;
     const bool ia0 = i0 + cl < k, ia1 = i0 + 32 + cl < k, jb0 = j0 + cl < n, jb1 = j0 + 32 + cl < n;
+    const bool two_i = i0 + 32 < k, two_j = j0 + 32 < n;             // does the tile have a second 32-row / 32-column half at all
     const float* ap = a + i0 + cl;
     const float* bp = b + j0 + cl;
     tr_f32x16 acc00 = tr_zero16(), acc01 = tr_zero16(), acc10 = tr_zero16(), acc11 = tr_zero16();
@@ -68,9 +69,11 @@ gemm_tn_k(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
         const float a0 = ok && ia0 ? ap[rr * lda] : 0.f, a1 = ok && ia1 ? ap[rr * lda + 32] : 0.f;
         const float b0 = ok && jb0 ? bp[rr * ldb] : 0.f, b1 = ok && jb1 ? bp[rr * ldb + 32] : 0.f;
         acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        if (two_j) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);       // (wave-uniform: thin products -- 10 -> 8
+        if (two_i) {                                                                            //  channels over 2.9 M rows -- issue one
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);               //  MFMA per row pair, not four)
+            if (two_j) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
