@@ -166,6 +166,55 @@ def randla_main():
     print("randla loss", loss.item(), "logits", logits.shape, {k: float(np.abs(out["grad:" + k]).max()) for k in keep[:4]})
 
 
+# the widths of randlanet_semantickitti.yml (the four stage widths 16 / 64 / 128 / 256 of the fused training kernels' LDS classes), at a size
+# PyTorch-CPU turns around in seconds
+RANDLA_WIDE_TRAIN_CFG = dict(num_neighbors=16, num_layers=4, num_points=1024, num_classes=19, sub_sampling_ratio=[4, 4, 4, 4], in_channels=3,
+                             dim_features=8, dim_output=[16, 64, 128, 256], ignored_label_inds=[0], grid_size=0.06)
+
+
+def randla_wide_train_inputs():
+    rng = np.random.default_rng(9)
+    pts = np.stack([synth_data.semantickitti_patch(90 + b, 1024) for b in range(3)])
+    labels = rng.integers(0, 20, (3, 1024)).astype(np.int64)
+    return pts, pts.copy(), labels
+
+
+def randla_wide_main():
+    """tests/golden/train_randlanet_wide.npz: forward + backward of the REAL reference RandLANet with the SemanticKITTI widths
+    (dim_output 16 / 64 / 128 / 256), 3 x 1024 points: logits, loss, the gradient of EVERY parameter's largest entry position-wise
+    for a spread of tensors across all four levels (the score Linears of all eight attentive poolings included)."""
+    from oracle import ops as oops
+    from oracle import randlanet_ref as R
+    rl = importlib.import_module("ml3d.torch.models.randlanet")
+    sl = importlib.import_module("ml3d.torch.modules.losses.semseg_loss")
+    cfg = dict(RANDLA_WIDE_TRAIN_CFG)
+    model = rl.RandLANet(**cfg)
+    model.load_state_dict(R.make_state_dict(cfg, 56))
+    model.device = torch.device("cpu")
+    model.train()
+    model.fc1[2].eval()
+    pts, feats, labels = randla_wide_train_inputs()
+    inp = R.build_inputs(pts, feats, cfg, oops.knn_search)
+    logits = model(inp)
+    scores, lab = sl.filter_valid_label(logits, torch.from_numpy(labels), cfg["num_classes"], cfg["ignored_label_inds"], "cpu")
+    loss = torch.nn.CrossEntropyLoss()(scores, lab)
+    loss.backward()
+    named = dict(model.named_parameters())
+    keep = ["fc0.weight"]
+    for l in range(4):
+        keep += ["encoder.%d.pool1.score_fn.0.weight" % l, "encoder.%d.pool2.score_fn.0.weight" % l, "encoder.%d.pool1.score_fn.0.bias" % l,
+                 "encoder.%d.lse1.mlp.conv.weight" % l, "encoder.%d.lse2.mlp.conv.weight" % l, "encoder.%d.mlp1.conv.weight" % l,
+                 "encoder.%d.pool2.mlp.batch_norm.weight" % l, "encoder.%d.shortcut.conv.bias" % l]
+    keep += ["mlp.conv.bias", "mlp.batch_norm.weight", "decoder.0.conv.bias", "decoder.0.batch_norm.bias", "decoder.3.conv.weight", "fc1.3.conv.weight"]   # (the 512 x 512 / 768 x 256 matrices would be megabytes)
+    out = dict(logits=logits.detach().numpy(), loss=np.float64(loss.item()), n_valid=np.int64(len(lab)))
+    for k in keep:
+        out["grad:" + k] = named[k].grad.numpy()
+    out["running_var:encoder.3.pool2.mlp"] = model.encoder[3].pool2.mlp.batch_norm.running_var.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_randlanet_wide.npz"), **out)
+    print("randla wide loss", loss.item(), "logits", logits.shape, len(keep), "gradients",
+          {k: float(np.abs(out["grad:" + k]).max()) for k in keep[1:5]})
+
+
 PP_LOSS_CFG = {"focal": {"gamma": 2.0, "alpha": 0.25, "loss_weight": 1.0}, "smooth_l1": {"beta": 0.11, "loss_weight": 2.0},
                "cross_entropy": {"loss_weight": 0.2}}
 
@@ -224,6 +273,8 @@ if __name__ == "__main__":
         ref_shim.reference_modules()
     if which in ("all", "randlanet"):
         randla_main()
+    if which in ("all", "randlanet_wide"):
+        randla_wide_main()
     if which in ("all", "pointpillars"):
         pointpillars_main()
     if which in ("all", "deform"):

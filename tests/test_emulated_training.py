@@ -310,3 +310,28 @@ for nq, ns, H, cin in ((3, 0, 0, 4), (0, 5, 3, 4), (4, 6, 0, 4)):               
     assert out.shape == (nq, 15 * cin) and float(out.abs().sum()) == 0.0 and float(dkp.grad.abs().sum()) == 0.0 and float(x.grad.abs().sum()) == 0.0
 print("ok")
 ''')
+
+
+def test_randlanet_with_the_semantickitti_widths_matches_the_reference():
+    """RandLANet with randlanet_semantickitti.yml's widths (stages of 16 / 64 / 128 / 256 channels: all four LDS classes of the fused
+    attention kernels) in ``.train()`` mode on the HIP ops against the REAL reference's training forward + backward
+    (tests/golden/train_randlanet_wide.npz): logits, loss, 39 gradients -- the score Linears' weights of all eight attentive poolings among
+    them -- within 1e-3 of each tensor's largest entry, one running variance."""
+    _run(_MODEL_CHECK + r'''
+from oracle import randlanet_ref as R
+from oracle.gen_golden_train import RANDLA_WIDE_TRAIN_CFG, randla_wide_train_inputs
+from ml3d.torch.models import RandLANet
+g = np.load(os.path.join(ROOT, "tests", "golden", "train_randlanet_wide.npz"))
+cfg = dict(RANDLA_WIDE_TRAIN_CFG)
+m = RandLANet(**cfg, device="cpu")
+m.load_state_dict(R.make_state_dict(cfg, 56))
+m.train()
+m.fc1[2].eval()
+pts, feats, labels = randla_wide_train_inputs()
+logits = m({"coords": [torch.from_numpy(pts)], "features": torch.from_numpy(feats)})
+loss, lab, _ = m.get_loss(loss_obj, logits, {"data": {"labels": torch.from_numpy(labels)}}, "cpu")
+assert int(lab.numel()) == int(g["n_valid"])
+worst = check(m, logits, loss, g, 39, 1e-3)
+assert np.abs(m.encoder[3].pool2.mlp.batch_norm.running_var.numpy() - g["running_var:encoder.3.pool2.mlp"]).max() <= 1e-5
+print("ok, worst relative gradient error %.2g" % worst)
+''', ML3D_TRAIN_OPS="hip")

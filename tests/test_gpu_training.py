@@ -372,3 +372,37 @@ def test_deformed_kpconv_aggregation_matches_torch_autograd():
         err = (dkp.grad - want[1]).abs()
         assert float(err.sum()) <= 1e-4 * float(want[1].abs().sum()), (float(err.sum()), float(want[1].abs().sum()))
         assert int((err > 1e-3 * max(1.0, float(want[1].abs().max()))).sum()) <= 3, int((err > 1e-3 * float(want[1].abs().max())).sum())
+
+
+def test_randlanet_with_the_semantickitti_widths_matches_the_reference(golden_dir):
+    """RandLANet with randlanet_semantickitti.yml's widths (stages of 16 / 64 / 128 / 256 channels: all four LDS classes of the fused
+    attention kernels) in train mode on the MI355X against the REAL reference's training forward + backward
+    (tests/golden/train_randlanet_wide.npz, oracle/gen_golden_train.py): logits, loss, 39 gradients -- the score Linears of all eight
+    attentive poolings among them."""
+    from oracle import randlanet_ref as R
+    from oracle.gen_golden_train import RANDLA_WIDE_TRAIN_CFG, randla_wide_train_inputs
+    from ml3d.torch.models import RandLANet
+    g = np.load(os.path.join(golden_dir, "train_randlanet_wide.npz"))
+    cfg = dict(RANDLA_WIDE_TRAIN_CFG)
+    m = RandLANet(**cfg, device="cuda:0")
+    m.load_state_dict(R.make_state_dict(cfg, 56))
+    m.to("cuda:0")
+    m.train()
+    m.fc1[2].eval()
+    pts, feats, labels = randla_wide_train_inputs()
+    logits = m({"coords": [torch.from_numpy(pts).cuda()], "features": torch.from_numpy(feats).cuda()})
+    assert logits.requires_grad and np.abs(logits.detach().cpu().numpy() - g["logits"]).max() <= 1e-4
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    loss, lab, _ = m.get_loss(loss_obj, logits, {"data": {"labels": torch.from_numpy(labels)}}, "cuda:0")
+    assert int(lab.numel()) == int(g["n_valid"]) and abs(float(loss) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            want, got = g[key], named[key[5:]].grad.detach().cpu().numpy()
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= max(2e-6, 1e-3 * float(np.abs(want).max())), (key, float(np.abs(got - want).max()), float(np.abs(want).max()))
+            checked += 1
+    assert checked == 39
+    assert np.abs(m.encoder[3].pool2.mlp.batch_norm.running_var.cpu().numpy() - g["running_var:encoder.3.pool2.mlp"]).max() <= 1e-5
