@@ -356,6 +356,43 @@ rw2b32(int iters, unsigned long long* __restrict__ mismatch_lanes, unsigned int*
     }
 }
 
+// kernel A4 (written after the round's GPU budget was spent: NOT RUN): are the destination registers of INACTIVE lanes preserved by a
+// 64-bit LDS read?  Every lane keeps a live 64-bit value in a register; under a per-lane mask the active lanes overwrite it by
+// ds_read_b64 with a read-write destination; afterwards every lane checks: active -> the LDS pattern, inactive -> its own old value.
+template <int WIDTH>        // 64: ds_read_b64, 32: ds_read_b32 (control)
+__global__ void __launch_bounds__(64)
+inactive_lanes(int iters, unsigned long long* __restrict__ mismatch_lanes, unsigned int* __restrict__ counts) {
+    __shared__ unsigned long long sh[32 * 64];
+    const unsigned lane = threadIdx.x;
+    for (int i = 0; i < 32; ++i) sh[i * 64 + lane] = ((unsigned long long)(lane * 131u + i) << 32) | (0x9e3779b9u ^ (lane + 64u * i));
+    __syncthreads();
+    bool bad = false;
+    for (int it = 0; it < iters; ++it) {
+        const bool active = (((lane * 2654435761u + (unsigned)it * 40503u + blockIdx.x) >> 9) & 1u) != 0u;
+        const unsigned i = (unsigned)it & 31u;
+        const unsigned long long keep = 0xabcdef0123456789ull ^ ((unsigned long long)lane << 20) ^ (unsigned long long)it;
+        unsigned long long v = keep;
+        const unsigned addr = (i * 64u + lane) * 8u;
+        if (active) {
+            if (WIDTH == 64) {
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(v) : "v"(addr) : "memory");
+            } else {
+                unsigned lo = (unsigned)v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(lo) : "v"(addr) : "memory");
+                v = (v & 0xffffffff00000000ull) | lo;
+            }
+        }
+        const unsigned long long pat = ((unsigned long long)(lane * 131u + i) << 32) | (0x9e3779b9u ^ (lane + 64u * i));
+        const unsigned long long want = active ? (WIDTH == 64 ? pat : ((keep & 0xffffffff00000000ull) | (unsigned)pat)) : keep;
+        bad |= v != want;
+    }
+    const unsigned long long m = __ballot(bad);
+    if (lane == 0) {
+        atomicAdd(&counts[0], 1u);
+        if (m) { atomicAdd(&counts[1], 1u); atomicOr(mismatch_lanes, m); atomicAdd(&counts[2], (unsigned)__popcll(m)); }
+    }
+}
+
 // co-runner B: 256 threads, LDS_BYTES of static LDS, optional bf16 MFMA, optional LDS traffic (b128 reads / writes)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -425,7 +462,7 @@ int main() {
     hipStream_t sa, sb;
     CHECK(hipStreamCreate(&sa));
     CHECK(hipStreamCreate(&sb));
-    const char* names[23] = {"quiet GPU", "62.5 KB LDS + bf16 MFMA + b128 reads / write / barrier", "62.5 KB LDS + the LDS traffic, no MFMA",
+    const char* names[27] = {"quiet GPU", "62.5 KB LDS + bf16 MFMA + b128 reads / write / barrier", "62.5 KB LDS + the LDS traffic, no MFMA",
                             "62.5 KB LDS allocated + bf16 MFMA, no LDS traffic", "8 KB LDS + bf16 MFMA + b128 reads / write / barrier",
                             "8 KB LDS + f32 MFMA (32x32x2) + b128 reads / write / barrier", "8 KB LDS + bf16 MFMA + b128 READS only",
                             "8 KB LDS + bf16 MFMA + traffic; kernel A with b32 LDS accesses", "quiet GPU; kernel A with b32 LDS accesses",
@@ -435,8 +472,10 @@ int main() {
                              "quiet GPU; A'' under a per-lane execution mask", "8 KB LDS + bf16 MFMA + traffic; A'' under a per-lane execution mask",
                              "quiet GPU; kernel A, b64 lists through unmerged volatile accesses", "8 KB LDS + bf16 MFMA + traffic; kernel A, unmerged volatile b64",
                              "quiet GPU; A3 = ds_write2_b32 / ds_read2_b32, full wave", "8 KB LDS + bf16 MFMA + traffic; A3 full wave",
-                             "quiet GPU; A3 under a per-lane execution mask", "8 KB LDS + bf16 MFMA + traffic; A3 under a per-lane execution mask"};
-    for (int mode = 0; mode < 23; ++mode) {
+                             "quiet GPU; A3 under a per-lane execution mask", "8 KB LDS + bf16 MFMA + traffic; A3 under a per-lane execution mask",
+                             "quiet GPU; A4 = inactive lanes keep their registers across ds_read_b64", "8 KB LDS + bf16 MFMA + traffic; A4 (ds_read_b64)",
+                             "quiet GPU; A4 with ds_read_b32 (control)", "8 KB LDS + bf16 MFMA + traffic; A4 with ds_read_b32 (control)"};
+    for (int mode = 0; mode < 27; ++mode) {
         CHECK(hipMemset(lanes, 0, 8));
         CHECK(hipMemset(counts, 0, 16));
         CHECK(hipDeviceSynchronize());
@@ -445,12 +484,14 @@ int main() {
             if (mode == 1) launch_corun<64000, 1, 1>(sb, out, iters);
             if (mode == 2) launch_corun<64000, 0, 1>(sb, out, iters);
             if (mode == 3) launch_corun<64000, 1, 0>(sb, out, iters);
-            if (mode == 4 || mode == 7 || mode == 10 || mode == 12 || mode == 14 || mode == 16 || mode == 18 || mode == 20 || mode == 22) launch_corun<8192, 1, 1>(sb, out, iters);
+            if (mode == 4 || mode == 7 || mode == 10 || mode == 12 || mode == 14 || mode == 16 || mode == 18 || mode == 20 || mode == 22 || mode == 24 || mode == 26) launch_corun<8192, 1, 1>(sb, out, iters);
             if (mode == 5) launch_corun<8192, 2, 1>(sb, out, iters);
             if (mode == 6) launch_corun<8192, 1, 2>(sb, out, iters);
             for (int k = 0; k < 24; ++k) {                               // 24 problems of 100 boxes per decode, like 8 sweeps x 3 classes
-                if (mode == 19 || mode == 20) hipLaunchKernelGGL((rw2b32<false>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
-                else if (mode >= 21) hipLaunchKernelGGL((rw2b32<true>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
+                if (mode == 23 || mode == 24) hipLaunchKernelGGL((inactive_lanes<64>), dim3(2 * n), dim3(64), 0, sa, 256, lanes, counts);
+                else if (mode >= 25) hipLaunchKernelGGL((inactive_lanes<32>), dim3(2 * n), dim3(64), 0, sa, 256, lanes, counts);
+                else if (mode == 19 || mode == 20) hipLaunchKernelGGL((rw2b32<false>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
+                else if (mode == 21 || mode == 22) hipLaunchKernelGGL((rw2b32<true>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
                 else if (mode >= 17) hipLaunchKernelGGL((clip_pairs<2>), dim3(2, n), dim3(64), 0, sa, boxes, n, lanes, counts);
                 else if (mode == 13 || mode == 14) hipLaunchKernelGGL((rw2st64<false>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
                 else if (mode >= 15 && mode <= 16) hipLaunchKernelGGL((rw2st64<true>), dim3(2 * n), dim3(64), 0, sa, 64, lanes, counts);
