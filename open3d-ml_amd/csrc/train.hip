@@ -187,7 +187,7 @@ bn_apply_k(const float* __restrict__ x, int64_t total, int c, const float* __res
     }
 }
 
-// gx = gamma invstd (g' - mean(g') - xhat mean(g' xhat));  ggamma = sum g' xhat, gbeta = sum g' (written by the first threads)
+// gx = gamma invstd (g' - mean(g') - xhat mean(g' xhat));  ggamma = sum g' xhat, gbeta = sum g' (written by a grid-stride walk over the channels)
 __global__ void __launch_bounds__(256)
 bn_backward_apply_k(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, int64_t m, int c,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -195,11 +195,12 @@ bn_backward_apply_k(const float* __restrict__ x, const float* __restrict__ y, co
                     float* __restrict__ gbeta) {
     const int64_t total = m * (int64_t)c;
     const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (first < c) {
-        if (ggamma) ggamma[first] = (float)sums[c + first];
-        if (gbeta) gbeta[first] = (float)sums[first];
-    }
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    // (a grid-stride walk over the channels: with 2-3 rows and c > 256 the grid has FEWER threads than channels)
+    for (int64_t ch = first; ch < c; ch += step) {
+        if (ggamma) ggamma[ch] = (float)sums[c + ch];
+        if (gbeta) gbeta[ch] = (float)sums[ch];
+    }
     RowCh w(first, step, c);
     for (int64_t e = first; e < total; e += step, w.next()) {
         const int ch = w.ch;

@@ -68,7 +68,7 @@ for shape, cout, bias in (((3, 50, 16, 10), 8, True), ((700, 64), 128, False), (
             assert (a_ - b_).abs().max() <= 2e-5 * max(1.0, float(b_.abs().max())), float((a_ - b_).abs().max())
 print("linear ok")
 # BatchNorm + act
-for shape, slope in (((4, 30, 16, 8), 0.2), ((500, 64), None), ((3, 7, 300), 0.1), ((10, 5), 0.0)):
+for shape, slope in (((4, 30, 16, 8), 0.2), ((500, 64), None), ((3, 7, 300), 0.1), ((10, 5), 0.0), ((2, 512), 0.1), ((3, 1024), None), ((3, 340), 0.2)):   # (last three: fewer grid threads than channels -- ADVICE r5)
     c = shape[-1]
     x = T(rng.standard_normal(shape) * 2 + 1).requires_grad_(True)
     gam = T(rng.random(c) + 0.5).requires_grad_(True); bet = T(rng.standard_normal(c)).requires_grad_(True)
@@ -82,10 +82,12 @@ for shape, slope in (((4, 30, 16, 8), 0.2), ((500, 64), None), ((3, 7, 300), 0.1
     x.grad = None; gam.grad = None; bet.grad = None
     out = ops.BatchNormActFunction.apply(x, gam, bet, rm2, rv2, 0.01, 1e-6, slope)
     out.backward(g)
-    assert (out - ref).abs().max() <= 2e-5, float((out - ref).abs().max())
+    few = x.numel() // c < 4        # 2-3 rows: 1 / sqrt(var) of near-equal rows amplifies float rounding (torch's own sums are float there)
+    assert (out - ref).abs().max() <= (5e-4 if few else 2e-5), float((out - ref).abs().max())
     assert (rm - rm2).abs().max() <= 1e-6 and (rv - rv2).abs().max() <= 1e-6
     for a_, b_ in zip([x.grad, gam.grad, bet.grad], want):
-        assert (a_ - b_).abs().max() <= 5e-5 * max(1.0, float(b_.abs().max())), (shape, float((a_ - b_).abs().max()), float(b_.abs().max()))
+        assert a_.shape == b_.shape and torch.isfinite(a_).all()
+        assert (a_ - b_).abs().max() <= (2e-3 if few else 5e-5) * max(1.0, float(b_.abs().max())), (shape, float((a_ - b_).abs().max()), float(b_.abs().max()))
 print("bn ok")
 # gathers
 x = T(rng.standard_normal((40, 12))).requires_grad_(True)

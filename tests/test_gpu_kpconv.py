@@ -168,19 +168,21 @@ def test_pipeline_with_several_builds_in_flight_is_bit_identical_to_the_sequenti
             assert a.shape == b.shape and np.array_equal(a, b)
 
 
-def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_per_sphere():
-    """The configuration bench.py --workload kpconv times: 64 input spheres (~640 000 points) per batch through
-    ``KPConvPipeline``.  Only at this size are deep split-K, the 32-bit offset epilogue (wf is 1.2 GB) and the three-launch
-    scans selected.  Spheres {0, 31, 63} are checked one by one against the oracle run on that sphere alone with the same grid
-    rotation: every points / neighbours / pools / upsamples matrix exact (after removing the item's row offset; the batch's
-    extra columns must be shadow entries), logits <= 1e-4.
+def test_bench_configuration_96_spheres_through_pipeline_n_matches_the_oracle_per_sphere():
+    """The configuration bench.py --workload kpconv times (bench_models.run_kpconv): 96 input spheres (~960 000 points) per batch
+    through ``KPConvPipelineN(builders=2, forward_streams=2)``, FOUR batches in a row so that two one-call builds are in flight
+    on their own streams beside forwards that alternate between two compute streams (bf16x3 contractions co-running with the
+    builds' LDS kernels).  Only at this size are deep split-K, the 32-bit offset epilogue (wf is 1.8 GB) and the three-launch
+    scans selected.  Spheres {0, 47, 95} of the FIRST and the LAST batch are checked one by one against the oracle run on that
+    sphere alone with the same grid rotation: every points / neighbours / pools / upsamples matrix exact (after removing the
+    item's row offset; the batch's extra columns must be shadow entries), logits <= 1e-4.
 
     The oracle forward gets the item's matrices AT THE BATCH'S WIDTH: ``max_pool`` (kpconv.py:821-839) takes the maximum over
     all columns, shadow entries (zero features) included, so in the reference itself a row's pooled value depends on how many
     padding columns the longest row of the batch adds (max(negatives) vs max(negatives, 0)) -- batch items are independent
     only up to that padding."""
-    from ml3d.engine import KPConvPipeline
-    B = 64
+    from ml3d.engine import KPConvPipelineN
+    B = 96
     spheres = [synth_data.toronto3d_sphere(i) for i in range(B)]          # the bench's spheres (rank 0)
     lens = [len(s) for s in spheres]
     dev = torch.device("cuda:0")
@@ -188,9 +190,20 @@ def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_
     sd = K.make_state_dict(CFG, 2024)
     m = _model(sd)
     np.random.seed(0)
-    pipe = KPConvPipeline(m, CFG, dev)
-    assert pipe.submit(pts, lens) is None
-    res = pipe.flush()
+    pipe = KPConvPipelineN(m, CFG, dev, builders=2, forward_streams=2)
+    results = []
+    for _ in range(4):
+        r = pipe.submit(pts, lens)
+        if r is not None:
+            results.append(r)
+    results += pipe.flush()
+    assert len(results) == 4
+    L = CFG["num_layers"]
+    for res in (results[0], results[-1]):
+        _check_batch_items_against_the_oracle(res, spheres, lens, sd, (0, 47, 95))
+
+
+def _check_batch_items_against_the_oracle(res, spheres, lens, sd, items):
     logits = res.wait().cpu().numpy()
     torch.cuda.synchronize()
     batch = res.batch
@@ -207,7 +220,7 @@ def test_bench_configuration_64_spheres_through_the_pipeline_matches_the_oracle_
         assert loc.shape[1] >= w and np.array_equal(loc[:, :w], ref) and (loc[:, w:] == s_len).all(), where
         return loc
 
-    for i in (0, 31, 63):
+    for i in items:
         rots = [None if R is None else R[i:i + 1] for R in batch.rotations]      # this item's grid orientations
         seg = K.segmentation_inputs(spheres[i], [lens[i]], CFG, rotations=rots)
         wide = dict(seg, neighbors=[], pools=[], upsamples=[])

@@ -258,7 +258,7 @@ def test_linear_batchnorm_gather_functions_match_torch_autograd():
         for got, wnt in zip([x.grad, w.grad, None if b is None else b.grad], want):
             if wnt is not None:
                 assert _close(got, wnt, 2e-6 * max(1.0, rows ** 0.5)), (shape, float((got - wnt).abs().max()), float(wnt.abs().max()))
-    for shape, slope in (((4, 2816, 16, 64), 0.2), ((300000, 32), None), ((7, 5), 0.1)):
+    for shape, slope in (((4, 2816, 16, 64), 0.2), ((300000, 32), None), ((7, 5), 0.1), ((2, 512), 0.1), ((3, 1024), None)):
         c = shape[-1]
         x = (rn(*shape) * 2 + 1).requires_grad_(True)
         gam, bet = (torch.rand(c, device="cuda", generator=g) + 0.5).requires_grad_(True), rn(c).requires_grad_(True)
@@ -272,9 +272,11 @@ def test_linear_batchnorm_gather_functions_match_torch_autograd():
         x.grad = gam.grad = bet.grad = None
         out = ops.BatchNormActFunction.apply(x, gam, bet, rm2, rv2, 0.01, 1e-6, slope)
         out.backward(gy)
-        assert _close(out, ref, 2e-5) and _close(rm2, rm, 1e-5) and _close(rv2, rv, 1e-5)
+        few = x.numel() // c < 4    # 2-3 rows: 1 / sqrt(var) of near-equal rows amplifies float rounding
+        assert _close(out, ref, 5e-4 if few else 2e-5) and _close(rm2, rm, 1e-5) and _close(rv2, rv, 1e-5)
         for got, wnt in zip([x.grad, gam.grad, bet.grad], want):
-            assert _close(got, wnt, 2e-4), (shape, float((got - wnt).abs().max()), float(wnt.abs().max()))
+            assert got.shape == wnt.shape and torch.isfinite(got).all()
+            assert _close(got, wnt, 2e-3 if few else 2e-4), (shape, float((got - wnt).abs().max()), float(wnt.abs().max()))
     x = rn(5000, 48).requires_grad_(True)
     idx = torch.randint(0, 5001, (70000,), device="cuda", generator=g).to(torch.int32)
     gy = rn(70000, 48)
