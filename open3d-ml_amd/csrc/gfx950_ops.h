@@ -64,6 +64,13 @@ __device__ __forceinline__ ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[l % 16][8 (l / 16) + e] and B[8 (l / 16) + e][l % 16], e = 0 .. 7; the 16 x 16 float result has
+// the layout of every 16 x 16 MFMA (row 4 (l / 16) + r, column l % 16).  Same matrix rate as the 32 x 32 x 16 form (16 cycles per SIMD).
+typedef float ml3d_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ml3d_f32x4 mfma_bf16_16x16x32(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x4 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 // "does any ACTIVE lane of this wave see pred" in DIVERGENT control flow (lanes whose loops have different trip counts): a ballot
 // over the current exec mask.  The host emulator runs every lane as its own fiber and cannot rendezvous lanes that sit at

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gemm.h"
+#include <gfx950_ops.h>
 #include "grid.h"
 #include "ml3d_hip.h"
 
@@ -57,6 +58,20 @@ static const Knobs& knobs() {
     }();
     return k;
 }
+
+// A/B switch (build time, tools/build_variant.sh): 0 keeps the f32-MFMA attention kernels for D >= 128
+#ifndef ML3D_ATTN_B3
+#define ML3D_ATTN_B3 1
+#endif
+#ifndef ML3D_B3_LB_DIV
+#define ML3D_B3_LB_DIV 1        // (register-pressure probe only: 2 lifts the budget to 512 VGPRs)
+#endif
+#ifndef ML3D_B3_TP256_S1
+#define ML3D_B3_TP256_S1 4
+#endif
+#ifndef ML3D_B3_TP256_S2
+#define ML3D_B3_TP256_S2 2
+#endif
 
 constexpr int RK = 16;        // neighbours per point (num_neighbors in every reference config)
 constexpr int XROW = 20;      // LDS row pitch of the K-slab: 16 + 4 pad floats keeps b128 reads conflict-free
@@ -1093,6 +1108,387 @@ static int launch_attn_wave(LfaArgs a, hipStream_t st) {
     return a.order ? go(lfa_attn_wave<D, STAGE, false, true>) : go(lfa_attn_wave<D, STAGE, false, false>);
 }
 
+// ------------------------------------------------------------------------------------------------
+// lfa_attn_b3 (D in {128, 256}, round 6) — the attention stage of lfa_attn_pf with every deep product on the BF16
+// matrix pipe: a float is exactly h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), a product of two
+// bf16 is exact in the float accumulator, and  a b = ah bh + (ah bm + am bh) + (am bm + ah bl + al bh) + O(2^-25 |a b|)
+// -- six v_mfma_f32_*_bf16 per 16-deep step against eight f32 MFMAs of TWICE the duration each (gemm.hip: measured
+// error equal to the f32 kernel's).  What makes it pay here, where gemm.hip's form did not (three weight planes = 1.5 x
+// the float footprint):
+//   * ALL weights sit in REGISTERS, split once per workgroup: wave w owns the 32-column tile w % NT of the score matrix
+//     (K = H, SPLIT form with the score bias inside gscore: 12 VGPRs per 16-deep step) and the 16-channel tile w % NC of lse2 (12 VGPRs per 32-deep step);
+//     D = 256: 96 + 48 VGPRs of a 256-VGPR budget (8 waves per CU, 2 per SIMD).  The 64 KB of f32 lse2 weights leave LDS.
+//   * the A operands (r1 = lse1(rel), r2 = lse2(r1)) are split ONCE, by the wave that produces them, on their way to LDS:
+//     both lse products run TRANSPOSED (C^T = W^T . R^T on the 16 x 16 forms), so a lane ends up with 4 CONSECUTIVE
+//     channels of one (point, neighbour) row = one ds_write_b64 per plane and one ds_write_b128 of the float row.
+//   * 64 / 128 rows per tile instead of 32 / 64: every wave has work in every phase (lfa_attn_pf<256> ran lse2 on 4 of
+//     its 8 waves) and the barriers are amortised over twice the rows.
+// LDS: X [ROWS][D + 4] f32 (gathered features | r) for the weighted sum, ONE set of planes [3][ROWS][H + 8] bf16 that
+// holds r1 and then r2 (a barrier between lse2's last read and its first write), REL [ROWS][13], NROWG [ROWS]:
+// 122 KB (D = 256) / 130 KB (D = 128), one workgroup per CU.  Prefetch of the next tile's gathers exactly as lfa_attn_pf.
+// lse1 (K = 10 + bias slot) stays on the f32 MFMA (16 x 16 x 4: three per 16 x 16 block, the same count the bf16x3 form needs).
+// ------------------------------------------------------------------------------------------------
+template <int D, int STAGE>
+struct B3Cfg {
+    static constexpr int H = D / 2;
+    static constexpr int WAVES = 8, THREADS = WAVES * 64;
+    // points per tile.  D = 256, stage 2 (144 VGPRs of weights): 64-row tiles need 56 VGPRs more than the wave has
+    static constexpr int TP = D >= 256 ? (STAGE == 1 ? ML3D_B3_TP256_S1 : ML3D_B3_TP256_S2) : 8;
+    static constexpr int ROWS = TP * RK;                    // 64 / 128 (point, neighbour) rows
+    static constexpr int NT = D / 32;                       // score column tiles (32 wide)
+    static constexpr int RT = ROWS / 32;                    // 32-row tiles
+    static constexpr int RG = WAVES / NT;                   // waves that share a column tile take row tiles rg, rg + RG, ..
+    static constexpr int SRT = RT / RG;                     // row tiles per wave in the score phase
+    static constexpr int NC = H / 16;                       // lse channel tiles (16 wide, transposed products)
+    static constexpr int RT16 = ROWS / 16;                  // 16-row tiles
+    static constexpr int RG2 = WAVES / NC;
+    static constexpr int LRT = RT16 / RG2;                  // 16-row tiles per wave in the lse phases
+    static constexpr int KS = H / 16;                       // 16-deep steps of the score product (32 x 32 x 16)
+    static constexpr int KS2 = H / 32;                      // 32-deep steps of lse2 (16 x 16 x 32)
+    static constexpr int XP = D + 4;                        // float pitch of X
+    static constexpr int PP = H + 8;                        // bf16 pitch of a plane row (16 bytes of padding: conflict-free b128 reads)
+    static constexpr int RELP = 13;                         // float pitch of REL (odd: the 16 rows of a B fragment hit 16 banks)
+    static constexpr int PLANE = ROWS * PP;                 // bf16 per plane
+    static constexpr bool AHEAD = D < 256;                  // operand fragments of step s + 1 requested before the MFMAs of step s (12 VGPRs)
+    static_assert(NT <= WAVES && WAVES % NT == 0 && RT % RG == 0, "score tiling");
+    static_assert(NC <= WAVES && WAVES % NC == 0 && RT16 % RG2 == 0, "lse tiling");
+    static constexpr size_t smem_bytes() {
+        return (size_t)ROWS * XP * 4 + (size_t)3 * PLANE * 2 + (size_t)ROWS * RELP * 4 + (size_t)ROWS * 4;
+    }
+};
+
+// four floats (consecutive channels) -> three packed bf16 quadruples
+__device__ __forceinline__ void b3_split4(float v0, float v1, float v2, float v3, uint2& h, uint2& m, uint2& l) {
+    h.x = bf16_pack2(v0, v1); h.y = bf16_pack2(v2, v3);
+    const float r0 = sub_f32(v0, __uint_as_float(h.x << 16)), r1 = sub_f32(v1, __uint_as_float(h.x & 0xffff0000u));
+    const float r2 = sub_f32(v2, __uint_as_float(h.y << 16)), r3 = sub_f32(v3, __uint_as_float(h.y & 0xffff0000u));
+    m.x = bf16_pack2(r0, r1); m.y = bf16_pack2(r2, r3);
+    l.x = bf16_pack2(sub_f32(r0, __uint_as_float(m.x << 16)), sub_f32(r1, __uint_as_float(m.x & 0xffff0000u)));
+    l.y = bf16_pack2(sub_f32(r2, __uint_as_float(m.y << 16)), sub_f32(r3, __uint_as_float(m.y & 0xffff0000u)));
+}
+// eight floats (consecutive K of one weight column) -> the three bf16 operand fragments of an MFMA
+__device__ __forceinline__ void b3_split8(const float (&v)[8], ml3d_u32x4& h, ml3d_u32x4& m, ml3d_u32x4& l) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    b3_split4(v[0], v[1], v[2], v[3], h0, m0, l0);
+    b3_split4(v[4], v[5], v[6], v[7], h1, m1, l1);
+    h = (ml3d_u32x4){h0.x, h0.y, h1.x, h1.y};
+    m = (ml3d_u32x4){m0.x, m0.y, m1.x, m1.y};
+    l = (ml3d_u32x4){l0.x, l0.y, l1.x, l1.y};
+}
+// the six products of a three-way split, small terms first (the order of gemm.hip)
+#define B3_PRODUCTS(MFMA, acc, a, b)                 \
+    acc = MFMA(a[2], b[0], acc);                      \
+    acc = MFMA(a[0], b[2], acc);                      \
+    acc = MFMA(a[1], b[1], acc);                      \
+    acc = MFMA(a[1], b[0], acc);                      \
+    acc = MFMA(a[0], b[1], acc);                      \
+    acc = MFMA(a[0], b[0], acc);
+
+template <int D, int STAGE, bool ORD>
+__global__ void __launch_bounds__((B3Cfg<D, STAGE>::THREADS / ML3D_B3_LB_DIV)) lfa_attn_b3(LfaArgs A) {
+    using C = B3Cfg<D, STAGE>;
+    constexpr int H = C::H, ROWS = C::ROWS, XP = C::XP, PP = C::PP, RELP = C::RELP, THREADS = C::THREADS;
+    constexpr int Q = H / 4;                                      // float4 pieces per gathered row
+    constexpr int G = ROWS * Q / THREADS;                         // pieces per thread
+    static_assert(ROWS * Q % THREADS == 0 && ROWS <= THREADS, "tile shape");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* X = smem;                                              // [ROWS][XP]
+    uint16_t* PL = reinterpret_cast<uint16_t*>(X + ROWS * XP);    // [3][ROWS][PP] bf16: r1, then r2
+    float* REL = reinterpret_cast<float*>(PL + 3 * C::PLANE);     // [ROWS][RELP]
+    uint32_t* NROWG = reinterpret_cast<uint32_t*>(REL + ROWS * RELP);   // [ROWS] byte offset of the neighbour's gscore row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;                    // 32 x 32 forms
+    const int l16 = lane & 15, kq = lane >> 4;                    // 16 x 16 forms
+    const int ct = wave % C::NT, rg = wave / C::NT;               // score: column tile, first row tile
+    const int ch0 = (wave % C::NC) * 16, rg2 = wave / C::NC;      // lse: channel tile, first 16-row tile
+
+    // ---- the wave's weights -> registers, split three ways (once per workgroup) --------------------------------
+    ml3d_u32x4 bsw[C::KS][3];                                     // score_WT[H + k][ct * 32 + col]: B operand, 32 x 32 x 16
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = A.score_wt[(int64_t)(H + 16 * ks + 8 * hi + e) * D + ct * 32 + col];
+        b3_split8(v, bsw[ks][0], bsw[ks][1], bsw[ks][2]);
+    }
+    ml3d_u32x4 w2[STAGE == 2 ? C::KS2 : 1][3];                    // lse2_WT[k][ch0 + l16]: A operand (W^T), 16 x 16 x 32
+    ml3d_f32x4 l2b = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (STAGE == 2) {
+#pragma unroll
+        for (int ks = 0; ks < C::KS2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = A.lse2_wt[(32 * ks + 8 * kq + e) * H + ch0 + l16];
+            b3_split8(v, w2[ks][0], w2[ks][1], w2[ks][2]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l2b[r] = A.lse2_b[ch0 + 4 * kq + r];      // C^T rows = channels
+    }
+    float w1[3];                                                  // lse1_WT[k = kq + 4 s][ch0 + l16]; K slot 10 = bias, 11 = 0
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int k = kq + 4 * s;
+        w1[s] = k < 10 ? A.lse1_wt[k * H + ch0 + l16] : (k == 10 ? A.lse1_b[ch0 + l16] : 0.f);
+    }
+
+    const int64_t tiles = (A.m_total + C::TP - 1) / C::TP;
+    const bool xw = A.xcd_chunk > 0;
+    const int64_t w_step = xw ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+    int64_t wi = xw ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    auto next_tile = [&]() -> int64_t {
+        for (;;) {
+            int64_t t = wi;
+            if (xw) t = xcd_tile(wi, (int)(blockIdx.x & 7), A.xcd_chunk, tiles);
+            wi += w_step;
+            if (t < 0) return -1;
+            if (t < tiles) return t;
+            if (!xw) return -1;
+        }
+    };
+
+    // ---- this thread's slots of a tile's inputs (as lfa_attn_pf) ---------------------------------------------------
+    int gi[G], nb_mine = 0;
+    float4 gq[G];
+    float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    bool mine_valid = false;
+    uint32_t grow_mine = 0;
+    const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
+    uint32_t gmp[ORD ? G : 1], mp_mine = 0, m_first = 0;
+    auto request_idx = [&](uint32_t tile) {
+        const uint32_t have = m_tot - tile * C::TP;
+        const uint32_t lim = (have < (uint32_t)C::TP ? have : (uint32_t)C::TP) * RK;
+        if constexpr (ORD) {
+            const int32_t* ord = A.order + tile * C::TP;
+            m_first = (uint32_t)ord[0];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
+                gi[i] = -1;
+                if (row < lim) {
+                    gmp[i] = (uint32_t)ord[row / RK];
+                    gi[i] = A.nidx[(int64_t)gmp[i] * RK + (row & (RK - 1))];
+                }
+            }
+            if (tid < ROWS) {
+                nb_mine = -1;
+                if ((uint32_t)tid < lim) {
+                    mp_mine = (uint32_t)ord[tid / RK];
+                    nb_mine = A.nidx[(int64_t)mp_mine * RK + (tid & (RK - 1))];
+                }
+            }
+        } else {
+            const int32_t* nb = A.nidx + (int64_t)tile * (C::TP * RK);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(tid + i * THREADS) / Q;
+                gi[i] = row < lim ? nb[row] : -1;
+            }
+            if (tid < ROWS) nb_mine = (uint32_t)tid < lim ? nb[tid] : -1;
+        }
+    };
+    auto request_data = [&](uint32_t tile) {
+        const uint32_t m0 = ORD ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m_first) : tile * C::TP;
+        const uint32_t b0 = m0 / n_pts, l0 = m0 - b0 * n_pts;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = tid + i * THREADS;
+            const int row = e / Q, q = e - row * Q;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gi[i] >= 0) {
+                uint32_t b;
+                if constexpr (ORD) b = b0 + (gmp[i] >= (b0 + 1) * n_pts ? 1u : 0u);
+                else b = b0 + ((l0 + (uint32_t)(row / RK) >= n_pts) ? 1u : 0u);
+                gq[i] = *reinterpret_cast<const float4*>(A.gfeat + ((int64_t)b * n_pts + (uint32_t)gi[i]) * H + 4 * q);
+            }
+        }
+        if (tid < ROWS) {
+            mine_valid = nb_mine >= 0;
+            if (mine_valid) {
+                uint32_t b, l;
+                if constexpr (ORD) {
+                    b = b0 + (mp_mine >= (b0 + 1) * n_pts ? 1u : 0u);
+                    l = mp_mine - b * n_pts;
+                } else {
+                    const uint32_t lp = l0 + (uint32_t)(tid / RK);
+                    const bool wrap = lp >= n_pts;
+                    b = b0 + (wrap ? 1u : 0u);
+                    l = wrap ? lp - n_pts : lp;
+                }
+                grow_mine = b * n_pts + (uint32_t)nb_mine;
+                const float* xb = A.xyz + 3 * ((int64_t)b * A.n0);
+                const float* qp = xb + 3 * l;
+                const float* sp = xb + 3 * (uint32_t)nb_mine;
+                qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
+            }
+        }
+    };
+    // one 16 x 16 block of r (C^T layout: this lane holds channels ch0 + 4 kq .. + 3 of row `row`) -> the planes [+ X]
+    auto store_r = [&](int row, const ml3d_f32x4& acc, bool to_x) {
+        const float v0 = lrelu_max(acc[0], 0.2f), v1 = lrelu_max(acc[1], 0.2f), v2 = lrelu_max(acc[2], 0.2f),
+                    v3 = lrelu_max(acc[3], 0.2f);
+        uint2 h, m, l;
+        b3_split4(v0, v1, v2, v3, h, m, l);
+        uint16_t* d = PL + row * PP + ch0 + 4 * kq;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + C::PLANE) = m;
+        *reinterpret_cast<uint2*>(d + 2 * C::PLANE) = l;
+        if (to_x) *reinterpret_cast<float4*>(X + row * XP + H + ch0 + 4 * kq) = make_float4(v0, v1, v2, v3);
+    };
+
+    int64_t cur = next_tile();
+    if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
+    while (cur >= 0) {
+        const int64_t nxt = next_tile();
+        const int64_t m_base = cur * C::TP;
+        // ---- registers -> LDS -----------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = tid + i * THREADS;
+            const int row = e / Q, q = e - row * Q;
+            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = gq[i];
+        }
+        if (tid < ROWS) {
+            float* r = REL + tid * RELP;
+            if (mine_valid) {
+                const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) r[j] = 0.f;
+            }
+            r[10] = 1.f; r[11] = 0.f;                              // bias slot, K padding
+            NROWG[tid] = mine_valid ? grow_mine * (uint32_t)(D * 4) : 0u;    // (rows past the data read row 0: never stored)
+        }
+        if (nxt >= 0) request_idx((uint32_t)nxt);
+        block_sync_lds();
+        // ---- r1 = lrelu(lse1(rel)), transposed on the f32 MFMA (K = 12) -> planes (stage 1: + X[:, H:]) -------------
+#pragma unroll 1
+        for (int j = 0; j < C::LRT; ++j) {
+            const int r0 = (rg2 + C::RG2 * j) * 16;
+            const float* br = REL + (r0 + l16) * RELP + kq;
+            ml3d_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], br[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], br[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], br[8], acc, 0, 0, 0);
+            store_r(r0 + l16, acc, STAGE == 1);
+        }
+        // the neighbours' per-point score halves (gscore = f . W_top^T + bias, one row per POINT) become the score accumulators'
+        // initial values: requested here, they land under the lse2 MFMAs / the barriers
+        f32x16 sacc[C::SRT];
+        {
+            const char* gbase = reinterpret_cast<const char*>(A.gscore + ct * 32);    // wave-uniform base
+            const uint32_t col4 = 4u * col;
+#pragma unroll
+            for (int j = 0; j < C::SRT; ++j) {
+                const int rt = rg + C::RG * j;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const uint4 nr = *reinterpret_cast<const uint4*>(NROWG + rt * 32 + 8 * q4 + 4 * hi);   // rows mfma_row(4 q4 .. 4 q4 + 3)
+                    sacc[j][4 * q4 + 0] = *reinterpret_cast<const float*>(gbase + (nr.x + col4));
+                    sacc[j][4 * q4 + 1] = *reinterpret_cast<const float*>(gbase + (nr.y + col4));
+                    sacc[j][4 * q4 + 2] = *reinterpret_cast<const float*>(gbase + (nr.z + col4));
+                    sacc[j][4 * q4 + 3] = *reinterpret_cast<const float*>(gbase + (nr.w + col4));
+                }
+            }
+        }
+        if constexpr (STAGE == 2) {
+            block_sync_lds();
+            // ---- r2 = lrelu(lse2(r1)), transposed on the bf16 pipe; every read of r1 precedes the first write of r2 ------
+            ml3d_f32x4 acc2[C::LRT];
+#pragma unroll
+            for (int j = 0; j < C::LRT; ++j) {
+                const int r0 = (rg2 + C::RG2 * j) * 16;
+                const uint16_t* br = PL + (r0 + l16) * PP + 8 * kq;
+                acc2[j] = l2b;
+                ml3d_u32x4 b[2][3];
+                if constexpr (C::AHEAD) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[0][p] = *reinterpret_cast<const ml3d_u32x4*>(br + p * C::PLANE);
+                }
+#pragma unroll
+                for (int ks = 0; ks < C::KS2; ++ks) {
+                    if constexpr (C::AHEAD) {
+                        if (ks + 1 < C::KS2) {
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) b[(ks + 1) & 1][p] = *reinterpret_cast<const ml3d_u32x4*>(br + p * C::PLANE + 32 * (ks + 1));
+                        }
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[ks & 1][p] = *reinterpret_cast<const ml3d_u32x4*>(br + p * C::PLANE + 32 * ks);
+                    }
+                    B3_PRODUCTS(mfma_bf16_16x16x32, acc2[j], w2[ks], b[ks & 1])
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            block_sync_lds();
+#pragma unroll
+            for (int j = 0; j < C::LRT; ++j) store_r((rg2 + C::RG2 * j) * 16 + l16, acc2[j], true);
+        }
+        if (nxt >= 0) request_data((uint32_t)nxt);
+        block_sync_lds();
+        // ---- scores on the bf16 pipe (K = H: the position half; the feature half arrives as gscore), softmax, weighted sum ---
+#pragma unroll
+        for (int j = 0; j < C::SRT; ++j) {
+            const int rt = rg + C::RG * j;
+            f32x16 acc = sacc[j];
+            // (the next step's three A fragments are requested before this step's six MFMAs; the scheduling barrier keeps the
+            //  compiler from hoisting every step's loads to the top -- 96 VGPRs the weights need)
+            const uint16_t* ar = PL + (rt * 32 + col) * PP + 8 * hi;
+            ml3d_u32x4 a[2][3];
+            if constexpr (C::AHEAD) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[0][p] = *reinterpret_cast<const ml3d_u32x4*>(ar + p * C::PLANE);
+            }
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                if constexpr (C::AHEAD) {
+                    if (ks + 1 < C::KS) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) a[(ks + 1) & 1][p] = *reinterpret_cast<const ml3d_u32x4*>(ar + p * C::PLANE + 16 * (ks + 1));
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[ks & 1][p] = *reinterpret_cast<const ml3d_u32x4*>(ar + p * C::PLANE + 16 * ks);
+                }
+                B3_PRODUCTS(mfma_bf16_32x32x16, acc, a[ks & 1], bsw[ks])
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float* xc = X + (rt * 32) * XP + ct * 32 + col;
+            float num[2], den[2];
+            softmax_wsum8<XP>(acc, 0, xc + (4 * hi) * XP, num[0], den[0]);
+            softmax_wsum8<XP>(acc, 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
+            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
+            int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0 of the row tile, half 1 point 1
+            if (m < A.m_total) {
+                if constexpr (ORD) m = A.order[m];
+                A.out[m * D + ct * 32 + col] = agg_mine;
+            }
+        }
+        block_sync_lds();
+        cur = nxt;
+    }
+}
+
+template <int D, int STAGE>
+static int launch_attn_b3(LfaArgs a, hipStream_t st) {
+    using C = B3Cfg<D, STAGE>;
+    static const int cus = device_cu_count();
+    const int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
+    unsigned grid = (unsigned)(tiles < cus ? tiles : cus);       // one 8-wave workgroup per CU, weights split once per workgroup
+    a.xcd_chunk = knobs().attn_xcd ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+    const size_t sm = C::smem_bytes();
+    auto go = [&](auto kern) -> int {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), sm, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    };
+    return a.order ? go(lfa_attn_b3<D, STAGE, true>) : go(lfa_attn_b3<D, STAGE, false>);
+}
+
 // launches the attention part of one stage; `a.out` receives agg [m, D].  D <= 64: the per-wave kernel, D >= 128: the
 // workgroup-tile prefetching kernel.  (Preconditions -- 32-bit point indices, at least one full tile per cloud -- are checked
 // by the caller, which sends everything else to the generic VALU kernel lfa_stage.)
@@ -1106,6 +1502,10 @@ static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     if constexpr (D <= 64) {
         return launch_attn_wave<D, STAGE>(a, st);
     } else {
+        // the bf16x3 kernel wants the SPLIT form (gscore), its tile inside one or two consecutive clouds and 32-bit gscore offsets
+        if constexpr ((ML3D_ATTN_B3) != 0) {
+            if (a.gscore && a.n >= B3Cfg<D, 1>::TP) return launch_attn_b3<D, STAGE>(a, st);     // (the caller put the score bias into gscore)
+        }
         using C = MfmaCfg<D>;
         const int grid_cap = knobs().attn_grid;   // tuning knob
         int64_t tiles = (a.m_total + C::TP - 1) / C::TP;
@@ -2121,10 +2521,12 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             const bool split_on = knobs().attn_split;
             const bool split = split_on && dd >= 32 && dd <= 256 && M * dd * 4 < ((int64_t)1 << 32) &&
                                M < ((int64_t)1 << 30);
-            // (the per-wave kernels of D <= 64 take the score bias inside gscore, the workgroup kernels add it themselves)
+            // (the per-wave kernels of D <= 64 and the bf16x3 kernels of D = 128 / 256 take the score bias inside gscore, the f32
+            //  workgroup kernels add it themselves)
+            const bool b3_attn = (ML3D_ATTN_B3) != 0 && split && ((dd == 128 && n[l] >= B3Cfg<128, 1>::TP) || (dd == 256 && n[l] >= B3Cfg<256, 1>::TP));
             auto point_scores = [&](const float* gfeat, const float* score_wt, const float* score_b, int tag) -> int {
                 LinArgs ga = {};
-                ga.a0 = gfeat; ga.c0 = h; ga.wt = score_wt; ga.bias = dd <= 64 ? score_b : nullptr; ga.out = p2;   // first h rows of [d][d]
+                ga.a0 = gfeat; ga.c0 = h; ga.wt = score_wt; ga.bias = (dd <= 64 || b3_attn) ? score_b : nullptr; ga.out = p2;   // first h rows of [d][d]
                 ga.m_total = M; ga.cout = dd; ga.act = 0;
                 T.begin(tag);
                 const int r = launch_linear_auto(ga, st);

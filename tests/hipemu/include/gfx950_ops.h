@@ -26,4 +26,6 @@ static inline void keep_if(uint32_t& x, bool ok, unsigned long long) { if (!ok) 
 typedef float ml3d_f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t ml3d_u32x4 __attribute__((ext_vector_type(4)));
 static inline ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x16 c) { return hipemu_mfma_32x32x16_bf16(a, b, c); }
+typedef float ml3d_f32x4 __attribute__((ext_vector_type(4)));
+static inline ml3d_f32x4 mfma_bf16_16x16x32(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x4 c) { return hipemu_mfma_16x16x32_bf16(a, b, c); }
 }  // namespace ml3d

@@ -326,6 +326,27 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32
     }
     return d;
 }
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l % 16][k = 8 (l / 16) + e] and B[k = 8 (l / 16) + e][j = l % 16], e = 0..7; the result
+// D[i = 4 (l / 16) + r][j = l % 16], r = 0..3 (summed in double, rounded once: see the 32 x 32 x 16 form above)
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x4 c) {
+    uint32_t ab[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    auto vw = hipemu::wave_exchange(ab, sizeof(ab));
+    const int lane = vw.lane;
+    auto bf = [](const uint32_t* w, int e) { uint32_t u = (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16); float f; memcpy(&f, &u, 4); return f; };
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r, col = lane & 15;
+        double acc = (double)c[r];
+        for (int q = 0; q < 4; ++q) {
+            uint32_t pa[8], pb[8];
+            memcpy(pa, vw.peer(row + 16 * q), sizeof(pa));
+            memcpy(pb, vw.peer(col + 16 * q), sizeof(pb));
+            for (int e = 0; e < 8; ++e) acc += (double)bf(pa, e) * (double)bf(pb + 4, e);
+        }
+        d[r] = (float)acc;
+    }
+    return d;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 
