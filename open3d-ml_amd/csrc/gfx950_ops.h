@@ -71,6 +71,12 @@ __device__ __forceinline__ ml3d_f32x4 mfma_bf16_16x16x32(ml3d_u32x4 a, ml3d_u32x
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// v_permlane32_swap_b32: lanes 32-63 of x trade places with lanes 0-31 of y (one instruction; no LDS, no index register)
+__device__ __forceinline__ void lane32_swap(uint32_t& x, uint32_t& y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
 
 // "does any ACTIVE lane of this wave see pred" in DIVERGENT control flow (lanes whose loops have different trip counts): a ballot
 // over the current exec mask.  The host emulator runs every lane as its own fiber and cannot rendezvous lanes that sit at

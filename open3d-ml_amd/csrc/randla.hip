@@ -59,9 +59,10 @@ static const Knobs& knobs() {
     return k;
 }
 
-// A/B switch (build time, tools/build_variant.sh): 0 keeps the f32-MFMA attention kernels for D >= 128
+// A/B switch (build time, tools/build_variant.sh): which attention stages run on the bf16 matrix pipe (three-way split).
+// bit 0: D = 128 / 256 (lfa_attn_b3), bit 1: D = 64 (lfa_attn_wave_b3); 0 keeps the f32-MFMA kernels everywhere
 #ifndef ML3D_ATTN_B3
-#define ML3D_ATTN_B3 1
+#define ML3D_ATTN_B3 3
 #endif
 #ifndef ML3D_B3_LB_DIV
 #define ML3D_B3_LB_DIV 1        // (register-pressure probe only: 2 lifts the budget to 512 VGPRs)
@@ -1489,6 +1490,314 @@ static int launch_attn_b3(LfaArgs a, hipStream_t st) {
     return a.order ? go(lfa_attn_b3<D, STAGE, true>) : go(lfa_attn_b3<D, STAGE, false>);
 }
 
+// ------------------------------------------------------------------------------------------------
+// lfa_attn_wave_b3 (D = 64, round 6) — lfa_attn_wave with lse2 and the score product on the BF16 matrix pipe (three-way
+// split, six v_mfma_f32_32x32x16_bf16 per 16-deep step: see lfa_attn_b3) and NO LDS round trip for their A operands:
+//   * the lse products run TRANSPOSED (C^T = W^T . R^T): a lane then holds, for ITS (point, neighbour) row, the channels
+//     {0-3, 8-11, 16-19, 24-27} + 4 (lane / 32) -- four runs of four consecutive channels.  They are split three ways in
+//     registers (packed bf16 pairs), and ONE v_permlane32_swap per dword pair trades the runs the two lanes of a row need from
+//     each other: the result IS the operand fragment of the next product (row = lane % 32, K = 8 (lane / 32) + 16 step ..+7).
+//     r1 and r2 never go to LDS as matrix operands; only the float r rows the weighted sum reads by COLUMN are stored
+//     (four ds_write_b128 per lane).
+//   * the weights sit in LDS once per workgroup as bf16 planes (score [3][64][32 + 8], lse2^T [3][32][32 + 8]: 23 KB -- the
+//     f32 form took 21.5 KB), read as conflict-free ds_read_b128 fragments; lse1 (K = 10 + bias slot) keeps the f32 MFMA with its
+//     weights in six registers.
+// Per 32-row tile: 6 f32 MFMAs + 12 + 24 bf16 MFMAs = 1536 matrix cycles against 3456 for the f32 kernel, and the bf16 MFMAs
+// leave the SIMD's VALU issue slots free (the f32 ones do not: tools/micro/mfma_valu_overlap.hip).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct WaveB3Cfg {
+    static constexpr int H = D / 2;                 // 32
+    static constexpr int NT = D / 32;               // score column tiles
+    static constexpr int XP = D + 4;
+    static constexpr int Q = H / 4, G = 32 * Q / 64;
+    static constexpr int W = 12;                    // waves per workgroup
+    static constexpr int PATCH = 32 * XP + 32 * 12 + 32;     // floats per wave: X, relative positions, gscore row offsets
+    static constexpr int WP = H + 8;                // bf16 pitch of a weight row (K = H + 16 bytes: conflict-free b128 fragments)
+    static constexpr int WSP = D * WP, W2P = H * WP;         // bf16 per plane
+    static constexpr size_t smem_bytes() { return (size_t)3 * (WSP + W2P) * 2 + (size_t)H * 4 + (size_t)W * PATCH * 4; }
+    static_assert(H == 32, "lfa_attn_wave_b3: D = 64");
+};
+
+template <int D, int STAGE, bool ORD>
+__global__ void __launch_bounds__((WaveB3Cfg<D>::W * 64)) lfa_attn_wave_b3(LfaArgs A) {
+    using C = WaveB3Cfg<D>;
+    constexpr int H = C::H, XP = C::XP, Q = C::Q, G = C::G, NT = C::NT, WP = C::WP;
+    HIP_DYNAMIC_SHARED(float, smem)
+    uint16_t* WS = reinterpret_cast<uint16_t*>(smem);            // [3][D][WP]   score_WT[H + k][col] as planes[col][k]
+    uint16_t* W2 = WS + 3 * C::WSP;                               // [3][H][WP]   lse2_WT[k][ch] as planes[ch][k]
+    float* B2 = reinterpret_cast<float*>(W2 + 3 * C::W2P);        // [H]          lse2 bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    float* X = B2 + H + wave * C::PATCH;                          // [32][XP]  this wave's tile
+    float* REL = X + 32 * XP;                                     // [32][12]
+    uint32_t* GOFF = reinterpret_cast<uint32_t*>(REL + 32 * 12); // [32] byte offset of each row's gscore row
+
+    // ---- weights -> bf16 planes in LDS (four consecutive K of one column per item) -------------------------------------
+    for (int e = tid; e < D * (H / 4); e += C::W * 64) {
+        const int c = e % D, k4 = (e / D) * 4;
+        uint2 h, m, l;
+        b3_split4(A.score_wt[(H + k4 + 0) * D + c], A.score_wt[(H + k4 + 1) * D + c], A.score_wt[(H + k4 + 2) * D + c],
+                  A.score_wt[(H + k4 + 3) * D + c], h, m, l);
+        uint16_t* d = WS + c * WP + k4;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + C::WSP) = m;
+        *reinterpret_cast<uint2*>(d + 2 * C::WSP) = l;
+    }
+    if constexpr (STAGE == 2) {
+        for (int e = tid; e < H * (H / 4); e += C::W * 64) {
+            const int c = e % H, k4 = (e / H) * 4;
+            uint2 h, m, l;
+            b3_split4(A.lse2_wt[(k4 + 0) * H + c], A.lse2_wt[(k4 + 1) * H + c], A.lse2_wt[(k4 + 2) * H + c],
+                      A.lse2_wt[(k4 + 3) * H + c], h, m, l);
+            uint16_t* d = W2 + c * WP + k4;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + C::W2P) = m;
+            *reinterpret_cast<uint2*>(d + 2 * C::W2P) = l;
+        }
+        for (int e = tid; e < H; e += C::W * 64) B2[e] = A.lse2_b[e];
+    }
+    // lse1^T A operand: W1^T[ch = col][k = 6 hi + s]; K slot 10 carries the bias (REL[:, 10] = 1), slot 11 is zero
+    float w1[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int k = 6 * hi + s;
+        w1[s] = k < 10 ? A.lse1_wt[k * H + col] : (k == 10 ? A.lse1_b[col] : 0.f);
+    }
+    __syncthreads();                                  // the only workgroup barrier
+
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t tiles = (uint32_t)((A.m_total + 1) / 2);       // 2 points per wave tile
+    const uint32_t n_pts = (uint32_t)A.n, m_tot = (uint32_t)A.m_total;
+    const bool xw = A.xcd_chunk > 0;
+    const uint32_t w_step = (xw ? (gridDim.x >> 3) : gridDim.x) * C::W;
+    uint32_t wi = (xw ? (blockIdx.x >> 3) : blockIdx.x) * C::W + swave;
+    auto next_tile = [&]() -> int64_t {
+        for (;;) {
+            int64_t t = wi;
+            if (xw) t = xcd_tile((int64_t)wi, (int)(blockIdx.x & 7), A.xcd_chunk, (int64_t)tiles);
+            wi += w_step;
+            if (t < 0) return -1;
+            if (t < (int64_t)tiles) return t;
+            if (!xw) return -1;
+        }
+    };
+
+    int gi[G], nb_mine = -1;
+    float4 gq[G];
+    float qx = 0.f, qy = 0.f, qz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    bool mine_valid = false;
+    uint32_t goff_mine = 0;
+    uint32_t mo0 = 0, mo1 = 0;
+    auto request_idx = [&](uint32_t tile) {
+        const uint32_t lim = (m_tot - tile * 2) >= 2 ? 32u : 16u;
+        if constexpr (ORD) {
+            mo0 = (uint32_t)A.order[tile * 2];
+            mo1 = lim == 32u ? (uint32_t)A.order[tile * 2 + 1] : mo0;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
+                gi[i] = row < lim ? __builtin_nontemporal_load(A.nidx + (int64_t)(row < RK ? mo0 : mo1) * RK + (row & (RK - 1))) : -1;
+            }
+            nb_mine = (uint32_t)lane < lim
+                          ? __builtin_nontemporal_load(A.nidx + (int64_t)(lane < RK ? mo0 : mo1) * RK + (lane & (RK - 1))) : -1;
+        } else {
+            const int32_t* nb = A.nidx + (int64_t)tile * 2 * RK;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t row = (uint32_t)(lane + 64 * i) / Q;
+                gi[i] = row < lim ? __builtin_nontemporal_load(nb + row) : -1;
+            }
+            nb_mine = (uint32_t)lane < lim ? __builtin_nontemporal_load(nb + lane) : -1;
+        }
+    };
+    auto request_data = [&](uint32_t tile) {
+        uint32_t b0, l0, b1, l1;
+        if constexpr (ORD) {
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mo0);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mo1);
+            b0 = m0 / n_pts; l0 = m0 - b0 * n_pts;
+            b1 = m1 / n_pts; l1 = m1 - b1 * n_pts;
+        } else {
+            const uint32_t m0 = tile * 2;
+            b0 = m0 / n_pts; l0 = m0 - b0 * n_pts;
+            const bool wrap = l0 + 1 == n_pts;
+            b1 = wrap ? b0 + 1 : b0; l1 = wrap ? 0u : l0 + 1;
+        }
+        const float* f0 = A.gfeat + (int64_t)b0 * n_pts * H;
+        const float* f1 = A.gfeat + (int64_t)b1 * n_pts * H;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / Q, q = e - row * Q;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gi[i] >= 0) gq[i] = *reinterpret_cast<const float4*>((row < RK ? f0 : f1) + (uint32_t)gi[i] * H + 4 * q);
+        }
+        mine_valid = lane < 32 && nb_mine >= 0;
+        if (mine_valid) {
+            const bool p1 = lane >= RK;
+            goff_mine = ((p1 ? b1 : b0) * n_pts + (uint32_t)nb_mine) * (uint32_t)(D * 4);
+            const float* xb = A.xyz + 3 * ((int64_t)(p1 ? b1 : b0) * A.n0);
+            const float* qp = xb + 3 * (p1 ? l1 : l0);
+            const float* sp = xb + 3 * (uint32_t)nb_mine;
+            qx = qp[0]; qy = qp[1]; qz = qp[2]; sx = sp[0]; sy = sp[1]; sz = sp[2];
+        }
+    };
+    // lrelu of a transposed 32 x 32 result (this lane: row col, channels 8 g + 4 hi .. + 3, g = 0..3) -> the float rows of X[:, H:]
+    // and the three-way split as operand fragments of the next product: frag[p][ks] = K 16 ks + 8 hi .. + 7 of row col
+    auto finish_r = [&](const f32x16& acc, const float* bias /* LDS [H] or null */, bool to_x, ml3d_u32x4 (&frag)[3][2]) {
+        uint2 pk[3][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * hi);
+            const float v0 = lrelu_max(acc[4 * g + 0] + b.x, 0.2f), v1 = lrelu_max(acc[4 * g + 1] + b.y, 0.2f),
+                        v2 = lrelu_max(acc[4 * g + 2] + b.z, 0.2f), v3 = lrelu_max(acc[4 * g + 3] + b.w, 0.2f);
+            if (to_x) *reinterpret_cast<float4*>(X + col * XP + H + 8 * g + 4 * hi) = make_float4(v0, v1, v2, v3);
+            b3_split4(v0, v1, v2, v3, pk[0][g], pk[1][g], pk[2][g]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // runs g = 2 ks (channels 16 ks + 4 hi ..) and g = 2 ks + 1 (16 ks + 8 + 4 hi ..): the low half-wave needs the high one's
+                // first run, the high half-wave the low one's second run
+                uint32_t x0 = pk[p][2 * ks].x, x1 = pk[p][2 * ks].y, y0 = pk[p][2 * ks + 1].x, y1 = pk[p][2 * ks + 1].y;
+                lane32_swap(x0, y0);
+                lane32_swap(x1, y1);
+                frag[p][ks] = (ml3d_u32x4){x0, x1, y0, y1};
+            }
+    };
+
+    int64_t cur = next_tile();
+    if (cur >= 0) { request_idx((uint32_t)cur); request_data((uint32_t)cur); }
+    while (cur >= 0) {
+        const int64_t nxt = next_tile();
+        const uint32_t mo0_cur = mo0, mo1_cur = mo1;
+        // ---- registers -> the wave's patch ---------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / Q, q = e - row * Q;
+            *reinterpret_cast<float4*>(X + row * XP + 4 * q) = gq[i];
+        }
+        if (lane < 32) {
+            float* r = REL + lane * 12;
+            if (mine_valid) {
+                const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+                r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+                r[1] = dx; r[2] = dy; r[3] = dz; r[4] = qx; r[5] = qy; r[6] = qz; r[7] = sx; r[8] = sy; r[9] = sz;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) r[j] = 0.f;
+            }
+            r[10] = 1.f; r[11] = 0.f;                             // bias slot, K padding
+            GOFF[lane] = mine_valid ? goff_mine : 0u;             // (rows past the data read row 0: never stored)
+        }
+        if (nxt >= 0) request_idx((uint32_t)nxt);
+        wave_lds_sync();
+        // the neighbours' per-point score halves (gscore, bias included) become the accumulators' initial value
+        f32x16 sc[NT];
+        {
+            const char* gbase = reinterpret_cast<const char*>(A.gscore);
+            const uint32_t col4 = 4u * col;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const uint4 go = *reinterpret_cast<const uint4*>(GOFF + 8 * q4 + 4 * hi);     // rows mfma_row(4 q4 .. 4 q4 + 3)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    sc[t][4 * q4 + 0] = *reinterpret_cast<const float*>(gbase + (go.x + col4 + 128u * t));
+                    sc[t][4 * q4 + 1] = *reinterpret_cast<const float*>(gbase + (go.y + col4 + 128u * t));
+                    sc[t][4 * q4 + 2] = *reinterpret_cast<const float*>(gbase + (go.z + col4 + 128u * t));
+                    sc[t][4 * q4 + 3] = *reinterpret_cast<const float*>(gbase + (go.w + col4 + 128u * t));
+                }
+            }
+        }
+        ml3d_u32x4 frag[3][2];
+        // ---- r1^T = lse1_W^T . rel^T on the f32 MFMA (K = 12); lrelu, float rows -> X[:, H:], split -> fragments -----------
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* br = REL + col * 12 + hi * 6;
+            const float2 b01 = *reinterpret_cast<const float2*>(br);
+            const float2 b23 = *reinterpret_cast<const float2*>(br + 2);
+            const float2 b45 = *reinterpret_cast<const float2*>(br + 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[0], b01.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[1], b01.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2], b23.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[3], b23.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[4], b45.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[5], b45.y, acc, 0, 0, 0);
+            finish_r(acc, nullptr, STAGE == 1, frag);
+        }
+        if constexpr (STAGE == 2) {
+            // ---- r2^T = lse2_W^T . r1^T on the bf16 pipe (A = weight planes from LDS, B = the fragments) ------------------------------
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const uint16_t* ar = W2 + col * WP + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ml3d_u32x4 a[3], b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { a[p] = *reinterpret_cast<const ml3d_u32x4*>(ar + p * C::W2P + 16 * ks); b[p] = frag[p][ks]; }
+                B3_PRODUCTS(mfma_bf16_32x32x16, acc, a, b)
+            }
+            finish_r(acc, B2, true, frag);
+        }
+        if (nxt >= 0) request_data((uint32_t)nxt);
+        // ---- scores (A = the fragments, B = weight planes from LDS), softmax over the 16 neighbours, weighted sum ------------
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ml3d_u32x4 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = frag[p][ks];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint16_t* br = WS + (32 * t + col) * WP + 8 * hi + 16 * ks;
+                ml3d_u32x4 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const ml3d_u32x4*>(br + p * C::WSP);
+                B3_PRODUCTS(mfma_bf16_32x32x16, sc[t], a, b)
+            }
+        }
+        wave_lds_sync();                                          // X[:, H:] of every row is written
+        const uint32_t mi = (uint32_t)cur * 2 + hi;               // half 0 stores point 0, half 1 point 1
+        const uint32_t m = ORD ? (hi ? mo1_cur : mo0_cur) : mi;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* xc = X + 32 * t + col;
+            float num[2], den[2];
+            softmax_wsum8<XP>(sc[t], 0, xc + (4 * hi) * XP, num[0], den[0]);
+            softmax_wsum8<XP>(sc[t], 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
+            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
+            if (mi < m_tot) __builtin_nontemporal_store(agg_mine, A.out + (int64_t)m * D + 32 * t + col);
+        }
+        wave_lds_sync();                                          // the patch is rewritten at the top of the loop
+        cur = nxt;
+    }
+}
+
+template <int D, int STAGE>
+static int launch_attn_wave_b3(LfaArgs a, hipStream_t st) {
+    using C = WaveB3Cfg<D>;
+    const int64_t tiles = (a.m_total + 1) / 2;
+    static const int cus = device_cu_count();
+    int64_t blocks = (tiles + C::W - 1) / C::W;
+    unsigned grid = (unsigned)(blocks < cus ? blocks : cus);     // one 12-wave workgroup per CU (LDS-bound)
+    a.xcd_chunk = knobs().attn_xcd ? xcd_chunk_tiles(tiles, a.n > 0 ? a.m_total / a.n : 0) : 0;
+    if (a.xcd_chunk > 0) grid = (grid + 7u) & ~7u;
+    const size_t sm = C::smem_bytes();
+    auto go = [&](auto kern) -> int {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+            return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::W * 64), sm, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    };
+    return a.order ? go(lfa_attn_wave_b3<D, STAGE, true>) : go(lfa_attn_wave_b3<D, STAGE, false>);
+}
+
 // launches the attention part of one stage; `a.out` receives agg [m, D].  D <= 64: the per-wave kernel, D >= 128: the
 // workgroup-tile prefetching kernel.  (Preconditions -- 32-bit point indices, at least one full tile per cloud -- are checked
 // by the caller, which sends everything else to the generic VALU kernel lfa_stage.)
@@ -1500,10 +1809,13 @@ static bool attn_mfma_fits(const LfaArgs& a) {
 template <int D, int STAGE>
 static int launch_attn_mfma(LfaArgs a, hipStream_t st) {
     if constexpr (D <= 64) {
+        if constexpr (D == 64 && ((ML3D_ATTN_B3) & 2) != 0) {
+            if (a.gscore) return launch_attn_wave_b3<D, STAGE>(a, st);
+        }
         return launch_attn_wave<D, STAGE>(a, st);
     } else {
         // the bf16x3 kernel wants the SPLIT form (gscore), its tile inside one or two consecutive clouds and 32-bit gscore offsets
-        if constexpr ((ML3D_ATTN_B3) != 0) {
+        if constexpr (((ML3D_ATTN_B3) & 1) != 0) {
             if (a.gscore && a.n >= B3Cfg<D, 1>::TP) return launch_attn_b3<D, STAGE>(a, st);     // (the caller put the score bias into gscore)
         }
         using C = MfmaCfg<D>;
@@ -2523,7 +2835,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
                                M < ((int64_t)1 << 30);
             // (the per-wave kernels of D <= 64 and the bf16x3 kernels of D = 128 / 256 take the score bias inside gscore, the f32
             //  workgroup kernels add it themselves)
-            const bool b3_attn = (ML3D_ATTN_B3) != 0 && split && ((dd == 128 && n[l] >= B3Cfg<128, 1>::TP) || (dd == 256 && n[l] >= B3Cfg<256, 1>::TP));
+            const bool b3_attn = ((ML3D_ATTN_B3) & 1) != 0 && split && ((dd == 128 && n[l] >= B3Cfg<128, 1>::TP) || (dd == 256 && n[l] >= B3Cfg<256, 1>::TP));
             auto point_scores = [&](const float* gfeat, const float* score_wt, const float* score_b, int tag) -> int {
                 LinArgs ga = {};
                 ga.a0 = gfeat; ga.c0 = h; ga.wt = score_wt; ga.bias = (dd <= 64 || b3_attn) ? score_b : nullptr; ga.out = p2;   // first h rows of [d][d]
