@@ -630,7 +630,7 @@ def run_kpconv(args, rank, world, dev, dist):
                    "index; two event intervals summed (grid build + gather, then expand): the host read-back of the longest row "
                    "between them is not in the figure" %
                    (rnq, cfg['first_subsampling_dl'] * cfg['conv_radius'], rnq, rH), len(prim_in)),
-        _hbm_entry("a11 batch grid subsample (kpconv.py:2037-2164)", "rotate_points + sub_keys + rs_hist / rs_scatter + sub_* (count + fill)",
+        _hbm_entry("a11 batch grid subsample (kpconv.py:2037-2164)", "rotate_rows_k + sub_items_k<count> + sub_items_k<fill> (one workgroup per sphere, grouping in LDS; round 5: 64-bit radix sort, ~30 launches)",
                    sub_bytes, col(prim_in, 1), col(prim_alone, 1), "kp_subsample", B,
                    "layer-0 pooling grid of the batch: %d points -> %d barycentres at dl = %.3g m on randomly oriented grids; two "
                    "event intervals summed (rotation + count, fill + rotation back): the read-back of the pooled size between them "

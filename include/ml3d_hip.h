@@ -47,7 +47,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes (2: ml3d_radius_fill takes a spill buffer).  The Python binding   */
 /* refuses a library whose version differs from the header it was written against: a stale .so would misread its arguments.        */
-#define ML3D_ABI_VERSION 11
+#define ML3D_ABI_VERSION 12
 int ml3d_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -205,6 +205,29 @@ int ml3d_subsample_fill(const float* points, const float* features, int64_t feat
                         const int32_t* labels, int64_t batch, int64_t n_points,
                         float* out_points, float* out_features, int32_t* out_labels,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same op with ONE WORKGROUP PER BATCH ITEM and no workspace (ABI 12): what the KPConv     */
+/* batch build calls ~4 times per batch on ~100 spheres (concat_batcher.py:243-247 ->         */
+/* kpconv.py:2037-2164).  The item's bounding box, an occupancy bitmap of its grid, the voxel  */
+/* ordinals (popcount prefix: ascending key order without a sort), the grouping and the        */
+/* float32 sums in original point order all happen in LDS; count and fill are one launch each  */
+/* (the fill repeats the grouping).  Points only (no features / labels).  Limits per item:     */
+/* ml3d_subsample_items_max_points() points -- pass the largest item length in                 */
+/* max_item_points (HOST value; ML3D_E_UNSUPPORTED when it is larger: use ml3d_subsample_count) */
+/* -- and 262 144 grid cells, checked on the device: out_stats[1] == 2 after the count means   */
+/* "an item's grid is larger: repeat the call with ml3d_subsample_count".  Results identical   */
+/* to ml3d_subsample_count / _fill bit for bit.                                                 */
+/*  count: out_lengths int64[batch], out_stats int64[2] = {total M, 0 or 2}                     */
+/*  fill : lengths = the count's out_lengths (device), out_points [M,3]                         */
+int64_t ml3d_subsample_items_max_points(void);
+
+int ml3d_subsample_items_count(const float* points, const int64_t* row_splits, int64_t batch,
+                               int64_t n_points, float sample_dl, int64_t max_item_points,
+                               int64_t* out_lengths, int64_t* out_stats, void* stream);
+
+int ml3d_subsample_items_fill(const float* points, const int64_t* row_splits, int64_t batch,
+                              int64_t n_points, float sample_dl, const int64_t* lengths,
+                              float* out_points, void* stream);
 
 /* Per-item row-vector rotation p' = p . R[b] (transpose != 0: p . R[b]^T) around the grid   */
 /* subsample of batch_grid_subsampling (random_grid_orient, kpconv.py:2059-2110); float32     */

@@ -157,6 +157,14 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
     auto mark = [&](int l, int i) {       // measurement hook: layer 0 only, only when the caller handed events in
         if (l == 0 && desc->trace_events[i]) (void)hipEventRecord((hipEvent_t)desc->trace_events[i], st);
     };
+    // the pooling of a layer runs one workgroup per item in LDS (ml3d_subsample_items_*: two launches instead of ~30) when every
+    // item of the level has at most ml3d_subsample_items_max_points() points; larger items keep the sort-based two-phase op
+    bool items_sub[ML3D_KPBATCH_MAX_LAYERS] = {};
+    auto max_item = [&](int l) -> int64_t {
+        int64_t m = 0;
+        for (int64_t b = 0; b < batch; ++b) m = out_lengths_host[(size_t)l * (size_t)batch + b] > m ? out_lengths_host[(size_t)l * (size_t)batch + b] : m;
+        return m;
+    };
     auto phase_a = [&](int l) -> int {
         KpbSet& W = S[l & 1];
         if (desc->has_conv[l]) {
@@ -174,7 +182,11 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
                 if (rc) return rc;
                 src = W.rot_in;
             }
-            rc = ml3d_subsample_count(src, splits[l], batch, n[l], desc->dl[l], rec[l] + 8, rec[l] + 2, W.sub_ws, W.sub_wsb, st);
+            items_sub[l] = max_item(l) <= ml3d_subsample_items_max_points();
+            if (items_sub[l])
+                rc = ml3d_subsample_items_count(src, splits[l], batch, n[l], desc->dl[l], max_item(l), rec[l] + 8, rec[l] + 2, st);
+            else
+                rc = ml3d_subsample_count(src, splits[l], batch, n[l], desc->dl[l], rec[l] + 8, rec[l] + 2, W.sub_ws, W.sub_wsb, st);
             if (rc) return rc;
             mark(l, 5);
         }
@@ -229,6 +241,7 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
         }
         if (l + 1 == L) break;
         // ---- pooled level l + 1 ------------------------------------------------------------------------------------------------
+        if (hrec[3] == 2) return ML3D_KPBATCH_FALLBACK;    // an item's grid has more cells than the per-item kernel's bitmap: per-layer path
         if (hrec[3]) return ML3D_E_UNSUPPORTED;            // an item spans >= 2^40 voxels at this dl
         const int64_t m_next = hrec[2];
         n[l + 1] = m_next;
@@ -239,8 +252,12 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
         if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
         const bool rot = rotations && rotations[l];
         mark(l, 6);
-        rc = ml3d_subsample_fill(rot ? W.rot_in : pts[l], nullptr, 0, nullptr, batch, n[l], rot ? W.rot_out : pool_p, nullptr, nullptr,
-                                 W.sub_ws, W.sub_wsb, st);
+        if (items_sub[l])
+            rc = ml3d_subsample_items_fill(rot ? W.rot_in : pts[l], splits[l], batch, n[l], desc->dl[l], rec[l] + 8,
+                                           rot ? W.rot_out : pool_p, st);
+        else
+            rc = ml3d_subsample_fill(rot ? W.rot_in : pts[l], nullptr, 0, nullptr, batch, n[l], rot ? W.rot_out : pool_p, nullptr, nullptr,
+                                     W.sub_ws, W.sub_wsb, st);
         if (rc) return rc;
         if (rot) {
             rc = ml3d_rotate_points(W.rot_out, splits[l + 1], batch, m_next, rotations[l], 1, pool_p, st);

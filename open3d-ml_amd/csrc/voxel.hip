@@ -297,6 +297,214 @@ __global__ void sub_fill(const uint32_t* __restrict__ vals, const int* __restric
     }
 }
 
+// ---- grid subsample, ONE WORKGROUP PER BATCH ITEM (round 6) -----------------------------------------------------------------------
+// The KPConv batch build subsamples ~100 spheres of <= 10 000 points four times per batch; through the stable 64-bit radix sort above
+// that is ~30 dependent launches per call over 12-byte pairs.  Here a 1024-thread workgroup owns one item END TO END in LDS, the
+// whole call is ONE launch (count) + ONE launch (fill):
+//   bounding box (the item's own min / max: the same origin and grid as sub_setup) -> occupancy BITMAP of the item's grid (1 bit per
+//   cell, atomicOr) -> popcount prefix of the bitmap words: the voxel ordinal of a cell = words before + bits below, i.e. voxels
+//   come out in ascending key order without a sort -> per-voxel counters (16-bit pairs, atomicAdd returns the arrival slot) ->
+//   exclusive scan -> scatter of the local point indices -> every run is put back into ORIGINAL point order (insertion sort by the
+//   voxel's thread; runs longer than SI_LONG by the whole workgroup: rank = number of smaller indices) -> float32 sums in that order.
+// The fill launch repeats the grouping (a few microseconds in LDS) instead of carrying 6 bytes per point through HBM, so the op
+// needs NO workspace.  Limits: SI_NMAX points and SI_CMAX grid cells per item (a 4 m sphere at dl = 0.16 m has 125 000); anything
+// larger -- whole clouds of the preprocessing front end -- keeps the sort path (the caller retries on stats[1] == 2).
+constexpr int SI_THREADS = 1024;
+constexpr int SI_NMAX = 12288;
+constexpr int SI_CMAX = 262144;
+constexpr int SI_WORDS = SI_CMAX / 32;
+constexpr int SI_LONG = 48;
+constexpr int SI_LIST = SI_NMAX / SI_LONG + 8;
+
+struct SiSmem {
+    uint32_t bitmap[SI_WORDS];          // 32 KB  occupancy; later the staging buffer of long runs (3 x 1024 floats)
+    uint16_t wpre[SI_WORDS];            // 16 KB  voxels before this word
+    uint16_t vox[SI_NMAX];              // 24 KB  voxel ordinal of local point i
+    uint32_t cnt[SI_NMAX / 2 + 8];      // 24 KB  16-bit pairs: per-voxel counters, then IN PLACE hp[v] (first slot; hp[M] = n)
+    uint16_t slot[SI_NMAX];             // 24 KB  arrival slot of point i; later the ordered copy of a long run
+    uint16_t run[SI_NMAX];              // 24 KB  local point indices grouped by voxel
+    uint16_t longv[SI_LIST];
+    float red[16][6];
+    int scan[16];
+    int misc[8];                        // [0] M  [1] number of long runs  [2] failure
+};
+
+// exclusive prefix of one int per thread over the 1024-thread workgroup; `total` = the sum (all threads)
+__device__ __forceinline__ int si_block_exscan(int v, int* scan16, int& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int incl = wave_inclusive_scan(v);
+    __syncthreads();                                   // (scan16 may still be read from the previous use)
+    if (lane == 63) scan16[wv] = incl;
+    __syncthreads();
+    int carry = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int s = scan16[w]; if (w < wv) carry += s; tot += s; }
+    total = tot;
+    return carry + incl - v;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(SI_THREADS)
+sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, int batch, float dl, int64_t* __restrict__ lengths,
+            int64_t* __restrict__ stats, float* __restrict__ out_pts) {
+    HIP_DYNAMIC_SHARED(unsigned char, si_raw)
+    SiSmem& L = *reinterpret_cast<SiSmem*>(si_raw);
+    uint16_t* hp = reinterpret_cast<uint16_t*>(L.cnt);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, b = blockIdx.x;
+    const int64_t s0 = splits[b];
+    const int n = (int)(splits[b + 1] - s0);
+    if (n <= 0) { if (!FILL && t == 0) lengths[b] = 0; return; }
+    if (n > SI_NMAX) { if (!FILL && t == 0) { lengths[b] = 0; stats[1] = 2; } return; }
+    const float* P = pts + 3 * s0;
+    // ---- the item's bounding box -> origin and grid (sub_setup's arithmetic) -----------------------------------------------------------
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = t; i < n; i += SI_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[3 * i + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { L.red[wv][a] = mn[a]; L.red[wv][3 + a] = mx[a]; }
+    }
+    for (int w = t; w < SI_WORDS; w += SI_THREADS) L.bitmap[w] = 0u;
+    for (int w = t; w < SI_NMAX / 2 + 8; w += SI_THREADS) L.cnt[w] = 0u;
+    if (t == 0) { L.misc[1] = 0; L.misc[2] = 0; }
+    __syncthreads();
+    float org[3];
+    int G[3];
+    double cells = 1.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = L.red[0][a], hi = L.red[0][3 + a];
+        for (int w = 1; w < 16; ++w) { lo = fminf(lo, L.red[w][a]); hi = fmaxf(hi, L.red[w][3 + a]); }
+        org[a] = __fmul_rn(floorf(__fdiv_rn(lo, dl)), dl);
+        const float gf = floorf(__fdiv_rn(__fsub_rn(hi, org[a]), dl));
+        G[a] = gf < 2.0e9f ? (int)gf + 1 : 0x7fffffff;
+        if (G[a] < 1) G[a] = 1;
+        cells *= (double)G[a];
+    }
+    if (cells > (double)SI_CMAX) { if (!FILL && t == 0) { lengths[b] = 0; stats[1] = 2; } return; }
+    auto cell_of = [&](int i) -> uint32_t {
+        const float* p = P + 3 * i;
+        const int c0 = (int)floorf(__fdiv_rn(__fsub_rn(p[0], org[0]), dl));
+        const int c1 = (int)floorf(__fdiv_rn(__fsub_rn(p[1], org[1]), dl));
+        const int c2 = (int)floorf(__fdiv_rn(__fsub_rn(p[2], org[2]), dl));
+        return (uint32_t)(c0 + G[0] * (c1 + G[1] * c2));
+    };
+    // ---- occupancy bitmap -------------------------------------------------------------------------------------------------------
+    for (int i = t; i < n; i += SI_THREADS) {
+        const uint32_t c = cell_of(i);
+        atomicOr(&L.bitmap[c >> 5], 1u << (c & 31u));
+    }
+    __syncthreads();
+    // ---- voxels before every word (each thread: 8 consecutive words) ------------------------------------------------------------------
+    int M;
+    {
+        int pc[SI_WORDS / SI_THREADS], sum = 0;
+#pragma unroll
+        for (int j = 0; j < SI_WORDS / SI_THREADS; ++j) { pc[j] = __popc(L.bitmap[t * (SI_WORDS / SI_THREADS) + j]); sum += pc[j]; }
+        int run0 = si_block_exscan(sum, L.scan, M);
+#pragma unroll
+        for (int j = 0; j < SI_WORDS / SI_THREADS; ++j) { L.wpre[t * (SI_WORDS / SI_THREADS) + j] = (uint16_t)run0; run0 += pc[j]; }
+    }
+    __syncthreads();
+    if (!FILL) {
+        if (t == 0) { lengths[b] = M; atomicAdd(reinterpret_cast<unsigned long long*>(stats), (unsigned long long)M); }
+        return;
+    }
+    // ---- voxel ordinal + arrival slot of every point ------------------------------------------------------------------------------------
+    for (int i = t; i < n; i += SI_THREADS) {
+        const uint32_t c = cell_of(i), w = c >> 5;
+        const int v = (int)L.wpre[w] + __popc(L.bitmap[w] & ((1u << (c & 31u)) - 1u));
+        L.vox[i] = (uint16_t)v;
+        const uint32_t old = atomicAdd(&L.cnt[v >> 1], (v & 1) ? 0x10000u : 1u);
+        L.slot[i] = (uint16_t)((v & 1) ? (old >> 16) : (old & 0xffffu));
+    }
+    __syncthreads();
+    // ---- counters -> first slots, in place (each thread: 12 consecutive voxels; entry M becomes n) ---------------------------------------
+    {
+        constexpr int PER = SI_NMAX / SI_THREADS;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { c[j] = hp[t * PER + j]; sum += c[j]; }
+        int tot, run0 = si_block_exscan(sum, L.scan, tot);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { hp[t * PER + j] = (uint16_t)run0; run0 += c[j]; }
+        if (t == SI_THREADS - 1) hp[SI_NMAX] = (uint16_t)run0;        // (M == SI_NMAX: every point its own voxel)
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += SI_THREADS) L.run[(int)hp[L.vox[i]] + (int)L.slot[i]] = (uint16_t)i;
+    __syncthreads();
+    // ---- first output row of this item ---------------------------------------------------------------------------------------------------
+    int64_t off = 0;
+    {
+        long long part = 0;
+        for (int q = t; q < b; q += SI_THREADS) part += (long long)lengths[q];
+        int lo32 = (int)(part & 0x7fffffffll), hi32 = (int)(part >> 31);      // (two 31-bit halves through the int scan)
+        int tl, th;
+        (void)si_block_exscan(lo32, L.scan, tl);
+        (void)si_block_exscan(hi32, L.scan, th);
+        off = ((int64_t)th << 31) + (int64_t)tl;
+    }
+    // ---- barycentres: float32 sums in original point order ----------------------------------------------------------------------------
+    for (int v = t; v < M; v += SI_THREADS) {
+        const int h0 = hp[v], h1 = hp[v + 1], c = h1 - h0;
+        if (c > SI_LONG) { L.longv[atomicAdd(&L.misc[1], 1)] = (uint16_t)v; continue; }
+        for (int i = h0 + 1; i < h1; ++i) {                         // insertion sort of the run (ascending local index)
+            const uint16_t x = L.run[i];
+            int j = i - 1;
+            while (j >= h0 && L.run[j] > x) { L.run[j + 1] = L.run[j]; --j; }
+            L.run[j + 1] = x;
+        }
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int h = h0; h < h1; ++h) {
+            const float* p = P + 3 * (int)L.run[h];
+            sx = __fadd_rn(sx, p[0]); sy = __fadd_rn(sy, p[1]); sz = __fadd_rn(sz, p[2]);
+        }
+        const float fc = (float)c;
+        float* o = out_pts + 3 * (off + v);
+        o[0] = __fdiv_rn(sx, fc); o[1] = __fdiv_rn(sy, fc); o[2] = __fdiv_rn(sz, fc);
+    }
+    __syncthreads();
+    const int n_long = L.misc[1];
+    float* stage = reinterpret_cast<float*>(L.bitmap);             // (the bitmap is no longer needed)
+    for (int q = 0; q < n_long; ++q) {
+        const int v = L.longv[q], h0 = hp[v], h1 = hp[v + 1], c = h1 - h0;
+        for (int e = t; e < c; e += SI_THREADS) {                   // ordered copy: rank = number of smaller indices in the run
+            const uint16_t x = L.run[h0 + e];
+            int r = 0;
+            for (int j = 0; j < c; ++j) r += (L.run[h0 + j] < x) ? 1 : 0;
+            L.slot[h0 + r] = x;
+        }
+        __syncthreads();
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int base = 0; base < c; base += SI_THREADS) {          // 1024 points at a time through LDS, summed in order by thread 0
+            const int e = base + t;
+            if (e < c) {
+                const float* p = P + 3 * (int)L.slot[h0 + e];
+                stage[3 * t + 0] = p[0]; stage[3 * t + 1] = p[1]; stage[3 * t + 2] = p[2];
+            }
+            __syncthreads();
+            if (t == 0) {
+                const int m = c - base < SI_THREADS ? c - base : SI_THREADS;
+                for (int j = 0; j < m; ++j) {
+                    sx = __fadd_rn(sx, stage[3 * j]); sy = __fadd_rn(sy, stage[3 * j + 1]); sz = __fadd_rn(sz, stage[3 * j + 2]);
+                }
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            const float fc = (float)c;
+            float* o = out_pts + 3 * (off + v);
+            o[0] = __fdiv_rn(sx, fc); o[1] = __fdiv_rn(sy, fc); o[2] = __fdiv_rn(sz, fc);
+        }
+    }
+}
+
 // out[i, j] = (p[i,0] * R[b][0][j] + p[i,1] * R[b][1][j]) + p[i,2] * R[b][2][j]   (transpose: R[b][j][.])
 // — the row-vector rotation of batch_grid_subsampling (kpconv.py:2086-2092, 2105-2110), every product and
 // sum rounded separately like numpy's float32 `np.sum(expand_dims(p, 2) * R, axis=1)`.
@@ -474,6 +682,40 @@ extern "C" int ml3d_subsample_fill(const float* points, const float* features, i
     hipLaunchKernelGGL(sub_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W.vals,
                        W.flags, n_points, W.hp, points, features, feature_dim, labels, out_points, out_features,
                        out_labels);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" int64_t ml3d_subsample_items_max_points(void) { return SI_NMAX; }
+
+extern "C" int ml3d_subsample_items_count(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
+                                          float sample_dl, int64_t max_item_points, int64_t* out_lengths, int64_t* out_stats,
+                                          void* stream) {
+    if (!row_splits || batch <= 0 || batch > 65535 || n_points < 0 || !(sample_dl > 0.f) || !out_lengths || !out_stats ||
+        (n_points > 0 && !points))
+        return ML3D_E_INVALID;
+    if (max_item_points < 0 || max_item_points > SI_NMAX) return ML3D_E_UNSUPPORTED;      // (the caller keeps ml3d_subsample_count)
+    hipStream_t st = (hipStream_t)stream;
+    zero_async(out_stats, 2 * sizeof(int64_t), st);
+    const auto kern = sub_items_k<false>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SiSmem)) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SI_THREADS), sizeof(SiSmem), st, points, row_splits, (int)batch, sample_dl,
+                       out_lengths, out_stats, (float*)nullptr);
+    VX_CHECK();
+    return 0;
+}
+
+extern "C" int ml3d_subsample_items_fill(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
+                                         float sample_dl, const int64_t* lengths, float* out_points, void* stream) {
+    if (!row_splits || batch <= 0 || batch > 65535 || n_points < 0 || !(sample_dl > 0.f) || !lengths) return ML3D_E_INVALID;
+    if (n_points == 0) return 0;
+    if (!points || !out_points) return ML3D_E_INVALID;
+    const auto kern = sub_items_k<true>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SiSmem)) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SI_THREADS), sizeof(SiSmem), (hipStream_t)stream, points, row_splits,
+                       (int)batch, sample_dl, const_cast<int64_t*>(lengths), (int64_t*)nullptr, out_points);
     VX_CHECK();
     return 0;
 }

@@ -15,7 +15,7 @@ _lib = None
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "unsupported configuration"}
 
-ABI_VERSION = 11         # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
+ABI_VERSION = 12         # ML3D_ABI_VERSION of include/ml3d_hip.h (checked against the loaded library in get())
 
 # every symbol include/ml3d_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
@@ -35,6 +35,9 @@ SYMBOLS = [
     "ml3d_subsample_workspace_bytes",
     "ml3d_subsample_count",
     "ml3d_subsample_fill",
+    "ml3d_subsample_items_max_points",
+    "ml3d_subsample_items_count",
+    "ml3d_subsample_items_fill",
     "ml3d_rotate_points",
     "ml3d_kpconv_batch_workspace_bytes", "ml3d_kpconv_batch_host_scratch_bytes", "ml3d_kpconv_batch_build",
     "ml3d_kpconv_workspace_bytes",
@@ -148,6 +151,12 @@ def bind(lib):
     lib.ml3d_subsample_count.argtypes = [vp, vp, i64, i64, f32, vp, vp, vp, sz, vp]
     lib.ml3d_subsample_fill.restype = C.c_int
     lib.ml3d_subsample_fill.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, sz, vp]
+    lib.ml3d_subsample_items_max_points.restype = i64
+    lib.ml3d_subsample_items_max_points.argtypes = []
+    lib.ml3d_subsample_items_count.restype = C.c_int
+    lib.ml3d_subsample_items_count.argtypes = [vp, vp, i64, i64, f32, i64, vp, vp, vp]
+    lib.ml3d_subsample_items_fill.restype = C.c_int
+    lib.ml3d_subsample_items_fill.argtypes = [vp, vp, i64, i64, f32, vp, vp, vp]
     lib.ml3d_rotate_points.restype = C.c_int
     lib.ml3d_rotate_points.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
     lib.ml3d_kpconv_batch_workspace_bytes.restype = sz

@@ -143,6 +143,9 @@ def rotate_points(points, lengths_or_splits, rotations, transpose=False, is_spli
     return out
 
 
+_FORCE_SORTED = False        # tests: True keeps every grid subsampling on the sort-based op (ml3d_subsample_count / _fill)
+
+
 class _SubsamplePlan:
     """``batch_grid_subsampling`` (points only) in two halves, so that its one host read-back (the number of pooled points, needed
     to allocate them) can be shared with other pending sizes: ``stats`` int64 [2] = (pooled points, overflow flag) and
@@ -160,19 +163,40 @@ class _SubsamplePlan:
         if total != self.n:
             raise RuntimeError("subsample_batch: batches_len does not sum to the number of points")
         self.B = self.rs.numel() - 1
-        self.wsb = lib.ml3d_subsample_workspace_bytes(self.n, self.B)
-        self.ws = _ws(self.wsb, dev)
+        self.dl = float(sampleDl)
         self.out_len = torch.empty(self.B, dtype=torch.int64, device=dev)
         self.stats = torch.empty(2, dtype=torch.int64, device=dev)
+        self.M = None
+        # one workgroup per item, everything in LDS, two launches per call (ml3d_subsample_items_*): whenever every item is small
+        # enough -- the KPConv batch build's case (spheres of <= 10 000 points); whole clouds take the sort-based op
+        lens = batches_len.tolist() if torch.is_tensor(batches_len) else list(batches_len)
+        self.items = (not _FORCE_SORTED) and self.B <= 65535 and max([int(v) for v in lens] or [0]) <= int(lib.ml3d_subsample_items_max_points())
+        if self.items:
+            with torch.cuda.device(dev):
+                rc = lib.ml3d_subsample_items_count(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl,
+                                                    max([int(v) for v in lens] or [0]), self.out_len.data_ptr(), self.stats.data_ptr(),
+                                                    _stream())
+            _abi.check(rc, "ml3d_subsample_items_count")
+        else:
+            self._count_sorted()
+
+    def _count_sorted(self):
+        lib = _abi.get()
+        dev = self.src.device
+        self.items = False
+        self.wsb = lib.ml3d_subsample_workspace_bytes(self.n, self.B)
+        self.ws = _ws(self.wsb, dev)
         with torch.cuda.device(dev):
-            rc = lib.ml3d_subsample_count(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, float(sampleDl),
+            rc = lib.ml3d_subsample_count(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl,
                                           self.out_len.data_ptr(), self.stats.data_ptr(), self.ws.data_ptr(), self.wsb, _stream())
         _abi.check(rc, "ml3d_subsample_count")
-        self.M = None
 
     def resolve(self, values=None):
         if self.M is None:
             self.M, err = (int(x) for x in (self.stats.tolist() if values is None else values))
+            if err == 2 and self.items:          # an item's grid has more cells than the per-item kernel's bitmap: the sort-based op
+                self._count_sorted()
+                self.M, err = (int(x) for x in self.stats.tolist())
             if err:
                 raise RuntimeError("subsample: a batch item spans >= 2^40 voxels at this sampleDl (unsupported)")
         return self
@@ -184,8 +208,12 @@ class _SubsamplePlan:
         dev = self.src.device
         op = torch.empty((self.M, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.ml3d_subsample_fill(self.src.data_ptr(), None, 0, None, self.B, self.n, op.data_ptr(), None, None,
-                                         self.ws.data_ptr(), self.wsb, _stream())
+            if self.items:
+                rc = lib.ml3d_subsample_items_fill(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl,
+                                                   self.out_len.data_ptr(), op.data_ptr(), _stream())
+            else:
+                rc = lib.ml3d_subsample_fill(self.src.data_ptr(), None, 0, None, self.B, self.n, op.data_ptr(), None, None,
+                                             self.ws.data_ptr(), self.wsb, _stream())
         _abi.check(rc, "ml3d_subsample_fill")
         if self.rotations is not None:
             # the pooled lengths stay on the device: their row splits are built there (no read-back for the rotation back)

@@ -237,6 +237,28 @@ def subsample_batch(points, lengths, dl, features=None, labels=None):
     return op, lens, of, ol
 
 
+def subsample_items(points, lengths, dl):
+    """ml3d_subsample_items_count / _fill (one workgroup per batch item) -> (points, lengths, status); status 2 = an item's grid is
+    larger than the kernel's bitmap, -4 = an item has more points than the kernel takes (the caller's cue for the sort-based op)."""
+    L = lib()
+    points = np.ascontiguousarray(points, np.float32)
+    rs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    B, n = len(rs) - 1, len(points)
+    lens = np.zeros(B, np.int64)
+    stats = np.zeros(2, np.int64)
+    rc = L.ml3d_subsample_items_count(points.ctypes.data, rs.ctypes.data, B, n, dl, int(max(list(lengths) + [0])), lens.ctypes.data,
+                                      stats.ctypes.data, None)
+    if rc == -4:          # ML3D_E_UNSUPPORTED
+        return None, None, -4
+    assert rc == 0, rc
+    if stats[1]:
+        return None, None, int(stats[1])
+    op = np.zeros((int(stats[0]), 3), np.float32)
+    rc = L.ml3d_subsample_items_fill(points.ctypes.data, rs.ctypes.data, B, n, dl, lens.ctypes.data, op.ctypes.data, None)
+    assert rc == 0, rc
+    return op, lens, 0
+
+
 def kpconv_rigid(q_pts, s_pts, inds, x, kp, weights, extent, bias=None, act=0, slope=0.0, influence=1, offset_features=None,
                  bf16x3=False):
     L = lib()

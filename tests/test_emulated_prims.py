@@ -434,3 +434,46 @@ def test_topk_rows_property_random_shapes_and_tie_patterns():
         assert np.array_equal(idx, oops.topk_rows(v, k)), (rows, n, k, kind, seed)
         assert np.array_equal(val, np.take_along_axis(v, idx, 1), equal_nan=True)
     check()
+
+
+def test_subsample_one_workgroup_per_item_is_bit_identical_to_the_sorted_op_and_the_oracle():
+    """ml3d_subsample_items_* (round 6: bounding box, occupancy bitmap, popcount ranks, grouping and the ordered float sums of an
+    item in the LDS of ONE workgroup; what the KPConv batch build calls): barycentres and lengths identical to the sort-based op
+    and to the oracle -- spheres of a KPConv batch (incl. an empty item and a one-point item), runs longer than the in-thread sort
+    takes (duplicated points: > 48 per voxel, ordered by the whole workgroup), negative coordinates."""
+    rng = np.random.default_rng(8)
+    spheres = [synth_data.toronto3d_sphere(60 + i, 1500 + 700 * i) for i in range(3)]
+    dup = np.repeat(spheres[0][:40], 70, 0)[rng.permutation(2800)] + rng.normal(0, 1e-3, (2800, 3)).astype(np.float32)   # 70 points per voxel
+    one = np.array([[-3.25, 7.5, -0.125]], np.float32)
+    items = [spheres[0], np.zeros((0, 3), np.float32), spheres[1], dup.astype(np.float32), one, spheres[2] - 20.0]
+    pts = np.concatenate(items).astype(np.float32)
+    lens = [len(x) for x in items]
+    for dl in (0.16, 0.4, 2.0):
+        op, ln, st = emu.subsample_items(pts, lens, dl)
+        assert st == 0
+        sp, sl, _, _ = emu.subsample_batch(pts, lens, dl)
+        rp, rl = oops.subsample_batch(pts, lens, sampleDl=dl)[:2]
+        assert np.array_equal(ln, sl) and np.array_equal(ln, rl)
+        assert np.array_equal(op, sp) and np.array_equal(op, rp)
+    # everything in ONE voxel (a run of the item's size) and every point its own voxel
+    p = (rng.random((3000, 3)) * 0.01 + 5.0).astype(np.float32)
+    op, ln, st = emu.subsample_items(p, [3000], 1.0)
+    ref = oops.subsample_batch(p, [3000], sampleDl=1.0)
+    assert st == 0 and op.shape == (1, 3) and np.array_equal(op, ref[0])
+    q = synth_data.uniform_cloud(4, 2000, extent=(1.0, 1.0, 1.0))
+    op, ln, st = emu.subsample_items(q, [2000], 0.02)
+    ref = oops.subsample_batch(q, [2000], sampleDl=0.02)
+    assert st == 0 and len(op) > 1900 and np.array_equal(op, ref[0])
+
+
+def test_subsample_per_item_kernel_reports_what_it_cannot_take():
+    """Limits of the per-item kernel: more points than fit its LDS -> ML3D_E_UNSUPPORTED at the call (host value); a grid of more
+    cells than its bitmap -> stats[1] == 2 after the count (device check).  Both are the caller's cue for the sort-based op."""
+    L = emu.lib()
+    nmax = int(L.ml3d_subsample_items_max_points())
+    assert nmax >= 10000                      # a KPConv input sphere (batch_limit / max_in_points of the Toronto3D config)
+    big = synth_data.uniform_cloud(1, nmax + 1)
+    assert emu.subsample_items(big, [nmax + 1], 0.5)[2] == -4
+    wide = synth_data.uniform_cloud(2, 4000)   # 10 x 10 x 2 m at 0.02 m: 500 * 500 * 100 cells
+    assert emu.subsample_items(wide, [4000], 0.02)[2] == 2
+    assert emu.subsample_items(np.concatenate([wide, wide]), [4000, 4000], 0.5)[2] == 0

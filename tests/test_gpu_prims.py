@@ -235,3 +235,44 @@ def test_topk_rows_is_the_nms_pre_topk_bit_exact():
         assert np.array_equal(val.cpu().numpy(), torch.topk(torch.from_numpy(v), k, dim=1)[0].numpy(), equal_nan=True)
     one = ops.topk_rows(_t(kitti[0]), 100)                       # the per-sample call of get_bboxes_single
     assert np.array_equal(one.cpu().numpy(), oops.topk_rows(kitti[:1], 100)[0])
+
+
+def test_subsample_one_workgroup_per_item_matches_the_oracle_and_the_sorted_op():
+    """``ops.batch_grid_subsampling`` on its round-6 path (``ml3d_subsample_items_*``: one 1024-thread workgroup per batch item, bitmap
+    ranks + grouping + ordered float sums in LDS, two launches per call) at the KPConv bench's shape (24 input spheres, a one-point
+    and an empty item among them), axis-aligned and on rotated grids, against the oracle AND the sort-based op (forced through
+    ``ops.voxel._FORCE_SORTED``): barycentres and lengths bit for bit.  Then the two cues for the sort-based op: a grid of more cells
+    than the kernel's bitmap (read back as stats[1] == 2, handled inside the plan) and an item of more points than its LDS takes."""
+    from ml3d import ops
+    from ml3d.ops import voxel as V
+    from ml3d.torch.models.kpconv import random_grid_rotations
+    items = [_kpconv_sphere(300 + i) for i in range(22)] + [np.zeros((0, 3), np.float32), np.array([[1.5, -2.5, 0.25]], np.float32)]
+    lens = [len(x) for x in items]
+    p = np.concatenate(items).astype(np.float32)
+    tp = _t(p)
+    np.random.seed(3)
+    R = random_grid_rotations(len(items))
+    for dl in (0.16, 0.32, 1.28):
+        for rot in (None, R):
+            tr = None if rot is None else _t(rot)
+            assert V._SubsamplePlan(tp, lens, dl, tr).items
+            q, ql = ops.batch_grid_subsampling(tp, lens, dl, tr)
+            V._FORCE_SORTED = True
+            try:
+                qs, qls = ops.batch_grid_subsampling(tp, lens, dl, tr)
+            finally:
+                V._FORCE_SORTED = False
+            assert torch.equal(q, qs) and torch.equal(ql, qls)
+            if rot is None:
+                rp, rl = oops.subsample_batch(p, lens, sampleDl=dl)[:2]
+                assert np.array_equal(q.cpu().numpy(), rp) and np.array_equal(ql.cpu().numpy(), rl)
+    # a grid with more cells than the bitmap: the plan falls back by itself and still equals the oracle
+    wide = synth_data.uniform_cloud(2, 4000)
+    plan = V._SubsamplePlan(_t(wide), [4000], 0.02)
+    assert plan.items
+    q, ql = plan.fill()
+    assert not plan.items
+    rp, rl = oops.subsample_batch(wide, [4000], sampleDl=0.02)[:2]
+    assert np.array_equal(q.cpu().numpy(), rp) and np.array_equal(ql.cpu().numpy(), rl)
+    big = synth_data.uniform_cloud(1, 20000)
+    assert not V._SubsamplePlan(_t(big), [20000], 0.3).items
