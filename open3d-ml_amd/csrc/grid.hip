@@ -271,22 +271,40 @@ __global__ void grid_setup0(Segs S, const unsigned* bbox, GridSeg* segs, int bat
 // ---- K3: occupancy probe at GRID_LEVELS power-of-two resolutions ------------------------------
 __global__ void __launch_bounds__(256)
 grid_occupancy(const float* __restrict__ pts, Segs S, int64_t n_total, const GridSeg* __restrict__ segs,
-               unsigned* bitmap, int64_t bitmap_words, unsigned* occ) {
+               unsigned* bitmap, int64_t bitmap_words, unsigned* occ, int dense_stride) {
     // one bit per (level, cell); the number of bits a block newly sets is summed per block (ballot
     // + popcount) so the per-item counters see one atomic per block and level, not one per point.
+    // dense_stride > 0 (uniform batches whose items all probe every dense_stride-th point: grid_build): thread t IS probe t -- item
+    // t / per, point (t % per) * dense_stride -- instead of one thread per point of which 15 in 16 leave at once.
     __shared__ unsigned cnt[GRID_LEVELS];
     const int64_t first = (int64_t)blockIdx.x * blockDim.x;
-    const int64_t last = first + blockDim.x - 1 < n_total ? first + blockDim.x - 1 : n_total - 1;
-    int s0, s1; int64_t l0, l1;
-    seg_locate_wave(S, first, s0, l0);
-    seg_locate_wave(S, last, s1, l1);
+    int s0, s1; int64_t l0 = 0, l1;
+    int64_t per = 0;
+    if (dense_stride > 0) {
+        per = (S.n_uniform + dense_stride - 1) / dense_stride;
+        const int64_t total = per * S.batch;
+        const int64_t last = first + blockDim.x - 1 < total ? first + blockDim.x - 1 : total - 1;
+        s0 = (int)(first / per); s1 = (int)(last / per);
+    } else {
+        const int64_t last = first + blockDim.x - 1 < n_total ? first + blockDim.x - 1 : n_total - 1;
+        seg_locate_wave(S, first, s0, l0);
+        seg_locate_wave(S, last, s1, l1);
+    }
     const bool one_item = (s0 == s1);            // block-uniform
     if (threadIdx.x < GRID_LEVELS) cnt[threadIdx.x] = 0u;
     __syncthreads();
     const int64_t i = first + threadIdx.x;
-    bool valid = i < n_total;
+    bool valid;
     int s = s0; int64_t local = l0 + threadIdx.x;
-    if (valid && !one_item) seg_locate(S, i, s, local);
+    if (dense_stride > 0) {
+        s = (int)(i / per);
+        local = (i - (int64_t)s * per) * dense_stride;
+        valid = s < S.batch && local < S.n_uniform;
+        if (!valid) s = s0;
+    } else {
+        valid = i < n_total;
+        if (valid && !one_item) seg_locate(S, i, s, local);
+    }
     int cx = 0, cy = 0, cz = 0;
     const GridSeg* g = &segs[s];
     valid = valid && (local % g->probe_stride == 0);
@@ -614,8 +632,11 @@ int grid_build(const float* points, Segs S, const GridWs& ws, float target_occ, 
     ML3D_LAUNCH_CHECK();
     int nb = (int)((n + 255) / 256);
     if (n > 0) {
-        hipLaunchKernelGGL(grid_occupancy, dim3(nb), dim3(256), 0, stream, points, S, n, ws.segs, ws.bitmap,
-                           ws.bitmap_words, ws.occ);
+        // (the probe stride is a function of the item size alone -- grid_setup0 -- so a uniform batch knows it on the host)
+        const int dense = (!S.splits && S.n_uniform >= 32768) ? 16 : 0;
+        const int nbo = dense ? (int)((((S.n_uniform + dense - 1) / dense) * (int64_t)S.batch + 255) / 256) : nb;
+        hipLaunchKernelGGL(grid_occupancy, dim3(nbo), dim3(256), 0, stream, points, S, n, ws.segs, ws.bitmap,
+                           ws.bitmap_words, ws.occ, dense);
         ML3D_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(grid_setup1, dim3(sb), dim3(64), 0, stream, ws.occ, ws.segs, B, target_occ);
