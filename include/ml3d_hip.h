@@ -213,9 +213,11 @@ int ml3d_subsample_fill(const float* points, const float* features, int64_t feat
 /* float32 sums in original point order all happen in LDS; count and fill are one launch each  */
 /* (the fill repeats the grouping).  Points only (no features / labels).  Limits per item:     */
 /* ml3d_subsample_items_max_points() points -- pass the largest item length in                 */
-/* max_item_points (HOST value; ML3D_E_UNSUPPORTED when it is larger: use ml3d_subsample_count) */
-/* -- and 262 144 grid cells, checked on the device: out_stats[1] == 2 after the count means   */
-/* "an item's grid is larger: repeat the call with ml3d_subsample_count".  Results identical   */
+/* max_item_points (HOST value, the same to count and fill: it picks one of three size classes */
+/* -- 1024 / 4096 / 12 288 points with 16 384 / 65 536 / 262 144 grid cells, 13 / 49 / 145 KB  */
+/* of LDS; ML3D_E_UNSUPPORTED when it is larger: use ml3d_subsample_count); the grid size is   */
+/* checked on the device: out_stats[1] == 2 after the count means "an item's grid has more     */
+/* cells than the class takes: repeat the call with ml3d_subsample_count".  Results identical  */
 /* to ml3d_subsample_count / _fill bit for bit.                                                 */
 /*  count: out_lengths int64[batch], out_stats int64[2] = {total M, 0 or 2}                     */
 /*  fill : lengths = the count's out_lengths (device), out_points [M,3]                         */
@@ -226,8 +228,8 @@ int ml3d_subsample_items_count(const float* points, const int64_t* row_splits, i
                                int64_t* out_lengths, int64_t* out_stats, void* stream);
 
 int ml3d_subsample_items_fill(const float* points, const int64_t* row_splits, int64_t batch,
-                              int64_t n_points, float sample_dl, const int64_t* lengths,
-                              float* out_points, void* stream);
+                              int64_t n_points, float sample_dl, int64_t max_item_points,
+                              const int64_t* lengths, float* out_points, void* stream);
 
 /* Per-item row-vector rotation p' = p . R[b] (transpose != 0: p . R[b]^T) around the grid   */
 /* subsample of batch_grid_subsampling (random_grid_orient, kpconv.py:2059-2110); float32     */

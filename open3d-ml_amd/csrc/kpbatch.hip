@@ -253,7 +253,7 @@ extern "C" int ml3d_kpconv_batch_build(const float* points, const int64_t* lengt
         const bool rot = rotations && rotations[l];
         mark(l, 6);
         if (items_sub[l])
-            rc = ml3d_subsample_items_fill(rot ? W.rot_in : pts[l], splits[l], batch, n[l], desc->dl[l], rec[l] + 8,
+            rc = ml3d_subsample_items_fill(rot ? W.rot_in : pts[l], splits[l], batch, n[l], desc->dl[l], max_item(l), rec[l] + 8,
                                            rot ? W.rot_out : pool_p, st);
         else
             rc = ml3d_subsample_fill(rot ? W.rot_in : pts[l], nullptr, 0, nullptr, batch, n[l], rot ? W.rot_out : pool_p, nullptr, nullptr,

@@ -309,27 +309,29 @@ __global__ void sub_fill(const uint32_t* __restrict__ vals, const int* __restric
 // The fill launch repeats the grouping (a few microseconds in LDS) instead of carrying 6 bytes per point through HBM, so the op
 // needs NO workspace.  Limits: SI_NMAX points and SI_CMAX grid cells per item (a 4 m sphere at dl = 0.16 m has 125 000); anything
 // larger -- whole clouds of the preprocessing front end -- keeps the sort path (the caller retries on stats[1] == 2).
-constexpr int SI_THREADS = 1024;
-constexpr int SI_NMAX = 12288;
-constexpr int SI_CMAX = 262144;
-constexpr int SI_WORDS = SI_CMAX / 32;
+// Three size classes (points, grid cells, threads, LDS): {12 288, 262 144, 1024, 145 KB} for the input spheres, {4096, 65 536, 512,
+// 49 KB} and {1024, 16 384, 256, 13 KB} for the pooled levels -- a workgroup that needs a whole CU's LDS waits for one to drain
+// when the forward of another batch co-runs (KPConvPipelineN), so the small levels must not ask for it.
+constexpr int SI_NMAX = 12288;       // (largest class: ml3d_subsample_items_max_points)
 constexpr int SI_LONG = 48;
-constexpr int SI_LIST = SI_NMAX / SI_LONG + 8;
 
-struct SiSmem {
-    uint32_t bitmap[SI_WORDS];          // 32 KB  occupancy; later the staging buffer of long runs (3 x 1024 floats)
-    uint16_t wpre[SI_WORDS];            // 16 KB  voxels before this word
-    uint16_t vox[SI_NMAX];              // 24 KB  voxel ordinal of local point i
-    uint32_t cnt[SI_NMAX / 2 + 8];      // 24 KB  16-bit pairs: per-voxel counters, then IN PLACE hp[v] (first slot; hp[M] = n)
-    uint16_t slot[SI_NMAX];             // 24 KB  arrival slot of point i; later the ordered copy of a long run
-    uint16_t run[SI_NMAX];              // 24 KB  local point indices grouped by voxel
-    uint16_t longv[SI_LIST];
+template <int NMAX, int CMAX, int THREADS>
+struct SiSmemT {
+    static constexpr int WORDS = CMAX / 32;
+    uint32_t bitmap[WORDS];             // occupancy; later the staging buffer of long runs (3 x THREADS floats)
+    uint16_t wpre[WORDS];               // voxels before this word
+    uint16_t vox[NMAX];                 // voxel ordinal of local point i
+    uint32_t cnt[NMAX / 2 + 8];         // 16-bit pairs: per-voxel counters, then IN PLACE hp[v] (first slot; hp[M] = n)
+    uint16_t slot[NMAX];                // arrival slot of point i; later the ordered copy of a long run
+    uint16_t run[NMAX];                 // local point indices grouped by voxel
+    uint16_t longv[NMAX / SI_LONG + 8];
     float red[16][6];
     int scan[16];
-    int misc[8];                        // [0] M  [1] number of long runs  [2] failure
+    int misc[8];                        // [1] number of long runs
 };
 
-// exclusive prefix of one int per thread over the 1024-thread workgroup; `total` = the sum (all threads)
+// exclusive prefix of one int per thread over the workgroup; `total` = the sum (all threads)
+template <int THREADS>
 __device__ __forceinline__ int si_block_exscan(int v, int* scan16, int& total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int incl = wave_inclusive_scan(v);
@@ -338,15 +340,19 @@ __device__ __forceinline__ int si_block_exscan(int v, int* scan16, int& total) {
     __syncthreads();
     int carry = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { const int s = scan16[w]; if (w < wv) carry += s; tot += s; }
+    for (int w = 0; w < THREADS / 64; ++w) { const int s = scan16[w]; if (w < wv) carry += s; tot += s; }
     total = tot;
     return carry + incl - v;
 }
 
-template <bool FILL>
+template <bool FILL, int SI_NMAXC, int SI_CMAX, int SI_THREADS>
 __global__ void __launch_bounds__(SI_THREADS)
 sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, int batch, float dl, int64_t* __restrict__ lengths,
             int64_t* __restrict__ stats, float* __restrict__ out_pts) {
+    typedef SiSmemT<SI_NMAXC, SI_CMAX, SI_THREADS> SiSmem;
+    constexpr int SI_WORDS = SI_CMAX / 32;
+    constexpr int SI_NMAX = SI_NMAXC;                  // (shadows the largest class's constant inside the kernel)
+    static_assert(SI_WORDS % SI_THREADS == 0 && SI_NMAX % SI_THREADS == 0 && SI_THREADS <= 1024, "size class");
     HIP_DYNAMIC_SHARED(unsigned char, si_raw)
     SiSmem& L = *reinterpret_cast<SiSmem*>(si_raw);
     uint16_t* hp = reinterpret_cast<uint16_t*>(L.cnt);
@@ -380,7 +386,7 @@ sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, i
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float lo = L.red[0][a], hi = L.red[0][3 + a];
-        for (int w = 1; w < 16; ++w) { lo = fminf(lo, L.red[w][a]); hi = fmaxf(hi, L.red[w][3 + a]); }
+        for (int w = 1; w < SI_THREADS / 64; ++w) { lo = fminf(lo, L.red[w][a]); hi = fmaxf(hi, L.red[w][3 + a]); }
         org[a] = __fmul_rn(floorf(__fdiv_rn(lo, dl)), dl);
         const float gf = floorf(__fdiv_rn(__fsub_rn(hi, org[a]), dl));
         G[a] = gf < 2.0e9f ? (int)gf + 1 : 0x7fffffff;
@@ -407,7 +413,7 @@ sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, i
         int pc[SI_WORDS / SI_THREADS], sum = 0;
 #pragma unroll
         for (int j = 0; j < SI_WORDS / SI_THREADS; ++j) { pc[j] = __popc(L.bitmap[t * (SI_WORDS / SI_THREADS) + j]); sum += pc[j]; }
-        int run0 = si_block_exscan(sum, L.scan, M);
+        int run0 = si_block_exscan<SI_THREADS>(sum, L.scan, M);
 #pragma unroll
         for (int j = 0; j < SI_WORDS / SI_THREADS; ++j) { L.wpre[t * (SI_WORDS / SI_THREADS) + j] = (uint16_t)run0; run0 += pc[j]; }
     }
@@ -431,7 +437,7 @@ sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, i
         int c[PER], sum = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) { c[j] = hp[t * PER + j]; sum += c[j]; }
-        int tot, run0 = si_block_exscan(sum, L.scan, tot);
+        int tot, run0 = si_block_exscan<SI_THREADS>(sum, L.scan, tot);
 #pragma unroll
         for (int j = 0; j < PER; ++j) { hp[t * PER + j] = (uint16_t)run0; run0 += c[j]; }
         if (t == SI_THREADS - 1) hp[SI_NMAX] = (uint16_t)run0;        // (M == SI_NMAX: every point its own voxel)
@@ -446,8 +452,8 @@ sub_items_k(const float* __restrict__ pts, const int64_t* __restrict__ splits, i
         for (int q = t; q < b; q += SI_THREADS) part += (long long)lengths[q];
         int lo32 = (int)(part & 0x7fffffffll), hi32 = (int)(part >> 31);      // (two 31-bit halves through the int scan)
         int tl, th;
-        (void)si_block_exscan(lo32, L.scan, tl);
-        (void)si_block_exscan(hi32, L.scan, th);
+        (void)si_block_exscan<SI_THREADS>(lo32, L.scan, tl);
+        (void)si_block_exscan<SI_THREADS>(hi32, L.scan, th);
         off = ((int64_t)th << 31) + (int64_t)tl;
     }
     // ---- barycentres: float32 sums in original point order ----------------------------------------------------------------------------
@@ -688,6 +694,27 @@ extern "C" int ml3d_subsample_fill(const float* points, const float* features, i
 
 extern "C" int64_t ml3d_subsample_items_max_points(void) { return SI_NMAX; }
 
+namespace {
+template <bool FILL, int NMAX, int CMAX, int THREADS>
+int si_launch(const float* points, const int64_t* row_splits, int64_t batch, float dl, int64_t* lengths, int64_t* stats, float* out,
+              hipStream_t st) {
+    const auto kern = sub_items_k<FILL, NMAX, CMAX, THREADS>;
+    const size_t sm = sizeof(SiSmemT<NMAX, CMAX, THREADS>);
+    if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(THREADS), sm, st, points, row_splits, (int)batch, dl, lengths, stats, out);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+// the size class is a function of the largest item (host value) alone, so count and fill agree on it
+template <bool FILL>
+int si_dispatch(int64_t max_item_points, const float* points, const int64_t* row_splits, int64_t batch, float dl, int64_t* lengths,
+                int64_t* stats, float* out, hipStream_t st) {
+    if (max_item_points <= 1024) return si_launch<FILL, 1024, 16384, 256>(points, row_splits, batch, dl, lengths, stats, out, st);
+    if (max_item_points <= 4096) return si_launch<FILL, 4096, 65536, 512>(points, row_splits, batch, dl, lengths, stats, out, st);
+    return si_launch<FILL, SI_NMAX, 262144, 1024>(points, row_splits, batch, dl, lengths, stats, out, st);
+}
+}  // namespace
+
 extern "C" int ml3d_subsample_items_count(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
                                           float sample_dl, int64_t max_item_points, int64_t* out_lengths, int64_t* out_stats,
                                           void* stream) {
@@ -697,27 +724,18 @@ extern "C" int ml3d_subsample_items_count(const float* points, const int64_t* ro
     if (max_item_points < 0 || max_item_points > SI_NMAX) return ML3D_E_UNSUPPORTED;      // (the caller keeps ml3d_subsample_count)
     hipStream_t st = (hipStream_t)stream;
     zero_async(out_stats, 2 * sizeof(int64_t), st);
-    const auto kern = sub_items_k<false>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SiSmem)) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SI_THREADS), sizeof(SiSmem), st, points, row_splits, (int)batch, sample_dl,
-                       out_lengths, out_stats, (float*)nullptr);
-    VX_CHECK();
-    return 0;
+    return si_dispatch<false>(max_item_points, points, row_splits, batch, sample_dl, out_lengths, out_stats, nullptr, st);
 }
 
 extern "C" int ml3d_subsample_items_fill(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,
-                                         float sample_dl, const int64_t* lengths, float* out_points, void* stream) {
+                                         float sample_dl, int64_t max_item_points, const int64_t* lengths, float* out_points,
+                                         void* stream) {
     if (!row_splits || batch <= 0 || batch > 65535 || n_points < 0 || !(sample_dl > 0.f) || !lengths) return ML3D_E_INVALID;
+    if (max_item_points < 0 || max_item_points > SI_NMAX) return ML3D_E_UNSUPPORTED;
     if (n_points == 0) return 0;
     if (!points || !out_points) return ML3D_E_INVALID;
-    const auto kern = sub_items_k<true>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SiSmem)) != hipSuccess)
-        return ML3D_E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SI_THREADS), sizeof(SiSmem), (hipStream_t)stream, points, row_splits,
-                       (int)batch, sample_dl, const_cast<int64_t*>(lengths), (int64_t*)nullptr, out_points);
-    VX_CHECK();
-    return 0;
+    return si_dispatch<true>(max_item_points, points, row_splits, batch, sample_dl, const_cast<int64_t*>(lengths), nullptr, out_points,
+                             (hipStream_t)stream);
 }
 
 extern "C" int ml3d_rotate_points(const float* points, const int64_t* row_splits, int64_t batch, int64_t n_points,

@@ -156,7 +156,7 @@ def bind(lib):
     lib.ml3d_subsample_items_count.restype = C.c_int
     lib.ml3d_subsample_items_count.argtypes = [vp, vp, i64, i64, f32, i64, vp, vp, vp]
     lib.ml3d_subsample_items_fill.restype = C.c_int
-    lib.ml3d_subsample_items_fill.argtypes = [vp, vp, i64, i64, f32, vp, vp, vp]
+    lib.ml3d_subsample_items_fill.argtypes = [vp, vp, i64, i64, f32, i64, vp, vp, vp]
     lib.ml3d_rotate_points.restype = C.c_int
     lib.ml3d_rotate_points.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
     lib.ml3d_kpconv_batch_workspace_bytes.restype = sz

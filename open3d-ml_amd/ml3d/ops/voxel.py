@@ -170,12 +170,12 @@ class _SubsamplePlan:
         # one workgroup per item, everything in LDS, two launches per call (ml3d_subsample_items_*): whenever every item is small
         # enough -- the KPConv batch build's case (spheres of <= 10 000 points); whole clouds take the sort-based op
         lens = batches_len.tolist() if torch.is_tensor(batches_len) else list(batches_len)
-        self.items = (not _FORCE_SORTED) and self.B <= 65535 and max([int(v) for v in lens] or [0]) <= int(lib.ml3d_subsample_items_max_points())
+        self.max_item = max([int(v) for v in lens] or [0])
+        self.items = (not _FORCE_SORTED) and self.B <= 65535 and self.max_item <= int(lib.ml3d_subsample_items_max_points())
         if self.items:
             with torch.cuda.device(dev):
                 rc = lib.ml3d_subsample_items_count(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl,
-                                                    max([int(v) for v in lens] or [0]), self.out_len.data_ptr(), self.stats.data_ptr(),
-                                                    _stream())
+                                                    self.max_item, self.out_len.data_ptr(), self.stats.data_ptr(), _stream())
             _abi.check(rc, "ml3d_subsample_items_count")
         else:
             self._count_sorted()
@@ -209,7 +209,7 @@ class _SubsamplePlan:
         op = torch.empty((self.M, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if self.items:
-                rc = lib.ml3d_subsample_items_fill(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl,
+                rc = lib.ml3d_subsample_items_fill(self.src.data_ptr(), self.rs.data_ptr(), self.B, self.n, self.dl, self.max_item,
                                                    self.out_len.data_ptr(), op.data_ptr(), _stream())
             else:
                 rc = lib.ml3d_subsample_fill(self.src.data_ptr(), None, 0, None, self.B, self.n, op.data_ptr(), None, None,

@@ -254,7 +254,8 @@ def subsample_items(points, lengths, dl):
     if stats[1]:
         return None, None, int(stats[1])
     op = np.zeros((int(stats[0]), 3), np.float32)
-    rc = L.ml3d_subsample_items_fill(points.ctypes.data, rs.ctypes.data, B, n, dl, lens.ctypes.data, op.ctypes.data, None)
+    rc = L.ml3d_subsample_items_fill(points.ctypes.data, rs.ctypes.data, B, n, dl, int(max(list(lengths) + [0])), lens.ctypes.data,
+                                     op.ctypes.data, None)
     assert rc == 0, rc
     return op, lens, 0
 

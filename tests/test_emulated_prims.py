@@ -455,15 +455,26 @@ def test_subsample_one_workgroup_per_item_is_bit_identical_to_the_sorted_op_and_
         rp, rl = oops.subsample_batch(pts, lens, sampleDl=dl)[:2]
         assert np.array_equal(ln, sl) and np.array_equal(ln, rl)
         assert np.array_equal(op, sp) and np.array_equal(op, rp)
+    # the two smaller size classes (items of <= 4096 / <= 1024 points: 512 / 256 threads), long runs included
+    for cap_n in (3000, 900):
+        its = [synth_data.toronto3d_sphere(80 + i, cap_n - 200 * i) for i in range(3)] + [dup[:cap_n - 100].astype(np.float32)]
+        pp = np.concatenate(its).astype(np.float32)
+        ll = [len(x) for x in its]
+        assert max(ll) <= cap_n
+        for dl in (0.3, 0.7):
+            op, ln, st = emu.subsample_items(pp, ll, dl)
+            rp, rl = oops.subsample_batch(pp, ll, sampleDl=dl)[:2]
+            assert st == 0 and np.array_equal(ln, rl) and np.array_equal(op, rp), (cap_n, dl)
     # everything in ONE voxel (a run of the item's size) and every point its own voxel
     p = (rng.random((3000, 3)) * 0.01 + 5.0).astype(np.float32)
     op, ln, st = emu.subsample_items(p, [3000], 1.0)
     ref = oops.subsample_batch(p, [3000], sampleDl=1.0)
     assert st == 0 and op.shape == (1, 3) and np.array_equal(op, ref[0])
     q = synth_data.uniform_cloud(4, 2000, extent=(1.0, 1.0, 1.0))
-    op, ln, st = emu.subsample_items(q, [2000], 0.02)
-    ref = oops.subsample_batch(q, [2000], sampleDl=0.02)
-    assert st == 0 and len(op) > 1900 and np.array_equal(op, ref[0])
+    op, ln, st = emu.subsample_items(q, [2000], 0.03)           # (34^3 cells: inside the 4096-point class's 65 536)
+    ref = oops.subsample_batch(q, [2000], sampleDl=0.03)
+    assert st == 0 and len(op) > 1850 and np.array_equal(op, ref[0])
+    assert emu.subsample_items(q, [2000], 0.02)[2] == 2          # 50^3 cells: more than that class takes -> the caller's cue
 
 
 def test_subsample_per_item_kernel_reports_what_it_cannot_take():
