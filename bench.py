@@ -370,6 +370,10 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the KPConv / PointPillars side measurements")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch (B = 1 / 4) model-API latency measurement")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel once (after the timed region)")
+    ap.add_argument("--train", action="store_true",
+                    help="SURVEY.md §8 f4: time a DATA-PARALLEL TRAINING step of RandLA-Net instead of inference -- forward + loss + backward "
+                         "on the HIP training kernels, DistributedDataParallel's gradient all-reduce over RCCL (nccl) at N > 1 -- "
+                         "and check that every rank ends the step with the same gradients")
     ap.add_argument("--stub", action="store_true",
                     help="CPU / gloo dry run of the launcher and of every N > 1 branch with a stand-in for the GPU step "
                          "(tests/test_bench_launcher.py); prints a line marked \"stub\": true that is NOT a measurement")
@@ -417,6 +421,16 @@ def main():
         mdist.init("gloo" if stub else "nccl", dev)
     seen = ranks_seen(dev, world, dist, stub, placement)
 
+    if args.train:
+        import bench_models
+        out = bench_models.run_randlanet_train(args, rank, world, dev, dist)
+        if rank == 0:
+            out["ranks_seen"] = seen
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     if args.workload != "randlanet":
         import bench_models
         fn = bench_models.run_kpconv if args.workload == "kpconv" else bench_models.run_pointpillars
@@ -511,6 +525,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1 on the hardware: the first multi-GPU run is also a CORRECTNESS run -- rank 0 recomputes, on the label buffers the RCCL
+    # gather delivered for the LAST step, the checksums every rank computed on its own labels (outside the timed region)
+    gather_check = None
+    if world > 1:
+        last_slot = (args.warmup + K - 1) % gather.depth
+        mine = mdist.label_checksum(gather.labels[last_slot])
+        allsums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsums, mine)
+        if rank == 0:
+            got = gather.gathered(last_slot)
+            ok = [bool(torch.equal(mdist.label_checksum(got[r]), allsums[r])) for r in range(world)]
+            gather_check = {"ranks_checked": world, "all_match": all(ok), "per_rank": ok,
+                            "what": "rank 0 recomputed every rank's label checksum (sum, position-weighted sum, xor-fold) on the buffers "
+                                    "the RCCL gather delivered for the last timed step"}
     out = None
     if stub:
         # the dry run's check: rank 0 must hold every rank's labels of the LAST step (the async gather's second buffer)
@@ -525,7 +553,7 @@ def main():
                    "value": B * K * world / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
                    "ms_per_step": dt / K * 1e3, "scaling": "weak", "ranks_seen": seen,
                    "self_launched": bool(os.environ.get("ML3D_BENCH_SELF_LAUNCHED")),
-                   "gathered_ranks_checked": world}
+                   "gathered_ranks_checked": world, "gather_self_check": gather_check}
             print(json.dumps(out), flush=True)
     elif rank == 0:
         n_lv = stream.n
@@ -603,6 +631,8 @@ def main():
                            "frac_of_f32_mfma_peak": 14.0e9 * (B * K * world / dt) / world / 1e12 / PEAK_F32_TFLOPS,
                            "note": "14 GFLOP per frame (SURVEY.md §8d, reference formulation) x frames/s per GPU"},
         }
+        if gather_check is not None:
+            out["gather_self_check"] = gather_check
         if args.breakdown:
             bd = {}
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,6 +8,8 @@ pillar features + backbone + heads).
 """
 import time
 
+import os
+
 import numpy as np
 import torch
 
@@ -653,3 +655,79 @@ def run_kpconv(args, rank, world, dev, dist):
     else:
         out["cpu_baseline"] = None
     return out
+
+
+def run_randlanet_train(args, rank, world, dev, dist):
+    """one DATA-PARALLEL training step of RandLA-Net per timed step (forward + weighted cross entropy + backward on the
+    HIP training kernels of csrc/train.hip + SGD update), ``torch.nn.parallel.DistributedDataParallel`` around the native model class:
+    at N > 1 its bucketed gradient all-reduce runs over RCCL (backend nccl) and overlaps the backward.  The reference refuses this
+    for semantic segmentation (ml3d/torch/pipelines/base_pipeline.py:44-47) and wraps only its detection models
+    (object_detection.py:340).  After the timed region every rank's gradient checksum is gathered: all ranks must hold the SAME
+    averaged gradients.  ``--stub``: the same code on CPU tensors over gloo with the emulated library is tests/test_ddp_training_emulated.py."""
+    import time
+    import synth_data
+    import synth_weights as W
+    from ml3d.torch.models import RandLANet
+    cfg = dict(W.RANDLANET_SEMANTICKITTI_CFG)
+    B = args.frames_per_step or 4                                   # randlanet_semantickitti.yml: batch_size 4
+    N = cfg["num_points"]
+    torch.manual_seed(0)
+    model = RandLANet(**cfg, device=dev)
+    model.load_state_dict(W.randlanet_state_dict(cfg, 2024))
+    model.to(dev)
+    model.train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], bucket_cap_mb=8)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    loss_obj = type("L", (), {"weighted_CrossEntropyLoss": torch.nn.CrossEntropyLoss()})()
+    pts = torch.from_numpy(np.stack([synth_data.semantickitti_patch(1000 * rank + i, N) for i in range(B)])).to(dev)
+    labels = torch.randint(1, cfg["num_classes"], (B, N), generator=torch.Generator().manual_seed(rank))
+    nbr, itp = model.neighbor_pyramid(pts)
+    inputs = {"coords": [pts], "features": pts.clone(), "neighbor_indices": nbr, "interp_idx": itp}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = net(inputs)
+        loss, _, _ = model.get_loss(loss_obj, logits, {"data": {"labels": labels}}, dev)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # one more backward WITHOUT the optimiser step: the averaged gradients every rank holds must be identical
+    opt.zero_grad(set_to_none=True)
+    logits = net(inputs)
+    l2, _, _ = model.get_loss(loss_obj, logits, {"data": {"labels": labels}}, dev)
+    l2.backward()
+    g = torch.cat([p.grad.reshape(-1).double() for p in model.parameters() if p.grad is not None])
+    chk = torch.stack([g.sum(), g.abs().sum(), (g * torch.arange(1, g.numel() + 1, device=dev, dtype=torch.float64)).sum()])
+    same = None
+    if world > 1:
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        same = all(bool(torch.equal(allc[0], c)) for c in allc)
+    return {"metric": "RandLA-Net SemanticKITTI TRAINING steps/sec (DDP: forward + loss + backward on HIP kernels + RCCL gradient all-reduce + SGD)",
+            "value": args.steps * world * B / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "loss": float(loss),
+            "config": {"workload": "RandLA-Net SemanticKITTI training step, %d x %d points per GPU (randlanet_semantickitti.yml batch_size 4)" % (B, N),
+                       "parallelism": "ddp x%d" % world, "train_ops": os.environ.get("ML3D_TRAIN_OPS", "hip")},
+            "ddp_gradients_identical_on_all_ranks": same, "grad_checksum": [float(v) for v in chk.tolist()]}

@@ -64,6 +64,10 @@ static const Knobs& knobs() {
 #ifndef ML3D_ATTN_B3
 #define ML3D_ATTN_B3 3
 #endif
+// deep per-point Linears of the forward (pool2, mlp2 | shortcut, the 512 -> 512 mlp) on the bf16 matrix pipe from this K on (0: never)
+#ifndef ML3D_LIN_B3_MINK
+#define ML3D_LIN_B3_MINK 128
+#endif
 #ifndef ML3D_B3_LB_DIV
 #define ML3D_B3_LB_DIV 1        // (register-pressure probe only: 2 lifts the budget to 512 VGPRs)
 #endif
@@ -99,6 +103,9 @@ struct LinArgs {
     int cout;
     int act;                             // 0 none, 1 leaky relu
     float slope;
+    // optional scratch for the weights' three bf16 planes (gemm_pack_bf16x3_bytes(c0 + c1, cout) bytes, 16-byte aligned): a deep
+    // dense Linear (K >= ML3D_LIN_B3_MINK, K % 32 == 0, no gather) then runs on the bf16 matrix pipe (gemm_tile_bf3, float32-equivalent)
+    void* pack_ws; size_t pack_bytes;
 };
 
 // fc0 (+ folded bn0 + lrelu 0.2) and the first encoder layer's mlp1 (8 -> 8, lrelu 0.2) in one pass over the input rows
@@ -2614,6 +2621,17 @@ static int launch_linear_auto(const LinArgs& a, hipStream_t st) {
         if (a.cout == 32 && mlp_shape_matches<ShapeLin32x32>(c)) return launch_mlp_wave_s<ShapeLin32x32, 8>(c, st);
         if (a.cout == 64 && mlp_shape_matches<ShapeLin32x64>(c)) return launch_mlp_wave_s<ShapeLin32x64, 8>(c, st);
     }
+    if ((ML3D_LIN_B3_MINK) > 0 && a.pack_ws && !a.gather && a.c0 % 32 == 0 && (a.a1 ? a.c1 : 0) % 32 == 0 &&
+        a.c0 + (a.a1 ? a.c1 : 0) >= (ML3D_LIN_B3_MINK) && a.cout % 4 == 0) {
+        const int K = a.c0 + (a.a1 ? a.c1 : 0);
+        const size_t need = gemm_pack_bf16x3_bytes(K, a.cout);
+        if (need > 0 && need <= a.pack_bytes && gemm_pack_bf16x3(a.wt, K, a.cout, a.pack_ws, st) == 0) {
+            Epilogue ep = {a.bias, nullptr, 0, a.act ? 1 : 0, a.slope, 0, 0, 0, 0, a.bias2};
+            const int rc = gemm_rows_bf16x3(a.a0, a.c0, a.c0, a.a1, a.c1, a.a1 ? a.c1 : 0, a.m_total, a.pack_ws, a.cout, ep, a.out,
+                                            a.cout, nullptr, 0, st);
+            if (rc != ML3D_E_UNSUPPORTED) return rc;
+        }
+    }
     if (lin_mode != 2 && a.c0 + a.c1 >= 8) {
         RowsA A;
         A.a = a.a0; A.lda = a.c0; A.k1 = a.c0;
@@ -2687,6 +2705,21 @@ static void make_layout(const ml3d_randla_desc* d, Layout* L) {
     L->off[s] = o;
 }
 
+// scratch for the bf16 planes of ONE weight matrix at a time (the pack kernel and the GEMM that reads it are stream-ordered; the
+// next Linear's pack overwrites it after that GEMM): the largest [K, N] of pool2 / mlp2 | shortcut / the final mlp
+static size_t lin_pack_bytes(const ml3d_randla_desc* d) {
+    size_t m = 0;
+    int d_in = d->dim_features;
+    for (int l = 0; l < d->num_layers; ++l) {
+        const int dd = d->dim_output[l];
+        const size_t a = gemm_pack_bf16x3_bytes(dd, dd), b = gemm_pack_bf16x3_bytes(dd + d_in, 2 * dd), c = gemm_pack_bf16x3_bytes(dd, dd / 2);
+        m = a > m ? a : m; m = b > m ? b : m; m = c > m ? c : m;
+        d_in = 2 * dd;
+    }
+    const size_t e = gemm_pack_bf16x3_bytes(d_in, d_in);
+    return (e > m ? e : m) + 256;
+}
+
 static size_t fwd_ws_floats(const ml3d_randla_desc* d) {
     int64_t n[ML3D_RANDLA_MAX_LAYERS + 1];
     n[0] = d->num_points;
@@ -2707,6 +2740,7 @@ static size_t fwd_ws_floats(const ml3d_randla_desc* d) {
         f += al(B * n[lev] * skip_c) + al(B * n[lev + 1] * skip_c);    // stage output + per-coarse-point half (decoder split)
     }
     f += al(B * n[0] * 64) + al(B * n[0] * 32);
+    f += al((int64_t)(lin_pack_bytes(d) + 3) / 4) + 64;              // three bf16 planes of the largest Linear's weights
     return (size_t)f;
 }
 
@@ -2771,6 +2805,9 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     float* wsf = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     auto take = [&](int64_t count) { float* p = wsf; wsf += (count + 63) & ~(int64_t)63; return p; };
 
+    // scratch for the bf16 planes of one weight matrix (deep Linears on the bf16 matrix pipe: launch_linear_auto)
+    const size_t pack_bytes = lin_pack_bytes(d);
+    void* pack_ws = take((int64_t)(pack_bytes + 3) / 4);
     // fc0 + bn0 + lrelu(0.2)            (randlanet.py:266-271)
     float* feat = take(B * n[0] * d->dim_features);
     // every reference config: 8 features into a 16-wide first layer -> fc0 and that layer's mlp1 share one launch
@@ -2784,7 +2821,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         T.end(1000);
         if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     } else {
-        LinArgs a = {};
+        LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
         a.a0 = features; a.c0 = d->in_channels; a.wt = P(0); a.bias = P(1); a.out = feat;
         a.m_total = B * n[0]; a.cout = d->dim_features; a.act = 1; a.slope = 0.2f;
         T.begin(1000); int rc = launch_linear_auto(a, st); T.end(1000); if (rc) return rc;
@@ -2799,7 +2836,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         float* enc = take(M * 2 * dd);
         float* samp = take(B * n[l + 1] * 2 * dd);
         if (!(l == 0 && f1_head)) {   // mlp1: SharedMLP(d_in, d/2) lrelu 0.2   (randlanet.py:680)
-            LinArgs a = {};
+            LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
             a.a0 = feat; a.c0 = d_in; a.wt = P(sb + 0); a.bias = P(sb + 1); a.out = f1;
             a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
             T.begin(8 * l); int rc = launch_linear_auto(a, st); T.end(8 * l); if (rc) return rc;
@@ -2837,7 +2874,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             //  workgroup kernels add it themselves)
             const bool b3_attn = ((ML3D_ATTN_B3) & 1) != 0 && split && ((dd == 128 && n[l] >= B3Cfg<128, 1>::TP) || (dd == 256 && n[l] >= B3Cfg<256, 1>::TP));
             auto point_scores = [&](const float* gfeat, const float* score_wt, const float* score_b, int tag) -> int {
-                LinArgs ga = {};
+                LinArgs ga = {}; ga.pack_ws = pack_ws; ga.pack_bytes = pack_bytes;
                 ga.a0 = gfeat; ga.c0 = h; ga.wt = score_wt; ga.bias = (dd <= 64 || b3_attn) ? score_b : nullptr; ga.out = p2;   // first h rows of [d][d]
                 ga.m_total = M; ga.cout = dd; ga.act = 0;
                 T.begin(tag);
@@ -2857,7 +2894,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
             T.end(8 * l + 1);
             if (rc) return rc;
             if (!epi16) {   // pool1.mlp: SharedMLP(d, d/2) lrelu 0.2            (randlanet.py:639)
-                LinArgs a = {};
+                LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
                 a.a0 = agg; a.c0 = dd; a.wt = P(sb + 6); a.bias = P(sb + 7); a.out = p1;
                 a.m_total = M; a.cout = h; a.act = 1; a.slope = 0.2f;
                 T.begin(8 * l + 4); rc = launch_linear_auto(a, st); T.end(8 * l + 4); if (rc) return rc;
@@ -2893,13 +2930,13 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
                 T.begin(8 * l + 5); rc = launch_chain_auto(ch, st); T.end(8 * l + 5); if (rc) return rc;
             } else {
                 {
-                    LinArgs a = {};
+                    LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
                     a.a0 = agg; a.c0 = dd; a.wt = P(sb + 12); a.bias = P(sb + 13); a.out = p2;
                     a.m_total = M; a.cout = dd; a.act = 1; a.slope = 0.2f;
                     T.begin(8 * l + 5); rc = launch_linear_auto(a, st); T.end(8 * l + 5); if (rc) return rc;
                 }
                 {
-                    LinArgs a = {};
+                    LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
                     a.a0 = p2; a.c0 = dd; a.a1 = feat; a.c1 = d_in; a.wt = P(sb + 14);
                     a.bias = P(sb + 16); a.bias2 = P(sb + 17); a.out = enc;
                     a.m_total = M; a.cout = 2 * dd; a.act = 1; a.slope = 0.01f;
@@ -2945,7 +2982,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     const int Dm = d_in;
     float* cur = take(B * n[Lr] * Dm);
     {   // mlp: SharedMLP(D, D) lrelu 0.2               (randlanet.py:285)
-        LinArgs a = {};
+        LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
         a.a0 = feat; a.c0 = Dm; a.wt = P(slot); a.bias = P(slot + 1); a.out = cur;
         a.m_total = B * n[Lr]; a.cout = Dm; a.act = 1; a.slope = 0.2f;
         T.begin(1001); int rc = launch_linear_auto(a, st); T.end(1001); if (rc) return rc;
@@ -2959,7 +2996,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
         const int lev = Lr - 1 - i;                 // output level
         const int skip_c = ed[Lr + 1 - i - 2];
         float* outp = take(B * n[lev] * skip_c);
-        LinArgs a = {};
+        LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
         a.a0 = enc_keep[Lr + 1 - i - 2]; a.c0 = skip_c;
         a.a1 = cur; a.c1 = cprev; a.gather = interp_idx[lev];
         a.rows_per_item = n[lev]; a.a1_rows_per_item = n[lev + 1];
@@ -3011,7 +3048,7 @@ extern "C" int ml3d_randla_forward_ordered(const ml3d_randla_desc* d, const floa
     float* t0 = take(B * n[0] * 64);
     float* t1 = take(B * n[0] * 32);
     {   // fc1                                            (randlanet.py:93-96, 296)
-        LinArgs a = {};
+        LinArgs a = {}; a.pack_ws = pack_ws; a.pack_bytes = pack_bytes;
         a.a0 = cur; a.c0 = cprev; a.wt = P(slot); a.bias = P(slot + 1); a.out = t0;
         a.m_total = B * n[0]; a.cout = 64; a.act = 1; a.slope = 0.2f;
         ChainArgs ch = {};

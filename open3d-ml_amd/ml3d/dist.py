@@ -73,6 +73,25 @@ def gather_ragged(values, dst=0):
     return [t[:k] for t, k in zip(out, sizes)] if rank == dst else None
 
 
+def label_checksum(labels):
+    """int64 [3] on the labels' device: (sum, position-weighted sum, xor-fold of 8-byte words) of a label tensor -- what a rank
+    publishes about its own predictions so that the receiver of a gather can verify the bytes it was handed (bench.py, N > 1)."""
+    flat = labels.reshape(-1).to(torch.int64)
+    n = flat.numel()
+    w = (torch.arange(n, device=flat.device, dtype=torch.int64) % 251) + 1
+    raw = labels.reshape(-1).contiguous().view(torch.uint8)
+    pad = (-raw.numel()) % 8
+    if pad:
+        raw = torch.cat([raw, torch.zeros(pad, dtype=torch.uint8, device=raw.device)])
+    words = raw.view(torch.int64)
+    x = words
+    while x.numel() > 1:                      # xor-fold by halves (no bitwise reduction op in torch)
+        if x.numel() % 2:
+            x = torch.cat([x, torch.zeros(1, dtype=torch.int64, device=x.device)])
+        x = x[: x.numel() // 2] ^ x[x.numel() // 2:]
+    return torch.stack([flat.sum(), (flat * w).sum(), x.reshape(-1)[0] if x.numel() else torch.zeros((), dtype=torch.int64, device=flat.device)])
+
+
 def compact_labels(scores):
     """argmax over classes as the smallest integer type that holds it (uint8 for <= 256 classes): what travels."""
     if scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous() and scores.shape[-1] <= 256:

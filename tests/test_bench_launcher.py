@@ -35,6 +35,9 @@ def test_self_launch_two_ranks_over_gloo(workload):
     out = _line(_run(["--gpus", "2", "--stub", "--steps", "3", "--warmup", "2", "--frames-per-step", "2", "--workload", workload]))
     assert out["stub"] is True and out["n_gpus"] == 2 and out["steps"] == 3
     assert out["gathered_ranks_checked"] == 2           # rank 0 verified BOTH ranks' predictions of the last step
+    # ... and the check the REAL N > 1 run carries (round 6): every rank's label checksum recomputed on the gathered buffers
+    if workload == "randlanet":
+        assert out["gather_self_check"]["ranks_checked"] == 2 and out["gather_self_check"]["all_match"] is True
     seen = out["ranks_seen"]
     assert seen["world_size"] == 2 and len(seen["devices"]) == 2 and len(set(seen["devices"])) == 2
 
@@ -49,6 +52,7 @@ def test_self_launch_eight_ranks_are_pinned_to_disjoint_cpus():
     (ml3d.dist.bind_rank; no GPUs here, so the slices are an even split of the allowed CPUs), the map printed in ranks_seen."""
     out = _line(_run(["--gpus", "8", "--stub", "--steps", "2", "--warmup", "1", "--frames-per-step", "1"], timeout=600))
     assert out["n_gpus"] == 8 and out["ranks_seen"]["world_size"] == 8 and out["gathered_ranks_checked"] == 8
+    assert out["gather_self_check"]["all_match"] is True and len(out["gather_self_check"]["per_rank"]) == 8
     cmap = out["ranks_seen"]["cpu_map"]
     assert len(cmap) == 8 and all(m["host_threads"] >= 1 and m["bound"] for m in cmap)
     from ml3d.dist import _parse_cpulist
