@@ -64,9 +64,15 @@ static const Knobs& knobs() {
 #ifndef ML3D_ATTN_B3
 #define ML3D_ATTN_B3 3
 #endif
-// deep per-point Linears of the forward (pool2, mlp2 | shortcut, the 512 -> 512 mlp) on the bf16 matrix pipe from this K on (0: never)
+// deep per-point Linears of the forward (mlp2 | shortcut of the 128- and 256-wide layers, the 512 -> 512 mlp) on the bf16 matrix pipe from this
+// K on (0: never).  Same-box A/B (profiles/r06_linear_b3_ab.log): never 6965 frames/s, K >= 64: 7066, K >= 128: 6937 (the K = 128 GEMMs lose
+// more to their pack launch than the pipe returns), K >= 256: 7104
 #ifndef ML3D_LIN_B3_MINK
-#define ML3D_LIN_B3_MINK 128
+#define ML3D_LIN_B3_MINK 256
+#endif
+// per-point chains (decoder-last + fc1, pool2 + mlp2 | shortcut of the 64-wide layer) on the bf16 pipe with activations in registers
+#ifndef ML3D_CHAIN_B3
+#define ML3D_CHAIN_B3 1
 #endif
 #ifndef ML3D_B3_LB_DIV
 #define ML3D_B3_LB_DIV 1        // (register-pressure probe only: 2 lifts the budget to 512 VGPRs)
@@ -2422,6 +2428,237 @@ static int launch_mlp_wave_s(const ChainArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mlp_chain_b3 (round 6) — the per-point chains of mlp_wave_s on the BF16 matrix pipe with the activations in REGISTERS from the first
+// layer's input rows to the last layer's output: no LDS patch at all.
+//   * a lane loads ITS row's 8 consecutive input channels of a 16-deep step straight from global memory (two 16-byte loads; the
+//     decoder's [skip | interp[idx]] rows and the encoder's extra `cat` columns are just further steps), splits them three ways
+//     (b3_split8): that IS the MFMA operand fragment (row = lane % 32, K = 16 step + 8 (lane / 32) ..+7);
+//   * hidden layers run TRANSPOSED (C^T = W^T . X^T: a lane gets runs of four consecutive output channels of its own row), lrelu +
+//     split + one v_permlane32_swap per dword pair turn the result into the next layer's fragments (lfa_attn_wave_b3's finish);
+//   * the LAST layer runs untransposed on the same fragments (C = X . W: lane = output column), so the output rows are stored
+//     as contiguous runs (76 bytes of a 19-class row, 128 bytes of a 128-wide one) like mlp_wave_s does;
+//   * all weights sit in LDS once per workgroup as W^T planes [3][cout_pad][cin + 8] bf16 (both forms read them K-contiguous per
+//     output column), biases as floats.
+// Six bf16 MFMAs per 16-deep step instead of eight f32 MFMAs of twice the duration, and the VALU issue slots beside them stay
+// free (f32 MFMAs block them on gfx950).  Shapes: the same compile-time MlpShape instances as mlp_wave_s, widths multiples of 16.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+struct ChainB3 {
+    static constexpr int wp(int l) { return S::cin(l) + 8; }                                  // bf16 pitch of a weight row
+    static constexpr int plane(int l) { return S::np(l) * wp(l); }                            // bf16 per plane
+    static constexpr int w_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += 3 * plane(i); return o; }     // in bf16
+    static constexpr int w_total() { return (w_off(S::NL) + 7) & ~7; }
+    static constexpr int b_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::np(i); return o; }          // in floats
+    static constexpr size_t smem_bytes() { return (size_t)w_total() * 2 + (size_t)b_off(S::NL) * 4; }
+    static constexpr int maxk() { int m = 0; for (int l = 0; l < S::NL; ++l) m = S::cin(l) > m ? S::cin(l) : m; return m; }
+    static constexpr bool ok() {
+        for (int l = 0; l < S::NL; ++l) if (S::cin(l) % 16 != 0) return false;
+        for (int l = 0; l + 1 < S::NL; ++l) if (S::n(l) % 32 != 0) return false;
+        return S::C0 % 16 == 0 && S::C1 % 16 == 0 && (S::CATL < 0 || S::CATC % 16 == 0);
+    }
+};
+
+// layer L of the chain on the fragments `in` (K = cin(L)); recursion instead of a loop: every layer has its own compile-time widths
+template <class S, int L>
+__device__ __forceinline__ void chain_b3_layer(const ChainArgs& A, const uint16_t* __restrict__ WT, const float* __restrict__ BS,
+                                                ml3d_u32x4 (&in)[ChainB3<S>::maxk() / 16][3], uint32_t m_row0, uint32_t m_tot,
+                                                int hi, int cl) {
+    using B = ChainB3<S>;
+    constexpr int KS = S::cin(L) / 16, NP = S::np(L), WP = B::wp(L), PL = B::plane(L);
+    constexpr bool LAST = L == S::NL - 1;
+    const ChainLayer& Ly = A.L[L];
+    const uint16_t* W = WT + B::w_off(L);
+    const float* bias = BS + B::b_off(L);
+    if constexpr (LAST) {
+        // C = X . W: lane = output column, registers = rows; stored as contiguous row runs
+#pragma unroll
+        for (int ct = 0; ct < NP / 32; ++ct) {
+            const int col = ct * 32 + cl;
+            f32x16 acc;
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = b;
+            const uint16_t* br = W + col * WP + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ml3d_u32x4 w[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) w[p] = *reinterpret_cast<const ml3d_u32x4*>(br + p * PL + 16 * ks);
+                B3_PRODUCTS(mfma_bf16_32x32x16, acc, in[ks], w)
+            }
+            if (col < Ly.cout) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = m_row0 + mfma_row(r, hi);
+                    float v = acc[r];
+                    if (Ly.act) v = lrelu_max(v, Ly.slope);
+                    if (m < m_tot) A.out[(int64_t)m * Ly.cout + col] = v;
+                }
+            }
+        }
+    } else {
+        // C^T = W^T . X^T: lane = row, registers = channels 32 ct + 8 g + 4 hi .. + 3; -> the next layer's fragments
+        ml3d_u32x4 out[B::maxk() / 16][3];
+#pragma unroll
+        for (int ct = 0; ct < NP / 32; ++ct) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + 32 * ct + 8 * g + 4 * hi);
+                acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+            }
+            const uint16_t* ar = W + (32 * ct + cl) * WP + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ml3d_u32x4 w[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) w[p] = *reinterpret_cast<const ml3d_u32x4*>(ar + p * PL + 16 * ks);
+                B3_PRODUCTS(mfma_bf16_32x32x16, acc, w, in[ks])
+            }
+            uint2 pk[3][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b3_split4(lrelu_max(acc[4 * g + 0], Ly.slope), lrelu_max(acc[4 * g + 1], Ly.slope), lrelu_max(acc[4 * g + 2], Ly.slope),
+                          lrelu_max(acc[4 * g + 3], Ly.slope), pk[0][g], pk[1][g], pk[2][g]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    uint32_t x0 = pk[p][2 * h2].x, x1 = pk[p][2 * h2].y, y0 = pk[p][2 * h2 + 1].x, y1 = pk[p][2 * h2 + 1].y;
+                    lane32_swap(x0, y0);
+                    lane32_swap(x1, y1);
+                    out[2 * ct + h2][p] = (ml3d_u32x4){x0, x1, y0, y1};
+                }
+        }
+        if constexpr (L + 1 == S::CATL) {
+            // the next layer's extra input columns, straight from their rows into fragment form (requested here: they land under
+            // nothing -- 32 columns of a layer that has 64 + 32 -- but need no LDS either)
+            const uint32_t m = m_row0 + (uint32_t)cl;
+#pragma unroll
+            for (int e = 0; e < S::CATC / 16; ++e) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (m < m_tot) {
+                    const float4* src = reinterpret_cast<const float4*>(A.cat + (int64_t)m * S::CATC + 16 * e + 8 * hi);
+                    const float4 a = src[0], b = src[1];
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                }
+                b3_split8(v, out[S::n(L) / 16 + e][0], out[S::n(L) / 16 + e][1], out[S::n(L) / 16 + e][2]);
+            }
+        }
+        chain_b3_layer<S, L + 1>(A, WT, BS, out, m_row0, m_tot, hi, cl);
+    }
+}
+
+template <class S, int NW>
+__global__ void __launch_bounds__(NW * 64) mlp_chain_b3(ChainArgs A) {
+    using B = ChainB3<S>;
+    static_assert(B::ok(), "mlp_chain_b3: widths must be multiples of 16 (hidden: 32)");
+    HIP_DYNAMIC_SHARED(float, smem)
+    uint16_t* WT = reinterpret_cast<uint16_t*>(smem);
+    float* BS = reinterpret_cast<float*>(WT + B::w_total());
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, cl = lane & 31;
+    // ---- weights -> W^T planes (four consecutive K of one output column per item), biases ---------------------------------------
+#pragma unroll
+    for (int l = 0; l < S::NL; ++l) {
+        const ChainLayer Ly = A.L[l];
+        const int np = S::np(l), cin = S::cin(l), wp = B::wp(l), pl = B::plane(l);
+        uint16_t* W = WT + B::w_off(l);
+        for (int e = tid; e < np * (cin / 4); e += NW * 64) {
+            const int c = e % np, k4 = (e / np) * 4;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (c < Ly.cout) {
+                v0 = Ly.wt[(k4 + 0) * Ly.cout + c]; v1 = Ly.wt[(k4 + 1) * Ly.cout + c];
+                v2 = Ly.wt[(k4 + 2) * Ly.cout + c]; v3 = Ly.wt[(k4 + 3) * Ly.cout + c];
+            }
+            uint2 h, m, lo;
+            b3_split4(v0, v1, v2, v3, h, m, lo);
+            uint16_t* d = W + c * wp + k4;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + pl) = m;
+            *reinterpret_cast<uint2*>(d + 2 * pl) = lo;
+        }
+        for (int c = tid; c < np; c += NW * 64) {
+            float b = 0.f;
+            if (c < Ly.cout) { if (Ly.bias) b = Ly.bias[c]; if (Ly.bias2) b += Ly.bias2[c]; }
+            BS[B::b_off(l) + c] = b;
+        }
+    }
+    __syncthreads();
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t m_tot = (uint32_t)A.m_total;
+    const uint32_t tiles = (m_tot + 31) / 32;
+    const uint32_t t_step = gridDim.x * NW;
+    constexpr int K0 = S::C0 + S::C1, KS0 = K0 / 16, KA = S::C0 / 16;
+    const uint32_t rpi = (uint32_t)A.rows_per_item, srpi = (uint32_t)A.a1_rows_per_item;
+
+    // the lane's input row of the NEXT tile is requested while the current one is computed (gathered rows: their index one step
+    // earlier still)
+    float4 pre[KS0][2];
+    int gix = -1;
+    auto request_idx = [&](uint32_t t) {
+        if constexpr (S::C1 > 0) {
+            const uint32_t m = t * 32 + (uint32_t)cl;
+            gix = -1;
+            if (m < m_tot) gix = A.gather ? A.gather[m] : (int)m;
+        }
+    };
+    auto request_rows = [&](uint32_t t) {
+        const uint32_t m0 = t * 32, m = m0 + (uint32_t)cl;
+        uint32_t it0 = 0, l0 = m0;
+        if (S::C1 > 0 && A.gather) { it0 = m0 / rpi; l0 = m0 - it0 * rpi; }
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+            pre[ks][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_tot) {
+                const float4* src;
+                if (ks < KA) {
+                    src = reinterpret_cast<const float4*>(A.a0 + (int64_t)m * S::C0 + 16 * ks + 8 * hi);
+                } else {
+                    int64_t grow = gix;
+                    if (A.gather) grow += (int64_t)(it0 + ((l0 + (uint32_t)cl >= rpi) ? 1u : 0u)) * srpi;   // a tile crosses items at most once
+                    src = reinterpret_cast<const float4*>(A.a1 + grow * S::C1 + 16 * (ks - KA) + 8 * hi);
+                }
+                pre[ks][0] = src[0];
+                pre[ks][1] = src[1];
+            }
+        }
+    };
+    uint32_t t = blockIdx.x * NW + swave;
+    if (t < tiles) { request_idx(t); request_rows(t); }
+    if (t + t_step < tiles) request_idx(t + t_step);
+    for (; t < tiles; t += t_step) {
+        ml3d_u32x4 in[B::maxk() / 16][3];
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+            const float v[8] = {pre[ks][0].x, pre[ks][0].y, pre[ks][0].z, pre[ks][0].w, pre[ks][1].x, pre[ks][1].y, pre[ks][1].z, pre[ks][1].w};
+            b3_split8(v, in[ks][0], in[ks][1], in[ks][2]);
+        }
+        if (t + t_step < tiles) {
+            request_rows(t + t_step);
+            if (t + 2 * t_step < tiles) request_idx(t + 2 * t_step);
+        }
+        chain_b3_layer<S, 0>(A, WT, BS, in, t * 32, m_tot, hi, cl);
+    }
+}
+
+template <class S, int NW>
+static int launch_mlp_chain_b3(const ChainArgs& a, hipStream_t st) {
+    const size_t sm = ChainB3<S>::smem_bytes();
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)mlp_chain_b3<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return ML3D_E_LAUNCH;
+    static const int cus = device_cu_count();
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)mlp_chain_b3<S, NW>, NW * 64, sm) != hipSuccess || occ < 1) occ = 1;
+    const int64_t tiles = (a.m_total + 31) / 32;
+    const int64_t want = (tiles + NW - 1) / NW, cap = (int64_t)occ * cus;
+    hipLaunchKernelGGL((mlp_chain_b3<S, NW>), dim3((unsigned)(want < cap ? want : cap)), dim3(NW * 64), sm, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+}
+
 // multi-layer chains run fused iff their shape has a compiled per-wave instance (callers fall back to one Linear per layer)
 static bool chain_compiled(const ChainArgs& a) {
     if (a.m_total <= 0 || !knobs().mlp_shaped) return false;
@@ -2430,6 +2667,13 @@ static bool chain_compiled(const ChainArgs& a) {
 }
 
 static int launch_chain_auto(const ChainArgs& a, hipStream_t st) {
+    if constexpr ((ML3D_CHAIN_B3) != 0) {
+        // (16-byte loads of 8 consecutive channels: rows must be 16-byte aligned, which every [m, C] buffer of the forward is)
+        const bool al = (((uintptr_t)a.a0 | (uintptr_t)a.a1 | (uintptr_t)a.cat) & 15) == 0;
+        if (al && mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_chain_b3<ShapeDecFc1, 4>(a, st);
+        if (al && mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_chain_b3<ShapeFc1, 4>(a, st);
+        if (al && mlp_shape_matches<ShapeEnc64>(a)) return launch_mlp_chain_b3<ShapeEnc64, 8>(a, st);
+    }
     if (mlp_shape_matches<ShapeDecFc1>(a)) return launch_mlp_wave_s<ShapeDecFc1, 8>(a, st);
     if (mlp_shape_matches<ShapeFc1>(a)) return launch_mlp_wave_s<ShapeFc1, 8>(a, st);
     if (mlp_shape_matches<ShapeEnc64>(a)) return launch_mlp_wave_s<ShapeEnc64, 4>(a, st);
