@@ -84,4 +84,16 @@ __device__ __forceinline__ void lane32_swap(uint32_t& x, uint32_t& y) {
 // `true` more often than that (k-NN pending queue: an early flush is always exact).
 __device__ __forceinline__ bool wave_any_active(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
 
+// One slot per ACTIVE lane of an append-only list, in DIVERGENT control flow: one atomicAdd per wave (the lowest active lane adds the
+// number of active lanes, the others take base + their rank among them), slots of a wave contiguous and in lane order.  (The host
+// emulator cannot rendezvous lanes in divergent flow: there every lane adds 1 -- slot values differ, set of slots identical.)
+__device__ __forceinline__ unsigned wave_append(unsigned* counter) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // rank among the active lanes
+    unsigned base = 0u;
+    if (lane == 0u) base = atomicAdd(counter, (unsigned)__builtin_popcountll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+    return base + lane;
+}
+
 }  // namespace ml3d

@@ -173,11 +173,25 @@ __device__ __forceinline__ void scan_shell(const GridView& G, const GridSeg& g, 
     }
 }
 
-template <int K, bool SUB>
+// Hand-off of the queries the first shell (the 3 x 3 x 3 block) does not settle, from the launch that reads that block for EVERY query
+// to a second launch that walks the further shells for those queries ONLY (round 6).  In one launch the ~44 % of the lanes that go on
+// drag their waves through the shell walk at that lane utilisation -- every candidate step of a wave costs the full insertion network
+// as soon as ONE lane inserts; compacted, the same walks run in full waves.  State per query: the 16 + 1 best keys (136 bytes) and the
+// query's (job, row); everything else is recomputed.  A full list (cap) is not an error: the lane simply continues inline.
+struct Handoff {
+    unsigned* count;        // number of appended queries (may exceed cap: the surplus continued inline)
+    uint32_t* who;          // [cap] job << 28 | query row of the job (rows < 2^28: the launcher's GRID_CAP check)
+    double* keys;           // [17][cap] best[0 .. 15], best1
+    unsigned cap;
+};
+
+// MODE 0: the whole search.  1: first shell, then hand-off (H).  2: continuation of hand-off entry `hslot` from the second shell on.
+template <int K, bool SUB, int MODE = 0>
 __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, int k, int index_local,
                                         const Segs& support_segs, int32_t* __restrict__ out_idx,
                                         float* __restrict__ out_d2, int64_t t, int n_sub = 0,
-                                        int32_t* __restrict__ out_sub = nullptr, bool vec_store = false) {
+                                        int32_t* __restrict__ out_sub = nullptr, bool vec_store = false,
+                                        const Handoff* H = nullptr, unsigned job = 0u, unsigned hslot = 0u) {
     if (t >= Q.n_total) return;
     int s = 0; int64_t local = 0;
     float qx, qy, qz;
@@ -203,29 +217,57 @@ __device__ __forceinline__ void knn_one(const GridView& G, const QuerySrc& Q, in
         int cy = cell_coord(qy, g.lo[1], g.inv_c, g.dims[1]);
         int cz = cell_coord(qz, g.lo[2], g.inv_c, g.dims[2]);
         constexpr int UNIT_SHELLS = 3;        // shells read one at a time before the box starts to grow geometrically
-        float dk = 3.0e38f;                   // squared distance both answers are known within (inf: not yet)
-        for (int r_in = 0, r = 1;;) {
+        // squared distance both answers are known within (inf: not yet) -- a function of the lists alone
+        auto known_within = [&](u64& kth) -> float {
+            kth = (u64)__double_as_longlong(best[K - 1]);
+            if (k < K) {
+                // fewer than K requested: the k-th entry decides
+#pragma unroll
+                for (int j = 0; j < K; ++j) if (j == k - 1) kth = (u64)__double_as_longlong(best[j]);
+            }
+            float d = 3.0e38f;
+            if (kth != KEY_EMPTY) {
+                d = __uint_as_float((unsigned)(kth >> 32));
+                if (SUB && n_sub > 0) {       // (n_sub == 0: no coarser level, the interpolation index is -1 whatever is scanned)
+                    // both answers must be final: the nearest prefix point may lie beyond the k-th neighbour
+                    const u64 k1 = (u64)__double_as_longlong(best1);
+                    if (k1 != KEY_EMPTY) d = fmaxf(d, __uint_as_float((unsigned)(k1 >> 32))); else d = 3.0e38f;
+                }
+            }
+            return d;
+        };
+        float dk = 3.0e38f;
+        int r_in = 0, r = 1;
+        if constexpr (MODE == 2) {
+            // the state the first launch left: the lists after the 3 x 3 x 3 block; the walk resumes with the second shell
+#pragma unroll
+            for (int j = 0; j < K; ++j) best[j] = H->keys[(size_t)j * H->cap + hslot];
+            best1 = H->keys[(size_t)K * H->cap + hslot];
+            u64 kth0;
+            dk = known_within(kth0);
+            r_in = 1; r = 2;
+        }
+        for (;;) {
             scan_shell<K, SUB>(G, g, qx, qy, qz, cx, cy, cz, r_in, r, dk, best, n_sub, best1);
             // every point outside the scanned box is at least `gd` away (inf when the box face is
             // past the grid).  Stop once the k-th best is strictly inside that radius.
             bool all;
             const float gd = shell_guard(g, qx, qy, qz, cx, cy, cz, r, all);
             if (all) break;
-            u64 kth = (u64)__double_as_longlong(best[K - 1]);
-            if (k < K) {
-                // fewer than K requested: the k-th entry decides
+            u64 kth;
+            dk = known_within(kth);
+            if (kth != KEY_EMPTY && gd > 0.f && dk < gd * gd * 0.999999f) break;
+            if constexpr (MODE == 1) {
+                if (r == 1) {
+                    const unsigned slot = wave_append(H->count);
+                    if (slot < H->cap) {
 #pragma unroll
-                for (int j = 0; j < K; ++j) if (j == k - 1) kth = (u64)__double_as_longlong(best[j]);
-            }
-            dk = 3.0e38f;
-            if (kth != KEY_EMPTY) {
-                dk = __uint_as_float((unsigned)(kth >> 32));
-                if (SUB && n_sub > 0) {       // (n_sub == 0: no coarser level, the interpolation index is -1 whatever is scanned)
-                    // both answers must be final: the nearest prefix point may lie beyond the k-th neighbour
-                    const u64 k1 = (u64)__double_as_longlong(best1);
-                    if (k1 != KEY_EMPTY) dk = fmaxf(dk, __uint_as_float((unsigned)(k1 >> 32))); else dk = 3.0e38f;
+                        for (int j = 0; j < K; ++j) H->keys[(size_t)j * H->cap + slot] = best[j];
+                        H->keys[(size_t)K * H->cap + slot] = best1;
+                        H->who[slot] = (job << 28) | (uint32_t)t;
+                        return;
+                    }
                 }
-                if (gd > 0.f && dk < gd * gd * 0.999999f) break;
             }
             r_in = r;
             if (r < UNIT_SHELLS) { ++r; continue; }
@@ -305,19 +347,52 @@ struct KnnJobs {
 #define KNN_WAVES 5        // register budget 512 / 5 = 96.  Round 2 ran six waves per SIMD (80 registers: 1.68 against 1.76 ms); with the
 #endif                    // shell walk of round 4 six waves spill 19 registers to scratch (+70 % FETCH_SIZE, +40 % WRITE_SIZE:
                           // profiles/r04_pmc_fetch.csv) for no gain: 1.42 ms / 5992 frames/s at six, 1.38 ms / 6041 at five (gpurun r4j)
-template <int K, bool SUB>
+template <int K, bool SUB, bool HAND>
 __global__ void __launch_bounds__(256)
 #if KNN_WAVES > 0
 ML3D_WAVES_PER_SIMD(KNN_WAVES)
 #endif
-knn_query_multi(KnnJobs J, int k, int index_local, int vec_store) {
+knn_query_multi(KnnJobs J, int k, int index_local, int vec_store, Handoff H) {
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < KNN_MAX_JOBS; ++i)
         if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
     const KnnJob& jb = J.j[ji];
-    knn_one<K, SUB>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
-                    (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub, vec_store != 0);
+    knn_one<K, SUB, HAND ? 1 : 0>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+                                  (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub, vec_store != 0,
+                                  &H, (unsigned)ji);
+}
+
+#ifndef KNN_WAVES_HAND
+#define KNN_WAVES_HAND 4   // register budget of the two hand-off launches: 128 (at 96 they spill 17 / 33 registers for the list addressing)
+#endif
+// the first launch of a hand-off (knn_query_multi<.., HAND = true> with its own register budget)
+template <int K, bool SUB>
+__global__ void __launch_bounds__(256)
+ML3D_WAVES_PER_SIMD(KNN_WAVES_HAND)
+knn_first(KnnJobs J, int k, int index_local, int vec_store, Handoff H) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < KNN_MAX_JOBS; ++i)
+        if (i < J.n && blockIdx.x >= J.j[i].block_begin) ji = i;
+    const KnnJob& jb = J.j[ji];
+    knn_one<K, SUB, 1>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr,
+                       (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x, jb.n_sub, jb.out_sub, vec_store != 0, &H, (unsigned)ji);
+}
+
+// the second launch of a hand-off: entry i of the list = one lane; blocks past the list's end leave at once
+template <int K, bool SUB>
+__global__ void __launch_bounds__(256)
+ML3D_WAVES_PER_SIMD(KNN_WAVES_HAND)
+knn_continue(KnnJobs J, int k, int index_local, int vec_store, Handoff H) {
+    const unsigned have = *H.count;
+    const unsigned n = have < H.cap ? have : H.cap;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t who = H.who[i];
+    const KnnJob& jb = J.j[who >> 28];
+    knn_one<K, SUB, 2>(jb.G, jb.Q, k, index_local, jb.support, jb.out_idx, nullptr, (int64_t)(who & 0x0fffffffu), jb.n_sub, jb.out_sub,
+                       vec_store != 0, &H, who >> 28, i);
 }
 
 // threads per workgroup of the multi-job launch.  No LDS, no barriers: ONE wave per workgroup, so a wave slot is refilled as soon
@@ -327,8 +402,28 @@ static int knn_block() { return 64; }
 // (16 or 32 queries per wave for launches that cannot fill the chip's wave slots -- the five levels of ONE frame are 940 full
 //  waves on 5120 slots -- measured: 0.363 -> 0.342 ms at batch 1, i.e. a launch that small is not bound by what shares a wave
 //  (the suspect: its slowest single query, an outlier walking hundreds of near-empty rows, two dependent loads each).  Removed.)
+// hand-off scratch behind the grids of a pyramid workspace: room for 5/8 of the queries (measured: ~44 % go past the first shell)
+static size_t handoff_bytes(int64_t total_queries) {
+    const size_t cap = (size_t)(total_queries * 5 / 8 + 64);
+    return 256 + ((cap * 4 + 255) & ~(size_t)255) + 17 * cap * 8 + 256;
+}
+static Handoff handoff_carve(char* p, int64_t total_queries) {
+    Handoff H;
+    const size_t cap = (size_t)(total_queries * 5 / 8 + 64);
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    H.count = (unsigned*)p;  p += 256;
+    H.who = (uint32_t*)p;    p += (cap * 4 + 255) & ~(size_t)255;
+    H.keys = (double*)p;
+    H.cap = (unsigned)cap;
+    return H;
+}
+
+#ifndef ML3D_KNN_HANDOFF
+#define ML3D_KNN_HANDOFF 1          // A/B switch (build time): 0 keeps the one-launch search
+#endif
+
 template <bool SUB>
-static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream) {
+static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t stream, const Handoff* hand = nullptr) {
     const int T = knn_block();
     unsigned blocks = 0;
     int vec = 1;            // 16-byte index stores need every job's rows at a 16-byte aligned base (a view or a carved slab may not be)
@@ -338,11 +433,21 @@ static int launch_query_multi(KnnJobs& J, int k, int index_local, hipStream_t st
         if ((uintptr_t)J.j[i].out_idx & 15) vec = 0;
     }
     if (blocks == 0) return 0;
-    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
-    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
-    else if (k <= 16) hipLaunchKernelGGL((knn_query_multi<16, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
-    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
-    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec);
+    Handoff H = {};
+    if ((ML3D_KNN_HANDOFF) && hand && k > 8 && k <= 16) {
+        // two launches: the 3 x 3 x 3 block of every query, then the further shells of the queries it did not settle, compacted
+        H = *hand;
+        zero_async(H.count, 16, stream);
+        hipLaunchKernelGGL((knn_first<16, SUB>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
+        if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
+        hipLaunchKernelGGL((knn_continue<16, SUB>), dim3((H.cap + T - 1) / T), dim3(T), 0, stream, J, k, index_local, vec, H);
+        return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
+    }
+    if (k == 1) hipLaunchKernelGGL((knn_query_multi<1, SUB, false>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
+    else if (k <= 8) hipLaunchKernelGGL((knn_query_multi<8, SUB, false>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
+    else if (k <= 16) hipLaunchKernelGGL((knn_query_multi<16, SUB, false>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
+    else if (k <= 32) hipLaunchKernelGGL((knn_query_multi<32, SUB, false>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
+    else if (k <= 64) hipLaunchKernelGGL((knn_query_multi<64, SUB, false>), dim3(blocks), dim3(T), 0, stream, J, k, index_local, vec, H);
     else return ML3D_E_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
@@ -432,8 +537,9 @@ extern "C" size_t ml3d_randla_pyramid_workspace_bytes(int64_t batch, int64_t n0,
     int64_t n[17];
     if (pyramid_sizes(n0, num_layers, ratios_host, n)) return 0;
     size_t b = 0;
-    for (int l = 0; l < num_layers; ++l) b += grid_ws_bytes(n[l] * batch, batch) + 256;
-    return b;
+    int64_t total = 0;
+    for (int l = 0; l < num_layers; ++l) { b += grid_ws_bytes(n[l] * batch, batch) + 256; total += n[l] * batch; }
+    return b + handoff_bytes(total);
 }
 
 extern "C" int ml3d_randla_knn_pyramid(const float* points, int64_t batch, int64_t n0, int num_layers,
@@ -514,8 +620,11 @@ extern "C" int ml3d_randla_knn_pyramid_ordered(const float* points, int64_t batc
         a.out_sub = interp_idx_host[l];
         a.n_sub = (int)n[l + 1];          // 0: every interpolation index comes out -1 (no coarser level)
     }
+    int64_t total_q = 0;
+    for (int l = 0; l < num_layers; ++l) total_q += n[l] * batch;
+    const Handoff hand = handoff_carve(p, total_q);
     tb(0);
-    int rc = launch_query_multi<true>(Jk, k, 1, st);
+    int rc = launch_query_multi<true>(Jk, k, 1, st, &hand);
     te(0);
     return rc;
 }

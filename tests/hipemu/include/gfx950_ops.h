@@ -28,6 +28,8 @@ typedef uint32_t ml3d_u32x4 __attribute__((ext_vector_type(4)));
 static inline ml3d_f32x16 mfma_bf16_32x32x16(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x16 c) { return hipemu_mfma_32x32x16_bf16(a, b, c); }
 typedef float ml3d_f32x4 __attribute__((ext_vector_type(4)));
 static inline ml3d_f32x4 mfma_bf16_16x16x32(ml3d_u32x4 a, ml3d_u32x4 b, ml3d_f32x4 c) { return hipemu_mfma_16x16x32_bf16(a, b, c); }
+// (lanes are independent fibers: no rendezvous in divergent flow -- every lane takes its slot with its own atomic)
+static inline unsigned wave_append(unsigned* counter) { return atomicAdd(counter, 1u); }
 // v_permlane32_swap_b32: lanes 32-63 of x trade places with lanes 0-31 of y
 static inline void lane32_swap(uint32_t& x, uint32_t& y) {
     uint32_t xy[2] = {x, y};
