@@ -419,7 +419,12 @@ static Handoff handoff_carve(char* p, int64_t total_queries) {
 }
 
 #ifndef ML3D_KNN_HANDOFF
-#define ML3D_KNN_HANDOFF 1          // A/B switch (build time): 0 keeps the one-launch search
+// A/B switch (build time).  Default 0 = the one-launch search: measured on the MI355X (profiles/r06_knn_handoff_ab.log, same box,
+// alternating) the hand-off LOSES -- k-NN alone 2.47 ms (2.31 at five waves per SIMD) against 2.09-2.12 ms, 7350 / 7234 against 7332 / 7471
+// frames/s: the 136 bytes of state per open query written and read back (~0.9 GB per 128-frame step), the second launch and the
+// register budget of the list addressing cost more than the fuller waves of the shell walk return.  The code stays as the record
+// of that experiment ("if it loses, commit the A/B log and stop").
+#define ML3D_KNN_HANDOFF 0
 #endif
 
 template <bool SUB>

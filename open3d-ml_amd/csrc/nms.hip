@@ -194,32 +194,40 @@ __global__ void nms_keys(const float* __restrict__ scores, int64_t n, u64* __res
     vals[i] = (uint32_t)i;
 }
 
-// mask[a][wb] bit j: sorted candidate (64*wb + j) is suppressed by sorted candidate a  (only b > a)
+// mask[a][wb] bit j: sorted candidate (64*wb + j) is suppressed by sorted candidate a  (only b > a).
+// One wave per (a, word): lane j tests the pair (a, 64 wb + j) with both boxes in REGISTERS and the ballot is the mask word (the form
+// of nmsb_mask).  Round 6: the earlier form -- a thread per row walking 64 boxes staged in LDS, with a per-lane first column on the
+// diagonal blocks -- returned a different keep list in ~1 of 200 calls beside a looping bf16x3 convolution on another stream
+// (tests/test_gpu_corun.py, profiles/r06_nms_corun.log): LDS reads inside a loop whose trip count differs per lane, the pattern of
+// DESIGN.md section 9.10.  This form has no LDS and no loop.
 __global__ void __launch_bounds__(64)
 nms_mask(const float* __restrict__ boxes, const uint32_t* __restrict__ order, int64_t n, float thr, int words,
          u64* __restrict__ mask) {
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb) return;
-    __shared__ float bb[64][5];
-    const int t = threadIdx.x;
-    const int64_t bj = (int64_t)cb * 64 + t;
-    if (bj < n) {
-        const float* s = boxes + 5 * (int64_t)order[bj];
-        for (int k = 0; k < 5; ++k) bb[t][k] = s[k];
+    const int64_t a = (int64_t)blockIdx.z * 32768 + blockIdx.y;
+    const int cb = blockIdx.x, lane = threadIdx.x;
+    if (a >= n || cb < (int)(a >> 6)) return;
+    const int64_t j = (int64_t)cb * 64 + lane;
+    bool sup = false;
+    if (j > a && j < n) {
+        float ba[5], bj[5];
+        const float* sa = boxes + 5 * (int64_t)order[a];
+        const float* sj = boxes + 5 * (int64_t)order[j];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { ba[q] = sa[q]; bj[q] = sj[q]; }
+        // circumscribed circles (rotation about the box centre): disjoint circles -> disjoint boxes -> IoU exactly 0, which is never
+        // > thr when thr >= 0 (NaN / inf boxes and negative thresholds take the full test)
+        const float dx = 0.5f * ((ba[0] + ba[2]) - (bj[0] + bj[2])), dy = 0.5f * ((ba[1] + ba[3]) - (bj[1] + bj[3]));
+        const float ra = 0.5f * sqrtf((ba[2] - ba[0]) * (ba[2] - ba[0]) + (ba[3] - ba[1]) * (ba[3] - ba[1]));
+        const float rj = 0.5f * sqrtf((bj[2] - bj[0]) * (bj[2] - bj[0]) + (bj[3] - bj[1]) * (bj[3] - bj[1]));
+        const float reach = (ra + rj) * 1.0001f + 1e-6f;
+        if (!(thr >= 0.f) || !(dx * dx + dy * dy > reach * reach)) {
+            P2 ca[4];
+            box_corners(ba, ca);
+            sup = iou_bev(ba, ca, bj) > thr;
+        }
     }
-    __syncthreads();
-    const int64_t a = (int64_t)rb * 64 + t;
-    if (a >= n) return;
-    float ba[5];
-    const float* s = boxes + 5 * (int64_t)order[a];
-    for (int k = 0; k < 5; ++k) ba[k] = s[k];
-    P2 ca[4];
-    box_corners(ba, ca);
-    u64 bits = 0ull;
-    const int cols = (int)((n - (int64_t)cb * 64) < 64 ? (n - (int64_t)cb * 64) : 64);
-    for (int j = (rb == cb ? t + 1 : 0); j < cols; ++j)
-        if (iou_bev(ba, ca, bb[j]) > thr) bits |= 1ull << j;
-    mask[a * words + cb] = bits;
+    const u64 bits = __ballot(sup);
+    if (lane == 0) mask[a * words + cb] = bits;
 }
 
 __global__ void __launch_bounds__(64)
@@ -645,8 +653,8 @@ extern "C" int ml3d_nms(const float* boxes, const float* scores, int64_t n, floa
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     if (sort_pairs_u64(keys, order, n, 64, sw, st)) return ML3D_E_LAUNCH;
     zero_async(mask, sizeof(u64) * (size_t)(n * words), st);
-    hipLaunchKernelGGL(nms_mask, dim3((unsigned)words, (unsigned)words), dim3(64), 0, st, boxes, order, n, iou_threshold,
-                       words, mask);
+    hipLaunchKernelGGL(nms_mask, dim3((unsigned)words, (unsigned)(n < 32768 ? n : 32768), (unsigned)((n + 32767) / 32768)), dim3(64), 0, st,
+                       boxes, order, n, iou_threshold, words, mask);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64), 0, st, mask, order, n, words, out_keep, out_count);
     return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
