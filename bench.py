@@ -49,7 +49,8 @@ import synth_weights
 
 CFG = dict(synth_weights.RANDLANET_SEMANTICKITTI_CFG)  # randlanet_semantickitti.yml:17-33
 
-PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+PEAK_F32_TFLOPS = 157.3
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md)   # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 # kernels traced live (library tag -> description).  k-NN tag 0 = the merged neighbour-search launch;
@@ -99,6 +100,10 @@ def _sq(kernel_key):
         return tj["sq"][kernel_key]
     except Exception:
         return None
+
+
+TRAFFIC_SOURCE = ("committed PMC pass (profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the op alone, "
+                  "2 x FETCH_SIZE + WRITE_SIZE, scaled to this batch) -- NOT measured in this run")
 
 
 def _traffic(kernel_key, batch):
@@ -605,7 +610,7 @@ def main():
                 d = CFG["dim_output"][layer]
                 fl_ref = lfa_flops(CFG, layer, stage, n_lv[layer] * B)
                 fl_ex = lfa_flops_executed(CFG, layer, stage, n_lv[layer] * B)
-                name = ("lfa_attn_mfma16<%d>" % stage) if d == 16 else ("lfa_attn_wave<%d,%d>" % (d, stage))
+                name = ("lfa_attn_mfma16<%d>" % stage) if d == 16 else ("lfa_attn_wave_b3<%d,%d>" % (d, stage))
                 cands.append({"bound": "mfma", "kernel": "%s (layer %d)" % (name, layer),
                               "achieved": fl_ex / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                               "frac": fl_ex / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
@@ -613,6 +618,15 @@ def main():
                               "traffic": _traffic(name, B), "avg_launch_ms": ms, "avg_launch_ms_alone": alone.get((kind, tag)),
                               "executed_flops_per_launch": fl_ex,
                               "reference_flops_per_launch": fl_ref})
+                if d != 16:
+                    # round 6: the deep products of this stage (lse2, the score Linear's position half) run on the bf16 pipe as six
+                    # bf16 MFMAs per 16-deep step (three-way split of both operands, float32-equivalent): `achieved` / `frac` stay
+                    # float32-equivalent flops against the f32 matrix peak; the bf16 flops the pipe actually executes are 3x the
+                    # float32-equivalent flops of those products (lse1 stays on the f32 MFMA)
+                    cands[-1]["note"] = ("float32-equivalent flops; lse2 + score product executed as 6 bf16 MFMAs per 16-deep step "
+                                         "(v_mfma_f32_32x32x16_bf16), dense bf16 peak %.0f TFLOP/s" % PEAK_BF16_TFLOPS)
+        for c in cands:
+            c["traffic_source"] = TRAFFIC_SOURCE if c.get("traffic") is not None else None
         cands.sort(key=lambda c: -c["avg_launch_ms"])
         out = {
             "metric": "point-cloud frames/sec (RandLA-Net SemanticKITTI inference: H2D + kNN pyramid + forward)",

@@ -29,11 +29,16 @@ def _hbm_entry(component, kernel, nbytes, ms_in, ms_alone, traffic_key, units, n
          "avg_launch_ms_alone": ms_alone,
          "frac_alone": (nbytes / (ms_alone * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms_alone else None,
          "bytes_per_launch": float(nbytes), "units_per_launch": units, "note": note}
+    e["traffic_source"] = TRAFFIC_SOURCE if e["traffic"] is not None else None
     if launches is not None:
         e["launches_timed"] = launches
     if extra:
         e.update(extra)
     return e
+
+
+TRAFFIC_SOURCE = ("committed PMC pass (profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the op alone, "
+                  "2 x FETCH_SIZE + WRITE_SIZE, scaled to this batch) -- NOT measured in this run")
 
 
 def _traffic(key, units):
@@ -363,7 +368,7 @@ def run_pointpillars(args, rank, world, dev, dist):
                         "achieved": mult * flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                         "frac": mult * flops / (ms * 1e-3) / 1e12 / peak,
                         "f32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
-                        "traffic": _traffic("pp_conv3x3_64", Bm), "avg_launch_ms": ms, "flops_per_launch": flops,
+                        "traffic": _traffic("pp_conv3x3_64", Bm), "traffic_source": TRAFFIC_SOURCE, "avg_launch_ms": ms, "flops_per_launch": flops,
                         "executed_flops_per_launch": mult * flops,
                         "sweeps_per_launch": int(Bm), "launches_timed": len(in_region),
                         "timed": "inside the timed region, on the lane's compute stream, the other lane co-running",
@@ -601,7 +606,7 @@ def run_kpconv(args, rank, world, dev, dist):
                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                         "frac_reference_formulation": flops_dense / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                        "traffic": _traffic("kpconv_block_32_32", B), "avg_launch_ms": ms,
+                        "traffic": _traffic("kpconv_block_32_32", B), "traffic_source": TRAFFIC_SOURCE, "avg_launch_ms": ms,
                         "executed_flops_per_launch": flops_exec, "reference_flops_per_launch": flops_dense,
                         "real_neighbours_per_query": real / float(nq), "launches_timed": len(in_region),
                         "timed": "inside the timed region, on the pipeline's compute stream, the next batch's build co-running",

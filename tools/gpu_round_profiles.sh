@@ -3,7 +3,7 @@
 # counter passes (separate passes, as MI355X_MICROARCH.md prescribes) of the RandLA step and of the KPConv / PointPillars
 # roofline ops run alone, the SQ counters of the k-NN launch, and profiles/traffic.json rebuilt from them.
 # usage: bash tools/gpu_round_profiles.sh r04   (then copy gpurun_out/r04/profiles/* into profiles/)
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 export TMPDIR=/tmp

@@ -9,7 +9,7 @@ import sys
 KEYS = {   # bench.py's kernel key -> substring of the rocprof kernel name
     "knn_query_multi<16, true>": "knn_query_multi<16, true",
     "lfa_attn_mfma16<1>": "lfa_attn_mfma16<1,",
-    "lfa_attn_wave<64,2>": "lfa_attn_wave<64, 2,",
+    "lfa_attn_wave_b3<64,2>": "lfa_attn_wave_b3<64, 2,",
 }
 
 
