@@ -1473,7 +1473,7 @@ __global__ void __launch_bounds__((B3Cfg<D, STAGE>::THREADS / ML3D_B3_LB_DIV)) l
             float num[2], den[2];
             softmax_wsum8<XP>(acc, 0, xc + (4 * hi) * XP, num[0], den[0]);
             softmax_wsum8<XP>(acc, 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
-            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
+            const float agg_mine = (hi ? num[1] : num[0]) * __builtin_amdgcn_rcpf(hi ? den[1] : den[0]);     // (v_rcp_f32 + multiply, 1 ulp: as lfa_attn_mfma16)
             int64_t m = m_base + 2 * rt + hi;                    // half 0 stores point 0 of the row tile, half 1 point 1
             if (m < A.m_total) {
                 if constexpr (ORD) m = A.order[m];
@@ -1784,7 +1784,7 @@ __global__ void __launch_bounds__((WaveB3Cfg<D>::W * 64)) lfa_attn_wave_b3(LfaAr
             float num[2], den[2];
             softmax_wsum8<XP>(sc[t], 0, xc + (4 * hi) * XP, num[0], den[0]);
             softmax_wsum8<XP>(sc[t], 8, xc + (16 + 4 * hi) * XP, num[1], den[1]);
-            const float agg_mine = (hi ? num[1] : num[0]) / (hi ? den[1] : den[0]);
+            const float agg_mine = (hi ? num[1] : num[0]) * __builtin_amdgcn_rcpf(hi ? den[1] : den[0]);     // (v_rcp_f32 + multiply, 1 ulp: as lfa_attn_mfma16)
             if (mi < m_tot) __builtin_nontemporal_store(agg_mine, A.out + (int64_t)m * D + 32 * t + col);
         }
         wave_lds_sync();                                          // the patch is rewritten at the top of the loop
