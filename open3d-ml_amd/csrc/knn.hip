@@ -716,28 +716,30 @@ argmax_rows(const float* __restrict__ scores, int64_t n, int C, uint8_t* __restr
     out[i] = (uint8_t)arg;
 }
 
-// the same for C <= 32 with the 256 rows of a workgroup staged through LDS: the rows are contiguous in memory, so the workgroup reads
+// the same for C <= 32 with the 64 rows of a workgroup staged through LDS: the rows are contiguous in memory, so the workgroup reads
 // them as one run of 16-byte loads (one thread per row reads 76-byte-strided scalars: 0.34 ms for the 438 MB of a 128-frame step,
 // ~1.3 TB/s), then every thread walks its row in LDS (row pitch C: odd pitches are conflict-free, even ones two-way)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 argmax_rows_lds(const float* __restrict__ scores, int64_t n, int C, uint8_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float tile[256 * 32];
-    const int64_t r0 = (int64_t)blockIdx.x * 256;
-    const int rows = (int)((n - r0) < 256 ? (n - r0) : 256);
+    // (64 rows per workgroup, <= 8 KB of LDS: the kernel runs on the post stream beside the forward's LDS-heavy kernels, and a 32 KB
+    //  workgroup waited for room -- 1.3 ms per launch in step against 0.09 ms alone)
+    __shared__ __attribute__((aligned(16))) float tile[64 * 32];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((n - r0) < 64 ? (n - r0) : 64);
     const int64_t f0 = r0 * C;                                   // first float of the tile
     const int total = rows * C;
     const float* src = scores + f0;
     const int mis = (int)(f0 & 3);                               // floats before the first 16-byte boundary of the tile's run
     const int head = mis ? 4 - mis : 0;
-    for (int e = threadIdx.x; e < head && e < total; e += 256) tile[e] = src[e];
+    for (int e = threadIdx.x; e < head && e < total; e += 64) tile[e] = src[e];
     const int n4 = total > head ? (total - head) / 4 : 0;
     const float4* s4 = reinterpret_cast<const float4*>(src + head);
-    for (int q = threadIdx.x; q < n4; q += 256) {
+    for (int q = threadIdx.x; q < n4; q += 64) {
         const float4 v = s4[q];
         float* d = tile + head + 4 * q;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    for (int e = head + 4 * n4 + threadIdx.x; e < total; e += 256) tile[e] = src[e];
+    for (int e = head + 4 * n4 + threadIdx.x; e < total; e += 64) tile[e] = src[e];
     __syncthreads();
     if ((int)threadIdx.x >= rows) return;
     const float* row = tile + threadIdx.x * C;
@@ -752,12 +754,16 @@ argmax_rows_lds(const float* __restrict__ scores, int64_t n, int C, uint8_t* __r
 
 }  // namespace ml3d
 
+#ifndef ML3D_ARGMAX_LDS
+#define ML3D_ARGMAX_LDS 1      // A/B switch (build time): 0 = one thread per row reading its 76-byte-strided scalars
+#endif
+
 extern "C" int ml3d_argmax_labels(const float* scores, int64_t n, int num_classes, uint8_t* out_labels, void* stream) {
     if (n < 0 || num_classes <= 0 || num_classes > 256) return ML3D_E_INVALID;
     if (n == 0) return 0;
     if (!scores || !out_labels) return ML3D_E_INVALID;
-    if (num_classes <= 32 && (((uintptr_t)scores) & 15) == 0)
-        hipLaunchKernelGGL(argmax_rows_lds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, n, num_classes,
+    if ((ML3D_ARGMAX_LDS) && num_classes <= 32 && (((uintptr_t)scores) & 15) == 0)
+        hipLaunchKernelGGL(argmax_rows_lds, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, scores, n, num_classes,
                            out_labels);
     else
         hipLaunchKernelGGL(argmax_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, n, num_classes,
