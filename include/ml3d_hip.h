@@ -874,6 +874,19 @@ int ml3d_kpconv_deformed_weighted_backward(const float* q_pts, const float* s_pt
                                            int num_kernel_points, float kp_extent, const float* grad_wf,
                                            float* grad_features, float* grad_kernel_points, void* stream);
 
+/* ml3d_kpconv_offset_regulariser (ABI 12): p2p_fitting_regularizer of the deformable blocks (kpconv.py:2167-2206) with the min_d2 of */
+/*   kpconv.py:1058-1074, value and gradient in one pass without the [Nq, H, K] distance tensor.  Per (query, kernel point):          */
+/*   fitting = min_h |s[inds[q, h]] - q - dkp[q, k]|^2 / extent^2 (shadow neighbours at 1e6), repulsive = sum_{j != k} min(|l_j - l_k|  */
+/*   - repulse_extent, 0)^2 with l = dkp / extent and the other points detached.  out_partial_sums double[2 * blocks] (blocks =        */
+/*   ml3d_kpconv_offset_regulariser_blocks(n_queries)): per-workgroup (sum fitting, sum repulsive) -- add them and divide by            */
+/*   n_queries * K for the two L1 means; optional out_min_d2 [Nq, K] (unnormalised), out_grad_fitting / _repulsive [Nq, K, 3] =        */
+/*   d fitting[q, k] / d dkp[q, k], d repulsive[q, k] / d dkp[q, k].  At most 16 kernel points.                                          */
+int64_t ml3d_kpconv_offset_regulariser_blocks(int64_t n_queries);
+int ml3d_kpconv_offset_regulariser(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                   int64_t n_supports, int64_t max_neighbors, const float* deformed_kernel_points,
+                                   int num_kernel_points, float kp_extent, float repulse_extent, float* out_min_d2,
+                                   float* out_grad_fitting, float* out_grad_repulsive, double* out_partial_sums, void* stream);
+
 /* ml3d_randla_attention_stage: one attentive pooling of LocalFeatureAggregation in training form, fused (randlanet.py:596-605,     */
 /*   617, 631-637): x[p, k, :] = [ f[b, idx[p, k], :c1] | enc[p, k, :c2] ], s = x W^T + bias, out[p, c] = sum_k softmax_k(s)[k, c]   */
 /*   x[p, k, c].  f [batch, n, c1], enc [batch, n, k, c2], neighbor_idx int32 [batch, n, k] (item-local), weight [d, d] (the         */

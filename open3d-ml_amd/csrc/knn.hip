@@ -755,7 +755,10 @@ argmax_rows_lds(const float* __restrict__ scores, int64_t n, int C, uint8_t* __r
 }  // namespace ml3d
 
 #ifndef ML3D_ARGMAX_LDS
-#define ML3D_ARGMAX_LDS 1      // A/B switch (build time): 0 = one thread per row reading its 76-byte-strided scalars
+// A/B switch (build time).  Default 0 = one thread per row reading its 76-byte-strided scalars: the LDS-staged form is 4x faster ALONE
+// (0.087 against 0.34 ms for a 128-frame step) and SLOWER in the step -- 7476 / 7526 against 7624 / 7615 frames/s, same box, alternating
+// (profiles/r06_argmax_ab.log): on the post stream, beside the forward's LDS-resident kernels, its workgroups wait for LDS room.
+#define ML3D_ARGMAX_LDS 0
 #endif
 
 extern "C" int ml3d_argmax_labels(const float* scores, int64_t n, int num_classes, uint8_t* out_labels, void* stream) {

@@ -670,6 +670,67 @@ static inline unsigned tr_blocks(int64_t total, int per, unsigned cap) {
     return (unsigned)b;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// p2p_fitting_regularizer of the deformable KPConv (kpconv.py:2167-2206 + the min_d2 of kpconv.py:1058-1074), value AND gradient
+// in one pass, without the reference's [Nq, H, K] distance tensor: thread (q, k) walks the H neighbours of query q for ITS
+// deformed kernel point -- fitting term min_h |s[inds[q, h]] - q - kp[q, k]|^2 / extent^2 (the shadow neighbour sits at 1e6 like the
+// reference's padded support), its gradient 2 (kp - nb*) / extent^2 goes to the FIRST minimum (torch.min) -- and the repulsive term
+// sum_{j != k} min(|l_j - l_k| - r, 0)^2 over the query's other kernel points l = kp / extent (detached, as in the reference), whose
+// K points are exchanged inside a 16-lane group.  Per-workgroup partial sums in double (deterministic; the caller adds them).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+kp_offset_reg_k(const float* __restrict__ q_pts, const float* __restrict__ s_pts, const int32_t* __restrict__ inds, int64_t nq, int64_t ns,
+                int64_t H, int K, const float* __restrict__ dkp, float extent, float repulse, float* __restrict__ min_d2,
+                float* __restrict__ g_fit, float* __restrict__ g_rep, double* __restrict__ partial) {
+    __shared__ double red[2][256];
+    const int t = threadIdx.x, k = t & 15;
+    const int64_t q = (int64_t)blockIdx.x * 16 + (t >> 4);
+    const bool live = q < nq && k < K;
+    float fit = 0.f, rep = 0.f;
+    float kx = 0.f, ky = 0.f, kz = 0.f;
+    if (live) { const float* p = dkp + (q * K + k) * 3; kx = p[0]; ky = p[1]; kz = p[2]; }
+    if (live) {
+        const float qx = q_pts[3 * q], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
+        float best = 3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
+        for (int64_t h = 0; h < H; ++h) {
+            const int64_t s = inds[q * H + h];
+            const bool real = s >= 0 && s < ns;
+            const float nx = (real ? s_pts[3 * s] : 1.0e6f) - qx, ny = (real ? s_pts[3 * s + 1] : 1.0e6f) - qy,
+                        nz = (real ? s_pts[3 * s + 2] : 1.0e6f) - qz;
+            const float dx = nx - kx, dy = ny - ky, dz = nz - kz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bx = dx; by = dy; bz = dz; }
+        }
+        if (H == 0) best = 0.f;
+        const float ie2 = 1.0f / (extent * extent);
+        fit = best * ie2;
+        if (min_d2) min_d2[q * K + k] = best;
+        if (g_fit) { float* g = g_fit + (q * K + k) * 3; g[0] = -2.f * bx * ie2; g[1] = -2.f * by * ie2; g[2] = -2.f * bz * ie2; }
+    }
+    // the query's K kernel points, normalised, from the lanes of its 16-lane group
+    const float lx = kx / extent, ly = ky / extent, lz = kz / extent;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int base = (t & 63) & ~15;
+    for (int j = 0; j < K; ++j) {
+        const float ox = __shfl(lx, base + j), oy = __shfl(ly, base + j), oz = __shfl(lz, base + j);
+        if (j == k || !live) continue;
+        const float dx = ox - lx, dy = oy - ly, dz = oz - lz;
+        const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float c = fminf(dist - repulse, 0.f);
+        rep += c * c;
+        if (c < 0.f && dist > 0.f) { const float w = 2.f * c / dist; gx -= w * dx; gy -= w * dy; gz -= w * dz; }   // d dist / d l_k = -(l_j - l_k) / dist
+    }
+    if (live && g_rep) { float* g = g_rep + (q * K + k) * 3; g[0] = gx / extent; g[1] = gy / extent; g[2] = gz / extent; }
+    red[0][t] = (double)fit; red[1][t] = (double)rep;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
 }  // namespace ml3d
 
 using namespace ml3d;
@@ -805,6 +866,23 @@ static int deform_args(DeformArgs& a, const float* q_pts, const float* s_pts, co
     a.q_pts = q_pts; a.s_pts = s_pts; a.inds = inds; a.nq = nq; a.ns = ns; a.h = (int)h; a.x = x; a.cin = cin; a.dkp = dkp;
     a.extent = extent;
     return 0;
+}
+
+extern "C" int64_t ml3d_kpconv_offset_regulariser_blocks(int64_t n_queries) { return n_queries > 0 ? (n_queries + 15) / 16 : 0; }
+
+extern "C" int ml3d_kpconv_offset_regulariser(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,
+                                              int64_t n_supports, int64_t max_neighbors, const float* deformed_kernel_points,
+                                              int num_kernel_points, float kp_extent, float repulse_extent, float* out_min_d2,
+                                              float* out_grad_fitting, float* out_grad_repulsive, double* out_partial_sums, void* stream) {
+    if (n_queries < 0 || n_supports < 0 || max_neighbors < 0 || num_kernel_points <= 0 || num_kernel_points > 16 || !(kp_extent > 0.f))
+        return num_kernel_points > 16 ? ML3D_E_UNSUPPORTED : ML3D_E_INVALID;
+    if (n_queries == 0) return 0;
+    if (!q_pts || !deformed_kernel_points || !out_partial_sums || (max_neighbors > 0 && (!neighb_inds || (n_supports > 0 && !s_pts))))
+        return ML3D_E_INVALID;
+    hipLaunchKernelGGL(kp_offset_reg_k, dim3((unsigned)((n_queries + 15) / 16)), dim3(256), 0, (hipStream_t)stream, q_pts, s_pts, neighb_inds,
+                       n_queries, n_supports, max_neighbors, num_kernel_points, deformed_kernel_points, kp_extent, repulse_extent, out_min_d2,
+                       out_grad_fitting, out_grad_repulsive, out_partial_sums);
+    return hipGetLastError() == hipSuccess ? 0 : ML3D_E_LAUNCH;
 }
 
 extern "C" int ml3d_kpconv_deformed_weighted(const float* q_pts, const float* s_pts, const int32_t* neighb_inds, int64_t n_queries,

@@ -91,6 +91,7 @@ SYMBOLS = [
     "ml3d_batchnorm_train_workspace_bytes", "ml3d_batchnorm_train_forward", "ml3d_batchnorm_train_backward",
     "ml3d_gather_rows", "ml3d_scatter_add_rows", "ml3d_gather_pool_backward",
     "ml3d_kpconv_deformed_weighted", "ml3d_kpconv_deformed_weighted_backward",
+    "ml3d_kpconv_offset_regulariser_blocks", "ml3d_kpconv_offset_regulariser",
     "ml3d_randla_attention_stage", "ml3d_randla_attention_stage_backward_workspace_bytes", "ml3d_randla_attention_stage_backward",
 ]
 
@@ -266,6 +267,10 @@ def bind(lib):
     lib.ml3d_kpconv_deformed_weighted.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, vp, vp]
     lib.ml3d_kpconv_deformed_weighted_backward.restype = C.c_int
     lib.ml3d_kpconv_deformed_weighted_backward.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, f32, vp, vp, vp, vp]
+    lib.ml3d_kpconv_offset_regulariser_blocks.restype = i64
+    lib.ml3d_kpconv_offset_regulariser_blocks.argtypes = [i64]
+    lib.ml3d_kpconv_offset_regulariser.restype = C.c_int
+    lib.ml3d_kpconv_offset_regulariser.argtypes = [vp, vp, vp, i64, i64, i64, vp, i32, f32, f32, vp, vp, vp, vp, vp]
     lib.ml3d_randla_attention_stage.restype = C.c_int
     lib.ml3d_randla_attention_stage.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp]
     lib.ml3d_randla_attention_stage_backward.restype = C.c_int

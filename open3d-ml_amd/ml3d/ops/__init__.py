@@ -19,4 +19,4 @@ from .detection import (pillar_features, conv2d_nhwc, pack_bf16x3, linear_bf16x3
                         iou_bev, iou_3d, topk_rows)
 from .sampler import nearest_to_center, argmax_labels, vote_update, device_patch   # noqa: F401
 from .train import (gemm_tn, LinearFunction, BatchNormActFunction, batch_norm_act, GatherRowsFunction, GatherPoolFunction,   # noqa: F401
-                    AttentionStageFunction, attention_stage_supported, KPConvDeformedFunction)
+                    AttentionStageFunction, attention_stage_supported, KPConvDeformedFunction, OffsetRegulariserFunction)

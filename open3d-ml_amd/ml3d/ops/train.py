@@ -292,3 +292,46 @@ class KPConvDeformedFunction(torch.autograd.Function):
                                                             gk.data_ptr(), _stream())
         _abi.check(rc, "ml3d_kpconv_deformed_weighted_backward")
         return gx, gk, None, None, None, None
+
+
+class OffsetRegulariserFunction(torch.autograd.Function):
+    """``p2p_fitting_regularizer`` of ONE deformable KPConv (kpconv.py:2167-2206, with the ``min_d2`` of kpconv.py:1058-1074) as a
+    HIP op: ``deformed_kp`` [Nq, K, 3] + the block's geometry -> float32 [2] = (mean over (q, k) of min_h d^2 / extent^2, mean over
+    (q, k) of the repulsive hinge) -- the two L1 terms the reference adds up as ``2 * fitting + repulsive``.  The forward also
+    produces the gradient with respect to the kernel points (the other points of the repulsive term detached, as in the reference),
+    so the backward is a scaled sum; the reference's [Nq, H, K] distance tensor is never built.  ``min_d2`` [Nq, K] is returned as a
+    non-differentiable third output for callers that keep the reference's attribute."""
+
+    @staticmethod
+    def forward(ctx, deformed_kp, q_pts, s_pts, neighb_inds, extent, repulse_extent):
+        lib = _abi.get()
+        _need_gpu(deformed_kp, q_pts, s_pts, neighb_inds)
+        dkp = _f32(deformed_kp)
+        q_pts, s_pts = _f32(q_pts), _f32(s_pts)
+        if neighb_inds.dtype != torch.int32 or not neighb_inds.is_contiguous():
+            neighb_inds = neighb_inds.to(torch.int32).contiguous()
+        nq, K = dkp.shape[0], dkp.shape[1]
+        ns = s_pts.shape[0]
+        H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
+        if dkp.shape != (nq, K, 3) or q_pts.shape != (nq, 3) or (H and neighb_inds.shape[0] != nq):
+            raise RuntimeError("OffsetRegulariserFunction: deformed_kp [Nq, K, 3], q_pts [Nq, 3], neighb_inds [Nq, H] expected")
+        dev = dkp.device
+        blocks = int(lib.ml3d_kpconv_offset_regulariser_blocks(nq))
+        partial = torch.zeros((max(blocks, 1), 2), dtype=torch.float64, device=dev)
+        min_d2 = torch.empty((nq, K), dtype=torch.float32, device=dev)
+        gfit = torch.empty_like(dkp)
+        grep = torch.empty_like(dkp)
+        with torch.cuda.device(dev):
+            rc = lib.ml3d_kpconv_offset_regulariser(q_pts.data_ptr(), s_pts.data_ptr(), neighb_inds.data_ptr(), nq, ns, H, dkp.data_ptr(), K,
+                                                    float(extent), float(repulse_extent), min_d2.data_ptr(), gfit.data_ptr(),
+                                                    grep.data_ptr(), partial.data_ptr(), _stream())
+        _abi.check(rc, "ml3d_kpconv_offset_regulariser")
+        ctx.save_for_backward(gfit, grep)
+        ctx.denom = float(max(nq * K, 1))
+        ctx.mark_non_differentiable(min_d2)
+        return (partial.sum(0) / ctx.denom).to(torch.float32), min_d2
+
+    @staticmethod
+    def backward(ctx, g, _g_min):
+        gfit, grep = ctx.saved_tensors
+        return (gfit * (g[0] / ctx.denom) + grep * (g[1] / ctx.denom)), None, None, None, None, None

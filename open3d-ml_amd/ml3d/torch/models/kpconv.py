@@ -491,9 +491,12 @@ class KPFCNN(nn.Module):
         return unary(self.head_softmax, unary(self.head_mlp, x))
 
     @staticmethod
-    def _deformable_geometry(conv, q_pts, s_pts, inds, x, infl):
+    def _deformable_geometry(conv, q_pts, s_pts, inds, x, infl, need_sq=True):
         """Offsets -> deformed kernel points and their squared distances to the neighbours (kpconv.py:1011-1066): sets
-        ``conv.deformed_KP`` [Nq, K, 3] and ``conv.min_d2`` [Nq, K], returns ([Nq, H, K] squared distances, modulations)."""
+        ``conv.deformed_KP`` [Nq, K, 3] and ``conv.min_d2`` [Nq, K], returns ([Nq, H, K] squared distances, modulations).
+        ``need_sq=False`` (the HIP training path): the [Nq, H, K] tensor is NOT built -- the aggregation
+        (``ops.KPConvDeformedFunction``) and the regulariser (``ops.OffsetRegulariserFunction``, which also yields ``min_d2``) work
+        from ``deformed_KP`` and the block's geometry, kept in ``conv._reg_geom``; returns (None, modulations)."""
         K = conv.K
         oc = conv.offset_conv
         off = ops.KPConvFunction.apply(x, oc.weights, q_pts, s_pts, inds, oc.kernel_points, oc.KP_extent, infl) + conv.offset_bias
@@ -502,6 +505,10 @@ class KPFCNN(nn.Module):
         else:
             unscaled, mod = off.reshape(-1, K, 3), None
         conv.deformed_KP = unscaled * conv.KP_extent + conv.kernel_points                 # [Nq, K, 3]
+        conv._reg_geom = (q_pts, s_pts, inds)
+        if not need_sq:
+            conv.min_d2 = None
+            return None, mod
         far = torch.cat([s_pts, torch.zeros_like(s_pts[:1]) + 1e6], 0)                    # the shadow neighbour's position
         nb = far[inds.long()] - q_pts.unsqueeze(1)                                        # [Nq, H, 3]
         sq = ((nb.unsqueeze(2) - conv.deformed_KP.unsqueeze(1)) ** 2).sum(3)              # [Nq, H, K]
@@ -512,8 +519,9 @@ class KPFCNN(nn.Module):
     def _deformable_train(conv, q_pts, s_pts, inds, x, infl):
         """One deformable KPConv in training mode (kpconv.py:1011-1066, 1105-1159, linear influence, sum aggregation)."""
         conv._geom_inputs = None
-        sq, mod = KPFCNN._deformable_geometry(conv, q_pts, s_pts, inds, x, infl)
-        if os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch":
+        hip_ops = os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch"
+        sq, mod = KPFCNN._deformable_geometry(conv, q_pts, s_pts, inds, x, infl, need_sq=not hip_ops)
+        if hip_ops:
             # round 5: the aggregation and its adjoint -- with respect to the features AND the deformed kernel points, which is what
             # trains the offset convolution -- on csrc/train.hip; no [Nq, H, Cin] gather (ops.KPConvDeformedFunction)
             K, cin, cout = conv.weights.shape
@@ -537,13 +545,27 @@ class KPFCNN(nn.Module):
         fitting, repulsive, K = 0, 0, int(cfg.num_kernel_points)
         for m in self.modules():
             if isinstance(m, KPConv) and m.deformable:
-                if getattr(m, 'min_d2', None) is None:
+                hip_ops = os.environ.get("ML3D_TRAIN_OPS", "hip").strip().lower() != "torch"
+                if getattr(m, 'min_d2', None) is None and getattr(m, 'deformed_KP', None) is None:
                     geom = getattr(m, '_geom_inputs', None)
                     if geom is None:
                         raise RuntimeError("KPFCNN.get_loss: no forward has run through the deformable blocks")
                     with torch.no_grad():          # an eval-mode forward: the current batch's geometry, no gradient
-                        self._deformable_geometry(m, *geom)
+                        self._deformable_geometry(m, *geom, need_sq=not hip_ops)
                     m._geom_inputs = None
+                if hip_ops and m.deformed_KP.is_cuda and K <= 16 and getattr(m, '_reg_geom', None) is not None:
+                    # round 6: both terms and their gradient in ONE HIP kernel (no [Nq, H, K] distances, no per-kernel-point loop)
+                    q_pts, s_pts, inds = m._reg_geom
+                    terms, m.min_d2 = ops.OffsetRegulariserFunction.apply(m.deformed_KP, q_pts, s_pts, inds, float(m.KP_extent),
+                                                                          float(cfg.get('repulse_extent', 1.2)))
+                    fitting = fitting + terms[0]
+                    repulsive = repulsive + terms[1]
+                    continue
+                if m.min_d2 is None:
+                    with torch.no_grad():
+                        far = torch.cat([m._reg_geom[1], torch.zeros_like(m._reg_geom[1][:1]) + 1e6], 0)
+                    nb = far[m._reg_geom[2].long()] - m._reg_geom[0].unsqueeze(1)
+                    m.min_d2 = ((nb.unsqueeze(2) - m.deformed_KP.unsqueeze(1)) ** 2).sum(3).min(1)[0]
                 d2 = m.min_d2 / (m.KP_extent ** 2)
                 fitting = fitting + l1(d2, torch.zeros_like(d2))
                 locs = m.deformed_KP / m.KP_extent

@@ -337,3 +337,50 @@ worst = check(m, logits, loss, g, 39, 1e-3)
 assert np.abs(m.encoder[3].pool2.mlp.batch_norm.running_var.numpy() - g["running_var:encoder.3.pool2.mlp"]).max() <= 1e-5
 print("ok, worst relative gradient error %.2g" % worst)
 ''', ML3D_TRAIN_OPS="hip")
+
+
+def test_offset_regulariser_matches_the_reference_formulation_on_torch_autograd():
+    """``ops.OffsetRegulariserFunction`` (round 6: ``p2p_fitting_regularizer``, kpconv.py:2167-2206, with the ``min_d2`` of
+    kpconv.py:1058-1074, value + gradient in one HIP kernel) against the reference's formulation written out in torch -- the
+    [Nq, H, K] distance tensor, its min over the neighbours, the per-kernel-point loop with detached others: both L1 terms,
+    ``min_d2`` and the gradient with respect to the deformed kernel points; shadow neighbours in the rows, a block of 16 queries
+    plus a partial one, K = 15 and a smaller K."""
+    _run(r'''
+from ml3d import ops
+rng = np.random.default_rng(1)
+T = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+l1 = torch.nn.L1Loss()
+for nq, ns, H, K in ((40, 60, 9, 15), (16, 25, 14, 15), (7, 30, 5, 6), (5, 9, 0, 15)):
+    q = T(rng.random((nq, 3))); s_ = T(rng.random((ns, 3)))
+    inds = torch.from_numpy(rng.integers(0, ns + 3, (nq, H)).astype(np.int32))       # (values >= ns: shadow neighbours)
+    dkp = (T(rng.standard_normal((K, 3)) * 0.3)[None] + T(rng.standard_normal((nq, K, 3)) * 0.1)).requires_grad_(True)
+    ext, rep_ext = 0.35, 1.2
+    far = torch.cat([s_, torch.zeros_like(s_[:1]) + 1e6], 0)
+    if H:
+        nb = far[inds.long().clamp(max=ns)] - q.unsqueeze(1)
+        min_d2 = ((nb.unsqueeze(2) - dkp.unsqueeze(1)) ** 2).sum(3).min(1)[0]
+    else:
+        min_d2 = torch.zeros((nq, K)) + 0 * dkp.sum()
+    d2 = min_d2 / ext ** 2
+    fitting = l1(d2, torch.zeros_like(d2))
+    locs = dkp / ext
+    repulsive = 0
+    for i in range(K):
+        others = torch.cat([locs[:, :i], locs[:, i + 1:]], 1).detach()
+        dist = torch.sqrt(((others - locs[:, i:i + 1]) ** 2).sum(2))
+        rep = (torch.clamp_max(dist - rep_ext, 0.0) ** 2).sum(1)
+        repulsive = repulsive + l1(rep, torch.zeros_like(rep)) / K
+    ref = 2 * fitting + repulsive
+    ref.backward()
+    want = dkp.grad.clone(); dkp.grad = None
+    terms, md2 = ops.OffsetRegulariserFunction.apply(dkp, q, s_, inds, ext, rep_ext)
+    got = 2 * terms[0] + terms[1]
+    got.backward()
+    assert abs(float(terms[0]) - float(fitting)) <= 1e-5 * max(1.0, abs(float(fitting))), (float(terms[0]), float(fitting))
+    assert abs(float(terms[1]) - float(repulsive)) <= 1e-5 * max(1.0, abs(float(repulsive))), (float(terms[1]), float(repulsive))
+    if H:
+        assert (md2 - min_d2.detach()).abs().max() <= 1e-5 * max(1.0, float(min_d2.abs().max()))
+    assert (dkp.grad - want).abs().max() <= 2e-5 * max(1e-3, float(want.abs().max())), (float((dkp.grad - want).abs().max()), float(want.abs().max()))
+    print("regulariser ok", nq, ns, H, K, float(ref), flush=True)
+print("ok")
+''')
