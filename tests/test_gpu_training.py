@@ -408,3 +408,37 @@ def test_randlanet_with_the_semantickitti_widths_matches_the_reference(golden_di
             checked += 1
     assert checked == 39
     assert np.abs(m.encoder[3].pool2.mlp.batch_norm.running_var.cpu().numpy() - g["running_var:encoder.3.pool2.mlp"]).max() <= 1e-5
+
+
+def test_offset_regulariser_matches_the_reference_formulation_on_torch_autograd():
+    """``ops.OffsetRegulariserFunction`` on the hardware (wave shuffles inside 16-lane groups, the block reduction) against the
+    reference's formulation of ``p2p_fitting_regularizer`` (kpconv.py:2167-2206) + ``min_d2`` (kpconv.py:1058-1074) on torch's
+    autograd: both L1 terms, ``min_d2``, the gradient of the deformed kernel points."""
+    from ml3d import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    l1 = torch.nn.L1Loss()
+    for nq, ns, H, K in ((4000, 6000, 33, 15), (16, 25, 14, 15), (7, 30, 5, 6)):
+        q = torch.rand((nq, 3), device="cuda", generator=g); s_ = torch.rand((ns, 3), device="cuda", generator=g)
+        inds = torch.randint(0, ns + 3, (nq, H), device="cuda", generator=g).to(torch.int32)
+        dkp = (torch.randn((1, K, 3), device="cuda", generator=g) * 0.3 + torch.randn((nq, K, 3), device="cuda", generator=g) * 0.1).requires_grad_(True)
+        ext, rep_ext = 0.35, 1.2
+        far = torch.cat([s_, torch.zeros_like(s_[:1]) + 1e6], 0)
+        nb = far[inds.long().clamp(max=ns)] - q.unsqueeze(1)
+        min_d2 = ((nb.unsqueeze(2) - dkp.unsqueeze(1)) ** 2).sum(3).min(1)[0]
+        d2 = min_d2 / ext ** 2
+        fitting = l1(d2, torch.zeros_like(d2))
+        locs = dkp / ext
+        repulsive = 0
+        for i in range(K):
+            others = torch.cat([locs[:, :i], locs[:, i + 1:]], 1).detach()
+            dist = torch.sqrt(((others - locs[:, i:i + 1]) ** 2).sum(2))
+            rep = (torch.clamp_max(dist - rep_ext, 0.0) ** 2).sum(1)
+            repulsive = repulsive + l1(rep, torch.zeros_like(rep)) / K
+        (2 * fitting + repulsive).backward()
+        want = dkp.grad.clone(); dkp.grad = None
+        terms, md2 = ops.OffsetRegulariserFunction.apply(dkp, q, s_, inds, ext, rep_ext)
+        (2 * terms[0] + terms[1]).backward()
+        assert abs(float(terms[0]) - float(fitting)) <= 2e-5 * max(1.0, abs(float(fitting)))
+        assert abs(float(terms[1]) - float(repulsive)) <= 2e-5 * max(1.0, abs(float(repulsive)))
+        assert _close(md2, min_d2.detach(), 1e-5)
+        assert float((dkp.grad - want).abs().max()) <= 5e-5 * max(1e-3, float(want.abs().max())), (nq, float((dkp.grad - want).abs().max()), float(want.abs().max()))
