@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(256) pillar_pfn(PfnArgs A) {
         for (int c = 0; c < PF_MAXC; ++c) wcol[c] = c < DC ? A.wt[c * A.units + u] : 0.f;
         const float b = A.bias[u];
         float vmax = -3.0e38f;
-        for (int j = 0; j < A.P; ++j) {
+        // only the pillar's REAL points are multiplied (a KITTI pillar holds ~2-5 of its 32 rows): a masked row is all zeros
+        // (point_pillars.py:546-549), its fma chain returns the bias bit for bit, so it contributes relu(bias) to the maximum
+        const int nreal = np < A.P ? np : A.P;
+        for (int j = 0; j < nreal; ++j) {
             const float* d = D[w][j];
             float v = b;
 #pragma unroll
@@ -113,6 +116,11 @@ __global__ void __launch_bounds__(256) pillar_pfn(PfnArgs A) {
             v = v > 0.f ? v : 0.f;
             vmax = v > vmax ? v : vmax;
             if (!A.last) A.xcat[(m * A.P + j) * (2 * A.units) + u] = v;
+        }
+        if (nreal < A.P) {
+            const float vb = b > 0.f ? b : 0.f;
+            vmax = vb > vmax ? vb : vmax;
+            if (!A.last) for (int j = nreal; j < A.P; ++j) A.xcat[(m * A.P + j) * (2 * A.units) + u] = vb;
         }
         if (A.last) {
             A.canvas[(((int64_t)sample * A.ny + cy) * A.nx + cx) * A.canvas_c + u] = vmax;
