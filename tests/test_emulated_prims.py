@@ -488,3 +488,31 @@ def test_subsample_per_item_kernel_reports_what_it_cannot_take():
     wide = synth_data.uniform_cloud(2, 4000)   # 10 x 10 x 2 m at 0.02 m: 500 * 500 * 100 cells
     assert emu.subsample_items(wide, [4000], 0.02)[2] == 2
     assert emu.subsample_items(np.concatenate([wide, wide]), [4000, 4000], 0.5)[2] == 0
+
+
+@pytest.mark.parametrize("max_points,max_voxels", [(2**62, 2**62), (32, 2**62), (32, 40)])
+def test_voxelize_bitmap_path_orders_long_runs_like_the_oracle(max_points, max_voxels):
+    """Round 6: the grid of the caller's range is small enough for the bitmap path (occupancy bits -> popcount ranks -> atomic grouping
+    -> runs put back into original point order).  Pillars with 1 point, with a few, with more than the in-thread sort takes (> 32),
+    with more than the LDS buffer of the long-run kernel takes (> 4096: ordered re-scan of the item), points outside the range, an
+    empty item -- coordinates, ragged point lists and batch splits identical to the oracle, for every truncation."""
+    rng = np.random.default_rng(21)
+    spread = rng.random((5000, 3), dtype=np.float32) * [69, 79, 3.9] + [0, -39.6, -3]
+    dense = rng.random((600, 3), dtype=np.float32) * [0.15, 0.15, 3.5] + [10.0, 0.0, -3]            # one pillar, 600 points
+    huge = rng.random((5000, 3), dtype=np.float32) * [0.15, 0.15, 3.5] + [20.005, 5.125, -3]           # one pillar, 5000 points
+    mid = rng.random((2000, 3), dtype=np.float32) * [1.2, 1.2, 3.5] + [30.0, -10.0, -3]              # ~60 pillars of ~35 points
+    out = rng.random((300, 3), dtype=np.float32) * 5 + [100, 100, 10]                                # outside the range
+    a = np.concatenate([spread, dense, huge, mid, out]).astype(np.float32)
+    a = a[rng.permutation(len(a))]
+    b = (rng.random((3000, 3), dtype=np.float32) * [69, 79, 3.9] + [0, -39.6, -3]).astype(np.float32)
+    pts = np.concatenate([a, b])
+    rs = [0, len(a), len(a), len(pts)]
+    vs, mn, mx = [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1]
+    c, pi, prs, bs = emu.voxelize(pts, rs, vs, mn, mx, max_points, max_voxels)
+    ref = oops.voxelize(pts, rs, vs, mn, mx, max_points, max_voxels)
+    assert np.array_equal(bs, ref.voxel_batch_splits)
+    assert np.array_equal(c, ref.voxel_coords)
+    assert np.array_equal(prs, ref.voxel_point_row_splits)
+    assert np.array_equal(pi, ref.voxel_point_indices)
+    if max_points > 5000:
+        assert np.diff(prs).max() >= 5000
