@@ -155,201 +155,8 @@ __global__ void vox_keys(const float* __restrict__ pts, int64_t stride, Segs S, 
     vals[i] = (uint32_t)i;
 }
 
-// ---- voxelize without a sort (round 6): bounded keys -> occupancy bitmap -> popcount ranks ------------------------------------------
-// The voxel keys of PointPillarsVoxelization are cells of the caller's range grid (batch x 214 272 for KITTI): when that grid has at
-// most DGV_MAX_WORDS * 32 cells the stable radix sort (4 passes x 5 launches over 12-byte pairs at 16 sweeps) is replaced by
-//   keys + bitmap   point -> 32-bit cell key (or "outside"), atomicOr of the cell's bit
-//   rank            ONE workgroup: popcount prefix of the bitmap words -> the voxel ordinal of a cell = words before + bits below, i.e.
-//                   voxels in ascending key order with no sort; first voxel of every batch item; number of voxels
-//   count           point -> its voxel ordinal, arrival slot = atomicAdd of the voxel's counter; the first arrival records the key
-//   scan            ONE workgroup, device-side length: counters -> first slots hp[v]
-//   scatter         point index -> vals[hp[v] + slot]
-//   order           arrival order -> ORIGINAL point order inside every voxel (the oracle's canonical order; max_points keeps the
-//                   FIRST points): runs of <= 32 by the voxel's thread (insertion sort in place), longer runs -- pillars next to the
-//                   sensor hold hundreds of points -- by one workgroup each: rank = number of smaller indices (runs <= 4096 in LDS),
-//                   beyond that an ordered re-scan of the item's points
-// after which hp / vals are exactly what the sort path leaves and the rest of the op (vox_counts, vox_fill) is shared: 11 launches
-// instead of 31 at the bench's size, 4-byte keys instead of 12-byte pairs.  Results identical bit for bit.
-constexpr int DGV_MAX_WORDS = 262144;       // 8.4 M cells (39 KITTI sweeps): what one workgroup ranks in ~20 us
-constexpr int DGV_SHORT = 32;
-constexpr int DGV_LDS_RUN = 4096;
-
-struct DgvWs {
-    uint32_t* ckey;      // [n] cell key of point i (0xffffffff: outside the range), then its voxel ordinal
-    uint32_t* slot;      // [n] arrival slot inside its voxel
-    uint32_t* vkey;      // [n] cell key of voxel ordinal v
-    uint32_t* bitmap;    // [DGV_MAX_WORDS]
-    int* wpre;           // [DGV_MAX_WORDS] voxels before this word
-    int* longl;          // [n / DGV_SHORT + 2]: [0] = number of long runs, then their voxel ordinals
-};
-
-static size_t dgv_ws_bytes(int64_t n) {
-    const size_t m = (size_t)(n > 0 ? n : 1);
-    return 3 * vx_align(4 * m) + 2 * vx_align(4 * (size_t)DGV_MAX_WORDS) + vx_align(4 * (m / DGV_SHORT + 4)) + 256;
-}
-static void dgv_carve(char* p, int64_t n, DgvWs* o) {
-    const size_t m = (size_t)(n > 0 ? n : 1);
-    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    o->ckey = (uint32_t*)p;   p += vx_align(4 * m);
-    o->slot = (uint32_t*)p;   p += vx_align(4 * m);
-    o->vkey = (uint32_t*)p;   p += vx_align(4 * m);
-    o->bitmap = (uint32_t*)p; p += vx_align(4 * (size_t)DGV_MAX_WORDS);
-    o->wpre = (int*)p;        p += vx_align(4 * (size_t)DGV_MAX_WORDS);
-    o->longl = (int*)p;
-}
-
-__global__ void __launch_bounds__(256)
-dgv_keys(const float* __restrict__ pts, int64_t stride, Segs S, int64_t n, VoxParams P, DgvWs D) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int s; int64_t local;
-    seg_locate(S, i, s, local);
-    const float* p = pts + stride * i;
-    bool ok = true;
-    long long c[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float v = p[a];
-        ok = ok && (v >= P.rmin[a]) && (v <= P.rmax[a]);
-        c[a] = (long long)__fdiv_rn(__fsub_rn(v, P.rmin[a]), P.vs[a]);
-    }
-    uint32_t key = 0xffffffffu;
-    if (ok) {
-        key = (uint32_t)((long long)s * P.cells + (c[0] + P.G[0] * (c[1] + P.G[1] * c[2])));
-        atomicOr(&D.bitmap[key >> 5], 1u << (key & 31u));
-    }
-    D.ckey[i] = key;
-}
-
-// exclusive prefix over the workgroup of one int per thread (1024 threads)
-__device__ __forceinline__ int dgv_block_exscan(int v, int* scan16, int& total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int incl = wave_inclusive_scan(v);
-    __syncthreads();
-    if (lane == 63) scan16[wv] = incl;
-    __syncthreads();
-    int carry = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const int s = scan16[w]; if (w < wv) carry += s; tot += s; }
-    total = tot;
-    return carry + incl - v;
-}
-
-__global__ void __launch_bounds__(1024)
-dgv_rank(DgvWs D, int words, long long cells, int batch, int64_t n, int* __restrict__ fv, int* __restrict__ flags) {
-    __shared__ int scan16[16];
-    const int t = threadIdx.x;
-    const int per = (words + 1023) / 1024, w0 = t * per, w1 = min(words, w0 + per);
-    int sum = 0;
-    for (int w = w0; w < w1; ++w) sum += __popc(D.bitmap[w]);
-    int M, run = dgv_block_exscan(sum, scan16, M);
-    for (int w = w0; w < w1; ++w) { D.wpre[w] = run; run += __popc(D.bitmap[w]); }
-    __syncthreads();
-    // first voxel ordinal of every batch item = voxels whose key is below the item's first cell
-    for (int b = t; b <= batch; b += 1024) {
-        int r = M;
-        if (b < batch) {
-            const unsigned long long key = (unsigned long long)b * (unsigned long long)cells;
-            const int w = (int)(key >> 5);
-            r = w < words ? D.wpre[w] + __popc(D.bitmap[w] & ((1u << (unsigned)(key & 31ull)) - 1u)) : M;
-        }
-        fv[b] = r;
-    }
-    if (t == 0) { flags[n] = M; D.longl[0] = 0; }
-}
-
-__global__ void __launch_bounds__(256)
-dgv_count(DgvWs D, int64_t n, int* __restrict__ hp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = D.ckey[i];
-    if (key == 0xffffffffu) return;
-    const uint32_t w = key >> 5;
-    const int v = D.wpre[w] + __popc(D.bitmap[w] & ((1u << (key & 31u)) - 1u));
-    D.ckey[i] = (uint32_t)v;
-    const int sl = atomicAdd(&hp[v + 1], 1);
-    D.slot[i] = (uint32_t)sl;
-    if (sl == 0) D.vkey[v] = key;
-}
-
-// in-place inclusive scan of a[0 .. *len) by ONE workgroup (device-side length: the number of voxels)
-__global__ void __launch_bounds__(1024)
-dgv_scan(int* __restrict__ a, const int* __restrict__ len_ptr, int extra) {
-    __shared__ int scan16[16];
-    const int t = threadIdx.x, len = *len_ptr + extra;
-    const int per = (len + 1023) / 1024, i0 = t * per, i1 = min(len, i0 + per);
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += a[i];
-    int tot, run = dgv_block_exscan(sum, scan16, tot);
-    for (int i = i0; i < i1; ++i) { run += a[i]; a[i] = run; }
-}
-
-__global__ void __launch_bounds__(256)
-dgv_scatter(DgvWs D, int64_t n, const int* __restrict__ hp, uint32_t* __restrict__ vals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = D.ckey[i];
-    if (v == 0xffffffffu) return;
-    vals[hp[v] + (int)D.slot[i]] = (uint32_t)i;
-}
-
-// arrival order -> ascending point index inside every voxel (runs <= DGV_SHORT; longer ones are queued)
-__global__ void __launch_bounds__(256)
-dgv_order_short(DgvWs D, int64_t n, const int* __restrict__ flags, const int* __restrict__ hp, uint32_t* __restrict__ vals) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || v >= flags[n]) return;
-    const int h0 = hp[v], h1 = hp[v + 1], c = h1 - h0;
-    if (c <= 1) return;
-    if (c > DGV_SHORT) { D.longl[1 + atomicAdd(&D.longl[0], 1)] = (int)v; return; }
-    for (int i = h0 + 1; i < h1; ++i) {
-        const uint32_t x = vals[i];
-        int j = i - 1;
-        while (j >= h0 && vals[j] > x) { vals[j + 1] = vals[j]; --j; }
-        vals[j + 1] = x;
-    }
-}
-
-__global__ void __launch_bounds__(256)
-dgv_order_long(DgvWs D, Segs S, long long cells, const int* __restrict__ hp, uint32_t* __restrict__ vals) {
-    __shared__ uint32_t run[DGV_LDS_RUN];
-    __shared__ int wsum[4];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int n_long = D.longl[0];
-    for (int q = blockIdx.x; q < n_long; q += gridDim.x) {
-        const int v = D.longl[1 + q], h0 = hp[v], c = hp[v + 1] - h0;
-        if (c <= DGV_LDS_RUN) {
-            for (int e = t; e < c; e += 256) run[e] = vals[h0 + e];
-            __syncthreads();
-            for (int e = t; e < c; e += 256) {
-                const uint32_t x = run[e];
-                int r = 0;
-                for (int j = 0; j < c; ++j) r += run[j] < x ? 1 : 0;
-                vals[h0 + r] = x;
-            }
-            __syncthreads();
-        } else {
-            // a run longer than the LDS buffer: walk the item's points in order and take the members (ordered by construction)
-            const int b = (int)((unsigned long long)D.vkey[v] / (unsigned long long)cells);
-            const int64_t i0 = seg_begin_packed(S, b), i1 = i0 + seg_len(S, b);
-            int done = 0;
-            for (int64_t base = i0; base < i1; base += 256) {
-                const int64_t i = base + t;
-                const bool hit = i < i1 && D.ckey[i] == (uint32_t)v;
-                const unsigned long long m = __ballot(hit);
-                if (lane == 0) wsum[wv] = __popcll(m);
-                __syncthreads();
-                int before = 0, all = 0;
-                for (int w = 0; w < 4; ++w) { if (w < wv) before += wsum[w]; all += wsum[w]; }
-                if (hit) vals[h0 + done + before + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
-                done += all;
-                __syncthreads();
-            }
-        }
-    }
-}
-
 // kept points per voxel ordinal (0 for voxels beyond max_voxels of their batch item)
-__global__ void vox_counts(const u64* __restrict__ keys, const uint32_t* __restrict__ vkey, const int* __restrict__ flags, int64_t n,
+__global__ void vox_counts(const u64* __restrict__ keys, const int* __restrict__ flags, int64_t n,
                            const int* __restrict__ hp, const int* __restrict__ fv, VoxParams P, int* __restrict__ cnt) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v == 0) cnt[0] = 0;
@@ -357,7 +164,7 @@ __global__ void vox_counts(const u64* __restrict__ keys, const uint32_t* __restr
     const int nv = flags[n];
     if (v >= nv) { cnt[v + 1] = 0; return; }
     const int h = hp[v];
-    const int b = (int)((vkey ? (u64)vkey[v] : keys[h]) / (u64)P.cells);
+    const int b = (int)(keys[h] / (u64)P.cells);
     const long long rank = v - fv[b];
     long long c = hp[v + 1] - h;
     if (c > P.max_points) c = P.max_points;
@@ -379,7 +186,7 @@ __global__ void vox_batch_splits(const int* __restrict__ fv, int batch, long lon
     stats[1] = n > 0 ? (int64_t)cnt[flags[n]] : 0;
 }
 
-__global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restrict__ vkey, const uint32_t* __restrict__ vals, const int* __restrict__ flags,
+__global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restrict__ vals, const int* __restrict__ flags,
                          int64_t n, const int* __restrict__ hp, const int* __restrict__ fv, const int* __restrict__ cnt,
                          const int64_t* __restrict__ batch_splits, VoxParams P, int32_t* __restrict__ coords,
                          int64_t* __restrict__ pidx, int64_t* __restrict__ prs) {
@@ -387,7 +194,7 @@ __global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restric
     if (v == 0) prs[0] = 0;
     if (v >= n || v >= flags[n]) return;
     const int h = hp[v];
-    const u64 key = vkey ? (u64)vkey[v] : keys[h];
+    const u64 key = keys[h];
     const int b = (int)(key / (u64)P.cells);
     const long long rank = v - fv[b];
     if (rank >= P.max_voxels) return;
@@ -772,17 +579,9 @@ static int vox_params(const float* vs, const float* rmin, const float* rmax, int
 
 using namespace ml3d;
 
-#ifndef ML3D_VOXELIZE_DENSE
-#define ML3D_VOXELIZE_DENSE 1       // A/B switch (build time): 0 keeps the sort-based grouping for every grid
-#endif
-// the bitmap path takes grids of up to DGV_MAX_WORDS * 32 cells (host-known: count and fill decide alike)
-static bool vox_dense(const VoxParams& P, int64_t batch, int64_t n) {
-    return (ML3D_VOXELIZE_DENSE) && n > 0 && (double)P.cells * (double)batch <= (double)DGV_MAX_WORDS * 32.0;
-}
-
 extern "C" size_t ml3d_voxelize_workspace_bytes(int64_t n_points, int64_t batch) {
     if (n_points < 0 || batch <= 0) return 0;
-    return group_ws_bytes(n_points, batch) + dgv_ws_bytes(n_points);
+    return group_ws_bytes(n_points, batch);
 }
 
 extern "C" int ml3d_voxelize_count(const float* points, int64_t point_stride, const int64_t* row_splits, int64_t batch,
@@ -803,29 +602,6 @@ extern "C" int ml3d_voxelize_count(const float* points, int64_t point_stride, co
     const int64_t n = n_points;
     const unsigned nb = (unsigned)((n + 255) / 256);
     const u64 inval = (u64)batch * (u64)P.cells;
-    if (vox_dense(P, batch, n)) {
-        if (workspace_bytes < group_ws_bytes(n, batch) + dgv_ws_bytes(n)) return ML3D_E_WORKSPACE;
-        DgvWs D;
-        dgv_carve((char*)workspace + group_ws_bytes(n, batch), n, &D);
-        const int words = (int)(((u64)batch * (u64)P.cells + 31ull) / 32ull);
-        zero_async(D.bitmap, 4 * (size_t)((words + 3) & ~3), st);
-        zero_async(W.hp, 4 * (size_t)((n + 2 + 3) & ~(int64_t)3), st);
-        hipLaunchKernelGGL(dgv_keys, dim3(nb), dim3(256), 0, st, points, point_stride, S, n, P, D);
-        hipLaunchKernelGGL(dgv_rank, dim3(1), dim3(1024), 0, st, D, words, (long long)P.cells, (int)batch, n, W.fv, W.flags);
-        hipLaunchKernelGGL(dgv_count, dim3(nb), dim3(256), 0, st, D, n, W.hp);
-        hipLaunchKernelGGL(dgv_scan, dim3(1), dim3(1024), 0, st, W.hp + 1, W.flags + n, 0);
-        hipLaunchKernelGGL(dgv_scatter, dim3(nb), dim3(256), 0, st, D, n, W.hp, W.vals);
-        hipLaunchKernelGGL(dgv_order_short, dim3(nb), dim3(256), 0, st, D, n, W.flags, W.hp, W.vals);
-        hipLaunchKernelGGL(dgv_order_long, dim3(512), dim3(256), 0, st, D, S, (long long)P.cells, W.hp, W.vals);
-        zero_async(W.cnt, 4 * (size_t)((n + 2 + 3) & ~(int64_t)3), st);
-        hipLaunchKernelGGL(vox_counts, dim3(nb), dim3(256), 0, st, (const u64*)nullptr, D.vkey, W.flags, n, W.hp, W.fv, P, W.cnt);
-        hipLaunchKernelGGL(dgv_scan, dim3(1), dim3(1024), 0, st, W.cnt + 1, W.flags + n, 0);
-        VX_CHECK();
-        hipLaunchKernelGGL(vox_batch_splits, dim3(1), dim3(64), 0, st, W.fv, (int)batch, P.max_voxels, W.cnt, W.flags, n,
-                           out_batch_splits, out_stats);
-        VX_CHECK();
-        return 0;
-    }
     if (n > 0) {
         hipLaunchKernelGGL(vox_keys, dim3(nb), dim3(256), 0, st, points, point_stride, S, n, P, W.keys, W.vals);
         VX_CHECK();
@@ -833,7 +609,7 @@ extern "C" int ml3d_voxelize_count(const float* points, int64_t point_stride, co
     rc = group_pairs(W, n, bits_for(inval), inval, (u64)P.cells, -1, st);
     if (rc) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(vox_counts, dim3(nb), dim3(256), 0, st, W.keys, (const uint32_t*)nullptr, W.flags, n, W.hp, W.fv, P, W.cnt);
+        hipLaunchKernelGGL(vox_counts, dim3(nb), dim3(256), 0, st, W.keys, W.flags, n, W.hp, W.fv, P, W.cnt);
         VX_CHECK();
         if (scan_inclusive_i32(W.cnt + 1, n, W.block_sums, st)) return ML3D_E_LAUNCH;
     }
@@ -859,14 +635,7 @@ extern "C" int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* 
         (void)hipMemsetAsync(out_point_row_splits, 0, sizeof(int64_t), st);
         return 0;
     }
-    const uint32_t* vkey = nullptr;
-    if (vox_dense(P, batch, n_points)) {
-        if (workspace_bytes < group_ws_bytes(n_points, batch) + dgv_ws_bytes(n_points)) return ML3D_E_WORKSPACE;
-        DgvWs D;
-        dgv_carve((char*)workspace + group_ws_bytes(n_points, batch), n_points, &D);
-        vkey = D.vkey;
-    }
-    hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, W.keys, vkey, W.vals, W.flags,
+    hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, W.keys, W.vals, W.flags,
                        n_points, W.hp, W.fv, W.cnt, batch_splits, P, out_voxel_coords, out_point_indices,
                        out_point_row_splits);
     VX_CHECK();

@@ -491,11 +491,11 @@ def test_subsample_per_item_kernel_reports_what_it_cannot_take():
 
 
 @pytest.mark.parametrize("max_points,max_voxels", [(2**62, 2**62), (32, 2**62), (32, 40)])
-def test_voxelize_bitmap_path_orders_long_runs_like_the_oracle(max_points, max_voxels):
-    """Round 6: the grid of the caller's range is small enough for the bitmap path (occupancy bits -> popcount ranks -> atomic grouping
-    -> runs put back into original point order).  Pillars with 1 point, with a few, with more than the in-thread sort takes (> 32),
-    with more than the LDS buffer of the long-run kernel takes (> 4096: ordered re-scan of the item), points outside the range, an
-    empty item -- coordinates, ragged point lists and batch splits identical to the oracle, for every truncation."""
+def test_voxelize_orders_long_runs_like_the_oracle(max_points, max_voxels):
+    """Pillars with 1 point, with a few, with tens, with hundreds and with thousands of points (the pillars next to the sensor), points
+    outside the range, an empty item -- coordinates, ragged point lists (original point order inside a pillar, the first max_points
+    kept) and batch splits identical to the oracle, for every truncation.  (Written for round 6's occupancy-bitmap grouping, which was
+    exact and SLOWER than the stable sort on exactly these pillars -- profiles/r06_voxelize_bitmap_ab.log -- and was removed.)"""
     rng = np.random.default_rng(21)
     spread = rng.random((5000, 3), dtype=np.float32) * [69, 79, 3.9] + [0, -39.6, -3]
     dense = rng.random((600, 3), dtype=np.float32) * [0.15, 0.15, 3.5] + [10.0, 0.0, -3]            # one pillar, 600 points
