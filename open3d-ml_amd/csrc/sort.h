@@ -25,6 +25,9 @@ size_t sort_ws_bytes(int64_t n);
 bool sort_ws_carve(void* ws, size_t bytes, int64_t n, SortWs* out);
 // Sorts ascending by the low `key_bits` bits of the key, stable.  The result is left in
 // (keys, vals); an odd number of passes is rounded up so no copy-back is needed.
-int sort_pairs_u64(u64* keys, uint32_t* vals, int64_t n, int key_bits, const SortWs& ws, hipStream_t stream);
+// allow_odd: an odd number of passes is NOT rounded up; the result then lies in (ws.keys_alt, ws.vals_alt) -- sort_result_in_alt(n,
+// key_bits) tells (a pure function of its arguments, so a later call that re-carves the same workspace finds the result again).
+int sort_pairs_u64(u64* keys, uint32_t* vals, int64_t n, int key_bits, const SortWs& ws, hipStream_t stream, bool allow_odd = false);
+bool sort_result_in_alt(int64_t n, int key_bits);
 
 }  // namespace ml3d

@@ -129,12 +129,19 @@ rs_scatter(const u64* __restrict__ kin, const uint32_t* __restrict__ vin, u64* _
     }
 }
 
-int sort_pairs_u64(u64* keys, uint32_t* vals, int64_t n, int key_bits, const SortWs& ws, hipStream_t stream) {
+bool sort_result_in_alt(int64_t n, int key_bits) {
+    if (n <= 1) return false;
+    if (key_bits < 1) key_bits = 1;
+    if (key_bits > 64) key_bits = 64;
+    return (((key_bits + 7) / 8) & 1) != 0;
+}
+
+int sort_pairs_u64(u64* keys, uint32_t* vals, int64_t n, int key_bits, const SortWs& ws, hipStream_t stream, bool allow_odd) {
     if (n <= 1) return 0;
     if (key_bits < 1) key_bits = 1;
     if (key_bits > 64) key_bits = 64;
     int passes = (key_bits + 7) / 8;
-    if (passes & 1) ++passes;   // even: the result lands back in (keys, vals)
+    if ((passes & 1) && !allow_odd) ++passes;   // even: the result lands back in (keys, vals)
     if (passes > 8) passes = 8;
     const int nb = (int)sort_blocks(n);
     const int64_t hist_n = 256 * (int64_t)nb;

@@ -537,11 +537,21 @@ __global__ void rotate_rows_k(const float* __restrict__ pts, Segs S, int64_t n, 
     } while (0)
 
 // sort the pairs, flag the heads, scan, record head positions, first voxel per item
-static int group_pairs(const GroupWs& W, int64_t n, int key_bits, u64 key_invalid, u64 item_stride, int item_shift,
+// (the sort may stop after an ODD number of passes -- voxelize: 22 key bits at 16 KITTI sweeps = 3 passes instead of 4 -- and leave its
+//  result in the alternate buffers: group_swap_if_alt points W.keys / W.vals there, in the count AND in the fill call)
+static void group_swap_if_alt(GroupWs& W, int64_t n, int key_bits) {
+    if (sort_result_in_alt(n, key_bits)) {
+        u64* k = W.keys; W.keys = W.sort.keys_alt; W.sort.keys_alt = k;
+        uint32_t* v = W.vals; W.vals = W.sort.vals_alt; W.sort.vals_alt = v;
+    }
+}
+
+static int group_pairs(GroupWs& W, int64_t n, int key_bits, u64 key_invalid, u64 item_stride, int item_shift,
                        hipStream_t st) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (n > 0) {
-        if (sort_pairs_u64(W.keys, W.vals, n, key_bits, W.sort, st)) return ML3D_E_LAUNCH;
+        if (sort_pairs_u64(W.keys, W.vals, n, key_bits, W.sort, st, true)) return ML3D_E_LAUNCH;
+        group_swap_if_alt(W, n, key_bits);
         hipLaunchKernelGGL(group_heads, dim3(nb), dim3(256), 0, st, W.keys, n, key_invalid, W.flags);
         VX_CHECK();
         if (scan_inclusive_i32(W.flags + 1, n, W.block_sums, st)) return ML3D_E_LAUNCH;
@@ -635,6 +645,7 @@ extern "C" int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* 
         (void)hipMemsetAsync(out_point_row_splits, 0, sizeof(int64_t), st);
         return 0;
     }
+    group_swap_if_alt(W, n_points, bits_for((u64)batch * (u64)P.cells));
     hipLaunchKernelGGL(vox_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, W.keys, W.vals, W.flags,
                        n_points, W.hp, W.fv, W.cnt, batch_splits, P, out_voxel_coords, out_point_indices,
                        out_point_row_splits);
@@ -685,6 +696,7 @@ extern "C" int ml3d_subsample_fill(const float* points, const float* features, i
     if (!points || !out_points) return ML3D_E_INVALID;
     GroupWs W;
     if (!group_ws_carve(workspace, workspace_bytes, n_points, batch, &W)) return ML3D_E_WORKSPACE;
+    group_swap_if_alt(W, n_points, SUB_ITEM_SHIFT + bits_for((u64)batch));
     hipLaunchKernelGGL(sub_fill, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W.vals,
                        W.flags, n_points, W.hp, points, features, feature_dim, labels, out_points, out_features,
                        out_labels);
