@@ -482,6 +482,15 @@ int ml3d_linear_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int
                        int64_t ldr, int n, int act, float slope, float* out, int64_t ldc,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ... and with a GATHERED residual (ABI 12): output row m adds residual[residual_gather[m * residual_gather_stride]] (global row     */
+/* index; rows outside [0, residual_rows) add nothing) -- the decoder step of KPFCNN split by linearity,                                */
+/* (x W_x)[up[:, 0]] + skip W_skip (NearestUpsampleBlock + torch.cat + UnaryBlock, kpconv.py:283-286, 821-838, 1468-1481).             */
+int ml3d_linear_bf16x3_gathered(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2,
+                                int64_t rows, const void* packed, const float* bias, const float* residual,
+                                int64_t ldr, const int32_t* residual_gather, int64_t residual_gather_stride,
+                                int64_t residual_rows, int n, int act, float slope, float* out, int64_t ldc,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 int ml3d_deconv2d_nhwc_bf16x3(const float* in, int64_t batch, int h, int w, int cin,
                               const void* packed, const float* bias, int stride, int act,
                               float slope, int cout, float* out, int64_t out_pixel_stride,

@@ -75,8 +75,8 @@ int gemm_conv(const ConvA& A, const float* Bm, int N, const Epilogue& ep, float*
 size_t gemm_pack_bf16x3_bytes(int K, int N);
 int gemm_pack_bf16x3(const float* Bm, int K, int N, void* packed, hipStream_t stream);
 bool gemm_conv_bf16x3_ok(const ConvA& A);
-// dense rows [a[M, k1] | a2[M, k2]] (each block float4-addressable, k1 and k1 + k2 multiples of 32, no gathered residual, else
-// ML3D_E_UNSUPPORTED): Linears, KPConv's contraction, kernel == stride deconvolutions.  Small-M / deep-K problems are split along K into partial_ws (gemm_partial_bytes_bf16x3 bytes; without it
+// dense rows [a[M, k1] | a2[M, k2]] (each block float4-addressable, k1 and k1 + k2 multiples of 32; a gathered residual needs
+// rg_rows_per_item >= 128; else ML3D_E_UNSUPPORTED): Linears, KPConv's contraction, kernel == stride deconvolutions.  Small-M / deep-K problems are split along K into partial_ws (gemm_partial_bytes_bf16x3 bytes; without it
 // the problem runs unsplit)
 size_t gemm_partial_bytes_bf16x3(int64_t M, int N, int K);
 int gemm_rows_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2, int64_t M, const void* packed,

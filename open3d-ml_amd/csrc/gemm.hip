@@ -437,14 +437,32 @@ __device__ __forceinline__ void tile2_epilogue(f32x16 (&acc)[RT][CT], const Epil
         }
         float b = ep.bias ? ep.bias[col] : 0.f;
         if (ep.bias2) b += ep.bias2[col];
+        // gathered residual (round 6: the decoder step split by linearity on the bf16 pipe as well): the tile's first row fixes the
+        // item with ONE scalar division; a 128-row tile crosses items at most once (the host checks rg_rows_per_item >= 128)
+        int64_t rg_base = 0, rg_l0 = 0;
+        if (ep.res_gather) {
+            const int64_t item0 = m0 / ep.rg_rows_per_item;
+            rg_l0 = m0 - item0 * ep.rg_rows_per_item;
+            rg_base = item0 * ep.rg_src_rows_per_item;
+        }
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + i * 32 + mfma32_row(r, hi);
+                const int lr = wr * 64 + i * 32 + mfma32_row(r, hi);
+                const int64_t m = m0 + lr;
                 if (m < M) {
                     float v = acc[i][j][r] + b;
-                    if (ep.residual) v += ep.residual[m * ep.ldr + col];
+                    if (ep.residual) {
+                        int64_t rr = m;
+                        bool take = true;
+                        if (ep.res_gather) {
+                            const int64_t g = ep.res_gather[ep.rg_stride ? m * ep.rg_stride : m];
+                            take = g >= 0 && g < ep.rg_limit;
+                            rr = rg_base + (rg_l0 + lr >= ep.rg_rows_per_item ? ep.rg_src_rows_per_item : 0) + g;
+                        }
+                        if (take) v += ep.residual[rr * ep.ldr + col];
+                    }
                     C[m * ldc + col] = gm_act(v, ep.act, ep.slope);
                 }
             }
@@ -1256,7 +1274,7 @@ int gemm_rows_bf16x3(const float* a, int64_t lda, int k1, const float* a2, int64
                      int N, const Epilogue& ep, float* C, int64_t ldc, void* partial_ws, size_t partial_bytes, hipStream_t st) {
     const int K = k1 + k2;
     if (!a || !packed || !C || N <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2) || M < 0) return ML3D_E_INVALID;
-    if (ep.res_gather || (K % BF_KC) != 0 || (k1 % BF_KC) != 0 || (lda & 3) != 0 || (((uintptr_t)a) & 15) != 0 ||
+    if ((ep.res_gather && ep.rg_rows_per_item < G2_BM) || (K % BF_KC) != 0 || (k1 % BF_KC) != 0 || (lda & 3) != 0 || (((uintptr_t)a) & 15) != 0 ||
         (k2 > 0 && ((lda2 & 3) != 0 || (((uintptr_t)a2) & 15) != 0)))
         return ML3D_E_UNSUPPORTED;
     if (M == 0) return 0;

@@ -351,6 +351,26 @@ extern "C" int ml3d_linear_bf16x3(const float* a, int64_t lda, int k1, const flo
     return gemm_rows_bf16x3(a, lda, k1, a2, lda2, k2, rows, packed, n, ep, out, ldc, p, avail, (hipStream_t)stream);
 }
 
+// the same with a GATHERED residual (ABI 12): residual row of output row m = residual_gather[m * stride] (a global row index; rows
+// outside [0, residual_rows) add nothing) -- KPFCNN's decoder step split by linearity, (x W_x)[up[:, 0]] + skip W_skip (kpconv.py:283-286)
+extern "C" int ml3d_linear_bf16x3_gathered(const float* a, int64_t lda, int k1, const float* a2, int64_t lda2, int k2, int64_t rows,
+                                           const void* packed, const float* bias, const float* residual, int64_t ldr,
+                                           const int32_t* residual_gather, int64_t residual_gather_stride, int64_t residual_rows, int n,
+                                           int act, float slope, float* out, int64_t ldc, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+    if (rows < 0 || k1 <= 0 || k2 < 0 || n <= 0 || lda < k1 || (k2 > 0 && (!a2 || lda2 < k2)) || ldc < n || !a || !packed || !out ||
+        act < 0 || act > 2 || (residual && ldr < n) || (residual_gather && (!residual || residual_gather_stride < 1 || residual_rows < 0)))
+        return ML3D_E_INVALID;
+    Epilogue ep = {bias, residual, ldr, act, slope, 0, 0, 0, 0};
+    if (residual_gather) {      // global row indices: one "item" spanning every row
+        ep.res_gather = residual_gather; ep.rg_rows_per_item = (int64_t)1 << 62; ep.rg_src_rows_per_item = 0;
+        ep.rg_stride = residual_gather_stride; ep.rg_limit = residual_rows;
+    }
+    char* p = workspace ? (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
+    const size_t avail = workspace && workspace_bytes > 256 ? workspace_bytes - 256 : 0;
+    return gemm_rows_bf16x3(a, lda, k1, a2, lda2, k2, rows, packed, n, ep, out, ldc, p, avail, (hipStream_t)stream);
+}
+
 extern "C" int ml3d_nhwc_to_nchw(const float* in, int64_t in_pixel_stride, int channel_offset, int channels,
                                  int64_t batch, int64_t hw, float* out, void* stream) {
     if (batch <= 0 || hw <= 0 || channels <= 0 || channel_offset < 0 || !in || !out ||

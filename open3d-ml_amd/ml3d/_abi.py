@@ -53,6 +53,7 @@ SYMBOLS = [
     "ml3d_gemm_pack_bf16x3",
     "ml3d_conv2d_nhwc_bf16x3",
     "ml3d_linear_bf16x3",
+    "ml3d_linear_bf16x3_gathered",
     "ml3d_linear_bf16x3_workspace_bytes",
     "ml3d_kpconv_rigid_bf16x3",
     "ml3d_deconv2d_nhwc_bf16x3",
@@ -205,6 +206,8 @@ def bind(lib):
     lib.ml3d_conv2d_nhwc_bf16x3.argtypes = [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp]
     lib.ml3d_linear_bf16x3.restype = C.c_int
     lib.ml3d_linear_bf16x3.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, vp, vp, i64, i32, i32, f32, vp, i64, vp, sz, vp]
+    lib.ml3d_linear_bf16x3_gathered.restype = C.c_int
+    lib.ml3d_linear_bf16x3_gathered.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp, i64, vp, sz, vp]
     lib.ml3d_linear_bf16x3_workspace_bytes.restype = sz
     lib.ml3d_linear_bf16x3_workspace_bytes.argtypes = [i64, i32, i32]
     lib.ml3d_deconv2d_nhwc_bf16x3.restype = C.c_int

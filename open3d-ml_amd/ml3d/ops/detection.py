@@ -96,11 +96,13 @@ def conv2d_nhwc(x, weights, bias, kh, kw, stride, pad, act=2, slope=0.0, out=Non
     return out
 
 
-def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0, a2=None, residual=None):
+def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0, a2=None, residual=None, residual_gather=None):
     """act([a | a2] @ W + bias + residual) on the bf16 matrix pipe, `packed` = pack_bf16x3(W [K, n]) (float32-equivalent: pack_bf16x3).
+    ``residual_gather``: int32 [M, H] neighbour matrix whose first column selects the ROW of ``residual`` added to output row m
+    (rows >= residual.shape[0], the shadow index, add nothing) -- as ``ops.linear``.
     Returns None when the problem is not eligible (block widths % 32, alignment): the caller keeps ops.linear."""
     lib = _abi.get()
-    _need_gpu(a, bias, a2, residual)
+    _need_gpu(a, bias, a2, residual, residual_gather)
     for t in (a, a2, residual):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise RuntimeError("linear_bf16x3: float32 contiguous rows required")
@@ -112,9 +114,18 @@ def linear_bf16x3(a, packed, n, bias=None, act=0, slope=0.0, a2=None, residual=N
     wsb = int(lib.ml3d_linear_bf16x3_workspace_bytes(m, int(n), k1 + k2))
     ws = _ws(wsb, a.device)
     with torch.cuda.device(a.device):
-        rc = lib.ml3d_linear_bf16x3(a.data_ptr(), k1, k1, None if a2 is None else a2.data_ptr(), k2, k2, m, packed.data_ptr(),
-                                    None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
-                                    int(n), int(n), int(act), float(slope), out.data_ptr(), int(n), ws.data_ptr(), wsb, _stream())
+        if residual_gather is not None:
+            if residual is None or residual_gather.dtype != torch.int32 or not residual_gather.is_contiguous() or residual_gather.shape[0] != m:
+                raise RuntimeError("linear_bf16x3: residual_gather must be a contiguous int32 [M, H] matrix next to a residual")
+            rg_stride = residual_gather.shape[1] if residual_gather.dim() == 2 else 1
+            rc = lib.ml3d_linear_bf16x3_gathered(a.data_ptr(), k1, k1, None if a2 is None else a2.data_ptr(), k2, k2, m, packed.data_ptr(),
+                                                 None if bias is None else bias.data_ptr(), residual.data_ptr(), int(n),
+                                                 residual_gather.data_ptr(), rg_stride, residual.shape[0], int(n), int(act), float(slope),
+                                                 out.data_ptr(), int(n), ws.data_ptr(), wsb, _stream())
+        else:
+            rc = lib.ml3d_linear_bf16x3(a.data_ptr(), k1, k1, None if a2 is None else a2.data_ptr(), k2, k2, m, packed.data_ptr(),
+                                        None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
+                                        int(n), int(n), int(act), float(slope), out.data_ptr(), int(n), ws.data_ptr(), wsb, _stream())
     if rc == _abi.E_UNSUPPORTED:
         return None
     _abi.check(rc, "ml3d_linear_bf16x3")

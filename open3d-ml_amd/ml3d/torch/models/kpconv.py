@@ -314,10 +314,32 @@ class KPFCNN(nn.Module):
         return self._packed[1]
 
     # ---- inference ------------------------------------------------------------------------------------------
+    # Linears whose K (rows of the weight block) reaches this run on the bf16 matrix pipe (gemm_tile_bf3: three-way split, float32-
+    # equivalent) -- the decoder's 384 .. 3072-deep steps and the deep unary / shortcut Linears are ~60 % of the forward's flops and
+    # sat on the f32 pipe because their gathered residual had no bf16x3 epilogue until round 6.  ML3D_KP_LINEAR_B3: the K threshold
+    # (0 = never: the A/B side), read when the module is imported.
+    _LIN_B3_MINK = int(os.environ.get("ML3D_KP_LINEAR_B3", "256") or 0)
+
+    @staticmethod
+    def _packed_block(p, lo, hi):
+        """bf16 planes of rows [lo, hi) of a packed Linear's weight (None: not eligible), built once per (block, slice)."""
+        key = ('pk', lo, hi)
+        if key not in p:
+            p[key] = ops.pack_bf16x3(p['wt'][lo:hi].contiguous()) if (hi - lo) % 32 == 0 else None
+        return p[key]
+
     @staticmethod
     def _unary(p, x, a2=None, gather=None, residual=None, act=None, slope=None):
-        return ops.linear(x, p['wt'], p['b'], a2=a2, gather=gather, residual=residual,
-                          act=p['act'] if act is None else act, slope=p['slope'] if slope is None else slope)
+        act = p['act'] if act is None else act
+        slope = p['slope'] if slope is None else slope
+        K = p['wt'].shape[0]
+        if gather is None and KPFCNN._LIN_B3_MINK > 0 and K >= KPFCNN._LIN_B3_MINK and x.shape[1] % 32 == 0:
+            pk = KPFCNN._packed_block(p, 0, K)
+            if pk is not None:
+                out = ops.linear_bf16x3(x, pk, p['wt'].shape[1], p['b'], act=act, slope=slope, a2=a2, residual=residual)
+                if out is not None:
+                    return out
+        return ops.linear(x, p['wt'], p['b'], a2=a2, gather=gather, residual=residual, act=act, slope=slope)
 
     _SPLIT_DECODER = True        # decoder step split by linearity (+2 %, profiles/DESIGN_rounds_1_to_4.md §3.7); False = one gather + concat GEMM
     _FUSE_SHORTCUT = True        # unary2 + shortcut Linear as ONE GEMM over the concatenated K
@@ -331,7 +353,16 @@ class KPFCNN(nn.Module):
         if not self._SPLIT_DECODER:
             return self._unary(p, x, a2=skip, gather=up)
         k1 = x.shape[1]
-        coarse = ops.linear(x, p['wt'][:k1], None)
+        K, n, mink = p['wt'].shape[0], p['wt'].shape[1], self._LIN_B3_MINK
+        coarse = None
+        if mink > 0 and k1 >= mink and (pk := self._packed_block(p, 0, k1)) is not None:
+            coarse = ops.linear_bf16x3(x, pk, n)
+        if coarse is None:
+            coarse = ops.linear(x, p['wt'][:k1], None)
+        if mink > 0 and K - k1 >= mink and (pk := self._packed_block(p, k1, K)) is not None:
+            out = ops.linear_bf16x3(skip, pk, n, p['b'], act=p['act'], slope=p['slope'], residual=coarse, residual_gather=up)
+            if out is not None:
+                return out
         return ops.linear(skip, p['wt'][k1:], p['b'], residual=coarse, residual_gather=up, act=p['act'], slope=p['slope'])
 
     def forward(self, batch):

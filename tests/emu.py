@@ -400,7 +400,7 @@ def conv2d_nhwc_bf16x3(x, w, bias, stride, pad, act=2, kh=3, kw=3, out=None, ch_
     return rc, out
 
 
-def linear_bf16x3(a, w, bias, act=0, a2=None, residual=None):
+def linear_bf16x3(a, w, bias, act=0, a2=None, residual=None, residual_gather=None):
     L = lib()
     a = np.ascontiguousarray(a, np.float32)
     rc, packed = pack_bf16x3(w)
@@ -415,6 +415,13 @@ def linear_bf16x3(a, w, bias, act=0, a2=None, residual=None):
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     wsb = L.ml3d_linear_bf16x3_workspace_bytes(m, n, k1 + k2)
     ws = _ws(wsb)
+    if residual_gather is not None:
+        rg = np.ascontiguousarray(residual_gather, np.int32)
+        rc = L.ml3d_linear_bf16x3_gathered(a.ctypes.data, k1, k1, None if a2 is None else a2.ctypes.data, k2, k2, m, packed.ctypes.data,
+                                           None if b is None else b.ctypes.data, res.ctypes.data, n, rg.ctypes.data,
+                                           rg.shape[1] if rg.ndim == 2 else 1, res.shape[0], n, act, 0.0, out.ctypes.data, n,
+                                           ws.ctypes.data, wsb, None)
+        return rc, out
     rc = L.ml3d_linear_bf16x3(a.ctypes.data, k1, k1, None if a2 is None else a2.ctypes.data, k2, k2, m, packed.ctypes.data,
                               None if b is None else b.ctypes.data, None if res is None else res.ctypes.data, n, n, act, 0.0,
                               out.ctypes.data, n, ws.ctypes.data, wsb, None)

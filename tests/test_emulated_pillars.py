@@ -274,6 +274,25 @@ def test_bf16x3_linear_two_blocks_residual_split_k(m, k1, k2, n, act, res):
     assert np.abs(out - ref).max() <= 2e-5
 
 
+@pytest.mark.parametrize("m,mc,k,n,act", [(700, 200, 256, 128, 1), (130, 40, 64, 40, 0), (60, 17, 1024, 64, 1)])
+def test_bf16x3_linear_with_a_gathered_residual(m, mc, k, n, act):
+    """ml3d_linear_bf16x3_gathered (round 6): act(a . W + bias + residual[g[m, 0]]) -- KPFCNN's decoder step split by linearity on the
+    bf16 pipe: the gathered residual in the 128-row epilogue (shadow rows >= residual rows and negative rows add nothing), and, for
+    the 60-row / K = 1024 case, in gemm_reduce behind the split-K slices."""
+    rng = np.random.default_rng(m + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((mc, n)).astype(np.float32)
+    g = rng.integers(-1, mc + 2, (m, 3)).astype(np.int32)             # first column: the residual row (mc, mc + 1, -1: none)
+    rc, out = emu.linear_bf16x3(a, w, b, act=act, residual=r, residual_gather=g)
+    assert rc == 0
+    rr = np.where(((g[:, 0] >= 0) & (g[:, 0] < mc))[:, None], r[np.clip(g[:, 0], 0, mc - 1)], 0.0)
+    ref = a.astype(np.float64) @ w.astype(np.float64) + b + rr
+    ref = {0: ref, 1: np.where(ref > 0, ref, 0.0)}[act]
+    assert np.abs(out - ref).max() <= 2e-5
+
+
 def test_bf16x3_stride1_convolutions_through_both_kernels():
     """3 x 3 / stride 1 / pad 1 takes conv3x3s1_bf3 (the input window staged once per 16-channel chunk, border taps read a zero pixel);
     ML3D_CONV_WINDOW=0 (a test hook of the emulator build) sends the same problems through gemm_tile_bf3.  Shapes: image rows shorter
