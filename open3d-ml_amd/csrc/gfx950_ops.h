@@ -96,4 +96,12 @@ __device__ __forceinline__ unsigned wave_append(unsigned* counter) {
     return base + lane;
 }
 
+// ---- inter-workgroup hand-off words of the fused scans (sort.hip / voxel.hip) -----------------------------------------------------
+// A hand-off word carries its value AND a ready tag in ONE dword, so a relaxed device-scope load / store of that dword is all the
+// protocol needs: no fence (no L2 write-back: every XCD has its own L2, a release fence at device scope costs a buffer_wbl2), no
+// second location whose order against the first would matter.  Device scope makes the access bypass the non-coherent levels.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+
 }  // namespace ml3d

@@ -39,6 +39,7 @@ struct GroupWs {
     unsigned* occ;      // [batch][GRID_LEVELS] scratch of bbox_compute
     float* seg;         // [batch][8]  org[3], then G[3] as int bits, pad (subsample)
     SortWs sort;
+    FusedWs fused;      // hand-off tables of the fused voxelize (sort.h)
     int64_t n;
     int batch;
 };
@@ -54,7 +55,8 @@ static size_t group_ws_bytes(int64_t n, int64_t batch) {
     b += vx_align(sizeof(unsigned) * 6 * (size_t)batch);
     b += vx_align(sizeof(unsigned) * GRID_LEVELS * (size_t)batch);
     b += vx_align(sizeof(float) * 8 * (size_t)batch);
-    b += sort_ws_bytes(m);
+    b += vx_align(sort_ws_bytes(m));
+    b += fused_ws_bytes(m, batch);
     return b + 256;
 }
 
@@ -74,6 +76,8 @@ static bool group_ws_carve(void* ws, size_t bytes, int64_t n, int64_t batch, Gro
     o->seg = (float*)p;         p += vx_align(sizeof(float) * 8 * (size_t)batch);
     size_t sb = sort_ws_bytes(m);
     if (!sort_ws_carve(p, sb, m, &o->sort)) return false;
+    p += vx_align(sb);
+    if (!fused_ws_carve(p, fused_ws_bytes(m, batch), m, batch, &o->fused)) return false;
     o->n = n;
     o->batch = (int)batch;
     return true;
@@ -200,6 +204,296 @@ __global__ void vox_fill(const u64* __restrict__ keys, const uint32_t* __restric
     if (rank >= P.max_voxels) return;
     const int64_t ov = batch_splits[b] + rank;
     const long long lin = (long long)(key - (u64)b * (u64)P.cells);
+    coords[3 * ov + 0] = (int32_t)(lin % P.G[0]);
+    coords[3 * ov + 1] = (int32_t)((lin / P.G[0]) % P.G[1]);
+    coords[3 * ov + 2] = (int32_t)(lin / (P.G[0] * P.G[1]));
+    const int64_t o = cnt[v];
+    const int c = cnt[v + 1] - cnt[v];
+    prs[ov + 1] = cnt[v + 1];
+    for (int j = 0; j < c; ++j) pidx[o + j] = (int64_t)vals[h + j];
+}
+
+// ---- voxelize, fused form (round 6): 7 launches for the count phase instead of 27 -----------------------------------------------------
+// keys (32 bits: item * cells + cell fits for every PointPillars grid: 16 KITTI sweeps are 3.4 M cells) + the digit histograms of all
+// passes -> one launch per radix pass (sort.h: fs_pass) -> ONE grouping launch that does what group_heads / scan / group_headpos /
+// group_first_voxel / vox_counts / scan / vox_batch_splits did in eleven.  Results are the same arrays (hp, cnt, fv, batch_splits,
+// stats), bit for bit.
+__global__ void __launch_bounds__(256)
+vox_keys32(const float* __restrict__ pts, int64_t stride, Segs S, int64_t n, VoxParams P, uint32_t inval, int passes,
+           uint32_t* __restrict__ keys, int* __restrict__ ghist) {
+    __shared__ int h[4][256];
+    const int t = threadIdx.x, lane = t & 63;
+    h[0][t] = 0; h[1][t] = 0; h[2][t] = 0; h[3][t] = 0;
+    __syncthreads();
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < n; b0 += (int64_t)gridDim.x * 256) {    // (block-uniform trip count: ballots below)
+        const int64_t i = b0 + t;
+        const bool act = i < n;
+        uint32_t key = inval;
+        if (act) {
+            int s; int64_t local;
+            seg_locate(S, i, s, local);
+            const float* p = pts + stride * i;
+            bool ok = true;
+            long long c[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = p[a];
+                ok = ok && (v >= P.rmin[a]) && (v <= P.rmax[a]);
+                c[a] = (long long)__fdiv_rn(__fsub_rn(v, P.rmin[a]), P.vs[a]);
+            }
+            if (ok) key = (uint32_t)((u64)s * (u64)P.cells + (u64)(c[0] + P.G[0] * (c[1] + P.G[1] * c[2])));
+            keys[i] = key;
+        }
+        // out-of-range points (half of a KITTI sweep) all carry `inval`: one LDS add per wave and pass instead of a 64-way conflict
+        const bool inv = act && key == inval;
+        const u64 m = __ballot(inv);
+        const int lead = m ? __ffsll((long long)m) - 1 : -1;
+        for (int q = 0; q < passes; ++q) {
+            if (act && !inv) atomicAdd(&h[q][(key >> (8 * q)) & 255u], 1);
+            else if (lane == lead) atomicAdd(&h[q][(inval >> (8 * q)) & 255u], __popcll(m));
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < passes; ++q)
+        if (h[q][t]) atomicAdd(&ghist[256 * q + t], h[q][t]);
+}
+
+// what the scans of the grouping kernel carry along the sorted keys: h = voxel heads so far, r = heads since (and with) the last
+// head that opened a new batch item (f: there was one), p = 1 + position of the last head.  Associative, not commutative.
+struct GrpRec { int h, r, f, p; };
+__device__ __forceinline__ GrpRec grp_combine(const GrpRec& a, const GrpRec& b) {     // a in front of b
+    GrpRec o;
+    o.h = a.h + b.h;
+    o.r = b.f ? b.r : a.r + b.r;
+    o.f = a.f | b.f;
+    o.p = a.p > b.p ? a.p : b.p;
+    return o;
+}
+__device__ __forceinline__ GrpRec grp_wave_inclusive(GrpRec v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        GrpRec u;
+        u.h = __shfl_up(v.h, o); u.r = __shfl_up(v.r, o); u.f = __shfl_up(v.f, o); u.p = __shfl_up(v.p, o);
+        if (lane >= o) v = grp_combine(u, v);
+    }
+    return v;
+}
+__device__ __forceinline__ void grp_store(uint32_t* p, const GrpRec& v) {
+    st_agent(p + 0, fs_word(1u, (uint32_t)v.h));
+    st_agent(p + 1, fs_word(1u, (uint32_t)v.r | ((uint32_t)v.f << 28)));
+    st_agent(p + 2, fs_word(1u, (uint32_t)v.p));
+}
+__device__ __forceinline__ GrpRec grp_load_wait(const uint32_t* p) {
+    GrpRec v;
+    v.h = (int)fs_wait(p + 0, 1u);
+    const uint32_t w = fs_wait(p + 1, 1u);
+    v.r = (int)(w & ((1u << 28) - 1u));
+    v.f = (int)(w >> 28) & 1;
+    v.p = (int)fs_wait(p + 2, 1u);
+    return v;
+}
+// exclusive prefix of `mine` (the tile's aggregate, valid in thread 0) over the tiles in front: the flat two-level hand-off of sort.h
+// with records instead of digit counts, evaluated by wave 0 (lane = tile of the group / group), handed to the block through LDS
+__device__ __forceinline__ GrpRec grp_tile_prefix(int tile, int tiles, const GrpRec& mine, uint32_t* tA, uint32_t* gA, uint32_t* gcnt,
+                                                  int* s_flag, GrpRec* s_rec) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int g = tile / FS_GROUP, gfirst = g * FS_GROUP;
+    const int members = min(FS_GROUP, tiles - gfirst);
+    if (t == 0) {
+        grp_store(tA + 4 * (size_t)tile, mine);
+        *s_flag = atomicAdd(&gcnt[g], 1u) == (uint32_t)(members - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (t < 64) {
+        const GrpRec zero = {0, 0, 0, 0};
+        if (*s_flag) {                                  // this tile arrived last in its group: it publishes the group's record
+            GrpRec v = zero;
+            if (lane < members) v = grp_load_wait(tA + 4 * (size_t)(gfirst + lane));
+            v = grp_wave_inclusive(v, lane);
+            if (lane == 63) grp_store(gA + 4 * (size_t)g, v);
+        }
+        GrpRec a = zero;
+        if (lane < g) a = grp_load_wait(gA + 4 * (size_t)lane);
+        a = grp_wave_inclusive(a, lane);
+        GrpRec b = zero;
+        if (lane < tile - gfirst) b = grp_load_wait(tA + 4 * (size_t)(gfirst + lane));
+        b = grp_wave_inclusive(b, lane);
+        if (lane == 63) *s_rec = grp_combine(a, b);
+    }
+    __syncthreads();
+    const GrpRec out = *s_rec;
+    __syncthreads();
+    return out;
+}
+
+struct GrpArgs {
+    const uint32_t* keys;      // sorted ascending, `inval` (= batch * cells) behind every real key
+    int64_t n;
+    uint32_t inval, cells;
+    int batch;
+    long long max_points, max_voxels;
+    int *hp, *cnt, *fv;
+    int64_t *batch_splits, *stats;
+    uint32_t *ticket, *gcnt1, *gcnt2, *tA, *gA, *tC, *gC, *fvf;
+};
+
+// Thread t of a tile owns the 8 consecutive sorted positions [2048 tile + 8 t, + 8).  head: a real key differing from its predecessor;
+// end: a real key differing from its successor; a head whose batch item differs from its predecessor's opens that item (and every
+// empty item in between).  At a head: hp[ordinal] = position.  At an end: the voxel's kept points = min(length, max_points), 0 beyond
+// max_voxels of its item -> a second prefix gives cnt[ordinal + 1].  The thread that sees the LAST real key closes the open items,
+// and its tile -- which by then has waited for nothing but tiles in front of it -- turns the first-voxel table into batch_splits / stats.
+__global__ void __launch_bounds__(256) vox_group32(GrpArgs A) {
+    __shared__ GrpRec s_wave[4];
+    __shared__ GrpRec s_rec;
+    __shared__ int s_flag, s_tile, s_fin, s_nv, s_total;
+    __shared__ long long s_part[256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int tiles = (int)gridDim.x;
+    if (t == 0) { s_tile = (int)atomicAdd(A.ticket, 1u); s_fin = 0; }
+    __syncthreads();
+    const int tile = s_tile;
+    const int64_t p0 = (int64_t)tile * FS_TILE + 8 * t;
+    uint32_t k[8];
+    if (p0 + 8 <= A.n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(A.keys + p0), b = *reinterpret_cast<const uint4*>(A.keys + p0 + 4);
+        k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k[e] = p0 + e < A.n ? A.keys[p0 + e] : A.inval;
+    }
+    const uint32_t kprev = p0 > 0 && p0 - 1 < A.n ? A.keys[p0 - 1] : A.inval;          // (position 0: no predecessor, see `head` below)
+    const uint32_t knext = p0 + 8 < A.n ? A.keys[p0 + 8] : A.inval;
+    unsigned heads = 0u, iheads = 0u, ends = 0u;
+    GrpRec mine = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t prev = e ? k[e - 1] : kprev, next = e < 7 ? k[e + 1] : knext;
+        const bool valid = k[e] != A.inval;
+        const bool first = p0 + e == 0;
+        const bool head = valid && (first || prev != k[e]);
+        bool ihead = false;
+        if (head) ihead = first || prev / A.cells != k[e] / A.cells;
+        heads |= (head ? 1u : 0u) << e;
+        iheads |= (ihead ? 1u : 0u) << e;
+        ends |= (valid && next != k[e] ? 1u : 0u) << e;
+        if (head) { mine.h += 1; mine.r = ihead ? 1 : mine.r + 1; mine.f |= ihead ? 1 : 0; mine.p = (int)(p0 + e) + 1; }
+    }
+    // ---- stage 1: (h, r, p) in front of every thread ----
+    const GrpRec zero = {0, 0, 0, 0};
+    GrpRec inc = grp_wave_inclusive(mine, lane);
+    if (lane == 63) s_wave[w] = inc;
+    GrpRec exc;
+    exc.h = __shfl_up(inc.h, 1); exc.r = __shfl_up(inc.r, 1); exc.f = __shfl_up(inc.f, 1); exc.p = __shfl_up(inc.p, 1);
+    if (lane == 0) exc = zero;
+    __syncthreads();
+    GrpRec front = zero;
+    for (int w2 = 0; w2 < w; ++w2) front = grp_combine(front, s_wave[w2]);
+    GrpRec whole = grp_combine(grp_combine(s_wave[0], s_wave[1]), grp_combine(s_wave[2], s_wave[3]));
+    const GrpRec tile_front = grp_tile_prefix(tile, tiles, whole, A.tA, A.gA, A.gcnt1, &s_flag, &s_rec);
+    GrpRec cur = grp_combine(tile_front, grp_combine(front, exc));
+    int ce[8], ve[8];
+    int csum = 0;
+    bool fin = false;
+    int fin_v = -1, fin_item = -1, fin_valid = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t i = p0 + e;
+        ce[e] = 0; ve[e] = 0;
+        if ((heads >> e) & 1u) {
+            const bool ih = (iheads >> e) & 1u;
+            cur.h += 1; cur.r = ih ? 1 : cur.r + 1; cur.p = (int)i + 1;
+            A.hp[cur.h - 1] = (int)i;
+            if (ih) {
+                const uint32_t prev = e ? k[e - 1] : kprev;
+                const int b1 = (int)(k[e] / A.cells), b0 = i == 0 ? -1 : (int)(prev / A.cells);
+                for (int b = b0 + 1; b <= b1; ++b) st_agent(&A.fvf[b], fs_word(1u, (uint32_t)(cur.h - 1)));
+            }
+        }
+        if ((ends >> e) & 1u) {
+            const int v = cur.h - 1, rank = cur.r - 1;
+            const long long len = (long long)i - (long long)cur.p + 2;
+            const int c = (long long)rank < A.max_voxels ? (int)(len < A.max_points ? len : A.max_points) : 0;
+            ce[e] = c; ve[e] = v; csum += c;
+            const uint32_t next = e < 7 ? k[e + 1] : knext;
+            if (next == A.inval) { fin = true; fin_v = v; fin_item = (int)(k[e] / A.cells); fin_valid = (int)i + 1; }
+        }
+    }
+    if (p0 == 0 && k[0] == A.inval) fin = true;                                      // no real key at all: nv = 0
+    // ---- stage 2: kept points in front of every thread ----
+    const int cinc = wave_inclusive_scan(csum);
+    if (lane == 63) s_wave[w].h = cinc;
+    __syncthreads();
+    int cfront = cinc - csum;
+    for (int w2 = 0; w2 < w; ++w2) cfront += s_wave[w2].h;
+    GrpRec ctile = zero;
+    ctile.h = s_wave[0].h + s_wave[1].h + s_wave[2].h + s_wave[3].h;
+    __syncthreads();
+    const GrpRec ctile_front = grp_tile_prefix(tile, tiles, ctile, A.tC, A.gC, A.gcnt2, &s_flag, &s_rec);
+    int C = ctile_front.h + cfront;
+    if (p0 == 0) A.cnt[0] = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if ((ends >> e) & 1u) { C += ce[e]; A.cnt[ve[e] + 1] = C; }
+    if (fin) {
+        const int nv = fin_v + 1;
+        A.hp[nv] = fin_valid;                                                         // number of real keys
+        for (int b = fin_item + 1; b <= A.batch; ++b) st_agent(&A.fvf[b], fs_word(1u, (uint32_t)nv));
+        s_fin = 1; s_nv = nv; s_total = C;
+    }
+    __syncthreads();
+    if (!s_fin) return;
+    // ---- the tile of the last real key: first-voxel table -> fv, batch_splits, stats (every entry was written by a tile in front
+    //      of this one or by this one: the waits below cannot block) ----
+    const int per = (A.batch + 255) / 256;
+    const int b0 = min(A.batch, t * per), b1 = min(A.batch, b0 + per);
+    long long local = 0;
+    {
+        uint32_t lo = b0 < b1 ? fs_wait(&A.fvf[b0], 1u) : 0u;
+        for (int b = b0; b < b1; ++b) {
+            const uint32_t hi = fs_wait(&A.fvf[b + 1], 1u);
+            const long long nvb = (long long)hi - (long long)lo;
+            local += nvb < A.max_voxels ? nvb : A.max_voxels;
+            A.fv[b] = (int)lo;
+            lo = hi;
+        }
+    }
+    if (t == 0) A.fv[A.batch] = s_nv;
+    s_part[t] = local;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) { const long long v = s_part[i]; s_part[i] = run; run += v; }
+        A.batch_splits[0] = 0;
+        A.stats[0] = run;
+        A.stats[1] = s_total;
+    }
+    __syncthreads();
+    {
+        long long run = s_part[t];
+        uint32_t lo = b0 < b1 ? fs_wait(&A.fvf[b0], 1u) : 0u;
+        for (int b = b0; b < b1; ++b) {
+            const uint32_t hi = fs_wait(&A.fvf[b + 1], 1u);
+            const long long nvb = (long long)hi - (long long)lo;
+            run += nvb < A.max_voxels ? nvb : A.max_voxels;
+            A.batch_splits[b + 1] = run;
+            lo = hi;
+        }
+    }
+}
+
+__global__ void vox_fill32(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, const int* __restrict__ hp,
+                           const int* __restrict__ fv, const int* __restrict__ cnt, const int64_t* __restrict__ batch_splits,
+                           VoxParams P, int batch, int32_t* __restrict__ coords, int64_t* __restrict__ pidx, int64_t* __restrict__ prs) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) prs[0] = 0;
+    if (v >= n || v >= fv[batch]) return;
+    const int h = hp[v];
+    const uint32_t key = keys[h];
+    const int b = (int)(key / (uint32_t)P.cells);
+    const long long rank = v - fv[b];
+    if (rank >= P.max_voxels) return;
+    const int64_t ov = batch_splits[b] + rank;
+    const long long lin = (long long)(key - (uint32_t)b * (uint32_t)P.cells);
     coords[3 * ov + 0] = (int32_t)(lin % P.G[0]);
     coords[3 * ov + 1] = (int32_t)((lin / P.G[0]) % P.G[1]);
     coords[3 * ov + 2] = (int32_t)(lin / (P.G[0] * P.G[1]));
@@ -585,6 +879,20 @@ static int vox_params(const float* vs, const float* rmin, const float* rmax, int
     return 0;
 }
 
+// the fused form (one launch per pass, one grouping launch) when the keys fit 32 bits and the input the hand-off tables;
+// ML3D_VOX_FUSED=0 keeps the launch chain (A/B: profiles/r06_voxelize_fused_ab.log).  A pure function of the call's arguments, so the
+// fill call finds the count call's choice again.
+static bool vox_fused(int64_t n, int64_t batch, const VoxParams& P) {
+    static const bool off = [] { const char* e = getenv("ML3D_VOX_FUSED"); return e && atoi(e) == 0; }();
+    const double inval = (double)batch * (double)P.cells;
+    return !off && inval <= 4294967295.0 && fused_sort_fits(n, bits_for((u64)batch * (u64)P.cells));
+}
+
+struct VoxFusedBufs { uint32_t *ka, *va, *kb, *vb; };
+static VoxFusedBufs vox_fused_bufs(const GroupWs& W) {
+    return {(uint32_t*)W.keys, W.vals, (uint32_t*)W.sort.keys_alt, W.sort.vals_alt};
+}
+
 }  // namespace ml3d
 
 using namespace ml3d;
@@ -612,6 +920,26 @@ extern "C" int ml3d_voxelize_count(const float* points, int64_t point_stride, co
     const int64_t n = n_points;
     const unsigned nb = (unsigned)((n + 255) / 256);
     const u64 inval = (u64)batch * (u64)P.cells;
+    if (vox_fused(n, batch, P)) {
+        const FusedWs& F = W.fused;
+        const VoxFusedBufs B = vox_fused_bufs(W);
+        const int bits = bits_for(inval), passes = fused_passes(bits);
+        zero_async(F.base, F.bytes, st);
+        const unsigned kb = nb < 512u ? nb : 512u;
+        hipLaunchKernelGGL(vox_keys32, dim3(kb), dim3(256), 0, st, points, point_stride, S, n, P, (uint32_t)inval, passes, B.ka, F.ghist);
+        VX_CHECK();
+        if (sort_u32_fused(B.ka, B.va, B.kb, B.vb, n, bits, F, st) != passes) return ML3D_E_LAUNCH;
+        GrpArgs A;
+        A.keys = (passes & 1) ? B.kb : B.ka;
+        A.n = n; A.inval = (uint32_t)inval; A.cells = (uint32_t)P.cells; A.batch = (int)batch;
+        A.max_points = P.max_points; A.max_voxels = P.max_voxels;
+        A.hp = W.hp; A.cnt = W.cnt; A.fv = W.fv; A.batch_splits = out_batch_splits; A.stats = out_stats;
+        A.ticket = F.ticket + 4; A.gcnt1 = F.gcnt + 4 * FS_MAX_GROUPS; A.gcnt2 = F.gcnt + 5 * FS_MAX_GROUPS;
+        A.tA = F.tA; A.gA = F.gA; A.tC = F.tC; A.gC = F.gC; A.fvf = F.fvf;
+        hipLaunchKernelGGL(vox_group32, dim3(F.tiles), dim3(256), 0, st, A);
+        VX_CHECK();
+        return 0;
+    }
     if (n > 0) {
         hipLaunchKernelGGL(vox_keys, dim3(nb), dim3(256), 0, st, points, point_stride, S, n, P, W.keys, W.vals);
         VX_CHECK();
@@ -643,6 +971,15 @@ extern "C" int ml3d_voxelize_fill(int64_t batch, int64_t n_points, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (n_points == 0) {
         (void)hipMemsetAsync(out_point_row_splits, 0, sizeof(int64_t), st);
+        return 0;
+    }
+    if (vox_fused(n_points, batch, P)) {
+        const VoxFusedBufs B = vox_fused_bufs(W);
+        const bool in_b = fused_passes(bits_for((u64)batch * (u64)P.cells)) & 1;
+        hipLaunchKernelGGL(vox_fill32, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, in_b ? B.kb : B.ka, in_b ? B.vb : B.va,
+                           n_points, W.hp, W.fv, W.cnt, batch_splits, P, (int)batch, out_voxel_coords, out_point_indices,
+                           out_point_row_splits);
+        VX_CHECK();
         return 0;
     }
     group_swap_if_alt(W, n_points, bits_for((u64)batch * (u64)P.cells));

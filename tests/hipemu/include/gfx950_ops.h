@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #define ML3D_WAVES_PER_SIMD(n)
 
@@ -39,4 +40,8 @@ static inline void lane32_swap(uint32_t& x, uint32_t& y) {
     memcpy(peer, vw.peer(lane ^ 32), sizeof(peer));
     if (lane < 32) y = peer[0]; else x = peer[1];
 }
+// hand-off words of the fused scans: blocks of one launch run on several OS threads
+static inline uint32_t ld_agent(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void st_agent(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static inline void spin_pause() { std::this_thread::yield(); }
 }  // namespace ml3d

@@ -516,3 +516,52 @@ def test_voxelize_orders_long_runs_like_the_oracle(max_points, max_voxels):
     assert np.array_equal(pi, ref.voxel_point_indices)
     if max_points > 5000:
         assert np.diff(prs).max() >= 5000
+
+
+def _vox_cloud(seed, sizes):
+    """KITTI-shaped items: a spread of returns over the range, pillars of tens / hundreds / thousands of points next to the sensor,
+    returns outside the range, in shuffled order"""
+    rng = np.random.default_rng(seed)
+    items = []
+    for n in sizes:
+        if n == 0:
+            items.append(np.zeros((0, 3), np.float32))
+            continue
+        parts = [rng.random((n * 6 // 10, 3), dtype=np.float32) * [69, 79, 3.9] + [0, -39.6, -3],
+                 rng.random((n // 10, 3), dtype=np.float32) * [0.15, 0.15, 3.5] + [10.0, 0.0, -3],
+                 rng.random((n // 10, 3), dtype=np.float32) * [1.2, 1.2, 3.5] + [30.0, -10.0, -3],
+                 rng.random((n // 10, 3), dtype=np.float32) * 40 + [70, 40, 1]]
+        a = np.concatenate(parts)
+        a = np.concatenate([a, rng.random((n - len(a), 3), dtype=np.float32) * [3, 3, 3] + [5, 5, -3]]).astype(np.float32)
+        items.append(a[rng.permutation(n)])
+    return np.concatenate(items), np.concatenate([[0], np.cumsum(sizes)])
+
+
+@pytest.mark.parametrize("sizes,max_points,max_voxels", [
+    ((30000, 0, 41000, 70000, 9), 32, 2**62),        # 69 tiles: three groups of the hand-off, the last one partial
+    ((66000, 1, 0), 32, 900),                        # max_voxels cuts an item; 33 tiles: a group of one
+    ((2048 * 32,), 2**62, 2**62),                    # exactly one full group, the last tile full
+    ((2049,), 5, 2**62), ((1,), 32, 2**62)])
+def test_voxelize_fused_hand_off_over_many_tiles_matches_the_oracle(sizes, max_points, max_voxels):
+    """The fused voxelize (one launch per radix pass + one grouping launch, tiles handing their counts on through tagged words in
+    global memory: sort.h) at sizes where the flat two-level prefix has several groups, partial groups and single tiles: everything
+    identical to the oracle.  The emulator runs the workgroups of a launch on several OS threads, so the waits are real waits."""
+    pts, rs = _vox_cloud(len(sizes) * 7 + sizes[0] % 5, sizes)
+    vs, mn, mx = [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1]
+    c, pi, prs, bs = emu.voxelize(pts, rs, vs, mn, mx, max_points, max_voxels)
+    ref = oops.voxelize(pts, rs, vs, mn, mx, max_points, max_voxels)
+    assert np.array_equal(bs, ref.voxel_batch_splits)
+    assert np.array_equal(c, ref.voxel_coords)
+    assert np.array_equal(prs, ref.voxel_point_row_splits)
+    assert np.array_equal(pi, ref.voxel_point_indices)
+
+
+def test_voxelize_fused_with_no_point_in_range_and_with_every_point_in_one_pillar():
+    far = (np.random.default_rng(2).random((5000, 3), dtype=np.float32) * 5 + [100, 100, 10]).astype(np.float32)
+    c, pi, prs, bs = emu.voxelize(far, [0, 2000, 5000], [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1], 32, 100)
+    assert c.shape == (0, 3) and pi.shape == (0,) and prs.tolist() == [0] and bs.tolist() == [0, 0, 0]
+    one = (np.random.default_rng(3).random((9000, 3), dtype=np.float32) * [0.1, 0.1, 3] + [3.05, 3.05, -3]).astype(np.float32)
+    c, pi, prs, bs = emu.voxelize(one, [0, 0, 9000], [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1], 2**62, 2**62)
+    ref = oops.voxelize(one, [0, 0, 9000], [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1])
+    assert np.array_equal(c, ref.voxel_coords) and np.array_equal(pi, ref.voxel_point_indices) and bs.tolist() == [0, 0, 1]
+    assert prs.tolist() == [0, 9000]
