@@ -399,12 +399,12 @@ def run_pointpillars(args, rank, world, dev, dist):
     pb, pn, pm = pf_bytes(pf_shapes)
     va, pa = prim_alone["lane" if overlap else "batch"][:2]
     other = [
-        _hbm_entry("a15 voxelize (point_pillars.py:328-382)", "vox_* + rs_hist / rs_scatter (hash-free sort voxelize: count + fill)",
+        _hbm_entry("a15 voxelize (point_pillars.py:328-382)", "vox_keys32 + 3 x fs_pass + vox_group32 + vox_fill32 (fused stable radix voxelize: 8 launches, count + fill)",
                    vb, float(np.mean(vox_in)) if vox_in else None, va, "pp_voxelize", lane_units,
                    "%d in-range points -> %d pillars (%d kept points) of %d sweeps in one call; the interval holds the op's one host "
                    "read-back (pillar count) between count and fill" % (vn, vm, vk, lane_units), len(vox_in)),
         _hbm_entry("a16-a17 pillar gather + PFN + canvas scatter (point_pillars.py:512-616)",
-                   "pillar_pfn + canvas fill (grid_zero)", pb, float(np.mean(pf_in)) if pf_in else None, pa,
+                   "pillar_pfn_v4 + canvas fill (grid_zero)", pb, float(np.mean(pf_in)) if pf_in else None, pa,
                    "pp_pillar_features", lane_units,
                    "%d pillars of %d sweeps -> NHWC canvas %s: zero fill + one 256-byte row per pillar" %
                    (pm, lane_units, "x".join(str(int(d)) for d in pf_shapes[1].shape)), len(pf_in)),

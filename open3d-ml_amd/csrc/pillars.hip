@@ -22,6 +22,7 @@
 // convs = f32 matrix peak 157.3 TFLOP/s (68.3 GFLOP per KITTI frame).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gemm.h"
 #include "grid.h"
@@ -130,6 +131,59 @@ __global__ void __launch_bounds__(256) pillar_pfn(PfnArgs A) {
     }
 }
 
+// The KITTI-shaped case (4 input channels in 16-byte rows, one PFN layer of 64 units, <= 60 samples) with the pillar's DEPENDENT
+// round trips cut from eight to three.  pillar_pfn spends its time waiting (67 k pillars of 8 sweeps in 100 us at full occupancy, a
+// few hundred bytes each: profiles/r06_pillars_kernel_stats.csv): coords -> row splits -> point indices -> four scalar loads per
+// point -> LDS -> nine weight loads -> a binary search over batch_splits -> store.  Here the weights are requested first (they do not
+// depend on the pillar), ONE 32-bit and ONE 64-bit gather fetch coords, both row splits and the whole batch_splits table (lane =
+// entry: the sample is a ballot count), a point is one float4 load, and the decorated rows never go through LDS: the row of point j
+// reaches every lane as scalar operands (v_readlane with a uniform j).  Same operations in the same order as pillar_pfn -- the same bits.
+__global__ void __launch_bounds__(256) pillar_pfn_v4(PfnArgs A) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + w;
+    if (m >= A.n_pillars) return;                 // wave-uniform; no block barrier below
+    float wcol[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) wcol[c] = A.wt[c * 64 + lane];
+    const float b = A.bias[lane];
+    int c32 = 0;
+    if (lane < 2) c32 = A.coords[3 * m + lane];
+    long long v64 = 0x7fffffffffffffffll;
+    if (lane == 2 || lane == 3) v64 = A.prs[m + (lane - 2)];
+    else if (lane >= 4 && lane < 3 + A.batch) v64 = A.batch_splits[lane - 3];         // entries 1 .. batch - 1
+    const int cx = __builtin_amdgcn_readlane(c32, 0), cy = __builtin_amdgcn_readlane(c32, 1);
+    if (cx >= A.nx || cy >= A.ny) return;         // pillar on the upper range bound (point_pillars.py:373-380)
+    const int lo32 = (int)(unsigned)(v64 & 0xffffffffll), hi32 = (int)(v64 >> 32);
+    const int64_t p0 = (int64_t)(unsigned)__builtin_amdgcn_readlane(lo32, 2) | ((int64_t)__builtin_amdgcn_readlane(hi32, 2) << 32);
+    const int64_t p1 = (int64_t)(unsigned)__builtin_amdgcn_readlane(lo32, 3) | ((int64_t)__builtin_amdgcn_readlane(hi32, 3) << 32);
+    const int sample = __popcll(__ballot(lane >= 4 && v64 <= (long long)m));
+    const int np = (int)(p1 - p0);                // <= P
+    const bool real = lane < np;
+    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (real) f = *reinterpret_cast<const float4*>(A.points + 4 * A.pidx[p0 + lane]);
+    const float inv = 1.0f / (float)np;
+    const float mx = wave_sum(f.x) * inv, my = wave_sum(f.y) * inv, mz = wave_sum(f.z) * inv;
+    float d[9];
+    d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+    d[4] = f.x - mx; d[5] = f.y - my; d[6] = f.z - mz;
+    d[7] = f.x - ((float)cx * A.vx + A.x_off);
+    d[8] = f.y - ((float)cy * A.vy + A.y_off);
+    float vmax = -3.0e38f;
+    const int nreal = np < A.P ? np : A.P;
+    for (int j = 0; j < nreal; ++j) {
+        float v = b;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) v = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d[c]), j)), wcol[c], v);
+        v = v > 0.f ? v : 0.f;
+        vmax = v > vmax ? v : vmax;
+    }
+    if (nreal < A.P) {                            // masked rows are all zeros: relu(bias), bit for bit (see pillar_pfn)
+        const float vb = b > 0.f ? b : 0.f;
+        vmax = vb > vmax ? vb : vmax;
+    }
+    A.canvas[(((int64_t)sample * A.ny + cy) * A.nx + cx) * A.canvas_c + lane] = vmax;
+}
+
 // subsequent PFN layers: input rows [M, P, cin] -> Linear + folded BN + ReLU -> max (-> canvas) or [x | max]
 struct PfnNextArgs {
     const float* xin; int cin;
@@ -236,7 +290,12 @@ extern "C" int ml3d_pillar_features(const float* points, int64_t point_stride, i
     a.wt = weights_host[0]; a.bias = bias_host[0]; a.units = units_host[0];
     a.last = num_layers == 1 ? 1 : 0;
     a.canvas = canvas; a.canvas_c = canvas_channels; a.xcat = buf[0];
-    hipLaunchKernelGGL(pillar_pfn, dim3((unsigned)((n_pillars + 3) / 4)), dim3(256), 0, st, a);
+    static const bool v4_off = [] { const char* e = getenv("ML3D_PFN_V4"); return e && atoi(e) == 0; }();
+    if (!v4_off && in_channels == 4 && point_stride == 4 && ((uintptr_t)points & 15) == 0 && num_layers == 1 && units_host[0] == 64 &&
+        batch <= 60)
+        hipLaunchKernelGGL(pillar_pfn_v4, dim3((unsigned)((n_pillars + 3) / 4)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(pillar_pfn, dim3((unsigned)((n_pillars + 3) / 4)), dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) return ML3D_E_LAUNCH;
     int cin = 2 * units_host[0];
     for (int l = 1; l < num_layers; ++l) {
