@@ -181,6 +181,37 @@ __device__ __forceinline__ void seg_locate(const Segs& S, int64_t packed, int& s
     local = packed - S.splits[lo];
 }
 
+// The same for a WAVE-UNIFORM packed index, every lane of the wave calling: lane b holds splits[b + 1] (two loads cover 128 items) and the
+// segment is a ballot count -- ONE memory round trip instead of the log2(batch) dependent ones of the binary search (7 for the 96
+// spheres of a KPConv batch, in front of everything else a wave-per-query kernel does).  Returns the segment's first packed index too.
+__device__ __forceinline__ void seg_locate_wave(const Segs& S, int64_t packed, int lane, int& s, int64_t& local, int64_t& begin) {
+#ifdef ML3D_SEG_BINARY      // A/B build (tools/build_variant.sh): the binary search everywhere
+    const bool search = true;
+#else
+    const bool search = !S.splits || S.batch > 128;
+#endif
+    if (search) {
+        seg_locate(S, packed, s, local);
+        begin = packed - local;
+        return;
+    }
+    const long long big = 0x7fffffffffffffffll;
+    const long long first = S.splits[0];
+    const long long v0 = lane + 1 < S.batch ? (long long)S.splits[lane + 1] : big;
+    long long v1 = big;
+    if (S.batch > 64 && lane + 65 < S.batch) v1 = S.splits[lane + 65];
+    int cnt = __popcll(__ballot(v0 <= (long long)packed));
+    if (S.batch > 64) cnt += __popcll(__ballot(v1 <= (long long)packed));
+    s = cnt;
+    const long long src = cnt > 64 ? v1 : v0;
+    const int from = cnt > 64 ? cnt - 65 : (cnt > 0 ? cnt - 1 : 0);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(src & 0xffffffffll), from);
+    const int hi = __builtin_amdgcn_readlane((int)(src >> 32), from);
+    const long long held = (long long)(unsigned)lo | ((long long)hi << 32);
+    begin = cnt > 0 ? held : first;
+    local = packed - begin;
+}
+
 __device__ __forceinline__ int cell_coord(float p, float lo, float inv_c, int dim) {
     int v = (int)((p - lo) * inv_c);
     v = v < 0 ? 0 : v;

@@ -46,11 +46,19 @@ struct RadQuery {
 };
 
 __device__ __forceinline__ RadQuery rad_setup(const RadArgs& A, int64_t t) {
+    // (t is wave-uniform and the whole wave is here: the segment lookup is one round trip, seg_locate_wave; with row splits the
+    //  query's global row IS t, so its coordinates are requested before the lookup returns)
     RadQuery Q;
-    int64_t local;
-    seg_locate(A.qsegs, t, Q.s, local);
-    const float* p = A.queries + 3 * (seg_begin_global(A.qsegs, Q.s) + local);
-    Q.qx = p[0]; Q.qy = p[1]; Q.qz = p[2];
+    int64_t local, begin;
+    const float* p = A.queries + 3 * t;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (A.qsegs.splits) { qx = p[0]; qy = p[1]; qz = p[2]; }
+    seg_locate_wave(A.qsegs, t, (int)(threadIdx.x & 63), Q.s, local, begin);
+    if (!A.qsegs.splits) {
+        p = A.queries + 3 * (seg_begin_global(A.qsegs, Q.s) + local);
+        qx = p[0]; qy = p[1]; qz = p[2];
+    }
+    Q.qx = qx; Q.qy = qy; Q.qz = qz;
     Q.any = false;
     Q.xa = Q.xb = Q.ya = Q.yb = Q.za = Q.zb = 0;
     return Q;
@@ -251,6 +259,7 @@ radius_gather(RadArgs A, int cap, int32_t* __restrict__ stash, int* __restrict__
     if (t >= A.nq) return;                       // wave-uniform; no block barrier below
     RadQuery Q = rad_setup(A, t);
     const GridSeg g = A.G.segs[Q.s];
+    const int64_t base = seg_begin_global(A.psegs, Q.s);      // (requested here, beside the grid record: it only depends on the segment)
     rad_box(Q, g, A.r);
     int total = 0;
     rad_scan(A, Q, g, lane, [&](bool act, const float4& c) {
@@ -273,7 +282,6 @@ radius_gather(RadArgs A, int cap, int32_t* __restrict__ stash, int* __restrict__
     }
     if (total > cap || total > RAD_LDS_ROW) return;
     wave_sync();
-    const int64_t base = seg_begin_global(A.psegs, Q.s);
     const double* db = reinterpret_cast<const double*>(rows[w]);
     int32_t* orow = stash + t * cap;
     for (int e = lane; e < total; e += 64) {

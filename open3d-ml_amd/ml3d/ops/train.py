@@ -102,7 +102,9 @@ class BatchNormActFunction(torch.autograd.Function):
         _abi.check(rc, "ml3d_batchnorm_train_forward")
         if running_mean is not None and running_var is not None:
             with torch.no_grad():
-                mom = 0.1 if momentum is None else float(momentum)
+                if momentum is None:      # torch: cumulative moving average, factor 1 / num_batches_tracked (the caller counts)
+                    raise ValueError("BatchNormActFunction: momentum=None (cumulative average) needs num_batches_tracked; use batch_norm_act()")
+                mom = float(momentum)
                 running_mean.mul_(1.0 - mom).add_(mean.to(running_mean.dtype), alpha=mom)
                 running_var.mul_(1.0 - mom).add_(var.to(running_var.dtype), alpha=mom * rows / (rows - 1))
         ctx.save_for_backward(x2, y, g if g is not None else mean.new_empty(0), mean, invstd)
@@ -133,8 +135,11 @@ def batch_norm_act(x, bn, slope=None):
     """``bn`` (an ``nn.BatchNorm1d / 2d`` in training mode) over the rows of the point-major x [..., C] + LeakyReLU(slope)."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum
+    if momentum is None and bn.track_running_stats:       # torch's cumulative moving average: factor 1 / num_batches_tracked
+        momentum = 1.0 / float(max(int(bn.num_batches_tracked), 1)) if bn.num_batches_tracked is not None else 0.0
     return BatchNormActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                                      bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, slope)
+                                      bn.running_var if bn.track_running_stats else None, momentum, bn.eps, slope)
 
 
 class GatherRowsFunction(torch.autograd.Function):
@@ -199,9 +204,11 @@ class GatherPoolFunction(torch.autograd.Function):
         return gx, None, None
 
 
-def attention_stage_supported(k, c1, c2):
+def attention_stage_supported(k, c1, c2, rows=0):
+    """The shapes ``ml3d_randla_attention_stage`` takes (train.hip attn_check): K = 16, d = c1 + c2 even and <= 256, and
+    ``rows`` = B * N below 2^31 / 16 (32-bit row arithmetic) -- callers fall back to the unfused path otherwise."""
     d = c1 + c2
-    return k == 16 and d <= 256 and d % 2 == 0 and (d <= 128 or c1 <= 160)
+    return k == 16 and d <= 256 and d % 2 == 0 and (d <= 128 or c1 <= 160) and int(rows) < (1 << 31) // 16
 
 
 class AttentionStageFunction(torch.autograd.Function):
@@ -265,6 +272,18 @@ class KPConvDeformedFunction(torch.autograd.Function):
         lib = _abi.get()
         _need_gpu(x, deformed_kp, q_pts, s_pts, neighb_inds)
         x, dkp = _f32(x), _f32(deformed_kp)
+        # the kernel takes raw pointers: float32 [Nq, 3] / [Ns, 3] points, int32 [Nq, H] neighbour rows, one feature row per support
+        q_pts, s_pts = _f32(q_pts), _f32(s_pts)
+        if neighb_inds.dtype != torch.int32 or not neighb_inds.is_contiguous():
+            neighb_inds = neighb_inds.to(torch.int32).contiguous()
+        if q_pts.dim() != 2 or q_pts.shape[1] != 3 or s_pts.dim() != 2 or s_pts.shape[1] != 3:
+            raise ValueError("KPConvDeformedFunction: q_pts / s_pts must be [N, 3]")
+        if x.dim() != 2 or x.shape[0] != s_pts.shape[0]:
+            raise ValueError("KPConvDeformedFunction: x must hold one row per support point (%s vs %d)" % (tuple(x.shape), s_pts.shape[0]))
+        if neighb_inds.dim() != 2 or neighb_inds.shape[0] != q_pts.shape[0]:
+            raise ValueError("KPConvDeformedFunction: neighb_inds must be [Nq, H]")
+        if dkp.dim() != 3 or dkp.shape[0] != q_pts.shape[0] or dkp.shape[2] != 3:
+            raise ValueError("KPConvDeformedFunction: deformed_kp must be [Nq, K, 3]")
         nq, ns = q_pts.shape[0], s_pts.shape[0]
         H = neighb_inds.shape[1] if neighb_inds.dim() == 2 else 0
         cin, K = x.shape[1], dkp.shape[1]

@@ -398,8 +398,10 @@ class KPFCNN(nn.Module):
                     # the reference sets min_d2 / deformed_KP in EVERY forward, eval included (kpconv.py:1058,1074): its
                     # validation loss regularises the CURRENT batch.  The fused kernel does not materialise them, so the
                     # block keeps this call's inputs and `_offset_regulariser` derives the two tensors on demand
+                    # (that pins the batch's features and neighbour matrices until the next forward or get_loss; a
+                    #  caller that never asks for a loss -- pure inference -- sets ``model.retain_offset_geometry = False``)
                     m.min_d2 = m.deformed_KP = None
-                    m._geom_inputs = (q_pts, pts[L], inds, xin, infl)
+                    m._geom_inputs = (q_pts, pts[L], inds, xin, infl) if getattr(self, 'retain_offset_geometry', True) else None
                     return ops.kpconv_deformable(q_pts, pts[L], inds, xin, c['kp'], c['w'], c['b'], c['extent'], c['ow'],
                                                  c['ob'], 1, lr, infl)
             if isinstance(blk, SimpleBlock):

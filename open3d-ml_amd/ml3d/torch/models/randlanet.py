@@ -305,7 +305,7 @@ class RandLANet(nn.Module):
 
         def stage(pool, f, enc, l):  # LocalSpatialEncoding's gather + concat, then AttentivePooling.forward (randlanet.py:596-639)
             sc = pool.score_fn[0]
-            if hip and ops.attention_stage_supported(nbr[l].shape[-1], f.shape[-1], enc.shape[-1]):
+            if hip and ops.attention_stage_supported(nbr[l].shape[-1], f.shape[-1], enc.shape[-1], f.shape[0] * f.shape[1]):
                 pooled = ops.AttentionStageFunction.apply(f, enc, nbr32[l], sc.weight, sc.bias)
             else:
                 x = torch.cat([gather(f, nbr[l]), enc], -1)

@@ -565,3 +565,23 @@ def test_voxelize_fused_with_no_point_in_range_and_with_every_point_in_one_pilla
     ref = oops.voxelize(one, [0, 0, 9000], [0.16, 0.16, 4], [0, -39.68, -3], [69.12, 39.68, 1])
     assert np.array_equal(c, ref.voxel_coords) and np.array_equal(pi, ref.voxel_point_indices) and bs.tolist() == [0, 0, 1]
     assert prs.tolist() == [0, 9000]
+
+
+@pytest.mark.parametrize("batch", [64, 65, 96, 128, 130])
+def test_radius_segment_lookup_by_ballot_over_many_items_with_empty_ones(batch):
+    """Wave-per-query kernels find a query's batch item with ONE lane-parallel load of the row splits and a ballot count
+    (grid.h seg_locate_wave: <= 64 items one load, <= 128 two, beyond that the binary search): 64 / 65 / 96 (a KPConv batch) / 128 /
+    130 items, several of them empty on either side, queries and supports with different splits."""
+    rng = np.random.default_rng(batch)
+    plen = rng.integers(0, 60, batch); plen[[1, batch // 2, batch - 1]] = 0
+    qlen = rng.integers(0, 25, batch); qlen[[0, 2, batch // 2]] = 0
+    ps, qs = np.concatenate([[0], np.cumsum(plen)]), np.concatenate([[0], np.cumsum(qlen)])
+    p = rng.random((ps[-1], 3), dtype=np.float32)
+    q = rng.random((qs[-1], 3), dtype=np.float32)
+    idx, rs = emu.radius(p, ps, q, qs, 0.3)
+    ref = oops.fixed_radius_search(p, q, 0.3, ps, qs)
+    assert np.array_equal(rs, ref.neighbors_row_splits) and np.array_equal(idx, ref.neighbors_index)
+    dense = emu.radius(p, ps, q, qs, 0.3, dense=True)
+    cols = int(np.diff(ref.neighbors_row_splits).max())
+    assert np.array_equal(dense, oops.ragged_to_dense(ref.neighbors_index.reshape(-1, 1), ref.neighbors_row_splits, cols,
+                                                      np.array([len(p)], np.int32))[:, :, 0])
