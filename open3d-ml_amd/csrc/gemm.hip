@@ -1044,7 +1044,9 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
                             float* __restrict__ C, int64_t ldc) {
     const int64_t total = M * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / N;
+        // (32-bit index arithmetic whenever it fits: a 64-bit i / N is a ~100-instruction software division in front of `splits` loads)
+        int64_t m;
+        if (total < 0x7fffffffll) m = (int64_t)((unsigned)i / (unsigned)N); else m = i / N;
         const int col = (int)(i - m * N);
         float v = 0.f;
         for (int z = 0; z < splits; ++z) v += partial[(int64_t)z * total + i];
@@ -1067,7 +1069,7 @@ __global__ void gemm_reduce(const float* __restrict__ partial, int splits, int64
             if (ep.res_gather) {
                 const int64_t g = ep.res_gather[ep.rg_stride ? m * ep.rg_stride : m];
                 take = g >= 0 && g < ep.rg_limit;
-                rr = (m / ep.rg_rows_per_item) * ep.rg_src_rows_per_item + g;
+                rr = (m < ep.rg_rows_per_item ? 0 : m / ep.rg_rows_per_item) * ep.rg_src_rows_per_item + g;
             }
             if (take) v += ep.residual[rr * ep.ldr + col];
         }

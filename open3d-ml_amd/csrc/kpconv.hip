@@ -749,7 +749,8 @@ gather_pool_v4(const float4* __restrict__ x, int64_t ns, int c4, const int32_t* 
                float4* __restrict__ out) {
     const int64_t total = nq * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = i / c4;
+        int64_t q;                                      // (32-bit division whenever it fits: the 64-bit one is ~100 instructions)
+        if (total < 0x7fffffffll) q = (int64_t)((unsigned)i / (unsigned)c4); else q = i / c4;
         const int cq = (int)(i - q * c4);
         const int32_t* row = inds + q * h;
         float4 v;

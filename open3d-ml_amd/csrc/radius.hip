@@ -298,14 +298,29 @@ radius_gather(RadArgs A, int cap, int32_t* __restrict__ stash, int* __restrict__
     }
 }
 
+// (the 64-bit i / cols of the first version is a ~100-instruction software division per 4-byte element: below 2^31 elements the
+//  index arithmetic is 32-bit, and a thread walks its elements with an incremental (row, column) instead of dividing again)
 __global__ void __launch_bounds__(256)
 radius_expand(const int32_t* __restrict__ stash, const int* __restrict__ counts, int64_t nq, int cap, int64_t cols,
               int32_t pad_value, int32_t* __restrict__ out) {
     const int64_t total = nq * cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = i / cols;
-        const int j = (int)(i - t * cols);
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t t;
+    int j;
+    if (total < 0x7fffffffll) {
+        const unsigned c = (unsigned)cols, q = (unsigned)i / c;
+        t = q; j = (int)((unsigned)i - q * c);
+    } else {
+        t = i / cols; j = (int)(i - t * cols);
+    }
+    const int64_t dt = step / cols;                  // one division per thread, not per element
+    const int dj = (int)(step - dt * cols);
+    for (; i < total; i += step) {
         out[i] = j < counts[t] ? stash[t * cap + j] : pad_value;
+        t += dt; j += dj;
+        if (j >= (int)cols) { j -= (int)cols; ++t; }
     }
 }
 
