@@ -4,7 +4,7 @@ writes + barriers -- the co-runner under which `nmsb_mask`'s per-lane LDS lists 
 repetition's output is compared BIT FOR BIT with the result of the same call on a quiet GPU.  A kernel that is not stable under
 that co-runner fails here, in the driver's own `-m gpu` run.
 
-Victims: `radius_gather` (LDS row sort, radius.hip), `rs_hist / rs_scatter` through voxelize and the batch grid subsample
+Victims: `radius_gather` (LDS row sort, radius.hip), `rs_hist / rs_scatter` and (round 6) the fused `fs_pass` / `vox_group32` hand-off through voxelize and the batch grid subsample
 (sort.hip / voxel.hip), `kp_agg_gemm32` (kpconv.hip), `lfa_attn_mfma16 / _wave / _pf` through the RandLA-Net forward
 (randla.hip), `knn_query_multi` (knn.hip), `topk_*` (nms.hip), and the whole decode tail (`nmsb_*`)."""
 import threading
