@@ -131,6 +131,26 @@ def test_voxelize_kitti_sweep_bit_exact(max_points, max_voxels):
     assert len(ref.voxel_coords) > 1000
 
 
+@pytest.mark.parametrize("sweeps", [16, 36])
+def test_voxelize_bench_batch_in_one_call_bit_exact(sweeps):
+    """The PointPillars bench's shape -- 16 sweeps (1.9 M points, ~930 tiles in 29 groups of the fused hand-off, sort.h) in ONE call,
+    an empty item in the middle -- and 36 sweeps (4.3 M points: past FS_MAX_TILES, the call takes the launch chain): both identical
+    to the oracle."""
+    from ml3d import ops
+    clouds = [synth_data.kitti_sweep(40 + (i % 6))[:, :3] for i in range(sweeps)]
+    clouds.insert(sweeps // 2, np.zeros((0, 3), np.float32))
+    pts = np.ascontiguousarray(np.concatenate(clouds), dtype=np.float32)
+    rs = np.concatenate([[0], np.cumsum([len(c) for c in clouds])])
+    vs, mn, mx = [0.16, 0.16, 4.0], [0, -39.68, -3], [69.12, 39.68, 1]
+    r = ops.voxelize(_t(pts), torch.tensor(rs), torch.tensor(vs), torch.tensor(mn), torch.tensor(mx), 32, 40000)
+    ref = oops.voxelize(pts, rs, vs, mn, mx, 32, 40000)
+    assert np.array_equal(r.voxel_batch_splits.cpu().numpy(), ref.voxel_batch_splits)
+    assert np.array_equal(r.voxel_coords.cpu().numpy(), ref.voxel_coords)
+    assert np.array_equal(r.voxel_point_row_splits.cpu().numpy(), ref.voxel_point_row_splits)
+    assert np.array_equal(r.voxel_point_indices.cpu().numpy(), ref.voxel_point_indices)
+    assert (len(pts) + 2047) // 2048 > (2048 if sweeps == 36 else 800)
+
+
 def test_subsample_raw_sweep_006_bit_exact():
     """DataProcessing.grid_subsampling(points, grid_size=0.06) on a raw ~120k-point sweep (dataprocessing.py:14-49)."""
     from ml3d import ops
