@@ -301,12 +301,30 @@ def device_identity(dev):
                                       getattr(pr, "pci_device_id", 0))
 
 
+def emit(out):
+    """The ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through C stdio, which a pipe or a file buffers until
+    the process exits -- i.e. it would land BEHIND a line printed from Python (seen on the MI355X: tools/r06_calls/call_aa.sh).  Everything
+    C has buffered goes out first."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
+# ML3D_DIST_FORCE_GROUP=1: join a process group and take the gather / barrier / all-reduce / checksum path of N > 1 even at world size 1 --
+# the only way to put the RCCL calls of the multi-GPU path on real hardware from a one-GPU box (tools/r06_calls/call_aa.sh)
+FORCE_GROUP = os.environ.get("ML3D_DIST_FORCE_GROUP") == "1"
+
+
 def ranks_seen(dev, world, dist, stub=False, placement=None):
     """{"world_size", "devices", "cpu_map"}: the process group's own view of the job (every rank's device identity and host
     placement -- NUMA node of its GPU, the CPUs it is pinned to, its host thread count -- all-gathered).
     Two ranks on one GPU would share its HBM and CUs and still print n_gpus = N: that is an error here."""
     me = (device_identity(dev), placement)
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         both = [None] * world
         dist.all_gather_object(both, me)
         ws = dist.get_world_size()
@@ -421,7 +439,7 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         import torch.distributed as dist
         mdist.init("gloo" if stub else "nccl", dev)
     seen = ranks_seen(dev, world, dist, stub, placement)
@@ -431,8 +449,8 @@ def main():
         out = bench_models.run_randlanet_train(args, rank, world, dev, dist)
         if rank == 0:
             out["ranks_seen"] = seen
-            print(json.dumps(out), flush=True)
-        if world > 1:
+            emit(out)
+        if (world > 1 or FORCE_GROUP):
             dist.barrier()
             dist.destroy_process_group()
         return out
@@ -442,8 +460,8 @@ def main():
         out = fn(args, rank, world, dev, dist)
         if rank == 0:
             out["ranks_seen"] = seen
-            print(json.dumps(out), flush=True)
-        if world > 1:
+            emit(out)
+        if (world > 1 or FORCE_GROUP):
             dist.barrier()
             dist.destroy_process_group()
         return out
@@ -510,7 +528,7 @@ def main():
     for a, b in tev:
         a.record(); b.record()           # materialise the hipEvent_t handles
     sync()
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         dist.barrier()
     sync()
     done_ev[0].record(stream.compute_stream)
@@ -521,11 +539,11 @@ def main():
         one_step(tr if kind == "knn" else None, tr if kind == "fwd" else None, done_ev[i + 1])
     drain()
     sync()
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -533,7 +551,7 @@ def main():
     # N > 1 on the hardware: the first multi-GPU run is also a CORRECTNESS run -- rank 0 recomputes, on the label buffers the RCCL
     # gather delivered for the LAST step, the checksums every rank computed on its own labels (outside the timed region)
     gather_check = None
-    if world > 1:
+    if (world > 1 or FORCE_GROUP):
         last_slot = (args.warmup + K - 1) % gather.depth
         mine = mdist.label_checksum(gather.labels[last_slot])
         allsums = [torch.zeros_like(mine) for _ in range(world)]
@@ -559,7 +577,7 @@ def main():
                    "ms_per_step": dt / K * 1e3, "scaling": "weak", "ranks_seen": seen,
                    "self_launched": bool(os.environ.get("ML3D_BENCH_SELF_LAUNCHED")),
                    "gathered_ranks_checked": world, "gather_self_check": gather_check}
-            print(json.dumps(out), flush=True)
+            emit(out)
     elif rank == 0:
         n_lv = stream.n
         # the same three kernels with NOTHING else on the GPU (after the timed region): what the overlap with the other stream
@@ -711,8 +729,8 @@ def main():
             for name in ("kpconv", "pointpillars"):
                 for e in (wl.get(name) or {}).get("roofline_other", []) or []:
                     out["roofline_other"].append(dict(e, workload=name))
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(out)
+    if (world > 1 or FORCE_GROUP):
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -16,10 +16,21 @@ def env_rank_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+# the multi-rank code paths also at world size 1 (bench.py: the RCCL calls of the N > 1 path on a one-GPU box)
+FORCE_GROUP = os.environ.get("ML3D_DIST_FORCE_GROUP") == "1"
+
+
+def _single():
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_GROUP)
+
+
 def init(backend, device=None):
     """Join the process group described by the torchrun environment (rendezvous on 127.0.0.1 by default)."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    if FORCE_GROUP:                                    # a lone process joining a group of one (no torchrun around it)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if dist.is_initialized():
         return
     if backend == "nccl":
@@ -41,7 +52,7 @@ def gather_predictions(labels, dst=0, out=None, async_op=False):
     A no-op list of one tensor when no process group is initialised.  ``out``: preallocated receive list on
     ``dst``.  ``async_op=True`` returns (list, work): the collective runs on the backend's own stream so the next
     step's kernels overlap it; call ``work.wait()`` before reusing ``labels`` / reading the list."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return ([labels], None) if async_op else [labels]
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank == dst and out is None:
@@ -57,7 +68,7 @@ def gather_ragged(values, dst=0):
     all_gather), then a gather of the tensors padded to the longest; ``dst`` gets the list of every rank's tensor trimmed back
     to its own length, the other ranks None.  The reference does the same for detection boxes with ``gather_object``
     (ml3d/torch/pipelines/object_detection.py:222-233); tensors avoid the pickling."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return [values]
     rank, world = dist.get_rank(), dist.get_world_size()
     n = torch.tensor([values.numel()], dtype=torch.int64, device=values.device)
@@ -112,7 +123,8 @@ class PredictionGather:
         self.depth = int(depth)
         dt = torch.uint8 if int(num_classes) <= 256 else torch.int32
         self.labels = [torch.empty((batch, num_points), dtype=dt, device=device) for _ in range(self.depth)]
-        on = dist.is_initialized() and dist.get_world_size() > 1
+        on = not _single()
+        self.on = on
         self.world = dist.get_world_size() if on else 1
         self.rank = dist.get_rank() if on else 0
         self.recv = [[torch.empty_like(self.labels[0]) for _ in range(self.world)] if (on and self.rank == dst) else None
@@ -132,14 +144,14 @@ class PredictionGather:
             ops.argmax_labels(scores, out=self.labels[i])       # one HIP kernel: 19 floats in, 1 byte out per point
         else:
             self.labels[i].copy_(torch.argmax(scores, dim=2))
-        if self.world > 1:
+        if self.on:
             _, self.pending[i] = gather_predictions(self.labels[i], dst=self.dst, out=self.recv[i], async_op=True)
         return i
 
     def gathered(self, slot):
         """On ``dst``: the list of every rank's label tensor of that slot's last step (call after ``drain`` or after the
         slot's work has been waited for); elsewhere / single process: this rank's labels."""
-        if self.world > 1 and self.rank == self.dst:
+        if self.on and self.rank == self.dst:
             return self.recv[slot]
         return [self.labels[slot]]
 
