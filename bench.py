@@ -314,6 +314,28 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
+def flush_c():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def finish(out, rank, world, dist):
+    """Leave the process group FIRST, then let rank 0 print: every rank's stdout ends up in one stream under torchrun, and whatever a rank's
+    RCCL still holds in C stdio is written when that rank exits -- behind rank 0's JSON line if that was printed before the group was torn
+    down.  All ranks flush C stdio after the teardown; at N > 1 rank 0 gives the others half a second to exit."""
+    if world > 1 or FORCE_GROUP:
+        dist.barrier()
+        dist.destroy_process_group()
+        flush_c()
+        if rank == 0 and world > 1:
+            time.sleep(0.5)
+    if rank == 0 and out is not None:
+        emit(out)
+
+
 # ML3D_DIST_FORCE_GROUP=1: join a process group and take the gather / barrier / all-reduce / checksum path of N > 1 even at world size 1 --
 # the only way to put the RCCL calls of the multi-GPU path on real hardware from a one-GPU box (tools/r06_calls/call_aa.sh)
 FORCE_GROUP = os.environ.get("ML3D_DIST_FORCE_GROUP") == "1"
@@ -449,10 +471,7 @@ def main():
         out = bench_models.run_randlanet_train(args, rank, world, dev, dist)
         if rank == 0:
             out["ranks_seen"] = seen
-            emit(out)
-        if (world > 1 or FORCE_GROUP):
-            dist.barrier()
-            dist.destroy_process_group()
+        finish(out if rank == 0 else None, rank, world, dist)
         return out
     if args.workload != "randlanet":
         import bench_models
@@ -460,10 +479,7 @@ def main():
         out = fn(args, rank, world, dev, dist)
         if rank == 0:
             out["ranks_seen"] = seen
-            emit(out)
-        if (world > 1 or FORCE_GROUP):
-            dist.barrier()
-            dist.destroy_process_group()
+        finish(out if rank == 0 else None, rank, world, dist)
         return out
 
     from ml3d.engine import RandLAFrameStream, make_trace
@@ -577,7 +593,6 @@ def main():
                    "ms_per_step": dt / K * 1e3, "scaling": "weak", "ranks_seen": seen,
                    "self_launched": bool(os.environ.get("ML3D_BENCH_SELF_LAUNCHED")),
                    "gathered_ranks_checked": world, "gather_self_check": gather_check}
-            emit(out)
     elif rank == 0:
         n_lv = stream.n
         # the same three kernels with NOTHING else on the GPU (after the timed region): what the overlap with the other stream
@@ -729,10 +744,7 @@ def main():
             for name in ("kpconv", "pointpillars"):
                 for e in (wl.get(name) or {}).get("roofline_other", []) or []:
                     out["roofline_other"].append(dict(e, workload=name))
-        emit(out)
-    if (world > 1 or FORCE_GROUP):
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(out if rank == 0 else None, rank, world, dist)
     return out
 
 
