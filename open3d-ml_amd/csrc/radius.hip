@@ -85,38 +85,45 @@ __device__ __forceinline__ void rad_box(RadQuery& Q, const GridSeg& g, float r) 
 // ceil(T / 64) full-width steps per query.  body(active, candidate) is called in wave-uniform control flow.
 constexpr int RAD_ROWS = 16;
 
+// ROWS: compile-time bound of the row prefix held in scalar registers (9 = the 3 x 3 rows of the common box, 16 = up to 4 x 4):
+// the per-candidate row select is ROWS - 1 compare + select pairs
+template <int ROWS, class F>
+__device__ __forceinline__ void rad_scan_rows(const RadArgs& A, const RadQuery& Q, const GridSeg& g, int lane, int ny, int nrows, F&& body) {
+    int b = 0;
+    if (lane < 2 * nrows) {
+        const int r = lane >> 1;
+        const int row = g.cell_base + g.dims[0] * ((Q.ya + r % ny) + g.dims[1] * (Q.za + r / ny));
+        b = A.G.cell_start[row + ((lane & 1) ? Q.xb + 1 : Q.xa)];
+    }
+    int pre[ROWS + 1], D[ROWS];
+    pre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int p0 = __builtin_amdgcn_readlane(b, 2 * r), p1 = __builtin_amdgcn_readlane(b, 2 * r + 1);
+        D[r] = p0 - pre[r];                      // candidate f of row r is sorted[f + D[r]]
+        pre[r + 1] = pre[r] + (p1 - p0);         // (lanes >= 2 * nrows hold 0: empty rows)
+    }
+    const int T = pre[ROWS];
+    for (int f0 = 0; f0 < T; f0 += 64) {
+        const int f = f0 + lane;
+        int off = D[0];
+#pragma unroll
+        for (int j = 1; j < ROWS; ++j) off = f >= pre[j] ? D[j] : off;
+        const bool act = f < T;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) c = A.G.sorted[f + off];
+        body(act, c);
+    }
+}
+
 template <class F>
 __device__ __forceinline__ void rad_scan(const RadArgs& A, const RadQuery& Q, const GridSeg& g, int lane, F&& body) {
     if (!Q.any) return;
     const int ny = Q.yb - Q.ya + 1, nz = Q.zb - Q.za + 1, nrows = ny * nz;
-    if (nrows <= RAD_ROWS) {
-        int b = 0;
-        if (lane < 2 * nrows) {
-            const int r = lane >> 1;
-            const int row = g.cell_base + g.dims[0] * ((Q.ya + r % ny) + g.dims[1] * (Q.za + r / ny));
-            b = A.G.cell_start[row + ((lane & 1) ? Q.xb + 1 : Q.xa)];
-        }
-        int pre[RAD_ROWS + 1], D[RAD_ROWS];
-        pre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < RAD_ROWS; ++r) {
-            const int p0 = __builtin_amdgcn_readlane(b, 2 * r), p1 = __builtin_amdgcn_readlane(b, 2 * r + 1);
-            D[r] = p0 - pre[r];                      // candidate f of row r is sorted[f + D[r]]
-            pre[r + 1] = pre[r] + (p1 - p0);         // (lanes >= 2 * nrows hold 0: empty rows)
-        }
-        const int T = pre[RAD_ROWS];
-        for (int f0 = 0; f0 < T; f0 += 64) {
-            const int f = f0 + lane;
-            int off = D[0];
-#pragma unroll
-            for (int j = 1; j < RAD_ROWS; ++j) off = f >= pre[j] ? D[j] : off;
-            const bool act = f < T;
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) c = A.G.sorted[f + off];
-            body(act, c);
-        }
-        return;
-    }
+#ifndef ML3D_RAD_ROWS16_ONLY
+    if (nrows <= 9) { rad_scan_rows<9>(A, Q, g, lane, ny, nrows, body); return; }
+#endif
+    if (nrows <= RAD_ROWS) { rad_scan_rows<RAD_ROWS>(A, Q, g, lane, ny, nrows, body); return; }
     for (int z = Q.za; z <= Q.zb; ++z)               // (unreachable with cell >= r; kept for any other grid)
         for (int y = Q.ya; y <= Q.yb; ++y) {
             const int row = g.cell_base + g.dims[0] * (y + g.dims[1] * z);

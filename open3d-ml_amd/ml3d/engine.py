@@ -371,13 +371,24 @@ class KPConvPipelineN:
         self.ring = [dict() for _ in range(self.n + len(self.computes) + 2)] if reuse_buffers else None
         self.ring_done = [None] * (len(self.ring) if self.ring else 0)       # the forward that last read a ring entry's arena
         self.pool = ThreadPoolExecutor(max_workers=self.n, thread_name_prefix="kpconv-build")
+        import threading
+        self._slot_of_thread, self._slot_lock = {}, threading.Lock()
         self.inflight = []            # futures of (batch, built event), submission order
         self.alive = []
         self.count = 0
         self.pool_layers = sum(1 for b in cfg['architecture'] if 'pool' in b or 'strided' in b)
 
-    def _build(self, slot, points, lengths, features, rotations, ready, ring_index):
+    def _build(self, points, lengths, features, rotations, ready, ring_index):
         from .torch.models.kpconv import KPConvBatch
+        # The build stream belongs to the WORKER THREAD, not to the batch number: with `count % builders` the builds k and k + n shared
+        # a stream and its pinned read-back scratch, and k + n starts as soon as ANY worker is free -- i.e. while k may still be
+        # running when a later build overtook it: two host threads then drove one dependent chain each through the same stream and read
+        # each other's size records (round 6: 2 of 8 runs of tests/test_gpu_kpconv.py [3 builders] -- logits of another batch's shapes,
+        # or `ml3d_gather_pool: invalid argument`; never seen with 2 builders, the same hazard in principle).
+        import threading
+        tid = threading.get_ident()
+        with self._slot_lock:
+            slot = self._slot_of_thread.setdefault(tid, len(self._slot_of_thread)) % self.n
         st = self.build_streams[slot]
         buffers = None
         if self.ring is not None:
@@ -421,7 +432,7 @@ class KPConvPipelineN:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
         ring_index = self.count % len(self.ring) if self.ring is not None else 0
-        self.inflight.append(self.pool.submit(self._build, self.count % self.n, points, lengths, features, rotations, ready, ring_index))
+        self.inflight.append(self.pool.submit(self._build, points, lengths, features, rotations, ready, ring_index))
         self.count += 1
         if len(self.inflight) > self.n:
             return self._forward(self.inflight.pop(0))
