@@ -1,5 +1,6 @@
 """Neighbour searches: exact k-NN, the RandLA pyramid, fixed-radius search in its ragged\n(two-phase) and dense (one traversal) forms, ragged_to_dense."""
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -401,7 +402,9 @@ def kpconv_batch_build(points, lengths, radii, dls, has_conv, rotations=None, ca
             buffers['workspace'] = ws
     hsb = int(lib.ml3d_kpconv_batch_host_scratch_bytes(B, L))
     stream = _stream()
-    hkey = (str(dev), getattr(stream, "value", stream), (hsb + 4095) // 4096)      # (the stream handle is a ctypes c_void_p)
+    # (the stream handle is a ctypes c_void_p; the calling thread is part of the key: the scratch receives this call's size records
+    #  while the call blocks on them, so two host threads must never share one -- DESIGN.md §11.11)
+    hkey = (str(dev), getattr(stream, "value", stream), (hsb + 4095) // 4096, threading.get_ident())
     pinned = _PINNED.get(hkey)
     if pinned is None:
         if len(_PINNED) >= 16:
