@@ -377,6 +377,12 @@ class KPConvPipelineN:
         self.alive = []
         self.count = 0
         self.pool_layers = sum(1 for b in cfg['architecture'] if 'pool' in b or 'strided' in b)
+        # the model's folded / split weights (packed_params: uploads + pack kernels on the caller's stream) are built lazily in its
+        # first forward: with forwards alternating between streams the second stream would read planes the first is still writing
+        if hasattr(model, 'packed_params') and not getattr(model, 'training', False):
+            with torch.cuda.device(self.device):
+                model.packed_params(self.device)
+                torch.cuda.current_stream(self.device).synchronize()
 
     def _build(self, points, lengths, features, rotations, ready, ring_index):
         from .torch.models.kpconv import KPConvBatch
@@ -531,6 +537,14 @@ class PointPillarsStream:
         1404 / 1339 -- the single-threaded pipeline's two per-process modes (rounds 3-4: 1310 or 1400, drawn per process) are the
         slow and the fast interleaving of the two lanes' host work; with a thread per lane only the fast one is left."""
         self.lanes = [_PointPillarsLane(model, device) for _ in range(max(1, int(lanes)))]
+        # the folded / split weights are built lazily by the model (packed_params: uploads + pack kernels on the CALLER's stream):
+        # built here, once, and waited for -- otherwise the lanes' threads would race to build them in their first step and a lane
+        # could multiply with planes another lane's stream is still writing
+        if hasattr(model, 'packed_params'):
+            dev = self.lanes[0].device
+            with torch.cuda.device(dev):
+                model.packed_params(dev)
+                torch.cuda.current_stream(dev).synchronize()
         self.compute = self.lanes[-1].compute          # (the stream whose completion events pace a step in the bench)
         self.pool = None
         if threaded and len(self.lanes) > 1:
